@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the spectrogram hot path (BASELINE.json metric:
+"STFT frames/sec + spectrogram Mpixels/sec at n_fft=2048, 1/2/4/8 MI355X").
+
+  python bench.py --gpus N --steps K --warmup W            (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Workload (per GPU, fixed as N grows -> weak scaling): BASELINE config "1024 synthetic 48 kHz mono
+tracks, n_fft=2048, sharded across 8 GPUs" = 128 tracks x 30 s per GPU (track index = rank*128+i),
+Hann win 2048 / hop 512, linear-frequency dB.  At N = 8 this is exactly that config; at N = 1 it
+is its one-GPU shard (the single 60 s track of config[1] is 35 MB of traffic — a ~10 us launch that
+cannot load 256 CUs; it is reported beside the headline as `single_track_cfg2`).
+
+One step = one pass of the hot path over the resident batch:
+  STFT -> |X| -> 20 log10 (+ fused per-track min/max)          th_calc_spec_batch_dev
+  global dB range (2-float all-reduce over ranks when N > 1)    core/mod.rs:169-180
+  f32 dB -> u16 grey image, transposed                          th_spec_to_img_batch_dev
+  level-0 colormap raster of every tile -> RGBA                 th_raster_tiles_dev
+Inputs are resident in HBM when the timed region starts.  value = frames of all ranks / time.
+PyTorch provides device memory, the stream and torch.distributed (RCCL); all compute is the
+library's own HIP kernels through the C ABI.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tracks-per-gpu", type=int, default=128)
+    ap.add_argument("--seconds", type=float, default=30.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-track", action="store_true")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 wave")
+    return ap.parse_args()
+
+
+def synth_on_gpu(torch, dev, track0: int, n_tracks: int, sr: int, n: int):
+    """tests/synth.py's signal, evaluated on the GPU (f64 phase, same seeded parameters)."""
+    from tests.synth import track_params
+    out = torch.empty((n_tracks, n), dtype=torch.float32, device=dev)
+    t = torch.arange(n, dtype=torch.float64, device=dev) / sr
+    dur = n / sr
+    for i in range(n_tracks):
+        freqs, amps, phases, chirp_amp, noise_seed = track_params(track0 + i, sr)
+        x = torch.zeros(n, dtype=torch.float64, device=dev)
+        for f, a, p in zip(freqs, amps, phases):
+            x += a * torch.sin(2 * np.pi * f * t + p)
+        x += chirp_amp * torch.sin(2 * np.pi * (100.0 * t + 0.5 * (0.4 * sr - 100.0) / dur * t * t))
+        g = torch.Generator(device=dev)
+        g.manual_seed(noise_seed)
+        x += (torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 2 - 1) * 1e-3
+        out[i] = x.clamp_(-1.0, 1.0).to(torch.float32)
+    return out
+
+
+class Workload:
+    """Device-resident batch + descriptor tables for one GPU."""
+
+    def __init__(self, torch, ta, ctx, dev, track0, n_tracks, sr, n, win, hop, n_fft, kernel, cmap_bytes):
+        self.torch, self.ta, self.ctx = torch, ta, ctx
+        self.n_tracks, self.n = n_tracks, n
+        self.plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+        if kernel:
+            self.plan.set_kernel(kernel)
+        self.T, self.H = self.plan.n_frames(n), self.plan.height
+        self.wav = synth_on_gpu(torch, dev, track0, n_tracks, sr, n)
+        self.spec = torch.empty((n_tracks, self.T, self.H), dtype=torch.float32, device=dev)
+        self.img = torch.empty((n_tracks, self.H, self.T), dtype=torch.int16, device=dev)
+        self.minmax = torch.empty((n_tracks, 2), dtype=torch.float32, device=dev)
+        self.cmap = torch.frombuffer(bytearray(cmap_bytes), dtype=torch.uint8).to(dev)
+        self.n_colors = len(cmap_bytes) // 4
+        # every level-0 tile of every image (render_tiles.rs:290-313 geometry, gutters included)
+        geoms = []
+        tx = 0
+        while True:
+            ty, any_row = 0, False
+            while True:
+                g = ta.spectrogram_tile_geometry(self.T, self.H, 0, 0, tx, ty)
+                if g.width == 0 or g.height == 0:
+                    break
+                geoms.append(g)
+                any_row = True
+                ty += 1
+            if not any_row:
+                break
+            tx += 1
+        self.tile_px = sum(g.width * g.height for g in geoms)
+        self.rgba = torch.empty((n_tracks, self.tile_px, 4), dtype=torch.uint8, device=dev)
+        self.chan = (ta.ChanDesc * n_tracks)(*[
+            ta.ChanDesc(self.wav[i].data_ptr(), self.spec[i].data_ptr(), n, self.T) for i in range(n_tracks)])
+        self.imgd = (ta.ImgDesc * n_tracks)(*[
+            ta.ImgDesc(self.spec[i].data_ptr(), self.img[i].data_ptr(), self.T, self.H, 0, self.H)
+            for i in range(n_tracks)])
+        rast = []
+        for i in range(n_tracks):
+            off = 0
+            for g in geoms:
+                rast.append(ta.RasterDesc(self.img[i].data_ptr(), self.rgba[i].data_ptr() + off * 4, self.T,
+                                               self.H, g.origin_x, g.origin_y, g.width, g.height))
+                off += g.width * g.height
+        self.rast = (ta.RasterDesc * len(rast))(*rast)
+        self.frames = n_tracks * self.T
+        self.pixels = n_tracks * self.H * self.T
+        self.ev = []
+
+    def step(self, dist=None, record=False):
+        torch, ta = self.torch, self.ta
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.plan.calc_spec_batch_dev(self.chan, self.minmax.data_ptr())
+        if record:
+            e1.record()
+            self.ev.append((e0, e1))
+        # global dB range over every resident spec of every rank (core/mod.rs:169-180)
+        r = torch.stack([self.minmax[:, 0].min(), -self.minmax[:, 1].max()])
+        if dist is not None:
+            dist.all_reduce(r, op=dist.ReduceOp.MIN)   # the path's only exchange step: 2 floats
+        mn, negmx = r.tolist()
+        lo, hi = ta.global_db_range([mn], [-negmx], 100.0)
+        self.ctx.spec_to_img_batch(self.imgd, lo, hi, 258)
+        self.ctx.raster_tiles(self.rast, self.cmap.data_ptr(), self.n_colors)
+        return lo, hi
+
+    def stft_only(self):
+        self.plan.calc_spec_batch_dev(self.chan, self.minmax.data_ptr())
+
+
+def cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft, target_s=12.0):
+    """The oracle (CPU restatement of the reference algorithm, NOT rustfft) on this box's host
+    cores: same step (STFT->dB->min/max->u16->level-0 RGBA) on a bounded sample of the workload,
+    one task per track as the reference does when #channels >= #threads (core/mod.rs:152-163)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as orc
+    from tests.synth import synth_track
+    import thesia_amd as ta
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        cores = os.cpu_count()
+    cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+    n_s = min(n, 10 * sr)  # 10 s tracks keep the sample bounded
+
+    def one(i):
+        x = synth_track(i, sr, n_s)
+        t0 = time.perf_counter()
+        spec = orc.calc_spec(x, win, hop, n_fft, fft32=True)
+        mn, mx = orc.find_min_max(spec)
+        lo, hi = orc.global_db_range([mn], [mx], 100.0)
+        img = orc.convert_spectrogram_to_img(spec, (0, spec.shape[1]), (lo, hi), 258)
+        tx = 0
+        while True:
+            ty, any_row = 0, False
+            while True:
+                g = ta.spectrogram_tile_geometry(img.shape[1], img.shape[0], 0, 0, tx, ty)
+                if g.width == 0 or g.height == 0:
+                    break
+                orc.encode_spectrogram_tile(img, cmap_bytes, 1, 0, 0, tx, ty)
+                any_row = True
+                ty += 1
+            if not any_row:
+                break
+            tx += 1
+        return spec.shape[0], time.perf_counter() - t0
+
+    frames1, dt1 = one(0)  # calibration (also warms the library)
+    n_tasks = int(max(cores, min(64 * cores, round(target_s / max(dt1, 1e-3)) * cores)))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(one, range(n_tasks)))
+    wall = time.perf_counter() - t0
+    frames = sum(r[0] for r in res)
+    return {"value": frames / wall, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n_tasks} tracks x {n_s / sr:.0f} s 48 kHz mono, n_fft={n_fft} hop={hop}, "
+                      f"same step (STFT->dB->min/max->u16->level-0 RGBA), {wall:.1f} s wall; "
+                      "CPU restatement of the reference algorithm (f32 radix-2 FFT), not rustfft"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import __graft_entry__ as ge
+    if rank == 0 or not os.path.exists(ge.LIB):
+        ge.build()
+    import torch
+    import thesia_amd as ta
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist = dist_mod
+
+    sr, (hop, win, n_fft) = 48000, ta.calc_framing_params(2048 / 48, 4, 1, 48000)
+    n = int(round(args.seconds * sr))
+    cmap_bytes = open(os.path.join(ROOT, "tests", "golden", "colormap_inferno_rgba258.bin"), "rb").read()
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx = ta.Context(local_rank, stream)
+    wl = Workload(torch, ta, ctx, dev, rank * args.tracks_per_gpu, args.tracks_per_gpu, sr, n, win, hop, n_fft,
+                  args.kernel, cmap_bytes)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        wl.step(dist)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(dist, record=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stft_ms = float(np.mean([a.elapsed_time(b) for a, b in wl.ev]))  # HIP events on the launch stream
+
+    # stage-only rates: STFT->dB stage and quantise+raster stage, HIP events
+    def time_stage(fn, reps=10):
+        fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+
+    lo, hi = wl.step(dist)
+    img_ms = time_stage(lambda: (ctx.spec_to_img_batch(wl.imgd, lo, hi, 258),
+                                 ctx.raster_tiles(wl.rast, wl.cmap.data_ptr(), wl.n_colors)))
+
+    single = None
+    if rank == 0 and not args.no_single_track:
+        w1 = Workload(torch, ta, ctx, dev, 0, 1, sr, 60 * sr, win, hop, n_fft, args.kernel, cmap_bytes)
+        for _ in range(3):
+            w1.step(None)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        reps = 50
+        for _ in range(reps):
+            w1.step(None)
+        torch.cuda.synchronize(dev)
+        d1 = (time.perf_counter() - t1) / reps
+        k1 = time_stage(w1.stft_only, 50)
+        single = {"workload": "cfg2: 1 track 48 kHz mono 60 s, n_fft=2048 hop=512, dB + colormap raster",
+                  "frames": w1.frames, "ms_per_step": d1 * 1e3, "frames_per_s": w1.frames / d1,
+                  "stft_kernel_us": k1 * 1e3, "stft_frames_per_s": w1.frames / (k1 * 1e-3)}
+        del w1
+
+    if rank == 0:
+        total_frames = wl.frames * world
+        bytes_per_frame = 4 * hop + 4 * wl.H            # read 4*hop + write 4*H
+        ach = wl.frames * bytes_per_frame / (stft_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "stft_hbm_traffic.json")
+        if os.path.exists(tpath):  # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes)
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "STFT frames/sec (whole step: STFT->dB->min/max->u16 image->level-0 RGBA raster), n_fft=2048",
+            "value": total_frames * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg5 shard: {args.tracks_per_gpu} tracks/GPU x {args.seconds:g} s 48 kHz mono, "
+                                   f"n_fft={n_fft} hop={hop} Hann, linear dB + u16 image + level-0 RGBA tiles",
+                       "tracks_per_gpu": args.tracks_per_gpu, "frames_per_gpu": wl.frames,
+                       "parallelism": f"track-sharded x{world}, 2-float dB-range all-reduce"},
+            "stft_frames_per_s": total_frames / (stft_ms * 1e-3),
+            "raster_mpixels_per_s": wl.pixels * world / 1e6 / (img_ms * 1e-3),
+            "stft_kernel": wl.plan.kernel_name,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": wl.plan.kernel_name, "avg_launch_ms": stft_ms,
+                         "algorithmic_bytes_per_frame": bytes_per_frame,
+                         "read_only_frac": wl.frames * 4 * hop / (stft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if single is not None:
+            out["single_track_cfg2"] = single
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft)
+        print(json.dumps(out), flush=True)
+    barrier()
+    del wl
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,256 @@
+/*
+ * thesia_amd.h — C ABI of the MI355X-native spectrogram / waveform compute path for thesia.
+ *
+ * This is the drop-in boundary: a plain `extern "C"` surface (opaque handles, plain pointers
+ * and sizes, int status codes, no C++/torch types) that replaces the five pure Rust functions
+ * at the reference's internal seam and the TrackManager orchestration that calls them.
+ * All file:line citations are relative to the reference checkout (Sytronik/thesia).
+ *
+ *   reference seam                                         → entry point(s) here
+ *   ------------------------------------------------------------------------------------------
+ *   SpecSetting::calc_framing_params  spectrogram.rs:56-98  → th_calc_framing_params
+ *   calc_normalized_win               windows.rs:12-38      → th_calc_normalized_win
+ *   calc_mel_fb / _default            src-common/lib.rs:46-103 → th_calc_mel_fb, th_mel_default_n_mel
+ *   FreqScale::hz_range_to_idx        src-common/lib.rs:144-159 → th_hz_range_to_idx
+ *   SpectrogramAnalyzer prepare/retain spectrogram.rs:101-185 → th_plan_create / th_plan_destroy
+ *   SpectrogramAnalyzer::calc_spec    spectrogram.rs:187-212 → th_calc_spec_batch_dev, th_calc_spec_host
+ *     (perform_stft stft.rs:16-149, norm :200, mel dot :207, dB decibel.rs:170-214)
+ *   find_min_max + range clamp        simd.rs:14-36, core/mod.rs:169-180 → fused into th_calc_spec_*
+ *                                                             (per-channel min/max), th_global_db_range
+ *   convert_spectrogram_to_img        visualize/drawing.rs:4-33 → th_spec_to_img_dev
+ *   encode_spectrogram_tile           render_tiles.rs:281-393 → th_encode_spectrogram_tile_dev, th_raster_tiles_dev
+ *   encode_waveform_tile              render_tiles.rs:232-279 → th_encode_waveform_tile_dev, th_waveform_tiles_dev
+ *   TrackManager (update_specs, update_spec_imgs, ...) core/mod.rs:33-230 → th_tm_*
+ *   tile commands                     src-tauri/src/lib.rs:342-389 → th_tm_get_waveform_tile, th_tm_get_spectrogram_tile
+ *
+ * Conventions
+ *   - Every function returns th_status (0 = ok, <0 = error) and never throws or aborts;
+ *     th_last_error() returns a thread-local message for the last failure on this thread.
+ *   - The caller owns every host buffer it passes.  Inputs are borrowed for the call only.
+ *     Outputs go to caller buffers with a capacity; the written length is returned.
+ *   - The library owns device memory behind opaque handles with explicit destroy.
+ *   - "_dev" entries take DEVICE pointers, enqueue on the context's HIP stream and do not
+ *     synchronise unless they return data to the host.  All other entries take HOST pointers.
+ *   - Compute entries (th_calc_spec_*, th_tm_* mutators) may assume exclusive access, like the
+ *     reference's single write-lock worker (interface.rs:12-56).  Tile getters are re-entrant
+ *     with respect to each other (internal mutex on the stream).
+ *   - There is NO CPU fallback: compute entries fail with TH_ERR_NO_DEVICE without a GPU.
+ */
+#ifndef THESIA_AMD_H
+#define THESIA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+#define TH_EXTERN_C extern "C"
+#else
+#define TH_EXTERN_C
+#endif
+#define TH_API TH_EXTERN_C __attribute__((visibility("default")))
+
+typedef enum {
+    TH_OK = 0,
+    TH_ERR_INVALID_ARG = -1,
+    TH_ERR_UNSUPPORTED = -2,
+    TH_ERR_HIP = -3,
+    TH_ERR_NO_DEVICE = -4,
+    TH_ERR_OOM = -5,
+    TH_ERR_BUFFER_TOO_SMALL = -6,
+    TH_ERR_NOT_FOUND = -7,
+    TH_ERR_INTERNAL = -8
+} th_status;
+
+/* FreqScale (src-common/src/lib.rs:105-109) */
+#define TH_FREQ_LINEAR 0
+#define TH_FREQ_MEL 1
+
+/* render_tiles.rs:14-16 */
+#define TH_WAVEFORM_TILE_BINS 1024
+#define TH_SPECTROGRAM_TILE_SIZE 512
+#define TH_SPECTROGRAM_TILE_GUTTER 4
+#define TH_WAVEFORM_TILE_MAX_BYTES (24 + 1024 * 12)
+#define TH_SPECTROGRAM_TILE_MAX_BYTES (40 + 520 * 520 * 4)
+
+typedef struct th_ctx th_ctx;   /* device + stream + scratch */
+typedef struct th_plan th_plan; /* one SpectrogramAnalyzer cache entry */
+typedef struct th_tm th_tm;     /* TrackManager mirror */
+
+/* ---------------------------------------------------------------- errors / info */
+TH_API const char *th_last_error(void);
+TH_API int th_version(void);
+TH_API int th_device_count(int *count);
+
+/* ---------------------------------------------------------------- host-only helpers (no GPU) */
+/* SpecSetting::calc_framing_params — spectrogram.rs:56-98 */
+TH_API int th_calc_framing_params(double win_ms, uint32_t t_overlap, uint32_t f_overlap, uint32_t sr,
+                                  size_t *hop, size_t *win, size_t *n_fft);
+/* frame count of perform_stft — stft.rs:50-97 (T = floor((N + 2*(win/2) - win)/hop) + 1) */
+TH_API int th_stft_n_frames(size_t n_samples, size_t win, size_t hop, size_t *n_frames);
+/* calc_normalized_win(Hann, win, n_fft) — windows.rs:12-38,68-83; out[win] */
+TH_API int th_calc_normalized_win(size_t win, size_t n_fft, float *out);
+/* calc_mel_fb::<f32> — src-common/src/lib.rs:46-89; out[(n_fft/2+1) * n_mel], fmax < 0 = None */
+TH_API int th_calc_mel_fb(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, int do_norm,
+                          float *out);
+/* n_mel chosen by calc_mel_fb_default — src-common/src/lib.rs:91-103 */
+TH_API int th_mel_default_n_mel(uint32_t sr, size_t n_fft, size_t *n_mel);
+/* FreqScale::hz_range_to_idx — src-common/src/lib.rs:144-159 */
+TH_API int th_hz_range_to_idx(int freq_scale, float hz_min, float hz_max, uint32_t sr, size_t n_freqs_or_mels,
+                              size_t *i_start, size_t *i_end);
+/* max = min(max,0); min = max(min, max - dB_range) over per-spec (min,max) — core/mod.rs:169-180 */
+TH_API int th_global_db_range(const float *mins, const float *maxs, size_t n, float dB_range, float *min_dB,
+                              float *max_dB);
+
+typedef struct {
+    uint32_t width, height;       /* tile size in LOD pixels (0,0 = empty tile) */
+    uint32_t origin_x, origin_y;  /* tile origin in LOD pixels */
+    uint64_t lod_width, lod_height;
+} th_tile_geom;
+/* tile geometry of encode_spectrogram_tile — render_tiles.rs:290-313 */
+TH_API int th_spectrogram_tile_geometry(size_t img_width, size_t img_height, uint32_t level_x, uint32_t level_y,
+                                        uint32_t tile_x, uint32_t tile_y, th_tile_geom *geom);
+/* bin geometry of encode_waveform_tile — render_tiles.rs:233-241 */
+TH_API int th_waveform_tile_geometry(size_t n_samples, uint32_t level, uint32_t tile_index, size_t *start,
+                                     size_t *bin_count, size_t *samples_per_bin);
+
+/* ---------------------------------------------------------------- device context */
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to create one. */
+TH_API int th_ctx_create(int device, void *hip_stream, th_ctx **out);
+TH_API int th_ctx_destroy(th_ctx *ctx);
+TH_API int th_ctx_synchronize(th_ctx *ctx);
+/* device memory helpers for callers without their own allocator (tests, C hosts) */
+TH_API int th_dev_alloc(th_ctx *ctx, size_t bytes, void **dptr);
+TH_API int th_dev_free(th_ctx *ctx, void *dptr);
+TH_API int th_dev_upload(th_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+TH_API int th_dev_download(th_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* HIP-event timing on the context's stream (bench.py roofline leg) */
+TH_API int th_timer_start(th_ctx *ctx);
+TH_API int th_timer_stop_ms(th_ctx *ctx, float *ms);
+
+/* ---------------------------------------------------------------- SpectrogramAnalyzer plan */
+/* Device-resident window / twiddles / mel filterbank for one (sr, win, hop, n_fft, scale, n_mel)
+ * key; mirrors prepare()/retain() (spectrogram.rs:116-185).  n_mel = 0 with TH_FREQ_MEL selects
+ * calc_mel_fb_default's count.  n_fft must be a power of two in [8, 32768] and win <= n_fft. */
+TH_API int th_plan_create(th_ctx *ctx, uint32_t sr, size_t win, size_t hop, size_t n_fft, int freq_scale,
+                          size_t n_mel, th_plan **out);
+TH_API int th_plan_destroy(th_plan *plan);
+/* n_freq = n_fft/2+1; height = n_freq (linear) or n_mel (mel) = columns of the spec */
+TH_API int th_plan_dims(const th_plan *plan, size_t *n_freq, size_t *height);
+/* kernel selection: 0 = auto, 1 = force the generic workgroup kernel, 2 = force the wave kernel */
+TH_API int th_plan_set_kernel(th_plan *plan, int which);
+/* name of the kernel th_calc_spec_batch_dev will launch for this plan (for profiles / tests) */
+TH_API const char *th_plan_kernel_name(const th_plan *plan);
+
+/* ---------------------------------------------------------------- calc_spec (layer A, device pointers) */
+typedef struct {
+    const float *wav;    /* DEVICE: n_samples f32, one channel */
+    float *spec;         /* DEVICE: n_frames x height f32 dB, row-major (frame-major, like Array2 T x H) */
+    uint64_t n_samples;
+    uint64_t n_frames;   /* must equal th_stft_n_frames(n_samples, win, hop) */
+} th_chan_desc;
+
+/* Batched calc_spec over n_chan independent channels (core/mod.rs:153-163 → spectrogram.rs:187-212):
+ * reflect-centred framing → Hann/n_fft → real FFT → |X| → [mel] → 20*log10.
+ * d_minmax (DEVICE, 2*n_chan f32, may be NULL) receives per-channel (min, max) of the dB values
+ * (find_min_max, simd.rs:14-36), fused into the same launch.  Stream-ordered, no sync. */
+TH_API int th_calc_spec_batch_dev(th_plan *plan, const th_chan_desc *chans, size_t n_chan, float *d_minmax);
+
+/* Single-channel convenience with HOST buffers (upload, compute, download; synchronous).
+ * out_spec[n_frames * height]; out_min/out_max may be NULL. */
+TH_API int th_calc_spec_host(th_plan *plan, const float *wav, size_t n_samples, float *out_spec,
+                             size_t out_capacity_floats, size_t *n_frames, float *out_min, float *out_max);
+
+/* ---------------------------------------------------------------- f32 dB spec → u16 grey image */
+/* convert_spectrogram_to_img — visualize/drawing.rs:4-33.
+ * d_spec: n_frames x height f32; d_img: (i_end - i_start) x n_frames u16 (row 0 = lowest frequency).
+ * colormap_len = 0 means None. */
+TH_API int th_spec_to_img_dev(th_ctx *ctx, const float *d_spec, size_t n_frames, size_t height, size_t i_start,
+                              size_t i_end, float min_dB, float max_dB, uint32_t colormap_len, uint16_t *d_img);
+
+typedef struct {
+    const float *spec; /* DEVICE */
+    uint16_t *img;     /* DEVICE */
+    uint64_t n_frames, height, i_start, i_end;
+} th_img_desc;
+/* batched form: one launch for many channels sharing (min_dB, max_dB, colormap_len) — core/mod.rs:204-227 */
+TH_API int th_spec_to_img_batch_dev(th_ctx *ctx, const th_img_desc *descs, size_t n, float min_dB, float max_dB,
+                                    uint32_t colormap_len);
+
+/* ---------------------------------------------------------------- tiles */
+/* encode_spectrogram_tile — render_tiles.rs:281-352.  d_img: img_height x img_width u16 (DEVICE).
+ * colormap: HOST RGBA8 bytes.  Writes the 40-byte LE header + RGBA (top row = highest frequency)
+ * to the HOST buffer `out`.  Level (0,0) is an exact crop copy; level > 0 uses a separable
+ * Lanczos3 resample (parity unpinned vs fast_image_resize). */
+TH_API int th_encode_spectrogram_tile_dev(th_ctx *ctx, const uint16_t *d_img, size_t img_height, size_t img_width,
+                                          const uint8_t *colormap_rgba, size_t colormap_bytes, uint64_t revision,
+                                          uint32_t level_x, uint32_t level_y, uint32_t tile_x, uint32_t tile_y,
+                                          uint8_t *out, size_t out_capacity, size_t *out_len);
+
+typedef struct {
+    const uint16_t *img;  /* DEVICE: img_height x img_width */
+    uint8_t *rgba;        /* DEVICE: height x width x 4, top row = highest frequency */
+    uint32_t img_width, img_height;
+    uint32_t origin_x, origin_y, width, height; /* level-0 tile rectangle (th_spectrogram_tile_geometry) */
+} th_raster_desc;
+/* Batched level-0 colormap raster of many tile rectangles in one launch (device → device).
+ * d_colormap: DEVICE RGBA8, n_colors entries. */
+TH_API int th_raster_tiles_dev(th_ctx *ctx, const th_raster_desc *descs, size_t n, const uint8_t *d_colormap,
+                               uint32_t n_colors);
+
+/* encode_waveform_tile — render_tiles.rs:232-279.  d_wav: DEVICE samples.  Writes the 24-byte LE
+ * header + bins x (min, max, mean) f32 to the HOST buffer `out`. */
+TH_API int th_encode_waveform_tile_dev(th_ctx *ctx, const float *d_wav, size_t n_samples, uint64_t revision,
+                                       uint32_t level, uint32_t tile_index, uint8_t *out, size_t out_capacity,
+                                       size_t *out_len);
+
+typedef struct {
+    const float *wav; /* DEVICE */
+    float *bins;      /* DEVICE: bin_count x 3 f32 (min, max, mean) */
+    uint64_t n_samples;
+    uint64_t start;   /* first sample of the tile */
+    uint32_t level;
+    uint32_t bin_count;
+} th_wave_desc;
+/* Batched waveform decimation (many tiles / levels / channels in one launch, device → device). */
+TH_API int th_waveform_tiles_dev(th_ctx *ctx, const th_wave_desc *descs, size_t n);
+
+/* ---------------------------------------------------------------- TrackManager mirror (layer B, host buffers) */
+/* Mirrors core/mod.rs:33-230 with decoded audio handed over as planar host f32 (the output of
+ * the reference's decode step, audio.rs:65-78).  Audio, f32 dB specs and u16 images stay
+ * resident in HBM, so set_dB_range / set_colormap re-quantise without redoing the STFT. */
+TH_API int th_tm_create(th_ctx *ctx, th_tm **out);
+TH_API int th_tm_destroy(th_tm *tm);
+/* init(colormap_rgba) — lib.rs:51-98, render_tiles.rs:80-85; sets colormap_length = bytes/4 */
+TH_API int th_tm_set_colormap(th_tm *tm, const uint8_t *rgba, size_t bytes);
+/* TrackManager::set_setting — core/mod.rs:107-115 (recomputes every resident track) */
+TH_API int th_tm_set_setting(th_tm *tm, double win_ms, uint32_t t_overlap, uint32_t f_overlap, int freq_scale);
+/* TrackManager::set_dB_range — core/mod.rs:123-126 */
+TH_API int th_tm_set_dB_range(th_tm *tm, float dB_range);
+/* TrackList::add_tracks + TrackManager::add_tracks — core/mod.rs:62-71.
+ * channels[c] points to n_samples f32 of channel c (planar). */
+TH_API int th_tm_add_track(th_tm *tm, size_t id, uint32_t sr, uint32_t n_channels, const float *const *channels,
+                           size_t n_samples);
+/* batch form: computes all added tracks' specs in one launch per plan */
+TH_API int th_tm_add_tracks(th_tm *tm, size_t n_tracks, const size_t *ids, const uint32_t *srs,
+                            const uint32_t *n_channels, const float *const *channels_flat,
+                            const size_t *n_samples);
+TH_API int th_tm_remove_track(th_tm *tm, size_t id);
+/* TrackManager::apply_track_list_changes — core/mod.rs:102-105,168-230.
+ * updated_ids (may be NULL) receives up to cap ids whose images were re-made. */
+TH_API int th_tm_apply_track_list_changes(th_tm *tm, size_t *updated_ids, size_t cap, size_t *n_updated,
+                                          uint32_t *max_sr);
+TH_API int th_tm_get_db_state(const th_tm *tm, float *min_dB, float *max_dB, uint32_t *max_sr);
+/* shapes and copy-out accessors (parity tests, get_audio_render_metadata lib.rs:321-340) */
+TH_API int th_tm_spec_shape(const th_tm *tm, size_t id, uint32_t ch, size_t *n_frames, size_t *height);
+TH_API int th_tm_img_shape(const th_tm *tm, size_t id, uint32_t ch, size_t *img_height, size_t *img_width);
+TH_API int th_tm_copy_spec(th_tm *tm, size_t id, uint32_t ch, float *out, size_t capacity_floats);
+TH_API int th_tm_copy_img(th_tm *tm, size_t id, uint32_t ch, uint16_t *out, size_t capacity_px);
+TH_API int th_tm_revisions(const th_tm *tm, uint64_t *waveform_revision, uint64_t *spectrogram_revision);
+/* get_spectrogram_tile / get_waveform_tile — lib.rs:342-389 */
+TH_API int th_tm_get_spectrogram_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t level_x, uint32_t level_y,
+                                      uint32_t tile_x, uint32_t tile_y, uint8_t *out, size_t out_capacity,
+                                      size_t *out_len);
+TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t level, uint32_t tile_index,
+                                   uint8_t *out, size_t out_capacity, size_t *out_len);
+
+#endif /* THESIA_AMD_H */

@@ -633,7 +633,7 @@ ORC_API size_t orc_encode_waveform_tile(const float *wav, size_t n, uint64_t rev
     size_t tile_samples = sat_mul(1024, spb);
     size_t start = sat_mul((size_t)tile_index, tile_samples);
     size_t end = sat_add(start, tile_samples); if (end > n) end = n;
-    size_t bins = start >= end ? 0 : (end - start + spb - 1) / spb;
+    size_t bins = start >= end ? 0 : (end - start) / spb + ((end - start) % spb != 0); /* div_ceil */
     put_u64(out, revision);
     put_u32(out + 8, (uint32_t)bins);
     put_u32(out + 12, spb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)spb);

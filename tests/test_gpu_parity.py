@@ -1,0 +1,325 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Tolerances (BASELINE.json north_star):
+  * STFT magnitudes: max_k |m - m_ref| <= 1e-4 * max_k |m_ref| per frame, and |dB - dB_ref| <= 1e-3
+    wherever m_ref >= 1e-5 * max (per-bin relative error is undefined near spectral zeros);
+  * min/max (spec and waveform), u16 image, colour indices, RGBA bytes, headers: bit-exact given
+    identical inputs;  waveform mean: 1e-6 * max|x| absolute.
+"""
+import struct
+
+import numpy as np
+import pytest
+
+import thesia_amd as ta
+from oracle import oracle as orc
+from tests.synth import synth_track
+
+pytestmark = pytest.mark.gpu
+
+MAG_REL_TOL = 1e-4   # north_star: "within 1e-4 relative on STFT magnitudes"
+DB_ABS_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ta.Context(0)
+    yield c
+    c.close()
+
+
+def assert_spec_close(got_db, want_db, want_amp=None):
+    assert got_db.shape == want_db.shape, (got_db.shape, want_db.shape)
+    got_amp = np.power(10.0, got_db.astype(np.float64) / 20.0)
+    ref_amp = np.power(10.0, want_db.astype(np.float64) / 20.0) if want_amp is None else want_amp.astype(np.float64)
+    ref_amp = np.where(np.isneginf(want_db), 0.0, ref_amp)
+    got_amp = np.where(np.isneginf(got_db), 0.0, got_amp)
+    frame_max = ref_amp.max(axis=1, keepdims=True)
+    ok_frames = frame_max[:, 0] > 0
+    err = np.abs(got_amp - ref_amp)
+    rel = (err[ok_frames] / frame_max[ok_frames]).max() if ok_frames.any() else 0.0
+    assert rel <= MAG_REL_TOL, f"magnitude error {rel:.3e} of frame max"
+    # all-zero frames must be exactly -inf (decibel.rs:11,189-193)
+    assert np.all(np.isneginf(got_db[~ok_frames]))
+    strong = ref_amp >= 1e-5 * frame_max
+    strong &= ok_frames[:, None]
+    if strong.any():
+        d = np.abs(got_db[strong].astype(np.float64) - want_db[strong].astype(np.float64)).max()
+        assert d <= DB_ABS_TOL, f"dB error {d:.3e}"
+    return rel
+
+
+# ---------------------------------------------------------------- STFT -> dB
+def test_stft_impulse_known_answer(ctx):
+    """stft.rs:173-196 restated through calc_spec: |X| = [[0,0,0],[1/4,1/4,1/4],[1/4,1/4,1/4]].
+    n_fft=4 is below the library's minimum (8), so the same impulse is run at win=hop*2=8."""
+    x = np.zeros(8, np.float32)
+    x[4] = 1.0
+    plan = ta.Plan(ctx, 48000, 8, 4, 8, ta.LINEAR)
+    spec, mn, mx = plan.calc_spec(x)
+    want = orc.calc_spec(x, 8, 4, 8)
+    assert spec.shape == want.shape == (3, 5)
+    assert np.all(np.isneginf(spec[0]))                                   # impulse under w[0] = 0
+    assert np.allclose(spec[1], 20 * np.log10(1.0 / 8.0), atol=1e-4)     # impulse at the window peak: 1/n_fft
+    assert_spec_close(spec, want)
+    plan.close()
+
+
+@pytest.mark.parametrize("win,hop,n_fft", [(8, 2, 8), (16, 4, 16), (30, 10, 32), (64, 16, 64), (256, 64, 256),
+                                           (480, 120, 512), (1024, 256, 1024), (1920, 480, 2048),
+                                           (1764, 441, 2048), (2048, 512, 2048), (4096, 1024, 4096),
+                                           (8192, 2048, 8192), (2048, 2048, 2048), (2048, 64, 2048), (15, 5, 16)])
+def test_calc_spec_linear_parity(ctx, win, hop, n_fft):
+    plan = ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR)
+    n = min(6 * win + 3 * hop + 17, 60000)
+    x = synth_track(win + hop, 48000, n)
+    spec, mn, mx = plan.calc_spec(x)
+    want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+    assert_spec_close(spec, want, amp)
+    # fused find_min_max is bit-exact against the values the kernel itself wrote
+    assert mn == spec.min() and mx == spec.max()
+    plan.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 100, 511, 1023, 1024, 1025, 2047])
+def test_calc_spec_short_inputs(ctx, n):
+    """N < win (stft.rs:50-76): reflect padding cycles; frame count follows the same formula."""
+    win, hop, n_fft = 2048, 512, 2048
+    plan = ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR)
+    x = synth_track(n, 48000, n)
+    spec, _, _ = plan.calc_spec(x)
+    assert spec.shape[0] == orc.stft_n_frames(n, win, hop)
+    assert_spec_close(spec, orc.calc_spec(x, win, hop, n_fft))
+    plan.close()
+
+
+def test_calc_spec_silence_is_neg_inf(ctx):
+    plan = ta.Plan(ctx, 48000, 1024, 256, 1024, ta.LINEAR)
+    spec, mn, mx = plan.calc_spec(np.zeros(48000, np.float32))
+    assert np.all(np.isneginf(spec)) and mn == -np.inf and mx == -np.inf
+    plan.close()
+
+
+@pytest.mark.parametrize("sr,win,hop,n_fft,n_mel", [(44100, 2048, 512, 2048, 128), (48000, 1920, 480, 2048, 0),
+                                                    (44100, 1764, 441, 2048, 0), (16000, 512, 128, 512, 40),
+                                                    (48000, 1024, 256, 1024, 80)])
+def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
+    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
+    want_n_mel = n_mel or orc.mel_default_n_mel(sr, n_fft)
+    assert plan.height == want_n_mel
+    x = synth_track(7, sr, 30000)
+    spec, mn, mx = plan.calc_spec(x)
+    fb = orc.calc_mel_fb(sr, n_fft, want_n_mel)
+    want = orc.calc_spec(x, win, hop, n_fft, mel_fb=fb)
+    assert_spec_close(spec, want)
+    assert mn == spec.min() and mx == spec.max()
+    plan.close()
+
+
+def test_calc_spec_batch_ragged(ctx):
+    """Ragged batch: different lengths incl. N < win, one silent channel, per-channel min/max."""
+    win, hop, n_fft = 2048, 512, 2048
+    plan = ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR)
+    lens = [48000, 100, 7000, 2048, 2047, 33333, 1, 5000]
+    wavs = [synth_track(i, 48000, n) for i, n in enumerate(lens)]
+    wavs[3] = np.zeros(2048, np.float32)
+    specs, mm = plan.calc_spec_batch(wavs)
+    for i, (w, s) in enumerate(zip(wavs, specs)):
+        if len(w) == 1:
+            assert s.shape == (1, 1025)  # N == 1 is degenerate in the reference; shape only
+            continue
+        assert_spec_close(s, orc.calc_spec(w, win, hop, n_fft))
+        assert mm[i, 0] == s.min() and mm[i, 1] == s.max()
+    plan.close()
+
+
+def test_calc_spec_cfg2_full_size(ctx):
+    """BASELINE config 2 at full size: 60 s 48 kHz mono, n_fft=2048 hop=512 -> 5626 x 1025."""
+    sr, win, hop, n_fft = 48000, 2048, 512, 2048
+    x = synth_track(0, sr, 60 * sr)
+    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    spec, mn, mx = plan.calc_spec(x)
+    assert spec.shape == (5626, 1025)
+    want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+    rel = assert_spec_close(spec, want, amp)
+    assert mn == spec.min() and mx == spec.max()
+    # size-independent property: a shift by one hop moves interior frames down by one row
+    spec2, _, _ = plan.calc_spec(x[hop:])
+    a, b = spec[3:-3], spec2[2:-4]
+    assert np.abs(np.power(10, a / 20.0) - np.power(10, b / 20.0)).max() <= 1e-6
+    print(f"cfg2 max magnitude error {rel:.2e} of frame max")
+    plan.close()
+
+
+def test_calc_spec_golden_f64_fixtures(ctx, golden_dir):
+    """Committed float64 numpy.fft.rfft ground truth (scripts/make_golden.py)."""
+    z = np.load(f"{golden_dir}/stft_f64_cases.npz")
+    for name in sorted({k.rsplit("_", 1)[0] for k in z.files}):
+        sr, win, hop, n_fft = (int(v) for v in z[name + "_par"])
+        plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+        spec, _, _ = plan.calc_spec(z[name + "_x"])
+        amp = z[name + "_amp"]
+        with np.errstate(divide="ignore"):
+            assert_spec_close(spec, (20 * np.log10(amp)).astype(np.float32), amp)
+        plan.close()
+
+
+def test_plan_rejects_unsupported(ctx):
+    with pytest.raises(ta.ThError) as e:
+        ta.Plan(ctx, 48000, 1500, 500, 3000)
+    assert e.value.code == -2
+    with pytest.raises(ta.ThError):
+        ta.Plan(ctx, 48000, 4096, 512, 2048)  # win > n_fft
+
+
+# ---------------------------------------------------------------- spec -> u16 image
+def test_spec_to_img_known_answer(ctx):
+    """drawing.rs:41-56"""
+    spec = np.array([[-100.0, -50.0, 0.0], [100.0, -200.0, -25.0]], np.float32)
+    img = ctx.spec_to_img(spec, (0, 4), (-100.0, 0.0), 4)
+    assert img.tolist() == [[16384, 65535], [40960, 0], [65535, 53247], [0, 0]]
+
+
+@pytest.mark.parametrize("T,H,i0,i1,cm", [(1, 1, 0, 1, 258), (63, 65, 0, 65, 258), (300, 1025, 0, 1025, 258),
+                                          (257, 128, 0, 140, 258), (129, 513, 0, 1026, 4), (70, 70, 3, 50, None),
+                                          (1000, 37, 0, 37, 258)])
+def test_spec_to_img_bit_exact(ctx, T, H, i0, i1, cm):
+    rng = np.random.default_rng(T * 7 + H)
+    spec = rng.uniform(-140, 10, (T, H)).astype(np.float32)
+    spec.ravel()[rng.integers(0, spec.size, 5)] = -np.inf
+    spec.ravel()[rng.integers(0, spec.size, 3)] = np.nan
+    # values exactly on .5 rounding boundaries and on the clamp edges
+    spec.ravel()[:4] = [-100.0, 0.0, -50.0, -100.0 + 100.0 * 0.5 / 65281]
+    got = ctx.spec_to_img(spec, (i0, i1), (-100.0, 0.0), cm)
+    want = orc.convert_spectrogram_to_img(spec, (i0, i1), (-100.0, 0.0), cm)
+    assert np.array_equal(got, want)
+
+
+def test_spec_to_img_all_neg_inf_and_bad_range(ctx):
+    spec = np.full((10, 20), -np.inf, np.float32)
+    assert not ctx.spec_to_img(spec, (0, 20), (-np.inf, -np.inf), 258).any()
+    with pytest.raises(ta.ThError):
+        ctx.spec_to_img(spec, (0, 20), (-np.inf, 0.0), 258)  # assert!(dB_range.0.is_finite())
+
+
+# ---------------------------------------------------------------- tiles
+COLORS2 = bytes([0, 0, 0, 255, 255, 0, 0, 255])
+
+
+def test_spectrogram_tile_reference_cases(ctx):
+    """render_tiles.rs:449-471 (level-0 cases)"""
+    spec = np.full((513, 513), 65535, np.uint16)
+    b = ctx.encode_spectrogram_tile(spec, COLORS2, 4, 0, 0, 1, 1)
+    assert struct.unpack_from("<II", b, 8) == (5, 5) and struct.unpack_from("<II", b, 32) == (508, 508)
+    assert np.all(np.frombuffer(b[40:], np.uint8).reshape(-1, 4) == [255, 0, 0, 255])
+    spec = np.array([[0], [65535]], np.uint16)
+    b = ctx.encode_spectrogram_tile(spec, COLORS2, 4, 0, 0, 0, 0)
+    assert b[40:44] == bytes([255, 0, 0, 255]) and b[44:48] == bytes([0, 0, 0, 255])
+
+
+def test_spectrogram_tile_level0_bit_exact(ctx, golden_dir):
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 65536, (1025, 1400), dtype=np.uint16)
+    for tx, ty in ((0, 0), (1, 0), (2, 0), (0, 1), (2, 1), (0, 2), (2, 2), (3, 0), (0, 3)):
+        got = ctx.encode_spectrogram_tile(img, cmap, 11, 0, 0, tx, ty)
+        want = orc.encode_spectrogram_tile(img, cmap, 11, 0, 0, tx, ty)
+        assert got == want, (tx, ty)
+    one = bytes([9, 8, 7, 6])  # single colour: index 0 everywhere (render_tiles.rs:342-343)
+    assert ctx.encode_spectrogram_tile(img[:10, :10], one, 1, 0, 0, 0, 0) == \
+        orc.encode_spectrogram_tile(img[:10, :10], one, 1, 0, 0, 0, 0)
+
+
+def test_waveform_tile_reference_cases(ctx):
+    """render_tiles.rs:408-433"""
+    b = ctx.encode_waveform_tile(np.array([-1.0, 0.0, 0.5, 1.0], np.float32), 3, 1, 0)
+    assert struct.unpack_from("<I", b, 8)[0] == 2
+    assert struct.unpack_from("<fff", b, 24) == (-1.0, 0.0, -0.5)
+    b = ctx.encode_waveform_tile(np.full(1025, 0.25, np.float32), 1, 0, 1)
+    assert struct.unpack_from("<I", b, 8)[0] == 1
+    b = ctx.encode_waveform_tile(np.arange(64, dtype=np.float32) - 32.0, 1, 6, 0)
+    assert struct.unpack_from("<I", b, 8)[0] == 1
+    assert struct.unpack_from("<fff", b, 24) == (-32.0, 31.0, -0.5)
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 4, 5, 6, 7, 9, 12, 16, 30, 70])
+def test_waveform_tile_parity(ctx, level):
+    n = 300001
+    x = synth_track(level, 48000, n)
+    d = ctx.to_device(x)
+    spb = 2 ** min(level, 40)
+    n_tiles = -(-n // (1024 * spb))
+    for tile in sorted({0, 1, n_tiles // 2, max(n_tiles - 1, 0), n_tiles, n_tiles + 5}):
+        got = ctx.encode_waveform_tile_dev(d.ptr, n, 42, level, tile)
+        want = orc.encode_waveform_tile(x, 42, level, tile)
+        assert len(got) == len(want) and got[:24] == want[:24], (level, tile)
+        g = np.frombuffer(got[24:], np.float32).reshape(-1, 3)
+        w = np.frombuffer(want[24:], np.float32).reshape(-1, 3)
+        assert np.array_equal(g[:, :2], w[:, :2]), (level, tile)          # min / max bit-exact
+        if level <= 4:
+            assert np.array_equal(g[:, 2], w[:, 2])                        # sequential mean: bit-exact
+        else:
+            assert np.abs(g[:, 2] - w[:, 2]).max() <= 1e-6 * np.abs(x).max()
+    d.free()
+
+
+# ---------------------------------------------------------------- TrackManager flow
+def test_track_manager_flow(ctx, golden_dir):
+    """core/mod.rs:237-274 restated with numeric checks: add (mixed sample rates, one stereo) ->
+    apply_track_list_changes -> tiles -> set_dB_range -> remove."""
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    tm = ta.TrackManager(ctx)
+    tm.set_colormap(cmap)
+    tracks = [(0, 8000, synth_track(0, 8000, 12000)[None]), (1, 44100, synth_track(1, 44100, 30000)[None]),
+              (2, 48000, np.stack([synth_track(2, 48000, 40000), synth_track(3, 48000, 40000)]))]
+    w0, s0 = tm.revisions()
+    tm.add_tracks(tracks[:2])
+    tm.add_tracks(tracks[2:])
+    updated, max_sr = tm.apply_track_list_changes()
+    assert updated == [0, 1, 2] and max_sr == 48000
+    w1, s1 = tm.revisions()
+    assert w1 > w0 and s1 > s0
+    # oracle pipeline (default SpecSetting: 40 ms, t_overlap 4, f_overlap 1, Mel)
+    specs, mins, maxs = {}, [], []
+    for tid, sr, wav in tracks:
+        hop, win, n_fft = orc.calc_framing_params(40.0, 4, 1, sr)
+        fb = orc.calc_mel_fb_default(sr, n_fft)
+        for ch in range(wav.shape[0]):
+            s = orc.calc_spec(wav[ch], win, hop, n_fft, mel_fb=fb)
+            specs[(tid, ch)] = (s, sr)
+            g = tm.spec(tid, ch)
+            assert_spec_close(g, s)
+            mins.append(g.min()); maxs.append(g.max())
+    lo, hi = orc.global_db_range(mins, maxs, 100.0)
+    glo, ghi, gsr = tm.db_state()
+    assert (glo, ghi, gsr) == (lo, hi, 48000)
+    mism = tot = 0
+    for (tid, ch), (s, sr) in specs.items():
+        g_spec = tm.spec(tid, ch)
+        rng = orc.hz_range_to_idx(orc.MEL, (0.0, 24000.0), sr, s.shape[1])
+        img = tm.img(tid, ch)
+        # integer stage bit-exact given identical input (the GPU's own f32 spec)
+        assert np.array_equal(img, orc.convert_spectrogram_to_img(g_spec, rng, (lo, hi), 258))
+        ref_img = orc.convert_spectrogram_to_img(s, rng, (lo, hi), 258)
+        mism += np.count_nonzero(img != ref_img); tot += img.size
+        assert np.abs(img.astype(np.int32) - ref_img.astype(np.int32)).max() <= 2
+        b = tm.get_spectrogram_tile(tid, ch, 0, 0, 0, 0)
+        assert b == orc.encode_spectrogram_tile(img, cmap, s1, 0, 0, 0, 0)
+    print(f"end-to-end u16 mismatch rate vs oracle spec: {mism / tot:.3e}")
+    assert mism / tot < 0.02
+    wt = tm.get_waveform_tile(2, 1, 3, 1)
+    assert wt == orc.encode_waveform_tile(tracks[2][2][1], w1, 3, 1)
+    # nothing new: no ids
+    assert tm.apply_track_list_changes()[0] == []
+    tm.set_dB_range(60.0)
+    lo2, hi2, _ = tm.db_state()
+    assert (lo2, hi2) == orc.global_db_range(mins, maxs, 60.0)
+    assert np.array_equal(tm.img(0, 0), orc.convert_spectrogram_to_img(
+        tm.spec(0, 0), orc.hz_range_to_idx(orc.MEL, (0.0, 24000.0), 8000, tm.spec(0, 0).shape[1]), (lo2, hi2), 258))
+    tm.set_setting(2048 / 48, 4, 1, ta.LINEAR)
+    assert tm.spec(2, 0).shape == (orc.stft_n_frames(40000, 2048, 512), 1025)
+    assert_spec_close(tm.spec(2, 1), orc.calc_spec(tracks[2][2][1], 2048, 512, 2048))
+    tm.remove_track(0)
+    with pytest.raises(ta.ThError) as e:
+        tm.spec(0, 0)
+    assert e.value.code == -7
+    tm.close()

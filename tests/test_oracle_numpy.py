@@ -84,3 +84,15 @@ def test_calc_spec_linear_and_mel_vs_float64():
 def test_silence_gives_neg_inf():
     spec = orc.calc_spec(np.zeros(5000, np.float32), 1024, 256, 1024)
     assert np.all(np.isneginf(spec))
+
+
+def test_oracle_matches_committed_f64_fixtures(golden_dir):
+    z = np.load(f"{golden_dir}/stft_f64_cases.npz")
+    names = sorted({k.rsplit("_", 1)[0] for k in z.files})
+    assert len(names) == 7
+    for name in names:
+        sr, win, hop, n_fft = (int(v) for v in z[name + "_par"])
+        _, amp = orc.calc_spec(z[name + "_x"], win, hop, n_fft, return_amp=True)
+        want = z[name + "_amp"]
+        assert amp.shape == want.shape
+        assert np.abs(amp - want).max() <= 1e-6 * want.max()

@@ -1,0 +1,139 @@
+"""ctypes binding of libthesia_amd.so (the C ABI declared in include/thesia_amd.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  Importing
+this module fails loudly when it is missing: there is no CPU fallback of any kind.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libthesia_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the HIP extension first "
+        "(python -c 'import __graft_entry__ as g; g.build()').  thesia_amd has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+c_f32p = C.POINTER(C.c_float)
+c_u8p = C.POINTER(C.c_uint8)
+c_u16p = C.POINTER(C.c_uint16)
+c_szp = C.POINTER(C.c_size_t)
+vp = C.c_void_p
+
+
+class ThError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"thesia_amd error {code}: {msg}")
+        self.code = code
+
+
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_BUFFER_TOO_SMALL, ERR_NOT_FOUND, \
+    ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
+
+
+class TileGeom(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("origin_x", C.c_uint32), ("origin_y", C.c_uint32),
+                ("lod_width", C.c_uint64), ("lod_height", C.c_uint64)]
+
+
+class ChanDesc(C.Structure):
+    _fields_ = [("wav", vp), ("spec", vp), ("n_samples", C.c_uint64), ("n_frames", C.c_uint64)]
+
+
+class ImgDesc(C.Structure):
+    _fields_ = [("spec", vp), ("img", vp), ("n_frames", C.c_uint64), ("height", C.c_uint64),
+                ("i_start", C.c_uint64), ("i_end", C.c_uint64)]
+
+
+class RasterDesc(C.Structure):
+    _fields_ = [("img", vp), ("rgba", vp), ("img_width", C.c_uint32), ("img_height", C.c_uint32),
+                ("origin_x", C.c_uint32), ("origin_y", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class WaveDesc(C.Structure):
+    _fields_ = [("wav", vp), ("bins", vp), ("n_samples", C.c_uint64), ("start", C.c_uint64),
+                ("level", C.c_uint32), ("bin_count", C.c_uint32)]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES).  Keep in sync with include/thesia_amd.h;
+# tests/test_abi.py checks that every TH_API symbol of the header is exported and declared here.
+_SIGS = {
+    "th_version": [],
+    "th_device_count": [C.POINTER(C.c_int)],
+    "th_calc_framing_params": [C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, c_szp, c_szp, c_szp],
+    "th_stft_n_frames": [C.c_size_t, C.c_size_t, C.c_size_t, c_szp],
+    "th_calc_normalized_win": [C.c_size_t, C.c_size_t, c_f32p],
+    "th_calc_mel_fb": [C.c_uint32, C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.c_int, c_f32p],
+    "th_mel_default_n_mel": [C.c_uint32, C.c_size_t, c_szp],
+    "th_hz_range_to_idx": [C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_size_t, c_szp, c_szp],
+    "th_global_db_range": [c_f32p, c_f32p, C.c_size_t, C.c_float, c_f32p, c_f32p],
+    "th_spectrogram_tile_geometry": [C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.POINTER(TileGeom)],
+    "th_waveform_tile_geometry": [C.c_size_t, C.c_uint32, C.c_uint32, c_szp, c_szp, c_szp],
+    "th_ctx_create": [C.c_int, vp, C.POINTER(vp)],
+    "th_ctx_destroy": [vp],
+    "th_ctx_synchronize": [vp],
+    "th_dev_alloc": [vp, C.c_size_t, C.POINTER(vp)],
+    "th_dev_free": [vp, vp],
+    "th_dev_upload": [vp, vp, vp, C.c_size_t],
+    "th_dev_download": [vp, vp, vp, C.c_size_t],
+    "th_timer_start": [vp],
+    "th_timer_stop_ms": [vp, c_f32p],
+    "th_plan_create": [vp, C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.POINTER(vp)],
+    "th_plan_destroy": [vp],
+    "th_plan_dims": [vp, c_szp, c_szp],
+    "th_plan_set_kernel": [vp, C.c_int],
+    "th_plan_kernel_name": [vp],
+    "th_calc_spec_batch_dev": [vp, C.POINTER(ChanDesc), C.c_size_t, vp],
+    "th_calc_spec_host": [vp, c_f32p, C.c_size_t, c_f32p, C.c_size_t, c_szp, c_f32p, c_f32p],
+    "th_spec_to_img_dev": [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
+                           C.c_uint32, vp],
+    "th_spec_to_img_batch_dev": [vp, C.POINTER(ImgDesc), C.c_size_t, C.c_float, C.c_float, C.c_uint32],
+    "th_encode_spectrogram_tile_dev": [vp, vp, C.c_size_t, C.c_size_t, c_u8p, C.c_size_t, C.c_uint64, C.c_uint32,
+                                       C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
+    "th_raster_tiles_dev": [vp, C.POINTER(RasterDesc), C.c_size_t, vp, C.c_uint32],
+    "th_encode_waveform_tile_dev": [vp, vp, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t,
+                                    c_szp],
+    "th_waveform_tiles_dev": [vp, C.POINTER(WaveDesc), C.c_size_t],
+    "th_tm_create": [vp, C.POINTER(vp)],
+    "th_tm_destroy": [vp],
+    "th_tm_set_colormap": [vp, c_u8p, C.c_size_t],
+    "th_tm_set_setting": [vp, C.c_double, C.c_uint32, C.c_uint32, C.c_int],
+    "th_tm_set_dB_range": [vp, C.c_float],
+    "th_tm_add_track": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(c_f32p), C.c_size_t],
+    "th_tm_add_tracks": [vp, C.c_size_t, c_szp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(c_f32p),
+                         c_szp],
+    "th_tm_remove_track": [vp, C.c_size_t],
+    "th_tm_apply_track_list_changes": [vp, c_szp, C.c_size_t, c_szp, C.POINTER(C.c_uint32)],
+    "th_tm_get_db_state": [vp, c_f32p, c_f32p, C.POINTER(C.c_uint32)],
+    "th_tm_spec_shape": [vp, C.c_size_t, C.c_uint32, c_szp, c_szp],
+    "th_tm_img_shape": [vp, C.c_size_t, C.c_uint32, c_szp, c_szp],
+    "th_tm_copy_spec": [vp, C.c_size_t, C.c_uint32, c_f32p, C.c_size_t],
+    "th_tm_copy_img": [vp, C.c_size_t, C.c_uint32, c_u16p, C.c_size_t],
+    "th_tm_revisions": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    "th_tm_get_spectrogram_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   c_u8p, C.c_size_t, c_szp],
+    "th_tm_get_waveform_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
+}
+_RESTYPES = {"th_plan_kernel_name": C.c_char_p}
+
+lib.th_last_error.restype = C.c_char_p
+lib.th_last_error.argtypes = []
+for _name, _args in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header/library mismatch: fail loudly
+    _fn.argtypes = _args
+    _fn.restype = _RESTYPES.get(_name, C.c_int)
+
+
+def last_error() -> str:
+    return (lib.th_last_error() or b"").decode()
+
+
+def check(code: int) -> None:
+    if code != OK:
+        raise ThError(code, last_error())

@@ -1,0 +1,382 @@
+"""Thin Python face of the C ABI (include/thesia_amd.h) used by tests and bench.py.
+
+The host logic lives in C++ behind the C ABI (thesia_amd/csrc); this file only marshals numpy
+arrays / device pointers.  Names follow the reference: SpecSetting, SpectrogramAnalyzer plan,
+TrackManager, encode_*_tile (src-tauri/src/core/{spectrogram,mod,render_tiles}.rs).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (ChanDesc, ImgDesc, RasterDesc, ThError, TileGeom, WaveDesc, c_f32p, c_szp, c_u8p, c_u16p, check,
+                   lib, vp)
+
+LINEAR, MEL = 0, 1
+WAVEFORM_TILE_MAX_BYTES = 24 + 1024 * 12
+SPECTROGRAM_TILE_MAX_BYTES = 40 + 520 * 520 * 4
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+# ------------------------------------------------------------------ host-only helpers
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib.th_device_count(C.byref(n)))
+    return n.value
+
+
+def calc_framing_params(win_ms: float, t_overlap: int, f_overlap: int, sr: int):
+    """SpecSetting::calc_framing_params (spectrogram.rs:56-98) -> (hop, win, n_fft)."""
+    h, w, n = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    check(lib.th_calc_framing_params(win_ms, t_overlap, f_overlap, sr, C.byref(h), C.byref(w), C.byref(n)))
+    return h.value, w.value, n.value
+
+
+def stft_n_frames(n_samples: int, win: int, hop: int) -> int:
+    t = C.c_size_t()
+    check(lib.th_stft_n_frames(n_samples, win, hop, C.byref(t)))
+    return t.value
+
+
+def calc_normalized_win(win: int, n_fft: int) -> np.ndarray:
+    out = np.empty(win, np.float32)
+    check(lib.th_calc_normalized_win(win, n_fft, _ptr(out, c_f32p)))
+    return out
+
+
+def calc_mel_fb(sr: int, n_fft: int, n_mel: int, fmin: float = 0.0, fmax: Optional[float] = None,
+                do_norm: bool = True) -> np.ndarray:
+    out = np.empty((n_fft // 2 + 1, n_mel), np.float32)
+    check(lib.th_calc_mel_fb(sr, n_fft, n_mel, fmin, -1.0 if fmax is None else fmax, int(do_norm),
+                             _ptr(out, c_f32p)))
+    return out
+
+
+def mel_default_n_mel(sr: int, n_fft: int) -> int:
+    n = C.c_size_t()
+    check(lib.th_mel_default_n_mel(sr, n_fft, C.byref(n)))
+    return n.value
+
+
+def hz_range_to_idx(freq_scale: int, hz_range, sr: int, n: int):
+    a, b = C.c_size_t(), C.c_size_t()
+    check(lib.th_hz_range_to_idx(freq_scale, hz_range[0], hz_range[1], sr, n, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def global_db_range(mins, maxs, dB_range: float = 100.0):
+    mins, maxs = _f32(mins).ravel(), _f32(maxs).ravel()
+    lo, hi = C.c_float(), C.c_float()
+    check(lib.th_global_db_range(_ptr(mins, c_f32p), _ptr(maxs, c_f32p), mins.size, dB_range, C.byref(lo),
+                                 C.byref(hi)))
+    return lo.value, hi.value
+
+
+def spectrogram_tile_geometry(img_width: int, img_height: int, level_x: int, level_y: int, tile_x: int,
+                              tile_y: int) -> TileGeom:
+    g = TileGeom()
+    check(lib.th_spectrogram_tile_geometry(img_width, img_height, level_x, level_y, tile_x, tile_y, C.byref(g)))
+    return g
+
+
+def waveform_tile_geometry(n_samples: int, level: int, tile_index: int):
+    s, b, p = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    check(lib.th_waveform_tile_geometry(n_samples, level, tile_index, C.byref(s), C.byref(b), C.byref(p)))
+    return s.value, b.value, p.value
+
+
+# ------------------------------------------------------------------ device context
+class DeviceBuffer:
+    """hipMalloc'd buffer owned through the C ABI (th_dev_alloc / th_dev_free)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = vp()
+        check(lib.th_dev_alloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        check(lib.th_dev_upload(self.ctx.handle, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib.th_dev_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(lib.th_dev_free(self.ctx.handle, self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """th_ctx: one GPU + one HIP stream.  `stream` may be a raw hipStream_t (e.g. torch's)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        h = vp()
+        check(lib.th_ctx_create(device, vp(stream) if stream else None, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            check(lib.th_ctx_destroy(self.handle))
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def synchronize(self):
+        check(lib.th_ctx_synchronize(self.handle))
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, a: np.ndarray) -> DeviceBuffer:
+        a = np.ascontiguousarray(a)
+        return DeviceBuffer(self, max(a.nbytes, 1)).upload(a)
+
+    def timer_start(self):
+        check(lib.th_timer_start(self.handle))
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        check(lib.th_timer_stop_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+    # ---- convert_spectrogram_to_img (drawing.rs:4-33), numpy in/out
+    def spec_to_img(self, spec: np.ndarray, i_freq_range, dB_range, colormap_length: Optional[int]) -> np.ndarray:
+        spec = _f32(spec)
+        T, H = spec.shape
+        i0, i1 = i_freq_range
+        d_spec = self.to_device(spec)
+        d_img = self.alloc(max((i1 - i0) * T * 2, 1))
+        check(lib.th_spec_to_img_dev(self.handle, d_spec.ptr, T, H, i0, i1, dB_range[0], dB_range[1],
+                                     0 if colormap_length is None else colormap_length, d_img.ptr))
+        out = d_img.download((i1 - i0, T), np.uint16)
+        d_spec.free()
+        d_img.free()
+        return out
+
+    def spec_to_img_batch(self, descs: Sequence[ImgDesc], min_dB: float, max_dB: float, colormap_length: int):
+        arr = descs if isinstance(descs, C.Array) else (ImgDesc * len(descs))(*descs)
+        check(lib.th_spec_to_img_batch_dev(self.handle, arr, len(arr), min_dB, max_dB, colormap_length))
+
+    # ---- encode_spectrogram_tile (render_tiles.rs:281-352), numpy image in, bytes out
+    def encode_spectrogram_tile(self, img: np.ndarray, colormap_rgba: bytes, revision: int, level_x: int,
+                                level_y: int, tile_x: int, tile_y: int) -> bytes:
+        img = np.ascontiguousarray(img, dtype=np.uint16)
+        d_img = self.to_device(img)
+        try:
+            return self.encode_spectrogram_tile_dev(d_img.ptr, img.shape[0], img.shape[1], colormap_rgba, revision,
+                                                    level_x, level_y, tile_x, tile_y)
+        finally:
+            d_img.free()
+
+    def encode_spectrogram_tile_dev(self, d_img: int, img_height: int, img_width: int, colormap_rgba: bytes,
+                                    revision: int, level_x: int, level_y: int, tile_x: int, tile_y: int) -> bytes:
+        cm = np.frombuffer(bytes(colormap_rgba), np.uint8)
+        out = np.empty(SPECTROGRAM_TILE_MAX_BYTES, np.uint8)
+        n = C.c_size_t()
+        check(lib.th_encode_spectrogram_tile_dev(self.handle, d_img, img_height, img_width, _ptr(cm, c_u8p), cm.size,
+                                                 revision, level_x, level_y, tile_x, tile_y, _ptr(out, c_u8p),
+                                                 out.size, C.byref(n)))
+        return out[: n.value].tobytes()
+
+    def raster_tiles(self, descs: Sequence[RasterDesc], d_colormap: int, n_colors: int):
+        arr = descs if isinstance(descs, C.Array) else (RasterDesc * len(descs))(*descs)
+        check(lib.th_raster_tiles_dev(self.handle, arr, len(arr), d_colormap, n_colors))
+
+    # ---- encode_waveform_tile (render_tiles.rs:232-279)
+    def encode_waveform_tile(self, wav: np.ndarray, revision: int, level: int, tile_index: int) -> bytes:
+        wav = _f32(wav)
+        d = self.to_device(wav)
+        try:
+            return self.encode_waveform_tile_dev(d.ptr, wav.size, revision, level, tile_index)
+        finally:
+            d.free()
+
+    def encode_waveform_tile_dev(self, d_wav: int, n_samples: int, revision: int, level: int,
+                                 tile_index: int) -> bytes:
+        out = np.empty(WAVEFORM_TILE_MAX_BYTES, np.uint8)
+        n = C.c_size_t()
+        check(lib.th_encode_waveform_tile_dev(self.handle, d_wav, n_samples, revision, level, tile_index,
+                                              _ptr(out, c_u8p), out.size, C.byref(n)))
+        return out[: n.value].tobytes()
+
+    def waveform_tiles(self, descs: Sequence[WaveDesc]):
+        arr = descs if isinstance(descs, C.Array) else (WaveDesc * len(descs))(*descs)
+        check(lib.th_waveform_tiles_dev(self.handle, arr, len(arr)))
+
+
+# ------------------------------------------------------------------ SpectrogramAnalyzer plan
+class Plan:
+    """th_plan: device-resident window / twiddles / mel filterbank for one framing key
+    (SpectrogramAnalyzer::prepare, spectrogram.rs:116-154)."""
+
+    def __init__(self, ctx: Context, sr: int, win: int, hop: int, n_fft: int, freq_scale: int = LINEAR,
+                 n_mel: int = 0):
+        h = vp()
+        check(lib.th_plan_create(ctx.handle, sr, win, hop, n_fft, freq_scale, n_mel, C.byref(h)))
+        self.handle, self.ctx = h, ctx
+        self.sr, self.win, self.hop, self.n_fft, self.freq_scale = sr, win, hop, n_fft, freq_scale
+        f, hh = C.c_size_t(), C.c_size_t()
+        check(lib.th_plan_dims(h, C.byref(f), C.byref(hh)))
+        self.n_freq, self.height = f.value, hh.value
+
+    def close(self):
+        if self.handle:
+            check(lib.th_plan_destroy(self.handle))
+            self.handle = None
+
+    def set_kernel(self, which: int):
+        check(lib.th_plan_set_kernel(self.handle, which))
+
+    @property
+    def kernel_name(self) -> str:
+        return (lib.th_plan_kernel_name(self.handle) or b"").decode()
+
+    def n_frames(self, n_samples: int) -> int:
+        return stft_n_frames(n_samples, self.win, self.hop)
+
+    def calc_spec_batch_dev(self, descs: Sequence[ChanDesc], d_minmax: Optional[int]):
+        """Stream-ordered batched calc_spec on device pointers (no sync)."""
+        arr = descs if isinstance(descs, C.Array) else (ChanDesc * len(descs))(*descs)
+        check(lib.th_calc_spec_batch_dev(self.handle, arr, len(arr), d_minmax))
+
+    def calc_spec(self, wav: np.ndarray):
+        """calc_spec for one channel with host buffers -> (T x H f32 dB, min, max)."""
+        wav = _f32(wav)
+        T = self.n_frames(wav.size)
+        out = np.empty((T, self.height), np.float32)
+        n, mn, mx = C.c_size_t(), C.c_float(), C.c_float()
+        check(lib.th_calc_spec_host(self.handle, _ptr(wav, c_f32p), wav.size, _ptr(out, c_f32p), out.size,
+                                    C.byref(n), C.byref(mn), C.byref(mx)))
+        assert n.value == T
+        return out, mn.value, mx.value
+
+    def calc_spec_batch(self, wavs: Iterable[np.ndarray]):
+        """Batched calc_spec over host arrays -> (list of specs, (n,2) min/max)."""
+        wavs = [_f32(w) for w in wavs]
+        ctx = self.ctx
+        d_w = [ctx.to_device(w) for w in wavs]
+        Ts = [self.n_frames(w.size) for w in wavs]
+        d_s = [ctx.alloc(max(T * self.height * 4, 4)) for T in Ts]
+        d_mm = ctx.alloc(8 * len(wavs))
+        descs = [ChanDesc(dw.ptr, ds.ptr, w.size, T) for dw, ds, w, T in zip(d_w, d_s, wavs, Ts)]
+        self.calc_spec_batch_dev(descs, d_mm.ptr)
+        ctx.synchronize()
+        specs = [ds.download((T, self.height), np.float32) for ds, T in zip(d_s, Ts)]
+        mm = d_mm.download((len(wavs), 2), np.float32)
+        for b in d_w + d_s + [d_mm]:
+            b.free()
+        return specs, mm
+
+
+# ------------------------------------------------------------------ TrackManager mirror
+class TrackManager:
+    """th_tm: mirror of core/mod.rs TrackManager with HBM-resident audio / specs / images."""
+
+    def __init__(self, ctx: Context):
+        h = vp()
+        check(lib.th_tm_create(ctx.handle, C.byref(h)))
+        self.handle, self.ctx = h, ctx
+
+    def close(self):
+        if self.handle:
+            check(lib.th_tm_destroy(self.handle))
+            self.handle = None
+
+    def set_colormap(self, rgba: bytes):
+        a = np.frombuffer(bytes(rgba), np.uint8)
+        check(lib.th_tm_set_colormap(self.handle, _ptr(a, c_u8p), a.size))
+
+    def set_setting(self, win_ms: float, t_overlap: int, f_overlap: int, freq_scale: int):
+        check(lib.th_tm_set_setting(self.handle, win_ms, t_overlap, f_overlap, freq_scale))
+
+    def set_dB_range(self, dB_range: float):
+        check(lib.th_tm_set_dB_range(self.handle, dB_range))
+
+    def add_tracks(self, tracks):
+        """tracks: iterable of (id, sr, planar ndarray [channels, samples])."""
+        tracks = [(i, sr, np.atleast_2d(_f32(w))) for i, sr, w in tracks]
+        n = len(tracks)
+        ids = (C.c_size_t * n)(*[t[0] for t in tracks])
+        srs = (C.c_uint32 * n)(*[t[1] for t in tracks])
+        nch = (C.c_uint32 * n)(*[t[2].shape[0] for t in tracks])
+        ns = (C.c_size_t * n)(*[t[2].shape[1] for t in tracks])
+        rows = [np.ascontiguousarray(t[2][c]) for t in tracks for c in range(t[2].shape[0])]
+        ptrs = (c_f32p * len(rows))(*[_ptr(r, c_f32p) for r in rows])
+        check(lib.th_tm_add_tracks(self.handle, n, ids, srs, nch, ptrs, ns))
+
+    def remove_track(self, track_id: int):
+        check(lib.th_tm_remove_track(self.handle, track_id))
+
+    def apply_track_list_changes(self):
+        cap = 4096
+        ids = (C.c_size_t * cap)()
+        n, sr = C.c_size_t(), C.c_uint32()
+        check(lib.th_tm_apply_track_list_changes(self.handle, ids, cap, C.byref(n), C.byref(sr)))
+        return sorted(ids[i] for i in range(min(n.value, cap))), sr.value
+
+    def db_state(self):
+        lo, hi, sr = C.c_float(), C.c_float(), C.c_uint32()
+        check(lib.th_tm_get_db_state(self.handle, C.byref(lo), C.byref(hi), C.byref(sr)))
+        return lo.value, hi.value, sr.value
+
+    def revisions(self):
+        w, s = C.c_uint64(), C.c_uint64()
+        check(lib.th_tm_revisions(self.handle, C.byref(w), C.byref(s)))
+        return w.value, s.value
+
+    def spec(self, track_id: int, ch: int) -> np.ndarray:
+        t, h = C.c_size_t(), C.c_size_t()
+        check(lib.th_tm_spec_shape(self.handle, track_id, ch, C.byref(t), C.byref(h)))
+        out = np.empty((t.value, h.value), np.float32)
+        check(lib.th_tm_copy_spec(self.handle, track_id, ch, _ptr(out, c_f32p), out.size))
+        return out
+
+    def img(self, track_id: int, ch: int) -> np.ndarray:
+        h, w = C.c_size_t(), C.c_size_t()
+        check(lib.th_tm_img_shape(self.handle, track_id, ch, C.byref(h), C.byref(w)))
+        out = np.empty((h.value, w.value), np.uint16)
+        check(lib.th_tm_copy_img(self.handle, track_id, ch, _ptr(out, c_u16p), out.size))
+        return out
+
+    def get_spectrogram_tile(self, track_id: int, ch: int, level_x: int, level_y: int, tile_x: int,
+                             tile_y: int) -> bytes:
+        out = np.empty(SPECTROGRAM_TILE_MAX_BYTES, np.uint8)
+        n = C.c_size_t()
+        check(lib.th_tm_get_spectrogram_tile(self.handle, track_id, ch, level_x, level_y, tile_x, tile_y,
+                                             _ptr(out, c_u8p), out.size, C.byref(n)))
+        return out[: n.value].tobytes()
+
+    def get_waveform_tile(self, track_id: int, ch: int, level: int, tile_index: int) -> bytes:
+        out = np.empty(WAVEFORM_TILE_MAX_BYTES, np.uint8)
+        n = C.c_size_t()
+        check(lib.th_tm_get_waveform_tile(self.handle, track_id, ch, level, tile_index, _ptr(out, c_u8p), out.size,
+                                          C.byref(n)))
+        return out[: n.value].tobytes()

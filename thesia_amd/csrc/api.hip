@@ -1,0 +1,688 @@
+// api.hip — C ABI: errors, host helpers, device context, SpectrogramAnalyzer plan and the
+// device-pointer ("layer A") entry points.  The TrackManager mirror lives in track_manager.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "context.h"
+#include "host_math.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------ errors
+namespace th {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char *get_error() { return g_err; }
+}  // namespace th
+
+using namespace th;
+
+TH_API const char *th_last_error(void) { return th::get_error(); }
+TH_API int th_version(void) { return 100; }
+
+TH_API int th_device_count(int *count) {
+    TH_TRY
+    TH_REQUIRE(count, "count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return TH_OK;
+    TH_CATCH
+}
+
+// ------------------------------------------------------------------------------------------ host helpers
+TH_API int th_calc_framing_params(double win_ms, uint32_t t_overlap, uint32_t f_overlap, uint32_t sr, size_t *hop,
+                                  size_t *win, size_t *n_fft) {
+    TH_TRY
+    TH_REQUIRE(hop && win && n_fft, "output pointer is NULL");
+    // the reference asserts these in set_spec_setting (src-tauri/src/lib.rs:275-277)
+    TH_REQUIRE(win_ms > 0. && t_overlap >= 1 && f_overlap >= 1, "win_ms > 0, t_overlap >= 1, f_overlap >= 1 required");
+    calc_framing_params(win_ms, t_overlap, f_overlap, sr, hop, win, n_fft);
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_stft_n_frames(size_t n_samples, size_t win, size_t hop, size_t *n_frames) {
+    TH_TRY
+    TH_REQUIRE(n_frames, "n_frames is NULL");
+    TH_REQUIRE(win >= 1 && hop >= 1, "win and hop must be >= 1");
+    *n_frames = stft_n_frames(n_samples, win, hop);
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_calc_normalized_win(size_t win, size_t n_fft, float *out) {
+    TH_TRY
+    TH_REQUIRE(out, "out is NULL");
+    TH_REQUIRE(win > 1 && n_fft >= 1, "win must be > 1");  // windows.rs:73 debug_assert!(size > 1)
+    const std::vector<float> w = normalized_hann(win, n_fft);
+    std::memcpy(out, w.data(), sizeof(float) * win);
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_calc_mel_fb(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, int do_norm, float *out) {
+    TH_TRY
+    TH_REQUIRE(out, "out is NULL");
+    TH_REQUIRE(n_fft % 2 == 0 && n_mel != 0, "n_fft must be even and n_mel non-zero");  // lib.rs:59-60
+    const std::vector<float> fb = calc_mel_fb(sr, n_fft, n_mel, fmin, fmax, do_norm != 0);
+    std::memcpy(out, fb.data(), sizeof(float) * fb.size());
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_mel_default_n_mel(uint32_t sr, size_t n_fft, size_t *n_mel) {
+    TH_TRY
+    TH_REQUIRE(n_mel, "n_mel is NULL");
+    TH_REQUIRE(sr > 0 && n_fft >= 2 && n_fft % 2 == 0, "sr > 0 and even n_fft >= 2 required");
+    *n_mel = mel_default_n_mel(sr, n_fft);
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_hz_range_to_idx(int freq_scale, float hz_min, float hz_max, uint32_t sr, size_t n, size_t *i_start,
+                              size_t *i_end) {
+    TH_TRY
+    TH_REQUIRE(i_start && i_end, "output pointer is NULL");
+    TH_REQUIRE(freq_scale == TH_FREQ_LINEAR || freq_scale == TH_FREQ_MEL, "bad freq_scale %d", freq_scale);
+    hz_range_to_idx(freq_scale, hz_min, hz_max, sr, n, i_start, i_end);
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_global_db_range(const float *mins, const float *maxs, size_t n, float dB_range, float *min_dB,
+                              float *max_dB) {
+    TH_TRY
+    TH_REQUIRE(min_dB && max_dB && (n == 0 || (mins && maxs)), "NULL pointer");
+    global_db_range(mins, maxs, n, dB_range, min_dB, max_dB);
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_spectrogram_tile_geometry(size_t W, size_t Hh, uint32_t lx, uint32_t ly, uint32_t tx, uint32_t ty,
+                                        th_tile_geom *geom) {
+    TH_TRY
+    TH_REQUIRE(geom, "geom is NULL");
+    const TileGeom g = spectrogram_tile_geometry(W, Hh, lx, ly, tx, ty);
+    geom->width = (uint32_t)g.width;
+    geom->height = (uint32_t)g.height;
+    geom->origin_x = (uint32_t)g.origin_x;
+    geom->origin_y = (uint32_t)g.origin_y;
+    geom->lod_width = g.lod_w;
+    geom->lod_height = g.lod_h;
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_waveform_tile_geometry(size_t n_samples, uint32_t level, uint32_t tile_index, size_t *start,
+                                     size_t *bin_count, size_t *samples_per_bin) {
+    TH_TRY
+    TH_REQUIRE(start && bin_count && samples_per_bin, "output pointer is NULL");
+    waveform_tile_geometry(n_samples, level, tile_index, start, bin_count, samples_per_bin);
+    return TH_OK;
+    TH_CATCH
+}
+
+// ------------------------------------------------------------------------------------------ context
+TH_API int th_ctx_create(int device, void *hip_stream, th_ctx **out) {
+    TH_TRY
+    TH_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(TH_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    TH_REQUIRE(device >= 0 && device < n, "device %d out of range (have %d)", device, n);
+    TH_HIP(hipSetDevice(device));
+    th_ctx *c = new th_ctx();
+    c->device = device;
+    if (hip_stream) {
+        c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return fail(TH_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail(TH_ERR_HIP, "hipEventCreate failed");
+    }
+    *out = c;
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_ctx_destroy(th_ctx *c) {
+    TH_TRY
+    if (!c) return TH_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->release_scratch();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_ctx_synchronize(th_ctx *c) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_dev_alloc(th_ctx *c, size_t bytes, void **dptr) {
+    TH_TRY
+    TH_REQUIRE(c && dptr, "NULL argument");
+    *dptr = nullptr;
+    TH_HIP(hipSetDevice(c->device));
+    TH_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return TH_OK;
+    TH_CATCH
+}
+TH_API int th_dev_free(th_ctx *c, void *dptr) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    if (dptr) {
+        TH_HIP(hipStreamSynchronize(c->stream));
+        TH_HIP(hipFree(dptr));
+    }
+    return TH_OK;
+    TH_CATCH
+}
+TH_API int th_dev_upload(th_ctx *c, void *dst, const void *src, size_t bytes) {
+    TH_TRY
+    TH_REQUIRE(c && (bytes == 0 || (dst && src)), "NULL argument");
+    if (bytes) {
+        TH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        TH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return TH_OK;
+    TH_CATCH
+}
+TH_API int th_dev_download(th_ctx *c, void *dst, const void *src, size_t bytes) {
+    TH_TRY
+    TH_REQUIRE(c && (bytes == 0 || (dst && src)), "NULL argument");
+    if (bytes) {
+        TH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        TH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return TH_OK;
+    TH_CATCH
+}
+TH_API int th_timer_start(th_ctx *c) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    TH_HIP(hipEventRecord(c->ev0, c->stream));
+    return TH_OK;
+    TH_CATCH
+}
+TH_API int th_timer_stop_ms(th_ctx *c, float *ms) {
+    TH_TRY
+    TH_REQUIRE(c && ms, "NULL argument");
+    TH_HIP(hipEventRecord(c->ev1, c->stream));
+    TH_HIP(hipEventSynchronize(c->ev1));
+    TH_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return TH_OK;
+    TH_CATCH
+}
+
+// ------------------------------------------------------------------------------------------ plan
+namespace th {
+
+int DeviceTable::ensure(size_t bytes) {
+    if (bytes <= cap) return TH_OK;
+    if (dptr) {
+        TH_HIP(hipFree(dptr));
+        dptr = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes < 4096 ? 4096 : bytes + bytes / 2;
+    TH_HIP(hipMalloc(&dptr, want));
+    cap = want;
+    last.clear();
+    return TH_OK;
+}
+
+// Upload `bytes` of `src` unless the table already holds exactly these bytes (bench loops and
+// repeated tile requests re-send identical descriptor tables).  Synchronous on purpose: the
+// previous launch may still be reading the old table.
+int DeviceTable::upload(hipStream_t s, const void *src, size_t bytes) {
+    if (bytes == last.size() && bytes && std::memcmp(last.data(), src, bytes) == 0) return TH_OK;
+    TH_HIP(hipStreamSynchronize(s));
+    int rc = ensure(bytes);
+    if (rc != TH_OK) return rc;
+    if (bytes) TH_HIP(hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
+    last.assign(static_cast<const unsigned char *>(src), static_cast<const unsigned char *>(src) + bytes);
+    return TH_OK;
+}
+
+void DeviceTable::release() {
+    if (dptr) (void)hipFree(dptr);
+    dptr = nullptr;
+    cap = 0;
+    last.clear();
+}
+
+}  // namespace th
+
+static void plan_free(th_plan *p) {
+    if (!p) return;
+    if (p->d_window) (void)hipFree(p->d_window);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_mel_fb) (void)hipFree(p->d_mel_fb);
+    if (p->d_mel_lo) (void)hipFree(p->d_mel_lo);
+    if (p->d_mel_hi) (void)hipFree(p->d_mel_hi);
+    p->jobs.release();
+    p->tile_start.release();
+    delete p;
+}
+
+TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t n_fft, int freq_scale,
+                          size_t n_mel, th_plan **out) {
+    TH_TRY
+    TH_REQUIRE(c && out, "NULL argument");
+    *out = nullptr;
+    TH_REQUIRE(freq_scale == TH_FREQ_LINEAR || freq_scale == TH_FREQ_MEL, "bad freq_scale %d", freq_scale);
+    TH_REQUIRE(win > 1 && hop >= 1 && win <= n_fft, "need 1 < win <= n_fft and hop >= 1 (win=%zu hop=%zu n_fft=%zu)",
+               win, hop, n_fft);
+    TH_REQUIRE(sr > 0, "sr must be > 0");
+    if (!is_pow2(n_fft) || n_fft < 8 || n_fft > 16384)
+        return fail(TH_ERR_UNSUPPORTED, "n_fft=%zu: only powers of two in [8, 16384] are supported", n_fft);
+    TH_HIP(hipSetDevice(c->device));
+
+    th_plan *p = new th_plan();
+    p->ctx = c;
+    p->sr = sr;
+    p->freq_scale = freq_scale;
+    StftGeom &g = p->g;
+    g.hop = (uint32_t)hop;
+    g.win = (uint32_t)win;
+    g.n_fft = (uint32_t)n_fft;
+    g.pad_left = (uint32_t)((n_fft - win) / 2);
+    g.nc = (uint32_t)(n_fft / 2);
+    g.log2_nc = ilog2(g.nc);
+    g.n_freq = (uint32_t)(n_fft / 2 + 1);
+    g.n_mel = 0;
+    g.height = g.n_freq;
+    g.frames_per_tile = 8;
+
+    // window (windows.rs) and twiddles W_{n_fft}^i (double → f32)
+    const std::vector<float> w = normalized_hann(win, n_fft);
+    std::vector<cf32> tw(n_fft);
+    for (size_t i = 0; i < n_fft; i++) {
+        const double a = -2.0 * M_PI * (double)i / (double)n_fft;
+        tw[i].re = (float)std::cos(a);
+        tw[i].im = (float)std::sin(a);
+    }
+    int rc = TH_OK;
+    auto up = [&](void **d, const void *h, size_t bytes) -> int {
+        TH_HIP(hipMalloc(d, bytes));
+        TH_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+        return TH_OK;
+    };
+    rc = up((void **)&p->d_window, w.data(), w.size() * sizeof(float));
+    if (rc == TH_OK) rc = up((void **)&p->d_tw, tw.data(), tw.size() * sizeof(cf32));
+    if (rc == TH_OK && freq_scale == TH_FREQ_MEL) {
+        if (n_mel == 0) n_mel = mel_default_n_mel(sr, n_fft);  // calc_mel_fb_default, lib.rs:91-103
+        if (n_mel == 0 || n_mel > 65535) {
+            plan_free(p);
+            return fail(TH_ERR_INVALID_ARG, "n_mel=%zu out of range", n_mel);
+        }
+        g.n_mel = (uint32_t)n_mel;
+        g.height = (uint32_t)n_mel;
+        p->h_mel_fb = calc_mel_fb(sr, n_fft, n_mel, 0.f, -1.f, true);
+        std::vector<uint32_t> lo(n_mel, 0), hi(n_mel, 0);
+        for (size_t m = 0; m < n_mel; m++) {
+            uint32_t a = g.n_freq, b = 0;
+            for (uint32_t f = 0; f < g.n_freq; f++)
+                if (p->h_mel_fb[(size_t)f * n_mel + m] != 0.f) {
+                    a = std::min(a, f);
+                    b = f + 1;
+                }
+            lo[m] = b ? a : 0;
+            hi[m] = b;
+        }
+        rc = up((void **)&p->d_mel_fb, p->h_mel_fb.data(), p->h_mel_fb.size() * sizeof(float));
+        if (rc == TH_OK) rc = up((void **)&p->d_mel_lo, lo.data(), lo.size() * sizeof(uint32_t));
+        if (rc == TH_OK) rc = up((void **)&p->d_mel_hi, hi.data(), hi.size() * sizeof(uint32_t));
+    }
+    if (rc != TH_OK) {
+        plan_free(p);
+        return rc;
+    }
+    *out = p;
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_plan_destroy(th_plan *p) {
+    TH_TRY
+    if (!p) return TH_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    plan_free(p);
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_plan_dims(const th_plan *p, size_t *n_freq, size_t *height) {
+    TH_TRY
+    TH_REQUIRE(p, "plan is NULL");
+    if (n_freq) *n_freq = p->g.n_freq;
+    if (height) *height = p->g.height;
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_plan_set_kernel(th_plan *p, int which) {
+    TH_TRY
+    TH_REQUIRE(p, "plan is NULL");
+    TH_REQUIRE(which >= 0 && which <= 2, "kernel selector must be 0, 1 or 2");
+    p->kernel_choice = which;
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API const char *th_plan_kernel_name(const th_plan *p) {
+    if (!p) return "";
+    return "stft_generic_kernel";
+}
+
+// ------------------------------------------------------------------------------------------ calc_spec
+TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t n_chan, float *d_minmax) {
+    TH_TRY
+    TH_REQUIRE(p, "plan is NULL");
+    if (n_chan == 0) return TH_OK;
+    TH_REQUIRE(chans, "chans is NULL");
+    TH_REQUIRE(n_chan < (1u << 24), "too many channels");
+    th_ctx *c = p->ctx;
+    const StftGeom &g = p->g;
+    std::vector<ChanJob> jobs(n_chan);
+    std::vector<uint32_t> tile_start(n_chan + 1);
+    uint64_t tiles = 0;
+    for (size_t i = 0; i < n_chan; i++) {
+        const th_chan_desc &d = chans[i];
+        TH_REQUIRE(d.wav && d.spec, "channel %zu: NULL device pointer", i);
+        TH_REQUIRE(d.n_samples >= 1 && d.n_samples < (1ull << 31), "channel %zu: n_samples=%llu out of range", i,
+                   (unsigned long long)d.n_samples);
+        const size_t T = stft_n_frames(d.n_samples, g.win, g.hop);
+        TH_REQUIRE(d.n_frames == T, "channel %zu: n_frames=%llu but the framing gives %zu", i,
+                   (unsigned long long)d.n_frames, T);
+        jobs[i] = ChanJob{d.wav, d.spec, (uint32_t)d.n_samples, (uint32_t)T};
+        tile_start[i] = (uint32_t)tiles;
+        tiles += (T + g.frames_per_tile - 1) / g.frames_per_tile;
+        TH_REQUIRE(tiles < (1ull << 31), "batch too large for one launch");
+    }
+    tile_start[n_chan] = (uint32_t)tiles;
+
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    TH_HIP(hipSetDevice(c->device));
+    int rc = p->jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(ChanJob));
+    if (rc != TH_OK) return rc;
+    rc = p->tile_start.upload(c->stream, tile_start.data(), tile_start.size() * sizeof(uint32_t));
+    if (rc != TH_OK) return rc;
+    TH_HIP(launch_minmax_init(d_minmax, (uint32_t)n_chan, c->stream));
+    TH_HIP(launch_stft_generic(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
+                               (uint32_t)n_chan, (uint32_t)tiles, p->d_window, p->d_tw, p->d_mel_fb, p->d_mel_lo,
+                               p->d_mel_hi, d_minmax, c->stream));
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_calc_spec_host(th_plan *p, const float *wav, size_t n_samples, float *out_spec, size_t cap,
+                             size_t *n_frames, float *out_min, float *out_max) {
+    TH_TRY
+    TH_REQUIRE(p && wav && out_spec && n_frames, "NULL argument");
+    TH_REQUIRE(n_samples >= 1, "empty input");
+    const StftGeom &g = p->g;
+    const size_t T = stft_n_frames(n_samples, g.win, g.hop);
+    *n_frames = T;
+    if ((size_t)T * g.height > cap) return fail(TH_ERR_BUFFER_TOO_SMALL, "need %zu floats", (size_t)T * g.height);
+    th_ctx *c = p->ctx;
+    TH_HIP(hipSetDevice(c->device));
+    float *d_wav = nullptr, *d_spec = nullptr, *d_mm = nullptr;
+    int rc = TH_OK;
+    auto cleanup = [&]() {
+        if (d_wav) (void)hipFree(d_wav);
+        if (d_spec) (void)hipFree(d_spec);
+        if (d_mm) (void)hipFree(d_mm);
+    };
+    auto hipok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == TH_OK) rc = fail(e == hipErrorOutOfMemory ? TH_ERR_OOM : TH_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    if (hipok(hipMalloc((void **)&d_wav, n_samples * sizeof(float)), "hipMalloc wav") &&
+        hipok(hipMalloc((void **)&d_spec, std::max<size_t>(1, T * g.height) * sizeof(float)), "hipMalloc spec") &&
+        hipok(hipMalloc((void **)&d_mm, 2 * sizeof(float)), "hipMalloc minmax") &&
+        hipok(hipMemcpy(d_wav, wav, n_samples * sizeof(float), hipMemcpyHostToDevice), "upload")) {
+        th_chan_desc d{d_wav, d_spec, n_samples, T};
+        rc = th_calc_spec_batch_dev(p, &d, 1, d_mm);
+        if (rc == TH_OK) {
+            float mm[2];
+            if (hipok(hipStreamSynchronize(c->stream), "sync") &&
+                hipok(hipMemcpy(out_spec, d_spec, T * g.height * sizeof(float), hipMemcpyDeviceToHost), "download") &&
+                hipok(hipMemcpy(mm, d_mm, sizeof mm, hipMemcpyDeviceToHost), "download minmax")) {
+                if (out_min) *out_min = mm[0];
+                if (out_max) *out_max = mm[1];
+            }
+        }
+    }
+    cleanup();
+    return rc;
+    TH_CATCH
+}
+
+// ------------------------------------------------------------------------------------------ spec → img
+TH_API int th_spec_to_img_batch_dev(th_ctx *c, const th_img_desc *descs, size_t n, float min_dB, float max_dB,
+                                    uint32_t colormap_len) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    if (n == 0) return TH_OK;
+    TH_REQUIRE(descs, "descs is NULL");
+    const bool all_neg_inf = (min_dB == max_dB) && std::isinf(max_dB) && max_dB < 0;  // drawing.rs:16-18
+    if (!all_neg_inf) TH_REQUIRE(std::isfinite(min_dB), "min_dB must be finite (drawing.rs:19)");
+    std::vector<ImgJob> jobs(n);
+    std::vector<uint32_t> start(n + 1);
+    uint64_t tiles = 0;
+    for (size_t i = 0; i < n; i++) {
+        const th_img_desc &d = descs[i];
+        TH_REQUIRE(d.i_end >= d.i_start, "desc %zu: i_end < i_start", i);
+        const uint64_t out_h = d.i_end - d.i_start;
+        TH_REQUIRE(d.n_frames < (1ull << 31) && d.height < (1ull << 31) && d.i_end < (1ull << 31), "desc %zu: too large", i);
+        TH_REQUIRE((d.spec && d.img) || out_h * d.n_frames == 0, "desc %zu: NULL device pointer", i);
+        jobs[i] = ImgJob{d.spec, d.img, (uint32_t)d.n_frames, (uint32_t)d.height, (uint32_t)d.i_start, (uint32_t)d.i_end};
+        start[i] = (uint32_t)tiles;
+        tiles += ((d.n_frames + IMG_TILE - 1) / IMG_TILE) * ((out_h + IMG_TILE - 1) / IMG_TILE);
+        TH_REQUIRE(tiles < (1ull << 31), "batch too large for one launch");
+    }
+    start[n] = (uint32_t)tiles;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    TH_HIP(hipSetDevice(c->device));
+    if (all_neg_inf) {
+        for (size_t i = 0; i < n; i++) {
+            const size_t bytes = (size_t)(descs[i].i_end - descs[i].i_start) * descs[i].n_frames * sizeof(uint16_t);
+            if (bytes) TH_HIP(hipMemsetAsync(descs[i].img, 0, bytes, c->stream));
+        }
+        return TH_OK;
+    }
+    int rc = c->img_jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(ImgJob));
+    if (rc != TH_OK) return rc;
+    rc = c->img_start.upload(c->stream, start.data(), start.size() * sizeof(uint32_t));
+    if (rc != TH_OK) return rc;
+    TH_HIP(launch_spec_to_img((const ImgJob *)c->img_jobs.dptr, (const uint32_t *)c->img_start.dptr, (uint32_t)n,
+                              (uint32_t)tiles, min_dB, max_dB, colormap_len, c->stream));
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_spec_to_img_dev(th_ctx *c, const float *d_spec, size_t n_frames, size_t height, size_t i_start,
+                              size_t i_end, float min_dB, float max_dB, uint32_t colormap_len, uint16_t *d_img) {
+    th_img_desc d{d_spec, d_img, n_frames, height, i_start, i_end};
+    return th_spec_to_img_batch_dev(c, &d, 1, min_dB, max_dB, colormap_len);
+}
+
+// ------------------------------------------------------------------------------------------ raster
+TH_API int th_raster_tiles_dev(th_ctx *c, const th_raster_desc *descs, size_t n, const uint8_t *d_colormap,
+                               uint32_t n_colors) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    if (n == 0) return TH_OK;
+    TH_REQUIRE(descs && d_colormap && n_colors >= 1, "NULL descs/colormap or empty colormap");
+    std::vector<RasterJob> jobs(n);
+    std::vector<uint32_t> start(n + 1);
+    uint64_t blocks = 0;
+    for (size_t i = 0; i < n; i++) {
+        const th_raster_desc &d = descs[i];
+        TH_REQUIRE((uint64_t)d.origin_x + d.width <= d.img_width && (uint64_t)d.origin_y + d.height <= d.img_height,
+                   "desc %zu: tile rectangle outside the image", i);
+        const uint64_t px = (uint64_t)d.width * d.height;
+        TH_REQUIRE(px < (1ull << 31), "desc %zu: tile too large", i);
+        TH_REQUIRE(px == 0 || (d.img && d.rgba), "desc %zu: NULL device pointer", i);
+        jobs[i] = RasterJob{d.img, d.rgba, d.img_width, d.img_height, d.origin_x, d.origin_y, d.width, d.height};
+        start[i] = (uint32_t)blocks;
+        blocks += (px + RASTER_PIXELS_PER_BLOCK - 1) / RASTER_PIXELS_PER_BLOCK;
+        TH_REQUIRE(blocks < (1ull << 31), "batch too large for one launch");
+    }
+    start[n] = (uint32_t)blocks;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    TH_HIP(hipSetDevice(c->device));
+    int rc = c->raster_jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(RasterJob));
+    if (rc != TH_OK) return rc;
+    rc = c->raster_start.upload(c->stream, start.data(), start.size() * sizeof(uint32_t));
+    if (rc != TH_OK) return rc;
+    TH_HIP(launch_raster_level0((const RasterJob *)c->raster_jobs.dptr, (const uint32_t *)c->raster_start.dptr,
+                                (uint32_t)n, (uint32_t)blocks, d_colormap, n_colors, c->stream));
+    return TH_OK;
+    TH_CATCH
+}
+
+static void put_u32(uint8_t *p, uint32_t v) { std::memcpy(p, &v, 4); }  // little-endian host (x86-64)
+static void put_u64(uint8_t *p, uint64_t v) { std::memcpy(p, &v, 8); }
+
+TH_API int th_encode_spectrogram_tile_dev(th_ctx *c, const uint16_t *d_img, size_t img_height, size_t img_width,
+                                          const uint8_t *colormap_rgba, size_t colormap_bytes, uint64_t revision,
+                                          uint32_t level_x, uint32_t level_y, uint32_t tile_x, uint32_t tile_y,
+                                          uint8_t *out, size_t cap, size_t *out_len) {
+    TH_TRY
+    TH_REQUIRE(c && out && out_len, "NULL argument");
+    TH_REQUIRE(colormap_rgba && colormap_bytes >= 4 && colormap_bytes % 4 == 0, "colormap must be a non-empty RGBA8 array");
+    TH_REQUIRE(img_width < (1ull << 31) && img_height < (1ull << 31), "image too large");
+    const TileGeom g = spectrogram_tile_geometry(img_width, img_height, level_x, level_y, tile_x, tile_y);
+    const size_t need = 40 + g.width * g.height * 4;
+    *out_len = need;
+    if (cap < need) return fail(TH_ERR_BUFFER_TOO_SMALL, "need %zu bytes", need);
+    put_u64(out, revision);
+    put_u32(out + 8, (uint32_t)g.width);
+    put_u32(out + 12, (uint32_t)g.height);
+    put_u32(out + 16, level_x);
+    put_u32(out + 20, level_y);
+    put_u32(out + 24, tile_x);
+    put_u32(out + 28, tile_y);
+    put_u32(out + 32, (uint32_t)g.origin_x);
+    put_u32(out + 36, (uint32_t)g.origin_y);
+    if (g.width == 0 || g.height == 0) return TH_OK;
+    TH_REQUIRE(d_img, "d_img is NULL");
+    if (level_x != 0 || level_y != 0)
+        return fail(TH_ERR_UNSUPPORTED, "LOD level (%u,%u): only level (0,0) tiles are implemented on the GPU yet",
+                    level_x, level_y);
+    const uint32_t n_colors = (uint32_t)(colormap_bytes / 4);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);  // tile_out / colormap scratch: whole request
+    TH_HIP(hipSetDevice(c->device));
+    int rc = c->colormap.upload(c->stream, colormap_rgba, colormap_bytes);
+    if (rc != TH_OK) return rc;
+    rc = c->tile_out.ensure(g.width * g.height * 4);
+    if (rc != TH_OK) return rc;
+    th_raster_desc d{d_img, (uint8_t *)c->tile_out.dptr, (uint32_t)img_width, (uint32_t)img_height,
+                     (uint32_t)g.origin_x, (uint32_t)g.origin_y, (uint32_t)g.width, (uint32_t)g.height};
+    rc = th_raster_tiles_dev(c, &d, 1, (const uint8_t *)c->colormap.dptr, n_colors);
+    if (rc != TH_OK) return rc;
+    TH_HIP(hipMemcpyAsync(out + 40, c->tile_out.dptr, g.width * g.height * 4, hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+    TH_CATCH
+}
+
+// ------------------------------------------------------------------------------------------ waveform
+TH_API int th_waveform_tiles_dev(th_ctx *c, const th_wave_desc *descs, size_t n) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    if (n == 0) return TH_OK;
+    TH_REQUIRE(descs, "descs is NULL");
+    std::vector<WaveJob> jobs(n);
+    std::vector<uint32_t> start(n + 1);
+    uint64_t blocks = 0;
+    for (size_t i = 0; i < n; i++) {
+        const th_wave_desc &d = descs[i];
+        TH_REQUIRE(d.bin_count <= TH_WAVEFORM_TILE_BINS, "desc %zu: bin_count > 1024", i);
+        TH_REQUIRE(d.level < 40, "desc %zu: level %u too large", i, d.level);
+        TH_REQUIRE(d.bin_count == 0 || (d.wav && d.bins), "desc %zu: NULL device pointer", i);
+        if (d.bin_count) {
+            const uint64_t spb = 1ull << d.level;
+            TH_REQUIRE(d.start < d.n_samples && d.start + (uint64_t)(d.bin_count - 1) * spb < d.n_samples,
+                       "desc %zu: bins run past the end of the channel", i);
+        }
+        jobs[i] = WaveJob{d.wav, d.bins, d.n_samples, d.start, d.level, d.bin_count};
+        start[i] = (uint32_t)blocks;
+        blocks += waveform_blocks_for(d.level, d.bin_count);
+        TH_REQUIRE(blocks < (1ull << 31), "batch too large for one launch");
+    }
+    start[n] = (uint32_t)blocks;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    TH_HIP(hipSetDevice(c->device));
+    int rc = c->wave_jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(WaveJob));
+    if (rc != TH_OK) return rc;
+    rc = c->wave_start.upload(c->stream, start.data(), start.size() * sizeof(uint32_t));
+    if (rc != TH_OK) return rc;
+    TH_HIP(launch_waveform((const WaveJob *)c->wave_jobs.dptr, (const uint32_t *)c->wave_start.dptr, (uint32_t)n,
+                           (uint32_t)blocks, c->stream));
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_encode_waveform_tile_dev(th_ctx *c, const float *d_wav, size_t n_samples, uint64_t revision,
+                                       uint32_t level, uint32_t tile_index, uint8_t *out, size_t cap,
+                                       size_t *out_len) {
+    TH_TRY
+    TH_REQUIRE(c && out && out_len, "NULL argument");
+    size_t start, bins, spb;
+    waveform_tile_geometry(n_samples, level, tile_index, &start, &bins, &spb);
+    const size_t need = 24 + bins * 12;
+    *out_len = need;
+    if (cap < need) return fail(TH_ERR_BUFFER_TOO_SMALL, "need %zu bytes", need);
+    put_u64(out, revision);
+    put_u32(out + 8, (uint32_t)bins);
+    put_u32(out + 12, spb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)spb);
+    put_u32(out + 16, tile_index);
+    put_u32(out + 20, 0);
+    if (bins == 0) return TH_OK;
+    TH_REQUIRE(d_wav, "d_wav is NULL");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);  // tile_out scratch: whole request
+    TH_HIP(hipSetDevice(c->device));
+    int rc = c->tile_out.ensure(bins * 12);
+    if (rc != TH_OK) return rc;
+    // levels whose bins are longer than the channel all give one bin; keep the shift in range
+    const uint32_t level_eff = level < 39 ? level : 39;
+    th_wave_desc d{d_wav, (float *)c->tile_out.dptr, n_samples, start, level_eff, (uint32_t)bins};
+    rc = th_waveform_tiles_dev(c, &d, 1);
+    if (rc != TH_OK) return rc;
+    TH_HIP(hipMemcpyAsync(out + 24, c->tile_out.dptr, bins * 12, hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+    TH_CATCH
+}

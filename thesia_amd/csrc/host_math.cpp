@@ -1,0 +1,195 @@
+// host_math.cpp — see host_math.h.  Each function cites the reference code it mirrors
+// (paths relative to the reference checkout).
+#include "host_math.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace th {
+
+// SpecSetting::calc_framing_params — src-tauri/src/core/spectrogram.rs:56-98
+void calc_framing_params(double win_ms, uint32_t t_overlap, uint32_t f_overlap, uint32_t sr, size_t *hop,
+                         size_t *win, size_t *n_fft) {
+    const double win_float = win_ms * double(sr) / 1000.;                  // calc_win_length_float
+    const double h = std::round(win_float / double(t_overlap));           // f64::round: half away from 0
+    const size_t hop_length = h > 0. ? size_t(h) : 0;                     // `as usize` saturates
+    const size_t win_length = hop_length * size_t(t_overlap);
+    size_t p = 1;
+    while (p < win_length) p <<= 1;                                       // next_power_of_two
+    *hop = hop_length;
+    *win = win_length;
+    *n_fft = p * size_t(f_overlap);
+}
+
+// Frame count of perform_stft — stft.rs:50-97.  The three-segment construction (front / mid /
+// back) yields exactly the frames of a win/2 reflect-padded signal: T = (N + 2*(win/2) - win)/hop + 1
+// (tests/test_oracle_numpy.py checks this against the literal restatement).
+size_t stft_n_frames(size_t n, size_t win, size_t hop) {
+    if (!n || !win || !hop) return 0;
+    const size_t padded = n + 2 * (win / 2);
+    if (padded < win) return 0;
+    return (padded - win) / hop + 1;
+}
+
+// calc_normalized_win(Hann, size, n_fft) — windows.rs:12-38,68-83, evaluated in f32 in the
+// reference's operation order: x = PI*i/size; (0.5 - 0.5*cos(2x)) + (0*cos(4x) - 0*cos(6x)); / n_fft
+std::vector<float> normalized_hann(size_t win, size_t n_fft) {
+    std::vector<float> w(win);
+    const float pi = 3.14159265358979323846f;
+    const float norm = float(n_fft);
+    for (size_t i = 0; i < win; i++) {
+        const float x = pi * float(i) / float(win);  // size2 - 1 == size for the periodic window
+        const float b_ = 0.5f * std::cos(2.0f * x);
+        const float c_ = 0.0f * std::cos(4.0f * x);
+        const float d_ = 0.0f * std::cos(6.0f * x);
+        w[i] = ((0.5f - b_) + (c_ - d_)) / norm;
+    }
+    return w;
+}
+
+// Slaney mel scale — src-common/src/lib.rs:11-43 (f32 instantiation)
+static const float kMinLogHz = 1000.f;
+static const float kMinLogMel = 15.f;
+static const float kLogStep = float(0.06875177742094912);
+static const float kLinearScale = float(200. / 3.);
+
+float mel_to_hz(float mel) {
+    if (mel < kMinLogMel) return kLinearScale * mel;
+    return kMinLogHz * std::exp(kLogStep * (mel - kMinLogMel));
+}
+float mel_from_hz(float hz) {
+    if (hz < kMinLogHz) return hz / kLinearScale;
+    return kMinLogMel + std::log(hz / kMinLogHz) / kLogStep;
+}
+
+static void linspace(float a, float b, size_t n, float *out) {  // ndarray Array::linspace
+    const float step = n > 1 ? (b - a) / float(n - 1) : 0.f;
+    for (size_t i = 0; i < n; i++) out[i] = a + step * float(i);
+}
+
+// calc_mel_fb::<f32> — src-common/src/lib.rs:46-89; returns (n_fft/2+1) x n_mel, C order
+std::vector<float> calc_mel_fb(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, bool do_norm) {
+    const float f_nyquist = float(double(sr) / 2.);
+    if (fmax < 0.f) fmax = f_nyquist;
+    const size_t n_freq = n_fft / 2 + 1;
+    std::vector<float> lin(n_freq), mf(n_mel + 2), w(n_freq), fb(n_freq * n_mel, 0.f);
+    linspace(0.f, f_nyquist, n_freq, lin.data());
+    linspace(mel_from_hz(fmin), mel_from_hz(fmax), n_mel + 2, mf.data());
+    for (auto &m : mf) m = mel_to_hz(m);
+    for (size_t m = 0; m < n_mel; m++) {
+        std::fill(w.begin(), w.end(), 0.f);
+        for (size_t i = 0; i < n_freq; i++) {
+            const float f = lin[i];
+            if (f <= mf[m]) continue;
+            if (mf[m] < f && f < mf[m + 1]) w[i] = (f - mf[m]) / (mf[m + 1] - mf[m]);
+            else if (f == mf[m + 1]) w[i] = 1.f;
+            else if (mf[m + 1] < f && f < mf[m + 2]) w[i] = (mf[m + 2] - f) / (mf[m + 2] - mf[m + 1]);
+            else break;
+        }
+        if (do_norm) {
+            float s = 0.f;
+            for (size_t i = 0; i < n_freq; i++) s += w[i];
+            const float d = std::max(s, std::numeric_limits<float>::epsilon());
+            for (size_t i = 0; i < n_freq; i++) w[i] /= d;
+        }
+        for (size_t i = 0; i < n_freq; i++) fb[i * n_mel + m] = w[i];  // weights.t()
+    }
+    return fb;
+}
+
+// calc_mel_fb_default's n_mel search — src-common/src/lib.rs:91-103
+size_t mel_default_n_mel(uint32_t sr, size_t n_fft) {
+    const float r = mel_from_hz(float(sr) / 2.f) / mel_from_hz(float(sr) / float(n_fft));
+    const float v = std::fma(r, 2.f, -1.f);
+    size_t n_mel = (v > 0.f) ? size_t(v) : 0;
+    const size_t n_freq = n_fft / 2 + 1;
+    n_mel = std::min(n_mel, n_freq);
+    while (n_mel > 0) {
+        const std::vector<float> fb = calc_mel_fb(sr, n_fft, n_mel, 0.f, -1.f, true);
+        bool ok = true;
+        for (size_t m = 0; m < n_mel && ok; m++) {
+            float s = 0.f;
+            for (size_t i = 0; i < n_freq; i++) s += fb[i * n_mel + m];
+            ok = s > 0.f;
+        }
+        if (ok) break;
+        n_mel--;
+    }
+    return n_mel;
+}
+
+// FreqScale::hz_range_to_idx — src-common/src/lib.rs:134-159
+void hz_range_to_idx(int freq_scale, float hz0, float hz1, uint32_t sr, size_t n, size_t *i0, size_t *i1) {
+    if (hz0 >= hz1) {
+        *i0 = *i1 = 0;
+        return;
+    }
+    const float half_sr = float(sr) / 2.f;
+    const float r0 = freq_scale ? mel_from_hz(hz0) / mel_from_hz(half_sr) : hz0 / half_sr;
+    const float r1 = freq_scale ? mel_from_hz(hz1) / mel_from_hz(half_sr) : hz1 / half_sr;
+    float lo = std::floor(r0 * float(n));
+    if (!(lo > 0.f)) lo = 0.f;
+    const float hi = std::ceil(r1 * float(n));
+    *i0 = size_t(lo);
+    *i1 = hi > 0.f ? size_t(hi) : 0;
+}
+
+static inline float rs_min(float a, float b) { return std::isnan(a) ? b : (std::isnan(b) ? a : (a < b ? a : b)); }
+static inline float rs_max(float a, float b) { return std::isnan(a) ? b : (std::isnan(b) ? a : (a > b ? a : b)); }
+
+// TrackManager::update_spec_imgs range clamp — core/mod.rs:169-180
+void global_db_range(const float *mins, const float *maxs, size_t n, float dB_range, float *mn, float *mx) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (size_t i = 0; i < n; i++) {
+        lo = rs_min(lo, mins[i]);
+        hi = rs_max(hi, maxs[i]);
+    }
+    hi = rs_min(hi, 0.f);
+    lo = rs_max(lo, hi - dB_range);
+    *mn = lo;
+    *mx = hi;
+}
+
+static inline size_t sat_mul(size_t a, size_t b) {
+    size_t r;
+    return __builtin_mul_overflow(a, b, &r) ? SIZE_MAX : r;
+}
+static inline size_t sat_add(size_t a, size_t b) {
+    size_t r;
+    return __builtin_add_overflow(a, b, &r) ? SIZE_MAX : r;
+}
+static inline size_t shl_or_max(uint32_t level) { return level < 64 ? (size_t(1) << level) : SIZE_MAX; }
+static inline size_t div_ceil(size_t a, size_t b) { return a / b + (a % b != 0); }
+
+// encode_spectrogram_tile geometry — render_tiles.rs:290-313
+TileGeom spectrogram_tile_geometry(size_t W, size_t Hh, uint32_t lx, uint32_t ly, uint32_t tx, uint32_t ty) {
+    const size_t T = 512, G = 4;
+    TileGeom g{};
+    g.lod_w = div_ceil(W, shl_or_max(lx));
+    g.lod_h = div_ceil(Hh, shl_or_max(ly));
+    const size_t sx = sat_mul(tx, T), sy = sat_mul(ty, T);
+    const size_t cw = std::min(g.lod_w > sx ? g.lod_w - sx : 0, T);
+    const size_t ch = std::min(g.lod_h > sy ? g.lod_h - sy : 0, T);
+    g.origin_x = sx > G ? sx - G : 0;
+    g.origin_y = sy > G ? sy - G : 0;
+    if (cw && ch) {
+        const size_t rx = std::min(g.lod_w, sx + cw + G), ry = std::min(g.lod_h, sy + ch + G);
+        g.width = rx > g.origin_x ? rx - g.origin_x : 0;
+        g.height = ry > g.origin_y ? ry - g.origin_y : 0;
+    }
+    return g;
+}
+
+// encode_waveform_tile geometry — render_tiles.rs:233-241
+void waveform_tile_geometry(size_t n, uint32_t level, uint32_t tile, size_t *start, size_t *bins, size_t *spb) {
+    const size_t s = shl_or_max(level);
+    const size_t tile_samples = sat_mul(1024, s);
+    const size_t st = sat_mul(size_t(tile), tile_samples);
+    const size_t en = std::min(n, sat_add(st, tile_samples));
+    *start = st;
+    *spb = s;
+    *bins = st >= en ? 0 : div_ceil(en - st, s);
+}
+
+}  // namespace th

@@ -1,0 +1,35 @@
+// host_math.h — plan-preparation arithmetic done once on the host, exactly as the reference's
+// SpectrogramAnalyzer::prepare does (spectrogram.rs:116-154): window and mel filterbank tables,
+// framing parameters, tile geometry.  These are tables/shape decisions, not the hot path.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace th {
+
+void calc_framing_params(double win_ms, uint32_t t_overlap, uint32_t f_overlap, uint32_t sr, size_t *hop,
+                         size_t *win, size_t *n_fft);
+size_t stft_n_frames(size_t n, size_t win, size_t hop);
+std::vector<float> normalized_hann(size_t win, size_t n_fft);
+float mel_from_hz(float hz);
+float mel_to_hz(float mel);
+std::vector<float> calc_mel_fb(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, bool do_norm);
+size_t mel_default_n_mel(uint32_t sr, size_t n_fft);
+void hz_range_to_idx(int freq_scale, float hz0, float hz1, uint32_t sr, size_t n, size_t *i0, size_t *i1);
+void global_db_range(const float *mins, const float *maxs, size_t n, float dB_range, float *mn, float *mx);
+
+struct TileGeom {
+    size_t width, height, origin_x, origin_y, lod_w, lod_h;
+};
+TileGeom spectrogram_tile_geometry(size_t W, size_t Hh, uint32_t lx, uint32_t ly, uint32_t tx, uint32_t ty);
+void waveform_tile_geometry(size_t n, uint32_t level, uint32_t tile, size_t *start, size_t *bins, size_t *spb);
+
+inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+inline unsigned ilog2(size_t n) {
+    unsigned l = 0;
+    while ((size_t(1) << (l + 1)) <= n) l++;
+    return l;
+}
+
+}  // namespace th

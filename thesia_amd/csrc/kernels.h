@@ -1,0 +1,52 @@
+// kernels.h — launcher declarations (implemented in kernels_*.hip).  All launchers are
+// stream-ordered, never synchronise, and return the launch status.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/thesia_amd.h"
+#include "stft_core.h"
+
+namespace th {
+
+// ---- kernels_stft.hip
+hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, hipStream_t s);
+size_t stft_generic_lds_bytes(const StftGeom &g);
+hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
+                               uint32_t n_chan, uint32_t n_tiles, const float *d_window, const cf32 *d_tw,
+                               const float *d_mel_fb, const uint32_t *d_mel_lo, const uint32_t *d_mel_hi,
+                               float *d_minmax, hipStream_t s);
+
+// ---- kernels_image.hip
+struct ImgJob {  // device-visible copy of th_img_desc
+    const float *spec;
+    uint16_t *img;
+    uint32_t n_frames, height, i_start, i_end;
+};
+hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs,
+                              uint32_t n_tiles, float min_dB, float max_dB, uint32_t colormap_len, hipStream_t s);
+
+struct RasterJob {  // device-visible copy of th_raster_desc
+    const uint16_t *img;
+    uint8_t *rgba;
+    uint32_t img_width, img_height, origin_x, origin_y, width, height;
+};
+hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block_start, uint32_t n_jobs,
+                                uint32_t n_blocks, const uint8_t *d_colormap, uint32_t n_colors, hipStream_t s);
+constexpr uint32_t RASTER_PIXELS_PER_BLOCK = 1024;
+constexpr uint32_t IMG_TILE = 64;
+
+// ---- kernels_waveform.hip
+struct WaveJob {  // device-visible copy of th_wave_desc
+    const float *wav;
+    float *bins;
+    uint64_t n_samples, start;
+    uint32_t level, bin_count;
+};
+hipError_t launch_waveform(const WaveJob *d_jobs, const uint32_t *d_block_start, uint32_t n_jobs,
+                           uint32_t n_blocks, hipStream_t s);
+uint32_t waveform_blocks_for(uint32_t level, uint32_t bin_count);
+
+}  // namespace th

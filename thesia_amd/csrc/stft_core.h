@@ -1,0 +1,179 @@
+// stft_core.h — per-lane building blocks of the fused STFT → |X| → dB kernels.
+//
+// Everything here is written as small "phase" functions over (lane/thread id, registers, LDS
+// pointer) so that the very same code is compiled (a) by hipcc into the gfx950 kernels in
+// kernels_stft.hip and (b) by g++ into tests/emu/, which walks the lanes sequentially on the CPU
+// to check index arithmetic without a GPU.  (b) is test scaffolding only — the product never runs
+// it.
+//
+// Reference semantics implemented (paths relative to the reference checkout):
+//   framing / reflect padding      src-tauri/src/core/spectrogram/stft.rs:16-149, core/utils.rs:111-138
+//   window multiply + zero padding stft.rs:35-39,137-146
+//   forward real FFT (realfft R2C) stft.rs:44-48  (restated: N/2-point complex FFT + split pass)
+//   |X| = Complex::norm            spectrogram.rs:200
+//   20*log10, 0 -> -inf            dynamics/decibel.rs:170-214
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TH_HD __host__ __device__ __forceinline__
+#else
+#define TH_HD inline
+#endif
+
+namespace th {
+
+struct __attribute__((aligned(8))) cf32 {
+    float re, im;
+};
+
+TH_HD cf32 cadd(cf32 a, cf32 b) { return {a.re + b.re, a.im + b.im}; }
+TH_HD cf32 csub(cf32 a, cf32 b) { return {a.re - b.re, a.im - b.im}; }
+TH_HD cf32 cmul(cf32 a, cf32 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+TH_HD cf32 cmul_negi(cf32 a) { return {a.im, -a.re}; }  // a * (-i)
+TH_HD cf32 cconj(cf32 a) { return {a.re, -a.im}; }
+
+// Shapes shared by every STFT kernel (passed by value).
+struct StftGeom {
+    uint32_t hop, win, n_fft;
+    uint32_t pad_left;   // (n_fft - win) / 2               stft.rs:36
+    uint32_t nc;         // n_fft / 2  complex points of the packed FFT
+    uint32_t log2_nc;
+    uint32_t n_freq;     // n_fft / 2 + 1
+    uint32_t height;     // columns of the output spec: n_freq (linear) or n_mel
+    uint32_t n_mel;      // 0 = linear
+    uint32_t frames_per_tile;
+};
+
+// One channel of the batch (device pointers).
+struct ChanJob {
+    const float *wav;
+    float *spec;
+    uint32_t n_samples;
+    uint32_t n_frames;
+};
+
+// numpy-'reflect' index with periodic cycling for pads longer than N-1 (utils.rs:111-138;
+// SURVEY.md Appendix A2).  n == 1 replicates the sample (the reference leaves that pad
+// uninitialised, utils.rs:91,140).
+TH_HD uint32_t reflect_index(int64_t i, uint32_t n) {
+    if (i >= 0 && i < (int64_t)n) return (uint32_t)i;
+    if (n == 1) return 0;
+    const int64_t P = 2 * ((int64_t)n - 1);
+    int64_t j = i % P;
+    if (j < 0) j += P;
+    return (uint32_t)(j < (int64_t)n ? j : P - j);
+}
+
+// Sample `i` (0 <= i < n_fft) of the zero-padded, windowed frame starting at signal position s0
+// (= k*hop - win/2).  stft.rs:137-146
+TH_HD float frame_value(const float *wav, uint32_t n_samples, int64_t s0, uint32_t i, const float *window,
+                        const StftGeom &g) {
+    if (i < g.pad_left || i >= g.pad_left + g.win) return 0.0f;
+    const uint32_t wi = i - g.pad_left;
+    return wav[reflect_index(s0 + (int64_t)wi, n_samples)] * window[wi];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Radix butterflies, forward transform (e^{-i...}), in registers.
+// ---------------------------------------------------------------------------------------------
+TH_HD void fft2(cf32 &a, cf32 &b) {
+    const cf32 t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+
+TH_HD void fft4(cf32 &a0, cf32 &a1, cf32 &a2, cf32 &a3) {
+    const cf32 b0 = cadd(a0, a2), b1 = csub(a0, a2), b2 = cadd(a1, a3), b3 = cmul_negi(csub(a1, a3));
+    a0 = cadd(b0, b2);
+    a1 = cadd(b1, b3);
+    a2 = csub(b0, b2);
+    a3 = csub(b1, b3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic workgroup kernel phases (any power-of-two n_fft; one frame at a time in LDS).
+// Stockham autosort, decimation in time: pass with sub-transform size Ns and radix R maps
+//   v_r = in[j + r*Nc/R] * W_{Ns*R}^{r*k},  k = j mod Ns;  out[(j-k)*R + k + r*Ns] = DFT_R(v)_r
+// tw[i] = exp(-2*pi*i * i / n_fft), i in [0, n_fft).
+// ---------------------------------------------------------------------------------------------
+TH_HD void gen_load(uint32_t tid, uint32_t nthr, const StftGeom &g, const float *wav, uint32_t n_samples,
+                    int64_t s0, const float *window, cf32 *buf) {
+    for (uint32_t n = tid; n < g.nc; n += nthr) {
+        cf32 z;
+        z.re = frame_value(wav, n_samples, s0, 2 * n, window, g);
+        z.im = frame_value(wav, n_samples, s0, 2 * n + 1, window, g);
+        buf[n] = z;
+    }
+}
+
+TH_HD void gen_pass_r4(uint32_t tid, uint32_t nthr, const StftGeom &g, uint32_t Ns, const cf32 *tw,
+                       const cf32 *in, cf32 *out) {
+    const uint32_t q = g.nc >> 2;
+    const uint32_t tw_step = g.n_fft / (Ns * 4);  // W_{Ns*4}^m = tw[m * tw_step]
+    for (uint32_t j = tid; j < q; j += nthr) {
+        const uint32_t k = j & (Ns - 1);
+        cf32 v0 = in[j], v1 = in[j + q], v2 = in[j + 2 * q], v3 = in[j + 3 * q];
+        if (Ns > 1) {
+            v1 = cmul(v1, tw[k * tw_step]);
+            v2 = cmul(v2, tw[2 * k * tw_step]);
+            v3 = cmul(v3, tw[3 * k * tw_step]);
+        }
+        fft4(v0, v1, v2, v3);
+        const uint32_t j0 = (j - k) * 4 + k;
+        out[j0] = v0;
+        out[j0 + Ns] = v1;
+        out[j0 + 2 * Ns] = v2;
+        out[j0 + 3 * Ns] = v3;
+    }
+}
+
+TH_HD void gen_pass_r2(uint32_t tid, uint32_t nthr, const StftGeom &g, uint32_t Ns, const cf32 *tw,
+                       const cf32 *in, cf32 *out) {
+    const uint32_t h = g.nc >> 1;
+    const uint32_t tw_step = g.n_fft / (Ns * 2);
+    for (uint32_t j = tid; j < h; j += nthr) {
+        const uint32_t k = j & (Ns - 1);
+        cf32 v0 = in[j], v1 = in[j + h];
+        if (Ns > 1) v1 = cmul(v1, tw[k * tw_step]);
+        fft2(v0, v1);
+        const uint32_t j0 = (j - k) * 2 + k;
+        out[j0] = v0;
+        out[j0 + Ns] = v1;
+    }
+}
+
+// Split pass of the packed real FFT: from Z (Nc-point FFT of x[2n] + i*x[2n+1]) to the magnitudes
+// of X[k] and X[Nc-k]:  E = (Z[k] + conj Z[Nc-k])/2, O = -i (Z[k] - conj Z[Nc-k])/2,
+// T = W_{n_fft}^k O;  X[k] = E + T,  X[Nc-k] = conj(E - T).
+TH_HD void split_pair(cf32 zk, cf32 zm, cf32 w, float &mag_k, float &mag_m) {
+    const cf32 e = {0.5f * (zk.re + zm.re), 0.5f * (zk.im - zm.im)};
+    const cf32 d = {0.5f * (zk.re - zm.re), 0.5f * (zk.im + zm.im)};
+    const cf32 o = cmul_negi(d);
+    const cf32 t = cmul(o, w);
+    const cf32 xk = cadd(e, t), xm = csub(e, t);
+    mag_k = __builtin_sqrtf(xk.re * xk.re + xk.im * xk.im);  // correctly rounded (no fast-math)
+    mag_m = __builtin_sqrtf(xm.re * xm.re + xm.im * xm.im);
+}
+
+// dB_from_amp_inplace_default for one element — decibel.rs:179-202 (amin = 0, ref = 1):
+// NaN or sign-negative -> NaN; x > 0 -> log10(x); +0 -> log10(0) - 0 = -inf; then * 20.
+TH_HD float amp_to_dB(float x) {
+    if (__builtin_isnan(x) || __builtin_signbit(x)) return __builtin_nanf("");
+    return 20.0f * __builtin_log10f(x);
+}
+
+// Magnitudes of all n_freq bins of the frame whose packed FFT is in `z` (natural order) → mag[].
+TH_HD void gen_split(uint32_t tid, uint32_t nthr, const StftGeom &g, const cf32 *tw, const cf32 *z, float *mag) {
+    const uint32_t half = g.nc >> 1;
+    for (uint32_t k = tid; k <= half; k += nthr) {
+        const cf32 zk = z[k];
+        const cf32 zm = z[(g.nc - k) & (g.nc - 1)];
+        float mk, mm;
+        split_pair(zk, zm, tw[k], mk, mm);
+        mag[k] = mk;
+        mag[g.nc - k] = mm;  // k = 0 writes mag[nc] (Nyquist); k = nc/2 writes the same bin twice
+    }
+}
+
+}  // namespace th
