@@ -222,8 +222,10 @@ def main():
     n = int(round(args.seconds * sr))
     cmap_bytes = open(os.path.join(ROOT, "tests", "golden", "colormap_inferno_rgba258.bin"), "rb").read()
 
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ctx = ta.Context(local_rank, stream)
+    # one side stream shared by torch (plumbing ops, events, RCCL) and the library's kernels
+    side = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(side)
+    ctx = ta.Context(local_rank, side.cuda_stream)
     wl = Workload(torch, ta, ctx, dev, rank * args.tracks_per_gpu, args.tracks_per_gpu, sr, n, win, hop, n_fft,
                   args.kernel, cmap_bytes)
 

@@ -116,6 +116,9 @@ TH_API int th_waveform_tile_geometry(size_t n_samples, uint32_t level, uint32_t 
 /* ---------------------------------------------------------------- device context */
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to create one. */
 TH_API int th_ctx_create(int device, void *hip_stream, th_ctx **out);
+/* use_given_stream != 0: run on `hip_stream` exactly as given, NULL meaning the legacy default stream
+ * (what torch.cuda.current_stream() is unless a side stream is active); 0: same as th_ctx_create. */
+TH_API int th_ctx_create_ex(int device, void *hip_stream, int use_given_stream, th_ctx **out);
 TH_API int th_ctx_destroy(th_ctx *ctx);
 TH_API int th_ctx_synchronize(th_ctx *ctx);
 /* device memory helpers for callers without their own allocator (tests, C hosts) */

@@ -6,7 +6,9 @@ this module fails loudly when it is missing: there is no CPU fallback of any kin
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libthesia_amd.so")
@@ -17,6 +19,27 @@ if not os.path.exists(LIB_PATH):
         "(python -c 'import __graft_entry__ as g; g.build()').  thesia_amd has no CPU fallback."
     )
 
+
+
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  libthesia_amd.so needs `libamdhip64.so.7` by soname; PyTorch
+    wheels bundle their own copy under torch/lib with that same soname.  If torch is (or may later
+    be) in the process, load torch's copy first so the dynamic loader resolves our NEEDED entry to
+    it instead of mapping /opt/rocm's as a second runtime (two runtimes = "no device" in the second).
+    THESIA_AMD_SYSTEM_HIP=1 keeps the system runtime (pure C hosts, no torch)."""
+    if "torch" in sys.modules or os.environ.get("THESIA_AMD_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+_preload_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 c_f32p = C.POINTER(C.c_float)
@@ -76,6 +99,7 @@ _SIGS = {
                                      C.POINTER(TileGeom)],
     "th_waveform_tile_geometry": [C.c_size_t, C.c_uint32, C.c_uint32, c_szp, c_szp, c_szp],
     "th_ctx_create": [C.c_int, vp, C.POINTER(vp)],
+    "th_ctx_create_ex": [C.c_int, vp, C.c_int, C.POINTER(vp)],
     "th_ctx_destroy": [vp],
     "th_ctx_synchronize": [vp],
     "th_dev_alloc": [vp, C.c_size_t, C.POINTER(vp)],

@@ -130,11 +130,15 @@ class DeviceBuffer:
 
 
 class Context:
-    """th_ctx: one GPU + one HIP stream.  `stream` may be a raw hipStream_t (e.g. torch's)."""
+    """th_ctx: one GPU + one HIP stream.  `stream=None` creates a private stream; an int is used as
+    the raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; 0 = legacy default stream)."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         h = vp()
-        check(lib.th_ctx_create(device, vp(stream) if stream else None, C.byref(h)))
+        if stream is None:
+            check(lib.th_ctx_create(device, None, C.byref(h)))
+        else:
+            check(lib.th_ctx_create_ex(device, vp(stream), 1, C.byref(h)))
         self.handle = h
         self.device = device
 

@@ -134,6 +134,10 @@ TH_API int th_waveform_tile_geometry(size_t n_samples, uint32_t level, uint32_t 
 
 // ------------------------------------------------------------------------------------------ context
 TH_API int th_ctx_create(int device, void *hip_stream, th_ctx **out) {
+    return th_ctx_create_ex(device, hip_stream, hip_stream != nullptr, out);
+}
+
+TH_API int th_ctx_create_ex(int device, void *hip_stream, int use_given_stream, th_ctx **out) {
     TH_TRY
     TH_REQUIRE(out, "out is NULL");
     *out = nullptr;
@@ -144,8 +148,8 @@ TH_API int th_ctx_create(int device, void *hip_stream, th_ctx **out) {
     TH_HIP(hipSetDevice(device));
     th_ctx *c = new th_ctx();
     c->device = device;
-    if (hip_stream) {
-        c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (use_given_stream) {
+        c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = legacy default stream
         c->own_stream = false;
     } else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -7,6 +7,13 @@
 
 #include "kernels.h"
 
+// Integer / rounding stages must round once per operation exactly like the reference's scalar f32
+// code: no FMA contraction anywhere in this file (hipcc defaults to -ffp-contract=fast; the
+// __fmul_rn/__fadd_rn header helpers are plain operators compiled under that default, so they
+// still fuse after inlining — use plain operators below this pragma instead; the build also
+// passes -ffp-contract=off for this file).
+#pragma clang fp contract(off)
+
 namespace th {
 
 __device__ __forceinline__ uint32_t find_job(const uint32_t *__restrict__ start, uint32_t n, uint32_t b) {
@@ -23,8 +30,8 @@ __device__ __forceinline__ uint32_t find_job(const uint32_t *__restrict__ start,
 //   zero_to_one = (dB - min) / span;  u = zero_to_one * u16_span + min_value;
 //   u.round().clamp(0, 65535) as u16   (NaN -> 0)
 __device__ __forceinline__ uint16_t quantise(float dB, float min_dB, float span, float u16_span, float min_value) {
-    const float z = __fdiv_rn(__fsub_rn(dB, min_dB), span);
-    const float u = __fadd_rn(__fmul_rn(z, u16_span), min_value);
+    const float z = (dB - min_dB) / span;          // plain operators: contraction is off in this file
+    const float u = z * u16_span + min_value;
     const float r = roundf(u);  // half away from zero, like f32::round
     if (__builtin_isnan(r)) return 0;
     return (uint16_t)fminf(fmaxf(r, 0.0f), 65535.0f);

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
             for (uint32_t m = tid; m < g.n_mel; m += GEN_THREADS) {
                 float acc = 0.0f;
                 const uint32_t lo = mel_lo[m], hi = mel_hi[m];
-                for (uint32_t k = lo; k < hi; k++) acc = __fadd_rn(acc, __fmul_rn(mag[k], mel_fb[(size_t)k * g.n_mel + m]));
+                for (uint32_t k = lo; k < hi; k++) acc += mag[k] * mel_fb[(size_t)k * g.n_mel + m];
                 const float d = amp_to_dB(acc);
                 row[m] = d;
                 lmin = nmin(lmin, d);

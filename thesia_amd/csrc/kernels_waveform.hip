@@ -10,6 +10,10 @@
 
 #include "kernels.h"
 
+// Integer / rounding stages must round once per operation exactly like the reference's scalar f32
+// code: no FMA contraction anywhere in this file (the build also passes -ffp-contract=off).
+#pragma clang fp contract(off)
+
 namespace th {
 
 __device__ __forceinline__ uint32_t find_wjob(const uint32_t *__restrict__ start, uint32_t n, uint32_t b) {
@@ -49,12 +53,12 @@ __global__ __launch_bounds__(256) void waveform_kernel(const WaveJob *__restrict
             const float v = job.wav[i];
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
-            sum = __fadd_rn(sum, v);
+            sum = sum + v;
         }
         float *o = job.bins + 3ull * b;
         o[0] = mn;
         o[1] = mx;
-        o[2] = __fdiv_rn(sum, (float)(e - s));
+        o[2] = sum / (float)(e - s);
         return;
     }
 
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void waveform_kernel(const WaveJob *__restrict
         float *o = job.bins + 3ull * b;
         o[0] = mn;
         o[1] = mx;
-        o[2] = __fdiv_rn(sum, (float)(e - s));
+        o[2] = sum / (float)(e - s);
     }
 }
 
