@@ -1,0 +1,82 @@
+// emu_stft.cpp — CPU lane emulator of the wave STFT kernel (TEST SCAFFOLDING, never shipped):
+// compiles thesia_amd/csrc/stft_wave.h with g++ and walks the 64 lanes sequentially through the
+// same phase functions the gfx950 kernel runs, so the index arithmetic (Stockham passes, LDS
+// swizzle, mirror exchange, split pass) can be checked against the oracle without a GPU.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../thesia_amd/csrc/stft_wave.h"
+
+using namespace th;
+
+template <int LOG2_NC, bool PADDED>
+static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, const StftGeom &g, const cf32 *wtab,
+                      const cf32 *tw, float *row) {
+    using W = WaveFft<LOG2_NC>;
+    constexpr int P = W::P, NC = W::NC;
+    std::vector<cf32> slab(NC);
+    static cf32 x[64][P], z[64][P], zm[64][P];
+    std::vector<cf32> t2(W::T2_LEN), t3(W::T3_LEN);
+    const int64_t e0 = (int64_t)frame * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+    for (uint32_t t = 0; t < 256; t++) W::fill_tables(t, 256, tw, t2.data(), t3.data());
+    for (uint32_t l = 0; l < 64; l++) wave_fetch<P, PADDED>(l, x[l], wav, e0, g);
+    for (uint32_t l = 0; l < 64; l++) wave_window<P>(l, z[l], x[l], wtab);
+    for (uint32_t l = 0; l < 64; l++) W::pass1(l, z[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++) W::read1(l, z[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++) W::pass2(l, z[l], t2.data(), slab.data());
+    for (uint32_t l = 0; l < 64; l++) W::read2(l, z[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++) W::pass3(l, z[l], t3.data());
+    for (uint32_t l = 0; l < 64; l++) W::write_z(l, z[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++) W::read_mirror(l, zm[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++)
+        for (int m = 0; m < P; m++) {
+            const uint32_t k = l + 64u * m;
+            row[k] = power_to_dB(split_power(z[l][m], zm[l][m], tw[k]));
+        }
+    const cf32 wn = {-1.0f, 0.0f};
+    row[NC] = power_to_dB(split_power(z[0][0], z[0][0], wn));
+}
+
+// out: n_frames x (n_fft/2+1).  window: normalised window (len win).  Returns 0 on success.
+extern "C" __attribute__((visibility("default"))) int emu_stft_wave(const float *wav, uint32_t n_samples,
+                                                                     uint32_t win, uint32_t hop, uint32_t n_fft,
+                                                                     const float *window, uint32_t n_frames,
+                                                                     float *out) {
+    StftGeom g{};
+    g.hop = hop;
+    g.win = win;
+    g.n_fft = n_fft;
+    g.pad_left = (n_fft - win) / 2;
+    g.nc = n_fft / 2;
+    g.n_freq = n_fft / 2 + 1;
+    g.height = g.n_freq;
+    std::vector<cf32> tw(n_fft), wtab(g.nc);
+    for (uint32_t i = 0; i < n_fft; i++) {
+        const double a = -2.0 * M_PI * (double)i / (double)n_fft;
+        tw[i] = {(float)std::cos(a), (float)std::sin(a)};
+    }
+    std::vector<float> wpad(n_fft, 0.0f);
+    for (uint32_t i = 0; i < win; i++) wpad[g.pad_left + i] = 0.5f * window[i];
+    for (uint32_t n = 0; n < g.nc; n++) wtab[n] = {wpad[2 * n], wpad[2 * n + 1]};
+    const bool padded = win != n_fft;
+    for (uint32_t f = 0; f < n_frames; f++) {
+        float *row = out + (size_t)f * g.n_freq;
+        const int64_t s0 = (int64_t)f * hop - (int64_t)(win / 2);
+        if (s0 < 0 || s0 + (int64_t)win > (int64_t)n_samples) {  // boundary frame: not the wave kernel's job
+            for (uint32_t k = 0; k < g.n_freq; k++) row[k] = NAN;
+            continue;
+        }
+        switch (n_fft) {
+            case 1024: padded ? emu_frame<9, true>(wav, n_samples, f, g, wtab.data(), tw.data(), row)
+                              : emu_frame<9, false>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
+            case 2048: padded ? emu_frame<10, true>(wav, n_samples, f, g, wtab.data(), tw.data(), row)
+                              : emu_frame<10, false>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
+            case 4096: padded ? emu_frame<11, true>(wav, n_samples, f, g, wtab.data(), tw.data(), row)
+                              : emu_frame<11, false>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}

@@ -85,6 +85,28 @@ def test_calc_spec_linear_parity(ctx, win, hop, n_fft):
     plan.close()
 
 
+@pytest.mark.parametrize("win,hop,n_fft", [(1024, 256, 1024), (1000, 250, 1024), (2048, 512, 2048), (1920, 480, 2048),
+                                           (1764, 441, 2048), (2047, 2047, 2048), (4096, 1024, 4096),
+                                           (3001, 3001, 4096), (2048, 128, 2048)])
+def test_wave_and_generic_kernels(ctx, win, hop, n_fft):
+    """Both STFT kernels against the oracle on the same input; the wave kernel takes the interior
+    frames, the generic kernel the reflect-padded boundary frames of the same launch."""
+    n = 40000 + win
+    x = synth_track(n_fft + hop, 48000, n)
+    want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+    for which, name in ((1, "stft_generic_kernel"), (2, "stft_wave_kernel")):
+        plan = ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR)
+        plan.set_kernel(which)
+        assert plan.kernel_name == name
+        spec, mn, mx = plan.calc_spec(x)
+        assert_spec_close(spec, want, amp)
+        assert mn == spec.min() and mx == spec.max()
+        plan.close()
+    plan = ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR)
+    assert plan.kernel_name == "stft_wave_kernel"  # auto picks the fast path for these sizes
+    plan.close()
+
+
 @pytest.mark.parametrize("n", [2, 3, 5, 100, 511, 1023, 1024, 1025, 2047])
 def test_calc_spec_short_inputs(ctx, n):
     """N < win (stft.rs:50-76): reflect padding cycles; frame count follows the same formula."""

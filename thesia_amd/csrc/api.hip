@@ -148,6 +148,11 @@ TH_API int th_ctx_create_ex(int device, void *hip_stream, int use_given_stream, 
     TH_HIP(hipSetDevice(device));
     th_ctx *c = new th_ctx();
     c->device = device;
+    {
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0)
+            c->n_cu = (uint32_t)n_cu;
+    }
     if (use_given_stream) {
         c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = legacy default stream
         c->own_stream = false;
@@ -285,8 +290,14 @@ void DeviceTable::release() {
 
 }  // namespace th
 
+bool th_plan::use_wave() const {
+    if (kernel_choice == 1) return false;
+    return th::stft_wave_supported(g);
+}
+
 static void plan_free(th_plan *p) {
     if (!p) return;
+    if (p->d_wtab) (void)hipFree(p->d_wtab);
     if (p->d_window) (void)hipFree(p->d_window);
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_mel_fb) (void)hipFree(p->d_mel_fb);
@@ -294,6 +305,8 @@ static void plan_free(th_plan *p) {
     if (p->d_mel_hi) (void)hipFree(p->d_mel_hi);
     p->jobs.release();
     p->tile_start.release();
+    p->edge_jobs.release();
+    p->edge_tile_start.release();
     delete p;
 }
 
@@ -324,7 +337,7 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
     g.n_freq = (uint32_t)(n_fft / 2 + 1);
     g.n_mel = 0;
     g.height = g.n_freq;
-    g.frames_per_tile = 8;
+    g.frames_per_tile = 8;  // generic kernel; the wave kernel's tile is set at launch
 
     // window (windows.rs) and twiddles W_{n_fft}^i (double → f32)
     const std::vector<float> w = normalized_hann(win, n_fft);
@@ -340,7 +353,14 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
         TH_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
         return TH_OK;
     };
-    rc = up((void **)&p->d_window, w.data(), w.size() * sizeof(float));
+    {
+        // wave-kernel window table: wtab[n] = 0.5 * (wpad[2n], wpad[2n+1]), wpad = zero-padded window
+        // (the 1/2 of the real-FFT split pass is folded in here; exact, a power of two)
+        std::vector<float> wpad(n_fft, 0.f);
+        for (size_t i = 0; i < win; i++) wpad[g.pad_left + i] = 0.5f * w[i];
+        rc = up((void **)&p->d_wtab, wpad.data(), wpad.size() * sizeof(float));
+    }
+    if (rc == TH_OK) rc = up((void **)&p->d_window, w.data(), w.size() * sizeof(float));
     if (rc == TH_OK) rc = up((void **)&p->d_tw, tw.data(), tw.size() * sizeof(cf32));
     if (rc == TH_OK && freq_scale == TH_FREQ_MEL) {
         if (n_mel == 0) n_mel = mel_default_n_mel(sr, n_fft);  // calc_mel_fb_default, lib.rs:91-103
@@ -405,7 +425,7 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
 
 TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (!p) return "";
-    return "stft_generic_kernel";
+    return p->use_wave() ? "stft_wave_kernel" : "stft_generic_kernel";
 }
 
 // ------------------------------------------------------------------------------------------ calc_spec
@@ -416,35 +436,74 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     TH_REQUIRE(chans, "chans is NULL");
     TH_REQUIRE(n_chan < (1u << 24), "too many channels");
     th_ctx *c = p->ctx;
-    const StftGeom &g = p->g;
-    std::vector<ChanJob> jobs(n_chan);
-    std::vector<uint32_t> tile_start(n_chan + 1);
-    uint64_t tiles = 0;
+    const bool wave = p->use_wave();
+    if (p->kernel_choice == 2 && !wave)
+        return fail(TH_ERR_UNSUPPORTED, "the wave kernel covers linear scale, n_fft in {1024, 2048, 4096}");
+    StftGeom g = p->g;       // main launch
+    StftGeom ge = p->g;      // edge launch (generic kernel)
+    g.frames_per_tile = wave ? stft_wave_frames_per_tile(g) : 8;
+    ge.frames_per_tile = 1;
+    // main jobs: the wave kernel takes the interior frames [fa, fb) of every channel (all windowed
+    // samples inside the signal); the generic kernel takes the boundary frames (reflect padding,
+    // stft.rs:50-95) — or every frame when the wave kernel does not cover this plan.
+    std::vector<ChanJob> jobs, edge;
+    std::vector<uint32_t> tile_start, edge_start;
+    uint64_t tiles = 0, edge_tiles = 0;
+    auto add = [](std::vector<ChanJob> &v, std::vector<uint32_t> &st, uint64_t &n_tiles, const StftGeom &gg,
+                  const th_chan_desc &d, uint32_t T, uint32_t fb0, uint32_t fe0, uint32_t slot) {
+        if (fb0 >= fe0) return;
+        v.push_back(ChanJob{d.wav, d.spec, (uint32_t)d.n_samples, T, fb0, fe0, slot, 0});
+        st.push_back((uint32_t)n_tiles);
+        n_tiles += (fe0 - fb0 + gg.frames_per_tile - 1) / gg.frames_per_tile;
+    };
     for (size_t i = 0; i < n_chan; i++) {
         const th_chan_desc &d = chans[i];
         TH_REQUIRE(d.wav && d.spec, "channel %zu: NULL device pointer", i);
-        TH_REQUIRE(d.n_samples >= 1 && d.n_samples < (1ull << 31), "channel %zu: n_samples=%llu out of range", i,
-                   (unsigned long long)d.n_samples);
+        TH_REQUIRE(d.n_samples >= 1 && d.n_samples < (1ull << 31) - 2 * g.n_fft, "channel %zu: n_samples=%llu out of range",
+                   i, (unsigned long long)d.n_samples);
         const size_t T = stft_n_frames(d.n_samples, g.win, g.hop);
         TH_REQUIRE(d.n_frames == T, "channel %zu: n_frames=%llu but the framing gives %zu", i,
                    (unsigned long long)d.n_frames, T);
-        jobs[i] = ChanJob{d.wav, d.spec, (uint32_t)d.n_samples, (uint32_t)T};
-        tile_start[i] = (uint32_t)tiles;
-        tiles += (T + g.frames_per_tile - 1) / g.frames_per_tile;
-        TH_REQUIRE(tiles < (1ull << 31), "batch too large for one launch");
+        if (!wave) {
+            add(jobs, tile_start, tiles, g, d, (uint32_t)T, 0, (uint32_t)T, (uint32_t)i);
+        } else {
+            const uint64_t half = g.win / 2, N = d.n_samples;
+            uint64_t fa = (half + g.hop - 1) / g.hop;                    // first f with f*hop - win/2 >= 0
+            uint64_t fb = N + half >= g.win ? (N + half - g.win) / g.hop + 1 : 0;  // one past the last f with s0 + win <= N
+            fa = std::min<uint64_t>(fa, T);
+            fb = std::min<uint64_t>(std::max(fb, fa), T);
+            add(jobs, tile_start, tiles, g, d, (uint32_t)T, (uint32_t)fa, (uint32_t)fb, (uint32_t)i);
+            add(edge, edge_start, edge_tiles, ge, d, (uint32_t)T, 0, (uint32_t)fa, (uint32_t)i);
+            add(edge, edge_start, edge_tiles, ge, d, (uint32_t)T, (uint32_t)fb, (uint32_t)T, (uint32_t)i);
+        }
+        TH_REQUIRE(tiles < (1ull << 31) && edge_tiles < (1ull << 31), "batch too large for one launch");
     }
-    tile_start[n_chan] = (uint32_t)tiles;
+    tile_start.push_back((uint32_t)tiles);
+    edge_start.push_back((uint32_t)edge_tiles);
 
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     TH_HIP(hipSetDevice(c->device));
     int rc = p->jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(ChanJob));
-    if (rc != TH_OK) return rc;
-    rc = p->tile_start.upload(c->stream, tile_start.data(), tile_start.size() * sizeof(uint32_t));
+    if (rc == TH_OK) rc = p->tile_start.upload(c->stream, tile_start.data(), tile_start.size() * sizeof(uint32_t));
+    if (rc == TH_OK && !edge.empty()) {
+        rc = p->edge_jobs.upload(c->stream, edge.data(), edge.size() * sizeof(ChanJob));
+        if (rc == TH_OK) rc = p->edge_tile_start.upload(c->stream, edge_start.data(), edge_start.size() * sizeof(uint32_t));
+    }
     if (rc != TH_OK) return rc;
     TH_HIP(launch_minmax_init(d_minmax, (uint32_t)n_chan, c->stream));
-    TH_HIP(launch_stft_generic(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
-                               (uint32_t)n_chan, (uint32_t)tiles, p->d_window, p->d_tw, p->d_mel_fb, p->d_mel_lo,
-                               p->d_mel_hi, d_minmax, c->stream));
+    if (wave) {
+        TH_HIP(launch_stft_wave(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
+                                (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, d_minmax, c->n_cu,
+                                c->stream));
+        if (!edge.empty())
+            TH_HIP(launch_stft_generic(ge, (const ChanJob *)p->edge_jobs.dptr, (const uint32_t *)p->edge_tile_start.dptr,
+                                       (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, nullptr,
+                                       nullptr, nullptr, d_minmax, c->stream));
+    } else {
+        TH_HIP(launch_stft_generic(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
+                                   (uint32_t)jobs.size(), (uint32_t)tiles, p->d_window, p->d_tw, p->d_mel_fb,
+                                   p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream));
+    }
     return TH_OK;
     TH_CATCH
 }

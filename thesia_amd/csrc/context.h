@@ -26,6 +26,7 @@ struct DeviceTable {
 
 struct th_ctx {
     int device = 0;
+    uint32_t n_cu = 256;  // compute units (persistent-grid size of the wave kernel)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -53,8 +54,11 @@ struct th_plan {
     th::StftGeom g{};
     float *d_window = nullptr;
     th::cf32 *d_tw = nullptr;
+    th::cf32 *d_wtab = nullptr;  // wave kernel: 0.5 * zero-padded window as (even, odd) pairs
+    bool use_wave() const;
     float *d_mel_fb = nullptr;
     uint32_t *d_mel_lo = nullptr, *d_mel_hi = nullptr;
     std::vector<float> h_mel_fb;
-    th::DeviceTable jobs, tile_start;
+    th::DeviceTable jobs, tile_start;            // main launch (wave kernel, or generic for everything)
+    th::DeviceTable edge_jobs, edge_tile_start;  // boundary frames handed to the generic kernel
 };

@@ -19,6 +19,12 @@ hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const u
                                const float *d_mel_fb, const uint32_t *d_mel_lo, const uint32_t *d_mel_hi,
                                float *d_minmax, hipStream_t s);
 
+bool stft_wave_supported(const StftGeom &g);
+uint32_t stft_wave_frames_per_tile(const StftGeom &g);
+hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
+                            uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, uint32_t n_cu,
+                            hipStream_t s);
+
 // ---- kernels_image.hip
 struct ImgJob {  // device-visible copy of th_img_desc
     const float *spec;

@@ -9,6 +9,7 @@
 
 #include "kernels.h"
 #include "stft_core.h"
+#include "stft_wave.h"
 
 namespace th {
 
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
     const uint32_t tid = threadIdx.x;
     const uint32_t chan = find_chan(tile_start, n_chan, blockIdx.x);
     const ChanJob job = jobs[chan];
-    const uint32_t f0 = (blockIdx.x - tile_start[chan]) * g.frames_per_tile;
-    const uint32_t f1 = min(f0 + g.frames_per_tile, job.n_frames);
+    const uint32_t f0 = job.f_begin + (blockIdx.x - tile_start[chan]) * g.frames_per_tile;
+    const uint32_t f1 = min(f0 + g.frames_per_tile, job.f_end);
 
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
 
@@ -145,10 +146,177 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
                 a = nmin(a, red[2 * w]);
                 b = nmax(b, red[2 * w + 1]);
             }
-            atomic_min_f32(&minmax[2 * chan], a);
-            atomic_max_f32(&minmax[2 * chan + 1], b);
+            atomic_min_f32(&minmax[2 * job.mm_index], a);
+            atomic_max_f32(&minmax[2 * job.mm_index + 1], b);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave kernel (the fast path): one 64-lane wave per frame, n_fft in {1024, 2048, 4096}, linear
+// frequency scale.  See stft_wave.h for the FFT structure.
+//
+// Launch shape: a persistent grid of (at most) one workgroup per CU, WAVES waves each.  The
+// workgroup shares read-only LDS tables (half-scaled zero-padded window, split-pass twiddles and
+// the pass-2 / pass-3 twiddles) and gives every wave a private exchange slab:
+//   LDS = 8 B * (2*Nc + T2_LEN + T3_LEN) + WAVES * 8 B * Nc       (n_fft=2048, 16 waves: 152 KB)
+// After the table fill there is no workgroup barrier: waves run independently.
+// Work split: tiles (frames_per_tile consecutive frames of one channel) are dealt to workgroups in
+// contiguous ranges; inside a tile wave w takes frames f0+w, f0+w+WAVES, ... so the waves of a CU
+// read one contiguous, overlapping sample span at the same time (the 4x hop overlap is served by
+// L1/L2; HBM sees each sample once).  Each wave prefetches its next frame's samples into
+// registers before it transforms the current one, so HBM latency is covered even at 2-4 waves
+// per SIMD.  HBM traffic per frame: 4*hop B read + 4*n_freq B written.
+// ------------------------------------------------------------------------------------------
+// Orders this wave's LDS writes before its later LDS reads (and vice versa) for the compiler; the
+// hardware already executes one wave's DS instructions in order, so no instruction is needed.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A wave's position in its workgroup's tile range.
+struct FrameCursor {
+    uint32_t tile, tile_end, f, f1, mm_index;
+    const float *wav;
+    float *spec;
+    bool valid;
+};
+
+template <int WAVES>
+__device__ __forceinline__ void cursor_open_tile(FrameCursor &c, const StftGeom &g, const ChanJob *__restrict__ jobs,
+                                                 const uint32_t *__restrict__ tile_start, uint32_t n_chan,
+                                                 uint32_t wave) {
+    // advance to the next tile (of this workgroup's range) that has a frame for this wave
+    for (; c.tile < c.tile_end; c.tile++) {
+        const uint32_t chan = find_chan(tile_start, n_chan, c.tile);
+        const ChanJob job = jobs[chan];
+        const uint32_t f0 = job.f_begin + (c.tile - tile_start[chan]) * g.frames_per_tile;
+        const uint32_t f1 = min(f0 + g.frames_per_tile, job.f_end);
+        if (f0 + wave < f1) {
+            c.f = f0 + wave;
+            c.f1 = f1;
+            c.mm_index = job.mm_index;
+            c.wav = job.wav;
+            c.spec = job.spec;
+            c.valid = true;
+            return;
+        }
+    }
+    c.valid = false;
+}
+
+template <int WAVES>
+__device__ __forceinline__ void cursor_next(FrameCursor &c, const StftGeom &g, const ChanJob *__restrict__ jobs,
+                                            const uint32_t *__restrict__ tile_start, uint32_t n_chan, uint32_t wave) {
+    c.f += WAVES;
+    if (c.f < c.f1) return;
+    c.tile++;
+    cursor_open_tile<WAVES>(c, g, jobs, tile_start, n_chan, wave);
+}
+
+template <int P, bool PADDED>
+__device__ __forceinline__ void cursor_fetch(const FrameCursor &c, const StftGeom &g, uint32_t lane, cf32 (&x)[P]) {
+    // frame element 0 sits at signal position f*hop - win/2 - pad_left; the host only hands interior
+    // frames to this kernel, so every windowed sample is inside the channel
+    const int64_t e0 = (int64_t)c.f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+    wave_fetch<P, PADDED>(lane, x, c.wav, e0, g);
+}
+
+template <int LOG2_NC, bool PADDED, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
+    uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax) {
+    using W = WaveFft<LOG2_NC>;
+    constexpr int P = W::P, NC = W::NC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf32 *wtab = reinterpret_cast<cf32 *>(smem_raw);
+    cf32 *stw = wtab + NC;
+    cf32 *t2 = stw + NC;
+    cf32 *t3 = t2 + W::T2_LEN;
+    cf32 *slabs = t3 + W::T3_LEN;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
+        wtab[i] = wtab_g[i];
+        stw[i] = tw[i];
+    }
+    W::fill_tables(tid, 64 * WAVES, tw, t2, t3);
+    __syncthreads();
+
+    cf32 *slab = slabs + (size_t)wave * NC;
+    const uint32_t tiles_per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    FrameCursor cur;
+    cur.tile = min(blockIdx.x * tiles_per_wg, n_tiles);
+    cur.tile_end = min(cur.tile + tiles_per_wg, n_tiles);
+    cursor_open_tile<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
+
+    float lmin = __builtin_inff(), lmax = -__builtin_inff();
+    uint32_t mm_chan = cur.valid ? cur.mm_index : 0u;
+    bool mm_dirty = false;  // a wave that never got a frame must not touch any slot
+    auto flush_minmax = [&]() {
+        if (minmax != nullptr && mm_dirty) {
+            const float a = wave_min(lmin), b = wave_max(lmax);
+            if (lane == 0) {
+                atomic_min_f32(&minmax[2 * mm_chan], a);
+                atomic_max_f32(&minmax[2 * mm_chan + 1], b);
+            }
+        }
+        lmin = __builtin_inff();
+        lmax = -__builtin_inff();
+        mm_dirty = false;
+    };
+
+    cf32 x[P];
+    if (cur.valid) cursor_fetch<P, PADDED>(cur, g, lane, x);
+    while (cur.valid) {
+        FrameCursor nxt = cur;
+        cursor_next<WAVES>(nxt, g, jobs, tile_start, n_chan, wave);
+        cf32 xn[P];
+        if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, xn);  // prefetch: in flight during the FFT below
+
+        cf32 z[P];
+        wave_window<P>(lane, z, x, wtab);
+        W::pass1(lane, z, slab);
+        wave_lds_sync();
+        W::read1(lane, z, slab);
+        wave_lds_sync();
+        W::pass2(lane, z, t2, slab);
+        wave_lds_sync();
+        W::read2(lane, z, slab);
+        W::pass3(lane, z, t3);
+        wave_lds_sync();
+        W::write_z(lane, z, slab);
+        wave_lds_sync();
+        if (cur.mm_index != mm_chan) {
+            flush_minmax();
+            mm_chan = cur.mm_index;
+        }
+        mm_dirty = true;
+        float *row = cur.spec + (size_t)cur.f * g.height;
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+            const uint32_t k = lane + 64u * m;
+            const cf32 zm = slab[(NC - k) & (NC - 1)];  // mirror partner Z[(Nc - k) mod Nc]
+            const float d = power_to_dB(split_power(z[m], zm, stw[k]));
+            row[k] = d;
+            lmin = nmin(lmin, d);
+            lmax = nmax(lmax, d);
+        }
+        if (lane == 0) {  // Nyquist bin k = Nc: partner of Z[0] is Z[0], W^Nc = -1
+            const cf32 wn = {-1.0f, 0.0f};
+            const float d = power_to_dB(split_power(z[0], z[0], wn));
+            row[NC] = d;
+            lmin = nmin(lmin, d);
+            lmax = nmax(lmax, d);
+        }
+        wave_lds_sync();  // the slab is rewritten by the next frame's pass 1
+#pragma unroll
+        for (int m = 0; m < P; m++) x[m] = xn[m];
+        cur = nxt;
+    }
+    flush_minmax();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -176,6 +344,68 @@ hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const u
     hipLaunchKernelGGL(stft_generic_kernel, dim3(n_tiles), dim3(GEN_THREADS), lds, s, g, d_jobs, d_tile_start,
                        n_chan, d_window, d_tw, d_mel_fb, d_mel_lo, d_mel_hi, d_minmax);
     return hipGetLastError();
+}
+
+}  // namespace th
+
+namespace th {
+
+bool stft_wave_supported(const StftGeom &g) { return g.n_mel == 0 && g.log2_nc >= 9 && g.log2_nc <= 11; }
+
+template <int LOG2_NC>
+struct WaveLaunchCfg {  // waves per workgroup (one workgroup per CU): bounded by 160 KB LDS and VGPRs
+    static constexpr int WAVES = LOG2_NC == 11 ? 4 : 8;
+};
+
+template <int LOG2_NC>
+static size_t wave_lds_bytes() {
+    using W = WaveFft<LOG2_NC>;
+    return sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WaveLaunchCfg<LOG2_NC>::WAVES * W::NC);
+}
+
+template <int LOG2_NC, bool PADDED>
+static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
+                                 uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
+                                 float *d_minmax, uint32_t n_cu, hipStream_t s) {
+    constexpr int WAVES = WaveLaunchCfg<LOG2_NC>::WAVES;
+    auto kern = stft_wave_kernel<LOG2_NC, PADDED, WAVES>;
+    const size_t lds = wave_lds_bytes<LOG2_NC>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    const uint32_t grid = n_tiles < n_cu ? n_tiles : n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
+                       d_tw, d_minmax);
+    return hipGetLastError();
+}
+
+template <int LOG2_NC>
+static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
+                                uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
+                                float *d_minmax, uint32_t n_cu, hipStream_t s) {
+    if (g.win == g.n_fft)
+        return launch_wave_t2<LOG2_NC, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, s);
+    return launch_wave_t2<LOG2_NC, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, s);
+}
+
+uint32_t stft_wave_frames_per_tile(const StftGeom &g) {
+    switch (g.log2_nc) {
+        case 11: return 4 * WaveLaunchCfg<11>::WAVES;
+        case 10: return 4 * WaveLaunchCfg<10>::WAVES;
+        default: return 4 * WaveLaunchCfg<9>::WAVES;
+    }
+}
+
+hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
+                            uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, uint32_t n_cu,
+                            hipStream_t s) {
+    if (!n_tiles) return hipSuccess;
+    switch (g.log2_nc) {
+        case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, s);
+        case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, s);
+        case 11: return launch_wave_t<11>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace th

@@ -45,12 +45,16 @@ struct StftGeom {
     uint32_t frames_per_tile;
 };
 
-// One channel of the batch (device pointers).
+// One frame range of one channel of the batch (device pointers).  A launch processes frames
+// [f_begin, f_end) of the channel; its min/max goes to slot mm_index.
 struct ChanJob {
     const float *wav;
     float *spec;
     uint32_t n_samples;
     uint32_t n_frames;
+    uint32_t f_begin, f_end;
+    uint32_t mm_index;
+    uint32_t pad_;
 };
 
 // numpy-'reflect' index with periodic cycling for pads longer than N-1 (utils.rs:111-138;

@@ -1,0 +1,265 @@
+// stft_wave.h — one-wavefront-per-frame FFT building blocks (the fast STFT kernel).
+//
+// A 64-lane wave owns one frame: the packed real FFT of n_fft samples is an Nc = n_fft/2 point
+// complex FFT with P = Nc/64 points per lane, done as three register-resident radix passes
+// (Stockham autosort, decimation in time) with two lane exchanges through a private LDS slab and a
+// third exchange for the real-FFT split pass.  No workgroup barrier is needed anywhere: every
+// exchange stays inside the wave.
+//
+// Invariant before every pass: lane j holds in[j + 64*m] in z[m], m = 0..P-1.
+// A pass with sub-transform size Ns and radix R runs B = P/R butterflies per lane:
+//   butterfly b: jj = j + 64*b, k = jj mod Ns,
+//   v_r = z[b + B*r] * W_{Ns*R}^{r*k}                       (r = 0..R-1)
+//   out[(jj - k)*R + k + r*Ns] = DFT_R(v)_r
+// For the last pass Ns*R = Nc so out index = j + 64*(b + B*r): results stay in registers.
+//
+// Like stft_core.h this header compiles both for gfx950 (hipcc) and for the CPU lane emulator in
+// tests/emu (g++), which runs the phases lane by lane to check the index arithmetic.
+#pragma once
+#include "stft_core.h"
+
+namespace th {
+
+// ---------------------------------------------------------------------------------------------
+// register DFTs (forward).  Outputs are left in "digit-reversed slots"; OUT_SLOT maps natural
+// output index -> register slot, so callers permute at compile time for free.
+// ---------------------------------------------------------------------------------------------
+TH_HD cf32 cmul_c(cf32 a, float wr, float wi) { return {a.re * wr - a.im * wi, a.re * wi + a.im * wr}; }
+
+// DFT-8 as 2 x 4: n = n1 + 2*n2 (n1 in 0..1, n2 in 0..3), k = 4*k1 + k2
+//   v[n1 + 2*k2] <- DFT4 over n2 of v[n1 + 2*n2];  *= W8^(n1*k2);  DFT2 over n1  -> X[4*k1+k2] in v[k1 + 2*k2]
+TH_HD void dft8(cf32 (&v)[8]) {
+    const float h = 0.70710678118654752440f;
+    fft4(v[0], v[2], v[4], v[6]);
+    fft4(v[1], v[3], v[5], v[7]);
+    // W8^1 = (h, -h), W8^2 = -i, W8^3 = (-h, -h) on v[1 + 2*k2], k2 = 1..3
+    v[3] = {h * (v[3].re + v[3].im), h * (v[3].im - v[3].re)};
+    v[5] = cmul_negi(v[5]);
+    v[7] = {h * (v[7].im - v[7].re), -h * (v[7].re + v[7].im)};
+    fft2(v[0], v[1]);
+    fft2(v[2], v[3]);
+    fft2(v[4], v[5]);
+    fft2(v[6], v[7]);
+}
+// natural output X[k], k = 4*k1 + k2, sits in slot k1 + 2*k2
+TH_HD constexpr int dft8_slot(int k) { return (k >> 2) + 2 * (k & 3); }
+
+// DFT-16 as 4 x 4: n = n1 + 4*n2, k = 4*k1 + k2
+//   v[n1 + 4*k2] <- DFT4 over n2 of v[n1 + 4*n2];  *= W16^(n1*k2);  DFT4 over n1 -> X[4*k1+k2] in v[k1 + 4*k2]
+TH_HD void dft16(cf32 (&v)[16]) {
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;  // cos, sin(pi/8)
+    const float h = 0.70710678118654752440f;
+    fft4(v[0], v[4], v[8], v[12]);
+    fft4(v[1], v[5], v[9], v[13]);
+    fft4(v[2], v[6], v[10], v[14]);
+    fft4(v[3], v[7], v[11], v[15]);
+    // twiddle W16^(n1*k2) on v[n1 + 4*k2]; W16^m = (cos(pi m/8), -sin(pi m/8))
+    v[5] = cmul_c(v[5], c1, -s1);                                   // n1=1,k2=1: W^1
+    v[9] = {h * (v[9].re + v[9].im), h * (v[9].im - v[9].re)};      // n1=1,k2=2: W^2
+    v[13] = cmul_c(v[13], s1, -c1);                                 // n1=1,k2=3: W^3
+    v[6] = {h * (v[6].re + v[6].im), h * (v[6].im - v[6].re)};      // n1=2,k2=1: W^2
+    v[10] = cmul_negi(v[10]);                                       // n1=2,k2=2: W^4 = -i
+    v[14] = {h * (v[14].im - v[14].re), -h * (v[14].re + v[14].im)};  // n1=2,k2=3: W^6
+    v[7] = cmul_c(v[7], s1, -c1);                                   // n1=3,k2=1: W^3
+    v[11] = {h * (v[11].im - v[11].re), -h * (v[11].re + v[11].im)};  // n1=3,k2=2: W^6
+    v[15] = cmul_c(v[15], -c1, s1);                                 // n1=3,k2=3: W^9
+    fft4(v[0], v[1], v[2], v[3]);
+    fft4(v[4], v[5], v[6], v[7]);
+    fft4(v[8], v[9], v[10], v[11]);
+    fft4(v[12], v[13], v[14], v[15]);
+}
+// natural output X[k], k = 4*k1 + k2, sits in slot k1 + 4*k2
+TH_HD constexpr int dft16_slot(int k) { return (k >> 2) + 4 * (k & 3); }
+
+template <int R>
+struct RegDft;
+template <>
+struct RegDft<2> {
+    static TH_HD void run(cf32 (&v)[2]) { fft2(v[0], v[1]); }
+    static TH_HD constexpr int slot(int k) { return k; }
+};
+template <>
+struct RegDft<4> {
+    static TH_HD void run(cf32 (&v)[4]) { fft4(v[0], v[1], v[2], v[3]); }
+    static TH_HD constexpr int slot(int k) { return k; }
+};
+template <>
+struct RegDft<8> {
+    static TH_HD void run(cf32 (&v)[8]) { dft8(v); }
+    static TH_HD constexpr int slot(int k) { return dft8_slot(k); }
+};
+template <>
+struct RegDft<16> {
+    static TH_HD void run(cf32 (&v)[16]) { dft16(v); }
+    static TH_HD constexpr int slot(int k) { return dft16_slot(k); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Static description of the wave FFT for one n_fft.
+// ---------------------------------------------------------------------------------------------
+template <int LOG2_NC>
+struct WaveFftCfg;
+template <>
+struct WaveFftCfg<9> {  // n_fft = 1024: Nc = 512 = 8 * 8 * 8, P = 8
+    static constexpr int R1 = 8, R2 = 8, R3 = 8;
+};
+template <>
+struct WaveFftCfg<10> {  // n_fft = 2048: Nc = 1024 = 16 * 16 * 4, P = 16
+    static constexpr int R1 = 16, R2 = 16, R3 = 4;
+};
+template <>
+struct WaveFftCfg<11> {  // n_fft = 4096: Nc = 2048 = 16 * 16 * 8, P = 32
+    static constexpr int R1 = 16, R2 = 16, R3 = 8;
+};
+
+// LDS index swizzle for the first exchange (pass-1 output, Ns = 1): lane j writes the R1
+// consecutive slots R1*jj + r; XOR-ing the low bits with bits of the row index makes each
+// ds_write_b64 lane group hit 16 distinct bank pairs, and keeps 16-aligned blocks intact for the
+// consecutive-lane reads of pass 2.
+template <int R1>
+TH_HD uint32_t swz1(uint32_t i) {
+    if (R1 == 16) return i ^ ((i >> 4) & 15u);
+    if (R1 == 8) return i ^ ((i >> 4) & 7u);
+    return i;
+}
+
+template <int LOG2_NC>
+struct WaveFft {
+    using Cfg = WaveFftCfg<LOG2_NC>;
+    static constexpr int NC = 1 << LOG2_NC;
+    static constexpr int P = NC / 64;
+    static constexpr int R1 = Cfg::R1, R2 = Cfg::R2, R3 = Cfg::R3;
+    static constexpr int NS2 = R1, NS3 = R1 * R2;
+    static_assert(R1 * R2 * R3 == NC, "radix plan must multiply to Nc");
+    static constexpr int B1 = P / R1, B2 = P / R2, B3 = P / R3;
+    static_assert(B1 >= 1 && B2 >= 1 && B3 >= 1, "radix larger than points per lane");
+    // Twiddle tables (LDS in the kernel): a lane reads W_{Ns*R}^{r*k} for its own k = jj mod Ns.
+    //   t2[(r-1)*NS2 + k], k < NS2 (NS2 <= 64 so k does not depend on the butterfly index b)
+    //   t3[(r-1)*NS3 + jj], jj < NS3 (last pass: k = jj)
+    static constexpr int T2_LEN = (R2 - 1) * NS2, T3_LEN = (R3 - 1) * NS3;
+    static_assert(NS2 <= 64, "pass-2 twiddle index must be butterfly independent");
+    // tw[i] = exp(-2 pi i * i / n_fft), n_fft = 2*NC  ->  W_{M}^{e} = tw[e * (2*NC / M)]
+    static TH_HD void fill_tables(uint32_t tid, uint32_t nthr, const cf32 *tw, cf32 *t2, cf32 *t3) {
+        for (uint32_t i = tid; i < (uint32_t)T2_LEN; i += nthr) {
+            const uint32_t r = i / NS2 + 1, k = i % NS2;
+            t2[i] = tw[(r * k) * (2 * NC / (NS2 * R2))];
+        }
+        for (uint32_t i = tid; i < (uint32_t)T3_LEN; i += nthr) {
+            const uint32_t r = i / NS3 + 1, k = i % NS3;
+            t3[i] = tw[(r * k) * (2 * NC / (NS3 * R3))];
+        }
+    }
+
+    // pass 1 (Ns = 1, no twiddles): registers -> LDS slab (swizzled)
+    static TH_HD void pass1(uint32_t lane, cf32 (&z)[P], cf32 *slab) {
+        for (int b = 0; b < B1; b++) {
+            cf32 v[R1];
+            for (int r = 0; r < R1; r++) v[r] = z[b + B1 * r];
+            RegDft<R1>::run(v);
+            const uint32_t jj = lane + 64u * b;
+            for (int r = 0; r < R1; r++) slab[swz1<R1>(jj * R1 + r)] = v[RegDft<R1>::slot(r)];
+        }
+    }
+    static TH_HD void read1(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
+        for (int m = 0; m < P; m++) z[m] = slab[swz1<R1>(lane + 64u * m)];
+    }
+
+    // pass 2 (Ns = R1): registers -> LDS slab (linear)
+    static TH_HD void pass2(uint32_t lane, cf32 (&z)[P], const cf32 *t2, cf32 *slab) {
+        for (int b = 0; b < B2; b++) {
+            const uint32_t jj = lane + 64u * b, k = jj & (NS2 - 1);
+            cf32 v[R2];
+            v[0] = z[b];
+            for (int r = 1; r < R2; r++) v[r] = cmul(z[b + B2 * r], t2[(r - 1) * NS2 + k]);
+            RegDft<R2>::run(v);
+            const uint32_t j0 = (jj - k) * R2 + k;
+            for (int r = 0; r < R2; r++) slab[j0 + r * NS2] = v[RegDft<R2>::slot(r)];
+        }
+    }
+    static TH_HD void read2(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
+        for (int m = 0; m < P; m++) z[m] = slab[lane + 64u * m];
+    }
+
+    // pass 3 (Ns = R1*R2, last): registers -> registers, lane j ends with Z[j + 64*m] in z[m]
+    static TH_HD void pass3(uint32_t lane, cf32 (&z)[P], const cf32 *t3) {
+        for (int b = 0; b < B3; b++) {
+            const uint32_t jj = lane + 64u * b;
+            cf32 v[R3];
+            v[0] = z[b];
+            for (int r = 1; r < R3; r++) v[r] = cmul(z[b + B3 * r], t3[(r - 1) * NS3 + jj]);
+            RegDft<R3>::run(v);
+            for (int r = 0; r < R3; r++) z[b + B3 * r] = v[RegDft<R3>::slot(r)];
+        }
+    }
+
+    // split exchange: publish Z, then fetch the mirror partner Z[(Nc - k) mod Nc] of every own k
+    static TH_HD void write_z(uint32_t lane, const cf32 (&z)[P], cf32 *slab) {
+        for (int m = 0; m < P; m++) slab[lane + 64u * m] = z[m];
+    }
+    static TH_HD void read_mirror(uint32_t lane, cf32 (&zm)[P], const cf32 *slab) {
+        for (int m = 0; m < P; m++) zm[m] = slab[(NC - (lane + 64u * m)) & (NC - 1)];
+    }
+};
+
+// |X[k]|^2 from the half-scaled packed spectrum (window pre-multiplied by 1/2):
+//   e = Z[k] + conj Z[Nc-k],  o = -i (Z[k] - conj Z[Nc-k]),  X[k] = e + W^k o
+TH_HD float split_power(cf32 zk, cf32 zm, cf32 w) {
+    const float er = zk.re + zm.re, ei = zk.im - zm.im;
+    const float dr = zk.re - zm.re, di = zk.im + zm.im;  // d = Z[k] - conj Z[Nc-k];  o = (di, -dr)
+    const float xr = er + (di * w.re + dr * w.im);
+    const float xi = ei + (di * w.im - dr * w.re);
+    return xr * xr + xi * xi;
+}
+
+}  // namespace th
+
+namespace th {
+
+// ---------------------------------------------------------------------------------------------
+// Frame load: lane j fetches x[m] = (fr[2n], fr[2n+1]), n = j + 64*m, of the zero-padded frame
+// (stft.rs:137-146); e0 = signal position of frame element 0 (= k*hop - win/2 - pad_left).
+// The wave kernel only takes INTERIOR frames (every windowed sample inside [0, n_samples)): plain
+// coalesced 8-byte loads, no reflection.  Frames that touch the signal boundaries (the first and
+// last few per channel, and every frame of inputs shorter than the window) go to the generic
+// kernel, which implements the reflect padding.
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((aligned(4))) f32x2_u {  // 8-byte load that only assumes 4-byte alignment
+    float a, b;
+};
+
+template <int P, bool PADDED>
+TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], const float *wav, int64_t e0, const StftGeom &g) {
+    for (int m = 0; m < P; m++) {
+        const uint32_t n = lane + 64u * m;
+        float x0 = 0.0f, x1 = 0.0f;
+        if (!PADDED) {
+            const f32x2_u v = *reinterpret_cast<const f32x2_u *>(wav + (e0 + 2 * (int64_t)n));
+            x0 = v.a;
+            x1 = v.b;
+        } else {
+            const uint32_t i0 = 2 * n - g.pad_left, i1 = i0 + 1;  // unsigned: < win  <=>  inside the window
+            if (i0 < g.win) x0 = wav[e0 + 2 * (int64_t)n];
+            if (i1 < g.win) x1 = wav[e0 + 2 * (int64_t)n + 1];
+        }
+        x[m] = {x0, x1};
+    }
+}
+
+template <int P>
+TH_HD void wave_window(uint32_t lane, cf32 (&z)[P], const cf32 (&x)[P], const cf32 *wtab) {
+    for (int m = 0; m < P; m++) {
+        const cf32 w = wtab[lane + 64u * m];
+        z[m] = {x[m].re * w.re, x[m].im * w.im};
+    }
+}
+
+// 10*log10(p) with p = |X|^2  ==  20*log10(|X|)  (decibel.rs:170-214 with amin = 0: p = +0 -> -inf)
+TH_HD float power_to_dB(float p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 3.01029995663981195f * __builtin_amdgcn_logf(p);  // v_log_f32 (log2), <= 1 ulp
+#else
+    return 3.01029995663981195f * __builtin_log2f(p);
+#endif
+}
+
+}  // namespace th
