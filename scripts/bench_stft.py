@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""STFT-kernel microbenchmark (development tool): the bench.py workload, STFT->dB launch only.
+usage: python scripts/bench_stft.py [--kernel K] [--tracks N] [--seconds S] [--reps R] [--nfft 2048]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import thesia_amd as ta  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--kernel", type=int, nargs="*", default=[0])
+ap.add_argument("--tracks", type=int, default=128)
+ap.add_argument("--seconds", type=float, default=30.0)
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--nfft", type=int, default=2048)
+ap.add_argument("--win", type=int, default=0)
+ap.add_argument("--hop", type=int, default=0)
+a = ap.parse_args()
+sr = 48000
+n_fft = a.nfft
+win = a.win or n_fft
+hop = a.hop or win // 4
+dev = torch.device("cuda", 0)
+side = torch.cuda.Stream(dev)
+torch.cuda.set_stream(side)
+ctx = ta.Context(0, side.cuda_stream)
+n = int(a.seconds * sr)
+g = torch.Generator(device=dev)
+g.manual_seed(1)
+wav = (torch.rand((a.tracks, n), device=dev, generator=g) * 2 - 1) * 0.3
+for K in a.kernel:
+    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    if K:
+        plan.set_kernel(K)
+    T, H = plan.n_frames(n), plan.height
+    spec = torch.empty((a.tracks, T, H), dtype=torch.float32, device=dev)
+    mm = torch.empty((a.tracks, 2), dtype=torch.float32, device=dev)
+    chan = (ta.ChanDesc * a.tracks)(*[ta.ChanDesc(wav[i].data_ptr(), spec[i].data_ptr(), n, T) for i in range(a.tracks)])
+    for _ in range(3):
+        plan.calc_spec_batch_dev(chan, mm.data_ptr())
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(a.reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        plan.calc_spec_batch_dev(chan, mm.data_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = float(np.median(ts))
+    frames = a.tracks * T
+    bpf = 4 * hop + 4 * H
+    print(f"kernel={K} ({plan.kernel_name}) n_fft={n_fft} win={win} hop={hop}: median {ms:.3f} ms  min {min(ts):.3f} ms  "
+          f"{frames / ms / 1e3:.1f} Mframes/s  {frames * bpf / ms / 1e6:.0f} GB/s algorithmic "
+          f"({frames * bpf / ms / 1e6 / 80:.1f}% of 8 TB/s)", flush=True)
+    del spec

@@ -16,7 +16,7 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
                       const cf32 *tw, float *row) {
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
-    std::vector<cf32> slab(NC);
+    std::vector<cf32> slab(W::SLAB_LEN);
     static cf32 x[64][P], z[64][P], zm[64][P];
     std::vector<cf32> t2(W::T2_LEN), t3(W::T3_LEN);
     const int64_t e0 = (int64_t)frame * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
@@ -29,7 +29,8 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
     for (uint32_t l = 0; l < 64; l++) W::read2(l, z[l], slab.data());
     for (uint32_t l = 0; l < 64; l++) W::pass3(l, z[l], t3.data());
     for (uint32_t l = 0; l < 64; l++) W::write_z(l, z[l], slab.data());
-    for (uint32_t l = 0; l < 64; l++) W::read_mirror(l, zm[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++)
+        for (int m = 0; m < P; m++) zm[l][m] = W::read_mirror(l, m, slab.data());
     for (uint32_t l = 0; l < 64; l++)
         for (int m = 0; m < P; m++) {
             const uint32_t k = l + 64u * m;

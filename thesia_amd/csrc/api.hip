@@ -417,8 +417,12 @@ TH_API int th_plan_dims(const th_plan *p, size_t *n_freq, size_t *height) {
 TH_API int th_plan_set_kernel(th_plan *p, int which) {
     TH_TRY
     TH_REQUIRE(p, "plan is NULL");
-    TH_REQUIRE(which >= 0 && which <= 2, "kernel selector must be 0, 1 or 2");
-    p->kernel_choice = which;
+    // bits 0-7: 0 auto, 1 generic, 2 wave;  bits 8-15 (tuning): waves per workgroup of the wave kernel
+    const int k = which & 0xff, wv = (which >> 8) & 0xff;
+    TH_REQUIRE(k >= 0 && k <= 2, "kernel selector must be 0, 1 or 2");
+    TH_REQUIRE(wv == 0 || wv == 4 || wv == 8 || wv == 12 || wv == 16, "waves per workgroup must be 4, 8, 12 or 16");
+    p->kernel_choice = k;
+    p->wave_waves = wv;
     return TH_OK;
     TH_CATCH
 }
@@ -441,7 +445,8 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
         return fail(TH_ERR_UNSUPPORTED, "the wave kernel covers linear scale, n_fft in {1024, 2048, 4096}");
     StftGeom g = p->g;       // main launch
     StftGeom ge = p->g;      // edge launch (generic kernel)
-    g.frames_per_tile = wave ? stft_wave_frames_per_tile(g) : 8;
+    const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);
+    g.frames_per_tile = wave ? 4 * waves : 8;
     ge.frames_per_tile = 1;
     // main jobs: the wave kernel takes the interior frames [fa, fb) of every channel (all windowed
     // samples inside the signal); the generic kernel takes the boundary frames (reflect padding,
@@ -493,7 +498,7 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     TH_HIP(launch_minmax_init(d_minmax, (uint32_t)n_chan, c->stream));
     if (wave) {
         TH_HIP(launch_stft_wave(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
-                                (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, d_minmax, c->n_cu,
+                                (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, d_minmax, c->n_cu, waves,
                                 c->stream));
         if (!edge.empty())
             TH_HIP(launch_stft_generic(ge, (const ChanJob *)p->edge_jobs.dptr, (const uint32_t *)p->edge_tile_start.dptr,

@@ -51,6 +51,7 @@ struct th_plan {
     uint32_t sr = 0;
     int freq_scale = 0;
     int kernel_choice = 0;  // 0 auto, 1 generic, 2 wave
+    int wave_waves = 0;     // tuning: waves per workgroup of the wave kernel (0 = default)
     th::StftGeom g{};
     float *d_window = nullptr;
     th::cf32 *d_tw = nullptr;

@@ -20,10 +20,11 @@ hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const u
                                float *d_minmax, hipStream_t s);
 
 bool stft_wave_supported(const StftGeom &g);
-uint32_t stft_wave_frames_per_tile(const StftGeom &g);
+int stft_wave_default_waves(const StftGeom &g);
+// waves: waves per workgroup (4, 8, 12 or 16; <= 0 selects the default for this n_fft)
 hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                             uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, uint32_t n_cu,
-                            hipStream_t s);
+                            int waves, hipStream_t s);
 
 // ---- kernels_image.hip
 struct ImgJob {  // device-visible copy of th_img_desc

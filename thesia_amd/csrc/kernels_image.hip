@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "stft_core.h"
 
 // Integer / rounding stages must round once per operation exactly like the reference's scalar f32
 // code: no FMA contraction anywhere in this file (hipcc defaults to -ffp-contract=fast; the
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
         const uint32_t t = t0 + dt;
         uint16_t px = 0;
         if (t < job.n_frames && i_freq < job.height && r0 + tx < out_h)
-            px = quantise(job.spec[(size_t)t * job.height + i_freq], min_dB, span, u16_span, min_value);
+            px = quantise(as_global(job.spec)[(size_t)t * job.height + i_freq], min_dB, span, u16_span, min_value);
         tile[tx][dt] = px;
     }
     __syncthreads();
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
 #pragma unroll 4
     for (uint32_t dr = ty; dr < IMG_TILE; dr += 4) {
         const uint32_t r = r0 + dr, t = t0 + tx;
-        if (r < out_h && t < job.n_frames) job.img[(size_t)r * job.n_frames + t] = tile[dr][tx];
+        if (r < out_h && t < job.n_frames) as_global(job.img)[(size_t)r * job.n_frames + t] = tile[dr][tx];
     }
 }
 
@@ -104,16 +105,19 @@ __global__ __launch_bounds__(256) void raster_level0_kernel(const RasterJob *__r
     const RasterJob job = jobs[ji];
     const uint32_t n_px = job.width * job.height;
     const uint32_t base = (blockIdx.x - block_start[ji]) * RASTER_PIXELS_PER_BLOCK;
-    uint32_t *out = reinterpret_cast<uint32_t *>(job.rgba);
+    const gptr<uint32_t> out = as_global(reinterpret_cast<uint32_t *>(job.rgba));
 #pragma unroll
     for (uint32_t it = 0; it < RASTER_PIXELS_PER_BLOCK / 256; it++) {
         const uint32_t p = base + it * 256 + threadIdx.x;
         if (p >= n_px) break;
         const uint32_t r = p / job.width, c = p - r * job.width;
         const uint32_t src_row = job.origin_y + (job.height - 1 - r);
-        const uint32_t v = job.img[(size_t)src_row * job.img_width + job.origin_x + c];
+        const uint32_t v = as_global(job.img)[(size_t)src_row * job.img_width + job.origin_x + c];
         const uint32_t ci = n_colors <= 1 ? 0 : (v * (n_colors - 1) + 32767u) / 65535u;
-        out[p] = use_lds ? lut[ci] : colormap[ci];
+        uint32_t rgba;  // two explicit loads: a select between an LDS and a global pointer would go flat
+        if (use_lds) rgba = lut[ci];
+        else rgba = colormap[ci];
+        out[p] = rgba;
     }
 }
 

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
 
     for (uint32_t f = f0; f < f1; f++) {
         const int64_t s0 = (int64_t)f * g.hop - (int64_t)(g.win / 2);
-        gen_load(tid, GEN_THREADS, g, job.wav, job.n_samples, s0, window, bufA);
+        gen_load(tid, GEN_THREADS, g, as_global(job.wav), job.n_samples, s0, as_global(window), bufA);
         __syncthreads();
         cf32 *in = bufA, *out = bufB;
         uint32_t Ns = 1;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
         float *mag = reinterpret_cast<float *>(out);
         gen_split(tid, GEN_THREADS, g, tw, in, mag);
         __syncthreads();
-        float *row = job.spec + (size_t)f * g.height;
+        const gptr<float> row = as_global(job.spec) + (size_t)f * g.height;
         if (g.n_mel == 0) {
             for (uint32_t k = tid; k < g.n_freq; k += GEN_THREADS) {
                 const float d = amp_to_dB(mag[k]);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
 // Launch shape: a persistent grid of (at most) one workgroup per CU, WAVES waves each.  The
 // workgroup shares read-only LDS tables (half-scaled zero-padded window, split-pass twiddles and
 // the pass-2 / pass-3 twiddles) and gives every wave a private exchange slab:
-//   LDS = 8 B * (2*Nc + T2_LEN + T3_LEN) + WAVES * 8 B * Nc       (n_fft=2048, 16 waves: 152 KB)
+//   LDS = 8 B * (2*Nc + T2_LEN + T3_LEN) + WAVES * 8 B * (Nc + Nc/R1)   (n_fft=2048, 16 waves: 159.9 KB)
 // After the table fill there is no workgroup barrier: waves run independently.
 // Work split: tiles (frames_per_tile consecutive frames of one channel) are dealt to workgroups in
 // contiguous ranges; inside a tile wave w takes frames f0+w, f0+w+WAVES, ... so the waves of a CU
@@ -179,8 +179,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 // A wave's position in its workgroup's tile range.
 struct FrameCursor {
     uint32_t tile, tile_end, f, f1, mm_index;
-    const float *wav;
-    float *spec;
+    gptr<const float> wav;
+    gptr<float> spec;
     bool valid;
 };
 
@@ -198,8 +198,8 @@ __device__ __forceinline__ void cursor_open_tile(FrameCursor &c, const StftGeom 
             c.f = f0 + wave;
             c.f1 = f1;
             c.mm_index = job.mm_index;
-            c.wav = job.wav;
-            c.spec = job.spec;
+            c.wav = as_global(job.wav);
+            c.spec = as_global(job.spec);
             c.valid = true;
             return;
         }
@@ -237,7 +237,9 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     cf32 *t3 = t2 + W::T2_LEN;
     cf32 *slabs = t3 + W::T3_LEN;
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // wave index is wave-uniform: tell the compiler, so the frame cursor lives in SGPRs / SALU
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
         wtab[i] = wtab_g[i];
         stw[i] = tw[i];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     W::fill_tables(tid, 64 * WAVES, tw, t2, t3);
     __syncthreads();
 
-    cf32 *slab = slabs + (size_t)wave * NC;
+    cf32 *slab = slabs + (size_t)wave * W::SLAB_LEN;
     const uint32_t tiles_per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
     FrameCursor cur;
     cur.tile = min(blockIdx.x * tiles_per_wg, n_tiles);
@@ -268,37 +270,46 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         mm_dirty = false;
     };
 
+    // Per-frame pipeline of one wave.  The next frame's samples are requested right after the last
+    // register pass, when only z[] is live, and land during the split / dB / store epilogue and
+    // while the SIMD's other waves compute: HBM latency is covered without holding a second frame
+    // in registers through the FFT passes.  sched_barrier(0) pins the phases so the scheduler
+    // cannot hoist LDS / global loads across them and inflate register pressure.
     cf32 x[P];
     if (cur.valid) cursor_fetch<P, PADDED>(cur, g, lane, x);
     while (cur.valid) {
-        FrameCursor nxt = cur;
-        cursor_next<WAVES>(nxt, g, jobs, tile_start, n_chan, wave);
-        cf32 xn[P];
-        if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, xn);  // prefetch: in flight during the FFT below
-
         cf32 z[P];
         wave_window<P>(lane, z, x, wtab);
         W::pass1(lane, z, slab);
         wave_lds_sync();
+        __builtin_amdgcn_sched_barrier(0);
         W::read1(lane, z, slab);
         wave_lds_sync();
         W::pass2(lane, z, t2, slab);
         wave_lds_sync();
+        __builtin_amdgcn_sched_barrier(0);
         W::read2(lane, z, slab);
         W::pass3(lane, z, t3);
         wave_lds_sync();
         W::write_z(lane, z, slab);
         wave_lds_sync();
+        __builtin_amdgcn_sched_barrier(0);
+
+        FrameCursor nxt = cur;
+        cursor_next<WAVES>(nxt, g, jobs, tile_start, n_chan, wave);
+        if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, x);  // in flight during the epilogue
+        __builtin_amdgcn_sched_barrier(0);
+
         if (cur.mm_index != mm_chan) {
             flush_minmax();
             mm_chan = cur.mm_index;
         }
         mm_dirty = true;
-        float *row = cur.spec + (size_t)cur.f * g.height;
+        const gptr<float> row = cur.spec + (size_t)cur.f * g.height;
 #pragma unroll
         for (int m = 0; m < P; m++) {
             const uint32_t k = lane + 64u * m;
-            const cf32 zm = slab[(NC - k) & (NC - 1)];  // mirror partner Z[(Nc - k) mod Nc]
+            const cf32 zm = W::read_mirror(lane, m, slab);  // mirror partner Z[Nc - k]
             const float d = power_to_dB(split_power(z[m], zm, stw[k]));
             row[k] = d;
             lmin = nmin(lmin, d);
@@ -312,8 +323,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             lmax = nmax(lmax, d);
         }
         wave_lds_sync();  // the slab is rewritten by the next frame's pass 1
-#pragma unroll
-        for (int m = 0; m < P; m++) x[m] = xn[m];
+        __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
     }
     flush_minmax();
@@ -352,24 +362,26 @@ namespace th {
 
 bool stft_wave_supported(const StftGeom &g) { return g.n_mel == 0 && g.log2_nc >= 9 && g.log2_nc <= 11; }
 
+// Waves per workgroup (one persistent workgroup per CU).  Bounded by LDS (tables + one slab per
+// wave <= 160 KB) and by the VGPR file (64*WAVES threads => 512/(WAVES/4) VGPRs per lane).
 template <int LOG2_NC>
-struct WaveLaunchCfg {  // waves per workgroup (one workgroup per CU): bounded by 160 KB LDS and VGPRs
-    static constexpr int WAVES = LOG2_NC == 11 ? 4 : 8;
+struct WaveLaunchCfg {
+    static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? 4 : 16;
 };
 
-template <int LOG2_NC>
+template <int LOG2_NC, int WAVES>
 static size_t wave_lds_bytes() {
     using W = WaveFft<LOG2_NC>;
-    return sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WaveLaunchCfg<LOG2_NC>::WAVES * W::NC);
+    return sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
 }
 
-template <int LOG2_NC, bool PADDED>
-static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
+template <int LOG2_NC, bool PADDED, int WAVES>
+static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t n_cu, hipStream_t s) {
-    constexpr int WAVES = WaveLaunchCfg<LOG2_NC>::WAVES;
     auto kern = stft_wave_kernel<LOG2_NC, PADDED, WAVES>;
-    const size_t lds = wave_lds_bytes<LOG2_NC>();
+    const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>();
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -379,31 +391,52 @@ static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const
     return hipGetLastError();
 }
 
+template <int LOG2_NC, bool PADDED>
+static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
+                                 uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
+                                 float *d_minmax, uint32_t n_cu, int waves, hipStream_t s) {
+#define TH_WAVE_CASE(WV)                                                                                         \
+    case WV:                                                                                                     \
+        return launch_wave_t3<LOG2_NC, PADDED, WV>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, \
+                                                   n_cu, s);
+    switch (waves) {
+        TH_WAVE_CASE(4)
+        TH_WAVE_CASE(8)
+        TH_WAVE_CASE(12)
+        TH_WAVE_CASE(16)
+        default: return hipErrorInvalidValue;
+    }
+#undef TH_WAVE_CASE
+}
+
 template <int LOG2_NC>
 static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                 uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                float *d_minmax, uint32_t n_cu, hipStream_t s) {
+                                float *d_minmax, uint32_t n_cu, int waves, hipStream_t s) {
+    if (waves <= 0) waves = WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES;
     if (g.win == g.n_fft)
-        return launch_wave_t2<LOG2_NC, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, s);
-    return launch_wave_t2<LOG2_NC, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, s);
+        return launch_wave_t2<LOG2_NC, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu,
+                                              waves, s);
+    return launch_wave_t2<LOG2_NC, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, waves,
+                                         s);
 }
 
-uint32_t stft_wave_frames_per_tile(const StftGeom &g) {
+int stft_wave_default_waves(const StftGeom &g) {
     switch (g.log2_nc) {
-        case 11: return 4 * WaveLaunchCfg<11>::WAVES;
-        case 10: return 4 * WaveLaunchCfg<10>::WAVES;
-        default: return 4 * WaveLaunchCfg<9>::WAVES;
+        case 11: return WaveLaunchCfg<11>::DEFAULT_WAVES;
+        case 10: return WaveLaunchCfg<10>::DEFAULT_WAVES;
+        default: return WaveLaunchCfg<9>::DEFAULT_WAVES;
     }
 }
 
 hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                             uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, uint32_t n_cu,
-                            hipStream_t s) {
+                            int waves, hipStream_t s) {
     if (!n_tiles) return hipSuccess;
     switch (g.log2_nc) {
-        case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, s);
-        case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, s);
-        case 11: return launch_wave_t<11>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, s);
+        case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, waves, s);
+        case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, waves, s);
+        case 11: return launch_wave_t<11>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, waves, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "stft_core.h"
 
 // Integer / rounding stages must round once per operation exactly like the reference's scalar f32
 // code: no FMA contraction anywhere in this file (the build also passes -ffp-contract=off).
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void waveform_kernel(const WaveJob *__restrict
                                                        const uint32_t *__restrict__ block_start, uint32_t n_jobs) {
     const uint32_t ji = find_wjob(block_start, n_jobs, blockIdx.x);
     const WaveJob job = jobs[ji];
+    const gptr<const float> wav = as_global(job.wav);
     const uint32_t lb = blockIdx.x - block_start[ji];
     const uint64_t spb = job.level < 64 ? (1ull << job.level) : ~0ull;
     uint64_t tile_end = job.start + 1024ull * spb;  // callers keep level small enough not to overflow
@@ -50,12 +52,12 @@ __global__ __launch_bounds__(256) void waveform_kernel(const WaveJob *__restrict
         const uint64_t e = min(tile_end, s + spb);
         float mn = __builtin_inff(), mx = -__builtin_inff(), sum = 0.0f;
         for (uint64_t i = s; i < e; i++) {
-            const float v = job.wav[i];
+            const float v = wav[i];
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
             sum = sum + v;
         }
-        float *o = job.bins + 3ull * b;
+        const gptr<float> o = as_global(job.bins) + 3ull * b;
         o[0] = mn;
         o[1] = mx;
         o[2] = sum / (float)(e - s);
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void waveform_kernel(const WaveJob *__restrict
     const uint64_t e = min(tile_end, s + spb);
     float mn = __builtin_inff(), mx = -__builtin_inff(), sum = 0.0f;
     for (uint64_t i = s + lane; i < e; i += 64) {
-        const float v = job.wav[i];
+        const float v = wav[i];
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
         sum += v;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void waveform_kernel(const WaveJob *__restrict
         sum += __shfl_xor(sum, o, 64);
     }
     if (lane == 0) {
-        float *o = job.bins + 3ull * b;
+        const gptr<float> o = as_global(job.bins) + 3ull * b;
         o[0] = mn;
         o[1] = mx;
         o[2] = sum / (float)(e - s);

@@ -21,11 +21,27 @@
 #define TH_HD inline
 #endif
 
+// Pointers that reach a kernel inside a job table (loaded from memory) are "flat" to the compiler:
+// it then emits flat_load / flat_store, which count on BOTH vmcnt and lgkmcnt and serialise with
+// every LDS wait.  Kernels cast them to the global address space first (th::as_global).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TH_GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define TH_GLOBAL_AS
+#endif
+
 namespace th {
 
 struct __attribute__((aligned(8))) cf32 {
     float re, im;
 };
+
+template <class T>
+using gptr = T TH_GLOBAL_AS *;
+template <class T>
+TH_HD gptr<T> as_global(T *p) {
+    return (gptr<T>)p;
+}
 
 TH_HD cf32 cadd(cf32 a, cf32 b) { return {a.re + b.re, a.im + b.im}; }
 TH_HD cf32 csub(cf32 a, cf32 b) { return {a.re - b.re, a.im - b.im}; }
@@ -71,8 +87,8 @@ TH_HD uint32_t reflect_index(int64_t i, uint32_t n) {
 
 // Sample `i` (0 <= i < n_fft) of the zero-padded, windowed frame starting at signal position s0
 // (= k*hop - win/2).  stft.rs:137-146
-TH_HD float frame_value(const float *wav, uint32_t n_samples, int64_t s0, uint32_t i, const float *window,
-                        const StftGeom &g) {
+template <class WavPtr, class WinPtr>
+TH_HD float frame_value(WavPtr wav, uint32_t n_samples, int64_t s0, uint32_t i, WinPtr window, const StftGeom &g) {
     if (i < g.pad_left || i >= g.pad_left + g.win) return 0.0f;
     const uint32_t wi = i - g.pad_left;
     return wav[reflect_index(s0 + (int64_t)wi, n_samples)] * window[wi];
@@ -101,8 +117,9 @@ TH_HD void fft4(cf32 &a0, cf32 &a1, cf32 &a2, cf32 &a3) {
 //   v_r = in[j + r*Nc/R] * W_{Ns*R}^{r*k},  k = j mod Ns;  out[(j-k)*R + k + r*Ns] = DFT_R(v)_r
 // tw[i] = exp(-2*pi*i * i / n_fft), i in [0, n_fft).
 // ---------------------------------------------------------------------------------------------
-TH_HD void gen_load(uint32_t tid, uint32_t nthr, const StftGeom &g, const float *wav, uint32_t n_samples,
-                    int64_t s0, const float *window, cf32 *buf) {
+template <class WavPtr, class WinPtr>
+TH_HD void gen_load(uint32_t tid, uint32_t nthr, const StftGeom &g, WavPtr wav, uint32_t n_samples, int64_t s0,
+                    WinPtr window, cf32 *buf) {
     for (uint32_t n = tid; n < g.nc; n += nthr) {
         cf32 z;
         z.re = frame_value(wav, n_samples, s0, 2 * n, window, g);

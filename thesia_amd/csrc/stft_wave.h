@@ -112,15 +112,15 @@ struct WaveFftCfg<11> {  // n_fft = 4096: Nc = 2048 = 16 * 16 * 8, P = 32
     static constexpr int R1 = 16, R2 = 16, R3 = 8;
 };
 
-// LDS index swizzle for the first exchange (pass-1 output, Ns = 1): lane j writes the R1
-// consecutive slots R1*jj + r; XOR-ing the low bits with bits of the row index makes each
-// ds_write_b64 lane group hit 16 distinct bank pairs, and keeps 16-aligned blocks intact for the
-// consecutive-lane reads of pass 2.
+// LDS layout of the first exchange (pass-1 output, Ns = 1): lane jj writes the R1 consecutive
+// slots R1*jj + r.  Rows are padded by one slot (pad1(i) = i + i/R1): the 16 lanes of a
+// ds_write_b64 group then start 2 banks apart and never collide, and — unlike an XOR swizzle —
+// every address is "per-lane base + compile-time immediate" for the writes (base = (R1+1)*jj, imm = r)
+// and for the reads of pass 2 (i = lane + 64*m: base = pad1(lane), imm = (64 + 64/R1)*m), so no
+// address registers stay live across the frame loop.
 template <int R1>
-TH_HD uint32_t swz1(uint32_t i) {
-    if (R1 == 16) return i ^ ((i >> 4) & 15u);
-    if (R1 == 8) return i ^ ((i >> 4) & 7u);
-    return i;
+TH_HD uint32_t pad1(uint32_t i) {
+    return i + i / R1;
 }
 
 template <int LOG2_NC>
@@ -157,11 +157,11 @@ struct WaveFft {
             for (int r = 0; r < R1; r++) v[r] = z[b + B1 * r];
             RegDft<R1>::run(v);
             const uint32_t jj = lane + 64u * b;
-            for (int r = 0; r < R1; r++) slab[swz1<R1>(jj * R1 + r)] = v[RegDft<R1>::slot(r)];
+            for (int r = 0; r < R1; r++) slab[jj * (R1 + 1) + r] = v[RegDft<R1>::slot(r)];  // = pad1(jj*R1 + r)
         }
     }
     static TH_HD void read1(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
-        for (int m = 0; m < P; m++) z[m] = slab[swz1<R1>(lane + 64u * m)];
+        for (int m = 0; m < P; m++) z[m] = slab[pad1<R1>(lane) + (64u + 64u / R1) * m];  // = pad1(lane + 64*m)
     }
 
     // pass 2 (Ns = R1): registers -> LDS slab (linear)
@@ -192,12 +192,16 @@ struct WaveFft {
         }
     }
 
-    // split exchange: publish Z, then fetch the mirror partner Z[(Nc - k) mod Nc] of every own k
+    // split exchange: publish Z (plus Z[0] again at slot Nc, so the mirror index Nc - k needs no
+    // wrap-around), then every lane fetches the partner Z[Nc - k] of each own k = lane + 64*m:
+    // index (Nc - lane - 64*(P-1)) + 64*(P-1-m) = per-lane base + immediate.
+    static constexpr int SLAB_LEN = NC + NC / R1 > NC + 1 ? NC + NC / R1 : NC + 1;  // padded pass-1 image is the largest
     static TH_HD void write_z(uint32_t lane, const cf32 (&z)[P], cf32 *slab) {
         for (int m = 0; m < P; m++) slab[lane + 64u * m] = z[m];
+        if (lane == 0) slab[NC] = z[0];
     }
-    static TH_HD void read_mirror(uint32_t lane, cf32 (&zm)[P], const cf32 *slab) {
-        for (int m = 0; m < P; m++) zm[m] = slab[(NC - (lane + 64u * m)) & (NC - 1)];
+    static TH_HD cf32 read_mirror(uint32_t lane, int m, const cf32 *slab) {
+        return slab[(NC - 64u * (P - 1) - lane) + 64u * (P - 1 - m)];
     }
 };
 
@@ -223,19 +227,15 @@ namespace th {
 // last few per channel, and every frame of inputs shorter than the window) go to the generic
 // kernel, which implements the reflect padding.
 // ---------------------------------------------------------------------------------------------
-struct __attribute__((aligned(4))) f32x2_u {  // 8-byte load that only assumes 4-byte alignment
-    float a, b;
-};
-
-template <int P, bool PADDED>
-TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], const float *wav, int64_t e0, const StftGeom &g) {
+template <int P, bool PADDED, class WavPtr>
+TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0, const StftGeom &g) {
     for (int m = 0; m < P; m++) {
         const uint32_t n = lane + 64u * m;
         float x0 = 0.0f, x1 = 0.0f;
         if (!PADDED) {
-            const f32x2_u v = *reinterpret_cast<const f32x2_u *>(wav + (e0 + 2 * (int64_t)n));
-            x0 = v.a;
-            x1 = v.b;
+            const WavPtr p = wav + (e0 + 2 * (int64_t)n);  // two adjacent dwords: merged into one 8-byte load
+            x0 = p[0];
+            x1 = p[1];
         } else {
             const uint32_t i0 = 2 * n - g.pad_left, i1 = i0 + 1;  // unsigned: < win  <=>  inside the window
             if (i0 < g.win) x0 = wav[e0 + 2 * (int64_t)n];
