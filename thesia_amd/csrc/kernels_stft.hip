@@ -176,7 +176,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// A wave's position in its workgroup's tile range.
+// A wave's position in its workgroup's tile range.  All members are wave-uniform (SGPRs).
 struct FrameCursor {
     uint32_t tile, tile_end, f, f1, mm_index;
     gptr<const float> wav;
@@ -184,36 +184,39 @@ struct FrameCursor {
     bool valid;
 };
 
+// advance to the next tile (of this workgroup's range, starting at c.tile) that has a frame for
+// this wave
 template <int WAVES>
-__device__ __forceinline__ void cursor_open_tile(FrameCursor &c, const StftGeom &g, const ChanJob *__restrict__ jobs,
-                                                 const uint32_t *__restrict__ tile_start, uint32_t n_chan,
-                                                 uint32_t wave) {
-    // advance to the next tile (of this workgroup's range) that has a frame for this wave
+__device__ __forceinline__ FrameCursor cursor_open_tile(FrameCursor c, const StftGeom &g,
+                                                        const ChanJob *__restrict__ jobs,
+                                                        const uint32_t *__restrict__ tile_start, uint32_t n_chan,
+                                                        uint32_t wave) {
+    c.valid = false;
     for (; c.tile < c.tile_end; c.tile++) {
         const uint32_t chan = find_chan(tile_start, n_chan, c.tile);
-        const ChanJob job = jobs[chan];
-        const uint32_t f0 = job.f_begin + (c.tile - tile_start[chan]) * g.frames_per_tile;
-        const uint32_t f1 = min(f0 + g.frames_per_tile, job.f_end);
+        const uint32_t f0 = jobs[chan].f_begin + (c.tile - tile_start[chan]) * g.frames_per_tile;
+        const uint32_t f1 = min(f0 + g.frames_per_tile, jobs[chan].f_end);
         if (f0 + wave < f1) {
             c.f = f0 + wave;
             c.f1 = f1;
-            c.mm_index = job.mm_index;
-            c.wav = as_global(job.wav);
-            c.spec = as_global(job.spec);
+            c.mm_index = jobs[chan].mm_index;
+            c.wav = as_global(jobs[chan].wav);
+            c.spec = as_global(jobs[chan].spec);
             c.valid = true;
-            return;
+            break;
         }
     }
-    c.valid = false;
+    return c;
 }
 
 template <int WAVES>
-__device__ __forceinline__ void cursor_next(FrameCursor &c, const StftGeom &g, const ChanJob *__restrict__ jobs,
-                                            const uint32_t *__restrict__ tile_start, uint32_t n_chan, uint32_t wave) {
+__device__ __forceinline__ FrameCursor cursor_next(FrameCursor c, const StftGeom &g, const ChanJob *__restrict__ jobs,
+                                                   const uint32_t *__restrict__ tile_start, uint32_t n_chan,
+                                                   uint32_t wave) {
     c.f += WAVES;
-    if (c.f < c.f1) return;
+    if (c.f < c.f1) return c;
     c.tile++;
-    cursor_open_tile<WAVES>(c, g, jobs, tile_start, n_chan, wave);
+    return cursor_open_tile<WAVES>(c, g, jobs, tile_start, n_chan, wave);
 }
 
 template <int P, bool PADDED>
@@ -222,6 +225,15 @@ __device__ __forceinline__ void cursor_fetch(const FrameCursor &c, const StftGeo
     // frames to this kernel, so every windowed sample is inside the channel
     const int64_t e0 = (int64_t)c.f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
     wave_fetch<P, PADDED>(lane, x, c.wav, e0, g);
+}
+
+__device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_t slot, uint32_t lane, float lmin,
+                                             float lmax) {
+    const float a = wave_min(lmin), b = wave_max(lmax);
+    if (lane == 0) {
+        atomic_min_f32(&minmax[2 * slot], a);
+        atomic_max_f32(&minmax[2 * slot + 1], b);
+    }
 }
 
 template <int LOG2_NC, bool PADDED, int WAVES>
@@ -249,26 +261,14 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 
     cf32 *slab = slabs + (size_t)wave * W::SLAB_LEN;
     const uint32_t tiles_per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
-    FrameCursor cur;
+    FrameCursor cur{};
     cur.tile = min(blockIdx.x * tiles_per_wg, n_tiles);
     cur.tile_end = min(cur.tile + tiles_per_wg, n_tiles);
-    cursor_open_tile<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
+    cur = cursor_open_tile<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
 
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
-    uint32_t mm_chan = cur.valid ? cur.mm_index : 0u;
+    uint32_t mm_slot = cur.mm_index;
     bool mm_dirty = false;  // a wave that never got a frame must not touch any slot
-    auto flush_minmax = [&]() {
-        if (minmax != nullptr && mm_dirty) {
-            const float a = wave_min(lmin), b = wave_max(lmax);
-            if (lane == 0) {
-                atomic_min_f32(&minmax[2 * mm_chan], a);
-                atomic_max_f32(&minmax[2 * mm_chan + 1], b);
-            }
-        }
-        lmin = __builtin_inff();
-        lmax = -__builtin_inff();
-        mm_dirty = false;
-    };
 
     // Per-frame pipeline of one wave.  The next frame's samples are requested right after the last
     // register pass, when only z[] is live, and land during the split / dB / store epilogue and
@@ -295,15 +295,16 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         wave_lds_sync();
         __builtin_amdgcn_sched_barrier(0);
 
-        FrameCursor nxt = cur;
-        cursor_next<WAVES>(nxt, g, jobs, tile_start, n_chan, wave);
+        const FrameCursor nxt = cursor_next<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
         if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, x);  // in flight during the epilogue
         __builtin_amdgcn_sched_barrier(0);
 
-        if (cur.mm_index != mm_chan) {
-            flush_minmax();
-            mm_chan = cur.mm_index;
+        if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
+            flush_minmax(minmax, mm_slot, lane, lmin, lmax);
+            lmin = __builtin_inff();
+            lmax = -__builtin_inff();
         }
+        mm_slot = cur.mm_index;
         mm_dirty = true;
         const gptr<float> row = cur.spec + (size_t)cur.f * g.height;
 #pragma unroll
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
     }
-    flush_minmax();
+    if (minmax != nullptr && mm_dirty) flush_minmax(minmax, mm_slot, lane, lmin, lmax);
 }
 
 // ------------------------------------------------------------------------------------------
