@@ -26,6 +26,20 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
     for (uint32_t l = 0; l < 64; l++) W::pass1(l, z[l], slab.data());
     for (uint32_t l = 0; l < 64; l++) W::read1(l, z[l], slab.data());
     for (uint32_t l = 0; l < 64; l++) W::pass2(l, z[l], t2.data(), slab.data());
+    if (W::PAIRED) {  // mirror-local last pass: no third exchange
+        static cf32 za[64][W::NQ][W::R3], zb[64][W::NQ][W::R3];
+        for (uint32_t l = 0; l < 64; l++) W::read2_paired(l, za[l], zb[l], slab.data());
+        for (uint32_t l = 0; l < 64; l++) W::pass3_paired(l, za[l], zb[l], t3.data());
+        std::vector<int> hits(NC + 1, 0);
+        for (uint32_t l = 0; l < 64; l++)
+            W::split_paired(l, za[l], zb[l], tw, [&](uint32_t k, float p) {
+                row[k] = power_to_dB(p);
+                hits[k]++;
+            });
+        for (int k = 0; k <= NC; k++)
+            if (hits[k] != 1) row[k] = NAN;  // every bin must be emitted exactly once
+        return;
+    }
     for (uint32_t l = 0; l < 64; l++) W::read2(l, z[l], slab.data());
     for (uint32_t l = 0; l < 64; l++) W::pass3(l, z[l], t3.data());
     for (uint32_t l = 0; l < 64; l++) W::write_z(l, z[l], slab.data());

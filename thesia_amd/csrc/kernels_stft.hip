@@ -288,42 +288,66 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         W::pass2(lane, z, t2, slab);
         wave_lds_sync();
         __builtin_amdgcn_sched_barrier(0);
-        W::read2(lane, z, slab);
-        W::pass3(lane, z, t3);
-        wave_lds_sync();
-        W::write_z(lane, z, slab);
-        wave_lds_sync();
-        __builtin_amdgcn_sched_barrier(0);
 
-        const FrameCursor nxt = cursor_next<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
-        if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, x);  // in flight during the epilogue
-        __builtin_amdgcn_sched_barrier(0);
-
-        if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
-            flush_minmax(minmax, mm_slot, lane, lmin, lmax);
-            lmin = __builtin_inff();
-            lmax = -__builtin_inff();
+        FrameCursor nxt;
+        if constexpr (W::PAIRED) {
+            // mirror-local last pass: every Z[k] / Z[Nc-k] pair ends up in one lane's registers
+            cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
+            W::read2_paired(lane, za, zb, slab);
+            wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
+            W::pass3_paired(lane, za, zb, t3);
+            __builtin_amdgcn_sched_barrier(0);
+            nxt = cursor_next<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
+            if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, x);  // in flight during the epilogue
+            __builtin_amdgcn_sched_barrier(0);
+            if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
+                flush_minmax(minmax, mm_slot, lane, lmin, lmax);
+                lmin = __builtin_inff();
+                lmax = -__builtin_inff();
+            }
+            const gptr<float> row = cur.spec + (size_t)cur.f * g.height;
+            W::split_paired(lane, za, zb, stw, [&](uint32_t k, float p) {
+                const float d = power_to_dB(p);
+                row[k] = d;
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            });
+        } else {
+            W::read2(lane, z, slab);
+            W::pass3(lane, z, t3);
+            wave_lds_sync();
+            W::write_z(lane, z, slab);
+            wave_lds_sync();
+            __builtin_amdgcn_sched_barrier(0);
+            nxt = cursor_next<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
+            if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, x);  // in flight during the epilogue
+            __builtin_amdgcn_sched_barrier(0);
+            if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
+                flush_minmax(minmax, mm_slot, lane, lmin, lmax);
+                lmin = __builtin_inff();
+                lmax = -__builtin_inff();
+            }
+            const gptr<float> row = cur.spec + (size_t)cur.f * g.height;
+#pragma unroll
+            for (int m = 0; m < P; m++) {
+                const uint32_t k = lane + 64u * m;
+                const cf32 zm = W::read_mirror(lane, m, slab);  // mirror partner Z[Nc - k]
+                const float d = power_to_dB(split_power(z[m], zm, stw[k]));
+                row[k] = d;
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            }
+            if (lane == 0) {  // Nyquist bin k = Nc: partner of Z[0] is Z[0], W^Nc = -1
+                const cf32 wn = {-1.0f, 0.0f};
+                const float d = power_to_dB(split_power(z[0], z[0], wn));
+                row[NC] = d;
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            }
+            wave_lds_sync();  // the slab is rewritten by the next frame's pass 1
         }
         mm_slot = cur.mm_index;
         mm_dirty = true;
-        const gptr<float> row = cur.spec + (size_t)cur.f * g.height;
-#pragma unroll
-        for (int m = 0; m < P; m++) {
-            const uint32_t k = lane + 64u * m;
-            const cf32 zm = W::read_mirror(lane, m, slab);  // mirror partner Z[Nc - k]
-            const float d = power_to_dB(split_power(z[m], zm, stw[k]));
-            row[k] = d;
-            lmin = nmin(lmin, d);
-            lmax = nmax(lmax, d);
-        }
-        if (lane == 0) {  // Nyquist bin k = Nc: partner of Z[0] is Z[0], W^Nc = -1
-            const cf32 wn = {-1.0f, 0.0f};
-            const float d = power_to_dB(split_power(z[0], z[0], wn));
-            row[NC] = d;
-            lmin = nmin(lmin, d);
-            lmax = nmax(lmax, d);
-        }
-        wave_lds_sync();  // the slab is rewritten by the next frame's pass 1
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
     }

@@ -203,6 +203,87 @@ struct WaveFft {
     static TH_HD cf32 read_mirror(uint32_t lane, int m, const cf32 *slab) {
         return slab[(NC - 64u * (P - 1) - lane) + 64u * (P - 1 - m)];
     }
+
+    // -----------------------------------------------------------------------------------------
+    // Mirror-local last pass (used when B3 is even).  The real-FFT split pass needs Z[k] together
+    // with Z[Nc - k].  Output k = jj + r*Ns3 of butterfly jj mirrors to output R3-1-r of butterfly
+    // Ns3 - jj, so a lane that owns both butterflies of such a pair has every partner in its own
+    // registers and the third LDS exchange disappears.  Lane l owns the pairs (A_q, B_q), q < B3/2:
+    //     A_q = 64*q + l,   B_q = Ns3 - A_q
+    // except lane 0, q = 0, which owns the two self-mirrored butterflies A = 0 and B = Ns3/2
+    // (their outputs pair up inside each butterfly; k = 0 also yields the Nyquist bin Nc).
+    // -----------------------------------------------------------------------------------------
+    static constexpr bool PAIRED = (B3 % 2 == 0);
+    static constexpr int NQ = PAIRED ? B3 / 2 : 1;
+    static TH_HD uint32_t jj_a(uint32_t lane, int q) { return 64u * q + lane; }
+    static TH_HD uint32_t jj_b(uint32_t lane, int q) {
+        return (q == 0 && lane == 0) ? (uint32_t)NS3 / 2 : (uint32_t)NS3 - 64u * q - lane;
+    }
+    // exchange-2 read in the paired layout: za[q][r] = in[A_q + r*Ns3], zb[q][r] = in[B_q + r*Ns3]
+    static TH_HD void read2_paired(uint32_t lane, cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 *slab) {
+        for (int q = 0; q < NQ; q++) {
+            const uint32_t a = jj_a(lane, q), b = jj_b(lane, q);
+            for (int r = 0; r < R3; r++) {
+                za[q][r] = slab[a + (uint32_t)r * NS3];
+                zb[q][r] = slab[b + (uint32_t)r * NS3];
+            }
+        }
+    }
+    static TH_HD void bfly3(cf32 (&v)[R3], uint32_t jj, const cf32 *t3) {
+        cf32 w[R3];
+        w[0] = v[0];
+        for (int r = 1; r < R3; r++) w[r] = cmul(v[r], t3[(r - 1) * NS3 + jj]);
+        RegDft<R3>::run(w);
+        for (int r = 0; r < R3; r++) v[r] = w[RegDft<R3>::slot(r)];
+    }
+    // last pass: za[q][r] <- Z[A_q + r*Ns3], zb[q][r] <- Z[B_q + r*Ns3]
+    static TH_HD void pass3_paired(uint32_t lane, cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 *t3) {
+        for (int q = 0; q < NQ; q++) {
+            bfly3(za[q], jj_a(lane, q), t3);
+            bfly3(zb[q], jj_b(lane, q), t3);
+        }
+    }
+    // Split pass on lane-local pairs.  emit(k, |X[k]|^2) is called once for every bin this lane owns
+    // (k in [0, Nc]; lane 0 owns 17 of the 1025 at Nc = 1024, every other lane 16).
+    // stw[k] = W_{n_fft}^k = exp(-2 pi i k / (2 Nc)), k < Nc.
+    template <class Emit>
+    static TH_HD void split_paired(uint32_t lane, const cf32 (&za)[NQ][R3], const cf32 (&zb)[NQ][R3], const cf32 *stw,
+                                   Emit emit) {
+        const bool l0 = lane == 0;
+        for (int q = 0; q < NQ; q++) {
+            for (int s = 0; s < R3; s++) {
+                cf32 zk = za[q][s], zm = zb[q][R3 - 1 - s];
+                uint32_t k = jj_a(lane, q) + (uint32_t)s * NS3;
+                if (q == 0) {  // lane 0: pairs inside butterfly 0 (s < R3/2) and inside butterfly Ns3/2
+                    const int rp = s - R3 / 2;
+                    const cf32 zk0 = s < R3 / 2 ? za[0][s] : zb[0][rp];
+                    const cf32 zm0 = s < R3 / 2 ? za[0][(R3 - s) % R3] : zb[0][R3 - 1 - rp];
+                    const uint32_t k0 = s < R3 / 2 ? (uint32_t)s * NS3 : (uint32_t)NS3 / 2 + (uint32_t)rp * NS3;
+                    zk.re = l0 ? zk0.re : zk.re;
+                    zk.im = l0 ? zk0.im : zk.im;
+                    zm.re = l0 ? zm0.re : zm.re;
+                    zm.im = l0 ? zm0.im : zm.im;
+                    k = l0 ? k0 : k;
+                }
+                const cf32 w = stw[k];
+                // e = Z[k] + conj Z[Nc-k];  d = Z[k] - conj Z[Nc-k];  t = W^k * (-i d)
+                // X[k] = e + t,  X[Nc-k] = conj(e - t)
+                const float er = zk.re + zm.re, ei = zk.im - zm.im;
+                const float dr = zk.re - zm.re, di = zk.im + zm.im;
+                const float tr = di * w.re + dr * w.im, ti = di * w.im - dr * w.re;
+                const float xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
+                emit(k, xr * xr + xi * xi);
+                emit((uint32_t)NC - k, yr * yr + yi * yi);
+            }
+        }
+        if (l0) {  // the self-mirrored bin Nc/2 = output R3/2 of butterfly 0
+            const cf32 z = za[0][R3 / 2];
+            const cf32 w = stw[NC / 2];
+            const float er = 2.0f * z.re, di = 2.0f * z.im;  // zm = zk: e = (2 re, 0), d = (0, 2 im)
+            const float xr = er + di * w.re, xi = di * w.im;
+            emit((uint32_t)NC / 2, xr * xr + xi * xi);
+        }
+    }
 };
 
 // |X[k]|^2 from the half-scaled packed spectrum (window pre-multiplied by 1/2):
