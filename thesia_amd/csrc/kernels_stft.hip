@@ -168,6 +168,12 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
 // registers before it transforms the current one, so HBM latency is covered even at 2-4 waves
 // per SIMD.  HBM traffic per frame: 4*hop B read + 4*n_freq B written.
 // ------------------------------------------------------------------------------------------
+#if defined(TH_NO_SCHED_BARRIER)
+#define TH_SCHED_BARRIER() ((void)0)
+#else
+#define TH_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // Orders this wave's LDS writes before its later LDS reads (and vice versa) for the compiler; the
 // hardware already executes one wave's DS instructions in order, so no instruction is needed.
 __device__ __forceinline__ void wave_lds_sync() {
@@ -282,12 +288,12 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         wave_window<P>(lane, z, x, wtab);
         W::pass1(lane, z, slab);
         wave_lds_sync();
-        __builtin_amdgcn_sched_barrier(0);
+        TH_SCHED_BARRIER();
         W::read1(lane, z, slab);
         wave_lds_sync();
         W::pass2(lane, z, t2, slab);
         wave_lds_sync();
-        __builtin_amdgcn_sched_barrier(0);
+        TH_SCHED_BARRIER();
 
         FrameCursor nxt;
         if constexpr (W::PAIRED) {
@@ -296,10 +302,10 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             W::read2_paired(lane, za, zb, slab);
             wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
             W::pass3_paired(lane, za, zb, t3);
-            __builtin_amdgcn_sched_barrier(0);
+            TH_SCHED_BARRIER();
             nxt = cursor_next<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
             if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, x);  // in flight during the epilogue
-            __builtin_amdgcn_sched_barrier(0);
+            TH_SCHED_BARRIER();
             if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
                 flush_minmax(minmax, mm_slot, lane, lmin, lmax);
                 lmin = __builtin_inff();
@@ -318,10 +324,10 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             wave_lds_sync();
             W::write_z(lane, z, slab);
             wave_lds_sync();
-            __builtin_amdgcn_sched_barrier(0);
+            TH_SCHED_BARRIER();
             nxt = cursor_next<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
             if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, x);  // in flight during the epilogue
-            __builtin_amdgcn_sched_barrier(0);
+            TH_SCHED_BARRIER();
             if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
                 flush_minmax(minmax, mm_slot, lane, lmin, lmax);
                 lmin = __builtin_inff();
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         }
         mm_slot = cur.mm_index;
         mm_dirty = true;
-        __builtin_amdgcn_sched_barrier(0);
+        TH_SCHED_BARRIER();
         cur = nxt;
     }
     if (minmax != nullptr && mm_dirty) flush_minmax(minmax, mm_slot, lane, lmin, lmax);
