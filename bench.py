@@ -50,14 +50,14 @@ def parse_args():
     return ap.parse_args()
 
 
-def synth_on_gpu(torch, dev, track0: int, n_tracks: int, sr: int, n: int):
+def synth_on_gpu(torch, dev, track_ids, sr: int, n: int):
     """tests/synth.py's signal, evaluated on the GPU (f64 phase, same seeded parameters)."""
     from tests.synth import track_params
-    out = torch.empty((n_tracks, n), dtype=torch.float32, device=dev)
+    out = torch.empty((len(track_ids), n), dtype=torch.float32, device=dev)
     t = torch.arange(n, dtype=torch.float64, device=dev) / sr
     dur = n / sr
-    for i in range(n_tracks):
-        freqs, amps, phases, chirp_amp, noise_seed = track_params(track0 + i, sr)
+    for i, tid in enumerate(track_ids):
+        freqs, amps, phases, chirp_amp, noise_seed = track_params(tid, sr)
         x = torch.zeros(n, dtype=torch.float64, device=dev)
         for f, a, p in zip(freqs, amps, phases):
             x += a * torch.sin(2 * np.pi * f * t + p)
@@ -72,14 +72,15 @@ def synth_on_gpu(torch, dev, track0: int, n_tracks: int, sr: int, n: int):
 class Workload:
     """Device-resident batch + descriptor tables for one GPU."""
 
-    def __init__(self, torch, ta, ctx, dev, track0, n_tracks, sr, n, win, hop, n_fft, kernel, cmap_bytes):
+    def __init__(self, torch, ta, ctx, dev, track_ids, sr, n, win, hop, n_fft, kernel, cmap_bytes):
         self.torch, self.ta, self.ctx = torch, ta, ctx
+        n_tracks = len(track_ids)
         self.n_tracks, self.n = n_tracks, n
         self.plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
         if kernel:
             self.plan.set_kernel(kernel)
         self.T, self.H = self.plan.n_frames(n), self.plan.height
-        self.wav = synth_on_gpu(torch, dev, track0, n_tracks, sr, n)
+        self.wav = synth_on_gpu(torch, dev, track_ids, sr, n)
         self.spec = torch.empty((n_tracks, self.T, self.H), dtype=torch.float32, device=dev)
         self.img = torch.empty((n_tracks, self.H, self.T), dtype=torch.int16, device=dev)
         self.minmax = torch.empty((n_tracks, 2), dtype=torch.float32, device=dev)
@@ -226,8 +227,11 @@ def main():
     side = torch.cuda.Stream(dev)
     torch.cuda.set_stream(side)
     ctx = ta.Context(local_rank, side.cuda_stream)
-    wl = Workload(torch, ta, ctx, dev, rank * args.tracks_per_gpu, args.tracks_per_gpu, sr, n, win, hop, n_fft,
-                  args.kernel, cmap_bytes)
+    # shard the global track list over ranks by frame count (th_shard_assign; equal tracks -> round-robin)
+    total_tracks = args.tracks_per_gpu * world
+    owner = ta.shard_assign([ta.stft_n_frames(n, win, hop)] * total_tracks, world)
+    mine = [i for i in range(total_tracks) if owner[i] == rank]
+    wl = Workload(torch, ta, ctx, dev, mine, sr, n, win, hop, n_fft, args.kernel, cmap_bytes)
 
     def barrier():
         if dist is not None:
@@ -266,7 +270,7 @@ def main():
 
     single = None
     if rank == 0 and not args.no_single_track:
-        w1 = Workload(torch, ta, ctx, dev, 0, 1, sr, 60 * sr, win, hop, n_fft, args.kernel, cmap_bytes)
+        w1 = Workload(torch, ta, ctx, dev, [0], sr, 60 * sr, win, hop, n_fft, args.kernel, cmap_bytes)
         for _ in range(3):
             w1.step(None)
         torch.cuda.synchronize(dev)

@@ -101,6 +101,12 @@ TH_API int th_hz_range_to_idx(int freq_scale, float hz_min, float hz_max, uint32
 TH_API int th_global_db_range(const float *mins, const float *maxs, size_t n, float dB_range, float *min_dB,
                               float *max_dB);
 
+/* Multi-GPU partitioning of independent (track, channel) units (core/mod.rs:153-163 fans the same
+ * units out over rayon threads): deterministic longest-processing-time assignment of units to
+ * `world` ranks by weight (frame count).  owner[i] receives the rank of unit i.  No data-path
+ * collective is involved; the only exchange of the path is the 2-float dB-range all-reduce. */
+TH_API int th_shard_assign(const uint64_t *weights, size_t n_units, uint32_t world, uint32_t *owner);
+
 typedef struct {
     uint32_t width, height;       /* tile size in LOD pixels (0,0 = empty tile) */
     uint32_t origin_x, origin_y;  /* tile origin in LOD pixels */

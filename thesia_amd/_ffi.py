@@ -95,6 +95,7 @@ _SIGS = {
     "th_mel_default_n_mel": [C.c_uint32, C.c_size_t, c_szp],
     "th_hz_range_to_idx": [C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_size_t, c_szp, c_szp],
     "th_global_db_range": [c_f32p, c_f32p, C.c_size_t, C.c_float, c_f32p, c_f32p],
+    "th_shard_assign": [C.POINTER(C.c_uint64), C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)],
     "th_spectrogram_tile_geometry": [C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.POINTER(TileGeom)],
     "th_waveform_tile_geometry": [C.c_size_t, C.c_uint32, C.c_uint32, c_szp, c_szp, c_szp],

@@ -82,6 +82,15 @@ def global_db_range(mins, maxs, dB_range: float = 100.0):
     return lo.value, hi.value
 
 
+def shard_assign(weights, world: int):
+    """th_shard_assign: owner rank of every (track, channel) unit, by frame-count weight."""
+    w = np.ascontiguousarray(weights, dtype=np.uint64)
+    owner = np.empty(w.size, np.uint32)
+    check(lib.th_shard_assign(w.ctypes.data_as(C.POINTER(C.c_uint64)), w.size, world,
+                              owner.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return owner
+
+
 def spectrogram_tile_geometry(img_width: int, img_height: int, level_x: int, level_y: int, tile_x: int,
                               tile_y: int) -> TileGeom:
     g = TileGeom()

@@ -108,6 +108,15 @@ TH_API int th_global_db_range(const float *mins, const float *maxs, size_t n, fl
     TH_CATCH
 }
 
+TH_API int th_shard_assign(const uint64_t *weights, size_t n_units, uint32_t world, uint32_t *owner) {
+    TH_TRY
+    TH_REQUIRE(world >= 1, "world must be >= 1");
+    TH_REQUIRE(n_units == 0 || (weights && owner), "NULL pointer");
+    shard_assign(weights, n_units, world, owner);
+    return TH_OK;
+    TH_CATCH
+}
+
 TH_API int th_spectrogram_tile_geometry(size_t W, size_t Hh, uint32_t lx, uint32_t ly, uint32_t tx, uint32_t ty,
                                         th_tile_geom *geom) {
     TH_TRY

@@ -2,6 +2,7 @@
 // (paths relative to the reference checkout).
 #include "host_math.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -149,6 +150,23 @@ void global_db_range(const float *mins, const float *maxs, size_t n, float dB_ra
     lo = rs_max(lo, hi - dB_range);
     *mn = lo;
     *mx = hi;
+}
+
+// Longest-processing-time-first assignment: units sorted by weight (descending, index ascending
+// on ties) go to the currently least-loaded rank (lowest rank on ties).  Equal weights reduce to
+// round-robin, e.g. 1024 equal tracks on 8 GPUs = 128 per GPU.
+void shard_assign(const uint64_t *weights, size_t n, uint32_t world, uint32_t *owner) {
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weights[a] > weights[b]; });
+    std::vector<uint64_t> load(world, 0);
+    for (size_t i : order) {
+        uint32_t best = 0;
+        for (uint32_t r = 1; r < world; r++)
+            if (load[r] < load[best]) best = r;
+        owner[i] = best;
+        load[best] += weights[i];
+    }
 }
 
 static inline size_t sat_mul(size_t a, size_t b) {

@@ -17,6 +17,7 @@ float mel_to_hz(float mel);
 std::vector<float> calc_mel_fb(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, bool do_norm);
 size_t mel_default_n_mel(uint32_t sr, size_t n_fft);
 void hz_range_to_idx(int freq_scale, float hz0, float hz1, uint32_t sr, size_t n, size_t *i0, size_t *i1);
+void shard_assign(const uint64_t *weights, size_t n, uint32_t world, uint32_t *owner);
 void global_db_range(const float *mins, const float *maxs, size_t n, float dB_range, float *mn, float *mx);
 
 struct TileGeom {
