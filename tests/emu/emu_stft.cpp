@@ -21,7 +21,7 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
     std::vector<cf32> t2(W::T2_LEN), t3(W::T3_LEN);
     const int64_t e0 = (int64_t)frame * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
     for (uint32_t t = 0; t < 256; t++) W::fill_tables(t, 256, tw, t2.data(), t3.data());
-    for (uint32_t l = 0; l < 64; l++) wave_fetch<P, PADDED>(l, x[l], wav, e0, g);
+    for (uint32_t l = 0; l < 64; l++) wave_fetch<P, PADDED, 0>(l, x[l], wav, e0, g);
     for (uint32_t l = 0; l < 64; l++) wave_window<P>(l, z[l], x[l], wtab);
     for (uint32_t l = 0; l < 64; l++) W::pass1(l, z[l], slab.data());
     for (uint32_t l = 0; l < 64; l++) W::read1(l, z[l], slab.data());

@@ -307,6 +307,7 @@ bool th_plan::use_wave() const {
 static void plan_free(th_plan *p) {
     if (!p) return;
     if (p->d_wtab) (void)hipFree(p->d_wtab);
+    if (p->d_queue_head) (void)hipFree(p->d_queue_head);
     if (p->d_window) (void)hipFree(p->d_window);
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_mel_fb) (void)hipFree(p->d_mel_fb);
@@ -370,6 +371,10 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
         rc = up((void **)&p->d_wtab, wpad.data(), wpad.size() * sizeof(float));
     }
     if (rc == TH_OK) rc = up((void **)&p->d_window, w.data(), w.size() * sizeof(float));
+    if (rc == TH_OK) {
+        const uint32_t zero = 0;
+        rc = up((void **)&p->d_queue_head, &zero, sizeof zero);
+    }
     if (rc == TH_OK) rc = up((void **)&p->d_tw, tw.data(), tw.size() * sizeof(cf32));
     if (rc == TH_OK && freq_scale == TH_FREQ_MEL) {
         if (n_mel == 0) n_mel = mel_default_n_mel(sr, n_fft);  // calc_mel_fb_default, lib.rs:91-103
@@ -432,6 +437,7 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 8 || wv == 12 || wv == 16, "waves per workgroup must be 4, 8, 12 or 16");
     p->kernel_choice = k;
     p->wave_waves = wv;
+    p->wave_chunk = (which >> 16) & 0xff;  // tuning: frames per chunk of the wave kernel (0 = default)
     return TH_OK;
     TH_CATCH
 }
@@ -455,7 +461,9 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     StftGeom g = p->g;       // main launch
     StftGeom ge = p->g;      // edge launch (generic kernel)
     const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);
-    g.frames_per_tile = wave ? 4 * waves : 8;
+    // wave kernel: chunk of consecutive frames one wave walks (first frame loads everything, the rest
+    // only hop new samples)
+    g.frames_per_tile = wave ? (p->wave_chunk > 0 ? (uint32_t)p->wave_chunk : 16u) : 8u;
     ge.frames_per_tile = 1;
     // main jobs: the wave kernel takes the interior frames [fa, fb) of every channel (all windowed
     // samples inside the signal); the generic kernel takes the boundary frames (reflect padding,
@@ -504,11 +512,11 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
         if (rc == TH_OK) rc = p->edge_tile_start.upload(c->stream, edge_start.data(), edge_start.size() * sizeof(uint32_t));
     }
     if (rc != TH_OK) return rc;
-    TH_HIP(launch_minmax_init(d_minmax, (uint32_t)n_chan, c->stream));
+    TH_HIP(launch_minmax_init(d_minmax, (uint32_t)n_chan, wave ? p->d_queue_head : nullptr, c->stream));
     if (wave) {
         TH_HIP(launch_stft_wave(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
-                                (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, d_minmax, c->n_cu, waves,
-                                c->stream));
+                                (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, d_minmax, p->d_queue_head,
+                                c->n_cu, waves, c->stream));
         if (!edge.empty())
             TH_HIP(launch_stft_generic(ge, (const ChanJob *)p->edge_jobs.dptr, (const uint32_t *)p->edge_tile_start.dptr,
                                        (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, nullptr,

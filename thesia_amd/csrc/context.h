@@ -52,9 +52,11 @@ struct th_plan {
     int freq_scale = 0;
     int kernel_choice = 0;  // 0 auto, 1 generic, 2 wave
     int wave_waves = 0;     // tuning: waves per workgroup of the wave kernel (0 = default)
+    int wave_chunk = 0;     // tuning: frames per chunk of the wave kernel (0 = default)
     th::StftGeom g{};
     float *d_window = nullptr;
     th::cf32 *d_tw = nullptr;
+    uint32_t *d_queue_head = nullptr;  // wave kernel: chunk queue head (reset before every launch)
     th::cf32 *d_wtab = nullptr;  // wave kernel: 0.5 * zero-padded window as (even, odd) pairs
     bool use_wave() const;
     float *d_mel_fb = nullptr;

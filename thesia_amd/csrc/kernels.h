@@ -12,7 +12,7 @@
 namespace th {
 
 // ---- kernels_stft.hip
-hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, hipStream_t s);
+hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queue_head, hipStream_t s);
 size_t stft_generic_lds_bytes(const StftGeom &g);
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                uint32_t n_chan, uint32_t n_tiles, const float *d_window, const cf32 *d_tw,
@@ -23,8 +23,8 @@ bool stft_wave_supported(const StftGeom &g);
 int stft_wave_default_waves(const StftGeom &g);
 // waves: waves per workgroup (4, 8, 12 or 16; <= 0 selects the default for this n_fft)
 hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
-                            uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, uint32_t n_cu,
-                            int waves, hipStream_t s);
+                            uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
+                            uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s);
 
 // ---- kernels_image.hip
 struct ImgJob {  // device-visible copy of th_img_desc

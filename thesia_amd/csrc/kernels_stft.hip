@@ -28,9 +28,10 @@ __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
     else atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 
-__global__ void minmax_init_kernel(float *minmax, uint32_t n_chan) {
+__global__ void minmax_init_kernel(float *minmax, uint32_t n_chan, uint32_t *queue_head) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_chan) {
+    if (i == 0 && queue_head != nullptr) *queue_head = 0;  // work queue of the wave kernel
+    if (minmax != nullptr && i < n_chan) {
         minmax[2 * i] = __builtin_inff();
         minmax[2 * i + 1] = -__builtin_inff();
     }
@@ -156,17 +157,23 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
 // Wave kernel (the fast path): one 64-lane wave per frame, n_fft in {1024, 2048, 4096}, linear
 // frequency scale.  See stft_wave.h for the FFT structure.
 //
-// Launch shape: a persistent grid of (at most) one workgroup per CU, WAVES waves each.  The
-// workgroup shares read-only LDS tables (half-scaled zero-padded window, split-pass twiddles and
-// the pass-2 / pass-3 twiddles) and gives every wave a private exchange slab:
-//   LDS = 8 B * (2*Nc + T2_LEN + T3_LEN) + WAVES * 8 B * (Nc + Nc/R1)   (n_fft=2048, 16 waves: 159.9 KB)
-// After the table fill there is no workgroup barrier: waves run independently.
-// Work split: tiles (frames_per_tile consecutive frames of one channel) are dealt to workgroups in
-// contiguous ranges; inside a tile wave w takes frames f0+w, f0+w+WAVES, ... so the waves of a CU
-// read one contiguous, overlapping sample span at the same time (the 4x hop overlap is served by
-// L1/L2; HBM sees each sample once).  Each wave prefetches its next frame's samples into
-// registers before it transforms the current one, so HBM latency is covered even at 2-4 waves
-// per SIMD.  HBM traffic per frame: 4*hop B read + 4*n_freq B written.
+// Launch shape: a persistent grid of one workgroup per CU, WAVES waves each.  The workgroup shares
+// read-only LDS tables (half-scaled zero-padded window, split-pass twiddles, pass-2 / pass-3
+// twiddles) and gives every wave a private exchange slab:
+//   LDS = 8 B * (2*Nc + T2_LEN + T3_LEN) + WAVES * 8 B * (Nc + Nc/R1)
+// After the table fill there is no workgroup barrier: waves are independent.
+//
+// Work distribution: the interior frames of every channel are cut into CHUNKS of frames_per_tile
+// consecutive frames; each wave pulls the next chunk index from a device-wide queue head (one
+// returning atomicAdd per chunk) and walks its frames in order.  Walking consecutive frames is what
+// makes the hop overlap free: with hop a multiple of 128 samples, frame f+1 is frame f shifted by
+// S = hop/128 register slots, so a wave keeps its raw samples in registers, moves them S slots and
+// loads only the S new slots (4 of 16 at hop = n_fft/4).  Every sample then reaches the CU once
+// per chunk instead of once per overlapping frame (measured before: 2.4x read amplification at
+// the fabric, because four waves requesting the same lines at the same time are not merged).
+// The loads for frame f+1 are issued right after frame f's window multiply, a whole FFT ahead of
+// their use.  HBM traffic per frame: 4*hop B read (+ (n_fft - hop)*4 B once per chunk) and
+// 4*n_freq B written.
 // ------------------------------------------------------------------------------------------
 #if defined(TH_NO_SCHED_BARRIER)
 #define TH_SCHED_BARRIER() ((void)0)
@@ -182,55 +189,49 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// A wave's position in its workgroup's tile range.  All members are wave-uniform (SGPRs).
+// A wave's position in the frame stream.  All members are wave-uniform (SGPRs).
 struct FrameCursor {
-    uint32_t tile, tile_end, f, f1, mm_index;
+    uint32_t f, f1, mm_index;
     gptr<const float> wav;
     gptr<float> spec;
     bool valid;
+    bool fresh;  // first frame of a chunk: nothing of it is in registers yet
 };
 
-// advance to the next tile (of this workgroup's range, starting at c.tile) that has a frame for
-// this wave
-template <int WAVES>
-__device__ __forceinline__ FrameCursor cursor_open_tile(FrameCursor c, const StftGeom &g,
-                                                        const ChanJob *__restrict__ jobs,
-                                                        const uint32_t *__restrict__ tile_start, uint32_t n_chan,
-                                                        uint32_t wave) {
-    c.valid = false;
-    for (; c.tile < c.tile_end; c.tile++) {
-        const uint32_t chan = find_chan(tile_start, n_chan, c.tile);
-        const uint32_t f0 = jobs[chan].f_begin + (c.tile - tile_start[chan]) * g.frames_per_tile;
-        const uint32_t f1 = min(f0 + g.frames_per_tile, jobs[chan].f_end);
-        if (f0 + wave < f1) {
-            c.f = f0 + wave;
-            c.f1 = f1;
-            c.mm_index = jobs[chan].mm_index;
-            c.wav = as_global(jobs[chan].wav);
-            c.spec = as_global(jobs[chan].spec);
-            c.valid = true;
-            break;
-        }
+// pull the next chunk from the queue; every wave of the grid ends with valid == false
+__device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const ChanJob *__restrict__ jobs,
+                                                   const uint32_t *__restrict__ tile_start, uint32_t n_chan,
+                                                   uint32_t n_tiles, uint32_t *__restrict__ queue_head, uint32_t lane) {
+    FrameCursor c{};
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(queue_head, 1u);
+    t = __builtin_amdgcn_readfirstlane(t);
+    c.valid = t < n_tiles;
+    if (c.valid) {
+        const uint32_t chan = find_chan(tile_start, n_chan, t);
+        c.f = jobs[chan].f_begin + (t - tile_start[chan]) * g.frames_per_tile;
+        c.f1 = min(c.f + g.frames_per_tile, jobs[chan].f_end);
+        c.mm_index = jobs[chan].mm_index;
+        c.wav = as_global(jobs[chan].wav);
+        c.spec = as_global(jobs[chan].spec);
+        c.fresh = true;
     }
     return c;
 }
 
-template <int WAVES>
 __device__ __forceinline__ FrameCursor cursor_next(FrameCursor c, const StftGeom &g, const ChanJob *__restrict__ jobs,
                                                    const uint32_t *__restrict__ tile_start, uint32_t n_chan,
-                                                   uint32_t wave) {
-    c.f += WAVES;
+                                                   uint32_t n_tiles, uint32_t *__restrict__ queue_head, uint32_t lane) {
+    c.f += 1;
+    c.fresh = false;
     if (c.f < c.f1) return c;
-    c.tile++;
-    return cursor_open_tile<WAVES>(c, g, jobs, tile_start, n_chan, wave);
+    return cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
 }
 
-template <int P, bool PADDED>
-__device__ __forceinline__ void cursor_fetch(const FrameCursor &c, const StftGeom &g, uint32_t lane, cf32 (&x)[P]) {
-    // frame element 0 sits at signal position f*hop - win/2 - pad_left; the host only hands interior
-    // frames to this kernel, so every windowed sample is inside the channel
-    const int64_t e0 = (int64_t)c.f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
-    wave_fetch<P, PADDED>(lane, x, c.wav, e0, g);
+// frame element 0 sits at signal position f*hop - win/2 - pad_left; the host only hands interior
+// frames to this kernel, so every windowed sample is inside the channel
+__device__ __forceinline__ int64_t frame_e0(const FrameCursor &c, const StftGeom &g) {
+    return (int64_t)c.f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
 }
 
 __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_t slot, uint32_t lane, float lmin,
@@ -242,12 +243,17 @@ __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_
     }
 }
 
-template <int LOG2_NC, bool PADDED, int WAVES>
+// SHIFT = hop/128 register slots reused between consecutive frames (0 = no reuse: hop not a
+// multiple of 128 samples, hop >= n_fft, or a zero-padded window)
+template <int LOG2_NC, bool PADDED, int WAVES, int SHIFT>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
-    uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax) {
+    uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
+    uint32_t *__restrict__ queue_head) {
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
+    static_assert(SHIFT >= 0 && SHIFT < P, "shift must leave something to reuse");
+    static_assert(!(PADDED && SHIFT > 0), "a zero-padded window cannot reuse registers across frames");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *wtab = reinterpret_cast<cf32 *>(smem_raw);
     cf32 *stw = wtab + NC;
@@ -266,26 +272,29 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     __syncthreads();
 
     cf32 *slab = slabs + (size_t)wave * W::SLAB_LEN;
-    const uint32_t tiles_per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
-    FrameCursor cur{};
-    cur.tile = min(blockIdx.x * tiles_per_wg, n_tiles);
-    cur.tile_end = min(cur.tile + tiles_per_wg, n_tiles);
-    cur = cursor_open_tile<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
+    FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
 
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
     uint32_t mm_slot = cur.mm_index;
     bool mm_dirty = false;  // a wave that never got a frame must not touch any slot
 
-    // Per-frame pipeline of one wave.  The next frame's samples are requested right after the last
-    // register pass, when only z[] is live, and land during the split / dB / store epilogue and
-    // while the SIMD's other waves compute: HBM latency is covered without holding a second frame
-    // in registers through the FFT passes.  sched_barrier(0) pins the phases so the scheduler
-    // cannot hoist LDS / global loads across them and inflate register pressure.
-    cf32 x[P];
-    if (cur.valid) cursor_fetch<P, PADDED>(cur, g, lane, x);
+    cf32 x[P];  // raw samples of the current frame, then (shifted + refilled) of the next one
+    if (cur.valid) wave_fetch<P, PADDED, 0>(lane, x, cur.wav, frame_e0(cur, g), g);
     while (cur.valid) {
         cf32 z[P];
         wave_window<P>(lane, z, x, wtab);
+        // request the next frame now: its samples land while this frame is transformed
+        const FrameCursor nxt = cursor_next(cur, g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
+        if (nxt.valid) {
+            if (SHIFT > 0 && !nxt.fresh) {
+#pragma unroll
+                for (int m = 0; m + SHIFT < P; m++) x[m] = x[m + SHIFT];
+                wave_fetch<P, PADDED, P - SHIFT>(lane, x, nxt.wav, frame_e0(nxt, g), g);
+            } else {
+                wave_fetch<P, PADDED, 0>(lane, x, nxt.wav, frame_e0(nxt, g), g);
+            }
+        }
+        TH_SCHED_BARRIER();
         W::pass1(lane, z, slab);
         wave_lds_sync();
         TH_SCHED_BARRIER();
@@ -295,7 +304,12 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         wave_lds_sync();
         TH_SCHED_BARRIER();
 
-        FrameCursor nxt;
+        if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
+            flush_minmax(minmax, mm_slot, lane, lmin, lmax);
+            lmin = __builtin_inff();
+            lmax = -__builtin_inff();
+        }
+        const gptr<float> row = cur.spec + (size_t)cur.f * g.height;
         if constexpr (W::PAIRED) {
             // mirror-local last pass: every Z[k] / Z[Nc-k] pair ends up in one lane's registers
             cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
@@ -303,15 +317,6 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
             W::pass3_paired(lane, za, zb, t3);
             TH_SCHED_BARRIER();
-            nxt = cursor_next<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
-            if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, x);  // in flight during the epilogue
-            TH_SCHED_BARRIER();
-            if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
-                flush_minmax(minmax, mm_slot, lane, lmin, lmax);
-                lmin = __builtin_inff();
-                lmax = -__builtin_inff();
-            }
-            const gptr<float> row = cur.spec + (size_t)cur.f * g.height;
             W::split_paired(lane, za, zb, stw, [&](uint32_t k, float p) {
                 const float d = power_to_dB(p);
                 row[k] = d;
@@ -325,15 +330,6 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             W::write_z(lane, z, slab);
             wave_lds_sync();
             TH_SCHED_BARRIER();
-            nxt = cursor_next<WAVES>(cur, g, jobs, tile_start, n_chan, wave);
-            if (nxt.valid) cursor_fetch<P, PADDED>(nxt, g, lane, x);  // in flight during the epilogue
-            TH_SCHED_BARRIER();
-            if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
-                flush_minmax(minmax, mm_slot, lane, lmin, lmax);
-                lmin = __builtin_inff();
-                lmax = -__builtin_inff();
-            }
-            const gptr<float> row = cur.spec + (size_t)cur.f * g.height;
 #pragma unroll
             for (int m = 0; m < P; m++) {
                 const uint32_t k = lane + 64u * m;
@@ -363,9 +359,11 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, hipStream_t s) {
-    if (!d_minmax || !n_chan) return hipSuccess;
-    hipLaunchKernelGGL(minmax_init_kernel, dim3((n_chan + 255) / 256), dim3(256), 0, s, d_minmax, n_chan);
+hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queue_head, hipStream_t s) {
+    if ((!d_minmax || !n_chan) && !d_queue_head) return hipSuccess;
+    if (!n_chan) n_chan = 1;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3((n_chan + 255) / 256), dim3(256), 0, s, d_minmax, n_chan,
+                       d_queue_head);
     return hipGetLastError();
 }
 
@@ -406,30 +404,61 @@ static size_t wave_lds_bytes() {
     return sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
 }
 
-template <int LOG2_NC, bool PADDED, int WAVES>
-static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
+template <int LOG2_NC, bool PADDED, int WAVES, int SHIFT>
+static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                 float *d_minmax, uint32_t n_cu, hipStream_t s) {
-    auto kern = stft_wave_kernel<LOG2_NC, PADDED, WAVES>;
+                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
+    auto kern = stft_wave_kernel<LOG2_NC, PADDED, WAVES, SHIFT>;
     const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>();
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
-    const uint32_t grid = n_tiles < n_cu ? n_tiles : n_cu;
+    const uint32_t wg_needed = (n_tiles + WAVES - 1) / WAVES;
+    const uint32_t grid = wg_needed < n_cu ? wg_needed : n_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
-                       d_tw, d_minmax);
+                       d_tw, d_minmax, d_queue_head);
     return hipGetLastError();
+}
+
+// register-reuse shift of consecutive frames: hop/128 slots when hop is a multiple of 128 samples
+// and smaller than n_fft and the window is not zero-padded, else 0 (full reload per frame)
+template <int LOG2_NC>
+static int wave_shift(const StftGeom &g) {
+    constexpr int P = WaveFft<LOG2_NC>::P;
+    if (g.win != g.n_fft || g.hop % 128 != 0) return 0;
+    const int sh = (int)(g.hop / 128);
+    return (sh >= 1 && sh < P) ? sh : 0;
+}
+
+template <int LOG2_NC, bool PADDED, int WAVES>
+static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
+                                 uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
+                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
+    constexpr int P = WaveFft<LOG2_NC>::P;
+    const int sh = PADDED ? 0 : wave_shift<LOG2_NC>(g);
+    // instantiate the common overlaps only: 75 % (hop = n_fft/4), 50 % and 87.5 %
+#define TH_SHIFT_CASE(SH)                                                                                             \
+    if constexpr (!PADDED && (SH) > 0 && (SH) < P)                                                                    \
+        if (sh == (SH))                                                                                               \
+            return launch_wave_t4<LOG2_NC, PADDED, WAVES, (SH)>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, \
+                                                                d_minmax, d_queue_head, n_cu, s);
+    TH_SHIFT_CASE(P / 4)
+    TH_SHIFT_CASE(P / 2)
+    TH_SHIFT_CASE(P / 8)
+#undef TH_SHIFT_CASE
+    return launch_wave_t4<LOG2_NC, PADDED, WAVES, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
+                                                     d_queue_head, n_cu, s);
 }
 
 template <int LOG2_NC, bool PADDED>
 static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                 float *d_minmax, uint32_t n_cu, int waves, hipStream_t s) {
+                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s) {
 #define TH_WAVE_CASE(WV)                                                                                         \
     case WV:                                                                                                     \
         return launch_wave_t3<LOG2_NC, PADDED, WV>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, \
-                                                   n_cu, s);
+                                                   d_queue_head, n_cu, s);
     switch (waves) {
         TH_WAVE_CASE(4)
         TH_WAVE_CASE(8)
@@ -443,13 +472,13 @@ static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const
 template <int LOG2_NC>
 static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                 uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                float *d_minmax, uint32_t n_cu, int waves, hipStream_t s) {
+                                float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s) {
     if (waves <= 0) waves = WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES;
     if (g.win == g.n_fft)
-        return launch_wave_t2<LOG2_NC, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu,
-                                              waves, s);
-    return launch_wave_t2<LOG2_NC, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, waves,
-                                         s);
+        return launch_wave_t2<LOG2_NC, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
+                                              d_queue_head, n_cu, waves, s);
+    return launch_wave_t2<LOG2_NC, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head,
+                                         n_cu, waves, s);
 }
 
 int stft_wave_default_waves(const StftGeom &g) {
@@ -461,13 +490,14 @@ int stft_wave_default_waves(const StftGeom &g) {
 }
 
 hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
-                            uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, uint32_t n_cu,
-                            int waves, hipStream_t s) {
+                            uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
+                            uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s) {
     if (!n_tiles) return hipSuccess;
+    if (!d_queue_head) return hipErrorInvalidValue;
     switch (g.log2_nc) {
-        case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, waves, s);
-        case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, waves, s);
-        case 11: return launch_wave_t<11>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, n_cu, waves, s);
+        case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
+        case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
+        case 11: return launch_wave_t<11>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -308,9 +308,11 @@ namespace th {
 // last few per channel, and every frame of inputs shorter than the window) go to the generic
 // kernel, which implements the reflect padding.
 // ---------------------------------------------------------------------------------------------
-template <int P, bool PADDED, class WavPtr>
+// M0: first slot to (re)load — 0 loads the whole frame, P - S only the S slots that are new after the
+// previous frame's registers were moved down by S slots.
+template <int P, bool PADDED, int M0, class WavPtr>
 TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0, const StftGeom &g) {
-    for (int m = 0; m < P; m++) {
+    for (int m = M0; m < P; m++) {
         const uint32_t n = lane + 64u * m;
         float x0 = 0.0f, x1 = 0.0f;
         if (!PADDED) {
