@@ -81,8 +81,10 @@ class Workload:
             self.plan.set_kernel(kernel)
         self.T, self.H = self.plan.n_frames(n), self.plan.height
         self.wav = synth_on_gpu(torch, dev, track_ids, sr, n)
-        self.spec = torch.empty((n_tracks, self.T, self.H), dtype=torch.float32, device=dev)
-        self.img = torch.empty((n_tracks, self.H, self.T), dtype=torch.int16, device=dev)
+        # HBM layout: rows padded to 128 B (th_pitch_*); the dense reference layout is what copy-out returns
+        self.sp, self.ip = ta.pitch_f32(self.H), ta.pitch_u16(self.T)
+        self.spec = torch.empty((n_tracks, self.T, self.sp), dtype=torch.float32, device=dev)
+        self.img = torch.empty((n_tracks, self.H, self.ip), dtype=torch.int16, device=dev)
         self.minmax = torch.empty((n_tracks, 2), dtype=torch.float32, device=dev)
         self.cmap = torch.frombuffer(bytearray(cmap_bytes), dtype=torch.uint8).to(dev)
         self.n_colors = len(cmap_bytes) // 4
@@ -104,16 +106,16 @@ class Workload:
         self.tile_px = sum(g.width * g.height for g in geoms)
         self.rgba = torch.empty((n_tracks, self.tile_px, 4), dtype=torch.uint8, device=dev)
         self.chan = (ta.ChanDesc * n_tracks)(*[
-            ta.ChanDesc(self.wav[i].data_ptr(), self.spec[i].data_ptr(), n, self.T) for i in range(n_tracks)])
+            ta.ChanDesc(self.wav[i].data_ptr(), self.spec[i].data_ptr(), n, self.T, self.sp) for i in range(n_tracks)])
         self.imgd = (ta.ImgDesc * n_tracks)(*[
-            ta.ImgDesc(self.spec[i].data_ptr(), self.img[i].data_ptr(), self.T, self.H, 0, self.H)
+            ta.ImgDesc(self.spec[i].data_ptr(), self.img[i].data_ptr(), self.T, self.H, 0, self.H, self.sp, self.ip)
             for i in range(n_tracks)])
         rast = []
         for i in range(n_tracks):
             off = 0
             for g in geoms:
                 rast.append(ta.RasterDesc(self.img[i].data_ptr(), self.rgba[i].data_ptr() + off * 4, self.T,
-                                               self.H, g.origin_x, g.origin_y, g.width, g.height))
+                                               self.H, g.origin_x, g.origin_y, g.width, g.height, self.ip, 0))
                 off += g.width * g.height
         self.rast = (ta.RasterDesc * len(rast))(*rast)
         self.frames = n_tracks * self.T

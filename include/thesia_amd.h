@@ -151,12 +151,20 @@ TH_API int th_plan_set_kernel(th_plan *plan, int which);
 /* name of the kernel th_calc_spec_batch_dev will launch for this plan (for profiles / tests) */
 TH_API const char *th_plan_kernel_name(const th_plan *plan);
 
+/* Recommended row pitches (elements) for device-resident specs / images: rows padded to a multiple of
+ * 128 bytes so that every row starts on a cache line.  The reference layout (dense rows) is what the
+ * copy-out accessors return; the pitch is an HBM-layout choice of this library. */
+TH_API size_t th_pitch_f32(size_t row_elems);
+TH_API size_t th_pitch_u16(size_t row_elems);
+
 /* ---------------------------------------------------------------- calc_spec (layer A, device pointers) */
 typedef struct {
     const float *wav;    /* DEVICE: n_samples f32, one channel */
-    float *spec;         /* DEVICE: n_frames x height f32 dB, row-major (frame-major, like Array2 T x H) */
+    float *spec;         /* DEVICE: n_frames rows of f32 dB, frame-major like the reference's Array2 (T x H) */
     uint64_t n_samples;
     uint64_t n_frames;   /* must equal th_stft_n_frames(n_samples, win, hop) */
+    uint64_t spec_pitch; /* floats per row, >= height; 0 = dense (height).  Pitches that are multiples of
+                            32 floats (128 B) keep every row cache-line aligned (th_pitch_f32). */
 } th_chan_desc;
 
 /* Batched calc_spec over n_chan independent channels (core/mod.rs:153-163 → spectrogram.rs:187-212):
@@ -181,6 +189,8 @@ typedef struct {
     const float *spec; /* DEVICE */
     uint16_t *img;     /* DEVICE */
     uint64_t n_frames, height, i_start, i_end;
+    uint64_t spec_pitch; /* floats per spec row, 0 = dense (height) */
+    uint64_t img_pitch;  /* u16 per image row, 0 = dense (n_frames); multiples of 64 recommended (th_pitch_u16) */
 } th_img_desc;
 /* batched form: one launch for many channels sharing (min_dB, max_dB, colormap_len) — core/mod.rs:204-227 */
 TH_API int th_spec_to_img_batch_dev(th_ctx *ctx, const th_img_desc *descs, size_t n, float min_dB, float max_dB,
@@ -192,6 +202,7 @@ TH_API int th_spec_to_img_batch_dev(th_ctx *ctx, const th_img_desc *descs, size_
  * to the HOST buffer `out`.  Level (0,0) is an exact crop copy; level > 0 uses a separable
  * Lanczos3 resample (parity unpinned vs fast_image_resize). */
 TH_API int th_encode_spectrogram_tile_dev(th_ctx *ctx, const uint16_t *d_img, size_t img_height, size_t img_width,
+                                          size_t img_pitch /* u16 per row, 0 = dense */,
                                           const uint8_t *colormap_rgba, size_t colormap_bytes, uint64_t revision,
                                           uint32_t level_x, uint32_t level_y, uint32_t tile_x, uint32_t tile_y,
                                           uint8_t *out, size_t out_capacity, size_t *out_len);
@@ -201,6 +212,8 @@ typedef struct {
     uint8_t *rgba;        /* DEVICE: height x width x 4, top row = highest frequency */
     uint32_t img_width, img_height;
     uint32_t origin_x, origin_y, width, height; /* level-0 tile rectangle (th_spectrogram_tile_geometry) */
+    uint32_t img_pitch;                         /* u16 per image row, 0 = dense (img_width) */
+    uint32_t reserved;
 } th_raster_desc;
 /* Batched level-0 colormap raster of many tile rectangles in one launch (device → device).
  * d_colormap: DEVICE RGBA8, n_colors entries. */

@@ -38,9 +38,10 @@ for K in a.kernel:
     if K:
         plan.set_kernel(K)
     T, H = plan.n_frames(n), plan.height
-    spec = torch.empty((a.tracks, T, H), dtype=torch.float32, device=dev)
+    sp = H if os.environ.get('TH_DENSE') == '1' else ta.pitch_f32(H)
+    spec = torch.empty((a.tracks, T, sp), dtype=torch.float32, device=dev)
     mm = torch.empty((a.tracks, 2), dtype=torch.float32, device=dev)
-    chan = (ta.ChanDesc * a.tracks)(*[ta.ChanDesc(wav[i].data_ptr(), spec[i].data_ptr(), n, T) for i in range(a.tracks)])
+    chan = (ta.ChanDesc * a.tracks)(*[ta.ChanDesc(wav[i].data_ptr(), spec[i].data_ptr(), n, T, sp) for i in range(a.tracks)])
     for _ in range(3):
         plan.calc_spec_batch_dev(chan, mm.data_ptr())
     torch.cuda.synchronize()

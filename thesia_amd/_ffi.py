@@ -65,17 +65,19 @@ class TileGeom(C.Structure):
 
 
 class ChanDesc(C.Structure):
-    _fields_ = [("wav", vp), ("spec", vp), ("n_samples", C.c_uint64), ("n_frames", C.c_uint64)]
+    _fields_ = [("wav", vp), ("spec", vp), ("n_samples", C.c_uint64), ("n_frames", C.c_uint64),
+                ("spec_pitch", C.c_uint64)]
 
 
 class ImgDesc(C.Structure):
     _fields_ = [("spec", vp), ("img", vp), ("n_frames", C.c_uint64), ("height", C.c_uint64),
-                ("i_start", C.c_uint64), ("i_end", C.c_uint64)]
+                ("i_start", C.c_uint64), ("i_end", C.c_uint64), ("spec_pitch", C.c_uint64), ("img_pitch", C.c_uint64)]
 
 
 class RasterDesc(C.Structure):
     _fields_ = [("img", vp), ("rgba", vp), ("img_width", C.c_uint32), ("img_height", C.c_uint32),
-                ("origin_x", C.c_uint32), ("origin_y", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
+                ("origin_x", C.c_uint32), ("origin_y", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("img_pitch", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class WaveDesc(C.Structure):
@@ -119,7 +121,9 @@ _SIGS = {
     "th_spec_to_img_dev": [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
                            C.c_uint32, vp],
     "th_spec_to_img_batch_dev": [vp, C.POINTER(ImgDesc), C.c_size_t, C.c_float, C.c_float, C.c_uint32],
-    "th_encode_spectrogram_tile_dev": [vp, vp, C.c_size_t, C.c_size_t, c_u8p, C.c_size_t, C.c_uint64, C.c_uint32,
+    "th_pitch_f32": [C.c_size_t],
+    "th_pitch_u16": [C.c_size_t],
+    "th_encode_spectrogram_tile_dev": [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, c_u8p, C.c_size_t, C.c_uint64, C.c_uint32,
                                        C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
     "th_raster_tiles_dev": [vp, C.POINTER(RasterDesc), C.c_size_t, vp, C.c_uint32],
     "th_encode_waveform_tile_dev": [vp, vp, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t,
@@ -145,7 +149,7 @@ _SIGS = {
                                    c_u8p, C.c_size_t, c_szp],
     "th_tm_get_waveform_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
 }
-_RESTYPES = {"th_plan_kernel_name": C.c_char_p}
+_RESTYPES = {"th_plan_kernel_name": C.c_char_p, "th_pitch_f32": C.c_size_t, "th_pitch_u16": C.c_size_t}
 
 lib.th_last_error.restype = C.c_char_p
 lib.th_last_error.argtypes = []

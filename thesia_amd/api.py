@@ -82,6 +82,16 @@ def global_db_range(mins, maxs, dB_range: float = 100.0):
     return lo.value, hi.value
 
 
+def pitch_f32(row_elems: int) -> int:
+    """Recommended floats per row for device-resident specs (rows padded to 128 B)."""
+    return lib.th_pitch_f32(row_elems)
+
+
+def pitch_u16(row_elems: int) -> int:
+    """Recommended u16 per row for device-resident images (rows padded to 128 B)."""
+    return lib.th_pitch_u16(row_elems)
+
+
 def shard_assign(weights, world: int):
     """th_shard_assign: owner rank of every (track, channel) unit, by frame-count weight."""
     w = np.ascontiguousarray(weights, dtype=np.uint64)
@@ -205,16 +215,17 @@ class Context:
         d_img = self.to_device(img)
         try:
             return self.encode_spectrogram_tile_dev(d_img.ptr, img.shape[0], img.shape[1], colormap_rgba, revision,
-                                                    level_x, level_y, tile_x, tile_y)
+                                                    level_x, level_y, tile_x, tile_y, 0)
         finally:
             d_img.free()
 
     def encode_spectrogram_tile_dev(self, d_img: int, img_height: int, img_width: int, colormap_rgba: bytes,
-                                    revision: int, level_x: int, level_y: int, tile_x: int, tile_y: int) -> bytes:
+                                    revision: int, level_x: int, level_y: int, tile_x: int, tile_y: int,
+                                    img_pitch: int = 0) -> bytes:
         cm = np.frombuffer(bytes(colormap_rgba), np.uint8)
         out = np.empty(SPECTROGRAM_TILE_MAX_BYTES, np.uint8)
         n = C.c_size_t()
-        check(lib.th_encode_spectrogram_tile_dev(self.handle, d_img, img_height, img_width, _ptr(cm, c_u8p), cm.size,
+        check(lib.th_encode_spectrogram_tile_dev(self.handle, d_img, img_height, img_width, img_pitch, _ptr(cm, c_u8p), cm.size,
                                                  revision, level_x, level_y, tile_x, tile_y, _ptr(out, c_u8p),
                                                  out.size, C.byref(n)))
         return out[: n.value].tobytes()
@@ -299,7 +310,7 @@ class Plan:
         Ts = [self.n_frames(w.size) for w in wavs]
         d_s = [ctx.alloc(max(T * self.height * 4, 4)) for T in Ts]
         d_mm = ctx.alloc(8 * len(wavs))
-        descs = [ChanDesc(dw.ptr, ds.ptr, w.size, T) for dw, ds, w, T in zip(d_w, d_s, wavs, Ts)]
+        descs = [ChanDesc(dw.ptr, ds.ptr, w.size, T, 0) for dw, ds, w, T in zip(d_w, d_s, wavs, Ts)]
         self.calc_spec_batch_dev(descs, d_mm.ptr)
         ctx.synchronize()
         specs = [ds.download((T, self.height), np.float32) for ds, T in zip(d_s, Ts)]

@@ -447,6 +447,9 @@ TH_API const char *th_plan_kernel_name(const th_plan *p) {
     return p->use_wave() ? "stft_wave_kernel" : "stft_generic_kernel";
 }
 
+TH_API size_t th_pitch_f32(size_t n) { return (n + 31) / 32 * 32; }
+TH_API size_t th_pitch_u16(size_t n) { return (n + 63) / 64 * 64; }
+
 // ------------------------------------------------------------------------------------------ calc_spec
 TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t n_chan, float *d_minmax) {
     TH_TRY
@@ -463,7 +466,7 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);
     // wave kernel: chunk of consecutive frames one wave walks (first frame loads everything, the rest
     // only hop new samples)
-    g.frames_per_tile = wave ? (p->wave_chunk > 0 ? (uint32_t)p->wave_chunk : 16u) : 8u;
+    g.frames_per_tile = wave ? (p->wave_chunk > 0 ? (uint32_t)p->wave_chunk : 32u) : 8u;
     ge.frames_per_tile = 1;
     // main jobs: the wave kernel takes the interior frames [fa, fb) of every channel (all windowed
     // samples inside the signal); the generic kernel takes the boundary frames (reflect padding,
@@ -474,7 +477,8 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     auto add = [](std::vector<ChanJob> &v, std::vector<uint32_t> &st, uint64_t &n_tiles, const StftGeom &gg,
                   const th_chan_desc &d, uint32_t T, uint32_t fb0, uint32_t fe0, uint32_t slot) {
         if (fb0 >= fe0) return;
-        v.push_back(ChanJob{d.wav, d.spec, (uint32_t)d.n_samples, T, fb0, fe0, slot, 0});
+        const uint32_t pitch = d.spec_pitch ? (uint32_t)d.spec_pitch : gg.height;
+        v.push_back(ChanJob{d.wav, d.spec, (uint32_t)d.n_samples, T, fb0, fe0, slot, pitch});
         st.push_back((uint32_t)n_tiles);
         n_tiles += (fe0 - fb0 + gg.frames_per_tile - 1) / gg.frames_per_tile;
     };
@@ -486,6 +490,8 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
         const size_t T = stft_n_frames(d.n_samples, g.win, g.hop);
         TH_REQUIRE(d.n_frames == T, "channel %zu: n_frames=%llu but the framing gives %zu", i,
                    (unsigned long long)d.n_frames, T);
+        TH_REQUIRE(d.spec_pitch == 0 || (d.spec_pitch >= g.height && d.spec_pitch < (1ull << 31)),
+                   "channel %zu: spec_pitch %llu < height %u", i, (unsigned long long)d.spec_pitch, g.height);
         if (!wave) {
             add(jobs, tile_start, tiles, g, d, (uint32_t)T, 0, (uint32_t)T, (uint32_t)i);
         } else {
@@ -556,7 +562,7 @@ TH_API int th_calc_spec_host(th_plan *p, const float *wav, size_t n_samples, flo
         hipok(hipMalloc((void **)&d_spec, std::max<size_t>(1, T * g.height) * sizeof(float)), "hipMalloc spec") &&
         hipok(hipMalloc((void **)&d_mm, 2 * sizeof(float)), "hipMalloc minmax") &&
         hipok(hipMemcpy(d_wav, wav, n_samples * sizeof(float), hipMemcpyHostToDevice), "upload")) {
-        th_chan_desc d{d_wav, d_spec, n_samples, T};
+        th_chan_desc d{d_wav, d_spec, n_samples, T, 0};
         rc = th_calc_spec_batch_dev(p, &d, 1, d_mm);
         if (rc == TH_OK) {
             float mm[2];
@@ -591,9 +597,12 @@ TH_API int th_spec_to_img_batch_dev(th_ctx *c, const th_img_desc *descs, size_t 
         const uint64_t out_h = d.i_end - d.i_start;
         TH_REQUIRE(d.n_frames < (1ull << 31) && d.height < (1ull << 31) && d.i_end < (1ull << 31), "desc %zu: too large", i);
         TH_REQUIRE((d.spec && d.img) || out_h * d.n_frames == 0, "desc %zu: NULL device pointer", i);
-        jobs[i] = ImgJob{d.spec, d.img, (uint32_t)d.n_frames, (uint32_t)d.height, (uint32_t)d.i_start, (uint32_t)d.i_end};
+        TH_REQUIRE(d.spec_pitch == 0 || (d.spec_pitch >= d.height && d.spec_pitch < (1ull << 31)), "desc %zu: bad spec_pitch", i);
+        TH_REQUIRE(d.img_pitch == 0 || (d.img_pitch >= d.n_frames && d.img_pitch < (1ull << 31)), "desc %zu: bad img_pitch", i);
+        jobs[i] = ImgJob{d.spec, d.img, (uint32_t)d.n_frames, (uint32_t)d.height, (uint32_t)d.i_start, (uint32_t)d.i_end,
+                         (uint32_t)(d.spec_pitch ? d.spec_pitch : d.height), (uint32_t)(d.img_pitch ? d.img_pitch : d.n_frames)};
         start[i] = (uint32_t)tiles;
-        tiles += ((d.n_frames + IMG_TILE - 1) / IMG_TILE) * ((out_h + IMG_TILE - 1) / IMG_TILE);
+        tiles += ((d.n_frames + IMG_TILE_T - 1) / IMG_TILE_T) * ((out_h + IMG_TILE_F - 1) / IMG_TILE_F);
         TH_REQUIRE(tiles < (1ull << 31), "batch too large for one launch");
     }
     start[n] = (uint32_t)tiles;
@@ -601,8 +610,10 @@ TH_API int th_spec_to_img_batch_dev(th_ctx *c, const th_img_desc *descs, size_t 
     TH_HIP(hipSetDevice(c->device));
     if (all_neg_inf) {
         for (size_t i = 0; i < n; i++) {
-            const size_t bytes = (size_t)(descs[i].i_end - descs[i].i_start) * descs[i].n_frames * sizeof(uint16_t);
-            if (bytes) TH_HIP(hipMemsetAsync(descs[i].img, 0, bytes, c->stream));
+            const size_t rows = descs[i].i_end - descs[i].i_start, pitch = jobs[i].img_pitch;
+            if (rows && descs[i].n_frames)
+                TH_HIP(hipMemset2DAsync(descs[i].img, pitch * sizeof(uint16_t), 0, descs[i].n_frames * sizeof(uint16_t), rows,
+                                        c->stream));
         }
         return TH_OK;
     }
@@ -618,7 +629,7 @@ TH_API int th_spec_to_img_batch_dev(th_ctx *c, const th_img_desc *descs, size_t 
 
 TH_API int th_spec_to_img_dev(th_ctx *c, const float *d_spec, size_t n_frames, size_t height, size_t i_start,
                               size_t i_end, float min_dB, float max_dB, uint32_t colormap_len, uint16_t *d_img) {
-    th_img_desc d{d_spec, d_img, n_frames, height, i_start, i_end};
+    th_img_desc d{d_spec, d_img, n_frames, height, i_start, i_end, 0, 0};
     return th_spec_to_img_batch_dev(c, &d, 1, min_dB, max_dB, colormap_len);
 }
 
@@ -639,9 +650,15 @@ TH_API int th_raster_tiles_dev(th_ctx *c, const th_raster_desc *descs, size_t n,
         const uint64_t px = (uint64_t)d.width * d.height;
         TH_REQUIRE(px < (1ull << 31), "desc %zu: tile too large", i);
         TH_REQUIRE(px == 0 || (d.img && d.rgba), "desc %zu: NULL device pointer", i);
-        jobs[i] = RasterJob{d.img, d.rgba, d.img_width, d.img_height, d.origin_x, d.origin_y, d.width, d.height};
+        TH_REQUIRE(d.img_pitch == 0 || d.img_pitch >= d.img_width, "desc %zu: img_pitch < img_width", i);
+        const uint32_t qpr = (d.width + 3) / 4;
+        const uint32_t inv = qpr > 1 ? (uint32_t)((1ull << 32) / qpr) + 1u : 0u;  // exact for q * qpr < 2^32
+        TH_REQUIRE(px == 0 || (px + 4) * d.width < (1ull << 32), "desc %zu: tile too large", i);
+        const uint32_t inv_w = d.width > 1 ? (uint32_t)((1ull << 32) / d.width) + 1u : 0u;
+        jobs[i] = RasterJob{d.img, d.rgba, d.img_width, d.img_height, d.origin_x, d.origin_y, d.width, d.height,
+                            d.img_pitch ? d.img_pitch : d.img_width, qpr, inv, inv_w};
         start[i] = (uint32_t)blocks;
-        blocks += (px + RASTER_PIXELS_PER_BLOCK - 1) / RASTER_PIXELS_PER_BLOCK;
+        blocks += ((uint64_t)qpr * d.height + RASTER_QUADS_PER_BLOCK - 1) / RASTER_QUADS_PER_BLOCK;
         TH_REQUIRE(blocks < (1ull << 31), "batch too large for one launch");
     }
     start[n] = (uint32_t)blocks;
@@ -661,13 +678,14 @@ static void put_u32(uint8_t *p, uint32_t v) { std::memcpy(p, &v, 4); }  // littl
 static void put_u64(uint8_t *p, uint64_t v) { std::memcpy(p, &v, 8); }
 
 TH_API int th_encode_spectrogram_tile_dev(th_ctx *c, const uint16_t *d_img, size_t img_height, size_t img_width,
-                                          const uint8_t *colormap_rgba, size_t colormap_bytes, uint64_t revision,
+                                          size_t img_pitch, const uint8_t *colormap_rgba, size_t colormap_bytes, uint64_t revision,
                                           uint32_t level_x, uint32_t level_y, uint32_t tile_x, uint32_t tile_y,
                                           uint8_t *out, size_t cap, size_t *out_len) {
     TH_TRY
     TH_REQUIRE(c && out && out_len, "NULL argument");
     TH_REQUIRE(colormap_rgba && colormap_bytes >= 4 && colormap_bytes % 4 == 0, "colormap must be a non-empty RGBA8 array");
     TH_REQUIRE(img_width < (1ull << 31) && img_height < (1ull << 31), "image too large");
+    TH_REQUIRE(img_pitch == 0 || (img_pitch >= img_width && img_pitch < (1ull << 31)), "img_pitch < img_width");
     const TileGeom g = spectrogram_tile_geometry(img_width, img_height, level_x, level_y, tile_x, tile_y);
     const size_t need = 40 + g.width * g.height * 4;
     *out_len = need;
@@ -694,7 +712,8 @@ TH_API int th_encode_spectrogram_tile_dev(th_ctx *c, const uint16_t *d_img, size
     rc = c->tile_out.ensure(g.width * g.height * 4);
     if (rc != TH_OK) return rc;
     th_raster_desc d{d_img, (uint8_t *)c->tile_out.dptr, (uint32_t)img_width, (uint32_t)img_height,
-                     (uint32_t)g.origin_x, (uint32_t)g.origin_y, (uint32_t)g.width, (uint32_t)g.height};
+                     (uint32_t)g.origin_x, (uint32_t)g.origin_y, (uint32_t)g.width, (uint32_t)g.height,
+                     (uint32_t)img_pitch, 0};
     rc = th_raster_tiles_dev(c, &d, 1, (const uint8_t *)c->colormap.dptr, n_colors);
     if (rc != TH_OK) return rc;
     TH_HIP(hipMemcpyAsync(out + 40, c->tile_out.dptr, g.width * g.height * 4, hipMemcpyDeviceToHost, c->stream));

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
         float *mag = reinterpret_cast<float *>(out);
         gen_split(tid, GEN_THREADS, g, tw, in, mag);
         __syncthreads();
-        const gptr<float> row = as_global(job.spec) + (size_t)f * g.height;
+        const gptr<float> row = as_global(job.spec) + (size_t)f * job.spec_pitch;
         if (g.n_mel == 0) {
             for (uint32_t k = tid; k < g.n_freq; k += GEN_THREADS) {
                 const float d = amp_to_dB(mag[k]);
@@ -191,7 +191,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // A wave's position in the frame stream.  All members are wave-uniform (SGPRs).
 struct FrameCursor {
-    uint32_t f, f1, mm_index;
+    uint32_t f, f1, mm_index, spec_pitch;
     gptr<const float> wav;
     gptr<float> spec;
     bool valid;
@@ -212,6 +212,7 @@ __device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const Chan
         c.f = jobs[chan].f_begin + (t - tile_start[chan]) * g.frames_per_tile;
         c.f1 = min(c.f + g.frames_per_tile, jobs[chan].f_end);
         c.mm_index = jobs[chan].mm_index;
+        c.spec_pitch = jobs[chan].spec_pitch;
         c.wav = as_global(jobs[chan].wav);
         c.spec = as_global(jobs[chan].spec);
         c.fresh = true;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             lmin = __builtin_inff();
             lmax = -__builtin_inff();
         }
-        const gptr<float> row = cur.spec + (size_t)cur.f * g.height;
+        const gptr<float> row = cur.spec + (size_t)cur.f * cur.spec_pitch;
         if constexpr (W::PAIRED) {
             // mirror-local last pass: every Z[k] / Z[Nc-k] pair ends up in one lane's registers
             cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];

@@ -70,7 +70,7 @@ struct ChanJob {
     uint32_t n_frames;
     uint32_t f_begin, f_end;
     uint32_t mm_index;
-    uint32_t pad_;
+    uint32_t spec_pitch;  // floats per spec row (>= height; rows padded to 128 B keep every store line-aligned)
 };
 
 // numpy-'reflect' index with periodic cycling for pads longer than N-1 (utils.rs:111-138;

@@ -31,9 +31,9 @@ struct Channel {
     float *d_wav = nullptr;
     size_t n = 0;
     float *d_spec = nullptr;
-    size_t T = 0, H = 0;
+    size_t T = 0, H = 0, spec_pitch = 0;   // rows padded to 128 B (th_pitch_f32)
     uint16_t *d_img = nullptr;
-    size_t img_h = 0, img_w = 0;
+    size_t img_h = 0, img_w = 0, img_pitch = 0;  // rows padded to 128 B (th_pitch_u16)
     float mn = INFINITY, mx = -INFINITY;  // find_min_max of this spec (simd.rs:14-36)
     bool has_spec = false;
 };
@@ -140,10 +140,12 @@ int update_specs(th_tm *tm, const std::vector<size_t> &ids) {
                 TH_HIP(hipFree(ch.d_spec));
                 ch.d_spec = nullptr;
             }
-            if (!ch.d_spec) TH_HIP(hipMalloc((void **)&ch.d_spec, std::max<size_t>(1, T * H) * sizeof(float)));
+            const size_t pitch = th_pitch_f32(H);
+            if (!ch.d_spec) TH_HIP(hipMalloc((void **)&ch.d_spec, std::max<size_t>(1, T * pitch) * sizeof(float)));
             ch.T = T;
             ch.H = H;
-            descs[i] = th_chan_desc{ch.d_wav, ch.d_spec, ch.n, T};
+            ch.spec_pitch = pitch;
+            descs[i] = th_chan_desc{ch.d_wav, ch.d_spec, ch.n, T, pitch};
         }
         float *d_mm = nullptr;
         TH_HIP(hipMalloc((void **)&d_mm, 2 * chs.size() * sizeof(float)));
@@ -226,10 +228,12 @@ int update_spec_imgs(th_tm *tm, bool force_update_all, std::vector<size_t> *upda
                 TH_HIP(hipFree(ch.d_img));
                 ch.d_img = nullptr;
             }
-            if (!ch.d_img) TH_HIP(hipMalloc((void **)&ch.d_img, std::max<size_t>(1, h * w) * sizeof(uint16_t)));
+            const size_t ipitch = th_pitch_u16(w);
+            if (!ch.d_img) TH_HIP(hipMalloc((void **)&ch.d_img, std::max<size_t>(1, h * ipitch) * sizeof(uint16_t)));
             ch.img_h = h;
             ch.img_w = w;
-            descs.push_back(th_img_desc{ch.d_spec, ch.d_img, ch.T, ch.H, i0, i1});
+            ch.img_pitch = ipitch;
+            descs.push_back(th_img_desc{ch.d_spec, ch.d_img, ch.T, ch.H, i0, i1, ch.spec_pitch, ipitch});
         }
     }
     return th_spec_to_img_batch_dev(tm->ctx, descs.data(), descs.size(), tm->min_dB, tm->max_dB, tm->colormap_length);
@@ -431,7 +435,10 @@ TH_API int th_tm_copy_spec(th_tm *tm, size_t id, uint32_t ch, float *out, size_t
     Channel *c = find_channel(tm, id, ch);
     if (!c || !c->has_spec) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
     if (cap < c->T * c->H) return fail(TH_ERR_BUFFER_TOO_SMALL, "need %zu floats", c->T * c->H);
-    TH_HIP(hipMemcpyAsync(out, c->d_spec, c->T * c->H * sizeof(float), hipMemcpyDeviceToHost, tm->ctx->stream));
+    // de-pad to the reference's dense T x H layout
+    if (c->T && c->H)
+        TH_HIP(hipMemcpy2DAsync(out, c->H * sizeof(float), c->d_spec, c->spec_pitch * sizeof(float), c->H * sizeof(float),
+                                c->T, hipMemcpyDeviceToHost, tm->ctx->stream));
     TH_HIP(hipStreamSynchronize(tm->ctx->stream));
     return TH_OK;
     TH_CATCH
@@ -445,7 +452,9 @@ TH_API int th_tm_copy_img(th_tm *tm, size_t id, uint32_t ch, uint16_t *out, size
     Channel *c = find_channel(tm, id, ch);
     if (!c || !c->d_img) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
     if (cap < c->img_h * c->img_w) return fail(TH_ERR_BUFFER_TOO_SMALL, "need %zu pixels", c->img_h * c->img_w);
-    TH_HIP(hipMemcpyAsync(out, c->d_img, c->img_h * c->img_w * sizeof(uint16_t), hipMemcpyDeviceToHost, tm->ctx->stream));
+    if (c->img_h && c->img_w)
+        TH_HIP(hipMemcpy2DAsync(out, c->img_w * sizeof(uint16_t), c->d_img, c->img_pitch * sizeof(uint16_t),
+                                c->img_w * sizeof(uint16_t), c->img_h, hipMemcpyDeviceToHost, tm->ctx->stream));
     TH_HIP(hipStreamSynchronize(tm->ctx->stream));
     return TH_OK;
     TH_CATCH
@@ -468,7 +477,7 @@ TH_API int th_tm_get_spectrogram_tile(th_tm *tm, size_t id, uint32_t ch, uint32_
     std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
     Channel *c = find_channel(tm, id, ch);
     if (!c || !c->d_img) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
-    return th_encode_spectrogram_tile_dev(tm->ctx, c->d_img, c->img_h, c->img_w, tm->colormap_rgba.data(),
+    return th_encode_spectrogram_tile_dev(tm->ctx, c->d_img, c->img_h, c->img_w, c->img_pitch, tm->colormap_rgba.data(),
                                           tm->colormap_rgba.size(), tm->spectrogram_revision, level_x, level_y,
                                           tile_x, tile_y, out, cap, out_len);
     TH_CATCH
