@@ -124,36 +124,42 @@ class Workload:
 
     def step(self, dist=None, record=False):
         torch, ta = self.torch, self.ta
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
         if record:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            ev[0].record()
         self.plan.calc_spec_batch_dev(self.chan, self.minmax.data_ptr())
         if record:
-            e1.record()
-            self.ev.append((e0, e1))
+            ev[1].record()
         # global dB range over every resident spec of every rank (core/mod.rs:169-180)
         r = torch.stack([self.minmax[:, 0].min(), -self.minmax[:, 1].max()])
         if dist is not None:
             dist.all_reduce(r, op=dist.ReduceOp.MIN)   # the path's only exchange step: 2 floats
         mn, negmx = r.tolist()
         lo, hi = ta.global_db_range([mn], [-negmx], 100.0)
+        if record:
+            ev[2].record()
         self.ctx.spec_to_img_batch(self.imgd, lo, hi, 258)
+        if record:
+            ev[3].record()
         self.ctx.raster_tiles(self.rast, self.cmap.data_ptr(), self.n_colors)
+        if record:
+            ev[4].record()
+            self.ev.append(ev)
         return lo, hi
 
     def stft_only(self):
         self.plan.calc_spec_batch_dev(self.chan, self.minmax.data_ptr())
 
 
-def cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft, target_s=12.0):
+def cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft, target_s=15.0):
     """The oracle (CPU restatement of the reference algorithm, NOT rustfft) on this box's host
     cores: same step (STFT->dB->min/max->u16->level-0 RGBA) on a bounded sample of the workload,
-    one task per track as the reference does when #channels >= #threads (core/mod.rs:152-163)."""
+    one task per track as the reference does when #channels >= #threads (core/mod.rs:152-163).
+    Each task is ONE C call (oracle orc_track_step; ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as orc
     from tests.synth import synth_track
-    import thesia_amd as ta
     try:
         import psutil
         cores = psutil.cpu_count(logical=False) or os.cpu_count()
@@ -161,36 +167,20 @@ def cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft, target_s=12.0):
         cores = os.cpu_count()
     cores = max(1, min(cores, len(os.sched_getaffinity(0))))
     n_s = min(n, 10 * sr)  # 10 s tracks keep the sample bounded
+    pool_tracks = [synth_track(i, sr, n_s) for i in range(8)]  # inputs generated outside the timed region
 
     def one(i):
-        x = synth_track(i, sr, n_s)
-        t0 = time.perf_counter()
-        spec = orc.calc_spec(x, win, hop, n_fft, fft32=True)
-        mn, mx = orc.find_min_max(spec)
-        lo, hi = orc.global_db_range([mn], [mx], 100.0)
-        img = orc.convert_spectrogram_to_img(spec, (0, spec.shape[1]), (lo, hi), 258)
-        tx = 0
-        while True:
-            ty, any_row = 0, False
-            while True:
-                g = ta.spectrogram_tile_geometry(img.shape[1], img.shape[0], 0, 0, tx, ty)
-                if g.width == 0 or g.height == 0:
-                    break
-                orc.encode_spectrogram_tile(img, cmap_bytes, 1, 0, 0, tx, ty)
-                any_row = True
-                ty += 1
-            if not any_row:
-                break
-            tx += 1
-        return spec.shape[0], time.perf_counter() - t0
+        return orc.track_step(pool_tracks[i % len(pool_tracks)], win, hop, n_fft, cmap_bytes)
 
-    frames1, dt1 = one(0)  # calibration (also warms the library)
+    t0 = time.perf_counter()
+    frames1 = one(0)  # calibration (also warms the library)
+    dt1 = time.perf_counter() - t0
     n_tasks = int(max(cores, min(64 * cores, round(target_s / max(dt1, 1e-3)) * cores)))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         res = list(ex.map(one, range(n_tasks)))
     wall = time.perf_counter() - t0
-    frames = sum(r[0] for r in res)
+    frames = sum(res)
     return {"value": frames / wall, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n_tasks} tracks x {n_s / sr:.0f} s 48 kHz mono, n_fft={n_fft} hop={hop}, "
                       f"same step (STFT->dB->min/max->u16->level-0 RGBA), {wall:.1f} s wall; "
@@ -252,7 +242,10 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    stft_ms = float(np.mean([a.elapsed_time(b) for a, b in wl.ev]))  # HIP events on the launch stream
+    # HIP events on the launch stream, inside the timed region: per-kernel average launch durations
+    stft_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in wl.ev]))
+    quant_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in wl.ev]))
+    rast_ms = float(np.mean([e[3].elapsed_time(e[4]) for e in wl.ev]))
 
     # stage-only rates: STFT->dB stage and quantise+raster stage, HIP events
     def time_stage(fn, reps=10):
@@ -316,6 +309,14 @@ def main():
                          "kernel": wl.plan.kernel_name, "avg_launch_ms": stft_ms,
                          "algorithmic_bytes_per_frame": bytes_per_frame,
                          "read_only_frac": wl.frames * 4 * hop / (stft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            # the two other kernels of the step, same definition (algorithmic bytes / HIP-event duration)
+            "roofline_other": [
+                {"kernel": "spec_to_img_kernel", "bound": "hbm", "avg_launch_ms": quant_ms,
+                 "algorithmic_bytes_per_pixel": 6, "achieved": wl.pixels * 6 / (quant_ms * 1e-3) / 1e9,
+                 "frac": wl.pixels * 6 / (quant_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"},
+                {"kernel": "raster_level0_kernel", "bound": "hbm", "avg_launch_ms": rast_ms,
+                 "algorithmic_bytes_per_pixel": 6, "achieved": wl.n_tracks * wl.tile_px * 6 / (rast_ms * 1e-3) / 1e9,
+                 "frac": wl.n_tracks * wl.tile_px * 6 / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}],
         }
         if single is not None:
             out["single_track_cfg2"] = single

@@ -76,6 +76,9 @@ def lib():
         L.orc_encode_spectrogram_tile.restype = C.c_size_t
         L.orc_encode_spectrogram_tile.argtypes = [_u16p, C.c_size_t, C.c_size_t, _u8p, C.c_size_t, C.c_uint64,
                                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _u8p]
+        L.orc_track_step.restype = C.c_size_t
+        L.orc_track_step.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _u8p, C.c_size_t, C.c_float,
+                                     C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -261,3 +264,11 @@ def encode_spectrogram_tile(img, colormap_rgba, revision: int, level_x: int, lev
     n = lib().orc_encode_spectrogram_tile(_p(img, _u16p), Hh, W, _p(cm, _u8p), cm.size, revision, level_x,
                                           level_y, tile_x, tile_y, _p(out, _u8p))
     return out[:n].tobytes()
+
+
+def track_step(x, win: int, hop: int, n_fft: int, colormap_rgba: bytes, dB_range: float = 100.0) -> int:
+    """One track through the whole benchmark step on the CPU (cpu_baseline leg); returns #frames."""
+    x = _f32(x)
+    cm = np.frombuffer(bytes(colormap_rgba), np.uint8)
+    chk = C.c_uint64()
+    return lib().orc_track_step(_p(x, _f32p), x.size, win, hop, n_fft, _p(cm, _u8p), cm.size, dB_range, C.byref(chk))

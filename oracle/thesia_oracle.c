@@ -768,10 +768,44 @@ ORC_API size_t orc_encode_spectrogram_tile(const uint16_t *img, size_t Hh, size_
 }
 
 /* ------------------------------------------------------------------ */
-/* CPU-baseline helper: whole TrackManager step for a batch, threaded  */
-/* the way the reference is (core/mod.rs:152-163: one task per channel */
-/* when #channels >= #threads; frames split otherwise is approximated  */
-/* by chunking channels' frames — see bench.py).  Implemented by the   */
-/* Python driver with a thread pool over orc_calc_spec calls (ctypes   */
-/* releases the GIL), so nothing else is needed here.                  */
+/* CPU-baseline helper (bench.py cpu_baseline leg): one track through   */
+/* the same step the GPU bench times — calc_spec (f32 FFT) -> min/max   */
+/* -> dB range -> u16 image -> every level-0 RGBA tile — in one call,   */
+/* so the Python driver only fans tracks out over threads the way the   */
+/* reference fans channels out over rayon (core/mod.rs:152-163).        */
+/* Returns the number of frames processed.                              */
 /* ------------------------------------------------------------------ */
+ORC_API size_t orc_track_step(const float *x, size_t n, size_t win, size_t hop, size_t n_fft,
+                              const uint8_t *colormap, size_t colormap_bytes, float dB_range,
+                              uint64_t *checksum) {
+    size_t F = n_fft / 2 + 1;
+    size_t T = orc_stft_n_frames(n, win, hop);
+    if (T == 0) return 0;
+    float *window = (float *)malloc(sizeof(float) * win);
+    orc_calc_normalized_win(win, n_fft, window);
+    float *spec = (float *)malloc(sizeof(float) * T * F);
+    size_t T2 = orc_calc_spec(x, n, win, hop, n_fft, window, NULL, 0, 1, spec, NULL);
+    free(window);
+    if (T2 != T) { free(spec); return 0; }
+    float mn, mx, lo, hi;
+    orc_find_min_max(spec, T * F, &mn, &mx);
+    orc_global_db_range(&mn, &mx, 1, dB_range, &lo, &hi);
+    uint16_t *img = (uint16_t *)malloc(sizeof(uint16_t) * T * F);
+    orc_convert_spectrogram_to_img(spec, T, F, 0, F, lo, hi, (uint32_t)(colormap_bytes / 4), img);
+    free(spec);
+    uint8_t *tile = (uint8_t *)malloc(40 + 520 * 520 * 4);
+    uint64_t sum = 0;
+    for (uint32_t tx = 0;; tx++) {
+        int any = 0;
+        for (uint32_t ty = 0;; ty++) {
+            size_t len = orc_encode_spectrogram_tile(img, F, T, colormap, colormap_bytes, 1, 0, 0, tx, ty, tile);
+            if (len <= 40) break;
+            any = 1;
+            sum += tile[40] + tile[len - 1] + len;
+        }
+        if (!any) break;
+    }
+    free(tile); free(img);
+    if (checksum) *checksum = sum;
+    return T;
+}

@@ -464,9 +464,19 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     StftGeom g = p->g;       // main launch
     StftGeom ge = p->g;      // edge launch (generic kernel)
     const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);
-    // wave kernel: chunk of consecutive frames one wave walks (first frame loads everything, the rest
-    // only hop new samples)
-    g.frames_per_tile = wave ? (p->wave_chunk > 0 ? (uint32_t)p->wave_chunk : 32u) : 8u;
+    // wave kernel: chunk of consecutive frames one wave walks (the first frame of a chunk loads
+    // n_fft samples, the rest only hop new ones).  32 amortises that well on large batches; small
+    // batches (one track) get shorter chunks so that every wave of the chip has work.
+    if (wave) {
+        uint64_t total = 0;
+        for (size_t i = 0; i < n_chan; i++) total += chans[i].n_frames;
+        const uint64_t slots = (uint64_t)c->n_cu * (uint64_t)waves * 2;
+        uint64_t chunk = total / (slots ? slots : 1);
+        chunk = chunk < 4 ? 4 : (chunk > 32 ? 32 : chunk);
+        g.frames_per_tile = p->wave_chunk > 0 ? (uint32_t)p->wave_chunk : (uint32_t)chunk;
+    } else {
+        g.frames_per_tile = 8;
+    }
     ge.frames_per_tile = 1;
     // main jobs: the wave kernel takes the interior frames [fa, fb) of every channel (all windowed
     // samples inside the signal); the generic kernel takes the boundary frames (reflect padding,
