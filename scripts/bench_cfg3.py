@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""BASELINE config 3 (development/measurement tool): 64 stereo 48 kHz tracks x 60 s, n_fft=4096 hop=1024
+batched STFT + min/max waveform decimation (all levels 0..12 of every channel) on 1 GPU."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import thesia_amd as ta  # noqa: E402
+
+dev = torch.device("cuda", 0)
+side = torch.cuda.Stream(dev)
+torch.cuda.set_stream(side)
+ctx = ta.Context(0, side.cuda_stream)
+sr, n_ch, secs = 48000, int(os.environ.get("CH", "128")), 60
+n = sr * secs
+g = torch.Generator(device=dev); g.manual_seed(3)
+wav = (torch.rand((n_ch, n), device=dev, generator=g) * 2 - 1) * 0.25
+hop, win, n_fft = ta.calc_framing_params(4096 / 48, 4, 1, sr)
+plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+K = int(os.environ.get("KERNEL", "0"))
+if K:
+    plan.set_kernel(K)
+T, H = plan.n_frames(n), plan.height
+sp = ta.pitch_f32(H)
+spec = torch.empty((n_ch, T, sp), dtype=torch.float32, device=dev)
+mm = torch.empty((n_ch, 2), dtype=torch.float32, device=dev)
+chan = (ta.ChanDesc * n_ch)(*[ta.ChanDesc(wav[i].data_ptr(), spec[i].data_ptr(), n, T, sp) for i in range(n_ch)])
+
+
+def timeit(fn, reps=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+ms = timeit(lambda: plan.calc_spec_batch_dev(chan, mm.data_ptr()))
+frames = n_ch * T
+bpf = 4 * hop + 4 * H
+print(f"cfg3 STFT ({plan.kernel_name}) n_fft={n_fft} hop={hop}: {n_ch} ch x {T} frames: {ms:.3f} ms  {frames / ms / 1e3:.1f} Mframes/s  "
+      f"{frames * bpf / ms / 1e6:.0f} GB/s algorithmic ({frames * bpf / ms / 1e6 / 80:.1f}% of 8 TB/s)")
+
+# waveform decimation: every tile of levels 0..12 for every channel, one batched launch
+descs, total_bins = [], 0
+bins_buf = None
+per_ch = []
+for level in range(0, 13):
+    spb = 1 << level
+    n_tiles = -(-n // (1024 * spb))
+    for tile in range(n_tiles):
+        start, bins, _ = ta.waveform_tile_geometry(n, level, tile)
+        per_ch.append((level, start, bins))
+        total_bins += bins
+out = torch.empty((n_ch, total_bins, 3), dtype=torch.float32, device=dev)
+for c in range(n_ch):
+    off = 0
+    for level, start, bins in per_ch:
+        descs.append(ta.WaveDesc(wav[c].data_ptr(), out[c].data_ptr() + off * 12, n, start, level, bins))
+        off += bins
+arr = (ta.WaveDesc * len(descs))(*descs)
+ms = timeit(lambda: ctx.waveform_tiles(arr), 5)
+samples = n_ch * n
+rd = samples * 4 * 13 / 1e9
+print(f"cfg3 waveform: {len(descs)} tiles, levels 0..12: {ms:.3f} ms  {samples / ms / 1e3:.0f} Msamples/s per full pyramid "
+      f"({rd / ms * 1e3:.0f} GB/s read, each level re-reads the audio)")

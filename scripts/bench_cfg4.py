@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 (measurement tool): 128-bin mel spectrogram (MFMA filterbank), 32 tracks 44.1 kHz x 60 s,
+n_fft=2048 hop=512 on 1 GPU.  Also the app-default mel count.  KERNEL=1 forces the generic kernel."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import thesia_amd as ta  # noqa: E402
+
+dev = torch.device("cuda", 0)
+side = torch.cuda.Stream(dev)
+torch.cuda.set_stream(side)
+ctx = ta.Context(0, side.cuda_stream)
+sr, n_tr, secs = 44100, int(os.environ.get("TRACKS", "32")), 60
+n = sr * secs
+g = torch.Generator(device=dev); g.manual_seed(4)
+wav = (torch.rand((n_tr, n), device=dev, generator=g) * 2 - 1) * 0.25
+for n_mel in (128, 0):
+    plan = ta.Plan(ctx, sr, 2048, 512, 2048, ta.MEL, n_mel)
+    K = int(os.environ.get("KERNEL", "0"))
+    if K:
+        plan.set_kernel(K)
+    T, H = plan.n_frames(n), plan.height
+    sp = ta.pitch_f32(H)
+    spec = torch.empty((n_tr, T, sp), dtype=torch.float32, device=dev)
+    mm = torch.empty((n_tr, 2), dtype=torch.float32, device=dev)
+    chan = (ta.ChanDesc * n_tr)(*[ta.ChanDesc(wav[i].data_ptr(), spec[i].data_ptr(), n, T, sp) for i in range(n_tr)])
+    for _ in range(3):
+        plan.calc_spec_batch_dev(chan, mm.data_ptr())
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(15):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); plan.calc_spec_batch_dev(chan, mm.data_ptr()); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = float(np.median(ts))
+    frames = n_tr * T
+    bpf = 4 * 512 + 4 * H
+    flops = 2.0 * 1025 * H * frames
+    print(f"cfg4 mel-{H} ({plan.kernel_name}): {n_tr} tracks x {T} frames: {ms:.3f} ms  {frames / ms / 1e3:.1f} Mframes/s  "
+          f"{frames * bpf / ms / 1e6:.0f} GB/s algorithmic ({frames * bpf / ms / 1e6 / 80:.1f}% of 8 TB/s); "
+          f"dense-equivalent mel GEMM {flops / ms / 1e9:.1f} TFLOP/s f32")

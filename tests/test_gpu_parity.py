@@ -142,6 +142,29 @@ def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
     plan.close()
 
 
+@pytest.mark.parametrize("sr,win,hop,n_fft,n_mel", [(44100, 2048, 512, 2048, 128), (48000, 1920, 480, 2048, 0),
+                                                    (48000, 4096, 1024, 4096, 0), (48000, 1024, 256, 1024, 500),
+                                                    (44100, 2048, 512, 2048, 17)])
+def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
+    """The MFMA mel path (wave FFT kernel -> amplitudes -> v_mfma_f32_16x16x4_f32 filterbank) and
+    the generic kernel's banded VALU reduction against the oracle; ragged batch."""
+    want_n_mel = n_mel or orc.mel_default_n_mel(sr, n_fft)
+    fb = orc.calc_mel_fb(sr, n_fft, want_n_mel)
+    wavs = [synth_track(31 + i, sr, n) for i, n in enumerate((50000, 9000, win // 2, 23456))]
+    want = [orc.calc_spec(w, win, hop, n_fft, mel_fb=fb) for w in wavs]
+    fast = "stft_wave_kernel+mel_mfma_kernel" if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
+    for which, name in ((1, "stft_generic_kernel"), (0, fast)):
+        plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
+        if which:
+            plan.set_kernel(which)
+        assert plan.kernel_name == name and plan.height == want_n_mel
+        specs, mm = plan.calc_spec_batch(wavs)
+        for i, (s, w) in enumerate(zip(specs, want)):
+            assert_spec_close(s, w)
+            assert mm[i, 0] == s.min() and mm[i, 1] == s.max()
+        plan.close()
+
+
 def test_calc_spec_batch_ragged(ctx):
     """Ragged batch: different lengths incl. N < win, one silent channel, per-channel min/max."""
     win, hop, n_fft = 2048, 512, 2048

@@ -301,13 +301,21 @@ void DeviceTable::release() {
 
 bool th_plan::use_wave() const {
     if (kernel_choice == 1) return false;
-    return th::stft_wave_supported(g);
+    return th::stft_wave_supported(g) && (g.n_mel == 0 || d_fb_pad != nullptr);
 }
+// mel plans on the wave kernel: amplitude out of the FFT kernel, filterbank on the matrix cores
+bool th_plan::use_mel_mfma() const { return g.n_mel != 0 && use_wave(); }
 
 static void plan_free(th_plan *p) {
     if (!p) return;
     if (p->d_wtab) (void)hipFree(p->d_wtab);
     if (p->d_queue_head) (void)hipFree(p->d_queue_head);
+    if (p->d_fb_pad) (void)hipFree(p->d_fb_pad);
+    if (p->d_kb_jlo) (void)hipFree(p->d_kb_jlo);
+    if (p->d_kb_jhi) (void)hipFree(p->d_kb_jhi);
+    p->amp_buf.release();
+    p->mel_jobs.release();
+    p->mel_tile_start.release();
     if (p->d_window) (void)hipFree(p->d_window);
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_mel_fb) (void)hipFree(p->d_mel_fb);
@@ -396,7 +404,34 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
             lo[m] = b ? a : 0;
             hi[m] = b;
         }
-        rc = up((void **)&p->d_mel_fb, p->h_mel_fb.data(), p->h_mel_fb.size() * sizeof(float));
+        if (n_mel <= 512) {
+            // MFMA mel path tables: filterbank zero-padded to [16*KB][16*NT] (NT in {8,16,24,32}) and,
+            // per K block of 16 bins, the range of N tiles (16 mels each) that hold non-zeros
+            const uint32_t nt_need = (uint32_t)((n_mel + 15) / 16);
+            const uint32_t nt = nt_need <= 8 ? 8 : nt_need <= 16 ? 16 : nt_need <= 24 ? 24 : 32;
+            const uint32_t kb_n = (g.n_freq + 15) / 16, ncol = nt * 16;
+            std::vector<float> pad((size_t)kb_n * 16 * ncol, 0.f);
+            std::vector<uint8_t> jlo(kb_n, 0), jhi(kb_n, 0);
+            for (uint32_t f = 0; f < g.n_freq; f++)
+                for (size_t m = 0; m < n_mel; m++) pad[(size_t)f * ncol + m] = p->h_mel_fb[(size_t)f * n_mel + m];
+            for (uint32_t kb = 0; kb < kb_n; kb++) {
+                uint32_t lo_t = nt, hi_t = 0;
+                for (uint32_t f = 16 * kb; f < 16 * kb + 16 && f < g.n_freq; f++)
+                    for (size_t m = 0; m < n_mel; m++)
+                        if (p->h_mel_fb[(size_t)f * n_mel + m] != 0.f) {
+                            lo_t = std::min<uint32_t>(lo_t, (uint32_t)(m / 16));
+                            hi_t = std::max<uint32_t>(hi_t, (uint32_t)(m / 16) + 1);
+                        }
+                jlo[kb] = (uint8_t)(hi_t ? lo_t : 0);
+                jhi[kb] = (uint8_t)hi_t;
+            }
+            p->mel_kblocks = kb_n;
+            p->mel_ntiles = nt;
+            rc = up((void **)&p->d_fb_pad, pad.data(), pad.size() * sizeof(float));
+            if (rc == TH_OK) rc = up((void **)&p->d_kb_jlo, jlo.data(), jlo.size());
+            if (rc == TH_OK) rc = up((void **)&p->d_kb_jhi, jhi.data(), jhi.size());
+        }
+        if (rc == TH_OK) rc = up((void **)&p->d_mel_fb, p->h_mel_fb.data(), p->h_mel_fb.size() * sizeof(float));
         if (rc == TH_OK) rc = up((void **)&p->d_mel_lo, lo.data(), lo.size() * sizeof(uint32_t));
         if (rc == TH_OK) rc = up((void **)&p->d_mel_hi, hi.data(), hi.size() * sizeof(uint32_t));
     }
@@ -444,6 +479,7 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
 
 TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (!p) return "";
+    if (p->use_mel_mfma()) return "stft_wave_kernel+mel_mfma_kernel";
     return p->use_wave() ? "stft_wave_kernel" : "stft_generic_kernel";
 }
 
@@ -459,8 +495,9 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     TH_REQUIRE(n_chan < (1u << 24), "too many channels");
     th_ctx *c = p->ctx;
     const bool wave = p->use_wave();
+    const bool mel_mfma = p->use_mel_mfma();
     if (p->kernel_choice == 2 && !wave)
-        return fail(TH_ERR_UNSUPPORTED, "the wave kernel covers linear scale, n_fft in {1024, 2048, 4096}");
+        return fail(TH_ERR_UNSUPPORTED, "the wave kernel covers n_fft in {1024, 2048, 4096} (mel: n_mel <= 512)");
     StftGeom g = p->g;       // main launch
     StftGeom ge = p->g;      // edge launch (generic kernel)
     const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);
@@ -484,6 +521,13 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     std::vector<ChanJob> jobs, edge;
     std::vector<uint32_t> tile_start, edge_start;
     uint64_t tiles = 0, edge_tiles = 0;
+    // mel on the matrix cores: the wave kernel stores |X| rows (pitch amp_pitch) into plan-owned
+    // scratch, mel_mfma_kernel contracts them with the filterbank into the caller's spec
+    const uint32_t amp_pitch = (uint32_t)th_pitch_f32((size_t)p->mel_kblocks * 16);
+    std::vector<MelJob> mel_jobs;
+    std::vector<uint32_t> mel_start;
+    std::vector<uint64_t> amp_row0(n_chan, 0);
+    uint64_t mel_tiles = 0, amp_rows = 0;
     auto add = [](std::vector<ChanJob> &v, std::vector<uint32_t> &st, uint64_t &n_tiles, const StftGeom &gg,
                   const th_chan_desc &d, uint32_t T, uint32_t fb0, uint32_t fe0, uint32_t slot) {
         if (fb0 >= fe0) return;
@@ -511,6 +555,14 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
             fa = std::min<uint64_t>(fa, T);
             fb = std::min<uint64_t>(std::max(fb, fa), T);
             add(jobs, tile_start, tiles, g, d, (uint32_t)T, (uint32_t)fa, (uint32_t)fb, (uint32_t)i);
+            if (mel_mfma && fa < fb) {
+                amp_row0[i] = amp_rows;
+                amp_rows += T;
+                mel_jobs.push_back(MelJob{nullptr, d.spec, (uint32_t)fa, (uint32_t)fb,
+                                          (uint32_t)(d.spec_pitch ? d.spec_pitch : g.height), (uint32_t)i});
+                mel_start.push_back((uint32_t)mel_tiles);
+                mel_tiles += (fb - fa + MEL_TILE_FRAMES - 1) / MEL_TILE_FRAMES;
+            }
             add(edge, edge_start, edge_tiles, ge, d, (uint32_t)T, 0, (uint32_t)fa, (uint32_t)i);
             add(edge, edge_start, edge_tiles, ge, d, (uint32_t)T, (uint32_t)fb, (uint32_t)T, (uint32_t)i);
         }
@@ -519,9 +571,32 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     tile_start.push_back((uint32_t)tiles);
     edge_start.push_back((uint32_t)edge_tiles);
 
+    mel_start.push_back((uint32_t)mel_tiles);
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     TH_HIP(hipSetDevice(c->device));
-    int rc = p->jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(ChanJob));
+    int rc = TH_OK;
+    if (mel_mfma && amp_rows) {
+        const size_t need = (size_t)amp_rows * amp_pitch * sizeof(float);
+        if (need > p->amp_buf.cap || p->amp_zeroed < need) {
+            TH_HIP(hipStreamSynchronize(c->stream));
+            rc = p->amp_buf.ensure(need);
+            if (rc != TH_OK) return rc;
+            // the K tail (columns >= n_freq) must read as zero: the wave kernel never writes it
+            TH_HIP(hipMemsetAsync(p->amp_buf.dptr, 0, p->amp_buf.cap, c->stream));
+            p->amp_zeroed = p->amp_buf.cap;
+        }
+        float *amp = static_cast<float *>(p->amp_buf.dptr);
+        size_t mj = 0;
+        for (ChanJob &j : jobs) {  // interior jobs are in channel order, one per channel with interior frames
+            j.spec = amp + amp_row0[j.mm_index] * amp_pitch;
+            j.spec_pitch = amp_pitch;
+            mel_jobs[mj++].amp = j.spec;
+        }
+        rc = p->mel_jobs.upload(c->stream, mel_jobs.data(), mel_jobs.size() * sizeof(MelJob));
+        if (rc == TH_OK) rc = p->mel_tile_start.upload(c->stream, mel_start.data(), mel_start.size() * sizeof(uint32_t));
+        if (rc != TH_OK) return rc;
+    }
+    rc = p->jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(ChanJob));
     if (rc == TH_OK) rc = p->tile_start.upload(c->stream, tile_start.data(), tile_start.size() * sizeof(uint32_t));
     if (rc == TH_OK && !edge.empty()) {
         rc = p->edge_jobs.upload(c->stream, edge.data(), edge.size() * sizeof(ChanJob));
@@ -532,11 +607,15 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     if (wave) {
         TH_HIP(launch_stft_wave(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                 (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, d_minmax, p->d_queue_head,
-                                c->n_cu, waves, c->stream));
-        if (!edge.empty())
+                                c->n_cu, waves, mel_mfma, c->stream));
+        if (mel_mfma)
+            TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
+                                   (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, p->mel_kblocks, amp_pitch, p->d_fb_pad,
+                                   p->mel_ntiles, p->d_kb_jlo, p->d_kb_jhi, g.n_mel, d_minmax, c->stream));
+        if (!edge.empty())  // boundary frames: generic kernel (reflect padding; mel reduction included)
             TH_HIP(launch_stft_generic(ge, (const ChanJob *)p->edge_jobs.dptr, (const uint32_t *)p->edge_tile_start.dptr,
-                                       (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, nullptr,
-                                       nullptr, nullptr, d_minmax, c->stream));
+                                       (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, p->d_mel_fb,
+                                       p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream));
     } else {
         TH_HIP(launch_stft_generic(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                    (uint32_t)jobs.size(), (uint32_t)tiles, p->d_window, p->d_tw, p->d_mel_fb,

@@ -62,6 +62,13 @@ struct th_plan {
     float *d_mel_fb = nullptr;
     uint32_t *d_mel_lo = nullptr, *d_mel_hi = nullptr;
     std::vector<float> h_mel_fb;
+    // MFMA mel path: zero-padded filterbank [16*mel_kblocks][16*mel_ntiles], per-K-block band of N tiles
+    float *d_fb_pad = nullptr;
+    uint8_t *d_kb_jlo = nullptr, *d_kb_jhi = nullptr;
+    uint32_t mel_kblocks = 0, mel_ntiles = 0;
+    th::DeviceTable amp_buf, mel_jobs, mel_tile_start;  // amplitude scratch + job tables of mel_mfma_kernel
+    size_t amp_zeroed = 0;                               // bytes of amp_buf known to be zero-initialised
+    bool use_mel_mfma() const;
     th::DeviceTable jobs, tile_start;            // main launch (wave kernel, or generic for everything)
     th::DeviceTable edge_jobs, edge_tile_start;  // boundary frames handed to the generic kernel
 };

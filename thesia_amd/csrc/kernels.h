@@ -24,7 +24,19 @@ int stft_wave_default_waves(const StftGeom &g);
 // waves: waves per workgroup (4, 8, 12 or 16; <= 0 selects the default for this n_fft)
 hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                             uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
-                            uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s);
+                            uint32_t *d_queue_head, uint32_t n_cu, int waves, bool amp, hipStream_t s);
+
+// ---- kernels_mel.hip: mel filterbank contraction on the matrix cores (spectrogram.rs:207)
+struct MelJob {
+    const float *amp;  // n_frames x amp_pitch linear amplitudes |X| (columns >= n_freq are zero)
+    float *spec;       // n_frames x spec_pitch dB mel spectrogram
+    uint32_t f_begin, f_end, spec_pitch, mm_index;
+};
+constexpr uint32_t MEL_TILE_FRAMES = 64;  // 4 waves x 16 frames per workgroup
+hipError_t launch_mel_mfma(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
+                           uint32_t n_kblocks, uint32_t amp_pitch, const float *d_fb_pad, uint32_t n_ntiles,
+                           const uint8_t *d_kb_jlo, const uint8_t *d_kb_jhi, uint32_t n_mel, float *d_minmax,
+                           hipStream_t s);
 
 // ---- kernels_image.hip
 struct ImgJob {  // device-visible copy of th_img_desc

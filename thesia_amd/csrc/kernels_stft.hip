@@ -246,7 +246,9 @@ __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_
 
 // SHIFT = hop/128 register slots reused between consecutive frames (0 = no reuse: hop not a
 // multiple of 128 samples, hop >= n_fft, or a zero-padded window)
-template <int LOG2_NC, bool PADDED, int WAVES, int SHIFT>
+// AMP: store the linear amplitude |X| instead of dB and skip min/max (first half of the mel path;
+// mel_mfma_kernel then applies the filterbank).
+template <int LOG2_NC, bool PADDED, int WAVES, int SHIFT, bool AMP>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
@@ -319,10 +321,14 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             W::pass3_paired(lane, za, zb, t3);
             TH_SCHED_BARRIER();
             W::split_paired(lane, za, zb, stw, [&](uint32_t k, float p) {
-                const float d = power_to_dB(p);
-                row[k] = d;
-                lmin = nmin(lmin, d);
-                lmax = nmax(lmax, d);
+                if constexpr (AMP) {
+                    row[k] = power_to_amp(p);
+                } else {
+                    const float d = power_to_dB(p);
+                    row[k] = d;
+                    lmin = nmin(lmin, d);
+                    lmax = nmax(lmax, d);
+                }
             });
         } else {
             W::read2(lane, z, slab);
@@ -335,14 +341,16 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             for (int m = 0; m < P; m++) {
                 const uint32_t k = lane + 64u * m;
                 const cf32 zm = W::read_mirror(lane, m, slab);  // mirror partner Z[Nc - k]
-                const float d = power_to_dB(split_power(z[m], zm, stw[k]));
+                const float pw = split_power(z[m], zm, stw[k]);
+                const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
                 row[k] = d;
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }
             if (lane == 0) {  // Nyquist bin k = Nc: partner of Z[0] is Z[0], W^Nc = -1
                 const cf32 wn = {-1.0f, 0.0f};
-                const float d = power_to_dB(split_power(z[0], z[0], wn));
+                const float pw = split_power(z[0], z[0], wn);
+                const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
                 row[NC] = d;
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
@@ -390,7 +398,7 @@ hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const u
 
 namespace th {
 
-bool stft_wave_supported(const StftGeom &g) { return g.n_mel == 0 && g.log2_nc >= 9 && g.log2_nc <= 11; }
+bool stft_wave_supported(const StftGeom &g) { return g.log2_nc >= 9 && g.log2_nc <= 11 && g.n_mel <= 512; }
 
 // Waves per workgroup (one persistent workgroup per CU).  Bounded by LDS (tables + one slab per
 // wave <= 160 KB) and by the VGPR file (64*WAVES threads => 512/(WAVES/4) VGPRs per lane).
@@ -405,11 +413,11 @@ static size_t wave_lds_bytes() {
     return sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
 }
 
-template <int LOG2_NC, bool PADDED, int WAVES, int SHIFT>
-static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
+template <int LOG2_NC, bool PADDED, int WAVES, int SHIFT, bool AMP>
+static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
-    auto kern = stft_wave_kernel<LOG2_NC, PADDED, WAVES, SHIFT>;
+    auto kern = stft_wave_kernel<LOG2_NC, PADDED, WAVES, SHIFT, AMP>;
     const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>();
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -420,6 +428,21 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                        d_tw, d_minmax, d_queue_head);
     return hipGetLastError();
+}
+
+// amplitude output (mel path) is only instantiated for the default launch shape of each n_fft
+template <int LOG2_NC, bool PADDED, int WAVES, int SHIFT>
+static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
+                                 uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
+                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, bool amp, hipStream_t s) {
+    if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
+        if (amp)
+            return launch_wave_t5<LOG2_NC, PADDED, WAVES, SHIFT, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
+                                                                       d_tw, nullptr, d_queue_head, n_cu, s);
+    }
+    if (amp) return hipErrorInvalidValue;
+    return launch_wave_t5<LOG2_NC, PADDED, WAVES, SHIFT, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw,
+                                                                d_minmax, d_queue_head, n_cu, s);
 }
 
 // register-reuse shift of consecutive frames: hop/128 slots when hop is a multiple of 128 samples
@@ -435,7 +458,7 @@ static int wave_shift(const StftGeom &g) {
 template <int LOG2_NC, bool PADDED, int WAVES>
 static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
+                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, bool amp, hipStream_t s) {
     constexpr int P = WaveFft<LOG2_NC>::P;
     const int sh = PADDED ? 0 : wave_shift<LOG2_NC>(g);
     // instantiate the common overlaps only: 75 % (hop = n_fft/4), 50 % and 87.5 %
@@ -443,23 +466,23 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
     if constexpr (!PADDED && (SH) > 0 && (SH) < P)                                                                    \
         if (sh == (SH))                                                                                               \
             return launch_wave_t4<LOG2_NC, PADDED, WAVES, (SH)>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, \
-                                                                d_minmax, d_queue_head, n_cu, s);
+                                                                d_minmax, d_queue_head, n_cu, amp, s);
     TH_SHIFT_CASE(P / 4)
     TH_SHIFT_CASE(P / 2)
     TH_SHIFT_CASE(P / 8)
 #undef TH_SHIFT_CASE
     return launch_wave_t4<LOG2_NC, PADDED, WAVES, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
-                                                     d_queue_head, n_cu, s);
+                                                     d_queue_head, n_cu, amp, s);
 }
 
 template <int LOG2_NC, bool PADDED>
 static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s) {
+                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, bool amp, hipStream_t s) {
 #define TH_WAVE_CASE(WV)                                                                                         \
     case WV:                                                                                                     \
         return launch_wave_t3<LOG2_NC, PADDED, WV>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, \
-                                                   d_queue_head, n_cu, s);
+                                                   d_queue_head, n_cu, amp, s);
     switch (waves) {
         TH_WAVE_CASE(4)
         TH_WAVE_CASE(8)
@@ -473,13 +496,13 @@ static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const
 template <int LOG2_NC>
 static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                 uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s) {
+                                float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, bool amp, hipStream_t s) {
     if (waves <= 0) waves = WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES;
     if (g.win == g.n_fft)
         return launch_wave_t2<LOG2_NC, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
-                                              d_queue_head, n_cu, waves, s);
+                                              d_queue_head, n_cu, waves, amp, s);
     return launch_wave_t2<LOG2_NC, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head,
-                                         n_cu, waves, s);
+                                         n_cu, waves, amp, s);
 }
 
 int stft_wave_default_waves(const StftGeom &g) {
@@ -492,13 +515,13 @@ int stft_wave_default_waves(const StftGeom &g) {
 
 hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                             uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
-                            uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s) {
+                            uint32_t *d_queue_head, uint32_t n_cu, int waves, bool amp, hipStream_t s) {
     if (!n_tiles) return hipSuccess;
     if (!d_queue_head) return hipErrorInvalidValue;
     switch (g.log2_nc) {
-        case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
-        case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
-        case 11: return launch_wave_t<11>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
+        case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, amp, s);
+        case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, amp, s);
+        case 11: return launch_wave_t<11>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, amp, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -345,4 +345,13 @@ TH_HD float power_to_dB(float p) {
 #endif
 }
 
+// |X| from |X|^2 for the mel path (the mel filterbank is applied to amplitudes, spectrogram.rs:200-207)
+TH_HD float power_to_amp(float p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(p);  // v_sqrt_f32, <= 1 ulp
+#else
+    return __builtin_sqrtf(p);
+#endif
+}
+
 }  // namespace th
