@@ -280,6 +280,32 @@ def test_spectrogram_tile_level0_bit_exact(ctx, golden_dir):
         orc.encode_spectrogram_tile(img[:10, :10], one, 1, 0, 0, 0, 0)
 
 
+def test_spectrogram_tile_lod_reference_case(ctx):
+    """render_tiles.rs:435-447: 2x2 -> level (1,1) -> one pixel that must map to colour 1."""
+    spec = np.array([[0, 65535], [65535, 65535]], np.uint16)
+    b = ctx.encode_spectrogram_tile(spec, COLORS2, 4, 1, 1, 0, 0)
+    assert struct.unpack_from("<II", b, 8) == (1, 1)
+    assert b[40:] == bytes([255, 0, 0, 255])
+
+
+@pytest.mark.parametrize("lx,ly", [(1, 0), (0, 1), (1, 1), (2, 1), (1, 3), (3, 3), (5, 2)])
+def test_spectrogram_tile_lod_matches_restated_lanczos3(ctx, golden_dir, lx, ly):
+    """LOD > 0 tiles: separable Lanczos3.  PARITY UNPINNED against fast_image_resize 6.0.0 (source not
+    vendored); the GPU path must at least be identical to the CPU restatement of the textbook filter."""
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    rng = np.random.default_rng(lx * 10 + ly)
+    base = rng.integers(0, 65536, (1025 // 8 + 2, 2813 // 8 + 2), dtype=np.uint16)
+    img = np.kron(base, np.ones((8, 8), np.uint16))[:1025, :2813]            # blocky: exercises ringing / clamping
+    img = (img.astype(np.int64) + rng.integers(-300, 300, img.shape)).clip(0, 65535).astype(np.uint16)
+    d = ctx.to_device(img)
+    for tx, ty in ((0, 0), (1, 0), (0, 1), (2, 1), (9, 9)):
+        got = ctx.encode_spectrogram_tile_dev(d.ptr, img.shape[0], img.shape[1], cmap, 5, lx, ly, tx, ty)
+        want = orc.encode_spectrogram_tile(img, cmap, 5, lx, ly, tx, ty)
+        assert got[:40] == want[:40], (tx, ty)
+        assert got == want, (lx, ly, tx, ty, np.count_nonzero(np.frombuffer(got, np.uint8) != np.frombuffer(want, np.uint8)))
+    d.free()
+
+
 def test_waveform_tile_reference_cases(ctx):
     """render_tiles.rs:408-433"""
     b = ctx.encode_waveform_tile(np.array([-1.0, 0.0, 0.5, 1.0], np.float32), 3, 1, 0)

@@ -63,6 +63,22 @@ constexpr uint32_t RASTER_QUADS_PER_BLOCK = 1024;  // 256 threads x 4 quads of 4
 constexpr uint32_t IMG_TILE_T = 128;  // frames per quantise/transpose tile
 constexpr uint32_t IMG_TILE_F = 64;   // frequency rows per tile
 
+// Separable Lanczos3 LOD resample of a crop of a u16 image (encode_spectrogram_tile, LOD > 0,
+// render_tiles.rs:354-393).  Per output index of an axis the host tabulates the first source index,
+// the tap count, the f64 tap weights and their sum (same order as the CPU restatement).
+struct LodAxis {             // device pointers into one uploaded blob
+    const int32_t *start;    // [n_out] first source index (already clamped to the image / row window)
+    const int32_t *count;    // [n_out] number of taps
+    const double *wsum;      // [n_out] sum of the taps
+    const double *w;         // [n_out][max_taps]
+    uint32_t n_out, max_taps;
+};
+// horizontal pass: tmp[r][ox] for the source rows y_lo + r, r < n_rows; vertical pass: lod[oy][ox]
+hipError_t launch_lod_hpass(const uint16_t *d_img, uint32_t img_pitch, uint32_t y_lo, uint32_t n_rows, LodAxis ax,
+                            uint16_t *d_tmp, hipStream_t s);
+hipError_t launch_lod_vpass(const uint16_t *d_tmp, uint32_t y_lo, LodAxis ay, uint32_t dw, uint16_t *d_lod,
+                            hipStream_t s);
+
 // ---- kernels_waveform.hip
 struct WaveJob {  // device-visible copy of th_wave_desc
     const float *wav;

@@ -216,4 +216,57 @@ hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// LOD > 0 tiles: separable Lanczos3 in f64 with host-tabulated taps (see LodAxis).  The reference
+// delegates this to fast_image_resize 6.0.0, whose source is not vendored: parity is pinned only at
+// level (0,0) (exact copy) and by three coarse tests; this is the textbook filter, bit-identical to
+// the CPU restatement in oracle/ (same taps, same summation order, one rounding per pass).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t lod_round(double acc, double wsum) {
+    double v = wsum != 0.0 ? acc / wsum : 0.0;
+    v = floor(v + 0.5);
+    if (v < 0.0) v = 0.0;
+    if (v > 65535.0) v = 65535.0;
+    return (uint16_t)v;
+}
+
+__global__ __launch_bounds__(256) void lod_hpass_kernel(const uint16_t *__restrict__ img, uint32_t img_pitch,
+                                                        uint32_t y_lo, LodAxis ax, uint16_t *__restrict__ tmp) {
+    const uint32_t ox = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (ox >= ax.n_out) return;
+    const gptr<const uint16_t> row = as_global(img) + (size_t)(y_lo + r) * img_pitch + ax.start[ox];
+    const gptr<const double> w = as_global(ax.w) + (size_t)ox * ax.max_taps;
+    const int32_t n = ax.count[ox];
+    double acc = 0.0;
+    for (int32_t t = 0; t < n; t++) acc += w[t] * (double)row[t];
+    as_global(tmp)[(size_t)r * ax.n_out + ox] = lod_round(acc, ax.wsum[ox]);
+}
+
+__global__ __launch_bounds__(256) void lod_vpass_kernel(const uint16_t *__restrict__ tmp, uint32_t y_lo, LodAxis ay,
+                                                        uint32_t dw, uint16_t *__restrict__ lod) {
+    const uint32_t ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= dw) return;
+    const gptr<const uint16_t> col = as_global(tmp) + (size_t)(ay.start[oy] - (int32_t)y_lo) * dw + ox;
+    const gptr<const double> w = as_global(ay.w) + (size_t)oy * ay.max_taps;
+    const int32_t n = ay.count[oy];
+    double acc = 0.0;
+    for (int32_t t = 0; t < n; t++) acc += w[t] * (double)col[(size_t)t * dw];
+    as_global(lod)[(size_t)oy * dw + ox] = lod_round(acc, ay.wsum[oy]);
+}
+
+hipError_t launch_lod_hpass(const uint16_t *d_img, uint32_t img_pitch, uint32_t y_lo, uint32_t n_rows, LodAxis ax,
+                            uint16_t *d_tmp, hipStream_t s) {
+    if (!n_rows || !ax.n_out) return hipSuccess;
+    hipLaunchKernelGGL(lod_hpass_kernel, dim3((ax.n_out + 255) / 256, n_rows), dim3(256), 0, s, d_img, img_pitch, y_lo, ax,
+                       d_tmp);
+    return hipGetLastError();
+}
+
+hipError_t launch_lod_vpass(const uint16_t *d_tmp, uint32_t y_lo, LodAxis ay, uint32_t dw, uint16_t *d_lod,
+                            hipStream_t s) {
+    if (!ay.n_out || !dw) return hipSuccess;
+    hipLaunchKernelGGL(lod_vpass_kernel, dim3((dw + 255) / 256, ay.n_out), dim3(256), 0, s, d_tmp, y_lo, ay, dw, d_lod);
+    return hipGetLastError();
+}
+
 }  // namespace th
