@@ -74,28 +74,32 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     // read: lanes along frequency (contiguous in the spec)
     const uint32_t i_freq = job.i_start + r0 + lane;
     const bool f_ok = i_freq < job.height && r0 + lane < out_h;
-#pragma unroll 8
-    for (uint32_t dt = wv; dt < IMG_TILE_T; dt += 4) {
-        const uint32_t t = t0 + dt;
-        uint32_t px = 0;
-        if (f_ok && t < job.n_frames)
-            px = quantise(spec[(size_t)t * job.spec_pitch + i_freq], min_dB, span, u16_span, min_value);
-        tile[lane][dt] = (uint16_t)px;
+    // all 32 row segments of this wave are requested before the first is consumed: one HBM latency
+    // per tile instead of one per unroll group
+    float v[IMG_TILE_T / 4];
+#pragma unroll
+    for (uint32_t i = 0; i < IMG_TILE_T / 4; i++) {
+        const uint32_t t = t0 + wv + 4 * i;
+        v[i] = (f_ok && t < job.n_frames) ? spec[(size_t)t * job.spec_pitch + i_freq] : __builtin_nanf("");
     }
+#pragma unroll
+    for (uint32_t i = 0; i < IMG_TILE_T / 4; i++)
+        tile[lane][wv + 4 * i] = (uint16_t)quantise(v[i], min_dB, span, u16_span, min_value);  // NaN -> 0
     __syncthreads();
     // write: lanes along time (contiguous in the image), two samples per lane
     const uint32_t t = t0 + 2 * lane;
-#pragma unroll 4
-    for (uint32_t dr = wv; dr < IMG_TILE_F; dr += 4) {
-        const uint32_t r = r0 + dr;
-        if (r >= out_h) break;
+#pragma unroll
+    for (uint32_t i = 0; i < IMG_TILE_F / 4; i++) {
+        const uint32_t dr = wv + 4 * i, r = r0 + dr;
         const uint32_t pair = *reinterpret_cast<const uint32_t *>(&tile[dr][2 * lane]);
         const size_t e = (size_t)r * job.img_pitch + t;
-        if (t + 1 < job.n_frames && (e & 1) == 0 && (reinterpret_cast<uintptr_t>(job.img) & 3) == 0) {
-            *reinterpret_cast<gptr<uint32_t>>(img + e) = pair;
-        } else {
-            if (t < job.n_frames) img[e] = (uint16_t)(pair & 0xffffu);
-            if (t + 1 < job.n_frames) img[e + 1] = (uint16_t)(pair >> 16);
+        if (r < out_h) {
+            if (t + 1 < job.n_frames && (e & 1) == 0 && (reinterpret_cast<uintptr_t>(job.img) & 3) == 0) {
+                *reinterpret_cast<gptr<uint32_t>>(img + e) = pair;
+            } else {
+                if (t < job.n_frames) img[e] = (uint16_t)(pair & 0xffffu);
+                if (t + 1 < job.n_frames) img[e + 1] = (uint16_t)(pair >> 16);
+            }
         }
     }
 }
