@@ -166,6 +166,12 @@ def cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft, target_s=15.0):
     except Exception:
         cores = os.cpu_count()
     cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+    try:  # a cgroup CPU quota (containers) bounds the threads that can actually run
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            cores = max(1, min(cores, int(-(-int(q[0]) // int(q[1])))))
+    except Exception:
+        pass
     n_s = min(n, 10 * sr)  # 10 s tracks keep the sample bounded
     pool_tracks = [synth_track(i, sr, n_s) for i in range(8)]  # inputs generated outside the timed region
 
