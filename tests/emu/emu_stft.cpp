@@ -11,7 +11,7 @@
 
 using namespace th;
 
-template <int LOG2_NC, bool PADDED>
+template <int LOG2_NC>
 static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, const StftGeom &g, const cf32 *wtab,
                       const cf32 *tw, float *row) {
     using W = WaveFft<LOG2_NC>;
@@ -21,7 +21,7 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
     std::vector<cf32> t2(W::T2_LEN), t3(W::T3_LEN);
     const int64_t e0 = (int64_t)frame * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
     for (uint32_t t = 0; t < 256; t++) W::fill_tables(t, 256, tw, t2.data(), t3.data());
-    for (uint32_t l = 0; l < 64; l++) wave_fetch<P, PADDED, 0>(l, x[l], wav, e0, g);
+    for (uint32_t l = 0; l < 64; l++) wave_fetch<P, 0>(l, x[l], wav, e0);
     for (uint32_t l = 0; l < 64; l++) wave_window<P>(l, z[l], x[l], wtab);
     for (uint32_t l = 0; l < 64; l++) W::pass1(l, z[l], slab.data());
     for (uint32_t l = 0; l < 64; l++) W::read1(l, z[l], slab.data());
@@ -75,21 +75,17 @@ extern "C" __attribute__((visibility("default"))) int emu_stft_wave(const float 
     std::vector<float> wpad(n_fft, 0.0f);
     for (uint32_t i = 0; i < win; i++) wpad[g.pad_left + i] = 0.5f * window[i];
     for (uint32_t n = 0; n < g.nc; n++) wtab[n] = {wpad[2 * n], wpad[2 * n + 1]};
-    const bool padded = win != n_fft;
     for (uint32_t f = 0; f < n_frames; f++) {
         float *row = out + (size_t)f * g.n_freq;
-        const int64_t s0 = (int64_t)f * hop - (int64_t)(win / 2);
-        if (s0 < 0 || s0 + (int64_t)win > (int64_t)n_samples) {  // boundary frame: not the wave kernel's job
+        const int64_t e0 = (int64_t)f * hop - (int64_t)(win / 2) - (int64_t)g.pad_left;
+        if (e0 < 0 || e0 + (int64_t)n_fft > (int64_t)n_samples) {  // boundary frame: not the wave kernel's job
             for (uint32_t k = 0; k < g.n_freq; k++) row[k] = NAN;
             continue;
         }
         switch (n_fft) {
-            case 1024: padded ? emu_frame<9, true>(wav, n_samples, f, g, wtab.data(), tw.data(), row)
-                              : emu_frame<9, false>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
-            case 2048: padded ? emu_frame<10, true>(wav, n_samples, f, g, wtab.data(), tw.data(), row)
-                              : emu_frame<10, false>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
-            case 4096: padded ? emu_frame<11, true>(wav, n_samples, f, g, wtab.data(), tw.data(), row)
-                              : emu_frame<11, false>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
+            case 1024: emu_frame<9>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
+            case 2048: emu_frame<10>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
+            case 4096: emu_frame<11>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
             default: return -1;
         }
     }

@@ -38,8 +38,8 @@ def test_emulated_wave_kernel_matches_oracle(emu, win, hop, n_fft, n):
     assert rc == 0
     want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
     interior = ~np.isnan(out[:, 0])  # the wave kernel takes interior frames only (edges -> generic kernel)
-    s0 = np.arange(T) * hop - win // 2
-    assert np.array_equal(interior, (s0 >= 0) & (s0 + win <= n))
+    e0 = np.arange(T) * hop - win // 2 - (n_fft - win) // 2     # start of the frame's n_fft-sample span
+    assert np.array_equal(interior, (e0 >= 0) & (e0 + n_fft <= n))
     if n >= 2 * win:
         assert interior.sum() >= T - 6
     got_amp = np.power(10.0, out[interior].astype(np.float64) / 20.0)

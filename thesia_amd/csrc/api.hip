@@ -469,7 +469,7 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     // bits 0-7: 0 auto, 1 generic, 2 wave;  bits 8-15 (tuning): waves per workgroup of the wave kernel
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
     TH_REQUIRE(k >= 0 && k <= 2, "kernel selector must be 0, 1 or 2");
-    TH_REQUIRE(wv == 0 || wv == 4 || wv == 8 || wv == 12 || wv == 16, "waves per workgroup must be 4, 8, 12 or 16");
+    TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 8 || wv == 12 || wv == 16, "waves per workgroup must be 4, 6, 8, 12 or 16");
     p->kernel_choice = k;
     p->wave_waves = wv;
     p->wave_chunk = (which >> 16) & 0xff;  // tuning: frames per chunk of the wave kernel (0 = default)
@@ -549,9 +549,11 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
         if (!wave) {
             add(jobs, tile_start, tiles, g, d, (uint32_t)T, 0, (uint32_t)T, (uint32_t)i);
         } else {
-            const uint64_t half = g.win / 2, N = d.n_samples;
-            uint64_t fa = (half + g.hop - 1) / g.hop;                    // first f with f*hop - win/2 >= 0
-            uint64_t fb = N + half >= g.win ? (N + half - g.win) / g.hop + 1 : 0;  // one past the last f with s0 + win <= N
+            // interior = the frame's whole n_fft-sample span [e0, e0 + n_fft), e0 = f*hop - win/2 - pad_left,
+            // lies inside the channel (the wave kernel loads it unconditionally)
+            const uint64_t lead = g.win / 2 + g.pad_left, N = d.n_samples;
+            uint64_t fa = (lead + g.hop - 1) / g.hop;                          // first f with e0 >= 0
+            uint64_t fb = N + lead >= g.n_fft ? (N + lead - g.n_fft) / g.hop + 1 : 0;  // one past the last f with e0 + n_fft <= N
             fa = std::min<uint64_t>(fa, T);
             fb = std::min<uint64_t>(std::max(fb, fa), T);
             add(jobs, tile_start, tiles, g, d, (uint32_t)T, (uint32_t)fa, (uint32_t)fb, (uint32_t)i);

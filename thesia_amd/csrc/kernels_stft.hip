@@ -245,10 +245,10 @@ __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_
 }
 
 // SHIFT = hop/128 register slots reused between consecutive frames (0 = no reuse: hop not a
-// multiple of 128 samples, hop >= n_fft, or a zero-padded window)
+// multiple of 128 samples or hop >= n_fft)
 // AMP: store the linear amplitude |X| instead of dB and skip min/max (first half of the mel path;
 // mel_mfma_kernel then applies the filterbank).
-template <int LOG2_NC, bool PADDED, int WAVES, int SHIFT, bool AMP>
+template <int LOG2_NC, int WAVES, int SHIFT, bool AMP>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
@@ -256,7 +256,6 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
     static_assert(SHIFT >= 0 && SHIFT < P, "shift must leave something to reuse");
-    static_assert(!(PADDED && SHIFT > 0), "a zero-padded window cannot reuse registers across frames");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *wtab = reinterpret_cast<cf32 *>(smem_raw);
     cf32 *stw = wtab + NC;
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     bool mm_dirty = false;  // a wave that never got a frame must not touch any slot
 
     cf32 x[P];  // raw samples of the current frame, then (shifted + refilled) of the next one
-    if (cur.valid) wave_fetch<P, PADDED, 0>(lane, x, cur.wav, frame_e0(cur, g), g);
+    if (cur.valid) wave_fetch<P, 0>(lane, x, cur.wav, frame_e0(cur, g));
     while (cur.valid) {
         cf32 z[P];
         wave_window<P>(lane, z, x, wtab);
@@ -292,9 +291,9 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             if (SHIFT > 0 && !nxt.fresh) {
 #pragma unroll
                 for (int m = 0; m + SHIFT < P; m++) x[m] = x[m + SHIFT];
-                wave_fetch<P, PADDED, P - SHIFT>(lane, x, nxt.wav, frame_e0(nxt, g), g);
+                wave_fetch<P, P - SHIFT>(lane, x, nxt.wav, frame_e0(nxt, g));
             } else {
-                wave_fetch<P, PADDED, 0>(lane, x, nxt.wav, frame_e0(nxt, g), g);
+                wave_fetch<P, 0>(lane, x, nxt.wav, frame_e0(nxt, g));
             }
         }
         TH_SCHED_BARRIER();
@@ -404,7 +403,7 @@ bool stft_wave_supported(const StftGeom &g) { return g.log2_nc >= 9 && g.log2_nc
 // wave <= 160 KB) and by the VGPR file (64*WAVES threads => 512/(WAVES/4) VGPRs per lane).
 template <int LOG2_NC>
 struct WaveLaunchCfg {
-    static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? 4 : 16;
+    static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? 6 : 16;  // n_fft = 4096: 153 KB of LDS at 6 waves
 };
 
 template <int LOG2_NC, int WAVES>
@@ -413,11 +412,11 @@ static size_t wave_lds_bytes() {
     return sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
 }
 
-template <int LOG2_NC, bool PADDED, int WAVES, int SHIFT, bool AMP>
+template <int LOG2_NC, int WAVES, int SHIFT, bool AMP>
 static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
-    auto kern = stft_wave_kernel<LOG2_NC, PADDED, WAVES, SHIFT, AMP>;
+    auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, AMP>;
     const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>();
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -431,17 +430,17 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
 }
 
 // amplitude output (mel path) is only instantiated for the default launch shape of each n_fft
-template <int LOG2_NC, bool PADDED, int WAVES, int SHIFT>
+template <int LOG2_NC, int WAVES, int SHIFT>
 static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, bool amp, hipStream_t s) {
     if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
         if (amp)
-            return launch_wave_t5<LOG2_NC, PADDED, WAVES, SHIFT, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
+            return launch_wave_t5<LOG2_NC, WAVES, SHIFT, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                                                                        d_tw, nullptr, d_queue_head, n_cu, s);
     }
     if (amp) return hipErrorInvalidValue;
-    return launch_wave_t5<LOG2_NC, PADDED, WAVES, SHIFT, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw,
+    return launch_wave_t5<LOG2_NC, WAVES, SHIFT, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw,
                                                                 d_minmax, d_queue_head, n_cu, s);
 }
 
@@ -450,41 +449,42 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
 template <int LOG2_NC>
 static int wave_shift(const StftGeom &g) {
     constexpr int P = WaveFft<LOG2_NC>::P;
-    if (g.win != g.n_fft || g.hop % 128 != 0) return 0;
+    if (g.hop % 128 != 0) return 0;
     const int sh = (int)(g.hop / 128);
     return (sh >= 1 && sh < P) ? sh : 0;
 }
 
-template <int LOG2_NC, bool PADDED, int WAVES>
+template <int LOG2_NC, int WAVES>
 static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, bool amp, hipStream_t s) {
     constexpr int P = WaveFft<LOG2_NC>::P;
-    const int sh = PADDED ? 0 : wave_shift<LOG2_NC>(g);
+    const int sh = wave_shift<LOG2_NC>(g);
     // instantiate the common overlaps only: 75 % (hop = n_fft/4), 50 % and 87.5 %
 #define TH_SHIFT_CASE(SH)                                                                                             \
-    if constexpr (!PADDED && (SH) > 0 && (SH) < P)                                                                    \
+    if constexpr ((SH) > 0 && (SH) < P)                                                                               \
         if (sh == (SH))                                                                                               \
-            return launch_wave_t4<LOG2_NC, PADDED, WAVES, (SH)>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, \
+            return launch_wave_t4<LOG2_NC, WAVES, (SH)>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, \
                                                                 d_minmax, d_queue_head, n_cu, amp, s);
     TH_SHIFT_CASE(P / 4)
     TH_SHIFT_CASE(P / 2)
     TH_SHIFT_CASE(P / 8)
 #undef TH_SHIFT_CASE
-    return launch_wave_t4<LOG2_NC, PADDED, WAVES, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
+    return launch_wave_t4<LOG2_NC, WAVES, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
                                                      d_queue_head, n_cu, amp, s);
 }
 
-template <int LOG2_NC, bool PADDED>
+template <int LOG2_NC>
 static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, bool amp, hipStream_t s) {
 #define TH_WAVE_CASE(WV)                                                                                         \
     case WV:                                                                                                     \
-        return launch_wave_t3<LOG2_NC, PADDED, WV>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, \
+        return launch_wave_t3<LOG2_NC, WV>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, \
                                                    d_queue_head, n_cu, amp, s);
     switch (waves) {
         TH_WAVE_CASE(4)
+        TH_WAVE_CASE(6)
         TH_WAVE_CASE(8)
         TH_WAVE_CASE(12)
         TH_WAVE_CASE(16)
@@ -498,11 +498,8 @@ static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const 
                                 uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, bool amp, hipStream_t s) {
     if (waves <= 0) waves = WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES;
-    if (g.win == g.n_fft)
-        return launch_wave_t2<LOG2_NC, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
-                                              d_queue_head, n_cu, waves, amp, s);
-    return launch_wave_t2<LOG2_NC, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head,
-                                         n_cu, waves, amp, s);
+    return launch_wave_t2<LOG2_NC>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu,
+                                   waves, amp, s);
 }
 
 int stft_wave_default_waves(const StftGeom &g) {

@@ -301,30 +301,21 @@ TH_HD float split_power(cf32 zk, cf32 zm, cf32 w) {
 namespace th {
 
 // ---------------------------------------------------------------------------------------------
-// Frame load: lane j fetches x[m] = (fr[2n], fr[2n+1]), n = j + 64*m, of the zero-padded frame
-// (stft.rs:137-146); e0 = signal position of frame element 0 (= k*hop - win/2 - pad_left).
-// The wave kernel only takes INTERIOR frames (every windowed sample inside [0, n_samples)): plain
-// coalesced 8-byte loads, no reflection.  Frames that touch the signal boundaries (the first and
-// last few per channel, and every frame of inputs shorter than the window) go to the generic
-// kernel, which implements the reflect padding.
-// ---------------------------------------------------------------------------------------------
+// Frame load: lane j fetches x[m] = (fr[2n], fr[2n+1]), n = j + 64*m, of the frame's n_fft-sample
+// span starting at signal position e0 = k*hop - win/2 - pad_left (stft.rs:137-146).  The zero
+// padding of a window shorter than n_fft is applied by the window table (zeros there), so the
+// load is the same for every window length: plain coalesced 8-byte loads, no predication.
+// The wave kernel only takes INTERIOR frames (the whole n_fft span inside [0, n_samples)).  Frames
+// that touch the signal boundaries (the first and last few per channel, and every frame of inputs
+// shorter than n_fft) go to the generic kernel, which implements the reflect padding.
 // M0: first slot to (re)load — 0 loads the whole frame, P - S only the S slots that are new after the
 // previous frame's registers were moved down by S slots.
-template <int P, bool PADDED, int M0, class WavPtr>
-TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0, const StftGeom &g) {
+// ---------------------------------------------------------------------------------------------
+template <int P, int M0, class WavPtr>
+TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0) {
     for (int m = M0; m < P; m++) {
-        const uint32_t n = lane + 64u * m;
-        float x0 = 0.0f, x1 = 0.0f;
-        if (!PADDED) {
-            const WavPtr p = wav + (e0 + 2 * (int64_t)n);  // two adjacent dwords: merged into one 8-byte load
-            x0 = p[0];
-            x1 = p[1];
-        } else {
-            const uint32_t i0 = 2 * n - g.pad_left, i1 = i0 + 1;  // unsigned: < win  <=>  inside the window
-            if (i0 < g.win) x0 = wav[e0 + 2 * (int64_t)n];
-            if (i1 < g.win) x1 = wav[e0 + 2 * (int64_t)n + 1];
-        }
-        x[m] = {x0, x1};
+        const WavPtr p = wav + (e0 + 2 * (int64_t)(lane + 64u * m));  // two adjacent dwords: one 8-byte load
+        x[m] = {p[0], p[1]};
     }
 }
 
