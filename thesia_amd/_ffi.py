@@ -11,7 +11,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libthesia_amd.so")
+# THESIA_AMD_LIB: development override to A/B a variant build of the same library (scripts/build_variant.sh)
+LIB_PATH = os.environ.get("THESIA_AMD_LIB") or os.path.join(_HERE, "libthesia_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -181,6 +181,33 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
 #define TH_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// Development instrumentation (variant builds with -DTH_PHASE_PROF only, scripts/phase_prof.py): per-phase
+// shader-clock totals of the wave kernel's frame loop, summed over all waves.
+#if defined(TH_PHASE_PROF)
+__device__ unsigned long long th_phase_prof_dev[16];
+#define TH_PROF_DECL()                                                                               \
+    unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+    const unsigned long long prof_rt0 = wall_clock64(), prof_c0 = prof_t
+#define TH_PROF_MARK(i)                                              \
+    do {                                                             \
+        const unsigned long long t_ = __builtin_readcyclecounter();  \
+        prof_acc[i] += t_ - prof_t;                                  \
+        prof_t = t_;                                                 \
+    } while (0)
+#define TH_PROF_FLUSH(lane)                                                              \
+    do {                                                                                 \
+        if ((lane) == 0) {                                                               \
+            for (int i_ = 0; i_ < 9; i_++) atomicAdd(&th_phase_prof_dev[i_], prof_acc[i_]); \
+            atomicAdd(&th_phase_prof_dev[9], wall_clock64() - prof_rt0);   /* 100 MHz */   \
+            atomicAdd(&th_phase_prof_dev[10], __builtin_readcyclecounter() - prof_c0);      \
+        }                                                                                \
+    } while (0)
+#else
+#define TH_PROF_DECL() ((void)0)
+#define TH_PROF_MARK(i) ((void)0)
+#define TH_PROF_FLUSH(lane) ((void)0)
+#endif
+
 // Orders this wave's LDS writes before its later LDS reads (and vice versa) for the compiler; the
 // hardware already executes one wave's DS instructions in order, so no instruction is needed.
 __device__ __forceinline__ void wave_lds_sync() {
@@ -274,6 +301,14 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     __syncthreads();
 
     cf32 *slab = slabs + (size_t)wave * W::SLAB_LEN;
+#if defined(TH_EXP_PRIO)
+    {   // experiment: distinct static issue priorities for the waves that share a SIMD
+        const uint32_t pr = TH_EXP_PRIO == 1 ? (wave >> 2) & 3u : wave & 3u;
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
+#endif
     FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
 
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
@@ -282,8 +317,29 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 
     cf32 x[P];  // raw samples of the current frame, then (shifted + refilled) of the next one
     if (cur.valid) wave_fetch<P, 0>(lane, x, cur.wav, frame_e0(cur, g));
+    // Drain the first fetch before entering the loop.  The compiler's s_waitcnt bookkeeping merges the
+    // loop pre-header with the back edge; with loads still in flight here it concludes that x[] may be the
+    // YOUNGEST outstanding operations and waits with vmcnt(0) at the top of every frame — i.e. for the 17
+    // row stores the previous frame has just issued (a full HBM write latency per frame).  With nothing
+    // pending at entry the waits become vmcnt(>= 17): loads only, the stores keep streaming.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
+    const uint32_t lane_wave = lane;
+    TH_PROF_DECL();
     while (cur.valid) {
+        TH_PROF_MARK(8);
+        // Per-frame opaque copy of the lane id.  Everything below addresses LDS and the output row as
+        // "f(lane) + immediate"; left loop-invariant, LICM hoists ~40 such addresses out of the frame loop
+        // and the register allocator spills them.  Recomputing the handful of bases per frame is cheaper.
+        uint32_t lane = lane_wave;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lane));
+#endif
+        lane &= 63u;
+        // LDS reads return in order and a read issued next to its use exposes the whole LDS latency, so all
+        // table reads are issued ahead of their use (lds_ld keeps program order): pass-2 twiddles before the
+        // pass-1 arithmetic, pass-3 and split twiddles together with the reads of exchange 2.
         cf32 z[P];
+        cf32 w2[W::R2 - 1];
         wave_window<P>(lane, z, x, wtab);
         // request the next frame now: its samples land while this frame is transformed
         const FrameCursor nxt = cursor_next(cur, g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
@@ -297,39 +353,73 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             }
         }
         TH_SCHED_BARRIER();
+#if defined(TH_EXP_WAITLOADS)
+        TH_PROF_MARK(7);                     // experiment: expose the global-load latency in phase 0
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#endif
+        TH_PROF_MARK(0);
+        W::load_t2(lane, w2, t2);  // lands during the pass-1 arithmetic
         W::pass1(lane, z, slab);
         wave_lds_sync();
         TH_SCHED_BARRIER();
+        TH_PROF_MARK(1);
         W::read1(lane, z, slab);
         wave_lds_sync();
-        W::pass2(lane, z, t2, slab);
-        wave_lds_sync();
-        TH_SCHED_BARRIER();
+        TH_PROF_MARK(2);
+        W::pass2_twiddle(z, w2);
 
         if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
             flush_minmax(minmax, mm_slot, lane, lmin, lmax);
             lmin = __builtin_inff();
             lmax = -__builtin_inff();
         }
+#if defined(TH_EXP_SMALLROW)
+        const gptr<float> row = cur.spec + (size_t)(cur.f & 7u) * cur.spec_pitch;  // experiment: L2-resident output
+#else
         const gptr<float> row = cur.spec + (size_t)cur.f * cur.spec_pitch;
+#endif
         if constexpr (W::PAIRED) {
             // mirror-local last pass: every Z[k] / Z[Nc-k] pair ends up in one lane's registers
+            W::pass2_dft(lane, z, slab);
+            wave_lds_sync();
+            TH_SCHED_BARRIER();
+            TH_PROF_MARK(3);
+            cf32 wa[W::NQ][W::R3 - 1], wb[W::NQ][W::R3 - 1];
+            W::load_t3_paired(lane, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
             cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
             W::read2_paired(lane, za, zb, slab);
             wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
-            W::pass3_paired(lane, za, zb, t3);
+            constexpr bool PRELOAD_STW = W::NQ * W::R3 <= 8;  // 16 VGPRs at n_fft = 2048; too many at 4096
+            cf32 ws[W::NQ][W::R3];
+            if constexpr (PRELOAD_STW) W::load_stw_paired(lane, ws, stw);
             TH_SCHED_BARRIER();
-            W::split_paired(lane, za, zb, stw, [&](uint32_t k, float p) {
+            TH_PROF_MARK(4);
+            W::pass3_paired_w(za, zb, wa, wb);
+            TH_SCHED_BARRIER();
+            TH_PROF_MARK(5);
+            if constexpr (!PRELOAD_STW) W::load_stw_paired(lane, ws, stw);
+            W::split_paired_w(lane, za, zb, ws, stw, [&](int32_t k, float p) {
                 if constexpr (AMP) {
                     row[k] = power_to_amp(p);
                 } else {
+#if defined(TH_EXP_NOLOG)
+                    const float d = p;
+#else
                     const float d = power_to_dB(p);
+#endif
+#if defined(TH_EXP_NOSTORE)
+                    if (d == 12345.678f) row[k] = d;  // experiment: (almost) never stores
+#else
                     row[k] = d;
+#endif
                     lmin = nmin(lmin, d);
                     lmax = nmax(lmax, d);
                 }
             });
         } else {
+            W::pass2_dft(lane, z, slab);
+            wave_lds_sync();
+            TH_SCHED_BARRIER();
             W::read2(lane, z, slab);
             W::pass3(lane, z, t3);
             wave_lds_sync();
@@ -359,10 +449,25 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         mm_slot = cur.mm_index;
         mm_dirty = true;
         TH_SCHED_BARRIER();
+        TH_PROF_MARK(6);
         cur = nxt;
     }
     if (minmax != nullptr && mm_dirty) flush_minmax(minmax, mm_slot, lane, lmin, lmax);
+    TH_PROF_FLUSH(lane_wave);
 }
+
+#if defined(TH_PHASE_PROF)
+}  // namespace th
+extern "C" __attribute__((visibility("default"))) int th_debug_phase_prof(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(th::th_phase_prof_dev), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(th::th_phase_prof_dev), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace th {
+#endif
 
 // ------------------------------------------------------------------------------------------
 // launchers

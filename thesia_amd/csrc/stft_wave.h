@@ -20,6 +20,29 @@
 
 namespace th {
 
+// 8-byte LDS read that the backend may not fuse with a neighbour.  hipcc pairs adjacent 8-byte LDS
+// loads into ds_read2_b64 / ds_read2st64_b64, which on gfx950 occupy the LDS pipe for 8 cycles per
+// wave-instruction; two separate ds_read_b64 take 2 x 2.2 (scripts/ubench/lds_rate.hip).  A volatile
+// access is left alone by the load/store optimiser and still gets exact s_waitcnt tracking.
+TH_HD cf32 lds_ld(const cf32 *p) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TH_LDS_PAIRED_READS)
+    // LDS address space, explicit: address-space inference does not look through volatile accesses
+    // (they would become flat loads).  Loaded as one 64-bit integer and split, not as a float2 vector:
+    // vector-typed values make the backend pick half-rate v_pk_*_f32 for the arithmetic that follows.
+    const uint64_t v = *(const volatile __attribute__((address_space(3))) uint64_t *)(p);
+    return {__builtin_bit_cast(float, (uint32_t)v), __builtin_bit_cast(float, (uint32_t)(v >> 32))};
+#else
+    return *p;
+#endif
+}
+
+// full unrolling is required everywhere below: register arrays must never be indexed dynamically
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TH_UNROLL _Pragma("unroll")
+#else
+#define TH_UNROLL
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // register DFTs (forward).  Outputs are left in "digit-reversed slots"; OUT_SLOT maps natural
 // output index -> register slot, so callers permute at compile time for free.
@@ -113,15 +136,15 @@ struct WaveFftCfg<11> {  // n_fft = 4096: Nc = 2048 = 16 * 16 * 8, P = 32
 };
 
 // LDS layout of the first exchange (pass-1 output, Ns = 1): lane jj writes the R1 consecutive
-// slots R1*jj + r.  Rows are padded by one slot (pad1(i) = i + i/R1): the 16 lanes of a
-// ds_write_b64 group then start 2 banks apart and never collide, and — unlike an XOR swizzle —
-// every address is "per-lane base + compile-time immediate" for the writes (base = (R1+1)*jj, imm = r)
-// and for the reads of pass 2 (i = lane + 64*m: base = pad1(lane), imm = (64 + 64/R1)*m), so no
-// address registers stay live across the frame loop.
-template <int R1>
-TH_HD uint32_t pad1(uint32_t i) {
-    return i + i / R1;
-}
+// slots R1*jj + r.  One pad slot per 32 (pad1(i) = i + i/32) makes both sides of the transpose
+// conflict-free at the cheapest rate the LDS has (scripts/ubench/lds_rate.hip):
+//   writes: the 32 lanes of a half wave start at dword 2*R1*jj + 2*(R1*jj/32), i.e. on 32 distinct bank pairs;
+//   reads (pass 2, i = lane + 64*m): a half wave reads 32 CONSECUTIVE slots = all 64 banks once, 2.2 cycles
+//          per wave-instruction.  (A pad per R1 slots made a half wave span 33+ slots: 4 cycles.)
+// Unlike an XOR swizzle every address is "per-lane base + compile-time immediate": writes
+// base = pad1(R1*jj), imm = r (R1 divides 32, so R1*jj + r stays inside the 32-group); reads
+// base = pad1(lane), imm = 66*m.  No address registers stay live across the frame loop.
+TH_HD uint32_t pad1(uint32_t i) { return i + (i >> 5); }
 
 template <int LOG2_NC>
 struct WaveFft {
@@ -152,52 +175,68 @@ struct WaveFft {
 
     // pass 1 (Ns = 1, no twiddles): registers -> LDS slab (swizzled)
     static TH_HD void pass1(uint32_t lane, cf32 (&z)[P], cf32 *slab) {
-        for (int b = 0; b < B1; b++) {
+        TH_UNROLL for (int b = 0; b < B1; b++) {
             cf32 v[R1];
-            for (int r = 0; r < R1; r++) v[r] = z[b + B1 * r];
+            TH_UNROLL for (int r = 0; r < R1; r++) v[r] = z[b + B1 * r];
             RegDft<R1>::run(v);
             const uint32_t jj = lane + 64u * b;
-            for (int r = 0; r < R1; r++) slab[jj * (R1 + 1) + r] = v[RegDft<R1>::slot(r)];  // = pad1(jj*R1 + r)
+            TH_UNROLL for (int r = 0; r < R1; r++) slab[pad1(jj * R1) + r] = v[RegDft<R1>::slot(r)];  // = pad1(jj*R1 + r)
         }
     }
     static TH_HD void read1(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
-        for (int m = 0; m < P; m++) z[m] = slab[pad1<R1>(lane) + (64u + 64u / R1) * m];  // = pad1(lane + 64*m)
+        TH_UNROLL for (int m = 0; m < P; m++) z[m] = lds_ld(&slab[pad1(lane) + 66u * m]);  // = pad1(lane + 64*m)
     }
 
-    // pass 2 (Ns = R1): registers -> LDS slab (linear)
-    static TH_HD void pass2(uint32_t lane, cf32 (&z)[P], const cf32 *t2, cf32 *slab) {
-        for (int b = 0; b < B2; b++) {
+    // pass 2 (Ns = R1): registers -> LDS slab (linear).  In three pieces so that the kernel can issue the
+    // twiddle reads long before their use (LDS returns in order: a read issued next to its use exposes
+    // the whole LDS latency): load_t2 -> pass2_twiddle -> pass2_dft.  pass2() is the composition.
+    static TH_HD void load_t2(uint32_t lane, cf32 (&w2)[R2 - 1], const cf32 *t2) {
+        const uint32_t k = lane & (NS2 - 1);  // NS2 <= 64: the same twiddles for every butterfly of the lane
+        TH_UNROLL for (int r = 1; r < R2; r++) w2[r - 1] = lds_ld(&t2[(r - 1) * NS2 + k]);
+    }
+    static TH_HD void pass2_twiddle(cf32 (&z)[P], const cf32 (&w2)[R2 - 1]) {
+        TH_UNROLL for (int b = 0; b < B2; b++)
+            TH_UNROLL for (int r = 1; r < R2; r++) z[b + B2 * r] = cmul(z[b + B2 * r], w2[r - 1]);
+    }
+    static TH_HD void pass2_dft(uint32_t lane, cf32 (&z)[P], cf32 *slab) {
+        TH_UNROLL for (int b = 0; b < B2; b++) {
             const uint32_t jj = lane + 64u * b, k = jj & (NS2 - 1);
             cf32 v[R2];
-            v[0] = z[b];
-            for (int r = 1; r < R2; r++) v[r] = cmul(z[b + B2 * r], t2[(r - 1) * NS2 + k]);
+            TH_UNROLL for (int r = 0; r < R2; r++) v[r] = z[b + B2 * r];
             RegDft<R2>::run(v);
             const uint32_t j0 = (jj - k) * R2 + k;
-            for (int r = 0; r < R2; r++) slab[j0 + r * NS2] = v[RegDft<R2>::slot(r)];
+            TH_UNROLL for (int r = 0; r < R2; r++) slab[j0 + r * NS2] = v[RegDft<R2>::slot(r)];
         }
     }
+    static TH_HD void pass2(uint32_t lane, cf32 (&z)[P], const cf32 *t2, cf32 *slab) {
+        cf32 w2[R2 - 1];
+        load_t2(lane, w2, t2);
+        pass2_twiddle(z, w2);
+        pass2_dft(lane, z, slab);
+    }
     static TH_HD void read2(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
-        for (int m = 0; m < P; m++) z[m] = slab[lane + 64u * m];
+        TH_UNROLL for (int m = 0; m < P; m++) z[m] = slab[lane + 64u * m];
     }
 
     // pass 3 (Ns = R1*R2, last): registers -> registers, lane j ends with Z[j + 64*m] in z[m]
     static TH_HD void pass3(uint32_t lane, cf32 (&z)[P], const cf32 *t3) {
-        for (int b = 0; b < B3; b++) {
+        TH_UNROLL for (int b = 0; b < B3; b++) {
             const uint32_t jj = lane + 64u * b;
             cf32 v[R3];
             v[0] = z[b];
-            for (int r = 1; r < R3; r++) v[r] = cmul(z[b + B3 * r], t3[(r - 1) * NS3 + jj]);
+            TH_UNROLL for (int r = 1; r < R3; r++) v[r] = cmul(z[b + B3 * r], t3[(r - 1) * NS3 + jj]);
             RegDft<R3>::run(v);
-            for (int r = 0; r < R3; r++) z[b + B3 * r] = v[RegDft<R3>::slot(r)];
+            TH_UNROLL for (int r = 0; r < R3; r++) z[b + B3 * r] = v[RegDft<R3>::slot(r)];
         }
     }
 
     // split exchange: publish Z (plus Z[0] again at slot Nc, so the mirror index Nc - k needs no
     // wrap-around), then every lane fetches the partner Z[Nc - k] of each own k = lane + 64*m:
     // index (Nc - lane - 64*(P-1)) + 64*(P-1-m) = per-lane base + immediate.
-    static constexpr int SLAB_LEN = NC + NC / R1 > NC + 1 ? NC + NC / R1 : NC + 1;  // padded pass-1 image is the largest
+    static_assert(32 % R1 == 0, "pad1 needs R1 | 32");
+    static constexpr int SLAB_LEN = NC + NC / 32;  // padded pass-1 image is the largest (>= NC + 1)
     static TH_HD void write_z(uint32_t lane, const cf32 (&z)[P], cf32 *slab) {
-        for (int m = 0; m < P; m++) slab[lane + 64u * m] = z[m];
+        TH_UNROLL for (int m = 0; m < P; m++) slab[lane + 64u * m] = z[m];
         if (lane == 0) slab[NC] = z[0];
     }
     static TH_HD cf32 read_mirror(uint32_t lane, int m, const cf32 *slab) {
@@ -221,26 +260,96 @@ struct WaveFft {
     }
     // exchange-2 read in the paired layout: za[q][r] = in[A_q + r*Ns3], zb[q][r] = in[B_q + r*Ns3]
     static TH_HD void read2_paired(uint32_t lane, cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 *slab) {
-        for (int q = 0; q < NQ; q++) {
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
             const uint32_t a = jj_a(lane, q), b = jj_b(lane, q);
-            for (int r = 0; r < R3; r++) {
-                za[q][r] = slab[a + (uint32_t)r * NS3];
-                zb[q][r] = slab[b + (uint32_t)r * NS3];
+            TH_UNROLL for (int r = 0; r < R3; r++) {
+                za[q][r] = lds_ld(&slab[a + (uint32_t)r * NS3]);
+                zb[q][r] = lds_ld(&slab[b + (uint32_t)r * NS3]);
             }
         }
     }
-    static TH_HD void bfly3(cf32 (&v)[R3], uint32_t jj, const cf32 *t3) {
+    // last-pass twiddles of the lane's butterflies: wa[q][r-1] = W^(r*A_q), wb[q][r-1] = W^(r*B_q)
+    static TH_HD void load_t3_paired(uint32_t lane, cf32 (&wa)[NQ][R3 - 1], cf32 (&wb)[NQ][R3 - 1], const cf32 *t3) {
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
+            const uint32_t a = jj_a(lane, q), b = jj_b(lane, q);
+            TH_UNROLL for (int r = 1; r < R3; r++) {
+                wa[q][r - 1] = lds_ld(&t3[(r - 1) * NS3 + a]);
+                wb[q][r - 1] = lds_ld(&t3[(r - 1) * NS3 + b]);
+            }
+        }
+    }
+    static TH_HD void bfly3(cf32 (&v)[R3], const cf32 (&w3)[R3 - 1]) {
         cf32 w[R3];
         w[0] = v[0];
-        for (int r = 1; r < R3; r++) w[r] = cmul(v[r], t3[(r - 1) * NS3 + jj]);
+        TH_UNROLL for (int r = 1; r < R3; r++) w[r] = cmul(v[r], w3[r - 1]);
         RegDft<R3>::run(w);
-        for (int r = 0; r < R3; r++) v[r] = w[RegDft<R3>::slot(r)];
+        TH_UNROLL for (int r = 0; r < R3; r++) v[r] = w[RegDft<R3>::slot(r)];
     }
     // last pass: za[q][r] <- Z[A_q + r*Ns3], zb[q][r] <- Z[B_q + r*Ns3]
+    static TH_HD void pass3_paired_w(cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 (&wa)[NQ][R3 - 1],
+                                     const cf32 (&wb)[NQ][R3 - 1]) {
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
+            bfly3(za[q], wa[q]);
+            bfly3(zb[q], wb[q]);
+        }
+    }
     static TH_HD void pass3_paired(uint32_t lane, cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 *t3) {
-        for (int q = 0; q < NQ; q++) {
-            bfly3(za[q], jj_a(lane, q), t3);
-            bfly3(zb[q], jj_b(lane, q), t3);
+        cf32 wa[NQ][R3 - 1], wb[NQ][R3 - 1];
+        load_t3_paired(lane, wa, wb, t3);
+        pass3_paired_w(za, zb, wa, wb);
+    }
+    // bin index of pair (q, s) of this lane.  Lane 0, q = 0 pairs inside butterfly 0 (s < R3/2: k = s*Ns3, as
+    // for every other lane) and inside butterfly Ns3/2 (s >= R3/2: k = Ns3/2 + (s - R3/2)*Ns3, i.e. the
+    // generic k minus (R3-1)*Ns3/2): one adjusted per-lane base keeps every k "base + immediate".
+    static TH_HD int32_t split_k(uint32_t lane, int q, int s) {
+        const int32_t lane_lo = (int32_t)lane, lane_hi = lane == 0 ? -(int32_t)((R3 - 1) * NS3 / 2) : lane_lo;
+        return (q == 0 && s >= R3 / 2 ? lane_hi : lane_lo) + 64 * q + s * NS3;
+    }
+    // split twiddles of the lane's pairs: ws[q][s] = stw[k(q, s)], ws_mid = stw[Nc/2] (only lane 0 uses it)
+    static TH_HD void load_stw_paired(uint32_t lane, cf32 (&ws)[NQ][R3], const cf32 *stw) {
+        TH_UNROLL for (int q = 0; q < NQ; q++)
+            TH_UNROLL for (int s = 0; s < R3; s++) ws[q][s] = lds_ld(&stw[split_k(lane, q, s)]);
+    }
+    template <class Emit>
+    static TH_HD void split_paired_w(uint32_t lane, const cf32 (&za)[NQ][R3], const cf32 (&zb)[NQ][R3],
+                                     const cf32 (&ws)[NQ][R3], const cf32 *stw, Emit emit) {
+        const bool l0 = lane == 0;
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
+            TH_UNROLL for (int s = 0; s < R3; s++) {
+                cf32 zk = za[q][s], zm = zb[q][R3 - 1 - s];
+                const int32_t k = split_k(lane, q, s);
+                if (q == 0) {
+                    const int rp = s - R3 / 2;
+                    const cf32 zk0 = s < R3 / 2 ? za[0][s] : zb[0][rp];
+                    const cf32 zm0 = s < R3 / 2 ? za[0][(R3 - s) % R3] : zb[0][R3 - 1 - rp];
+                    if (s >= R3 / 2) {
+                        zk.re = l0 ? zk0.re : zk.re;
+                        zk.im = l0 ? zk0.im : zk.im;
+                    }
+                    zm.re = l0 ? zm0.re : zm.re;
+                    zm.im = l0 ? zm0.im : zm.im;
+                }
+                const cf32 w = ws[q][s];
+                // e = Z[k] + conj Z[Nc-k];  d = Z[k] - conj Z[Nc-k];  t = W^k * (-i d)
+                // X[k] = e + t,  X[Nc-k] = conj(e - t)
+                const float er = zk.re + zm.re, ei = zk.im - zm.im;
+                const float dr = zk.re - zm.re, di = zk.im + zm.im;
+                const float tr = di * w.re + dr * w.im, ti = di * w.im - dr * w.re;
+                const float xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
+                emit(k, xr * xr + xi * xi);
+#if defined(TH_EXP_ALIGNED_MIRROR)
+                emit(NC - k - 1, yr * yr + yi * yi);  // experiment (wrong bins): 256-B aligned mirrored stores
+#else
+                emit(NC - k, yr * yr + yi * yi);
+#endif
+            }
+        }
+        if (l0) {  // the self-mirrored bin Nc/2 = output R3/2 of butterfly 0
+            const cf32 z = za[0][R3 / 2];
+            const cf32 w = stw[NC / 2];
+            const float er = 2.0f * z.re, di = 2.0f * z.im;  // zm = zk: e = (2 re, 0), d = (0, 2 im)
+            const float xr = er + di * w.re, xi = di * w.im;
+            emit(NC / 2, xr * xr + xi * xi);
         }
     }
     // Split pass on lane-local pairs.  emit(k, |X[k]|^2) is called once for every bin this lane owns
@@ -249,40 +358,9 @@ struct WaveFft {
     template <class Emit>
     static TH_HD void split_paired(uint32_t lane, const cf32 (&za)[NQ][R3], const cf32 (&zb)[NQ][R3], const cf32 *stw,
                                    Emit emit) {
-        const bool l0 = lane == 0;
-        for (int q = 0; q < NQ; q++) {
-            for (int s = 0; s < R3; s++) {
-                cf32 zk = za[q][s], zm = zb[q][R3 - 1 - s];
-                uint32_t k = jj_a(lane, q) + (uint32_t)s * NS3;
-                if (q == 0) {  // lane 0: pairs inside butterfly 0 (s < R3/2) and inside butterfly Ns3/2
-                    const int rp = s - R3 / 2;
-                    const cf32 zk0 = s < R3 / 2 ? za[0][s] : zb[0][rp];
-                    const cf32 zm0 = s < R3 / 2 ? za[0][(R3 - s) % R3] : zb[0][R3 - 1 - rp];
-                    const uint32_t k0 = s < R3 / 2 ? (uint32_t)s * NS3 : (uint32_t)NS3 / 2 + (uint32_t)rp * NS3;
-                    zk.re = l0 ? zk0.re : zk.re;
-                    zk.im = l0 ? zk0.im : zk.im;
-                    zm.re = l0 ? zm0.re : zm.re;
-                    zm.im = l0 ? zm0.im : zm.im;
-                    k = l0 ? k0 : k;
-                }
-                const cf32 w = stw[k];
-                // e = Z[k] + conj Z[Nc-k];  d = Z[k] - conj Z[Nc-k];  t = W^k * (-i d)
-                // X[k] = e + t,  X[Nc-k] = conj(e - t)
-                const float er = zk.re + zm.re, ei = zk.im - zm.im;
-                const float dr = zk.re - zm.re, di = zk.im + zm.im;
-                const float tr = di * w.re + dr * w.im, ti = di * w.im - dr * w.re;
-                const float xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
-                emit(k, xr * xr + xi * xi);
-                emit((uint32_t)NC - k, yr * yr + yi * yi);
-            }
-        }
-        if (l0) {  // the self-mirrored bin Nc/2 = output R3/2 of butterfly 0
-            const cf32 z = za[0][R3 / 2];
-            const cf32 w = stw[NC / 2];
-            const float er = 2.0f * z.re, di = 2.0f * z.im;  // zm = zk: e = (2 re, 0), d = (0, 2 im)
-            const float xr = er + di * w.re, xi = di * w.im;
-            emit((uint32_t)NC / 2, xr * xr + xi * xi);
-        }
+        cf32 ws[NQ][R3];
+        load_stw_paired(lane, ws, stw);
+        split_paired_w(lane, za, zb, ws, stw, emit);
     }
 };
 
@@ -313,7 +391,7 @@ namespace th {
 // ---------------------------------------------------------------------------------------------
 template <int P, int M0, class WavPtr>
 TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0) {
-    for (int m = M0; m < P; m++) {
+    TH_UNROLL for (int m = M0; m < P; m++) {
         const WavPtr p = wav + (e0 + 2 * (int64_t)(lane + 64u * m));  // two adjacent dwords: one 8-byte load
         x[m] = {p[0], p[1]};
     }
@@ -321,8 +399,8 @@ TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0) {
 
 template <int P>
 TH_HD void wave_window(uint32_t lane, cf32 (&z)[P], const cf32 (&x)[P], const cf32 *wtab) {
-    for (int m = 0; m < P; m++) {
-        const cf32 w = wtab[lane + 64u * m];
+    TH_UNROLL for (int m = 0; m < P; m++) {
+        const cf32 w = lds_ld(&wtab[lane + 64u * m]);
         z[m] = {x[m].re * w.re, x[m].im * w.im};
     }
 }
