@@ -7,6 +7,8 @@
 // the windowed frames, the complex spectrum and the linear magnitudes never leave the CU.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "stft_core.h"
 #include "stft_wave.h"
@@ -271,6 +273,149 @@ __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_
     }
 }
 
+// One frame of the wave kernel (see stft_wave_kernel).  OFF = register rotation of x[] (logical slot m lives
+// in physical x[(m + OFF) % P]); ROTATE = the caller instantiates one body per rotation instead of moving
+// registers.  All state is passed as separate by-reference scalars / arrays: the body is always inlined and
+// everything must stay in registers (a by-reference closure or struct here puts x[] into scratch memory).
+// Advances cur to the next frame and returns true when that frame continues the same chunk.
+#if defined(TH_PHASE_PROF)
+#define TH_PROF_PARAMS , unsigned long long &prof_t, unsigned long long (&prof_acc)[9]
+#define TH_PROF_ARGS , prof_t, prof_acc
+#else
+#define TH_PROF_PARAMS
+#define TH_PROF_ARGS
+#endif
+template <int LOG2_NC, int SHIFT, bool AMP, bool ROTATE, int OFF>
+__device__ __forceinline__ void wave_frame(const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2,
+                                           const cf32 *t3, cf32 *slab, uint32_t lane_wave, uint32_t f, uint32_t f1,
+                                           gptr<const float> wav, gptr<float> spec, uint32_t spec_pitch,
+                                           cf32 (&x)[WaveFft<LOG2_NC>::P], float &lmin, float &lmax TH_PROF_PARAMS) {
+    using W = WaveFft<LOG2_NC>;
+    constexpr int P = W::P, NC = W::NC;
+    TH_PROF_MARK(8);
+    // Per-frame opaque copy of the lane id.  Everything below addresses LDS and the output row as
+    // "f(lane) + immediate"; left loop-invariant, LICM hoists ~40 such addresses out of the frame loop
+    // and the register allocator spills them.  Recomputing the handful of bases per frame is cheaper.
+    uint32_t lane = lane_wave;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane));
+#endif
+    lane &= 63u;
+    // LDS reads return in order and a read issued next to its use exposes the whole LDS latency, so all
+    // table reads are issued ahead of their use (lds_ld keeps program order): pass-2 twiddles before the
+    // pass-1 arithmetic, pass-3 and split twiddles together with the reads of exchange 2.
+    cf32 z[P];
+    cf32 w2[W::R2 - 1];
+    wave_window_rot<P, OFF>(lane, z, x, wtab);
+    // Request the next frame of the chunk now: its samples land while this frame is transformed.  The fetch
+    // is unconditional (branch-free register flow: no copies of x[]); on the last frame of a chunk it simply
+    // re-reads this frame's span, which is in bounds, and the result is never used.
+    {
+        const uint32_t fn = f + 1 < f1 ? f + 1 : f;
+        const int64_t e0n = (int64_t)fn * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+        if constexpr (SHIFT == 0) {
+            wave_fetch<P, 0>(lane, x, wav, e0n);
+        } else if constexpr (ROTATE) {
+            wave_fetch_rot<P, SHIFT, OFF>(lane, x, wav, e0n);
+        } else {
+#pragma unroll
+            for (int m = 0; m + SHIFT < P; m++) x[m] = x[m + SHIFT];
+            wave_fetch<P, P - SHIFT>(lane, x, wav, e0n);
+        }
+    }
+    TH_SCHED_BARRIER();
+#if defined(TH_EXP_WAITLOADS)
+    TH_PROF_MARK(7);                     // experiment: expose the global-load latency in phase 0
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#endif
+    TH_PROF_MARK(0);
+    W::load_t2(lane, w2, t2);  // lands during the pass-1 arithmetic
+    W::pass1(lane, z, slab);
+    wave_lds_sync();
+    TH_SCHED_BARRIER();
+    TH_PROF_MARK(1);
+    W::read1(lane, z, slab);
+    wave_lds_sync();
+    TH_PROF_MARK(2);
+    W::pass2_twiddle(z, w2);
+
+#if defined(TH_EXP_SMALLROW)
+    const gptr<float> row = spec + (size_t)(f & 7u) * spec_pitch;  // experiment: L2-resident output
+#else
+    const gptr<float> row = spec + (size_t)f * spec_pitch;
+#endif
+    if constexpr (W::PAIRED) {
+        // mirror-local last pass: every Z[k] / Z[Nc-k] pair ends up in one lane's registers
+        W::pass2_dft(lane, z, slab);
+        wave_lds_sync();
+        TH_SCHED_BARRIER();
+        TH_PROF_MARK(3);
+        cf32 wa[W::NQ][W::R3 - 1], wb[W::NQ][W::R3 - 1];
+        W::load_t3_paired(lane, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
+        cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
+        W::read2_paired(lane, za, zb, slab);
+        wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
+        constexpr bool PRELOAD_STW = W::NQ * W::R3 <= 8;  // 16 VGPRs at n_fft = 2048; too many at 4096
+        cf32 ws[W::NQ][W::R3];
+        if constexpr (PRELOAD_STW) W::load_stw_paired(lane, ws, stw);
+        TH_SCHED_BARRIER();
+        TH_PROF_MARK(4);
+        W::pass3_paired_w(za, zb, wa, wb);
+        TH_SCHED_BARRIER();
+        TH_PROF_MARK(5);
+        if constexpr (!PRELOAD_STW) W::load_stw_paired(lane, ws, stw);
+        W::split_paired_w(lane, za, zb, ws, stw, [&](int32_t k, float p) {
+            if constexpr (AMP) {
+                row[k] = power_to_amp(p);
+            } else {
+#if defined(TH_EXP_NOLOG)
+                const float d = p;
+#else
+                const float d = power_to_dB(p);
+#endif
+#if defined(TH_EXP_NOSTORE)
+                if (d == 12345.678f) row[k] = d;  // experiment: (almost) never stores
+#else
+                row[k] = d;
+#endif
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            }
+        });
+    } else {
+        W::pass2_dft(lane, z, slab);
+        wave_lds_sync();
+        TH_SCHED_BARRIER();
+        W::read2(lane, z, slab);
+        W::pass3(lane, z, t3);
+        wave_lds_sync();
+        W::write_z(lane, z, slab);
+        wave_lds_sync();
+        TH_SCHED_BARRIER();
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+            const uint32_t k = lane + 64u * m;
+            const cf32 zm = W::read_mirror(lane, m, slab);  // mirror partner Z[Nc - k]
+            const float pw = split_power(z[m], zm, stw[k]);
+            const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
+            row[k] = d;
+            lmin = nmin(lmin, d);
+            lmax = nmax(lmax, d);
+        }
+        if (lane == 0) {  // Nyquist bin k = Nc: partner of Z[0] is Z[0], W^Nc = -1
+            const cf32 wn = {-1.0f, 0.0f};
+            const float pw = split_power(z[0], z[0], wn);
+            const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
+            row[NC] = d;
+            lmin = nmin(lmin, d);
+            lmax = nmax(lmax, d);
+        }
+        wave_lds_sync();  // the slab is rewritten by the next frame's pass 1
+    }
+    TH_SCHED_BARRIER();
+    TH_PROF_MARK(6);
+}
+
 // SHIFT = hop/128 register slots reused between consecutive frames (0 = no reuse: hop not a
 // multiple of 128 samples or hop >= n_fft)
 // AMP: store the linear amplitude |X| instead of dB and skip min/max (first half of the mel path;
@@ -309,149 +454,55 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         else if (pr == 3) __builtin_amdgcn_s_setprio(3);
     }
 #endif
-    FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
-
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
-    uint32_t mm_slot = cur.mm_index;
+    uint32_t mm_slot = 0;
     bool mm_dirty = false;  // a wave that never got a frame must not touch any slot
-
-    cf32 x[P];  // raw samples of the current frame, then (shifted + refilled) of the next one
-    if (cur.valid) wave_fetch<P, 0>(lane, x, cur.wav, frame_e0(cur, g));
-    // Drain the first fetch before entering the loop.  The compiler's s_waitcnt bookkeeping merges the
-    // loop pre-header with the back edge; with loads still in flight here it concludes that x[] may be the
-    // YOUNGEST outstanding operations and waits with vmcnt(0) at the top of every frame — i.e. for the 17
-    // row stores the previous frame has just issued (a full HBM write latency per frame).  With nothing
-    // pending at entry the waits become vmcnt(>= 17): loads only, the stores keep streaming.
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
     const uint32_t lane_wave = lane;
     TH_PROF_DECL();
-    while (cur.valid) {
-        TH_PROF_MARK(8);
-        // Per-frame opaque copy of the lane id.  Everything below addresses LDS and the output row as
-        // "f(lane) + immediate"; left loop-invariant, LICM hoists ~40 such addresses out of the frame loop
-        // and the register allocator spills them.  Recomputing the handful of bases per frame is cheaper.
-        uint32_t lane = lane_wave;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(lane));
-#endif
-        lane &= 63u;
-        // LDS reads return in order and a read issued next to its use exposes the whole LDS latency, so all
-        // table reads are issued ahead of their use (lds_ld keeps program order): pass-2 twiddles before the
-        // pass-1 arithmetic, pass-3 and split twiddles together with the reads of exchange 2.
-        cf32 z[P];
-        cf32 w2[W::R2 - 1];
-        wave_window<P>(lane, z, x, wtab);
-        // request the next frame now: its samples land while this frame is transformed
-        const FrameCursor nxt = cursor_next(cur, g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
-        if (nxt.valid) {
-            if (SHIFT > 0 && !nxt.fresh) {
-#pragma unroll
-                for (int m = 0; m + SHIFT < P; m++) x[m] = x[m + SHIFT];
-                wave_fetch<P, P - SHIFT>(lane, x, nxt.wav, frame_e0(nxt, g));
-            } else {
-                wave_fetch<P, 0>(lane, x, nxt.wav, frame_e0(nxt, g));
-            }
-        }
-        TH_SCHED_BARRIER();
-#if defined(TH_EXP_WAITLOADS)
-        TH_PROF_MARK(7);                     // experiment: expose the global-load latency in phase 0
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#endif
-        TH_PROF_MARK(0);
-        W::load_t2(lane, w2, t2);  // lands during the pass-1 arithmetic
-        W::pass1(lane, z, slab);
-        wave_lds_sync();
-        TH_SCHED_BARRIER();
-        TH_PROF_MARK(1);
-        W::read1(lane, z, slab);
-        wave_lds_sync();
-        TH_PROF_MARK(2);
-        W::pass2_twiddle(z, w2);
-
+    // Register rotation instead of register moves: with hop = SHIFT slots, frame f+1 is frame f moved down by
+    // SHIFT slots.  Rather than moving P - SHIFT complex registers per frame, the frame body is instantiated
+    // NROT = P/SHIFT times; instance ROT reads logical slot m from physical x[(m + ROT*SHIFT) % P] and loads
+    // the next frame's SHIFT new slots over the ones that just went out of the window.  A new chunk (all P
+    // slots loaded) always starts at rotation 0.
+    constexpr bool ROTATE = SHIFT > 0 && P % SHIFT == 0 && P / SHIFT <= 4;
+    constexpr int NROT = ROTATE ? P / SHIFT : 1;
+#define TH_FRAME(ROT)                                                                                                  \
+    wave_frame<LOG2_NC, SHIFT, AMP, ROTATE, ROTATE ? (ROT) * SHIFT : 0>(g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1,  \
+                                                                      cur.wav, cur.spec, cur.spec_pitch, x, lmin, lmax \
+                                                                          TH_PROF_ARGS)
+    // chunk loop: one queue pull and one full fetch per chunk of up to frames_per_tile consecutive frames
+    for (;;) {
+        const FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
+        if (!cur.valid) break;
         if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
             flush_minmax(minmax, mm_slot, lane, lmin, lmax);
             lmin = __builtin_inff();
             lmax = -__builtin_inff();
         }
-#if defined(TH_EXP_SMALLROW)
-        const gptr<float> row = cur.spec + (size_t)(cur.f & 7u) * cur.spec_pitch;  // experiment: L2-resident output
-#else
-        const gptr<float> row = cur.spec + (size_t)cur.f * cur.spec_pitch;
-#endif
-        if constexpr (W::PAIRED) {
-            // mirror-local last pass: every Z[k] / Z[Nc-k] pair ends up in one lane's registers
-            W::pass2_dft(lane, z, slab);
-            wave_lds_sync();
-            TH_SCHED_BARRIER();
-            TH_PROF_MARK(3);
-            cf32 wa[W::NQ][W::R3 - 1], wb[W::NQ][W::R3 - 1];
-            W::load_t3_paired(lane, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
-            cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
-            W::read2_paired(lane, za, zb, slab);
-            wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
-            constexpr bool PRELOAD_STW = W::NQ * W::R3 <= 8;  // 16 VGPRs at n_fft = 2048; too many at 4096
-            cf32 ws[W::NQ][W::R3];
-            if constexpr (PRELOAD_STW) W::load_stw_paired(lane, ws, stw);
-            TH_SCHED_BARRIER();
-            TH_PROF_MARK(4);
-            W::pass3_paired_w(za, zb, wa, wb);
-            TH_SCHED_BARRIER();
-            TH_PROF_MARK(5);
-            if constexpr (!PRELOAD_STW) W::load_stw_paired(lane, ws, stw);
-            W::split_paired_w(lane, za, zb, ws, stw, [&](int32_t k, float p) {
-                if constexpr (AMP) {
-                    row[k] = power_to_amp(p);
-                } else {
-#if defined(TH_EXP_NOLOG)
-                    const float d = p;
-#else
-                    const float d = power_to_dB(p);
-#endif
-#if defined(TH_EXP_NOSTORE)
-                    if (d == 12345.678f) row[k] = d;  // experiment: (almost) never stores
-#else
-                    row[k] = d;
-#endif
-                    lmin = nmin(lmin, d);
-                    lmax = nmax(lmax, d);
-                }
-            });
-        } else {
-            W::pass2_dft(lane, z, slab);
-            wave_lds_sync();
-            TH_SCHED_BARRIER();
-            W::read2(lane, z, slab);
-            W::pass3(lane, z, t3);
-            wave_lds_sync();
-            W::write_z(lane, z, slab);
-            wave_lds_sync();
-            TH_SCHED_BARRIER();
-#pragma unroll
-            for (int m = 0; m < P; m++) {
-                const uint32_t k = lane + 64u * m;
-                const cf32 zm = W::read_mirror(lane, m, slab);  // mirror partner Z[Nc - k]
-                const float pw = split_power(z[m], zm, stw[k]);
-                const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
-                row[k] = d;
-                lmin = nmin(lmin, d);
-                lmax = nmax(lmax, d);
-            }
-            if (lane == 0) {  // Nyquist bin k = Nc: partner of Z[0] is Z[0], W^Nc = -1
-                const cf32 wn = {-1.0f, 0.0f};
-                const float pw = split_power(z[0], z[0], wn);
-                const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
-                row[NC] = d;
-                lmin = nmin(lmin, d);
-                lmax = nmax(lmax, d);
-            }
-            wave_lds_sync();  // the slab is rewritten by the next frame's pass 1
-        }
         mm_slot = cur.mm_index;
         mm_dirty = true;
-        TH_SCHED_BARRIER();
-        TH_PROF_MARK(6);
-        cur = nxt;
+        cf32 x[P];  // raw samples of the current frame; the frame body refills it for the next one
+        wave_fetch<P, 0>(lane, x, cur.wav, frame_e0(cur, g));
+        uint32_t f = cur.f;
+        // frame loop (steady state: branch-free register flow, see wave_frame)
+        for (;;) {
+            TH_FRAME(0);
+            if (++f >= cur.f1) break;
+            if constexpr (NROT > 1) {
+                TH_FRAME(1);
+                if (++f >= cur.f1) break;
+            }
+            if constexpr (NROT > 2) {
+                TH_FRAME(2);
+                if (++f >= cur.f1) break;
+            }
+            if constexpr (NROT > 3) {
+                TH_FRAME(3);
+                if (++f >= cur.f1) break;
+            }
+        }
     }
+#undef TH_FRAME
     if (minmax != nullptr && mm_dirty) flush_minmax(minmax, mm_slot, lane, lmin, lmax);
     TH_PROF_FLUSH(lane_wave);
 }

@@ -397,6 +397,25 @@ TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0) {
     }
 }
 
+// Rotated variants for the register-rotation frame loop: logical slot m lives in physical x[(m + OFF) % P].
+// wave_fetch_rot loads the S newest logical slots P-S..P-1 of the NEXT frame (rotation OFF + S), which are the
+// physical slots (OFF + i) % P that held the current frame's oldest S slots.
+template <int P, int S, int OFF, class WavPtr>
+TH_HD void wave_fetch_rot(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0_next) {
+    TH_UNROLL for (int i = 0; i < S; i++) {
+        const WavPtr p = wav + (e0_next + 2 * (int64_t)(lane + 64u * (P - S + i)));
+        x[(OFF + i) % P] = {p[0], p[1]};
+    }
+}
+template <int P, int OFF>
+TH_HD void wave_window_rot(uint32_t lane, cf32 (&z)[P], const cf32 (&x)[P], const cf32 *wtab) {
+    TH_UNROLL for (int m = 0; m < P; m++) {
+        const cf32 w = lds_ld(&wtab[lane + 64u * m]);
+        const cf32 v = x[(m + OFF) % P];
+        z[m] = {v.re * w.re, v.im * w.im};
+    }
+}
+
 template <int P>
 TH_HD void wave_window(uint32_t lane, cf32 (&z)[P], const cf32 (&x)[P], const cf32 *wtab) {
     TH_UNROLL for (int m = 0; m < P; m++) {
