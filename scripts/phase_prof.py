@@ -19,6 +19,7 @@ ap.add_argument("--seconds", type=float, default=30.0)
 ap.add_argument("--nfft", type=int, default=2048)
 ap.add_argument("--win", type=int, default=0)
 ap.add_argument("--hop", type=int, default=0)
+ap.add_argument("--kernel", type=int, default=0)
 a = ap.parse_args()
 sr, n_fft = 48000, a.nfft
 win = a.win or n_fft
@@ -30,6 +31,8 @@ ctx = ta.Context(0, side.cuda_stream)
 n = int(a.seconds * sr)
 wav = (torch.rand((a.tracks, n), device=dev) * 2 - 1) * 0.3
 plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+if a.kernel:
+    plan.set_kernel(a.kernel)
 T, H = plan.n_frames(n), plan.height
 sp = ta.pitch_f32(H)
 spec = torch.empty((a.tracks, T, sp), dtype=torch.float32, device=dev)
@@ -53,11 +56,12 @@ names = ["window+cursor+fetch issue", "pass1 + LDS writes", "read1 (exchange-1 r
          "pass3", "split + dB + stores", "(exp) before vmcnt(0) wait", "loop top (cur = nxt)"]
 frames = a.tracks * T
 tot = sum(buf[i] for i in range(9))
+n_waves = 256 * (((a.kernel >> 8) & 0xFF) or 12)
 print(f"{ms:.3f} ms for {frames} frames (instrumented); ticks are s_memtime units summed over all waves")
 for i, nm in enumerate(names):
     if not buf[i]:
         continue
     print(f"  {nm:28s} {buf[i] / frames:9.1f} ticks/frame  {100.0 * buf[i] / tot:5.1f} %")
 if buf[9]:
-    print(f"  shader clock during the frame loop: {buf[10] / buf[9] * 100.0:.0f} MHz (s_memtime ticks per 100 MHz s_memrealtime tick); loop wall time per wave {buf[9] / 4096 / 100.0:.1f} us")
-print(f"  {'total':28s} {tot / frames:9.1f} ticks/frame;  wave-time {tot / (256 * 16) / 1e6:.3f} Mticks per wave -> {tot / (256 * 16) / (ms * 1e-3) / 1e6:.1f} MHz tick rate if waves were busy the whole launch")
+    print(f"  shader clock during the frame loop: {buf[10] / buf[9] * 100.0:.0f} MHz (s_memtime ticks per 100 MHz s_memrealtime tick); loop wall time per wave {buf[9] / n_waves / 100.0:.1f} us")
+print(f"  {'total':28s} {tot / frames:9.1f} ticks/frame;  wave-time {tot / n_waves / 1e6:.3f} Mticks per wave -> {tot / n_waves / (ms * 1e-3) / 1e6:.1f} MHz tick rate if waves were busy the whole launch")

@@ -285,11 +285,17 @@ __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_
 #define TH_PROF_PARAMS
 #define TH_PROF_ARGS
 #endif
-template <int LOG2_NC, int SHIFT, bool AMP, bool ROTATE, int OFF>
-__device__ __forceinline__ void wave_frame(const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2,
-                                           const cf32 *t3, cf32 *slab, uint32_t lane_wave, uint32_t f, uint32_t f1,
-                                           gptr<const float> wav, gptr<float> spec, uint32_t spec_pitch,
-                                           cf32 (&x)[WaveFft<LOG2_NC>::P], float &lmin, float &lmax TH_PROF_PARAMS) {
+// RES: which per-lane constant tables the caller keeps resident in registers instead of re-reading them from
+// LDS every frame (bit 0 window, 1 pass-2 twiddles, 2 pass-3 twiddles, 3 split twiddles; 2 and 3 only on the
+// mirror-local path).  Worth it when fewer waves per SIMD leave the VGPRs: LDS is a co-bottleneck of this kernel.
+template <int LOG2_NC, int SHIFT, bool AMP, bool ROTATE, int OFF, int RES>
+__device__ __forceinline__ void wave_frame(
+    const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
+    uint32_t f, uint32_t f1, gptr<const float> wav, gptr<float> spec, uint32_t spec_pitch, cf32 (&x)[WaveFft<LOG2_NC>::P],
+    const cf32 (&rw)[(RES & 1) ? WaveFft<LOG2_NC>::P : 1], const cf32 (&rw2)[(RES & 2) ? WaveFft<LOG2_NC>::R2 - 1 : 1],
+    const cf32 (&rwa)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
+    const cf32 (&rwb)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
+    const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], float &lmin, float &lmax TH_PROF_PARAMS) {
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
     TH_PROF_MARK(8);
@@ -306,7 +312,15 @@ __device__ __forceinline__ void wave_frame(const StftGeom &g, const cf32 *wtab, 
     // pass-1 arithmetic, pass-3 and split twiddles together with the reads of exchange 2.
     cf32 z[P];
     cf32 w2[W::R2 - 1];
-    wave_window_rot<P, OFF>(lane, z, x, wtab);
+    if constexpr (RES & 1) {
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+            const cf32 v = x[(m + OFF) % P];
+            z[m] = {v.re * rw[m].re, v.im * rw[m].im};
+        }
+    } else {
+        wave_window_rot<P, OFF>(lane, z, x, wtab);
+    }
     // Request the next frame of the chunk now: its samples land while this frame is transformed.  The fetch
     // is unconditional (branch-free register flow: no copies of x[]); on the last frame of a chunk it simply
     // re-reads this frame's span, which is in bounds, and the result is never used.
@@ -329,7 +343,7 @@ __device__ __forceinline__ void wave_frame(const StftGeom &g, const cf32 *wtab, 
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #endif
     TH_PROF_MARK(0);
-    W::load_t2(lane, w2, t2);  // lands during the pass-1 arithmetic
+    if constexpr (!(RES & 2)) W::load_t2(lane, w2, t2);  // lands during the pass-1 arithmetic
     W::pass1(lane, z, slab);
     wave_lds_sync();
     TH_SCHED_BARRIER();
@@ -337,7 +351,8 @@ __device__ __forceinline__ void wave_frame(const StftGeom &g, const cf32 *wtab, 
     W::read1(lane, z, slab);
     wave_lds_sync();
     TH_PROF_MARK(2);
-    W::pass2_twiddle(z, w2);
+    if constexpr (RES & 2) W::pass2_twiddle(z, rw2);
+    else W::pass2_twiddle(z, w2);
 
 #if defined(TH_EXP_SMALLROW)
     const gptr<float> row = spec + (size_t)(f & 7u) * spec_pitch;  // experiment: L2-resident output
@@ -351,20 +366,21 @@ __device__ __forceinline__ void wave_frame(const StftGeom &g, const cf32 *wtab, 
         TH_SCHED_BARRIER();
         TH_PROF_MARK(3);
         cf32 wa[W::NQ][W::R3 - 1], wb[W::NQ][W::R3 - 1];
-        W::load_t3_paired(lane, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
+        if constexpr (!(RES & 4)) W::load_t3_paired(lane, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
         cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
         W::read2_paired(lane, za, zb, slab);
         wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
         constexpr bool PRELOAD_STW = W::NQ * W::R3 <= 8;  // 16 VGPRs at n_fft = 2048; too many at 4096
         cf32 ws[W::NQ][W::R3];
-        if constexpr (PRELOAD_STW) W::load_stw_paired(lane, ws, stw);
+        if constexpr (PRELOAD_STW && !(RES & 8)) W::load_stw_paired(lane, ws, stw);
         TH_SCHED_BARRIER();
         TH_PROF_MARK(4);
-        W::pass3_paired_w(za, zb, wa, wb);
+        if constexpr (RES & 4) W::pass3_paired_w(za, zb, rwa, rwb);
+        else W::pass3_paired_w(za, zb, wa, wb);
         TH_SCHED_BARRIER();
         TH_PROF_MARK(5);
-        if constexpr (!PRELOAD_STW) W::load_stw_paired(lane, ws, stw);
-        W::split_paired_w(lane, za, zb, ws, stw, [&](int32_t k, float p) {
+        if constexpr (!PRELOAD_STW && !(RES & 8)) W::load_stw_paired(lane, ws, stw);
+        auto emit = [&](int32_t k, float p) {
             if constexpr (AMP) {
                 row[k] = power_to_amp(p);
             } else {
@@ -375,13 +391,17 @@ __device__ __forceinline__ void wave_frame(const StftGeom &g, const cf32 *wtab, 
 #endif
 #if defined(TH_EXP_NOSTORE)
                 if (d == 12345.678f) row[k] = d;  // experiment: (almost) never stores
+#elif defined(TH_EXP_NT_STORE)
+                __builtin_nontemporal_store(d, &row[k]);
 #else
                 row[k] = d;
 #endif
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }
-        });
+        };
+        if constexpr (RES & 8) W::split_paired_w(lane, za, zb, rws, stw, emit);
+        else W::split_paired_w(lane, za, zb, ws, stw, emit);
     } else {
         W::pass2_dft(lane, z, slab);
         wave_lds_sync();
@@ -420,7 +440,7 @@ __device__ __forceinline__ void wave_frame(const StftGeom &g, const cf32 *wtab, 
 // multiple of 128 samples or hop >= n_fft)
 // AMP: store the linear amplitude |X| instead of dB and skip min/max (first half of the mel path;
 // mel_mfma_kernel then applies the filterbank).
-template <int LOG2_NC, int WAVES, int SHIFT, bool AMP>
+template <int LOG2_NC, int WAVES, int SHIFT, bool AMP, int RES>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
@@ -467,9 +487,19 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     constexpr bool ROTATE = SHIFT > 0 && P % SHIFT == 0 && P / SHIFT <= 4;
     constexpr int NROT = ROTATE ? P / SHIFT : 1;
 #define TH_FRAME(ROT)                                                                                                  \
-    wave_frame<LOG2_NC, SHIFT, AMP, ROTATE, ROTATE ? (ROT) * SHIFT : 0>(g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1,  \
-                                                                      cur.wav, cur.spec, cur.spec_pitch, x, lmin, lmax \
-                                                                          TH_PROF_ARGS)
+    wave_frame<LOG2_NC, SHIFT, AMP, ROTATE, ROTATE ? (ROT) * SHIFT : 0, RES>(                                          \
+        g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, lmin, \
+        lmax TH_PROF_ARGS)
+    // per-lane constant tables kept in registers for the whole launch (see wave_frame)
+    cf32 rw[(RES & 1) ? P : 1], rw2[(RES & 2) ? W::R2 - 1 : 1];
+    cf32 rwa[(RES & 4) ? W::NQ : 1][W::R3 - 1], rwb[(RES & 4) ? W::NQ : 1][W::R3 - 1], rws[(RES & 8) ? W::NQ : 1][W::R3];
+    if constexpr (RES & 1) {
+#pragma unroll
+        for (int m = 0; m < P; m++) rw[m] = wtab[lane + 64u * m];
+    }
+    if constexpr (RES & 2) W::load_t2(lane, rw2, t2);
+    if constexpr (RES & 4) W::load_t3_paired(lane, rwa, rwb, t3);
+    if constexpr (RES & 8) W::load_stw_paired(lane, rws, stw);
     // chunk loop: one queue pull and one full fetch per chunk of up to frames_per_tile consecutive frames
     for (;;) {
         const FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
@@ -557,9 +587,17 @@ bool stft_wave_supported(const StftGeom &g) { return g.log2_nc >= 9 && g.log2_nc
 
 // Waves per workgroup (one persistent workgroup per CU).  Bounded by LDS (tables + one slab per
 // wave <= 160 KB) and by the VGPR file (64*WAVES threads => 512/(WAVES/4) VGPRs per lane).
+#if !defined(TH_RES12)
+#define TH_RES12 1
+#endif
 template <int LOG2_NC>
 struct WaveLaunchCfg {
-    static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? 6 : 16;  // n_fft = 4096: 153 KB of LDS at 6 waves
+    static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? 6 : 12;  // n_fft = 4096: 153 KB of LDS at 6 waves
+    // register-resident tables by VGPR budget (512 / waves per SIMD); mirror-local path only for bits 2, 3
+    static constexpr int resident(int waves) {
+        if (LOG2_NC != 10) return 0;
+        return waves <= 8 ? 15 : waves <= 12 ? TH_RES12 : 0;
+    }
 };
 
 template <int LOG2_NC, int WAVES>
@@ -572,7 +610,7 @@ template <int LOG2_NC, int WAVES, int SHIFT, bool AMP>
 static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
-    auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, AMP>;
+    auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, AMP, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
     const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>();
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -642,7 +680,9 @@ static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const
         TH_WAVE_CASE(4)
         TH_WAVE_CASE(6)
         TH_WAVE_CASE(8)
+        TH_WAVE_CASE(10)
         TH_WAVE_CASE(12)
+        TH_WAVE_CASE(14)
         TH_WAVE_CASE(16)
         default: return hipErrorInvalidValue;
     }
