@@ -1,11 +1,25 @@
 #!/bin/bash
-# Development tool: build thesia_amd/libthesia_amd_<tag>.so with extra flags for kernels_stft.hip
-# (A/B on one GPU box: THESIA_AMD_LIB=thesia_amd/libthesia_amd_<tag>.so python scripts/bench_stft.py).
+# Development tool: build thesia_amd/libthesia_amd_<tag>.so with extra -D flags (A/B on one GPU box:
+# THESIA_AMD_LIB=thesia_amd/libthesia_amd_<tag>.so python scripts/bench_stft.py).
 # usage: scripts/build_variant.sh <tag> [flags...]     (run after __graft_entry__.build())
+# By default only kernels_stft.hip is recompiled; VARIANT_SOURCES="kernels_image.hip api.hip" picks others.
 set -e
 tag=$1; shift
 cd "$(dirname "$0")/../thesia_amd/csrc"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fno-slp-vectorize "$@" -c kernels_stft.hip -o build/kernels_stft_$tag.o
-objs=$(ls build/*.hip.o build/*.cpp.o | grep -v kernels_stft.hip.o)
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../libthesia_amd_$tag.so $objs build/kernels_stft_$tag.o
+srcs=${VARIANT_SOURCES:-kernels_stft.hip}
+objs=""
+for f in api.hip track_manager.hip kernels_stft.hip kernels_mel.hip kernels_image.hip kernels_waveform.hip host_math.cpp; do
+  if [[ " $srcs " == *" $f "* ]]; then
+    extra=""
+    case $f in
+      kernels_stft.hip) extra="-fno-slp-vectorize";;
+      kernels_image.hip|kernels_waveform.hip) extra="-ffp-contract=off";;
+    esac
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden $extra "$@" -c $f -o build/${f}_$tag.o
+    objs="$objs build/${f}_$tag.o"
+  else
+    objs="$objs build/$f.o"
+  fi
+done
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libthesia_amd_$tag.so $objs
 echo built thesia_amd/libthesia_amd_$tag.so

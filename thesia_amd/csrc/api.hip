@@ -681,7 +681,7 @@ TH_API int th_spec_to_img_batch_dev(th_ctx *c, const th_img_desc *descs, size_t 
     const bool all_neg_inf = (min_dB == max_dB) && std::isinf(max_dB) && max_dB < 0;  // drawing.rs:16-18
     if (!all_neg_inf) TH_REQUIRE(std::isfinite(min_dB), "min_dB must be finite (drawing.rs:19)");
     std::vector<ImgJob> jobs(n);
-    std::vector<uint32_t> start(n + 1);
+    std::vector<uint32_t> start;  // job index of every block
     uint64_t tiles = 0;
     for (size_t i = 0; i < n; i++) {
         const th_img_desc &d = descs[i];
@@ -691,13 +691,14 @@ TH_API int th_spec_to_img_batch_dev(th_ctx *c, const th_img_desc *descs, size_t 
         TH_REQUIRE((d.spec && d.img) || out_h * d.n_frames == 0, "desc %zu: NULL device pointer", i);
         TH_REQUIRE(d.spec_pitch == 0 || (d.spec_pitch >= d.height && d.spec_pitch < (1ull << 31)), "desc %zu: bad spec_pitch", i);
         TH_REQUIRE(d.img_pitch == 0 || (d.img_pitch >= d.n_frames && d.img_pitch < (1ull << 31)), "desc %zu: bad img_pitch", i);
+        const uint64_t nt = ((d.n_frames + IMG_TILE_T - 1) / IMG_TILE_T) * ((out_h + IMG_TILE_F - 1) / IMG_TILE_F);
+        TH_REQUIRE(tiles + nt < (1ull << 27), "batch too large for one launch");
         jobs[i] = ImgJob{d.spec, d.img, (uint32_t)d.n_frames, (uint32_t)d.height, (uint32_t)d.i_start, (uint32_t)d.i_end,
-                         (uint32_t)(d.spec_pitch ? d.spec_pitch : d.height), (uint32_t)(d.img_pitch ? d.img_pitch : d.n_frames)};
-        start[i] = (uint32_t)tiles;
-        tiles += ((d.n_frames + IMG_TILE_T - 1) / IMG_TILE_T) * ((out_h + IMG_TILE_F - 1) / IMG_TILE_F);
-        TH_REQUIRE(tiles < (1ull << 31), "batch too large for one launch");
+                         (uint32_t)(d.spec_pitch ? d.spec_pitch : d.height), (uint32_t)(d.img_pitch ? d.img_pitch : d.n_frames),
+                         (uint32_t)tiles, (uint32_t)nt};
+        tiles += nt;
+        start.insert(start.end(), (size_t)nt, (uint32_t)i);  // block -> job table
     }
-    start[n] = (uint32_t)tiles;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     TH_HIP(hipSetDevice(c->device));
     if (all_neg_inf) {
@@ -733,7 +734,7 @@ TH_API int th_raster_tiles_dev(th_ctx *c, const th_raster_desc *descs, size_t n,
     if (n == 0) return TH_OK;
     TH_REQUIRE(descs && d_colormap && n_colors >= 1, "NULL descs/colormap or empty colormap");
     std::vector<RasterJob> jobs(n);
-    std::vector<uint32_t> start(n + 1);
+    std::vector<uint32_t> start;  // job index of every block
     uint64_t blocks = 0;
     for (size_t i = 0; i < n; i++) {
         const th_raster_desc &d = descs[i];
@@ -747,13 +748,13 @@ TH_API int th_raster_tiles_dev(th_ctx *c, const th_raster_desc *descs, size_t n,
         const uint32_t inv = qpr > 1 ? (uint32_t)((1ull << 32) / qpr) + 1u : 0u;  // exact for q * qpr < 2^32
         TH_REQUIRE(px == 0 || (px + 4) * d.width < (1ull << 32), "desc %zu: tile too large", i);
         const uint32_t inv_w = d.width > 1 ? (uint32_t)((1ull << 32) / d.width) + 1u : 0u;
+        const uint64_t nb = ((uint64_t)qpr * d.height + RASTER_QUADS_PER_BLOCK - 1) / RASTER_QUADS_PER_BLOCK;
+        TH_REQUIRE(blocks + nb < (1ull << 27), "batch too large for one launch");
         jobs[i] = RasterJob{d.img, d.rgba, d.img_width, d.img_height, d.origin_x, d.origin_y, d.width, d.height,
-                            d.img_pitch ? d.img_pitch : d.img_width, qpr, inv, inv_w};
-        start[i] = (uint32_t)blocks;
-        blocks += ((uint64_t)qpr * d.height + RASTER_QUADS_PER_BLOCK - 1) / RASTER_QUADS_PER_BLOCK;
-        TH_REQUIRE(blocks < (1ull << 31), "batch too large for one launch");
+                            d.img_pitch ? d.img_pitch : d.img_width, qpr, inv, inv_w, (uint32_t)blocks};
+        blocks += nb;
+        start.insert(start.end(), (size_t)nb, (uint32_t)i);  // block -> job table
     }
-    start[n] = (uint32_t)blocks;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     TH_HIP(hipSetDevice(c->device));
     int rc = c->raster_jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(RasterJob));

@@ -44,8 +44,9 @@ struct ImgJob {  // device-visible copy of th_img_desc
     uint16_t *img;
     uint32_t n_frames, height, i_start, i_end;
     uint32_t spec_pitch, img_pitch;  // elements per row (>= height / n_frames)
+    uint32_t first_tile, n_tiles;    // this job's block range in the launch
 };
-hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs,
+hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_job, uint32_t n_jobs,
                               uint32_t n_tiles, float min_dB, float max_dB, uint32_t colormap_len, hipStream_t s);
 
 struct RasterJob {  // device-visible copy of th_raster_desc (+ derived fields)
@@ -56,10 +57,18 @@ struct RasterJob {  // device-visible copy of th_raster_desc (+ derived fields)
     uint32_t quads_per_row;  // ceil(width / 4): a thread rasterises 4 horizontally adjacent pixels
     uint32_t inv_qpr;        // floor(2^32 / quads_per_row) + 1: q / quads_per_row == umulhi(q, inv_qpr)
     uint32_t inv_width;      // floor(2^32 / width) + 1 (flat-quad path of widths that are not multiples of 4)
+    uint32_t first_block;    // this job's first block in the launch
 };
-hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block_start, uint32_t n_jobs,
+hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block_job, uint32_t n_jobs,
                                 uint32_t n_blocks, const uint8_t *d_colormap, uint32_t n_colors, hipStream_t s);
-constexpr uint32_t RASTER_QUADS_PER_BLOCK = 1024;  // 256 threads x 4 quads of 4 pixels
+#if !defined(TH_RASTER_THREADS)
+#define TH_RASTER_THREADS 256
+#endif
+#if !defined(TH_RASTER_QPB)
+#define TH_RASTER_QPB 1024
+#endif
+constexpr uint32_t RASTER_THREADS = TH_RASTER_THREADS;
+constexpr uint32_t RASTER_QUADS_PER_BLOCK = TH_RASTER_QPB;  // default: 256 threads x 4 quads of 4 pixels
 constexpr uint32_t IMG_TILE_T = 128;  // frames per quantise/transpose tile
 constexpr uint32_t IMG_TILE_F = 64;   // frequency rows per tile
 

@@ -17,15 +17,9 @@
 
 namespace th {
 
-__device__ __forceinline__ uint32_t find_job(const uint32_t *__restrict__ start, uint32_t n, uint32_t b) {
-    uint32_t lo = 0, hi = n;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (start[mid] <= b) lo = mid;
-        else hi = mid;
-    }
-    return lo;
-}
+// Block -> job: a host-built table with one entry per block (one scalar load), not a binary search over the
+// per-job prefix sums: the search is a chain of ~log2(n_jobs) dependent loads (microseconds) in front of
+// every block's first data request, during which the block holds its LDS and wave slots for nothing.
 
 // drawing.rs:26-28 in f32, one rounding per operation (no FMA contraction):
 //   zero_to_one = (dB - min) / span;  u = zero_to_one * u16_span + min_value;
@@ -47,12 +41,11 @@ __device__ __forceinline__ uint32_t quantise(float dB, float min_dB, float span,
 constexpr uint32_t IMG_LDS_PITCH = IMG_TILE_T + 2;
 
 __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restrict__ jobs,
-                                                          const uint32_t *__restrict__ tile_start, uint32_t n_jobs,
+                                                          const uint32_t *__restrict__ tile_job, uint32_t n_jobs,
                                                           float min_dB, float span, float u16_span,
                                                           float min_value) {
     __shared__ __attribute__((aligned(4))) uint16_t tile[IMG_TILE_F][IMG_LDS_PITCH];  // [freq][frame]
-    const uint32_t ji = find_job(tile_start, n_jobs, blockIdx.x);
-    const ImgJob job = jobs[ji];
+    const ImgJob job = jobs[tile_job[blockIdx.x]];
     const gptr<const float> spec = as_global(job.spec);
     const gptr<uint16_t> img = as_global(job.img);
     const uint32_t out_h = job.i_end - job.i_start;
@@ -61,8 +54,8 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     // 4100-byte spec rows straddles three 128-byte lines; the frequency-adjacent tile needs the
     // other halves of the two boundary lines and now finds them in its XCD's L2 instead of
     // fetching them again (measured: 1.49x read over-fetch with time-fastest order).
-    const uint32_t n_local = tile_start[ji + 1] - tile_start[ji];
-    const uint32_t local0 = blockIdx.x - tile_start[ji];
+    const uint32_t n_local = job.n_tiles;
+    const uint32_t local0 = blockIdx.x - job.first_tile;
     const uint32_t per_xcd = (n_local + 7) / 8;
     uint32_t local = (local0 % 8) * per_xcd + local0 / 8;  // bijective when n_local % 8 == 0
     if (n_local % 8 != 0) local = local0;                   // ragged tail: plain order
@@ -104,7 +97,7 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     }
 }
 
-hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs,
+hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_job, uint32_t n_jobs,
                               uint32_t n_tiles, float min_dB, float max_dB, uint32_t colormap_len, hipStream_t s) {
     if (!n_tiles) return hipSuccess;
     // drawing.rs:20-22 — min_value = max(round(65535 / C), 1) in f64; u16_span = (65535 - min_value) as f32
@@ -115,7 +108,7 @@ hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_start
         min_value = v > 1 ? v : 1;
     }
     const float span = max_dB - min_dB;
-    hipLaunchKernelGGL(spec_to_img_kernel, dim3(n_tiles), dim3(256), 0, s, d_jobs, d_tile_start, n_jobs, min_dB, span,
+    hipLaunchKernelGGL(spec_to_img_kernel, dim3(n_tiles), dim3(256), 0, s, d_jobs, d_tile_job, n_jobs, min_dB, span,
                        (float)(65535u - min_value), (float)min_value);
     return hipGetLastError();
 }
@@ -144,9 +137,9 @@ __device__ __forceinline__ void raster_quads(const RasterJob &job, uint32_t base
     if (job.width % 4 == 0) {
         // row quads: 4 horizontally adjacent pixels of one tile row per thread
         const uint32_t n_quads = job.quads_per_row * job.height;
-#pragma unroll
-        for (uint32_t it = 0; it < RASTER_QUADS_PER_BLOCK / 256; it++) {
-            const uint32_t q = base + it * 256 + threadIdx.x;
+#pragma unroll 4
+        for (uint32_t it = 0; it < RASTER_QUADS_PER_BLOCK / RASTER_THREADS; it++) {
+            const uint32_t q = base + it * RASTER_THREADS + threadIdx.x;
             if (q >= n_quads) break;
             const uint32_t r = job.quads_per_row == 1 ? q : __umulhi(q, job.inv_qpr);  // 2^32/1 does not fit inv_qpr
             const uint32_t c = (q - r * job.quads_per_row) * 4;
@@ -169,8 +162,8 @@ __device__ __forceinline__ void raster_quads(const RasterJob &job, uint32_t base
         // 16 bytes wide whatever the tile width (the last tile column is rarely a multiple of 4)
         const uint32_t n_px = job.width * job.height, n_quads = (n_px + 3) / 4;
 #pragma unroll
-        for (uint32_t it = 0; it < RASTER_QUADS_PER_BLOCK / 256; it++) {
-            const uint32_t q = base + it * 256 + threadIdx.x;
+        for (uint32_t it = 0; it < RASTER_QUADS_PER_BLOCK / RASTER_THREADS; it++) {
+            const uint32_t q = base + it * RASTER_THREADS + threadIdx.x;
             if (q >= n_quads) break;
             const uint32_t o = 4 * q;
             uint32_t r = job.width == 1 ? o : __umulhi(o, job.inv_width);  // o / width
@@ -195,27 +188,26 @@ __device__ __forceinline__ void raster_quads(const RasterJob &job, uint32_t base
     }
 }
 
-__global__ __launch_bounds__(256) void raster_level0_kernel(const RasterJob *__restrict__ jobs,
-                                                            const uint32_t *__restrict__ block_start,
+__global__ __launch_bounds__(RASTER_THREADS) void raster_level0_kernel(const RasterJob *__restrict__ jobs,
+                                                            const uint32_t *__restrict__ block_job,
                                                             uint32_t n_jobs, const uint32_t *__restrict__ colormap,
                                                             uint32_t n_colors) {
     __shared__ uint32_t lut[1024];
     const bool use_lds = n_colors <= 1024;
     if (use_lds) {
-        for (uint32_t i = threadIdx.x; i < n_colors; i += 256) lut[i] = colormap[i];
+        for (uint32_t i = threadIdx.x; i < n_colors; i += RASTER_THREADS) lut[i] = colormap[i];
         __syncthreads();
     }
-    const uint32_t ji = find_job(block_start, n_jobs, blockIdx.x);
-    const RasterJob job = jobs[ji];
-    const uint32_t base = (blockIdx.x - block_start[ji]) * RASTER_QUADS_PER_BLOCK;
+    const RasterJob job = jobs[block_job[blockIdx.x]];
+    const uint32_t base = (blockIdx.x - job.first_block) * RASTER_QUADS_PER_BLOCK;
     if (use_lds) raster_quads<true>(job, base, lut, as_global(colormap), n_colors);
     else raster_quads<false>(job, base, lut, as_global(colormap), n_colors);
 }
 
-hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block_start, uint32_t n_jobs,
+hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block_job, uint32_t n_jobs,
                                 uint32_t n_blocks, const uint8_t *d_colormap, uint32_t n_colors, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
-    hipLaunchKernelGGL(raster_level0_kernel, dim3(n_blocks), dim3(256), 0, s, d_jobs, d_block_start, n_jobs,
+    hipLaunchKernelGGL(raster_level0_kernel, dim3(n_blocks), dim3(RASTER_THREADS), 0, s, d_jobs, d_block_job, n_jobs,
                        reinterpret_cast<const uint32_t *>(d_colormap), n_colors);
     return hipGetLastError();
 }
