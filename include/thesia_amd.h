@@ -237,6 +237,30 @@ typedef struct {
 /* Batched waveform decimation (many tiles / levels / channels in one launch, device → device). */
 TH_API int th_waveform_tiles_dev(th_ctx *ctx, const th_wave_desc *descs, size_t n);
 
+/* ---------------------------------------------------------------- waveform-tile cache (host only, no GPU needed) */
+/* Mirror of RenderTileCache — src-tauri/src/core/render_tiles.rs:51-230: a byte-budgeted LRU of encoded
+ * waveform tiles keyed by (id, ch, waveform_revision, level, tile_index) plus the waveform / spectrogram
+ * revision counters.  th_tm_* owns one; hosts that keep thesia's own lib.rs:342-367 flow can use it directly. */
+typedef struct th_tile_cache th_tile_cache;
+/* budget_bytes = 0 selects DEFAULT_WAVEFORM_CACHE_BUDGET_BYTES (32 MiB, render_tiles.rs:17) */
+TH_API int th_tile_cache_create(size_t budget_bytes, th_tile_cache **out);
+TH_API int th_tile_cache_destroy(th_tile_cache *cache);
+/* cached_waveform_tile (:124-144): *revision = current waveform revision; *hit = 1 and the bytes on a hit
+ * (which also makes the entry most recently used) */
+TH_API int th_tile_cache_lookup(th_tile_cache *cache, size_t id, uint32_t ch, uint32_t level, uint32_t tile_index,
+                                uint64_t *revision, uint8_t *out, size_t out_capacity, size_t *out_len, int *hit);
+/* store_waveform_tile (:146-169): ignored when `revision` is no longer current; evicts least recently used
+ * entries until the budget holds (:205-218) */
+TH_API int th_tile_cache_store(th_tile_cache *cache, size_t id, uint32_t ch, uint64_t revision, uint32_t level,
+                               uint32_t tile_index, const uint8_t *bytes, size_t len);
+/* invalidate_waveform (bumps the revision, drops every tile) / invalidate_spectrogram (:87-99) */
+TH_API int th_tile_cache_invalidate(th_tile_cache *cache, int waveform, int spectrogram);
+TH_API int th_tile_cache_set_budget(th_tile_cache *cache, size_t budget_bytes);
+/* any out pointer may be NULL */
+TH_API int th_tile_cache_stats(const th_tile_cache *cache, size_t *entries, size_t *bytes, size_t *budget_bytes,
+                               uint64_t *waveform_revision, uint64_t *spectrogram_revision, uint64_t *hits,
+                               uint64_t *misses);
+
 /* ---------------------------------------------------------------- TrackManager mirror (layer B, host buffers) */
 /* Mirrors core/mod.rs:33-230 with decoded audio handed over as planar host f32 (the output of
  * the reference's decode step, audio.rs:65-78).  Audio, f32 dB specs and u16 images stay
@@ -275,5 +299,7 @@ TH_API int th_tm_get_spectrogram_tile(th_tm *tm, size_t id, uint32_t ch, uint32_
                                       size_t *out_len);
 TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t level, uint32_t tile_index,
                                    uint8_t *out, size_t out_capacity, size_t *out_len);
+/* the RenderTileCache in front of get_waveform_tile (lib.rs:350-366): borrowed, owned by tm */
+TH_API int th_tm_tile_cache(th_tm *tm, th_tile_cache **out);
 
 #endif /* THESIA_AMD_H */

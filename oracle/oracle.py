@@ -272,3 +272,65 @@ def track_step(x, win: int, hop: int, n_fft: int, colormap_rgba: bytes, dB_range
     cm = np.frombuffer(bytes(colormap_rgba), np.uint8)
     chk = C.c_uint64()
     return lib().orc_track_step(_p(x, _f32p), x.size, win, hop, n_fft, _p(cm, _u8p), cm.size, dB_range, C.byref(chk))
+
+
+# ---------------------------------------------------------------------------------------------
+# RenderTileCache — src-tauri/src/core/render_tiles.rs:51-230 (waveform-tile LRU + revisions).
+# Literal restatement: a dict of entries with last_used ticks and the reference's linear min_by_key
+# eviction scan.  Pinned by the reference's four cache tests (render_tiles.rs:473-537), restated in
+# tests/test_tile_cache.py.
+# ---------------------------------------------------------------------------------------------
+class RenderTileCache:
+    DEFAULT_BUDGET = 32 * 1024 * 1024  # render_tiles.rs:17
+
+    def __init__(self, budget_bytes: int = DEFAULT_BUDGET):  # with_budget, :68-78
+        self.entries = {}  # key -> [bytes, last_used]
+        self.bytes = 0
+        self.budget_bytes = budget_bytes
+        self.tick = 0
+        self.waveform_revision = 1
+        self.spectrogram_revision = 1
+
+    def _next_tick(self) -> int:  # :226-228
+        self.tick = (self.tick + 1) & 0xFFFFFFFFFFFFFFFF
+        return self.tick
+
+    def invalidate_waveform(self):  # :87-90
+        self.waveform_revision = max((self.waveform_revision + 1) & 0xFFFFFFFFFFFFFFFF, 1)
+        self.entries.clear()  # clear_tiles, :220-224
+        self.bytes = 0
+
+    def invalidate_spectrogram(self):  # :92-94
+        self.spectrogram_revision = max((self.spectrogram_revision + 1) & 0xFFFFFFFFFFFFFFFF, 1)
+
+    def invalidate_all(self):  # :96-99
+        self.invalidate_waveform()
+        self.invalidate_spectrogram()
+
+    def cached_waveform_tile(self, id_, ch, level, tile_index):  # :124-144
+        revision = self.waveform_revision
+        e = self.entries.get((id_, ch, revision, level, tile_index))
+        if e is None:
+            return revision, None
+        e[1] = self._next_tick()
+        return revision, e[0]
+
+    def store_waveform_tile(self, id_, ch, revision, level, tile_index, data: bytes):  # :146-169
+        if revision != self.waveform_revision:
+            return
+        self._insert((id_, ch, revision, level, tile_index), bytes(data))
+
+    def _insert(self, key, data):  # :190-203
+        old = self.entries.get(key)
+        self.entries[key] = [data, self._next_tick()]
+        if old is not None:
+            self.bytes = max(self.bytes - len(old[0]), 0)
+        self.bytes += len(data)
+        self._evict()
+
+    def _evict(self):  # :205-218
+        while self.bytes > self.budget_bytes:
+            if not self.entries:
+                break
+            key = min(self.entries, key=lambda k: self.entries[k][1])
+            self.bytes -= len(self.entries.pop(key)[0])

@@ -8,7 +8,7 @@ tag=$1; shift
 cd "$(dirname "$0")/../thesia_amd/csrc"
 srcs=${VARIANT_SOURCES:-kernels_stft.hip}
 objs=""
-for f in api.hip track_manager.hip kernels_stft.hip kernels_mel.hip kernels_image.hip kernels_waveform.hip host_math.cpp; do
+for f in api.hip track_manager.hip kernels_stft.hip kernels_mel.hip kernels_image.hip kernels_waveform.hip host_math.cpp tile_cache.cpp; do
   if [[ " $srcs " == *" $f "* ]]; then
     extra=""
     case $f in

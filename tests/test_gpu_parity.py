@@ -403,3 +403,43 @@ def test_track_manager_flow(ctx, golden_dir):
         tm.spec(0, 0)
     assert e.value.code == -7
     tm.close()
+
+
+def test_track_manager_waveform_tile_cache_and_lod_tiles(ctx, golden_dir):
+    """lib.rs:342-389 through the manager: a waveform tile is encoded once and then served from the LRU
+    (render_tiles.rs:124-169), invalidations follow the command layer (lib.rs:192,221), and LOD > 0 spectrogram
+    tiles match the restated Lanczos3 on the manager's own image."""
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    tm = ta.TrackManager(ctx)
+    tm.set_colormap(cmap)
+    wav = synth_track(5, 48000, 200000)
+    tm.add_tracks([(3, 48000, wav[None])])
+    tm.apply_track_list_changes()
+    cache = tm.tile_cache()
+    w_rev, s_rev = tm.revisions()
+    st0 = cache.stats()
+    assert st0["entries"] == 0 and st0["waveform_revision"] == w_rev
+    want = orc.encode_waveform_tile(wav, w_rev, 2, 1)
+    first = tm.get_waveform_tile(3, 0, 2, 1)
+    again = tm.get_waveform_tile(3, 0, 2, 1)
+    assert first == want and again == want
+    st = cache.stats()
+    assert st["entries"] == 1 and st["bytes"] == len(want) and st["hits"] == st0["hits"] + 1
+    assert st["misses"] == st0["misses"] + 1
+    # a tiny budget: every new tile evicts the previous one
+    cache.set_budget(len(want))
+    other = tm.get_waveform_tile(3, 0, 2, 0)
+    assert other == orc.encode_waveform_tile(wav, w_rev, 2, 0)
+    assert cache.stats()["entries"] == 1 and cache.lookup(3, 0, 2, 1)[1] is None
+    # a track-list change bumps both revisions and clears the tiles (lib.rs:192 -> invalidate_all)
+    tm.add_tracks([(4, 48000, synth_track(6, 48000, 30000)[None])])
+    tm.apply_track_list_changes()
+    w2, s2 = tm.revisions()
+    assert w2 > w_rev and s2 > s_rev and cache.stats()["entries"] == 0
+    assert tm.get_waveform_tile(3, 0, 2, 1) == orc.encode_waveform_tile(wav, w2, 2, 1)
+    # LOD tiles through the manager
+    img = tm.img(3, 0)
+    for lx, ly, tx, ty in [(1, 0, 0, 0), (0, 1, 1, 0), (2, 1, 0, 0)]:
+        got = tm.get_spectrogram_tile(3, 0, lx, ly, tx, ty)
+        assert got == orc.encode_spectrogram_tile(img, cmap, s2, lx, ly, tx, ty), (lx, ly, tx, ty)
+    tm.close()

@@ -149,6 +149,16 @@ _SIGS = {
     "th_tm_get_spectrogram_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    c_u8p, C.c_size_t, c_szp],
     "th_tm_get_waveform_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
+    "th_tm_tile_cache": [vp, C.POINTER(vp)],
+    "th_tile_cache_create": [C.c_size_t, C.POINTER(vp)],
+    "th_tile_cache_destroy": [vp],
+    "th_tile_cache_lookup": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), c_u8p, C.c_size_t,
+                             c_szp, C.POINTER(C.c_int)],
+    "th_tile_cache_store": [vp, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t],
+    "th_tile_cache_invalidate": [vp, C.c_int, C.c_int],
+    "th_tile_cache_set_budget": [vp, C.c_size_t],
+    "th_tile_cache_stats": [vp, c_szp, c_szp, c_szp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                            C.POINTER(C.c_uint64)],
 }
 _RESTYPES = {"th_plan_kernel_name": C.c_char_p, "th_pitch_f32": C.c_size_t, "th_pitch_u16": C.c_size_t}
 

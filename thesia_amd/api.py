@@ -321,6 +321,68 @@ class Plan:
 
 
 # ------------------------------------------------------------------ TrackManager mirror
+class TileCache:
+    """th_tile_cache: mirror of RenderTileCache (render_tiles.rs:51-230) — byte-budgeted LRU of encoded waveform
+    tiles plus the waveform / spectrogram revision counters.  Host only."""
+
+    def __init__(self, budget_bytes: int = 0, _borrowed=None):
+        if _borrowed is not None:
+            self.handle, self._own = _borrowed, False
+            return
+        h = vp()
+        check(lib.th_tile_cache_create(budget_bytes, C.byref(h)))
+        self.handle, self._own = h, True
+
+    def close(self):
+        if self.handle and self._own:
+            check(lib.th_tile_cache_destroy(self.handle))
+        self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def lookup(self, track_id: int, ch: int, level: int, tile_index: int):
+        """-> (current waveform revision, bytes or None); a hit makes the entry most recently used."""
+        cap = WAVEFORM_TILE_MAX_BYTES
+        while True:
+            out = np.empty(cap, np.uint8)
+            n, rev, hit = C.c_size_t(), C.c_uint64(), C.c_int()
+            rc = lib.th_tile_cache_lookup(self.handle, track_id, ch, level, tile_index, C.byref(rev), _ptr(out, c_u8p),
+                                          out.size, C.byref(n), C.byref(hit))
+            if rc == _ffi.ERR_BUFFER_TOO_SMALL and n.value > cap:
+                cap = n.value
+                continue
+            check(rc)
+            return rev.value, (out[: n.value].tobytes() if hit.value else None)
+
+    def store(self, track_id: int, ch: int, revision: int, level: int, tile_index: int, data: bytes):
+        a = np.frombuffer(bytes(data), np.uint8)
+        check(lib.th_tile_cache_store(self.handle, track_id, ch, revision, level, tile_index, _ptr(a, c_u8p), a.size))
+
+    def invalidate_waveform(self):
+        check(lib.th_tile_cache_invalidate(self.handle, 1, 0))
+
+    def invalidate_spectrogram(self):
+        check(lib.th_tile_cache_invalidate(self.handle, 0, 1))
+
+    def invalidate_all(self):
+        check(lib.th_tile_cache_invalidate(self.handle, 1, 1))
+
+    def set_budget(self, budget_bytes: int):
+        check(lib.th_tile_cache_set_budget(self.handle, budget_bytes))
+
+    def stats(self) -> dict:
+        e, b, bud = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        wr, sr, h, m = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib.th_tile_cache_stats(self.handle, C.byref(e), C.byref(b), C.byref(bud), C.byref(wr), C.byref(sr),
+                                      C.byref(h), C.byref(m)))
+        return {"entries": e.value, "bytes": b.value, "budget_bytes": bud.value, "waveform_revision": wr.value,
+                "spectrogram_revision": sr.value, "hits": h.value, "misses": m.value}
+
+
 class TrackManager:
     """th_tm: mirror of core/mod.rs TrackManager with HBM-resident audio / specs / images."""
 
@@ -397,6 +459,12 @@ class TrackManager:
         check(lib.th_tm_get_spectrogram_tile(self.handle, track_id, ch, level_x, level_y, tile_x, tile_y,
                                              _ptr(out, c_u8p), out.size, C.byref(n)))
         return out[: n.value].tobytes()
+
+    def tile_cache(self) -> TileCache:
+        """The RenderTileCache in front of get_waveform_tile (borrowed; owned by the manager)."""
+        h = vp()
+        check(lib.th_tm_tile_cache(self.handle, C.byref(h)))
+        return TileCache(_borrowed=h)
 
     def get_waveform_tile(self, track_id: int, ch: int, level: int, tile_index: int) -> bytes:
         out = np.empty(WAVEFORM_TILE_MAX_BYTES, np.uint8)

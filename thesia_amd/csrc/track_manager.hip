@@ -8,7 +8,7 @@
 // the revision bumps the command layer applies around them (lib.rs:192,221,244,265,284), and
 // get_waveform_tile / get_spectrogram_tile.
 // What is not: file decoding, normalisation / clip guarding (TrackList, out of scope — the path
-// starts at an in-memory planar f32 channel, audio.rs:65-78) and the waveform-tile LRU cache.
+// starts at an in-memory planar f32 channel, audio.rs:65-78).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -22,6 +22,7 @@
 #include "context.h"
 #include "host_math.h"
 #include "kernels.h"
+#include "tile_cache.h"
 
 using namespace th;
 
@@ -63,13 +64,18 @@ struct th_tm {
     std::map<PlanKey, th_plan *> plans;  // SpectrogramAnalyzer caches, spectrogram.rs:101-105
     // RenderTileCache state that the tile encoders need — render_tiles.rs:68-96
     std::vector<uint8_t> colormap_rgba{0, 0, 0, 255, 255, 255, 255, 255};
-    uint64_t waveform_revision = 1, spectrogram_revision = 1;
+    th_tile_cache cache{th_tile_cache::DEFAULT_BUDGET};  // revisions + waveform-tile LRU, render_tiles.rs:51-230
 
-    void invalidate_waveform() { waveform_revision = std::max<uint64_t>(waveform_revision + 1, 1); }
-    void invalidate_spectrogram() { spectrogram_revision = std::max<uint64_t>(spectrogram_revision + 1, 1); }
-    void invalidate_all() {
-        invalidate_waveform();
-        invalidate_spectrogram();
+    void invalidate_waveform() { cache.invalidate_waveform(); }
+    void invalidate_spectrogram() { cache.invalidate_spectrogram(); }
+    void invalidate_all() { cache.invalidate_all(); }
+    uint64_t waveform_revision() const {
+        std::lock_guard<std::mutex> lk(cache.mu);
+        return cache.waveform_revision;
+    }
+    uint64_t spectrogram_revision() const {
+        std::lock_guard<std::mutex> lk(cache.mu);
+        return cache.spectrogram_revision;
     }
 };
 
@@ -463,8 +469,8 @@ TH_API int th_tm_copy_img(th_tm *tm, size_t id, uint32_t ch, uint16_t *out, size
 TH_API int th_tm_revisions(const th_tm *tm, uint64_t *waveform_revision, uint64_t *spectrogram_revision) {
     TH_TRY
     TH_REQUIRE(tm, "tm is NULL");
-    if (waveform_revision) *waveform_revision = tm->waveform_revision;
-    if (spectrogram_revision) *spectrogram_revision = tm->spectrogram_revision;
+    if (waveform_revision) *waveform_revision = tm->waveform_revision();
+    if (spectrogram_revision) *spectrogram_revision = tm->spectrogram_revision();
     return TH_OK;
     TH_CATCH
 }
@@ -478,12 +484,12 @@ TH_API int th_tm_get_spectrogram_tile(th_tm *tm, size_t id, uint32_t ch, uint32_
     Channel *c = find_channel(tm, id, ch);
     if (!c || !c->d_img) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
     return th_encode_spectrogram_tile_dev(tm->ctx, c->d_img, c->img_h, c->img_w, c->img_pitch, tm->colormap_rgba.data(),
-                                          tm->colormap_rgba.size(), tm->spectrogram_revision, level_x, level_y,
+                                          tm->colormap_rgba.size(), tm->spectrogram_revision(), level_x, level_y,
                                           tile_x, tile_y, out, cap, out_len);
     TH_CATCH
 }
 
-// get_waveform_tile — lib.rs:342-367 (the LRU cache in front of it is not mirrored yet)
+// get_waveform_tile — lib.rs:342-367: cache lookup (:350-355), encode on a miss, store (:358-365)
 TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t level, uint32_t tile_index,
                                    uint8_t *out, size_t cap, size_t *out_len) {
     TH_TRY
@@ -491,7 +497,24 @@ TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t l
     std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
     Channel *c = find_channel(tm, id, ch);
     if (!c) return fail(TH_ERR_NOT_FOUND, "Track %zu does not exist", id);
-    return th_encode_waveform_tile_dev(tm->ctx, c->d_wav, c->n, tm->waveform_revision, level, tile_index, out, cap,
-                                       out_len);
+    uint64_t revision = 0;
+    std::vector<uint8_t> cached;
+    if (tm->cache.lookup(id, ch, level, tile_index, &revision, &cached)) {
+        *out_len = cached.size();
+        if (cap < cached.size()) return fail(TH_ERR_BUFFER_TOO_SMALL, "need %zu bytes", cached.size());
+        std::memcpy(out, cached.data(), cached.size());
+        return TH_OK;
+    }
+    const int rc = th_encode_waveform_tile_dev(tm->ctx, c->d_wav, c->n, revision, level, tile_index, out, cap, out_len);
+    if (rc == TH_OK) tm->cache.store(id, ch, revision, level, tile_index, out, *out_len);
+    return rc;
+    TH_CATCH
+}
+
+TH_API int th_tm_tile_cache(th_tm *tm, th_tile_cache **out) {
+    TH_TRY
+    TH_REQUIRE(tm && out, "NULL argument");
+    *out = &tm->cache;
+    return TH_OK;
     TH_CATCH
 }
