@@ -269,6 +269,23 @@ def main():
     img_ms = time_stage(lambda: (ctx.spec_to_img_batch(wl.imgd, lo, hi, 258),
                                  ctx.raster_tiles(wl.rast, wl.cmap.data_ptr(), wl.n_colors)))
 
+    # waveform side of the path: every decimation level of every channel, one pass over the audio
+    wave = None
+    if rank == 0 and not args.no_single_track:
+        from thesia_amd import _ffi
+        n_lv = 13
+        tot = ta.api.pyramid_offset(n, n_lv)
+        pyr = torch.empty((wl.n_tracks, tot), dtype=torch.float32, device=dev)
+        pdesc = (_ffi.PyramidDesc * wl.n_tracks)(*[_ffi.PyramidDesc(wl.wav[i].data_ptr(), pyr[i].data_ptr(), n, n_lv, 0)
+                                                   for i in range(wl.n_tracks)])
+        pyr_ms = time_stage(lambda: ctx.waveform_pyramid_dev(pdesc))
+        smp = wl.n_tracks * n
+        wave = {"workload": f"levels 0..{n_lv - 1} (min, max, mean) of {wl.n_tracks} channels x {n} samples",
+                "ms": pyr_ms, "msamples_per_s": smp / 1e6 / (pyr_ms * 1e-3), "bound": "hbm",
+                "algorithmic_bytes_per_sample": 4 + 4.0 * tot / n,
+                "frac": (smp * 4 + wl.n_tracks * tot * 4) / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del pyr
+
     single = None
     if rank == 0 and not args.no_single_track:
         w1 = Workload(torch, ta, ctx, dev, [0], sr, 60 * sr, win, hop, n_fft, args.kernel, cmap_bytes)
@@ -326,6 +343,8 @@ def main():
         }
         if single is not None:
             out["single_track_cfg2"] = single
+        if wave is not None:
+            out["waveform_pyramid"] = wave
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft)
         print(json.dumps(out), flush=True)

@@ -237,6 +237,22 @@ typedef struct {
 /* Batched waveform decimation (many tiles / levels / channels in one launch, device → device). */
 TH_API int th_waveform_tiles_dev(th_ctx *ctx, const th_wave_desc *descs, size_t n);
 
+/* Waveform pyramid: every decimation level of a channel from one pass over the audio.  Level L
+ * (samples per bin 2^L, exactly the bins encode_waveform_tile emits for that level — render_tiles.rs:232-279)
+ * has th_waveform_pyramid_bins(n, L) = ceil(n / 2^L) bins of (min, max, mean) f32 and starts at float offset
+ * th_waveform_pyramid_offset(n, L) of `out`; tile t of level L is bins [1024 t, 1024 (t + 1)) of that level.
+ * `out` must hold th_waveform_pyramid_offset(n, n_levels) floats. */
+typedef struct {
+    const float *wav; /* DEVICE */
+    float *out;       /* DEVICE */
+    uint64_t n_samples;
+    uint32_t n_levels; /* levels 0 .. n_levels-1, at most 40 */
+    uint32_t reserved;
+} th_pyramid_desc;
+TH_API size_t th_waveform_pyramid_bins(uint64_t n_samples, uint32_t level);
+TH_API size_t th_waveform_pyramid_offset(uint64_t n_samples, uint32_t level);
+TH_API int th_waveform_pyramid_dev(th_ctx *ctx, const th_pyramid_desc *descs, size_t n);
+
 /* ---------------------------------------------------------------- waveform-tile cache (host only, no GPU needed) */
 /* Mirror of RenderTileCache — src-tauri/src/core/render_tiles.rs:51-230: a byte-budgeted LRU of encoded
  * waveform tiles keyed by (id, ch, waveform_revision, level, tile_index) plus the waveform / spectrogram
@@ -299,6 +315,22 @@ TH_API int th_tm_get_spectrogram_tile(th_tm *tm, size_t id, uint32_t ch, uint32_
                                       size_t *out_len);
 TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t level, uint32_t tile_index,
                                    uint8_t *out, size_t out_capacity, size_t *out_len);
+/* AudioRenderMetadata — render_tiles.rs:36-49, filled as RenderTileCache::metadata (:101-122) does for
+ * get_audio_render_metadata (lib.rs:321-340).  track_sec and is_clipped come from the reference's TrackList
+ * (decode / clip guard, upstream of this path) and are passed through unchanged; an absent spectrogram gives
+ * width = height = 0 (`unwrap_or_default`, :109). */
+typedef struct {
+    uint64_t waveform_revision, spectrogram_revision;
+    uint32_t sample_rate;
+    uint32_t is_clipped;
+    uint64_t sample_count;
+    double track_sec;
+    uint64_t spectrogram_width, spectrogram_height;
+    uint64_t waveform_tile_bins;    /* WAVEFORM_TILE_BINS = 1024, :14 */
+    uint64_t spectrogram_tile_size; /* SPECTROGRAM_TILE_SIZE = 512, :15 */
+} th_render_metadata;
+TH_API int th_tm_get_audio_render_metadata(th_tm *tm, size_t id, uint32_t ch, double track_sec, int is_clipped,
+                                           th_render_metadata *out);
 /* the RenderTileCache in front of get_waveform_tile (lib.rs:350-366): borrowed, owned by tm */
 TH_API int th_tm_tile_cache(th_tm *tm, th_tile_cache **out);
 

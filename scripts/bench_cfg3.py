@@ -72,3 +72,26 @@ samples = n_ch * n
 rd = samples * 4 * 13 / 1e9
 print(f"cfg3 waveform: {len(descs)} tiles, levels 0..12: {ms:.3f} ms  {samples / ms / 1e3:.0f} Msamples/s per full pyramid "
       f"({rd / ms * 1e3:.0f} GB/s read, each level re-reads the audio)")
+
+# the same bins from ONE pass over the audio (th_waveform_pyramid_dev)
+from thesia_amd import _ffi  # noqa: E402
+
+n_levels = 13
+tot = ta.api.pyramid_offset(n, n_levels)
+pyr = torch.empty((n_ch, tot), dtype=torch.float32, device=dev)
+pd = (_ffi.PyramidDesc * n_ch)(*[_ffi.PyramidDesc(wav[c].data_ptr(), pyr[c].data_ptr(), n, n_levels, 0) for c in range(n_ch)])
+ms = timeit(lambda: ctx.waveform_pyramid_dev(pd), 10)
+byt = samples * 4 + n_ch * tot * 4
+print(f"cfg3 waveform pyramid (one pass, levels 0..12): {ms:.3f} ms  {samples / ms / 1e3:.0f} Msamples/s  "
+      f"{byt / ms / 1e6:.0f} GB/s algorithmic ({byt / ms / 1e6 / 80:.1f}% of 8 TB/s; 4 B read + {n_ch * tot * 4 / samples:.2f} B written per sample)")
+# cross-check against the per-tile kernel on one channel
+a = out[0].flatten()
+off = 0
+ok = True
+for level in range(n_levels):
+    nb = ta.api.pyramid_bins(n, level)
+    p = pyr[0, ta.api.pyramid_offset(n, level): ta.api.pyramid_offset(n, level + 1)].reshape(-1, 3)
+    t = a[off * 3:(off + nb) * 3].reshape(-1, 3)
+    off += nb
+    ok &= bool(torch.equal(p[:, :2], t[:, :2])) and float((p[:, 2] - t[:, 2]).abs().max()) <= 1e-6 * 0.25
+print("pyramid == per-tile kernel (min/max exact, mean 1e-6):", ok)

@@ -417,6 +417,12 @@ def test_track_manager_waveform_tile_cache_and_lod_tiles(ctx, golden_dir):
     tm.apply_track_list_changes()
     cache = tm.tile_cache()
     w_rev, s_rev = tm.revisions()
+    # metadata_reports_clipped_waveform_and_dimensions (render_tiles.rs:539-546) through the manager
+    md = tm.render_metadata(3, 0, 200000 / 48000, True)
+    ih, iw = tm.img(3, 0).shape
+    assert md == {"waveform_revision": w_rev, "spectrogram_revision": s_rev, "sample_rate": 48000, "is_clipped": 1,
+                  "sample_count": 200000, "track_sec": 200000 / 48000, "spectrogram_width": iw, "spectrogram_height": ih,
+                  "waveform_tile_bins": 1024, "spectrogram_tile_size": 512}
     st0 = cache.stats()
     assert st0["entries"] == 0 and st0["waveform_revision"] == w_rev
     want = orc.encode_waveform_tile(wav, w_rev, 2, 1)
@@ -443,3 +449,56 @@ def test_track_manager_waveform_tile_cache_and_lod_tiles(ctx, golden_dir):
         got = tm.get_spectrogram_tile(3, 0, lx, ly, tx, ty)
         assert got == orc.encode_spectrogram_tile(img, cmap, s2, lx, ly, tx, ty), (lx, ly, tx, ty)
     tm.close()
+
+
+# ---------------------------------------------------------------- waveform pyramid (all levels, one pass)
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 4095, 4096, 4097, 100_000, 1_000_003])
+def test_waveform_pyramid_matches_tiles(ctx, n):
+    """Every level of th_waveform_pyramid_dev equals the bins encode_waveform_tile emits for that level
+    (render_tiles.rs:232-279): min / max bit-exact, the mean bit-exact for bins <= 16 samples (sequential sum) and
+    within 1e-6 of the peak above (the reference's own order there is not deterministic)."""
+    x = synth_track(n, 48000, n)
+    n_levels = 15
+    lv = ctx.waveform_pyramid(x, n_levels)
+    peak = float(np.abs(x).max())
+    for level in range(n_levels):
+        spb = 1 << level
+        bins = -(-n // spb)
+        assert lv[level].shape == (bins, 3), (level, lv[level].shape)
+        assert ta.api.pyramid_bins(n, level) == bins
+        n_tiles = -(-bins // 1024)
+        tiles = range(n_tiles) if n_tiles <= 4 else [0, 1, n_tiles // 2, n_tiles - 1]
+        for t in tiles:
+            want = np.frombuffer(orc.encode_waveform_tile(x, 1, level, t)[24:], np.float32).reshape(-1, 3)
+            got = lv[level][1024 * t: 1024 * (t + 1)]
+            assert got.shape == want.shape, (level, t)
+            assert np.array_equal(got[:, :2], want[:, :2]), (level, t)
+            if level <= 4:
+                assert np.array_equal(got[:, 2], want[:, 2]), (level, t)
+            else:
+                assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-6 * peak, (level, t)
+
+
+def test_waveform_pyramid_batch_ragged_and_partial_levels(ctx):
+    """several channels of different lengths in one call, fewer levels than the kernel's base pass, empty channel"""
+    from thesia_amd import _ffi
+    lens, levels = [5000, 0, 70_001, 33], [3, 5, 9, 7]
+    xs = [synth_track(40 + i, 44100, max(n, 1))[:n] for i, n in enumerate(lens)]
+    dw = [ctx.to_device(x if x.size else np.zeros(1, np.float32)) for x in xs]
+    tot = [ta.api.pyramid_offset(n, l) for n, l in zip(lens, levels)]
+    do = [ctx.alloc(max(t, 1) * 4) for t in tot]
+    ctx.waveform_pyramid_dev([_ffi.PyramidDesc(w.ptr, o.ptr, n, l, 0) for w, o, n, l in zip(dw, do, lens, levels)])
+    for x, o, n, l, t in zip(xs, do, lens, levels, tot):
+        flat = o.download((max(t, 1),), np.float32)[:t]
+        for level in range(l):
+            a, b = ta.api.pyramid_offset(n, level), ta.api.pyramid_offset(n, level + 1)
+            got = flat[a:b].reshape(-1, 3)
+            if n == 0:
+                assert got.size == 0
+                continue
+            want = np.concatenate([np.frombuffer(orc.encode_waveform_tile(x, 1, level, t_)[24:], np.float32)
+                                   for t_ in range(-(-(-(-n // (1 << level))) // 1024))]).reshape(-1, 3)
+            assert np.array_equal(got[:, :2], want[:, :2]), (n, level)
+            assert np.abs(got[:, 2] - want[:, 2]).max() <= (0 if level <= 4 else 1e-6 * np.abs(x).max()), (n, level)
+    for b in dw + do:
+        b.free()

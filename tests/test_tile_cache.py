@@ -14,12 +14,18 @@ def _tile(seed: int, n: int = TILE) -> bytes:
     return np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8).tobytes()
 
 
+def _wf(n_tiles: int, revision: int, tile_index: int) -> bytes:
+    """encode_waveform_tile(&vec![0.0; WAVEFORM_TILE_BINS * n_tiles], revision, 0, tile_index) as in the reference's
+    cache tests"""
+    return orc.encode_waveform_tile(np.zeros(1024 * n_tiles, np.float32), revision, 0, tile_index)
+
+
 def test_cache_evicts_and_invalidates():
     # render_tiles.rs:473-487
     with ta.TileCache(TILE) as c:
         rev = c.stats()["waveform_revision"]
-        c.store(1, 0, rev, 0, 0, _tile(0))
-        c.store(1, 0, rev, 0, 1, _tile(1))
+        c.store(1, 0, rev, 0, 0, _wf(2, rev, 0))
+        c.store(1, 0, rev, 0, 1, _wf(2, rev, 1))
         st = c.stats()
         assert st["entries"] == 1 and st["bytes"] <= st["budget_bytes"]
         c.invalidate_waveform()
@@ -31,7 +37,8 @@ def test_cache_replaces_duplicate_without_double_counting():
     # render_tiles.rs:489-501
     with ta.TileCache(2**40) as c:
         rev = c.stats()["waveform_revision"]
-        b = _tile(2)
+        b = _wf(1, rev, 0)
+        assert len(b) == TILE
         c.store(1, 0, rev, 0, 0, b)
         c.store(1, 0, rev, 0, 0, b)
         st = c.stats()
@@ -43,12 +50,12 @@ def test_cache_hit_updates_lru_order():
     with ta.TileCache(TILE * 2) as c:
         rev = c.stats()["waveform_revision"]
         for i in range(2):
-            c.store(1, 0, rev, 0, i, _tile(10 + i))
+            c.store(1, 0, rev, 0, i, _wf(3, rev, i))
         assert c.lookup(1, 0, 0, 0)[1] is not None  # touch tile 0: tile 1 is now the oldest
-        c.store(1, 0, rev, 0, 2, _tile(12))
-        assert c.lookup(1, 0, 0, 0)[1] == _tile(10)
+        c.store(1, 0, rev, 0, 2, _wf(3, rev, 2))
+        assert c.lookup(1, 0, 0, 0)[1] == _wf(3, rev, 0)
         assert c.lookup(1, 0, 0, 1)[1] is None
-        assert c.lookup(1, 0, 0, 2)[1] == _tile(12)
+        assert c.lookup(1, 0, 0, 2)[1] == _wf(3, rev, 2)
 
 
 def test_cache_drops_tile_from_stale_revision():
@@ -58,7 +65,7 @@ def test_cache_drops_tile_from_stale_revision():
         assert st["budget_bytes"] == 32 * 1024 * 1024  # DEFAULT_WAVEFORM_CACHE_BUDGET_BYTES, :17
         rev = st["waveform_revision"]
         c.invalidate_waveform()
-        c.store(1, 0, rev, 0, 0, _tile(3))
+        c.store(1, 0, rev, 0, 0, _wf(1, rev, 0))
         assert c.stats()["entries"] == 0
 
 

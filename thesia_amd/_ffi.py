@@ -60,6 +60,18 @@ OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_BUFFE
     ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 
+class PyramidDesc(C.Structure):
+    _fields_ = [("wav", C.c_void_p), ("out", C.c_void_p), ("n_samples", C.c_uint64), ("n_levels", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class RenderMetadata(C.Structure):
+    _fields_ = [("waveform_revision", C.c_uint64), ("spectrogram_revision", C.c_uint64), ("sample_rate", C.c_uint32),
+                ("is_clipped", C.c_uint32), ("sample_count", C.c_uint64), ("track_sec", C.c_double),
+                ("spectrogram_width", C.c_uint64), ("spectrogram_height", C.c_uint64), ("waveform_tile_bins", C.c_uint64),
+                ("spectrogram_tile_size", C.c_uint64)]
+
+
 class TileGeom(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("origin_x", C.c_uint32), ("origin_y", C.c_uint32),
                 ("lod_width", C.c_uint64), ("lod_height", C.c_uint64)]
@@ -149,7 +161,11 @@ _SIGS = {
     "th_tm_get_spectrogram_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    c_u8p, C.c_size_t, c_szp],
     "th_tm_get_waveform_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
+    "th_waveform_pyramid_bins": [C.c_uint64, C.c_uint32],
+    "th_waveform_pyramid_offset": [C.c_uint64, C.c_uint32],
+    "th_waveform_pyramid_dev": [vp, C.POINTER(PyramidDesc), C.c_size_t],
     "th_tm_tile_cache": [vp, C.POINTER(vp)],
+    "th_tm_get_audio_render_metadata": [vp, C.c_size_t, C.c_uint32, C.c_double, C.c_int, C.POINTER(RenderMetadata)],
     "th_tile_cache_create": [C.c_size_t, C.POINTER(vp)],
     "th_tile_cache_destroy": [vp],
     "th_tile_cache_lookup": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), c_u8p, C.c_size_t,
@@ -160,7 +176,8 @@ _SIGS = {
     "th_tile_cache_stats": [vp, c_szp, c_szp, c_szp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                             C.POINTER(C.c_uint64)],
 }
-_RESTYPES = {"th_plan_kernel_name": C.c_char_p, "th_pitch_f32": C.c_size_t, "th_pitch_u16": C.c_size_t}
+_RESTYPES = {"th_plan_kernel_name": C.c_char_p, "th_pitch_f32": C.c_size_t, "th_pitch_u16": C.c_size_t,
+             "th_waveform_pyramid_bins": C.c_size_t, "th_waveform_pyramid_offset": C.c_size_t}
 
 lib.th_last_error.restype = C.c_char_p
 lib.th_last_error.argtypes = []

@@ -92,6 +92,15 @@ def pitch_u16(row_elems: int) -> int:
     return lib.th_pitch_u16(row_elems)
 
 
+def pyramid_bins(n_samples: int, level: int) -> int:
+    return lib.th_waveform_pyramid_bins(n_samples, level)
+
+
+def pyramid_offset(n_samples: int, level: int) -> int:
+    """float offset of level `level` in a channel's pyramid buffer (= total floats for level = n_levels)"""
+    return lib.th_waveform_pyramid_offset(n_samples, level)
+
+
 def shard_assign(weights, world: int):
     """th_shard_assign: owner rank of every (track, channel) unit, by frame-count weight."""
     w = np.ascontiguousarray(weights, dtype=np.uint64)
@@ -254,6 +263,25 @@ class Context:
     def waveform_tiles(self, descs: Sequence[WaveDesc]):
         arr = descs if isinstance(descs, C.Array) else (WaveDesc * len(descs))(*descs)
         check(lib.th_waveform_tiles_dev(self.handle, arr, len(arr)))
+
+    # ---- waveform pyramid: all levels of a channel in one pass over the audio
+    def waveform_pyramid_dev(self, descs):
+        arr = descs if isinstance(descs, C.Array) else (_ffi.PyramidDesc * len(descs))(*descs)
+        check(lib.th_waveform_pyramid_dev(self.handle, arr, len(arr)))
+
+    def waveform_pyramid(self, wav: np.ndarray, n_levels: int):
+        """Host convenience (tests): returns [level] -> ndarray [bins, 3] of (min, max, mean)."""
+        wav = _f32(wav)
+        total = pyramid_offset(wav.size, n_levels)
+        d = self.to_device(wav)
+        o = self.alloc(max(total, 1) * 4)
+        try:
+            self.waveform_pyramid_dev([_ffi.PyramidDesc(d.ptr, o.ptr, wav.size, n_levels, 0)])
+            flat = o.download((max(total, 1),), np.float32)[:total]
+        finally:
+            d.free()
+            o.free()
+        return [flat[pyramid_offset(wav.size, l): pyramid_offset(wav.size, l + 1)].reshape(-1, 3) for l in range(n_levels)]
 
 
 # ------------------------------------------------------------------ SpectrogramAnalyzer plan
@@ -459,6 +487,12 @@ class TrackManager:
         check(lib.th_tm_get_spectrogram_tile(self.handle, track_id, ch, level_x, level_y, tile_x, tile_y,
                                              _ptr(out, c_u8p), out.size, C.byref(n)))
         return out[: n.value].tobytes()
+
+    def render_metadata(self, track_id: int, ch: int, track_sec: float, is_clipped: bool) -> dict:
+        """AudioRenderMetadata of get_audio_render_metadata (lib.rs:321-340)."""
+        m = _ffi.RenderMetadata()
+        check(lib.th_tm_get_audio_render_metadata(self.handle, track_id, ch, track_sec, int(is_clipped), C.byref(m)))
+        return {k: getattr(m, k) for k, _ in m._fields_}
 
     def tile_cache(self) -> TileCache:
         """The RenderTileCache in front of get_waveform_tile (borrowed; owned by the manager)."""

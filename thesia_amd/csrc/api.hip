@@ -948,6 +948,62 @@ TH_API int th_waveform_tiles_dev(th_ctx *c, const th_wave_desc *descs, size_t n)
     TH_CATCH
 }
 
+// ------------------------------------------------------------------------------------------ waveform pyramid
+TH_API size_t th_waveform_pyramid_bins(uint64_t n_samples, uint32_t level) { return (size_t)pyramid_bins(n_samples, level); }
+TH_API size_t th_waveform_pyramid_offset(uint64_t n_samples, uint32_t level) {
+    return (size_t)pyramid_offset(n_samples, level < PYR_MAX_LEVELS ? level : PYR_MAX_LEVELS);
+}
+
+TH_API int th_waveform_pyramid_dev(th_ctx *c, const th_pyramid_desc *descs, size_t n) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    if (n == 0) return TH_OK;
+    TH_REQUIRE(descs, "descs is NULL");
+    TH_REQUIRE(n <= 65535, "at most 65535 channels per call");
+    std::vector<PyrJob> jobs(n);
+    uint64_t max_samples = 0, sums_total = 0;
+    uint32_t max_levels = 0;
+    for (size_t i = 0; i < n; i++) {
+        const th_pyramid_desc &d = descs[i];
+        TH_REQUIRE(d.n_levels <= PYR_MAX_LEVELS, "desc %zu: more than %u levels", i, PYR_MAX_LEVELS);
+        TH_REQUIRE(d.n_samples == 0 || d.n_levels == 0 || (d.wav && d.out), "desc %zu: NULL device pointer", i);
+        TH_REQUIRE(d.n_samples < (1ull << 40), "desc %zu: too many samples", i);
+        PyrJob &j = jobs[i];
+        j = PyrJob{};
+        j.wav = d.wav;
+        j.out = d.out;
+        j.n_samples = d.n_levels ? d.n_samples : 0;
+        j.n_levels = d.n_levels;
+        j.aligned16 = (reinterpret_cast<uintptr_t>(d.wav) & 15u) == 0;
+        uint64_t off = 0;
+        for (uint32_t l = 0; l < PYR_MAX_LEVELS; l++) {
+            j.level_off[l] = off;
+            off += 3 * pyramid_bins(d.n_samples, l);
+        }
+        j.sums_half = pyramid_bins(d.n_samples, 12);
+        sums_total += 2 * j.sums_half;
+        max_samples = std::max<uint64_t>(max_samples, j.n_samples);
+        max_levels = std::max(max_levels, d.n_levels);
+    }
+    if (!max_samples || !max_levels) return TH_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    TH_HIP(hipSetDevice(c->device));
+    int rc = c->pyr_sums.ensure(std::max<uint64_t>(sums_total, 1) * sizeof(float));
+    if (rc != TH_OK) return rc;
+    uint64_t so = 0;
+    for (PyrJob &j : jobs) {
+        j.sums = reinterpret_cast<float *>(c->pyr_sums.dptr) + so;
+        so += 2 * j.sums_half;
+    }
+    rc = c->pyr_jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(PyrJob));
+    if (rc != TH_OK) return rc;
+    const PyrJob *dj = (const PyrJob *)c->pyr_jobs.dptr;
+    TH_HIP(launch_pyramid_base(dj, (uint32_t)n, max_samples, c->stream));
+    for (uint32_t l = 13; l < max_levels; l++) TH_HIP(launch_pyramid_up(dj, (uint32_t)n, max_samples, l, (l - 13) & 1u, c->stream));
+    return TH_OK;
+    TH_CATCH
+}
+
 TH_API int th_encode_waveform_tile_dev(th_ctx *c, const float *d_wav, size_t n_samples, uint64_t revision,
                                        uint32_t level, uint32_t tile_index, uint8_t *out, size_t cap,
                                        size_t *out_len) {

@@ -33,7 +33,8 @@ struct th_ctx {
     // Serialises use of the stream-side scratch below; recursive so composed entry points
     // (tile encoders → batched launchers) can hold it across the whole request.
     std::recursive_mutex mu;
-    th::DeviceTable img_jobs, img_start, raster_jobs, raster_start, wave_jobs, wave_start, colormap, tile_out, lod_tabs, lod_tmp;
+    th::DeviceTable img_jobs, img_start, raster_jobs, raster_start, wave_jobs, wave_start, colormap, tile_out, lod_tabs, lod_tmp,
+        pyr_jobs, pyr_sums;
     void release_scratch() {
         img_jobs.release();
         img_start.release();
@@ -45,6 +46,8 @@ struct th_ctx {
         tile_out.release();
         lod_tabs.release();
         lod_tmp.release();
+        pyr_jobs.release();
+        pyr_sums.release();
     }
 };
 

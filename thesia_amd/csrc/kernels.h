@@ -97,6 +97,24 @@ struct WaveJob {  // device-visible copy of th_wave_desc
 };
 hipError_t launch_waveform(const WaveJob *d_jobs, const uint32_t *d_block_start, uint32_t n_jobs,
                            uint32_t n_blocks, hipStream_t s);
+
+// waveform pyramid (all levels of a channel in one pass over the audio)
+constexpr uint32_t PYR_MAX_LEVELS = 40;
+struct PyrJob {
+    const float *wav;
+    float *out;          // all levels, level L at float offset level_off[L]
+    float *sums;         // scratch: 2 * sums_half floats (bin sums of the level being reduced, ping-pong)
+    uint64_t n_samples;
+    uint64_t sums_half;
+    uint64_t level_off[PYR_MAX_LEVELS];
+    uint32_t n_levels;
+    uint32_t aligned16;  // wav is 16-byte aligned: float4 loads
+};
+uint64_t pyramid_bins(uint64_t n, uint32_t level);
+uint64_t pyramid_offset(uint64_t n, uint32_t level);
+hipError_t launch_pyramid_base(const PyrJob *d_jobs, uint32_t n_jobs, uint64_t max_samples, hipStream_t s);
+hipError_t launch_pyramid_up(const PyrJob *d_jobs, uint32_t n_jobs, uint64_t max_samples, uint32_t level, uint32_t parity,
+                             hipStream_t s);
 uint32_t waveform_blocks_for(uint32_t level, uint32_t bin_count);
 
 }  // namespace th

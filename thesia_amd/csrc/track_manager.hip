@@ -511,6 +511,30 @@ TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t l
     TH_CATCH
 }
 
+// get_audio_render_metadata — lib.rs:321-340 → RenderTileCache::metadata (render_tiles.rs:101-122)
+TH_API int th_tm_get_audio_render_metadata(th_tm *tm, size_t id, uint32_t ch, double track_sec, int is_clipped,
+                                           th_render_metadata *out) {
+    TH_TRY
+    TH_REQUIRE(tm && out, "NULL argument");
+    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    auto it = tm->tracks.find(id);
+    if (it == tm->tracks.end() || ch >= it->second.ch.size()) return fail(TH_ERR_NOT_FOUND, "Track %zu does not exist", id);
+    const Channel &c = it->second.ch[ch];
+    *out = th_render_metadata{};
+    out->waveform_revision = tm->waveform_revision();
+    out->spectrogram_revision = tm->spectrogram_revision();
+    out->sample_rate = it->second.sr;
+    out->is_clipped = is_clipped ? 1u : 0u;
+    out->sample_count = c.n;
+    out->track_sec = track_sec;
+    out->spectrogram_height = c.d_img ? c.img_h : 0;  // (shape[0], shape[1]) of the u16 image, lib.rs:330-332
+    out->spectrogram_width = c.d_img ? c.img_w : 0;
+    out->waveform_tile_bins = 1024;
+    out->spectrogram_tile_size = 512;
+    return TH_OK;
+    TH_CATCH
+}
+
 TH_API int th_tm_tile_cache(th_tm *tm, th_tile_cache **out) {
     TH_TRY
     TH_REQUIRE(tm && out, "NULL argument");
