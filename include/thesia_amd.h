@@ -237,6 +237,16 @@ typedef struct {
 /* Batched waveform decimation (many tiles / levels / channels in one launch, device → device). */
 TH_API int th_waveform_tiles_dev(th_ctx *ctx, const th_wave_desc *descs, size_t n);
 
+/* Channel statistics upstream of the path: sum of squares and absolute peak per channel in one
+ * pass — simd.rs:113-183 sum_squares / abs_max as StatCalculator::calc uses them (dynamics/stats.rs:56-86:
+ * mean_squared = Σ_ch sum_squares / n_elem, max_peak = max_ch abs_max).  Results are written to HOST arrays. */
+typedef struct {
+    const float *wav; /* DEVICE */
+    uint64_t n_samples;
+} th_stats_desc;
+TH_API int th_channel_stats_dev(th_ctx *ctx, const th_stats_desc *descs, size_t n, float *out_sum_squares,
+                                float *out_abs_max);
+
 /* Waveform pyramid: every decimation level of a channel from one pass over the audio.  Level L
  * (samples per bin 2^L, exactly the bins encode_waveform_tile emits for that level — render_tiles.rs:232-279)
  * has th_waveform_pyramid_bins(n, L) = ceil(n / 2^L) bins of (min, max, mean) f32 and starts at float offset

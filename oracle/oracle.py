@@ -66,6 +66,10 @@ def lib():
                                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.orc_find_min_max.argtypes = [_f32p, C.c_size_t, _f32p, _f32p]
         L.orc_sum_avx2.restype = C.c_float
+        L.orc_sum_squares.restype = C.c_float
+        L.orc_sum_squares.argtypes = [_f32p, C.c_size_t]
+        L.orc_abs_max.restype = C.c_float
+        L.orc_abs_max.argtypes = [_f32p, C.c_size_t]
         L.orc_sum_avx2.argtypes = [_f32p, C.c_size_t, C.c_size_t]
         L.orc_scalar_mul.argtypes = [_f32p, C.c_size_t, C.c_float]
         L.orc_global_db_range.argtypes = [_f32p, _f32p, C.c_size_t, C.c_float, _f32p, _f32p]
@@ -220,6 +224,18 @@ def find_min_max(x):
 def sum_avx2(x, misalign: int = 0) -> float:
     x = _f32(x).ravel()
     return lib().orc_sum_avx2(_p(x, _f32p), x.size, misalign)
+
+
+def sum_squares(x) -> float:
+    """simd.rs:820-832 (Kahan, scalar tier)"""
+    x = _f32(x).ravel()
+    return lib().orc_sum_squares(_p(x, _f32p), x.size)
+
+
+def abs_max(x) -> float:
+    """simd.rs:935-937"""
+    x = _f32(x).ravel()
+    return lib().orc_abs_max(_p(x, _f32p), x.size)
 
 
 def scalar_mul(x, s: float) -> np.ndarray:

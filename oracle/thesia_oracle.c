@@ -546,6 +546,26 @@ ORC_API float orc_sum_avx2(const float *x, size_t n, size_t misalign) {
     return sum;
 }
 
+/* simd::sum_squares, scalar tier (simd.rs:820-832): Kahan-compensated f32 sum of x*x.  (The SIMD tiers keep
+ * per-lane compensations, :705-750; all agree to ~1 ulp of the exact sum.) */
+ORC_API float orc_sum_squares(const float *x, size_t n) {
+    volatile float sum = 0.0f, c = 0.0f; /* volatile: keep the compensation from being optimised away */
+    for (size_t i = 0; i < n; i++) {
+        volatile float y = x[i] * x[i] - c;
+        volatile float t = sum + y;
+        c = (t - sum) - y;
+        sum = t;
+    }
+    return sum;
+}
+
+/* simd::abs_max, scalar tier (simd.rs:935-937): fold(0.0, max(|x|)); f32::max ignores NaN */
+ORC_API float orc_abs_max(const float *x, size_t n) {
+    float m = 0.0f;
+    for (size_t i = 0; i < n; i++) m = rs_max(m, fabsf(x[i]));
+    return m;
+}
+
 ORC_API void orc_scalar_mul(float *x, size_t n, float s) { /* simd.rs:185-207 */
     for (size_t i = 0; i < n; i++) x[i] *= s;
 }

@@ -502,3 +502,26 @@ def test_waveform_pyramid_batch_ragged_and_partial_levels(ctx):
             assert np.abs(got[:, 2] - want[:, 2]).max() <= (0 if level <= 4 else 1e-6 * np.abs(x).max()), (n, level)
     for b in dw + do:
         b.free()
+
+
+# ---------------------------------------------------------------- channel statistics (upstream)
+def test_channel_stats_match_reference_reductions(ctx):
+    """sum_squares / abs_max (simd.rs:113-183): the reference's own test vectors (:1252-1272, :1357-1379), then
+    ragged random channels against the Kahan restatement (1 ulp-level agreement) and the exact peak."""
+    from thesia_amd import _ffi
+    cases = [[1, 2, 3, 4], [-1, -2, -3], [0, 0, 0], [1.0], [-1.0], [], [1, -2, 3, -4]]
+    rng = np.random.default_rng(7)
+    for n in [5, 4095, 4096, 4097, 300_001]:
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        x[rng.integers(0, n)] = -1.5 if n % 2 else 1.25
+        cases.append(x)
+    xs = [np.asarray(c, np.float32) for c in cases]
+    bufs = [ctx.to_device(x if x.size else np.zeros(1, np.float32)) for x in xs]
+    ss, pk = ctx.channel_stats_dev([_ffi.StatsDesc(b.ptr, x.size) for b, x in zip(bufs, xs)])
+    for x, s, p in zip(xs, ss, pk):
+        want_s, want_p = orc.sum_squares(x), orc.abs_max(x)
+        assert p == want_p, (x.size, p, want_p)
+        assert abs(s - want_s) <= 2.5e-7 * max(want_s, 1e-30), (x.size, s, want_s)
+    assert ss[0] == 30.0 and ss[1] == 14.0 and ss[5] == 0.0 and pk[5] == 0.0 and pk[6] == 4.0
+    for b in bufs:
+        b.free()

@@ -121,6 +121,22 @@ def test_sum_cases():
             assert abs(orc.sum_avx2(data, mis) - want) < 1e-5
 
 
+# simd.rs:1252-1272  test_sum_squares
+def test_sum_squares_cases():
+    for data, want in [([1, 2, 3, 4], 30.0), ([-1, -2, -3], 14.0), ([0, 0, 0], 0.0), ([1.0], 1.0), ([], 0.0)]:
+        assert abs(orc.sum_squares(data) - want) < 1e-5
+    # the compensated sum tracks float64 where a naive f32 sum drifts
+    x = np.random.default_rng(0).uniform(-1, 1, 1_000_000).astype(np.float32)
+    exact = float(np.sum(x.astype(np.float64) ** 2))
+    assert abs(orc.sum_squares(x) - exact) <= 2e-7 * exact
+
+
+# simd.rs:1357-1379  test_abs_max
+def test_abs_max_cases():
+    for data, want in [([1, -2, 3, -4], 4.0), ([-1, -2, -3], 3.0), ([0, 0, 0], 0.0), ([1.0], 1.0), ([-1.0], 1.0), ([], 0.0)]:
+        assert abs(orc.abs_max(data) - want) < 1e-5
+
+
 # simd.rs:1438-1456  test_scalar_mul
 def test_scalar_mul_cases():
     assert orc.scalar_mul([1, 2, 3, 4], 2.0).tolist() == [2, 4, 6, 8]

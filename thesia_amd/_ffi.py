@@ -60,6 +60,10 @@ OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_BUFFE
     ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 
+class StatsDesc(C.Structure):
+    _fields_ = [("wav", C.c_void_p), ("n_samples", C.c_uint64)]
+
+
 class PyramidDesc(C.Structure):
     _fields_ = [("wav", C.c_void_p), ("out", C.c_void_p), ("n_samples", C.c_uint64), ("n_levels", C.c_uint32),
                 ("reserved", C.c_uint32)]
@@ -161,6 +165,7 @@ _SIGS = {
     "th_tm_get_spectrogram_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    c_u8p, C.c_size_t, c_szp],
     "th_tm_get_waveform_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
+    "th_channel_stats_dev": [vp, C.POINTER(StatsDesc), C.c_size_t, c_f32p, c_f32p],
     "th_waveform_pyramid_bins": [C.c_uint64, C.c_uint32],
     "th_waveform_pyramid_offset": [C.c_uint64, C.c_uint32],
     "th_waveform_pyramid_dev": [vp, C.POINTER(PyramidDesc), C.c_size_t],

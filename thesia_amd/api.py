@@ -264,6 +264,14 @@ class Context:
         arr = descs if isinstance(descs, C.Array) else (WaveDesc * len(descs))(*descs)
         check(lib.th_waveform_tiles_dev(self.handle, arr, len(arr)))
 
+    # ---- channel statistics (sum_squares / abs_max, simd.rs:113-183)
+    def channel_stats_dev(self, descs):
+        """-> (sum_squares[n], abs_max[n]) float32 host arrays"""
+        arr = descs if isinstance(descs, C.Array) else (_ffi.StatsDesc * len(descs))(*descs)
+        ss, pk = np.empty(len(arr), np.float32), np.empty(len(arr), np.float32)
+        check(lib.th_channel_stats_dev(self.handle, arr, len(arr), _ptr(ss, c_f32p), _ptr(pk, c_f32p)))
+        return ss, pk
+
     # ---- waveform pyramid: all levels of a channel in one pass over the audio
     def waveform_pyramid_dev(self, descs):
         arr = descs if isinstance(descs, C.Array) else (_ffi.PyramidDesc * len(descs))(*descs)

@@ -948,6 +948,45 @@ TH_API int th_waveform_tiles_dev(th_ctx *c, const th_wave_desc *descs, size_t n)
     TH_CATCH
 }
 
+// ------------------------------------------------------------------------------------------ channel statistics
+TH_API int th_channel_stats_dev(th_ctx *c, const th_stats_desc *descs, size_t n, float *out_sum_squares,
+                                float *out_abs_max) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    if (n == 0) return TH_OK;
+    TH_REQUIRE(descs && out_sum_squares && out_abs_max, "NULL argument");
+    TH_REQUIRE(n <= 65535, "at most 65535 channels per call");
+    std::vector<StatsJob> jobs(n);
+    uint64_t max_samples = 0;
+    for (size_t i = 0; i < n; i++) {
+        TH_REQUIRE(descs[i].n_samples == 0 || descs[i].wav, "desc %zu: NULL device pointer", i);
+        TH_REQUIRE(descs[i].n_samples < (1ull << 40), "desc %zu: too many samples", i);
+        jobs[i] = StatsJob{descs[i].wav, descs[i].n_samples, (reinterpret_cast<uintptr_t>(descs[i].wav) & 15u) == 0, 0};
+        max_samples = std::max<uint64_t>(max_samples, descs[i].n_samples);
+    }
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    TH_HIP(hipSetDevice(c->device));
+    int rc = c->pyr_sums.ensure(n * (sizeof(double) + sizeof(uint32_t)));
+    if (rc != TH_OK) return rc;
+    double *d_sum = reinterpret_cast<double *>(c->pyr_sums.dptr);
+    uint32_t *d_pk = reinterpret_cast<uint32_t *>(d_sum + n);
+    TH_HIP(hipMemsetAsync(d_sum, 0, n * (sizeof(double) + sizeof(uint32_t)), c->stream));  // sum = 0, peak = +0.0 (:841,876)
+    rc = c->pyr_jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(StatsJob));
+    if (rc != TH_OK) return rc;
+    TH_HIP(launch_channel_stats((const StatsJob *)c->pyr_jobs.dptr, (uint32_t)n, max_samples, d_sum, d_pk, c->stream));
+    std::vector<double> hs(n);
+    std::vector<uint32_t> hp(n);
+    TH_HIP(hipMemcpyAsync(hs.data(), d_sum, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipMemcpyAsync(hp.data(), d_pk, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) {
+        out_sum_squares[i] = (float)hs[i];
+        std::memcpy(&out_abs_max[i], &hp[i], sizeof(float));
+    }
+    return TH_OK;
+    TH_CATCH
+}
+
 // ------------------------------------------------------------------------------------------ waveform pyramid
 TH_API size_t th_waveform_pyramid_bins(uint64_t n_samples, uint32_t level) { return (size_t)pyramid_bins(n_samples, level); }
 TH_API size_t th_waveform_pyramid_offset(uint64_t n_samples, uint32_t level) {

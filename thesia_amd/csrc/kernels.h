@@ -110,6 +110,13 @@ struct PyrJob {
     uint32_t n_levels;
     uint32_t aligned16;  // wav is 16-byte aligned: float4 loads
 };
+struct StatsJob {
+    const float *wav;
+    uint64_t n_samples;
+    uint32_t aligned16, pad_;
+};
+hipError_t launch_channel_stats(const StatsJob *d_jobs, uint32_t n_jobs, uint64_t max_samples, double *d_sumsq,
+                                uint32_t *d_peak_bits, hipStream_t s);
 uint64_t pyramid_bins(uint64_t n, uint32_t level);
 uint64_t pyramid_offset(uint64_t n, uint32_t level);
 hipError_t launch_pyramid_base(const PyrJob *d_jobs, uint32_t n_jobs, uint64_t max_samples, hipStream_t s);

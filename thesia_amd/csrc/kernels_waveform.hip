@@ -349,4 +349,65 @@ hipError_t launch_pyramid_up(const PyrJob *d_jobs, uint32_t n_jobs, uint64_t max
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Channel statistics upstream of the path: sum of squares and absolute peak of a channel in one pass
+// (reference: simd.rs:113-183 — sum_squares (Kahan-compensated f32, :820-832) and abs_max (:935-937), used by
+// StatCalculator::calc, dynamics/stats.rs:56-86, for rms_dB and max_peak).  The sum is accumulated in f64
+// (per-thread, wave shuffle tree, one f64 atomic per block) and rounded to f32 once: within 1 ulp of what the
+// reference's compensated sums deliver, whatever their SIMD tier; the peak is exact (max of |x|).
+// Pure HBM streaming: 4 B read per sample.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_stats_kernel(const StatsJob *__restrict__ jobs, double *__restrict__ sumsq,
+                                                            uint32_t *__restrict__ peak_bits) {
+    __shared__ double wsum[4];
+    __shared__ float wmax[4];
+    const StatsJob job = jobs[blockIdx.y];
+    const uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if ((uint64_t)blockIdx.x * 4096 >= job.n_samples) return;
+    const gptr<const float> wav = as_global(job.wav);
+    double acc = 0.0;
+    float pk = 0.0f;
+    if (base + 16 <= job.n_samples && job.aligned16) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const float4 t = *reinterpret_cast<gptr<const float4>>(wav + base + 4 * q);
+            acc += (double)t.x * (double)t.x + (double)t.y * (double)t.y + ((double)t.z * (double)t.z + (double)t.w * (double)t.w);
+            pk = fmaxf(fmaxf(pk, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
+        }
+    } else {
+        for (uint32_t i = 0; i < 16; i++) {
+            if (base + i < job.n_samples) {
+                const float v = wav[base + i];
+                acc += (double)v * (double)v;
+                pk = fmaxf(pk, fabsf(v));  // f32::max ignores NaN (abs_max_scalar, :935-937)
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o, 64);
+        pk = fmaxf(pk, __shfl_xor(pk, o, 64));
+    }
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        wsum[wv] = acc;
+        wmax[wv] = pk;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sumsq[blockIdx.y], (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+        // |x| >= 0: the IEEE bit patterns of non-negative floats order like unsigned integers
+        atomicMax(&peak_bits[blockIdx.y], __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+    }
+}
+
+hipError_t launch_channel_stats(const StatsJob *d_jobs, uint32_t n_jobs, uint64_t max_samples, double *d_sumsq,
+                                uint32_t *d_peak_bits, hipStream_t s) {
+    const uint64_t blocks = (max_samples + 4095) / 4096;
+    if (!n_jobs || !blocks) return hipSuccess;
+    hipLaunchKernelGGL(channel_stats_kernel, dim3((uint32_t)blocks, n_jobs), dim3(256), 0, s, d_jobs, d_sumsq, d_peak_bits);
+    return hipGetLastError();
+}
+
 }  // namespace th
