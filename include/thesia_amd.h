@@ -146,8 +146,14 @@ TH_API int th_plan_destroy(th_plan *plan);
 /* n_freq = n_fft/2+1; height = n_freq (linear) or n_mel (mel) = columns of the spec */
 TH_API int th_plan_dims(const th_plan *plan, size_t *n_freq, size_t *height);
 /* kernel selection: 0 = auto, 1 = force the generic workgroup kernel, 2 = force the wave kernel;
- * tuning: (waves << 8) | 2 runs the wave kernel with 4, 8, 12 or 16 waves per workgroup */
+ * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
+ * frames per queue pull */
 TH_API int th_plan_set_kernel(th_plan *plan, int which);
+/* Measurement hook: with enable != 0 every th_calc_spec_batch_dev records two HIP events on the context's stream
+ * around its dominant kernel launch (the wave kernel, or the generic one when that is all there is);
+ * th_plan_last_kernel_ms waits for the last such launch and returns its duration. */
+TH_API int th_plan_time_kernel(th_plan *plan, int enable);
+TH_API int th_plan_last_kernel_ms(th_plan *plan, float *ms);
 /* name of the kernel th_calc_spec_batch_dev will launch for this plan (for profiles / tests) */
 TH_API const char *th_plan_kernel_name(const th_plan *plan);
 

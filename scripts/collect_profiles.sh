@@ -1,0 +1,29 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): collects every measurement that profiles/ and the docs quote into gpurun_out/final/.
+# usage: scripts/collect_profiles.sh        then locally: python scripts/make_profiles.py gpurun_out/final r01
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/final
+rm -rf "$out"; mkdir -p "$out"
+python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-single-track > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
+scripts/pmc_stft.sh "$out/pmc_stft" > "$out/pmc_stft.log" 2>&1
+TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pmc_img.log" 2>&1
+{
+  python3 scripts/bench_stft.py --reps 30 --kernel 0 1
+  python3 scripts/bench_stft.py --reps 30 --nfft 1024
+  python3 scripts/bench_stft.py --reps 30 --nfft 4096
+  python3 scripts/bench_stft.py --reps 30 --win 1920 --hop 480
+  python3 scripts/bench_stft.py --reps 30 --hop 1024
+  python3 scripts/bench_stft.py --reps 30 --kernel $((2+(8<<8)+(32<<16))) $((2+(12<<8)+(32<<16))) $((2+(16<<8)+(32<<16)))
+} > "$out/bench_stft.txt" 2>&1
+python3 scripts/bench_img.py > "$out/bench_img.txt" 2>&1
+python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
+python3 scripts/bench_cfg4.py > "$out/bench_cfg4.txt" 2>&1
+for u in lds_rate valu_rate valu_bank copy_rate; do
+  [ -x scripts/ubench/$u ] && timeout 120 scripts/ubench/$u > "$out/ubench_$u.txt" 2>&1
+done
+if [ -f thesia_amd/libthesia_amd_prof.so ]; then
+  THESIA_AMD_LIB=thesia_amd/libthesia_amd_prof.so python3 scripts/phase_prof.py > "$out/phase_prof.txt" 2>&1
+fi
+ls -la "$out"

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Turn the raw output of scripts/collect_profiles.sh (gpurun_out/final) into the tracked summaries under profiles/.
+usage: python scripts/make_profiles.py gpurun_out/final r01"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def last_json_line(path):
+    for line in reversed(open(path).read().splitlines()):
+        line = line.strip()
+        if line.startswith("{"):
+            return json.loads(line)
+    raise SystemExit(f"no JSON line in {path}")
+
+
+# 1. bench lines
+json.dump(last_json_line(f"{src}/bench.json"), open(f"{dst}/{tag}_bench_line.json", "w"), indent=1)
+json.dump(last_json_line(f"{src}/bench_under_rocprof.json"), open(f"{dst}/{tag}_bench_line_under_rocprof.json", "w"), indent=1)
+
+# 2. kernel stats of the bench run (library kernels only)
+rows = []
+for f in glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True):
+    rows += [r for r in csv.DictReader(open(f)) if r["Name"].startswith(("th::", "void th::"))]
+with open(f"{dst}/{tag}_bench_kernel_stats.csv", "w") as fo:
+    fo.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 "
+             "--no-cpu-baseline --no-single-track\n# MI355X.  Library kernels only (torch kernels of the synthetic-signal "
+             "generator omitted); durations in ns.\n")
+    if rows:
+        cols = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"]
+        fo.write(",".join(cols) + "\n")
+        for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+            fo.write(",".join('"' + r[c] + '"' if "," in r[c] else r[c] for c in cols) + "\n")
+
+# 3. PMC summaries
+hdr = ("# rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python3 {script} --reps 3   (scripts/pmc_stft.sh)\n"
+       "# per-dispatch medians over the launches of each kernel; SQ_* in quad-cycles summed over waves, FETCH_SIZE/WRITE_SIZE in KB.\n"
+       "# gfx950: FETCH_SIZE reports exactly 1/2 of streamed bytes for 4/8/16-byte-per-lane reads "
+       "(profiles/r01_fetch_calibration.txt); WRITE_SIZE is exact.\n")
+for name, script in (("stft", "scripts/bench_stft.py"), ("img", "scripts/bench_img.py")):
+    p = f"{src}/pmc_{name}/summary.txt"
+    if os.path.exists(p):
+        open(f"{dst}/{tag}_{name}_pmc_summary.txt", "w").write(hdr.format(script=script) + open(p).read())
+
+# 4. HBM traffic of the dominant kernel (bench.py reads this file)
+p = f"{src}/pmc_stft/summary.txt"
+if os.path.exists(p):
+    kern, vals = None, {}
+    for line in open(p):
+        if not line.startswith(" "):
+            kern = line.strip()
+            continue
+        if kern and "stft_wave_kernel" in kern:
+            c, rest = line.split(None, 1)
+            if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[c] = float(rest.split("median=")[1].split()[0])
+                vals["kernel"] = kern
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        frames, bpf = 128 * 2813, 6148
+        json.dump({"kernel": vals["kernel"].replace("void th::", ""),
+                   "bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+                   "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+                   "correction": "gfx950 FETCH_SIZE x2 (calibrated, profiles/r01_fetch_calibration.txt); WRITE_SIZE exact",
+                   "workload": "128 tracks x 30 s 48 kHz mono, n_fft=2048 hop=512 (scripts/bench_stft.py, same shapes as bench.py)",
+                   "algorithmic_bytes_per_launch": frames * bpf, "source": f"profiles/{tag}_stft_pmc_summary.txt"},
+                  open(f"{dst}/stft_hbm_traffic.json", "w"), indent=1)
+
+# 5. plain-text measurement logs
+for f in ("bench_stft.txt", "bench_img.txt", "bench_cfg3.txt", "bench_cfg4.txt", "phase_prof.txt", "ubench_lds_rate.txt",
+          "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt"):
+    if os.path.exists(f"{src}/{f}"):
+        txt = "\n".join(l for l in open(f"{src}/{f}").read().splitlines() if "amdgpu.ids" not in l) + "\n"
+        open(f"{dst}/{tag}_{f}", "w").write(txt)
+print("\n".join(sorted(os.listdir(dst))))

@@ -165,6 +165,8 @@ _SIGS = {
     "th_tm_get_spectrogram_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    c_u8p, C.c_size_t, c_szp],
     "th_tm_get_waveform_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
+    "th_plan_time_kernel": [vp, C.c_int],
+    "th_plan_last_kernel_ms": [vp, C.POINTER(C.c_float)],
     "th_channel_stats_dev": [vp, C.POINTER(StatsDesc), C.c_size_t, c_f32p, c_f32p],
     "th_waveform_pyramid_bins": [C.c_uint64, C.c_uint32],
     "th_waveform_pyramid_offset": [C.c_uint64, C.c_uint32],

@@ -312,6 +312,15 @@ class Plan:
             check(lib.th_plan_destroy(self.handle))
             self.handle = None
 
+    def time_kernel(self, enable: bool = True):
+        """record HIP events around the dominant kernel of every calc_spec_batch_dev (measurement hook)"""
+        check(lib.th_plan_time_kernel(self.handle, int(enable)))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        check(lib.th_plan_last_kernel_ms(self.handle, C.byref(ms)))
+        return ms.value
+
     def set_kernel(self, which: int):
         check(lib.th_plan_set_kernel(self.handle, which))
 

@@ -308,6 +308,8 @@ bool th_plan::use_mel_mfma() const { return g.n_mel != 0 && use_wave(); }
 
 static void plan_free(th_plan *p) {
     if (!p) return;
+    if (p->ev_k0) (void)hipEventDestroy(p->ev_k0);
+    if (p->ev_k1) (void)hipEventDestroy(p->ev_k1);
     if (p->d_wtab) (void)hipFree(p->d_wtab);
     if (p->d_queue_head) (void)hipFree(p->d_queue_head);
     if (p->d_fb_pad) (void)hipFree(p->d_fb_pad);
@@ -607,10 +609,14 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     }
     if (rc != TH_OK) return rc;
     TH_HIP(launch_minmax_init(d_minmax, (uint32_t)n_chan, wave ? p->d_queue_head : nullptr, c->stream));
+    // optional timing of the dominant kernel alone (th_plan_time_kernel): two events on the launch stream
+    const bool timed = p->time_kernel && p->ev_k0 && p->ev_k1;
+    if (timed) TH_HIP(hipEventRecord(p->ev_k0, c->stream));
     if (wave) {
         TH_HIP(launch_stft_wave(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                 (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, d_minmax, p->d_queue_head,
                                 c->n_cu, waves, mel_mfma, c->stream));
+        if (timed) TH_HIP(hipEventRecord(p->ev_k1, c->stream));
         if (mel_mfma)
             TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
                                    (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, p->mel_kblocks, amp_pitch, p->d_fb_pad,
@@ -623,7 +629,35 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
         TH_HIP(launch_stft_generic(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                    (uint32_t)jobs.size(), (uint32_t)tiles, p->d_window, p->d_tw, p->d_mel_fb,
                                    p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream));
+        if (timed) TH_HIP(hipEventRecord(p->ev_k1, c->stream));
     }
+    if (timed) p->kernel_timed = true;
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_plan_time_kernel(th_plan *p, int enable) {
+    TH_TRY
+    TH_REQUIRE(p, "plan is NULL");
+    std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
+    TH_HIP(hipSetDevice(p->ctx->device));
+    if (enable && !p->ev_k0) {
+        TH_HIP(hipEventCreate(&p->ev_k0));
+        TH_HIP(hipEventCreate(&p->ev_k1));
+    }
+    p->time_kernel = enable != 0;
+    p->kernel_timed = false;
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_plan_last_kernel_ms(th_plan *p, float *ms) {
+    TH_TRY
+    TH_REQUIRE(p && ms, "NULL argument");
+    std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
+    TH_REQUIRE(p->time_kernel && p->kernel_timed, "no timed launch: call th_plan_time_kernel(plan, 1) and th_calc_spec_batch_dev first");
+    TH_HIP(hipEventSynchronize(p->ev_k1));
+    TH_HIP(hipEventElapsedTime(ms, p->ev_k0, p->ev_k1));
     return TH_OK;
     TH_CATCH
 }

@@ -58,6 +58,8 @@ struct th_plan {
     int kernel_choice = 0;  // 0 auto, 1 generic, 2 wave
     int wave_waves = 0;     // tuning: waves per workgroup of the wave kernel (0 = default)
     int wave_chunk = 0;     // tuning: frames per chunk of the wave kernel (0 = default)
+    bool time_kernel = false, kernel_timed = false;  // th_plan_time_kernel: events around the STFT kernel launch
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     th::StftGeom g{};
     float *d_window = nullptr;
     th::cf32 *d_tw = nullptr;

@@ -36,6 +36,17 @@ TH_HD cf32 lds_ld(const cf32 *p) {
 #endif
 }
 
+// 8-byte LDS write that may not be fused with a neighbour (experiment switch TH_LDS_UNPAIRED_WRITES: hipcc pairs
+// adjacent stores into ds_write2_b64, 13 cycles per wave-instruction against 2 x 6 for two ds_write_b64)
+TH_HD void lds_st(cf32 *p, cf32 v) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TH_LDS_UNPAIRED_WRITES)
+    const uint64_t u = (uint64_t)__builtin_bit_cast(uint32_t, v.re) | ((uint64_t)__builtin_bit_cast(uint32_t, v.im) << 32);
+    *(volatile __attribute__((address_space(3))) uint64_t *)(p) = u;
+#else
+    *p = v;
+#endif
+}
+
 // full unrolling is required everywhere below: register arrays must never be indexed dynamically
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TH_UNROLL _Pragma("unroll")
@@ -136,15 +147,18 @@ struct WaveFftCfg<11> {  // n_fft = 4096: Nc = 2048 = 16 * 16 * 8, P = 32
 };
 
 // LDS layout of the first exchange (pass-1 output, Ns = 1): lane jj writes the R1 consecutive
-// slots R1*jj + r.  One pad slot per 32 (pad1(i) = i + i/32) makes both sides of the transpose
+// slots R1*jj + r.  Two pad slots per 32 (pad1(i) = i + 2*(i/32)) make both sides of the transpose
 // conflict-free at the cheapest rate the LDS has (scripts/ubench/lds_rate.hip):
-//   writes: the 32 lanes of a half wave start at dword 2*R1*jj + 2*(R1*jj/32), i.e. on 32 distinct bank pairs;
+//   writes: hipcc pairs the stores of r, r+1 into ds_write2_b64 (16 B per lane, 16 lanes per LDS pass): lane jj
+//          starts at dword 2*R1*jj + 4*(R1*jj/32), so the 16 lanes of a pass cover all 64 banks exactly once
+//          (one pad slot per 32 is enough for 8-byte writes but gives two-way conflicts on the 16-byte pairs:
+//          SQ_LDS_BANK_CONFLICT = 64 cycles per frame);
 //   reads (pass 2, i = lane + 64*m): a half wave reads 32 CONSECUTIVE slots = all 64 banks once, 2.2 cycles
 //          per wave-instruction.  (A pad per R1 slots made a half wave span 33+ slots: 4 cycles.)
 // Unlike an XOR swizzle every address is "per-lane base + compile-time immediate": writes
 // base = pad1(R1*jj), imm = r (R1 divides 32, so R1*jj + r stays inside the 32-group); reads
-// base = pad1(lane), imm = 66*m.  No address registers stay live across the frame loop.
-TH_HD uint32_t pad1(uint32_t i) { return i + (i >> 5); }
+// base = pad1(lane), imm = 68*m.  No address registers stay live across the frame loop.
+TH_HD uint32_t pad1(uint32_t i) { return i + ((i >> 5) << 1); }
 
 template <int LOG2_NC>
 struct WaveFft {
@@ -180,11 +194,11 @@ struct WaveFft {
             TH_UNROLL for (int r = 0; r < R1; r++) v[r] = z[b + B1 * r];
             RegDft<R1>::run(v);
             const uint32_t jj = lane + 64u * b;
-            TH_UNROLL for (int r = 0; r < R1; r++) slab[pad1(jj * R1) + r] = v[RegDft<R1>::slot(r)];  // = pad1(jj*R1 + r)
+            TH_UNROLL for (int r = 0; r < R1; r++) lds_st(&slab[pad1(jj * R1) + r], v[RegDft<R1>::slot(r)]);  // = pad1(jj*R1 + r)
         }
     }
     static TH_HD void read1(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
-        TH_UNROLL for (int m = 0; m < P; m++) z[m] = lds_ld(&slab[pad1(lane) + 66u * m]);  // = pad1(lane + 64*m)
+        TH_UNROLL for (int m = 0; m < P; m++) z[m] = lds_ld(&slab[pad1(lane) + 68u * m]);  // = pad1(lane + 64*m)
     }
 
     // pass 2 (Ns = R1): registers -> LDS slab (linear).  In three pieces so that the kernel can issue the
@@ -205,7 +219,7 @@ struct WaveFft {
             TH_UNROLL for (int r = 0; r < R2; r++) v[r] = z[b + B2 * r];
             RegDft<R2>::run(v);
             const uint32_t j0 = (jj - k) * R2 + k;
-            TH_UNROLL for (int r = 0; r < R2; r++) slab[j0 + r * NS2] = v[RegDft<R2>::slot(r)];
+            TH_UNROLL for (int r = 0; r < R2; r++) lds_st(&slab[j0 + r * NS2], v[RegDft<R2>::slot(r)]);
         }
     }
     static TH_HD void pass2(uint32_t lane, cf32 (&z)[P], const cf32 *t2, cf32 *slab) {
@@ -234,7 +248,7 @@ struct WaveFft {
     // wrap-around), then every lane fetches the partner Z[Nc - k] of each own k = lane + 64*m:
     // index (Nc - lane - 64*(P-1)) + 64*(P-1-m) = per-lane base + immediate.
     static_assert(32 % R1 == 0, "pad1 needs R1 | 32");
-    static constexpr int SLAB_LEN = NC + NC / 32;  // padded pass-1 image is the largest (>= NC + 1)
+    static constexpr int SLAB_LEN = NC + NC / 16;  // padded pass-1 image is the largest (>= NC + 1)
     static TH_HD void write_z(uint32_t lane, const cf32 (&z)[P], cf32 *slab) {
         TH_UNROLL for (int m = 0; m < P; m++) slab[lane + 64u * m] = z[m];
         if (lane == 0) slab[NC] = z[0];
