@@ -1,5 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): collects every measurement that profiles/ and the docs quote into gpurun_out/final/.
+# (build the instrumented variant first if the phase profile is wanted: scripts/build_variant.sh prof -DTH_PHASE_PROF)
 # usage: scripts/collect_profiles.sh        then locally: python scripts/make_profiles.py gpurun_out/final r01
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -27,9 +27,12 @@ json.dump(last_json_line(f"{src}/bench.json"), open(f"{dst}/{tag}_bench_line.jso
 json.dump(last_json_line(f"{src}/bench_under_rocprof.json"), open(f"{dst}/{tag}_bench_line_under_rocprof.json", "w"), indent=1)
 
 # 2. kernel stats of the bench run (library kernels only)
-rows = []
-for f in glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True):
-    rows += [r for r in csv.DictReader(open(f)) if r["Name"].startswith(("th::", "void th::"))]
+rows, seen = [], set()
+for f in sorted(glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime, reverse=True)[:1]:  # newest run only
+    for r in csv.DictReader(open(f)):
+        if r["Name"].startswith(("th::", "void th::")) and r["Name"] not in seen:
+            seen.add(r["Name"])
+            rows.append(r)
 with open(f"{dst}/{tag}_bench_kernel_stats.csv", "w") as fo:
     fo.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 "
              "--no-cpu-baseline --no-single-track\n# MI355X.  Library kernels only (torch kernels of the synthetic-signal "
