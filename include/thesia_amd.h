@@ -149,10 +149,21 @@ TH_API int th_plan_dims(const th_plan *plan, size_t *n_freq, size_t *height);
  * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
  * frames per queue pull */
 TH_API int th_plan_set_kernel(th_plan *plan, int which);
+/* find_min_max over every resident spec (core/mod.rs:169-178) without leaving the device: reduces the n_chan
+ * (min, max) pairs a th_calc_spec_batch_dev left in d_minmax to d_out = [min, -max] (2 floats, DEVICE), the form
+ * in which ONE element-wise MIN all-reduce merges the ranks of a multi-GPU job.  n_chan = 0 gives [+inf, +inf]. */
+TH_API int th_minmax_reduce_dev(th_ctx *ctx, const float *d_minmax, size_t n_chan, float *d_out);
+/* update_spec_imgs' range clamp (core/mod.rs:179-180) on the device: d_min_negmax = [min, -max] (DEVICE, as
+ * th_minmax_reduce_dev and a MIN all-reduce leave it) -> d_range = [min_dB, max_dB] (DEVICE) with
+ * max_dB = min(max, 0), min_dB = max(min, max_dB - dB_range). */
+TH_API int th_global_db_range_dev(th_ctx *ctx, const float *d_min_negmax, float dB_range, float *d_range);
 /* Measurement hook: with enable != 0 every th_calc_spec_batch_dev records two HIP events on the context's stream
  * around its dominant kernel launch (the wave kernel, or the generic one when that is all there is);
- * th_plan_last_kernel_ms waits for the last such launch and returns its duration. */
+ * recording does not synchronise.  th_plan_kernel_ms_history returns the durations of the most recent launches
+ * (oldest first, at most 64 are kept; it waits for them), th_plan_last_kernel_ms the latest one.
+ * th_plan_time_kernel also resets the history. */
 TH_API int th_plan_time_kernel(th_plan *plan, int enable);
+TH_API int th_plan_kernel_ms_history(th_plan *plan, float *out_ms, size_t capacity, size_t *n_out);
 TH_API int th_plan_last_kernel_ms(th_plan *plan, float *ms);
 /* name of the kernel th_calc_spec_batch_dev will launch for this plan (for profiles / tests) */
 TH_API const char *th_plan_kernel_name(const th_plan *plan);
@@ -201,6 +212,10 @@ typedef struct {
 /* batched form: one launch for many channels sharing (min_dB, max_dB, colormap_len) — core/mod.rs:204-227 */
 TH_API int th_spec_to_img_batch_dev(th_ctx *ctx, const th_img_desc *descs, size_t n, float min_dB, float max_dB,
                                     uint32_t colormap_len);
+/* same with the range left on the device by th_global_db_range_dev (no host round trip between the STFT stage
+ * and the quantiser); an all -inf range zero-fills the images as drawing.rs:16-18 */
+TH_API int th_spec_to_img_batch_dev_ranged(th_ctx *ctx, const th_img_desc *descs, size_t n, const float *d_range,
+                                           uint32_t colormap_len);
 
 /* ---------------------------------------------------------------- tiles */
 /* encode_spectrogram_tile — render_tiles.rs:281-352.  d_img: img_height x img_width u16 (DEVICE).

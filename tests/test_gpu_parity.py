@@ -525,3 +525,52 @@ def test_channel_stats_match_reference_reductions(ctx):
     assert ss[0] == 30.0 and ss[1] == 14.0 and ss[5] == 0.0 and pk[5] == 0.0 and pk[6] == 4.0
     for b in bufs:
         b.free()
+
+
+def test_minmax_reduce_dev(ctx):
+    """th_minmax_reduce_dev == find_min_max over all specs (core/mod.rs:169-178) in the [min, -max] all-reduce form"""
+    rng = np.random.default_rng(3)
+    for n in [1, 2, 63, 257, 1000]:
+        mm = rng.uniform(-120, 5, (n, 2)).astype(np.float32)
+        mm[rng.integers(0, n), 0] = -np.inf
+        d, o = ctx.to_device(mm), ctx.alloc(8)
+        ctx.minmax_reduce_dev(d.ptr, n, o.ptr)
+        got = o.download((2,), np.float32)
+        assert got[0] == mm[:, 0].min() and got[1] == -mm[:, 1].max()
+        d.free(); o.free()
+    o = ctx.alloc(8)
+    ctx.minmax_reduce_dev(0, 0, o.ptr)
+    assert o.download((2,), np.float32).tolist() == [np.inf, np.inf]
+    o.free()
+
+
+def test_device_resident_db_range_path(ctx):
+    """th_minmax_reduce_dev -> th_global_db_range_dev -> th_spec_to_img_batch_dev_ranged gives bit for bit the images
+    of the host-range path (core/mod.rs:169-180, drawing.rs:4-33), including the all -inf case (zero image)."""
+    from thesia_amd import _ffi
+    rng = np.random.default_rng(11)
+    T, H = 300, 97
+    for case in ("normal", "wide", "silent"):
+        spec = rng.uniform(-140, 3, (T, H)).astype(np.float32)
+        if case == "wide":
+            spec[5, 7] = 40.0
+        if case == "silent":
+            spec[:] = -np.inf
+        mm = np.array([[spec.min(), spec.max()]], np.float32)
+        lo, hi = orc.global_db_range([mm[0, 0]], [mm[0, 1]], 100.0)
+        d_spec, d_mm = ctx.to_device(spec), ctx.to_device(mm)
+        d_r2, d_rng = ctx.alloc(8), ctx.alloc(8)
+        ctx.minmax_reduce_dev(d_mm.ptr, 1, d_r2.ptr)
+        ctx.global_db_range_dev(d_r2.ptr, 100.0, d_rng.ptr)
+        got_rng = d_rng.download((2,), np.float32)
+        assert (got_rng[0], got_rng[1]) == (np.float32(lo), np.float32(hi)), (case, got_rng, lo, hi)
+        pitch = ta.pitch_u16(T)
+        d_img = ctx.alloc(H * pitch * 2)
+        ctx.spec_to_img_batch_ranged([_ffi.ImgDesc(d_spec.ptr, d_img.ptr, T, H, 0, H, 0, pitch)], d_rng.ptr, 258)
+        img = d_img.download((H, pitch), np.uint16)[:, :T]
+        want = orc.convert_spectrogram_to_img(spec, (0, H), (lo, hi), 258)
+        assert np.array_equal(img, want), case
+        if case == "silent":
+            assert not img.any()
+        for b in (d_spec, d_mm, d_r2, d_rng, d_img):
+            b.free()

@@ -165,8 +165,12 @@ _SIGS = {
     "th_tm_get_spectrogram_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    c_u8p, C.c_size_t, c_szp],
     "th_tm_get_waveform_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
+    "th_minmax_reduce_dev": [vp, C.c_void_p, C.c_size_t, C.c_void_p],
+    "th_global_db_range_dev": [vp, C.c_void_p, C.c_float, C.c_void_p],
+    "th_spec_to_img_batch_dev_ranged": [vp, C.POINTER(ImgDesc), C.c_size_t, C.c_void_p, C.c_uint32],
     "th_plan_time_kernel": [vp, C.c_int],
     "th_plan_last_kernel_ms": [vp, C.POINTER(C.c_float)],
+    "th_plan_kernel_ms_history": [vp, c_f32p, C.c_size_t, c_szp],
     "th_channel_stats_dev": [vp, C.POINTER(StatsDesc), C.c_size_t, c_f32p, c_f32p],
     "th_waveform_pyramid_bins": [C.c_uint64, C.c_uint32],
     "th_waveform_pyramid_offset": [C.c_uint64, C.c_uint32],

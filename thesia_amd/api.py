@@ -264,6 +264,18 @@ class Context:
         arr = descs if isinstance(descs, C.Array) else (WaveDesc * len(descs))(*descs)
         check(lib.th_waveform_tiles_dev(self.handle, arr, len(arr)))
 
+    def minmax_reduce_dev(self, d_minmax: int, n_chan: int, d_out: int):
+        """[min, -max] over n_chan per-channel (min, max) pairs, device to device (core/mod.rs:169-178)"""
+        check(lib.th_minmax_reduce_dev(self.handle, d_minmax, n_chan, d_out))
+
+    def global_db_range_dev(self, d_min_negmax: int, dB_range: float, d_range: int):
+        """[min, -max] -> [min_dB, max_dB] on the device (core/mod.rs:179-180)"""
+        check(lib.th_global_db_range_dev(self.handle, d_min_negmax, dB_range, d_range))
+
+    def spec_to_img_batch_ranged(self, descs, d_range: int, colormap_len: int):
+        arr = descs if isinstance(descs, C.Array) else (ImgDesc * len(descs))(*descs)
+        check(lib.th_spec_to_img_batch_dev_ranged(self.handle, arr, len(arr), d_range, colormap_len))
+
     # ---- channel statistics (sum_squares / abs_max, simd.rs:113-183)
     def channel_stats_dev(self, descs):
         """-> (sum_squares[n], abs_max[n]) float32 host arrays"""
@@ -315,6 +327,12 @@ class Plan:
     def time_kernel(self, enable: bool = True):
         """record HIP events around the dominant kernel of every calc_spec_batch_dev (measurement hook)"""
         check(lib.th_plan_time_kernel(self.handle, int(enable)))
+
+    def kernel_ms_history(self) -> np.ndarray:
+        """durations (ms) of the most recent timed launches, oldest first (at most 64)"""
+        out, n = np.empty(64, np.float32), C.c_size_t()
+        check(lib.th_plan_kernel_ms_history(self.handle, _ptr(out, c_f32p), out.size, C.byref(n)))
+        return out[: n.value].copy()
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

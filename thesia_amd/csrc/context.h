@@ -35,7 +35,12 @@ struct th_ctx {
     std::recursive_mutex mu;
     th::DeviceTable img_jobs, img_start, raster_jobs, raster_start, wave_jobs, wave_start, colormap, tile_out, lod_tabs, lod_tmp,
         pyr_jobs, pyr_sums;
+    // the descriptor batches the img / raster tables were built from (identical batch -> tables reused as they are)
+    std::vector<unsigned char> img_descs_key, raster_descs_key;
+    uint32_t img_tiles_key = 0, raster_blocks_key = 0;
     void release_scratch() {
+        img_descs_key.clear();
+        raster_descs_key.clear();
         img_jobs.release();
         img_start.release();
         raster_jobs.release();
@@ -58,8 +63,11 @@ struct th_plan {
     int kernel_choice = 0;  // 0 auto, 1 generic, 2 wave
     int wave_waves = 0;     // tuning: waves per workgroup of the wave kernel (0 = default)
     int wave_chunk = 0;     // tuning: frames per chunk of the wave kernel (0 = default)
-    bool time_kernel = false, kernel_timed = false;  // th_plan_time_kernel: events around the STFT kernel launch
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+    // th_plan_time_kernel: a ring of event pairs around the STFT kernel launch (no synchronisation while recording)
+    static constexpr size_t TIMER_SLOTS = 64;
+    bool time_kernel = false;
+    uint64_t timed_launches = 0;
+    std::vector<hipEvent_t> ev_k0, ev_k1;
     th::StftGeom g{};
     float *d_window = nullptr;
     th::cf32 *d_tw = nullptr;

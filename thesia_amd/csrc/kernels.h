@@ -13,6 +13,7 @@ namespace th {
 
 // ---- kernels_stft.hip
 hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queue_head, hipStream_t s);
+hipError_t launch_minmax_reduce(const float *d_minmax, uint32_t n_chan, float *d_out, hipStream_t s);
 size_t stft_generic_lds_bytes(const StftGeom &g);
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                uint32_t n_chan, uint32_t n_tiles, const float *d_window, const cf32 *d_tw,
@@ -47,7 +48,9 @@ struct ImgJob {  // device-visible copy of th_img_desc
     uint32_t first_tile, n_tiles;    // this job's block range in the launch
 };
 hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_job, uint32_t n_jobs,
-                              uint32_t n_tiles, float min_dB, float max_dB, uint32_t colormap_len, hipStream_t s);
+                              uint32_t n_tiles, float min_dB, float max_dB, uint32_t colormap_len, const float *d_range,
+                              hipStream_t s);
+hipError_t launch_db_range(const float *d_in, float dB_range, float *d_out, hipStream_t s);
 
 struct RasterJob {  // device-visible copy of th_raster_desc (+ derived fields)
     const uint16_t *img;

@@ -43,8 +43,15 @@ constexpr uint32_t IMG_LDS_PITCH = IMG_TILE_T + 2;
 __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restrict__ jobs,
                                                           const uint32_t *__restrict__ tile_job, uint32_t n_jobs,
                                                           float min_dB, float span, float u16_span,
-                                                          float min_value) {
+                                                          float min_value, const float *__restrict__ d_range) {
     __shared__ __attribute__((aligned(4))) uint16_t tile[IMG_TILE_F][IMG_LDS_PITCH];  // [freq][frame]
+    bool all_zero = false;
+    if (d_range != nullptr) {  // (min_dB, max_dB) left on the device by th_global_db_range_dev
+        const float lo = d_range[0], hi = d_range[1];
+        min_dB = lo;
+        span = hi - lo;
+        all_zero = lo == hi && __builtin_isinf(hi) && hi < 0.0f;  // every value -inf: zero image (drawing.rs:16-18)
+    }
     const ImgJob job = jobs[tile_job[blockIdx.x]];
     const gptr<const float> spec = as_global(job.spec);
     const gptr<uint16_t> img = as_global(job.img);
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     }
 #pragma unroll
     for (uint32_t i = 0; i < IMG_TILE_T / 4; i++)
-        tile[lane][wv + 4 * i] = (uint16_t)quantise(v[i], min_dB, span, u16_span, min_value);  // NaN -> 0
+        tile[lane][wv + 4 * i] = all_zero ? (uint16_t)0 : (uint16_t)quantise(v[i], min_dB, span, u16_span, min_value);  // NaN -> 0
     __syncthreads();
     // write: lanes along time (contiguous in the image), two samples per lane
     const uint32_t t = t0 + 2 * lane;
@@ -97,8 +104,23 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     }
 }
 
+// update_spec_imgs' range clamp (core/mod.rs:179-180) on the device: in = [min, -max] as th_minmax_reduce_dev (and a
+// MIN all-reduce across ranks) leaves it, out = [min_dB, max_dB].
+__global__ void db_range_kernel(const float *__restrict__ in, float dB_range, float *__restrict__ out) {
+    float mx = -in[1];
+    mx = fminf(mx, 0.0f);
+    const float mn = fmaxf(in[0], mx - dB_range);
+    out[0] = mn;
+    out[1] = mx;
+}
+hipError_t launch_db_range(const float *d_in, float dB_range, float *d_out, hipStream_t s) {
+    hipLaunchKernelGGL(db_range_kernel, dim3(1), dim3(1), 0, s, d_in, dB_range, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_job, uint32_t n_jobs,
-                              uint32_t n_tiles, float min_dB, float max_dB, uint32_t colormap_len, hipStream_t s) {
+                              uint32_t n_tiles, float min_dB, float max_dB, uint32_t colormap_len, const float *d_range,
+                              hipStream_t s) {
     if (!n_tiles) return hipSuccess;
     // drawing.rs:20-22 — min_value = max(round(65535 / C), 1) in f64; u16_span = (65535 - min_value) as f32
     uint32_t min_value = 1;
@@ -109,7 +131,7 @@ hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_job, 
     }
     const float span = max_dB - min_dB;
     hipLaunchKernelGGL(spec_to_img_kernel, dim3(n_tiles), dim3(256), 0, s, d_jobs, d_tile_job, n_jobs, min_dB, span,
-                       (float)(65535u - min_value), (float)min_value);
+                       (float)(65535u - min_value), (float)min_value, d_range);
     return hipGetLastError();
 }
 
@@ -129,6 +151,8 @@ __device__ __forceinline__ void raster_quads(const RasterJob &job, uint32_t base
     const gptr<const uint16_t> img = as_global(job.img);
     const gptr<uint32_t> out = as_global(reinterpret_cast<uint32_t *>(job.rgba));
     const bool base_aligned = (reinterpret_cast<uintptr_t>(job.rgba) & 15u) == 0;
+    // 8-byte aligned source quads: base pointer, row pitch and tile origin all multiples of 4 pixels
+    const bool src_al = (reinterpret_cast<uintptr_t>(job.img) & 7u) == 0 && job.img_pitch % 4 == 0 && job.origin_x % 4 == 0;
     auto look = [&](uint32_t v) -> uint32_t {
         const uint32_t ci = colour_index(v, n_colors);
         if constexpr (LUT_IN_LDS) return lut[ci];
@@ -137,16 +161,60 @@ __device__ __forceinline__ void raster_quads(const RasterJob &job, uint32_t base
     if (job.width % 4 == 0) {
         // row quads: 4 horizontally adjacent pixels of one tile row per thread
         const uint32_t n_quads = job.quads_per_row * job.height;
+        constexpr uint32_t NIT = RASTER_QUADS_PER_BLOCK / RASTER_THREADS;
+        if (src_al && base_aligned && base + RASTER_QUADS_PER_BLOCK <= n_quads) {
+            // fast path (block-uniform): the whole block is inside the tile and everything is aligned — request
+            // all NIT source quads of the thread first (NIT x 8 bytes in flight per lane instead of one), then
+            // look up and store
+            uint2 w[NIT];
+            uint32_t o[NIT];
+#pragma unroll
+            for (uint32_t it = 0; it < NIT; it++) {
+                const uint32_t q = base + it * RASTER_THREADS + threadIdx.x;
+                const uint32_t r = job.quads_per_row == 1 ? q : __umulhi(q, job.inv_qpr);
+                const uint32_t c = (q - r * job.quads_per_row) * 4;
+                const uint32_t src_row = job.origin_y + (job.height - 1 - r);
+                w[it] = *reinterpret_cast<gptr<const uint2>>(img + ((size_t)src_row * job.img_pitch + job.origin_x + c));
+                o[it] = r * job.width + c;
+            }
+#pragma unroll
+            for (uint32_t it = 0; it < NIT; it++) {
+                *reinterpret_cast<gptr<uint4>>(out + o[it]) =
+                    make_uint4(look(w[it].x & 0xffffu), look(w[it].x >> 16), look(w[it].y & 0xffffu), look(w[it].y >> 16));
+            }
+            return;
+        }
 #pragma unroll 4
-        for (uint32_t it = 0; it < RASTER_QUADS_PER_BLOCK / RASTER_THREADS; it++) {
+        for (uint32_t it = 0; it < NIT; it++) {
             const uint32_t q = base + it * RASTER_THREADS + threadIdx.x;
             if (q >= n_quads) break;
             const uint32_t r = job.quads_per_row == 1 ? q : __umulhi(q, job.inv_qpr);  // 2^32/1 does not fit inv_qpr
             const uint32_t c = (q - r * job.quads_per_row) * 4;
             const uint32_t src_row = job.origin_y + (job.height - 1 - r);  // first output row = highest frequency
+#if defined(TH_EXP_RASTER_LINEAR)
+            const gptr<const uint16_t> src = img + (size_t)blockIdx.x * RASTER_QUADS_PER_BLOCK * 4 % ((size_t)job.img_pitch * job.img_height - 8192) + (size_t)(it * RASTER_THREADS + threadIdx.x) * 4 + 0 * src_row;  // experiment
+#else
             const gptr<const uint16_t> src = img + ((size_t)src_row * job.img_pitch + job.origin_x + c);
+#endif
             const uint32_t o = r * job.width + c;
-            const uint32_t p0 = look(src[0]), p1 = look(src[1]), p2 = look(src[2]), p3 = look(src[3]);
+            uint32_t v0, v1, v2, v3;
+            if (src_al) {  // 8-byte aligned quads (uniform per job): one load instead of four 2-byte loads
+                const uint2 w = *reinterpret_cast<gptr<const uint2>>(src);
+                v0 = w.x & 0xffffu;
+                v1 = w.x >> 16;
+                v2 = w.y & 0xffffu;
+                v3 = w.y >> 16;
+            } else {
+                v0 = src[0];
+                v1 = src[1];
+                v2 = src[2];
+                v3 = src[3];
+            }
+#if defined(TH_EXP_RASTER_NOLUT)
+            const uint32_t p0 = v0 * 0x10101u, p1 = v1 * 0x10101u, p2 = v2 * 0x10101u, p3 = v3 * 0x10101u;  // experiment
+#else
+            const uint32_t p0 = look(v0), p1 = look(v1), p2 = look(v2), p3 = look(v3);
+#endif
             if (base_aligned) {
                 *reinterpret_cast<gptr<uint4>>(out + o) = make_uint4(p0, p1, p2, p3);
             } else {
@@ -193,7 +261,11 @@ __global__ __launch_bounds__(RASTER_THREADS) void raster_level0_kernel(const Ras
                                                             uint32_t n_jobs, const uint32_t *__restrict__ colormap,
                                                             uint32_t n_colors) {
     __shared__ uint32_t lut[1024];
+#if defined(TH_EXP_RASTER_GLOBAL_LUT)
+    const bool use_lds = false;  // experiment: gather the colours from the (L1-resident) global table
+#else
     const bool use_lds = n_colors <= 1024;
+#endif
     if (use_lds) {
         for (uint32_t i = threadIdx.x; i < n_colors; i += RASTER_THREADS) lut[i] = colormap[i];
         __syncthreads();

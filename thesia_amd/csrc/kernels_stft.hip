@@ -561,6 +561,34 @@ hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queu
     return hipGetLastError();
 }
 
+// find_min_max over every resident spec (core/mod.rs:169-178): one block reduces the per-channel (min, max) pairs
+// the STFT launch left in d_minmax to out = [min, -max] (so that ONE element-wise MIN all-reduce merges ranks).
+__global__ __launch_bounds__(256) void minmax_reduce_kernel(const float *__restrict__ minmax, uint32_t n_chan,
+                                                            float *__restrict__ out) {
+    __shared__ float smn[4], smx[4];
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    for (uint32_t i = threadIdx.x; i < n_chan; i += 256) {
+        mn = nmin(mn, minmax[2 * i]);
+        mx = nmax(mx, minmax[2 * i + 1]);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63u) == 0) {
+        smn[threadIdx.x >> 6] = mn;
+        smx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = nmin(nmin(smn[0], smn[1]), nmin(smn[2], smn[3]));
+        out[1] = -nmax(nmax(smx[0], smx[1]), nmax(smx[2], smx[3]));
+    }
+}
+
+hipError_t launch_minmax_reduce(const float *d_minmax, uint32_t n_chan, float *d_out, hipStream_t s) {
+    hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(256), 0, s, d_minmax, n_chan, d_out);
+    return hipGetLastError();
+}
+
 size_t stft_generic_lds_bytes(const StftGeom &g) { return 2 * (size_t)g.nc * sizeof(cf32); }
 
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
