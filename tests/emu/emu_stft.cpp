@@ -91,3 +91,19 @@ extern "C" __attribute__((visibility("default"))) int emu_stft_wave(const float 
     }
     return 0;
 }
+
+// Check of the quotient the quantise kernel uses (kernels_image.hip: quantise): q0 = a*r, e = fma(-q0, b, a),
+// q = fma(e, r, q0) with r = RN(1/b) against the IEEE quotient a / b.  Returns the number of mismatches (signed
+// zeros compare equal).  fmaf is the correctly rounded C library / hardware operation.
+extern "C" __attribute__((visibility("default"))) uint64_t emu_fma_div_mismatches(const float *a, uint64_t n, float b) {
+    const float r = 1.0f / b;
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const float want = a[i] / b;
+        const float q0 = a[i] * r;
+        const float e = std::fmaf(-q0, b, a[i]);
+        const float q = std::fmaf(e, r, q0);
+        if (std::memcmp(&q, &want, 4) != 0 && !(q == 0.0f && want == 0.0f)) bad++;
+    }
+    return bad;
+}

@@ -45,3 +45,22 @@ def test_emulated_wave_kernel_matches_oracle(emu, win, hop, n_fft, n):
     got_amp = np.power(10.0, out[interior].astype(np.float64) / 20.0)
     rel = (np.abs(got_amp - amp[interior]) / amp[interior].max(axis=1, keepdims=True)).max() if interior.any() else 0
     assert rel <= 2e-6, rel
+
+
+def test_fma_corrected_division_is_exact(emu):
+    """The quantiser divides by the launch-uniform span with one FMA correction step on the correctly rounded
+    reciprocal (kernels_image.hip: quantise).  Sampled version of the exhaustive check (all 2^32 dividends x 60
+    divisors: zero mismatches) that was run when the kernel was written."""
+    lib = emu
+    lib.emu_fma_div_mismatches.restype = C.c_uint64
+    lib.emu_fma_div_mismatches.argtypes = [C.POINTER(C.c_float), C.c_uint64, C.c_float]
+    rng = np.random.default_rng(5)
+    n = 1 << 21
+    # dividends as the kernel sees them: dB - min_dB, plus random bit patterns of moderate magnitude
+    a = np.concatenate([rng.uniform(-300, 300, n).astype(np.float32),
+                        (rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)).view(np.float32)])
+    a = a[np.isfinite(a) & ((a == 0) | ((np.abs(a) > 1e-30) & (np.abs(a) < 1e30)))]
+    a = np.ascontiguousarray(a)
+    for b in [100.0, 99.99999, 60.0, 3.0, 1e-3, 2e3] + list(np.exp(rng.uniform(np.log(1e-3), np.log(2e3), 10))):
+        bad = lib.emu_fma_div_mismatches(a.ctypes.data_as(C.POINTER(C.c_float)), a.size, np.float32(b))
+        assert bad == 0, (b, bad)
