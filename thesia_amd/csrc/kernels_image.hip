@@ -30,10 +30,11 @@ namespace th {
 // pixel).  Verified bit for bit against a / span for all 2^32 dividends and 60 divisors spread over [1e-3, 2e3]
 // (tests/test_host_logic.py keeps a sampled version); non-finite dividends bypass it, spans outside the
 // verified range take the plain division (rinv = 0).
+template <bool FAST>
 __device__ __forceinline__ uint32_t quantise(float dB, float min_dB, float span, float rinv, float u16_span, float min_value) {
     const float a = dB - min_dB;  // plain operators: contraction is off in this file
     float z;
-    if (rinv != 0.0f) {  // launch-uniform
+    if constexpr (FAST) {
         const float q0 = a * rinv;
         const float e = __builtin_fmaf(-q0, span, a);
         const float q = __builtin_fmaf(e, rinv, q0);
@@ -92,7 +93,10 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     const uint32_t tiles_r = (out_h + IMG_TILE_F - 1) / IMG_TILE_F;
     const uint32_t r0 = (local % tiles_r) * IMG_TILE_F;  // image row (relative to i_start)
     const uint32_t t0 = (local / tiles_r) * IMG_TILE_T;
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    // wave-uniform (tell the compiler): row pointers and the per-row predicates then live in SGPRs, and every access is
+    // "scalar row base + 32-bit lane offset" with no per-element 64-bit VALU address arithmetic
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     // read: lanes along frequency (contiguous in the spec)
     const uint32_t i_freq = job.i_start + r0 + lane;
@@ -103,11 +107,22 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
 #pragma unroll
     for (uint32_t i = 0; i < IMG_TILE_T / 4; i++) {
         const uint32_t t = t0 + wv + 4 * i;
-        v[i] = (f_ok && t < job.n_frames) ? spec[(size_t)t * job.spec_pitch + i_freq] : __builtin_nanf("");
+        const gptr<const float> rowp = spec + (size_t)t * job.spec_pitch;  // scalar
+        v[i] = (f_ok && t < job.n_frames) ? rowp[i_freq] : __builtin_nanf("");
     }
+    // the three cases are launch-uniform: one specialised loop each instead of a branch per element
+    if (all_zero) {
 #pragma unroll
-    for (uint32_t i = 0; i < IMG_TILE_T / 4; i++)
-        tile[lane][wv + 4 * i] = all_zero ? (uint16_t)0 : (uint16_t)quantise(v[i], min_dB, span, rinv, u16_span, min_value);  // NaN -> 0
+        for (uint32_t i = 0; i < IMG_TILE_T / 4; i++) tile[lane][wv + 4 * i] = 0;
+    } else if (rinv != 0.0f) {
+#pragma unroll
+        for (uint32_t i = 0; i < IMG_TILE_T / 4; i++)
+            tile[lane][wv + 4 * i] = (uint16_t)quantise<true>(v[i], min_dB, span, rinv, u16_span, min_value);  // NaN -> 0
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < IMG_TILE_T / 4; i++)
+            tile[lane][wv + 4 * i] = (uint16_t)quantise<false>(v[i], min_dB, span, rinv, u16_span, min_value);
+    }
     __syncthreads();
     // write: lanes along time (contiguous in the image), two samples per lane
     const uint32_t t = t0 + 2 * lane;
@@ -115,13 +130,15 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     for (uint32_t i = 0; i < IMG_TILE_F / 4; i++) {
         const uint32_t dr = wv + 4 * i, r = r0 + dr;
         const uint32_t pair = *reinterpret_cast<const uint32_t *>(&tile[dr][2 * lane]);
-        const size_t e = (size_t)r * job.img_pitch + t;
+        const gptr<uint16_t> rowo = img + (size_t)r * job.img_pitch;  // scalar
+        // (t is even; the row base is 4-byte aligned when the image base is and the pitch is even: wave-uniform)
+        const bool row_al = ((reinterpret_cast<uintptr_t>(job.img) + 2 * (size_t)r * job.img_pitch) & 3) == 0;
         if (r < out_h) {
-            if (t + 1 < job.n_frames && (e & 1) == 0 && (reinterpret_cast<uintptr_t>(job.img) & 3) == 0) {
-                *reinterpret_cast<gptr<uint32_t>>(img + e) = pair;
+            if (t + 1 < job.n_frames && row_al) {
+                *reinterpret_cast<gptr<uint32_t>>(rowo + t) = pair;
             } else {
-                if (t < job.n_frames) img[e] = (uint16_t)(pair & 0xffffu);
-                if (t + 1 < job.n_frames) img[e + 1] = (uint16_t)(pair >> 16);
+                if (t < job.n_frames) rowo[t] = (uint16_t)(pair & 0xffffu);
+                if (t + 1 < job.n_frames) rowo[t + 1] = (uint16_t)(pair >> 16);
             }
         }
     }
