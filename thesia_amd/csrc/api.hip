@@ -839,6 +839,7 @@ TH_API int th_raster_tiles_dev(th_ctx *c, const th_raster_desc *descs, size_t n,
     TH_REQUIRE(c, "ctx is NULL");
     if (n == 0) return TH_OK;
     TH_REQUIRE(descs && d_colormap && n_colors >= 1, "NULL descs/colormap or empty colormap");
+    TH_REQUIRE(n_colors <= 65536, "colormaps of more than 65536 entries are not supported");
     {   // same batch as the previous call: the device tables are still valid
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         if (c->raster_descs_key.size() == n * sizeof(th_raster_desc) &&

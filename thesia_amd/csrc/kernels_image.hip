@@ -179,8 +179,13 @@ hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_job, 
 // colour index = (v * (C - 1) + 32767) / 65535 in integer arithmetic (:342-346), RGBA from the LUT.
 // A thread rasterises quads of 4 horizontally adjacent pixels: 4 u16 loads, one 16-byte store
 // (1 KiB per wave-instruction) when the tile row pitch allows it.
+// x / 65535 == (x + 1 + (x >> 16)) >> 16 for every x < 2^32 - 65536 (checked exhaustively), i.e. for every
+// v <= 65535 and n_colors <= 65536 (the host entry points require that): three full-rate operations instead of a
+// quarter-rate 32-bit multiply-high.
 __device__ __forceinline__ uint32_t colour_index(uint32_t v, uint32_t n_colors) {
-    return n_colors <= 1 ? 0u : (v * (n_colors - 1) + 32767u) / 65535u;
+    if (n_colors <= 1) return 0u;
+    const uint32_t x = v * (n_colors - 1) + 32767u;
+    return (x + 1u + (x >> 16)) >> 16;
 }
 
 // LUT_IN_LDS is a template parameter on purpose: a run-time select between an LDS and a global
