@@ -303,7 +303,7 @@ __device__ __forceinline__ void raster_quads(const RasterJob &job, uint32_t base
 
 __global__ __launch_bounds__(RASTER_THREADS) void raster_level0_kernel(const RasterJob *__restrict__ jobs,
                                                             const uint32_t *__restrict__ block_job,
-                                                            uint32_t n_jobs, const uint32_t *__restrict__ colormap,
+                                                            uint32_t n_chunks, const uint32_t *__restrict__ colormap,
                                                             uint32_t n_colors) {
     __shared__ uint32_t lut[1024];
 #if defined(TH_EXP_RASTER_GLOBAL_LUT)
@@ -315,16 +315,25 @@ __global__ __launch_bounds__(RASTER_THREADS) void raster_level0_kernel(const Ras
         for (uint32_t i = threadIdx.x; i < n_colors; i += RASTER_THREADS) lut[i] = colormap[i];
         __syncthreads();
     }
-    const RasterJob job = jobs[block_job[blockIdx.x]];
-    const uint32_t base = (blockIdx.x - job.first_block) * RASTER_QUADS_PER_BLOCK;
-    if (use_lds) raster_quads<true>(job, base, lut, as_global(colormap), n_colors);
-    else raster_quads<false>(job, base, lut, as_global(colormap), n_colors);
+    // chunk loop: with a grid smaller than the number of chunks (launch_raster_level0) a block keeps its LUT and
+    // walks chunks b, b + gridDim.x, ...
+    for (uint32_t b = blockIdx.x; b < n_chunks; b += gridDim.x) {
+        const RasterJob job = jobs[block_job[b]];
+        const uint32_t base = (b - job.first_block) * RASTER_QUADS_PER_BLOCK;
+        if (use_lds) raster_quads<true>(job, base, lut, as_global(colormap), n_colors);
+        else raster_quads<false>(job, base, lut, as_global(colormap), n_colors);
+    }
 }
 
 hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block_job, uint32_t n_jobs,
                                 uint32_t n_blocks, const uint8_t *d_colormap, uint32_t n_colors, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
-    hipLaunchKernelGGL(raster_level0_kernel, dim3(n_blocks), dim3(RASTER_THREADS), 0, s, d_jobs, d_block_job, n_jobs,
+#if defined(TH_RASTER_PERSIST)
+    const uint32_t grid = n_blocks < 256u * TH_RASTER_PERSIST ? n_blocks : 256u * TH_RASTER_PERSIST;
+#else
+    const uint32_t grid = n_blocks;
+#endif
+    hipLaunchKernelGGL(raster_level0_kernel, dim3(grid), dim3(RASTER_THREADS), 0, s, d_jobs, d_block_job, n_blocks,
                        reinterpret_cast<const uint32_t *>(d_colormap), n_colors);
     return hipGetLastError();
 }
