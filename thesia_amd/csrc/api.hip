@@ -471,8 +471,8 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     // bits 0-7: 0 auto, 1 generic, 2 wave;  bits 8-15 (tuning): waves per workgroup of the wave kernel
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
     TH_REQUIRE(k >= 0 && k <= 2, "kernel selector must be 0, 1 or 2");
-    TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
-               "waves per workgroup must be 4, 6, 8, 10, 12, 14 or 16");
+    TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
+               "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     p->kernel_choice = k;
     p->wave_waves = wv;
     p->wave_chunk = (which >> 16) & 0xff;  // tuning: frames per chunk of the wave kernel (0 = default)

@@ -295,7 +295,7 @@ __device__ __forceinline__ void wave_frame(
     const cf32 (&rw)[(RES & 1) ? WaveFft<LOG2_NC>::P : 1], const cf32 (&rw2)[(RES & 2) ? WaveFft<LOG2_NC>::R2 - 1 : 1],
     const cf32 (&rwa)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
     const cf32 (&rwb)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
-    const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], float &lmin, float &lmax TH_PROF_PARAMS) {
+    const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], cf32 rw_mid, float &lmin, float &lmax TH_PROF_PARAMS) {
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
     TH_PROF_MARK(8);
@@ -400,8 +400,8 @@ __device__ __forceinline__ void wave_frame(
                 lmax = nmax(lmax, d);
             }
         };
-        if constexpr (RES & 8) W::split_paired_w(lane, za, zb, rws, stw, emit);
-        else W::split_paired_w(lane, za, zb, ws, stw, emit);
+        if constexpr (RES & 8) W::split_paired_w(lane, za, zb, rws, rw_mid, emit);
+        else W::split_paired_w(lane, za, zb, ws, stw[NC / 2], emit);
     } else {
         W::pass2_dft(lane, z, slab);
         wave_lds_sync();
@@ -450,8 +450,10 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     static_assert(SHIFT >= 0 && SHIFT < P, "shift must leave something to reuse");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *wtab = reinterpret_cast<cf32 *>(smem_raw);
+    // the split-twiddle table is not kept in LDS when the lanes hold their entries in registers (RES bit 3)
+    constexpr bool STW_IN_LDS = !((RES & 8) && W::PAIRED);
     cf32 *stw = wtab + NC;
-    cf32 *t2 = stw + NC;
+    cf32 *t2 = stw + (STW_IN_LDS ? NC : 0);
     cf32 *t3 = t2 + W::T2_LEN;
     cf32 *slabs = t3 + W::T3_LEN;
 
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
         wtab[i] = wtab_g[i];
-        stw[i] = tw[i];
+        if constexpr (STW_IN_LDS) stw[i] = tw[i];
     }
     W::fill_tables(tid, 64 * WAVES, tw, t2, t3);
     __syncthreads();
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     constexpr int NROT = ROTATE ? P / SHIFT : 1;
 #define TH_FRAME(ROT)                                                                                                  \
     wave_frame<LOG2_NC, SHIFT, AMP, ROTATE, ROTATE ? (ROT) * SHIFT : 0, RES>(                                          \
-        g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, lmin, \
+        g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
         lmax TH_PROF_ARGS)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
     cf32 rw[(RES & 1) ? P : 1], rw2[(RES & 2) ? W::R2 - 1 : 1];
@@ -499,7 +501,14 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     }
     if constexpr (RES & 2) W::load_t2(lane, rw2, t2);
     if constexpr (RES & 4) W::load_t3_paired(lane, rwa, rwb, t3);
-    if constexpr (RES & 8) W::load_stw_paired(lane, rws, stw);
+    cf32 rw_mid = {0.0f, 0.0f};
+    if constexpr ((RES & 8) != 0 && W::PAIRED) {  // straight from the global table: no LDS copy exists
+#pragma unroll
+        for (int q = 0; q < W::NQ; q++)
+#pragma unroll
+            for (int s = 0; s < W::R3; s++) rws[q][s] = tw[W::split_k(lane, q, s)];
+        rw_mid = tw[NC / 2];
+    }
     // chunk loop: one queue pull and one full fetch per chunk of up to frames_per_tile consecutive frames
     for (;;) {
         const FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
@@ -618,11 +627,15 @@ bool stft_wave_supported(const StftGeom &g) { return g.log2_nc >= 9 && g.log2_nc
 #if !defined(TH_RES12)
 #define TH_RES12 1
 #endif
+#if !defined(TH_WAVES_4096)
+#define TH_WAVES_4096 7
+#endif
 template <int LOG2_NC>
 struct WaveLaunchCfg {
-    static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? 6 : 12;  // n_fft = 4096: 153 KB of LDS at 6 waves
+    static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? TH_WAVES_4096 : 12;  // n_fft = 4096: LDS-bound (17 KB slab per wave)
     // register-resident tables by VGPR budget (512 / waves per SIMD); mirror-local path only for bits 2, 3
     static constexpr int resident(int waves) {
+        if (LOG2_NC == 11) return waves <= 7 ? 8 : 0;  // 206 + 32 VGPRs of 256; frees the 16 KB table: 7 waves fit
         if (LOG2_NC != 10) return 0;
         return waves <= 8 ? 15 : waves <= 12 ? TH_RES12 : 0;
     }
@@ -631,7 +644,8 @@ struct WaveLaunchCfg {
 template <int LOG2_NC, int WAVES>
 static size_t wave_lds_bytes() {
     using W = WaveFft<LOG2_NC>;
-    return sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
+    const bool stw_in_lds = !((WaveLaunchCfg<LOG2_NC>::resident(WAVES) & 8) && W::PAIRED);
+    return sizeof(cf32) * ((size_t)(stw_in_lds ? 2 : 1) * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
 }
 
 template <int LOG2_NC, int WAVES, int SHIFT, bool AMP>
@@ -707,6 +721,7 @@ static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const
     switch (waves) {
         TH_WAVE_CASE(4)
         TH_WAVE_CASE(6)
+        TH_WAVE_CASE(7)
         TH_WAVE_CASE(8)
         TH_WAVE_CASE(10)
         TH_WAVE_CASE(12)

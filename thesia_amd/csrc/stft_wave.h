@@ -324,9 +324,10 @@ struct WaveFft {
         TH_UNROLL for (int q = 0; q < NQ; q++)
             TH_UNROLL for (int s = 0; s < R3; s++) ws[q][s] = lds_ld(&stw[split_k(lane, q, s)]);
     }
+    // w_mid = stw[Nc/2] (the twiddle of the self-mirrored bin; only lane 0 uses it)
     template <class Emit>
     static TH_HD void split_paired_w(uint32_t lane, const cf32 (&za)[NQ][R3], const cf32 (&zb)[NQ][R3],
-                                     const cf32 (&ws)[NQ][R3], const cf32 *stw, Emit emit) {
+                                     const cf32 (&ws)[NQ][R3], cf32 w_mid, Emit emit) {
         const bool l0 = lane == 0;
         TH_UNROLL for (int q = 0; q < NQ; q++) {
             TH_UNROLL for (int s = 0; s < R3; s++) {
@@ -360,7 +361,7 @@ struct WaveFft {
         }
         if (l0) {  // the self-mirrored bin Nc/2 = output R3/2 of butterfly 0
             const cf32 z = za[0][R3 / 2];
-            const cf32 w = stw[NC / 2];
+            const cf32 w = w_mid;
             const float er = 2.0f * z.re, di = 2.0f * z.im;  // zm = zk: e = (2 re, 0), d = (0, 2 im)
             const float xr = er + di * w.re, xi = di * w.im;
             emit(NC / 2, xr * xr + xi * xi);
@@ -374,7 +375,7 @@ struct WaveFft {
                                    Emit emit) {
         cf32 ws[NQ][R3];
         load_stw_paired(lane, ws, stw);
-        split_paired_w(lane, za, zb, ws, stw, emit);
+        split_paired_w(lane, za, zb, ws, stw[NC / 2], emit);
     }
 };
 
