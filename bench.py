@@ -213,9 +213,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TH_BENCH_FORCE_DIST") == "1":  # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist = dist_mod
 
@@ -357,6 +358,12 @@ def main():
             out["waveform_pyramid"] = wave
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft)
+        try:  # RCCL prints a version banner through C stdio; push it out first so that the JSON is the last stdout line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     barrier()
     del wl
