@@ -201,6 +201,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if rank != 0:  # only rank 0 reports; keep library banners (RCCL prints one through C stdio) of the others off stdout
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
     import __graft_entry__ as ge
     if rank == 0 or not os.path.exists(ge.LIB):
