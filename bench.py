@@ -104,7 +104,10 @@ class Workload:
                 break
             tx += 1
         self.tile_px = sum(g.width * g.height for g in geoms)
-        self.rgba = torch.empty((n_tracks, self.tile_px, 4), dtype=torch.uint8, device=dev)
+        # every tile starts on a 256-byte boundary (the rasteriser stores 16 bytes per lane: an unaligned tile base
+        # degrades it to 4-byte stores)
+        self.tile_slots = sum(-(-(g.width * g.height) // 64) * 64 for g in geoms)
+        self.rgba = torch.empty((n_tracks, self.tile_slots, 4), dtype=torch.uint8, device=dev)
         self.chan = (ta.ChanDesc * n_tracks)(*[
             ta.ChanDesc(self.wav[i].data_ptr(), self.spec[i].data_ptr(), n, self.T, self.sp) for i in range(n_tracks)])
         self.imgd = (ta.ImgDesc * n_tracks)(*[
@@ -116,7 +119,7 @@ class Workload:
             for g in geoms:
                 rast.append(ta.RasterDesc(self.img[i].data_ptr(), self.rgba[i].data_ptr() + off * 4, self.T,
                                                self.H, g.origin_x, g.origin_y, g.width, g.height, self.ip, 0))
-                off += g.width * g.height
+                off += -(-(g.width * g.height) // 64) * 64
         self.rast = (ta.RasterDesc * len(rast))(*rast)
         self.frames = n_tracks * self.T
         self.pixels = n_tracks * self.H * self.T

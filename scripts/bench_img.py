@@ -42,14 +42,15 @@ while True:
         break
     tx += 1
 tile_px = sum(g.width * g.height for g in geoms)
-rgba = torch.empty((n, tile_px, 4), dtype=torch.uint8, device=dev)
+tile_slots = sum(-(-(g.width * g.height) // 64) * 64 for g in geoms)  # every tile on a 256-byte boundary
+rgba = torch.empty((n, tile_slots, 4), dtype=torch.uint8, device=dev)
 imgd = (ta.ImgDesc * n)(*[ta.ImgDesc(spec[i].data_ptr(), img[i].data_ptr(), T, H, 0, H, sp, ip) for i in range(n)])
 rast = []
 for i in range(n):
     off = 0
     for g in geoms:
         rast.append(ta.RasterDesc(img[i].data_ptr(), rgba[i].data_ptr() + off * 4, T, H, g.origin_x, g.origin_y, g.width, g.height, ip, 0))
-        off += g.width * g.height
+        off += -(-(g.width * g.height) // 64) * 64
 rast = (ta.RasterDesc * len(rast))(*rast)
 
 
