@@ -72,8 +72,8 @@ hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block
 #endif
 constexpr uint32_t RASTER_THREADS = TH_RASTER_THREADS;
 constexpr uint32_t RASTER_QUADS_PER_BLOCK = TH_RASTER_QPB;  // default: 256 threads x 4 quads of 4 pixels
-constexpr uint32_t IMG_TILE_T = 128;  // frames per quantise/transpose tile
-constexpr uint32_t IMG_TILE_F = 64;   // frequency rows per tile
+constexpr uint32_t IMG_TILE_T = 64;   // frames per quantise/transpose tile
+constexpr uint32_t IMG_TILE_F = 128;  // frequency rows per tile
 
 // Separable Lanczos3 LOD resample of a crop of a u16 image (encode_spectrogram_tile, LOD > 0,
 // render_tiles.rs:354-393).  Per output index of an axis the host tabulates the first source index,

@@ -54,12 +54,14 @@ __host__ __device__ __forceinline__ float quantise_rinv(float span) {
     return (span >= 1e-3f && span <= 2e3f) ? 1.0f / span : 0.0f;
 }
 
-// One block = one IMG_TILE_T(frames) x IMG_TILE_F(freq rows) tile: coalesced f32 row reads
-// (frame-major spec, 256 B per wave-instruction), quantise, transpose through a u16 LDS tile, then
-// each lane stores two adjacent time samples of one image row as one dword (256 B per
-// wave-instruction) when the row's base is 4-byte aligned, else as two shorts.
-// LDS pitch 130 u16 = 65 dwords (odd): the transposing ds_write_b16 of the read phase and the
-// row-wise ds_read_b32 of the write phase are both conflict-free.
+// One block = one tile of IMG_TILE_F = 128 frequency rows x IMG_TILE_T = 64 frames.  Read: lanes along frequency
+// (contiguous in the frame-major spec), two bins per lane: a wave-instruction fetches 512 contiguous bytes of one
+// frame row.  Quantise, transpose through a u16 LDS tile.  Write: lanes along time, two frames per lane as one dword:
+// the 64 frames of an image row are one 128-byte line, a wave-instruction writes two rows.
+// Shape chosen by measurement (scripts/ubench/transpose_shapes.hip, same traffic without the arithmetic):
+// 128 x 64 streams at 5.3-5.5 TB/s, the earlier 64 freq x 128 frames tile at 3.9-4.1, larger tiles worse.
+// LDS pitch 66 u16 = 33 dwords (odd): the row-wise ds_read_b32 of the write phase are conflict-free, the
+// transposing ds_write_b16 of the read phase two-way at worst.
 constexpr uint32_t IMG_LDS_PITCH = IMG_TILE_T + 2;
 
 __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restrict__ jobs,
@@ -80,16 +82,17 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     const gptr<const float> spec = as_global(job.spec);
     const gptr<uint16_t> img = as_global(job.img);
     const uint32_t out_h = job.i_end - job.i_start;
-    // Tile order: frequency-tile fastest, and consecutive tiles on the SAME XCD (workgroups are dealt
-    // round-robin over the 8 XCDs, so blocks b and b+8 share an L2).  A 256-byte row segment of the
-    // 4100-byte spec rows straddles three 128-byte lines; the frequency-adjacent tile needs the
-    // other halves of the two boundary lines and now finds them in its XCD's L2 instead of
-    // fetching them again (measured: 1.49x read over-fetch with time-fastest order).
+    // Tile order: frequency-tile fastest, and consecutive tiles on the SAME XCD (workgroups are dealt round-robin
+    // over the 8 XCDs, so blocks b and b+8 share an L2): frequency-adjacent tiles read adjacent 512-byte segments of
+    // the same spec rows, so whatever straddles a line boundary (unpadded row pitches) is found in that L2.
     const uint32_t n_local = job.n_tiles;
     const uint32_t local0 = blockIdx.x - job.first_tile;
     const uint32_t per_xcd = (n_local + 7) / 8;
     uint32_t local = (local0 % 8) * per_xcd + local0 / 8;  // bijective when n_local % 8 == 0
     if (n_local % 8 != 0) local = local0;                   // ragged tail: plain order
+#if defined(TH_IMG_PLAIN_ORDER)
+    local = local0;
+#endif
     const uint32_t tiles_r = (out_h + IMG_TILE_F - 1) / IMG_TILE_F;
     const uint32_t r0 = (local % tiles_r) * IMG_TILE_F;  // image row (relative to i_start)
     const uint32_t t0 = (local / tiles_r) * IMG_TILE_T;
@@ -98,43 +101,75 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     // "scalar row base + 32-bit lane offset" with no per-element 64-bit VALU address arithmetic
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // read: lanes along frequency (contiguous in the spec)
-    const uint32_t i_freq = job.i_start + r0 + lane;
-    const bool f_ok = i_freq < job.height && r0 + lane < out_h;
-    // all 32 row segments of this wave are requested before the first is consumed: one HBM latency
-    // per tile instead of one per unroll group
-    float v[IMG_TILE_T / 4];
+    // read: lanes along frequency (contiguous in the spec), bins 2*lane and 2*lane + 1 of the tile
+    const uint32_t i_freq = job.i_start + r0 + 2 * lane;
+    const bool ok0 = i_freq < job.height && r0 + 2 * lane < out_h;
+    const bool ok1 = i_freq + 1 < job.height && r0 + 2 * lane + 1 < out_h;
+    // 8-byte loads need an even element offset (even row pitch, even first bin, 8-byte aligned base) and one float of
+    // row padding, because the pair of the last bin reads one element past `height`: all launch-uniform.
+    const bool al2 = (reinterpret_cast<uintptr_t>(job.spec) & 7u) == 0 && job.spec_pitch % 2 == 0 && (job.i_start + r0) % 2 == 0 &&
+                     job.spec_pitch > job.height;
+    // all 16 row segments of this wave are requested before the first is consumed: one HBM latency per tile.  The loads
+    // are unconditional (indices clamped, results discarded by selects): a per-lane branch around a load makes the
+    // compiler wait for the previous one.
+    constexpr uint32_t NLD = IMG_TILE_T / 4;
+    float v0[NLD], v1[NLD];
+    const float qnan = __builtin_nanf("");
+    const uint32_t f0c = min(i_freq, (job.height - 1) & ~1u), f1c = min(i_freq + 1, job.height - 1);  // height >= 1 here
+    if (al2) {
 #pragma unroll
-    for (uint32_t i = 0; i < IMG_TILE_T / 4; i++) {
-        const uint32_t t = t0 + wv + 4 * i;
-        const gptr<const float> rowp = spec + (size_t)t * job.spec_pitch;  // scalar
-        v[i] = (f_ok && t < job.n_frames) ? rowp[i_freq] : __builtin_nanf("");
+        for (uint32_t i = 0; i < NLD; i++) {
+            const uint32_t t = t0 + wv + 4 * i;
+            const gptr<const float> rowp = spec + (size_t)min(t, job.n_frames - 1) * job.spec_pitch;  // scalar
+            const float2 x = *reinterpret_cast<gptr<const float2>>(rowp + f0c);
+            v0[i] = (ok0 && t < job.n_frames) ? x.x : qnan;
+            v1[i] = (ok1 && t < job.n_frames) ? x.y : qnan;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < NLD; i++) {
+            const uint32_t t = t0 + wv + 4 * i;
+            const gptr<const float> rowp = spec + (size_t)min(t, job.n_frames - 1) * job.spec_pitch;  // scalar
+            const float a = rowp[min(i_freq, job.height - 1)], b2 = rowp[f1c];
+            v0[i] = (ok0 && t < job.n_frames) ? a : qnan;
+            v1[i] = (ok1 && t < job.n_frames) ? b2 : qnan;
+        }
     }
     // the three cases are launch-uniform: one specialised loop each instead of a branch per element
     if (all_zero) {
 #pragma unroll
-        for (uint32_t i = 0; i < IMG_TILE_T / 4; i++) tile[lane][wv + 4 * i] = 0;
+        for (uint32_t i = 0; i < NLD; i++) tile[2 * lane][wv + 4 * i] = tile[2 * lane + 1][wv + 4 * i] = 0;
     } else if (rinv != 0.0f) {
 #pragma unroll
-        for (uint32_t i = 0; i < IMG_TILE_T / 4; i++)
-            tile[lane][wv + 4 * i] = (uint16_t)quantise<true>(v[i], min_dB, span, rinv, u16_span, min_value);  // NaN -> 0
+        for (uint32_t i = 0; i < NLD; i++) {
+            tile[2 * lane][wv + 4 * i] = (uint16_t)quantise<true>(v0[i], min_dB, span, rinv, u16_span, min_value);  // NaN -> 0
+            tile[2 * lane + 1][wv + 4 * i] = (uint16_t)quantise<true>(v1[i], min_dB, span, rinv, u16_span, min_value);
+        }
     } else {
 #pragma unroll
-        for (uint32_t i = 0; i < IMG_TILE_T / 4; i++)
-            tile[lane][wv + 4 * i] = (uint16_t)quantise<false>(v[i], min_dB, span, rinv, u16_span, min_value);
+        for (uint32_t i = 0; i < NLD; i++) {
+            tile[2 * lane][wv + 4 * i] = (uint16_t)quantise<false>(v0[i], min_dB, span, rinv, u16_span, min_value);
+            tile[2 * lane + 1][wv + 4 * i] = (uint16_t)quantise<false>(v1[i], min_dB, span, rinv, u16_span, min_value);
+        }
     }
     __syncthreads();
-    // write: lanes along time (contiguous in the image), two samples per lane
-    const uint32_t t = t0 + 2 * lane;
+    // write: lanes along time, two frames per lane; a wave-instruction covers two image rows (lanes 0-31 / 32-63).
+    // All LDS reads first (they are unconditional), then the stores: one LDS latency per wave instead of one per row.
+    constexpr uint32_t NST = IMG_TILE_F / 8;  // 2 rows per instruction, 4 waves
+    const uint32_t half = lane >> 5, tl = 2 * (lane & 31u);
+    const uint32_t t = t0 + tl;
+    uint32_t pairs[NST];
 #pragma unroll
-    for (uint32_t i = 0; i < IMG_TILE_F / 4; i++) {
-        const uint32_t dr = wv + 4 * i, r = r0 + dr;
-        const uint32_t pair = *reinterpret_cast<const uint32_t *>(&tile[dr][2 * lane]);
-        const gptr<uint16_t> rowo = img + (size_t)r * job.img_pitch;  // scalar
-        // (t is even; the row base is 4-byte aligned when the image base is and the pitch is even: wave-uniform)
-        const bool row_al = ((reinterpret_cast<uintptr_t>(job.img) + 2 * (size_t)r * job.img_pitch) & 3) == 0;
+    for (uint32_t i = 0; i < NST; i++) pairs[i] = *reinterpret_cast<const uint32_t *>(&tile[2 * (wv + 4 * i) + half][tl]);
+    // (t is even; a row base is 4-byte aligned when the image base is and the pitch is even: launch-uniform)
+    const bool rows_al = (reinterpret_cast<uintptr_t>(job.img) & 3u) == 0 && job.img_pitch % 2 == 0;
+#pragma unroll
+    for (uint32_t i = 0; i < NST; i++) {
+        const uint32_t r = r0 + 2 * (wv + 4 * i) + half;
+        const uint32_t pair = pairs[i];
+        const gptr<uint16_t> rowo = img + (size_t)r * job.img_pitch;
         if (r < out_h) {
-            if (t + 1 < job.n_frames && row_al) {
+            if (t + 1 < job.n_frames && rows_al) {
                 *reinterpret_cast<gptr<uint32_t>>(rowo + t) = pair;
             } else {
                 if (t < job.n_frames) rowo[t] = (uint16_t)(pair & 0xffffu);
