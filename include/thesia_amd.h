@@ -230,9 +230,8 @@ TH_API int th_encode_spectrogram_tile_dev(th_ctx *ctx, const uint16_t *d_img, si
 
 typedef struct {
     const uint16_t *img;  /* DEVICE: img_height x img_width */
-    uint8_t *rgba;        /* DEVICE: height x width x 4, top row = highest frequency.  Any 4-byte aligned address
-                           * works; 16-byte aligned tile bases let the kernel store 16 bytes per lane (a packed
-                           * array of odd-sized tiles without that padding costs 20 % of the launch) */
+    uint8_t *rgba;        /* DEVICE: height x width x 4, top row = highest frequency; 4-byte aligned (tiles may be
+                           * packed back to back: the kernel lays its 16-byte stores on the address grid) */
     uint32_t img_width, img_height;
     uint32_t origin_x, origin_y, width, height; /* level-0 tile rectangle (th_spectrogram_tile_geometry) */
     uint32_t img_pitch;                         /* u16 per image row, 0 = dense (img_width) */

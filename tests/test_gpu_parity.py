@@ -574,3 +574,39 @@ def test_device_resident_db_range_path(ctx):
             assert not img.any()
         for b in (d_spec, d_mm, d_r2, d_rng, d_img):
             b.free()
+
+
+@pytest.mark.parametrize("W,H", [(1100, 700), (1031, 530), (3, 5), (517, 9)])
+def test_raster_tiles_batch_any_alignment(ctx, golden_dir, W, H):
+    """th_raster_tiles_dev on a whole batch of level-0 tiles packed back to back (tile bases only 4-byte aligned,
+    widths that are not multiples of 4, tiny tiles): every tile equals the RGBA payload of encode_spectrogram_tile
+    (render_tiles.rs:281-352)."""
+    from thesia_amd import _ffi
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    rng = np.random.default_rng(W * 31 + H)
+    img = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+    pitch = ta.pitch_u16(W)
+    padded = np.zeros((H, pitch), np.uint16)
+    padded[:, :W] = img
+    d_img, d_cmap = ctx.to_device(padded), ctx.to_device(np.frombuffer(cmap, np.uint8))
+    geoms = []
+    for tx in range(-(-W // 512)):
+        for ty in range(-(-H // 512)):
+            geoms.append((tx, ty, ta.spectrogram_tile_geometry(W, H, 0, 0, tx, ty)))
+    for lead in (0, 1, 2, 3):  # pixels of padding in front of the first tile: base offset 0, 4, 8, 12 bytes
+        total = lead + sum(g.width * g.height for _, _, g in geoms)
+        d_out = ctx.alloc(total * 4 + 64)
+        descs, off = [], lead
+        for _, _, g in geoms:
+            descs.append(_ffi.RasterDesc(d_img.ptr, d_out.ptr + off * 4, W, H, g.origin_x, g.origin_y, g.width, g.height, pitch, 0))
+            off += g.width * g.height
+        ctx.raster_tiles(descs, d_cmap.ptr, len(cmap) // 4)
+        flat = d_out.download((total * 4,), np.uint8)
+        off = lead
+        for tx, ty, g in geoms:
+            want = orc.encode_spectrogram_tile(img, cmap, 1, 0, 0, tx, ty)[40:]
+            got = flat[off * 4:(off + g.width * g.height) * 4].tobytes()
+            assert got == want, (W, H, lead, tx, ty)
+            off += g.width * g.height
+        d_out.free()
+    d_img.free(); d_cmap.free()

@@ -860,12 +860,14 @@ TH_API int th_raster_tiles_dev(th_ctx *c, const th_raster_desc *descs, size_t n,
         const uint64_t px = (uint64_t)d.width * d.height;
         TH_REQUIRE(px < (1ull << 31), "desc %zu: tile too large", i);
         TH_REQUIRE(px == 0 || (d.img && d.rgba), "desc %zu: NULL device pointer", i);
+        TH_REQUIRE((reinterpret_cast<uintptr_t>(d.rgba) & 3u) == 0, "desc %zu: rgba must be 4-byte aligned", i);
         TH_REQUIRE(d.img_pitch == 0 || d.img_pitch >= d.img_width, "desc %zu: img_pitch < img_width", i);
         const uint32_t qpr = (d.width + 3) / 4;
         const uint32_t inv = qpr > 1 ? (uint32_t)((1ull << 32) / qpr) + 1u : 0u;  // exact for q * qpr < 2^32
         TH_REQUIRE(px == 0 || (px + 4) * d.width < (1ull << 32), "desc %zu: tile too large", i);
         const uint32_t inv_w = d.width > 1 ? (uint32_t)((1ull << 32) / d.width) + 1u : 0u;
-        const uint64_t nb = ((uint64_t)qpr * d.height + RASTER_QUADS_PER_BLOCK - 1) / RASTER_QUADS_PER_BLOCK;
+        // (+1: a tile base off the 16-byte grid shifts the quads by up to 3 pixels, see raster_quads)
+        const uint64_t nb = ((uint64_t)qpr * d.height + 1 + RASTER_QUADS_PER_BLOCK - 1) / RASTER_QUADS_PER_BLOCK;
         TH_REQUIRE(blocks + nb < (1ull << 27), "batch too large for one launch");
         jobs[i] = RasterJob{d.img, d.rgba, d.img_width, d.img_height, d.origin_x, d.origin_y, d.width, d.height,
                             d.img_pitch ? d.img_pitch : d.img_width, qpr, inv, inv_w, (uint32_t)blocks};

@@ -238,7 +238,7 @@ __device__ __forceinline__ void raster_quads(const RasterJob &job, uint32_t base
         if constexpr (LUT_IN_LDS) return lut[ci];
         else return colormap[ci];
     };
-    if (job.width % 4 == 0) {
+    if (job.width % 4 == 0 && base_aligned) {
         // row quads: 4 horizontally adjacent pixels of one tile row per thread
         const uint32_t n_quads = job.quads_per_row * job.height;
         constexpr uint32_t NIT = RASTER_QUADS_PER_BLOCK / RASTER_THREADS;
@@ -313,25 +313,31 @@ __device__ __forceinline__ void raster_quads(const RasterJob &job, uint32_t base
         // (Row quads with 4-byte-aligned 16-byte stores were 40 % slower per pixel; the first version of this path
         // recomputed row and column per pixel with 64-bit multiplies and cost 23 % of the whole kernel for 9 % of the
         // bench's pixels.)
-        const uint32_t n_px = job.width * job.height, n_quads = (n_px + 3) / 4;
+        // A tile base that is only 4-byte aligned (tiles packed back to back) is handled here too: quads are laid on the
+        // 16-byte grid of the ADDRESSES, i.e. quad q covers output pixels 4q - mis .. 4q - mis + 3 with mis = the base's
+        // offset from the grid in pixels; only the first and the last quad of the tile are partial.
+        const uint32_t n_px = job.width * job.height;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(job.rgba) >> 2) & 3u;
+        const uint32_t n_quads = (n_px + mis + 3) / 4;
         const int32_t wrap = -(int32_t)(job.img_pitch + job.width);
 #pragma unroll 4
         for (uint32_t it = 0; it < RASTER_QUADS_PER_BLOCK / RASTER_THREADS; it++) {
             const uint32_t q = base + it * RASTER_THREADS + threadIdx.x;
             if (q >= n_quads) break;
-            const uint32_t o = 4 * q;
-            const uint32_t r = job.width == 1 ? o : __umulhi(o, job.inv_width);  // o / width
-            const uint32_t c = o - r * job.width;
-            const gptr<const uint16_t> src = img + ((size_t)(job.origin_y + (job.height - 1 - r)) * job.img_pitch + job.origin_x + c);
-            if (o + 4 <= n_px && base_aligned && job.width >= 4) {
+            const int32_t o = (int32_t)(4 * q) - (int32_t)mis;  // first output pixel of the quad (negative: before the tile)
+            const uint32_t o0 = o < 0 ? 0u : (uint32_t)o;
+            const uint32_t r = job.width == 1 ? o0 : __umulhi(o0, job.inv_width);  // o0 / width
+            const uint32_t c = o0 - r * job.width;
+            if (o >= 0 && (uint32_t)o + 4 <= n_px && job.width >= 4) {
+                const gptr<const uint16_t> src = img + ((size_t)(job.origin_y + (job.height - 1 - r)) * job.img_pitch + job.origin_x + c);
                 uint32_t px[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) px[i] = look(src[(int32_t)i + (c + i >= job.width ? wrap : 0)]);
                 *reinterpret_cast<gptr<uint4>>(out + o) = make_uint4(px[0], px[1], px[2], px[3]);
-            } else {  // the last quad of the tile, unaligned tile bases, tiles narrower than 4 pixels: pixel by pixel
+            } else {  // the first / last quad of the tile, tiles narrower than 4 pixels: pixel by pixel
                 uint32_t rr = r, cc = c;
-                for (uint32_t i = 0; i < 4 && o + i < n_px; i++) {
-                    out[o + i] = look(img[(size_t)(job.origin_y + (job.height - 1 - rr)) * job.img_pitch + job.origin_x + cc]);
+                for (int32_t p = (int32_t)o0; p < o + 4 && (uint32_t)p < n_px; p++) {
+                    out[p] = look(img[(size_t)(job.origin_y + (job.height - 1 - rr)) * job.img_pitch + job.origin_x + cc]);
                     if (++cc == job.width) {
                         cc = 0;
                         rr++;
