@@ -7,18 +7,23 @@
 constexpr int T = 2813, H = 1025, HP = 1056, TP = 2816, N = 128;
 
 // TF freq rows x TT frames per block; RV floats per lane per load (along freq); WB bytes per lane per store (along time)
-template <int TF, int TT, int RV, int WB>
+template <int TF, int TT, int RV, int WB, int ORDER>
 __global__ __launch_bounds__(256) void k(const float *__restrict__ spec, uint16_t *__restrict__ img) {
     constexpr int PITCH = TT + 2;  // u16; odd dword count
     extern __shared__ uint16_t tile[];  // [TF][PITCH]
     constexpr int tiles_f = (H + TF - 1) / TF, tiles_t = (T + TT - 1) / TT;
     const int b = blockIdx.x;
-    const int n = b / (tiles_f * tiles_t), l = b % (tiles_f * tiles_t);
-#if defined(TIME_FASTEST)
-    const int f0 = (l / tiles_t) * TF, t0 = (l % tiles_t) * TT;
-#else
-    const int f0 = (l % tiles_f) * TF, t0 = (l / tiles_f) * TT;
-#endif
+    const int per = tiles_f * tiles_t;
+    const int n = b / per;
+    int l = b % per;
+    if (ORDER >= 2) {  // blocks b, b+8, ... share an XCD (and its L2): make THEM neighbours
+        const int per_xcd = (per + 7) / 8;
+        const int l2 = (l % 8) * per_xcd + l / 8;
+        if (per % 8 == 0) l = l2;
+    }
+    int f0, t0;
+    if (ORDER & 1) { f0 = (l / tiles_t) * TF; t0 = (l % tiles_t) * TT; }   // time-fastest
+    else { f0 = (l % tiles_f) * TF; t0 = (l / tiles_f) * TT; }             // frequency-fastest
     const float *sp = spec + (size_t)n * T * HP;
     uint16_t *im = img + (size_t)n * H * TP;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -60,19 +65,19 @@ __global__ __launch_bounds__(256) void k(const float *__restrict__ spec, uint16_
     }
 }
 
-template <int TF, int TT, int RV, int WB>
+template <int TF, int TT, int RV, int WB, int ORDER>
 void run(const float *a, uint16_t *b) {
     constexpr int tiles = ((H + TF - 1) / TF) * ((T + TT - 1) / TT) * N;
     const size_t lds = (size_t)TF * (TT + 2) * 2;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k<TF, TT, RV, WB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k<TF, TT, RV, WB, ORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<TF, TT, RV, WB>), dim3(tiles), dim3(256), lds, 0, a, b);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k<TF, TT, RV, WB, ORDER>), dim3(tiles), dim3(256), lds, 0, a, b);
     float sum = 0;
     for (int i = 0; i < 10; i++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<TF, TT, RV, WB>), dim3(tiles), dim3(256), lds, 0, a, b);
+        hipLaunchKernelGGL((k<TF, TT, RV, WB, ORDER>), dim3(tiles), dim3(256), lds, 0, a, b);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -80,7 +85,7 @@ void run(const float *a, uint16_t *b) {
         sum += ms;
     }
     const double bytes = (double)N * T * H * 6.0;
-    printf("tile %3d freq x %3d frames, read %2d B/lane, write %2d B/lane, LDS %5.1f KB: %.3f ms  %.0f GB/s\n", TF, TT, 4 * RV, WB,
+    printf("order %d tile %3d freq x %3d frames, read %2d B/lane, write %2d B/lane, LDS %5.1f KB: %.3f ms  %.0f GB/s\n", ORDER, TF, TT, 4 * RV, WB,
            lds / 1024.0, sum / 10, bytes / (sum / 10) / 1e6);
 }
 
@@ -90,11 +95,15 @@ int main() {
     hipMalloc(&a, (size_t)N * T * HP * 4);
     hipMalloc(&b, (size_t)N * H * TP * 2);
     hipMemset(a, 0, (size_t)N * T * HP * 4);
-    run<64, 128, 1, 4>(a, b);
-    run<128, 64, 2, 4>(a, b);
-    run<256, 64, 4, 4>(a, b);
-    run<128, 32, 2, 4>(a, b);
-    run<256, 32, 4, 4>(a, b);
-    run<64, 64, 1, 4>(a, b);
+    run<128, 64, 2, 4, 0>(a, b);
+    run<128, 64, 2, 4, 1>(a, b);
+    run<128, 64, 2, 4, 2>(a, b);
+    run<128, 64, 2, 4, 3>(a, b);
+    run<64, 128, 1, 4, 0>(a, b);
+    run<64, 128, 1, 4, 1>(a, b);
+    run<64, 128, 1, 4, 2>(a, b);
+    run<64, 128, 1, 4, 3>(a, b);
+    run<128, 128, 2, 4, 2>(a, b);
+    run<128, 128, 2, 4, 3>(a, b);
     return 0;
 }
