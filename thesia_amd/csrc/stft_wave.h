@@ -151,8 +151,8 @@ struct WaveFftCfg<11> {  // n_fft = 4096: Nc = 2048 = 16 * 16 * 8, P = 32
 // conflict-free at the cheapest rate the LDS has (scripts/ubench/lds_rate.hip):
 //   writes: hipcc pairs the stores of r, r+1 into ds_write2_b64 (16 B per lane, 16 lanes per LDS pass): lane jj
 //          starts at dword 2*R1*jj + 4*(R1*jj/32), so the 16 lanes of a pass cover all 64 banks exactly once
-//          (one pad slot per 32 is enough for 8-byte writes but gives two-way conflicts on the 16-byte pairs:
-//          SQ_LDS_BANK_CONFLICT = 64 cycles per frame);
+//          (one pad slot per 32 is enough for 8-byte writes but would put the 16-byte pairs of lanes jj and jj + 2 on
+//          overlapping banks);
 //   reads (pass 2, i = lane + 64*m): a half wave reads 32 CONSECUTIVE slots = all 64 banks once, 2.2 cycles
 //          per wave-instruction.  (A pad per R1 slots made a half wave span 33+ slots: 4 cycles.)
 // Unlike an XOR swizzle every address is "per-lane base + compile-time immediate": writes
