@@ -208,8 +208,7 @@ def main():
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
     import __graft_entry__ as ge
-    if rank == 0 or not os.path.exists(ge.LIB):
-        ge.build()
+    ge.build()  # no-op when up to date; serialised across ranks by a file lock
     import torch
     import thesia_amd as ta
 
