@@ -486,7 +486,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // NROT = P/SHIFT times; instance ROT reads logical slot m from physical x[(m + ROT*SHIFT) % P] and loads
     // the next frame's SHIFT new slots over the ones that just went out of the window.  A new chunk (all P
     // slots loaded) always starts at rotation 0.
-    constexpr bool ROTATE = SHIFT > 0 && P % SHIFT == 0 && P / SHIFT <= 4;
+    constexpr int SHIFT_NZ = SHIFT > 0 ? SHIFT : 1;  // (keeps the constant expression below free of a % 0)
+    constexpr bool ROTATE = SHIFT > 0 && P % SHIFT_NZ == 0 && P / SHIFT_NZ <= 4;
     constexpr int NROT = ROTATE ? P / SHIFT : 1;
 #define TH_FRAME(ROT)                                                                                                  \
     wave_frame<LOG2_NC, SHIFT, AMP, ROTATE, ROTATE ? (ROT) * SHIFT : 0, RES>(                                          \
