@@ -170,7 +170,11 @@ TH_API const char *th_plan_kernel_name(const th_plan *plan);
 
 /* Recommended row pitches (elements) for device-resident specs / images: rows padded to a multiple of
  * 128 bytes so that every row starts on a cache line.  The reference layout (dense rows) is what the
- * copy-out accessors return; the pitch is an HBM-layout choice of this library. */
+ * copy-out accessors return; the pitch is an HBM-layout choice of this library.
+ * Rows laid out at exactly these pitches OWN their padding (elements [row_elems, pitch) of every row): the kernels
+ * may fill it with zeros so that the last 128-byte line of a row is written whole (a partially written line costs
+ * HBM a read-modify-write: 3.9 -> 5.4 TB/s for 1025-float rows, scripts/ubench/row_stores.hip).  Any other pitch
+ * (dense rows, or rows embedded in a wider caller-owned array) is never written outside [0, row_elems). */
 TH_API size_t th_pitch_f32(size_t row_elems);
 TH_API size_t th_pitch_u16(size_t row_elems);
 

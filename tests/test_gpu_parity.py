@@ -639,7 +639,7 @@ def _batch_on_gpu(ctx, plan, n_tr, n, seed):
 def test_baseline_sizes_properties(ctx, cfg):
     """BASELINE.json configs at FULL size (the oracle cannot run these in test time): the batched launch must equal
     single-track launches of sampled tracks bit for bit (no cross-talk, chunk seams, boundary frames), agree with
-    the oracle on sampled tracks cut short, leave the row padding alone, and report the true min / max."""
+    the oracle on sampled tracks cut short, write nothing but zeros into the row padding, and report the true min / max."""
     import torch
     if cfg == "cfg5_shard":
         sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (2048, 512, 2048), 128, 30 * 48000, ta.LINEAR, 0
@@ -651,8 +651,11 @@ def test_baseline_sizes_properties(ctx, cfg):
     wav, spec, mm = _batch_on_gpu(ctx, plan, n_tr, n, 123)
     T, H = plan.n_frames(n), plan.height
     assert (n_tr * T) in (360064, 165376)
-    # row padding untouched, every real cell written
-    assert bool((spec[:, :, H:] == -12345.0).all()) and not bool((spec[:, :, :H] == -12345.0).any())
+    # every real cell written; the padding of a th_pitch_f32 row belongs to the library: either untouched or zeros up to
+    # the end of the 128-byte line of the last bin (the wave kernel completes that line: a partial line costs HBM a
+    # read-modify-write), never anything else
+    pad = spec[:, :, H:]
+    assert bool(((pad == -12345.0) | (pad == 0.0)).all()) and not bool((spec[:, :, :H] == -12345.0).any())
     # fused min / max = the true extrema of each track's spec
     assert torch.equal(mm[:, 0], spec[:, :, :H].amin(dim=(1, 2))) and torch.equal(mm[:, 1], spec[:, :, :H].amax(dim=(1, 2)))
     for i in (0, n_tr // 2, n_tr - 1):
@@ -719,4 +722,37 @@ def test_baseline_size_image_stage(ctx, golden_dir):
             want = orc.encode_spectrogram_tile(want_img, cmap, 1, 0, 0, tx, ty)[40:]
             assert flat[off * 4:(off + g.width * g.height) * 4].tobytes() == want, (i, tx, ty)
             off += s
+    plan.close()
+
+
+@pytest.mark.parametrize("extra_f32,extra_u16", [(3, 2), (32, 64), (40, 70), (63, 126)])
+def test_foreign_row_pitches_are_never_written_outside_the_row(ctx, extra_f32, extra_u16):
+    """Only rows at exactly th_pitch_f32 / th_pitch_u16 own their padding (include/thesia_amd.h); with any other pitch the
+    rows may be embedded in a caller's wider array, so nothing outside [0, row_elems) may change — and the values inside
+    must not depend on the pitch."""
+    import torch
+    from thesia_amd import _ffi
+    sr, win, hop, n_fft, n = 48000, 2048, 512, 2048, 70_000
+    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    T, H = plan.n_frames(n), plan.height
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    wav = ((torch.rand(n, device=dev, generator=g) - 0.5) * 0.4).contiguous()
+    outs = []
+    for sp, ip in ((ta.pitch_f32(H), ta.pitch_u16(T)), (H + extra_f32, T + extra_u16)):
+        spec = torch.full((T, sp), -12345.0, dtype=torch.float32, device=dev)
+        mm = torch.empty((1, 2), dtype=torch.float32, device=dev)
+        chan = (ta.ChanDesc * 1)(ta.ChanDesc(wav.data_ptr(), spec.data_ptr(), n, T, sp))
+        plan.calc_spec_batch_dev(chan, mm.data_ptr())
+        img = torch.full((H, ip), 0x5a5a, dtype=torch.int16, device=dev)
+        ctx.synchronize()  # the library's stream is not torch's: mm is read on the host next
+        lo, hi = orc.global_db_range(mm[:, 0].cpu().numpy(), mm[:, 1].cpu().numpy(), 100.0)
+        ctx.spec_to_img_batch([_ffi.ImgDesc(spec.data_ptr(), img.data_ptr(), T, H, 0, H, sp, ip)], lo, hi, 258)
+        ctx.synchronize()
+        outs.append((spec.cpu().numpy(), img.cpu().numpy()))
+    (s_lib, i_lib), (s_for, i_for) = outs
+    assert np.array_equal(s_lib[:, :H], s_for[:, :H]) and np.array_equal(i_lib[:, :T], i_for[:, :T])
+    assert (s_for[:, H:] == -12345.0).all() and (i_for[:, T:] == 0x5a5a).all()
+    assert np.isin(s_lib[:, H:], (-12345.0, 0.0)).all() and np.isin(i_lib[:, T:], (0x5a5a, 0)).all()
     plan.close()

@@ -163,17 +163,24 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     for (uint32_t i = 0; i < NST; i++) pairs[i] = *reinterpret_cast<const uint32_t *>(&tile[2 * (wv + 4 * i) + half][tl]);
     // (t is even; a row base is 4-byte aligned when the image base is and the pitch is even: launch-uniform)
     const bool rows_al = (reinterpret_cast<uintptr_t>(job.img) & 3u) == 0 && job.img_pitch % 2 == 0;
+    // Rows at the library's padded pitch (th_pitch_u16): the padding is ours, and the tile holds zeros there (NaN -> 0), so
+    // store the whole last 128-byte line of every row — a partially written line costs HBM a read-modify-write.
+#if defined(TH_EXP_NO_TAILFILL)
+    const uint32_t t_lim = job.n_frames;
+#else
+    const uint32_t t_lim = (job.img_pitch % IMG_TILE_T == 0 && job.img_pitch - job.n_frames < IMG_TILE_T) ? job.img_pitch : job.n_frames;
+#endif
 #pragma unroll
     for (uint32_t i = 0; i < NST; i++) {
         const uint32_t r = r0 + 2 * (wv + 4 * i) + half;
         const uint32_t pair = pairs[i];
         const gptr<uint16_t> rowo = img + (size_t)r * job.img_pitch;
         if (r < out_h) {
-            if (t + 1 < job.n_frames && rows_al) {
+            if (t + 1 < t_lim && rows_al) {
                 *reinterpret_cast<gptr<uint32_t>>(rowo + t) = pair;
             } else {
-                if (t < job.n_frames) rowo[t] = (uint16_t)(pair & 0xffffu);
-                if (t + 1 < job.n_frames) rowo[t + 1] = (uint16_t)(pair >> 16);
+                if (t < t_lim) rowo[t] = (uint16_t)(pair & 0xffffu);
+                if (t + 1 < t_lim) rowo[t + 1] = (uint16_t)(pair >> 16);
             }
         }
     }

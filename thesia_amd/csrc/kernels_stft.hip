@@ -368,7 +368,16 @@ __device__ __forceinline__ void wave_frame(
         cf32 wa[W::NQ][W::R3 - 1], wb[W::NQ][W::R3 - 1];
         if constexpr (!(RES & 4)) W::load_t3_paired(lane, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
         cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
+#if defined(TH_ABL_NO_EX2)
+        // ablation (wrong results): no second exchange
+        for (int q = 0; q < W::NQ; q++)
+            for (int r = 0; r < W::R3; r++) {
+                za[q][r] = z[(W::R3 * q + r) % P];
+                zb[q][r] = z[(W::R3 * (q + W::NQ) + r) % P];
+            }
+#else
         W::read2_paired(lane, za, zb, slab);
+#endif
         wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
         constexpr bool PRELOAD_STW = W::NQ * W::R3 <= 8;  // 16 VGPRs at n_fft = 2048; too many at 4096
         cf32 ws[W::NQ][W::R3];
@@ -432,6 +441,15 @@ __device__ __forceinline__ void wave_frame(
         }
         wave_lds_sync();  // the slab is rewritten by the next frame's pass 1
     }
+#if !defined(TH_EXP_NO_TAILFILL) && !defined(TH_EXP_NOSTORE)
+    // Rows at the library's padded pitch (th_pitch_f32): bin Nc would be the only dword written in its 128-byte line, and
+    // a partially written line costs HBM a read-modify-write (scripts/ubench/row_stores.hip: 3.9 -> 5.4 TB/s for this row
+    // shape).  The padding is ours, so complete the line with zeros.
+    {
+        const uint32_t pad = spec_pitch - (uint32_t)(NC + 1);
+        if (lane - 1u < ((pad < 32u && spec_pitch % 32u == 0) ? pad : 0u)) row[NC + lane] = 0.0f;
+    }
+#endif
     TH_SCHED_BARRIER();
     TH_PROF_MARK(6);
 }

@@ -189,15 +189,23 @@ struct WaveFft {
 
     // pass 1 (Ns = 1, no twiddles): registers -> LDS slab (swizzled)
     static TH_HD void pass1(uint32_t lane, cf32 (&z)[P], cf32 *slab) {
+#if defined(TH_ABL_NO_EX1)
+        return;  // ablation (wrong results): no pass-1 arithmetic output exchange
+#endif
         TH_UNROLL for (int b = 0; b < B1; b++) {
             cf32 v[R1];
             TH_UNROLL for (int r = 0; r < R1; r++) v[r] = z[b + B1 * r];
+#if !defined(TH_ABL_NO_DFT)
             RegDft<R1>::run(v);
+#endif
             const uint32_t jj = lane + 64u * b;
             TH_UNROLL for (int r = 0; r < R1; r++) lds_st(&slab[pad1(jj * R1) + r], v[RegDft<R1>::slot(r)]);  // = pad1(jj*R1 + r)
         }
     }
     static TH_HD void read1(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
+#if defined(TH_ABL_NO_EX1)
+        return;
+#endif
         TH_UNROLL for (int m = 0; m < P; m++) z[m] = lds_ld(&slab[pad1(lane) + 68u * m]);  // = pad1(lane + 64*m)
     }
 
@@ -217,9 +225,16 @@ struct WaveFft {
             const uint32_t jj = lane + 64u * b, k = jj & (NS2 - 1);
             cf32 v[R2];
             TH_UNROLL for (int r = 0; r < R2; r++) v[r] = z[b + B2 * r];
+#if !defined(TH_ABL_NO_DFT)
             RegDft<R2>::run(v);
+#endif
             const uint32_t j0 = (jj - k) * R2 + k;
+#if defined(TH_ABL_NO_EX2)
+            TH_UNROLL for (int r = 0; r < R2; r++) z[b + B2 * r] = v[RegDft<R2>::slot(r)];  // ablation: keep in registers
+            (void)j0;
+#else
             TH_UNROLL for (int r = 0; r < R2; r++) lds_st(&slab[j0 + r * NS2], v[RegDft<R2>::slot(r)]);
+#endif
         }
     }
     static TH_HD void pass2(uint32_t lane, cf32 (&z)[P], const cf32 *t2, cf32 *slab) {
