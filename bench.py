@@ -330,6 +330,23 @@ def main():
                 traffic = json.load(open(tpath)).get("bytes_per_launch")
             except Exception:
                 traffic = None
+        # a measured device-to-device copy on this box in the same run, beside the vendor peak
+        copy_gbs = None
+        try:
+            a_ = torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB
+            b_ = torch.empty_like(a_)
+            for _ in range(2):
+                b_.copy_(a_)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(5):
+                b_.copy_(a_)
+            c1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * a_.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            del a_, b_
+        except Exception:
+            copy_gbs = None
         out = {
             "metric": "STFT frames/sec (whole step: STFT->dB->min/max->u16 image->level-0 RGBA raster), n_fft=2048",
             "value": total_frames * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -346,7 +363,8 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": wl.plan.kernel_name, "avg_launch_ms": stft_ms, "stage_ms_incl_init_and_boundary_frames": stft_stage_ms,
                          "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": interior,
-                         "read_only_frac": interior * 4 * hop / (stft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "read_only_frac": interior * 4 * hop / (stft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": (ach / copy_gbs) if copy_gbs else None},
             # the two other kernels of the step, same definition (algorithmic bytes / HIP-event duration)
             "roofline_other": [
                 {"kernel": "spec_to_img_kernel", "bound": "hbm", "avg_launch_ms": quant_ms,

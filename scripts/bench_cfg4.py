@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 4 (measurement tool): 128-bin mel spectrogram (MFMA filterbank), 32 tracks 44.1 kHz x 60 s,
-n_fft=2048 hop=512 on 1 GPU.  Also the app-default mel count.  KERNEL=1 forces the generic kernel."""
+n_fft=2048 hop=512 on 1 GPU.  Also the app-default mel count.  KERNEL=1 forces the generic kernel, KERNEL=3 the matrix-core mel path."""
 import os
 import sys
 

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../thesia_amd/csrc/stft_wave.h"
+#include "../../thesia_amd/csrc/mel_fuse.h"
 
 using namespace th;
 
@@ -106,4 +107,26 @@ extern "C" __attribute__((visibility("default"))) uint64_t emu_fma_div_mismatche
         if (std::memcmp(&q, &want, 4) != 0 && !(q == 0.0f && want == 0.0f)) bad++;
     }
     return bad;
+}
+
+// Fused mel epilogue (mel_fuse.h tables + stft_wave.h lane functions) on one amplitude row: out[m] = the filter outputs
+// (linear, before dB).  info[0..2] = pieces, slots, groups.  Returns 0, or 1 when the filterbank is not fusable.
+extern "C" __attribute__((visibility("default"))) int emu_mel_fuse(const float *amp, const float *fb, uint32_t n_freq,
+                                                                    uint32_t n_mel, uint32_t max_pieces, float *out,
+                                                                    uint32_t *info) {
+    const MelFuseHost h = build_mel_fuse(fb, n_freq, n_mel, max_pieces);
+    if (!h.ok) return 1;
+    info[0] = h.n_pieces;
+    info[1] = h.n_slots;
+    info[2] = h.n_groups;
+    if (h.words.size() != mel_fuse_words(h.n_slots, h.n_groups)) return -1;
+    const MelFuseTab t = mel_fuse_view(h.words.data(), h.n_slots, h.n_groups);
+    std::vector<cf32> prf(64 * (size_t)h.n_slots);
+    for (uint32_t m = 0; m < n_mel; m++) out[m] = NAN;
+    for (uint32_t l = 0; l < 64; l++) mel_pieces(l, amp, prf.data(), t);
+    for (uint32_t l = 0; l < 64; l++)
+        mel_gather(l, prf.data(), t, [&](uint32_t m, float v) {
+            if (m < n_mel) out[m] = v;
+        });
+    return 0;
 }

@@ -64,3 +64,31 @@ def test_fma_corrected_division_is_exact(emu):
     for b in [100.0, 99.99999, 60.0, 3.0, 1e-3, 2e3] + list(np.exp(rng.uniform(np.log(1e-3), np.log(2e3), 10))):
         bad = lib.emu_fma_div_mismatches(a.ctypes.data_as(C.POINTER(C.c_float)), a.size, np.float32(b))
         assert bad == 0, (b, bad)
+
+
+@pytest.mark.parametrize("sr,n_fft,n_mel", [(44100, 2048, 128), (48000, 2048, 0), (44100, 2048, 0), (48000, 1024, 128),
+                                            (24000, 2048, 80), (48000, 2048, 40), (16000, 1024, 0), (96000, 2048, 256),
+                                            (48000, 2048, 400), (44100, 2048, 17)])
+def test_fused_mel_epilogue_tables(emu, sr, n_fft, n_mel):
+    """mel_fuse.h piece / gather tables + the lane functions of the fused mel epilogue against amp @ fb in f64
+    (spectrogram.rs:207).  n_mel = 0: the reference's default count (src-common/src/lib.rs:91-103)."""
+    fb = orc.calc_mel_fb_default(sr, n_fft) if n_mel == 0 else orc.calc_mel_fb(sr, n_fft, n_mel)
+    fb = np.ascontiguousarray(fb, np.float32)
+    F, M = fb.shape
+    assert F == n_fft // 2 + 1
+    rng = np.random.default_rng(3)
+    f32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    emu.emu_mel_fuse.argtypes = [f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p]
+    info = np.zeros(3, np.uint32)
+    for trial in range(3):
+        # wide dynamic range, like a spectrum: quiet bands next to loud ones
+        amp = (rng.uniform(0, 1, F) * 10.0 ** rng.uniform(-6, 0, F)).astype(np.float32)
+        out = np.empty(M, np.float32)
+        rc = emu.emu_mel_fuse(amp.ctypes.data_as(f32p), fb.ctypes.data_as(f32p), F, M, 512, out.ctypes.data_as(f32p),
+                              info.ctypes.data_as(u32p))
+        assert rc == 0, "filterbank not fusable"  # (needs <= 512 pieces and <= 512 mels; else the plan falls back)
+        want = amp.astype(np.float64) @ fb.astype(np.float64)
+        # every term is non-negative: the sum is well conditioned, f32 accumulation order is the only difference
+        assert np.all(np.abs(out - want) <= 4e-6 * want + 1e-30), np.abs(out / np.maximum(want, 1e-300) - 1).max()
+    # the pieces cost about what the non-zeros do: 2 weights per bin, 4 bins per piece
+    assert info[0] <= F / 4 + M + 2, info

@@ -146,14 +146,18 @@ def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
                                                     (48000, 4096, 1024, 4096, 0), (48000, 1024, 256, 1024, 500),
                                                     (44100, 2048, 512, 2048, 17)])
 def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
-    """The MFMA mel path (wave FFT kernel -> amplitudes -> v_mfma_f32_16x16x4_f32 filterbank) and
-    the generic kernel's banded VALU reduction against the oracle; ragged batch."""
+    """The three mel paths against the oracle on a ragged batch: the filterbank fused into the wave kernel's epilogue
+    (n_fft = 2048), the matrix-core path (wave FFT kernel -> amplitudes -> v_mfma_f32_16x16x4_f32 filterbank) and the
+    generic kernel's banded VALU reduction."""
     want_n_mel = n_mel or orc.mel_default_n_mel(sr, n_fft)
     fb = orc.calc_mel_fb(sr, n_fft, want_n_mel)
     wavs = [synth_track(31 + i, sr, n) for i, n in enumerate((50000, 9000, win // 2, 23456))]
     want = [orc.calc_spec(w, win, hop, n_fft, mel_fb=fb) for w in wavs]
-    fast = "stft_wave_kernel+mel_mfma_kernel" if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
-    for which, name in ((1, "stft_generic_kernel"), (0, fast)):
+    mfma = "stft_wave_kernel+mel_mfma_kernel" if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
+    auto = "stft_wave_kernel(fused mel)" if n_fft == 2048 else mfma
+    for which, name in ((1, "stft_generic_kernel"), (3, mfma), (0, auto)):
+        if which == 3 and name == "stft_generic_kernel":
+            continue  # more than 512 mels: there is no matrix-core path to force
         plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
         if which:
             plan.set_kernel(which)

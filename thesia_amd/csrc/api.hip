@@ -11,6 +11,7 @@
 #include "context.h"
 #include "host_math.h"
 #include "kernels.h"
+#include "mel_fuse.h"
 
 // ------------------------------------------------------------------------------------------ errors
 namespace th {
@@ -301,10 +302,15 @@ void DeviceTable::release() {
 
 bool th_plan::use_wave() const {
     if (kernel_choice == 1) return false;
-    return th::stft_wave_supported(g) && (g.n_mel == 0 || d_fb_pad != nullptr);
+    return th::stft_wave_supported(g) && (g.n_mel == 0 || d_mel_bt != nullptr);
 }
-// mel plans on the wave kernel: amplitude out of the FFT kernel, filterbank on the matrix cores
-bool th_plan::use_mel_mfma() const { return g.n_mel != 0 && use_wave(); }
+// mel plans on the wave kernel: the filterbank fused into the FFT kernel's epilogue where its table fits (n_fft 1024 /
+// 2048 at the default launch shape), else amplitude out of the FFT kernel and the filterbank on the matrix cores
+bool th_plan::use_mel_fused() const {
+    return g.n_mel != 0 && use_wave() && kernel_choice != 3 && d_mel_fuse != nullptr &&
+           th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words);
+}
+bool th_plan::use_mel_mfma() const { return g.n_mel != 0 && use_wave() && !use_mel_fused(); }
 
 static void plan_free(th_plan *p) {
     if (!p) return;
@@ -312,9 +318,10 @@ static void plan_free(th_plan *p) {
     for (hipEvent_t e : p->ev_k1) (void)hipEventDestroy(e);
     if (p->d_wtab) (void)hipFree(p->d_wtab);
     if (p->d_queue_head) (void)hipFree(p->d_queue_head);
-    if (p->d_fb_pad) (void)hipFree(p->d_fb_pad);
-    if (p->d_kb_jlo) (void)hipFree(p->d_kb_jlo);
-    if (p->d_kb_jhi) (void)hipFree(p->d_kb_jhi);
+    if (p->d_mel_bt) (void)hipFree(p->d_mel_bt);
+    if (p->d_mel_band) (void)hipFree(p->d_mel_band);
+    if (p->d_mel_slice) (void)hipFree(p->d_mel_slice);
+    if (p->d_mel_fuse) (void)hipFree(p->d_mel_fuse);
     p->amp_buf.release();
     p->mel_jobs.release();
     p->mel_tile_start.release();
@@ -407,31 +414,67 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
             hi[m] = b;
         }
         if (n_mel <= 512) {
-            // MFMA mel path tables: filterbank zero-padded to [16*KB][16*NT] (NT in {8,16,24,32}) and,
-            // per K block of 16 bins, the range of N tiles (16 mels each) that hold non-zeros
-            const uint32_t nt_need = (uint32_t)((n_mel + 15) / 16);
-            const uint32_t nt = nt_need <= 8 ? 8 : nt_need <= 16 ? 16 : nt_need <= 24 ? 24 : 32;
-            const uint32_t kb_n = (g.n_freq + 15) / 16, ncol = nt * 16;
-            std::vector<float> pad((size_t)kb_n * 16 * ncol, 0.f);
-            std::vector<uint8_t> jlo(kb_n, 0), jhi(kb_n, 0);
-            for (uint32_t f = 0; f < g.n_freq; f++)
-                for (size_t m = 0; m < n_mel; m++) pad[(size_t)f * ncol + m] = p->h_mel_fb[(size_t)f * n_mel + m];
-            for (uint32_t kb = 0; kb < kb_n; kb++) {
-                uint32_t lo_t = nt, hi_t = 0;
-                for (uint32_t f = 16 * kb; f < 16 * kb + 16 && f < g.n_freq; f++)
-                    for (size_t m = 0; m < n_mel; m++)
-                        if (p->h_mel_fb[(size_t)f * n_mel + m] != 0.f) {
-                            lo_t = std::min<uint32_t>(lo_t, (uint32_t)(m / 16));
-                            hi_t = std::max<uint32_t>(hi_t, (uint32_t)(m / 16) + 1);
-                        }
-                jlo[kb] = (uint8_t)(hi_t ? lo_t : 0);
-                jhi[kb] = (uint8_t)hi_t;
+            // MFMA mel path tables (kernels_mel.hip): for every N tile j of 16 mels the band of K blocks (16 bins each)
+            // that hold non-zeros, and the filterbank of those blocks in operand order: lane (kq = lane / 16,
+            // li = lane % 16), step s -> fb[16 kb + 4 kq + s][16 j + li]
+            const uint32_t nt = (uint32_t)((n_mel + 15) / 16);
+            const uint32_t kb_n = (g.n_freq + 15) / 16;
+            std::vector<uint32_t> band(3 * (size_t)nt, 0);
+            std::vector<float> bt;
+            auto fbv = [&](uint32_t f, size_t m) { return (f < g.n_freq && m < n_mel) ? p->h_mel_fb[(size_t)f * n_mel + m] : 0.f; };
+            for (uint32_t j = 0; j < nt; j++) {
+                uint32_t klo = kb_n, khi = 0;
+                for (uint32_t kb = 0; kb < kb_n; kb++) {
+                    bool nz = false;
+                    for (uint32_t f = 16 * kb; f < 16 * kb + 16 && !nz; f++)
+                        for (size_t m = 16 * (size_t)j; m < 16 * (size_t)j + 16 && !nz; m++) nz = fbv(f, m) != 0.f;
+                    if (nz) {
+                        klo = std::min(klo, kb);
+                        khi = kb + 1;
+                    }
+                }
+                if (!khi) klo = 0;
+                band[3 * j] = klo;
+                band[3 * j + 1] = khi;
+                band[3 * j + 2] = (uint32_t)(bt.size() / 256);
+                for (uint32_t kb = klo; kb < khi; kb++)
+                    for (uint32_t lane = 0; lane < 64; lane++)
+                        for (uint32_t st = 0; st < 4; st++) bt.push_back(fbv(16 * kb + 4 * (lane >> 4) + st, 16 * (size_t)j + (lane & 15u)));
             }
+            p->mel_zero_block = (uint32_t)(bt.size() / 256);
+            bt.insert(bt.end(), 256, 0.f);
             p->mel_kblocks = kb_n;
             p->mel_ntiles = nt;
-            rc = up((void **)&p->d_fb_pad, pad.data(), pad.size() * sizeof(float));
-            if (rc == TH_OK) rc = up((void **)&p->d_kb_jlo, jlo.data(), jlo.size());
-            if (rc == TH_OK) rc = up((void **)&p->d_kb_jhi, jhi.data(), jhi.size());
+            // slices of the tile range (grid y): contiguous, about equal numbers of 4-K-block groups
+#if !defined(TH_MEL_SLICES)
+#define TH_MEL_SLICES 6
+#endif
+            std::vector<uint32_t> slice{0};
+            {
+                uint64_t total = 0;
+                for (uint32_t j = 0; j < nt; j++) total += (band[3 * j + 1] - band[3 * j] + 3) / 4 + 1;  // + epilogue
+                const uint32_t want = std::min<uint32_t>(TH_MEL_SLICES, nt);
+                uint64_t acc_g = 0;
+                for (uint32_t j = 0; j < nt; j++) {
+                    acc_g += (band[3 * j + 1] - band[3 * j] + 3) / 4 + 1;
+                    if (slice.size() < want && acc_g * want >= total * slice.size() && j + 1 < nt) slice.push_back(j + 1);
+                }
+                slice.push_back(nt);
+            }
+            p->mel_slices = (uint32_t)slice.size() - 1;
+            rc = up((void **)&p->d_mel_bt, bt.data(), bt.size() * sizeof(float));
+            if (rc == TH_OK) rc = up((void **)&p->d_mel_band, band.data(), band.size() * sizeof(uint32_t));
+            if (rc == TH_OK) rc = up((void **)&p->d_mel_slice, slice.data(), slice.size() * sizeof(uint32_t));
+        }
+        if (rc == TH_OK && th::stft_wave_supported(g)) {
+            // fused mel epilogue of the wave kernel: piece / gather tables, when the filterbank has the expected structure
+            const th::MelFuseHost mf = th::build_mel_fuse(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, th::stft_wave_mel_max_pieces(g));
+            if (mf.ok) {
+                p->mel_fuse_words = (uint32_t)mf.words.size();
+                p->mel_fuse_slots = mf.n_slots;
+                p->mel_fuse_groups = mf.n_groups;
+                rc = up((void **)&p->d_mel_fuse, mf.words.data(), mf.words.size() * sizeof(uint32_t));
+            }
         }
         if (rc == TH_OK) rc = up((void **)&p->d_mel_fb, p->h_mel_fb.data(), p->h_mel_fb.size() * sizeof(float));
         if (rc == TH_OK) rc = up((void **)&p->d_mel_lo, lo.data(), lo.size() * sizeof(uint32_t));
@@ -468,9 +511,9 @@ TH_API int th_plan_dims(const th_plan *p, size_t *n_freq, size_t *height) {
 TH_API int th_plan_set_kernel(th_plan *p, int which) {
     TH_TRY
     TH_REQUIRE(p, "plan is NULL");
-    // bits 0-7: 0 auto, 1 generic, 2 wave;  bits 8-15 (tuning): waves per workgroup of the wave kernel
+    // bits 0-7: 0 auto, 1 generic, 2 wave, 3 wave + matrix-core mel;  bits 8-15 (tuning): waves per workgroup of the wave kernel
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 2, "kernel selector must be 0, 1 or 2");
+    TH_REQUIRE(k >= 0 && k <= 3, "kernel selector must be 0, 1, 2 or 3");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     p->kernel_choice = k;
@@ -482,6 +525,7 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
 
 TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (!p) return "";
+    if (p->use_mel_fused()) return "stft_wave_kernel(fused mel)";
     if (p->use_mel_mfma()) return "stft_wave_kernel+mel_mfma_kernel";
     return p->use_wave() ? "stft_wave_kernel" : "stft_generic_kernel";
 }
@@ -498,8 +542,8 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     TH_REQUIRE(n_chan < (1u << 24), "too many channels");
     th_ctx *c = p->ctx;
     const bool wave = p->use_wave();
-    const bool mel_mfma = p->use_mel_mfma();
-    if (p->kernel_choice == 2 && !wave)
+    const bool mel_mfma = p->use_mel_mfma(), mel_fused = p->use_mel_fused();
+    if (p->kernel_choice >= 2 && !wave)
         return fail(TH_ERR_UNSUPPORTED, "the wave kernel covers n_fft in {1024, 2048, 4096} (mel: n_mel <= 512)");
     StftGeom g = p->g;       // main launch
     StftGeom ge = p->g;      // edge launch (generic kernel)
@@ -614,14 +658,23 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     const size_t slot = (size_t)(p->timed_launches % th_plan::TIMER_SLOTS);
     if (timed) TH_HIP(hipEventRecord(p->ev_k0[slot], c->stream));
     if (wave) {
+        th::WaveOut wo;
+        wo.mode = mel_mfma ? 1 : (mel_fused ? 2 : 0);
+        if (mel_fused) {
+            wo.mel_tab = p->d_mel_fuse;
+            wo.mel_words = p->mel_fuse_words;
+            wo.mel_slots = p->mel_fuse_slots;
+            wo.mel_groups = p->mel_fuse_groups;
+            wo.n_mel = g.n_mel;
+        }
         TH_HIP(launch_stft_wave(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                 (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, d_minmax, p->d_queue_head,
-                                c->n_cu, waves, mel_mfma, c->stream));
+                                c->n_cu, waves, wo, c->stream));
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
         if (mel_mfma)
             TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
-                                   (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, p->mel_kblocks, amp_pitch, p->d_fb_pad,
-                                   p->mel_ntiles, p->d_kb_jlo, p->d_kb_jhi, g.n_mel, d_minmax, c->stream));
+                                   (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_bt, p->d_mel_band,
+                                   p->d_mel_slice, p->mel_slices, p->mel_zero_block, g.n_mel, d_minmax, c->stream));
         if (!edge.empty())  // boundary frames: generic kernel (reflect padding; mel reduction included)
             TH_HIP(launch_stft_generic(ge, (const ChanJob *)p->edge_jobs.dptr, (const uint32_t *)p->edge_tile_start.dptr,
                                        (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, p->d_mel_fb,

@@ -60,7 +60,7 @@ struct th_plan {
     th_ctx *ctx = nullptr;
     uint32_t sr = 0;
     int freq_scale = 0;
-    int kernel_choice = 0;  // 0 auto, 1 generic, 2 wave
+    int kernel_choice = 0;  // 0 auto, 1 generic, 2 wave, 3 wave with the matrix-core mel kernel (no fused epilogue)
     int wave_waves = 0;     // tuning: waves per workgroup of the wave kernel (0 = default)
     int wave_chunk = 0;     // tuning: frames per chunk of the wave kernel (0 = default)
     // th_plan_time_kernel: a ring of event pairs around the STFT kernel launch (no synchronisation while recording)
@@ -77,13 +77,18 @@ struct th_plan {
     float *d_mel_fb = nullptr;
     uint32_t *d_mel_lo = nullptr, *d_mel_hi = nullptr;
     std::vector<float> h_mel_fb;
-    // MFMA mel path: zero-padded filterbank [16*mel_kblocks][16*mel_ntiles], per-K-block band of N tiles
-    float *d_fb_pad = nullptr;
-    uint8_t *d_kb_jlo = nullptr, *d_kb_jhi = nullptr;
-    uint32_t mel_kblocks = 0, mel_ntiles = 0;
+    // MFMA mel path: filterbank packed per (N tile of 16 mels, K block of 16 bins) in operand order (256 floats per
+    // block, band blocks only, + one all-zero block), per-tile band {klo, khi, first block}
+    float *d_mel_bt = nullptr;
+    uint32_t *d_mel_band = nullptr, *d_mel_slice = nullptr;  // + slices of the tile range with ~equal K-group counts
+    uint32_t mel_kblocks = 0, mel_ntiles = 0, mel_zero_block = 0, mel_slices = 0;
     th::DeviceTable amp_buf, mel_jobs, mel_tile_start;  // amplitude scratch + job tables of mel_mfma_kernel
     size_t amp_zeroed = 0;                               // bytes of amp_buf known to be zero-initialised
-    bool use_mel_mfma() const;
+    bool use_mel_mfma() const;   // mel plan: amplitude rows + mel_mfma_kernel
+    bool use_mel_fused() const;  // mel plan: filterbank fused into the wave kernel's epilogue (mel_fuse.h)
+    // fused mel epilogue: device copy of the mel_fuse.h word table
+    uint32_t *d_mel_fuse = nullptr;
+    uint32_t mel_fuse_words = 0, mel_fuse_slots = 0, mel_fuse_groups = 0;
     th::DeviceTable jobs, tile_start;            // main launch (wave kernel, or generic for everything)
     th::DeviceTable edge_jobs, edge_tile_start;  // boundary frames handed to the generic kernel
 };

@@ -22,10 +22,21 @@ hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const u
 
 bool stft_wave_supported(const StftGeom &g);
 int stft_wave_default_waves(const StftGeom &g);
+// What the wave kernel writes: dB rows of the linear spectrum, linear amplitude rows (first half of the matrix-core
+// mel path), or dB rows of the mel spectrum with the filterbank fused into the epilogue (mel_fuse.h tables).
+struct WaveOut {
+    int mode = 0;                     // 0 dB linear, 1 amplitude, 2 fused mel
+    const uint32_t *mel_tab = nullptr;  // DEVICE: mel_fuse.h word table
+    uint32_t mel_words = 0, mel_slots = 0, mel_groups = 0, n_mel = 0;
+};
+// pieces the per-wave (r, f) buffer of the fused mel epilogue can hold for this n_fft (0: not supported), and whether
+// the launch shape leaves room in LDS for a table of `words`
+uint32_t stft_wave_mel_max_pieces(const StftGeom &g);
+bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words);
 // waves: waves per workgroup (4, 8, 12 or 16; <= 0 selects the default for this n_fft)
 hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                             uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
-                            uint32_t *d_queue_head, uint32_t n_cu, int waves, bool amp, hipStream_t s);
+                            uint32_t *d_queue_head, uint32_t n_cu, int waves, const WaveOut &out, hipStream_t s);
 
 // ---- kernels_mel.hip: mel filterbank contraction on the matrix cores (spectrogram.rs:207)
 struct MelJob {
@@ -33,11 +44,14 @@ struct MelJob {
     float *spec;       // n_frames x spec_pitch dB mel spectrogram
     uint32_t f_begin, f_end, spec_pitch, mm_index;
 };
-constexpr uint32_t MEL_TILE_FRAMES = 64;  // 4 waves x 16 frames per workgroup
+#if !defined(TH_MEL_MT)
+#define TH_MEL_MT 2
+#endif
+constexpr int MEL_MT = TH_MEL_MT;                         // 16-frame row tiles per wave
+constexpr uint32_t MEL_TILE_FRAMES = 64 * MEL_MT;         // 4 waves x MEL_MT x 16 frames per workgroup
 hipError_t launch_mel_mfma(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
-                           uint32_t n_kblocks, uint32_t amp_pitch, const float *d_fb_pad, uint32_t n_ntiles,
-                           const uint8_t *d_kb_jlo, const uint8_t *d_kb_jhi, uint32_t n_mel, float *d_minmax,
-                           hipStream_t s);
+                           uint32_t amp_pitch, const float *d_bt, const uint32_t *d_tile_band, const uint32_t *d_slice_start,
+                           uint32_t n_slices, uint32_t zero_block, uint32_t n_mel, float *d_minmax, hipStream_t s);
 
 // ---- kernels_image.hip
 struct ImgJob {  // device-visible copy of th_img_desc

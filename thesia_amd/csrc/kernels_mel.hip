@@ -6,17 +6,16 @@
 // This is the path's one genuine dense contraction.  It runs on `v_mfma_f32_16x16x4_f32` (f32 in,
 // f32 accumulate: bit-for-bit an fmaf chain, no reduced-precision shortcut — gfx950 has no xf32).
 //
-// Shape per workgroup: 4 waves x 16 frames = 64 frames, all n_mel columns (NT tiles of 16 mels,
-// accumulators in registers: 4*NT VGPRs).  K (= frequency bins) is walked in blocks of 16:
+// Shape per workgroup: 4 waves x 16 frames = 64 frames; a wave computes all mel tiles (16 mels each) of its 16
+// frames, one tile at a time (4 accumulator VGPRs).  K (= frequency bins) is walked in blocks of 16:
 //   A operand: every lane loads ONE float4 of its frame row per K block (16 rows x 64 B per
 //              wave-instruction); MFMA step s of the block uses element s, i.e. the block's 16 bins
 //              are consumed in the order {s, 4+s, 8+s, 12+s} — a permutation of k, which a sum
 //              does not care about — so no register shuffling is needed to feed the 16x16x4 shape.
-//   B operand: filterbank values straight from L2 (the zero-padded table is <= 2 MB and shared by
-//              every workgroup), one dword per lane per MFMA.
-//   Band structure: a mel filter is a triangle, so for K block kb only the N tiles
-//              [jlo[kb], jhi[kb]) hold non-zeros (≈ 1/7 of the dense product at 128 mels);
-//              everything else is skipped with wave-uniform branches.
+//   B operand: the filterbank repacked per (tile, K block) in exactly the operand order, one 16-byte load per lane
+//              per K block (1 KB contiguous per wave), L2-resident (80 KB at 128 mels, ~250 KB at 370).
+//   Band structure: a mel filter is a triangle, so tile j only needs the K blocks [klo_j, khi_j)
+//              (≈ 1/7 of the dense product at 128 mels).
 // Epilogue: 20*log10 via v_log_f32, store, min/max, one atomic pair per workgroup.
 // Input is the linear amplitude written by stft_wave_kernel<..., AMP = true> (columns >= n_freq of
 // the amplitude buffer are zero-filled once, so the padded K tail multiplies 0 * 0).
@@ -52,66 +51,122 @@ __device__ __forceinline__ void mel_atomic_max(float *addr, float v) {
     else atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 
-template <int NT>
+// One wave = MEL_MT x 16 frames x all mel tiles (the MEL_MT row tiles share every B load).  Tile-outer / band-inner: for N tile j only the K blocks [klo_j, khi_j) hold
+// non-zeros, so the inner loop is branch-free and is unrolled MEL_UNROLL K blocks deep with every load of the group
+// issued before its first MFMA (the first version walked K outside with a wave-uniform band test per tile and exposed
+// one HBM + one L2 latency per K block: 0.29 ms for config 4 where the amplitude stream alone takes 0.14 ms).
+// B comes from a packed table: block (j, kb) = 64 lanes x 4 steps, laid out so that a lane's four B values are ONE
+// 16-byte load and a wave's load is 1 KB contiguous; one all-zero block at index `zero_block` pads ragged groups.
+// The amplitude rows of a band's first K blocks were read a moment ago as the previous tile's last ones (adjacent
+// triangles overlap), so the ~1.2x re-read is served by L1/L2.
+constexpr int MEL_UNROLL = 4;                       // K blocks per group = one 256-byte span of every row
+constexpr int MEL_LDS_PITCH = 16 * MEL_UNROLL + 4;  // floats per row of the transpose tile
+__device__ __forceinline__ void mel_wave_sync() {   // LDS hand-over inside one wave (no workgroup barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __global__ __launch_bounds__(256) void mel_mfma_kernel(const MelJob *__restrict__ jobs,
                                                        const uint32_t *__restrict__ tile_start, uint32_t n_jobs,
-                                                       uint32_t n_kblocks, uint32_t amp_pitch,
-                                                       const float *__restrict__ fb_pad,
-                                                       const uint8_t *__restrict__ kb_jlo,
-                                                       const uint8_t *__restrict__ kb_jhi, uint32_t n_mel,
+                                                       uint32_t amp_pitch, const float *__restrict__ bt,
+                                                       const uint32_t *__restrict__ tile_band,
+                                                       const uint32_t *__restrict__ slice_start,
+                                                       uint32_t zero_block, uint32_t n_mel,
                                                        float *__restrict__ minmax) {
-    constexpr uint32_t NCOL = NT * 16;  // columns of the zero-padded filterbank
     __shared__ float red[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t ji = mel_find_job(tile_start, n_jobs, blockIdx.x);
     const MelJob job = jobs[ji];
-    const uint32_t frame0 = job.f_begin + (blockIdx.x - tile_start[ji]) * MEL_TILE_FRAMES + wave * 16;
+    const uint32_t frame0 = job.f_begin + (blockIdx.x - tile_start[ji]) * MEL_TILE_FRAMES + wave * (16 * MEL_MT);
     const uint32_t kq = lane >> 4, li = lane & 15u;
     // rows past the end of the range are clamped for the loads and masked at the store
-    const uint32_t my_row = min(frame0 + li, job.f_end - 1);
-    const gptr<const float> arow = as_global(job.amp) + (size_t)my_row * amp_pitch + 4 * kq;
-    const gptr<const float> fb = as_global(fb_pad) + (size_t)(4 * kq) * NCOL + li;
-
-    f32x4 acc[NT];
+    // A operand: the MFMA layout wants lane (kq, li) to hold row li — read straight from memory that is 16 different
+    // rows x 16 B per quarter wave, 64 cache-line accesses per load instruction, and the L1 tag rate (not HBM) bounds
+    // the kernel (measured: loads alone 0.24 ms for 0.7 GB).  So the rows are loaded COALESCED (16 lanes x 16 B = 256
+    // contiguous bytes of one row, 4 rows per instruction) and transposed through a wave-private LDS tile:
+    // [MEL_MT][16 rows][64 + 4 floats] (the 4-float pad makes both the b128 writes and the b128 reads conflict-free).
+    __shared__ __attribute__((aligned(16))) float lds_a[4][MEL_MT][16][MEL_LDS_PITCH];
+    const uint32_t lr = lane >> 4, lq = lane & 15u;  // coalesced load: row 4c + lr of the tile, 16-byte column lq
+    gptr<const float> ldrow[MEL_MT][4];
 #pragma unroll
-    for (int j = 0; j < NT; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MEL_MT; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            ldrow[t][c] = as_global(job.amp) + (size_t)min(frame0 + 16 * t + 4 * c + lr, job.f_end - 1) * amp_pitch;
+    const gptr<const f32x4> bl = reinterpret_cast<gptr<const f32x4>>(as_global(bt)) + lane;
+    const gptr<float> spec = as_global(job.spec);
+    float lmin = __builtin_inff(), lmax = -__builtin_inff();
 
     if (frame0 < job.f_end) {  // wave-uniform: this wave has at least one frame
-        for (uint32_t kb = 0; kb < n_kblocks; kb++) {
-            const float4 a = *reinterpret_cast<gptr<const float4>>(arow + 16 * kb);
-            const uint32_t jlo = kb_jlo[kb], jhi = kb_jhi[kb];
-            const gptr<const float> bk = fb + (size_t)(16 * kb) * NCOL;
+        // blockIdx.y = slice of the mel tiles (slices hold about equal numbers of K groups): with every workgroup
+        // walking all tiles a workgroup lives ~100 us (its groups are one dependent load latency each) and the 1.26
+        // rounds the grid needs cost two; short work units fill the tail
+        const uint32_t j0 = slice_start[blockIdx.y], j1 = slice_start[blockIdx.y + 1];
+        for (uint32_t j = j0; j < j1; j++) {
+            const uint32_t klo = tile_band[3 * j], khi = tile_band[3 * j + 1], off = tile_band[3 * j + 2];  // scalar loads
+            f32x4 acc[MEL_MT];
 #pragma unroll
-            for (int j = 0; j < NT; j++) {
-                if ((uint32_t)j >= jlo && (uint32_t)j < jhi) {  // wave-uniform band test
-                    const gptr<const float> bp = bk + 16 * j;
-                    const float b0 = bp[0], b1 = bp[NCOL], b2 = bp[2 * NCOL], b3 = bp[3 * NCOL];
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b2, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b3, acc[j], 0, 0, 0);
+            for (int t = 0; t < MEL_MT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (uint32_t kb = klo; kb < khi; kb += MEL_UNROLL) {
+                f32x4 raw[MEL_MT][4], b[MEL_UNROLL];
+                // 64 floats of every row starting at K block kb; a ragged last group runs into the next K blocks (or, at
+                // the end of the row, is clamped): whatever it reads there meets the all-zero B block
+                const uint32_t col = min(16 * kb + 4 * lq, amp_pitch - 4);
+#pragma unroll
+                for (int t = 0; t < MEL_MT; t++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) raw[t][c] = *reinterpret_cast<gptr<const f32x4>>(ldrow[t][c] + col);
+#pragma unroll
+                for (int u = 0; u < MEL_UNROLL; u++) {
+                    const uint32_t kbi = kb + u < khi ? off + (kb + u - klo) : zero_block;  // wave-uniform
+                    b[u] = bl[(size_t)kbi * 64];
+                }
+                mel_wave_sync();  // the previous group's reads of the tile are done
+#pragma unroll
+                for (int t = 0; t < MEL_MT; t++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) *reinterpret_cast<f32x4 *>(&lds_a[wave][t][4 * c + lr][4 * lq]) = raw[t][c];
+                mel_wave_sync();
+                f32x4 a[MEL_MT][MEL_UNROLL];
+#pragma unroll
+                for (int t = 0; t < MEL_MT; t++)
+#pragma unroll
+                    for (int u = 0; u < MEL_UNROLL; u++) a[t][u] = *reinterpret_cast<const f32x4 *>(&lds_a[wave][t][li][16 * u + 4 * kq]);
+#if defined(TH_MEL_EXP_NOMFMA)
+#pragma unroll
+                for (int u = 0; u < MEL_UNROLL; u++)  // experiment: loads only
+#pragma unroll
+                    for (int t = 0; t < MEL_MT; t++) acc[t][0] += a[t][u].x * b[u].x + a[t][u].y * b[u].y + a[t][u].z * b[u].z + a[t][u].w * b[u].w;
+                continue;
+#endif
+#pragma unroll
+                for (int u = 0; u < MEL_UNROLL; u++) {
+#pragma unroll
+                    for (int t = 0; t < MEL_MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u].x, b[u].x, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MEL_MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u].y, b[u].y, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MEL_MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u].z, b[u].z, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MEL_MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u].w, b[u].w, acc[t], 0, 0, 0);
                 }
             }
-        }
-    }
-
-    // C/D layout of the 16x16 shapes: col = lane & 15, row = 4 * (lane >> 4) + r
-    float lmin = __builtin_inff(), lmax = -__builtin_inff();
-    const gptr<float> spec = as_global(job.spec);
+            // C/D layout of the 16x16 shapes: col = lane & 15, row = 4 * (lane >> 4) + r
+            const uint32_t m = 16 * j + li;
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-        const uint32_t m = 16 * j + li;
+            for (int t = 0; t < MEL_MT; t++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t f = frame0 + 4 * kq + r;
-            if (f < job.f_end && m < n_mel) {
-                // dB_from_amp (decibel.rs:179-202): 20*log10(x); x = +0 -> -inf
-                const float d = 6.02059991327962390f * __builtin_amdgcn_logf(acc[j][r]);
-                spec[(size_t)f * job.spec_pitch + m] = d;
-                lmin = fminf(lmin, d);
-                lmax = fmaxf(lmax, d);
-            }
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t f = frame0 + 16 * t + 4 * kq + r;
+                    if (f < job.f_end && m < n_mel) {
+                        // dB_from_amp (decibel.rs:179-202): 20*log10(x); x = +0 -> -inf
+                        const float d = 6.02059991327962390f * __builtin_amdgcn_logf(acc[t][r]);
+                        spec[(size_t)f * job.spec_pitch + m] = d;
+                        lmin = fminf(lmin, d);
+                        lmax = fmaxf(lmax, d);
+                    }
+                }
         }
     }
     if (minmax != nullptr) {
@@ -138,22 +193,12 @@ __global__ __launch_bounds__(256) void mel_mfma_kernel(const MelJob *__restrict_
 }
 
 hipError_t launch_mel_mfma(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
-                           uint32_t n_kblocks, uint32_t amp_pitch, const float *d_fb_pad, uint32_t n_ntiles,
-                           const uint8_t *d_kb_jlo, const uint8_t *d_kb_jhi, uint32_t n_mel, float *d_minmax,
-                           hipStream_t s) {
-    if (!n_tiles) return hipSuccess;
-#define TH_MEL_CASE(NT)                                                                                             \
-    if (n_ntiles <= (NT)) {                                                                                         \
-        hipLaunchKernelGGL(mel_mfma_kernel<NT>, dim3(n_tiles), dim3(256), 0, s, d_jobs, d_tile_start, n_jobs, n_kblocks, \
-                           amp_pitch, d_fb_pad, d_kb_jlo, d_kb_jhi, n_mel, d_minmax);                               \
-        return hipGetLastError();                                                                                   \
-    }
-    TH_MEL_CASE(8)
-    TH_MEL_CASE(16)
-    TH_MEL_CASE(24)
-    TH_MEL_CASE(32)
-#undef TH_MEL_CASE
-    return hipErrorInvalidValue;
+                           uint32_t amp_pitch, const float *d_bt, const uint32_t *d_tile_band, const uint32_t *d_slice_start,
+                           uint32_t n_slices, uint32_t zero_block, uint32_t n_mel, float *d_minmax, hipStream_t s) {
+    if (!n_tiles || !n_slices) return hipSuccess;
+    hipLaunchKernelGGL(mel_mfma_kernel, dim3(n_tiles, n_slices), dim3(256), 0, s, d_jobs, d_tile_start, n_jobs, amp_pitch,
+                       d_bt, d_tile_band, d_slice_start, zero_block, n_mel, d_minmax);
+    return hipGetLastError();
 }
 
 }  // namespace th

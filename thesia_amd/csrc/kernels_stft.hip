@@ -288,14 +288,16 @@ __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_
 // RES: which per-lane constant tables the caller keeps resident in registers instead of re-reading them from
 // LDS every frame (bit 0 window, 1 pass-2 twiddles, 2 pass-3 twiddles, 3 split twiddles; 2 and 3 only on the
 // mirror-local path).  Worth it when fewer waves per SIMD leave the VGPRs: LDS is a co-bottleneck of this kernel.
-template <int LOG2_NC, int SHIFT, bool AMP, bool ROTATE, int OFF, int RES>
+template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES>
 __device__ __forceinline__ void wave_frame(
     const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
     uint32_t f, uint32_t f1, gptr<const float> wav, gptr<float> spec, uint32_t spec_pitch, cf32 (&x)[WaveFft<LOG2_NC>::P],
     const cf32 (&rw)[(RES & 1) ? WaveFft<LOG2_NC>::P : 1], const cf32 (&rw2)[(RES & 2) ? WaveFft<LOG2_NC>::R2 - 1 : 1],
     const cf32 (&rwa)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
     const cf32 (&rwb)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
-    const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], cf32 rw_mid, float &lmin, float &lmax TH_PROF_PARAMS) {
+    const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], cf32 rw_mid, float &lmin, float &lmax,
+    const uint32_t *meltab, const WaveOut &wo TH_PROF_PARAMS) {
+    constexpr bool AMP = OUT == 1, MELF = OUT == 2;
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
     TH_PROF_MARK(8);
@@ -326,7 +328,11 @@ __device__ __forceinline__ void wave_frame(
     // re-reads this frame's span, which is in bounds, and the result is never used.
     {
         const uint32_t fn = f + 1 < f1 ? f + 1 : f;
+#if defined(TH_EXP_SMALLWAV)
+        const int64_t e0n = ((int64_t)fn * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left) & 0x1FFE;  // experiment: input from L2
+#else
         const int64_t e0n = (int64_t)fn * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+#endif
         if constexpr (SHIFT == 0) {
             wave_fetch<P, 0>(lane, x, wav, e0n);
         } else if constexpr (ROTATE) {
@@ -389,8 +395,11 @@ __device__ __forceinline__ void wave_frame(
         TH_SCHED_BARRIER();
         TH_PROF_MARK(5);
         if constexpr (!PRELOAD_STW && !(RES & 8)) W::load_stw_paired(lane, ws, stw);
+        float *const slab_f = reinterpret_cast<float *>(slab);
         auto emit = [&](int32_t k, float p) {
-            if constexpr (AMP) {
+            if constexpr (MELF) {
+                slab_f[k] = power_to_amp(p);  // the slab is free after the second exchange: amplitude row for mel_pieces
+            } else if constexpr (AMP) {
                 row[k] = power_to_amp(p);
             } else {
 #if defined(TH_EXP_NOLOG)
@@ -411,7 +420,26 @@ __device__ __forceinline__ void wave_frame(
         };
         if constexpr (RES & 8) W::split_paired_w(lane, za, zb, rws, rw_mid, emit);
         else W::split_paired_w(lane, za, zb, ws, stw[NC / 2], emit);
+        if constexpr (MELF) {
+            // fused mel filterbank (stft_wave.h / mel_fuse.h): pieces of 4 bins -> (r, f) partial sums -> one mel per lane
+            // and group; the (r, f) buffer sits behind the amplitude row in the same slab
+            cf32 *const prf = slab + (NC + 2) / 2;
+            const MelFuseTab mt = mel_fuse_view(meltab, wo.mel_slots, wo.mel_groups);
+            wave_lds_sync();
+            mel_pieces(lane, slab_f, prf, mt);
+            wave_lds_sync();
+            mel_gather(lane, prf, mt, [&](uint32_t m, float v) {
+                if (m < wo.n_mel) {
+                    const float d = amp_to_dB_fast(v);
+                    row[m] = d;
+                    lmin = nmin(lmin, d);
+                    lmax = nmax(lmax, d);
+                }
+            });
+            wave_lds_sync();  // the next frame's pass 1 rewrites the slab
+        }
     } else {
+        static_assert(!MELF, "the fused mel epilogue needs the mirror-local layout");
         W::pass2_dft(lane, z, slab);
         wave_lds_sync();
         TH_SCHED_BARRIER();
@@ -446,8 +474,9 @@ __device__ __forceinline__ void wave_frame(
     // a partially written line costs HBM a read-modify-write (scripts/ubench/row_stores.hip: 3.9 -> 5.4 TB/s for this row
     // shape).  The padding is ours, so complete the line with zeros.
     {
-        const uint32_t pad = spec_pitch - (uint32_t)(NC + 1);
-        if (lane - 1u < ((pad < 32u && spec_pitch % 32u == 0) ? pad : 0u)) row[NC + lane] = 0.0f;
+        const uint32_t height = MELF ? wo.n_mel : (uint32_t)(NC + 1);
+        const uint32_t pad = spec_pitch - height;
+        if (lane - 1u < ((pad < 32u && spec_pitch % 32u == 0) ? pad : 0u)) row[height - 1u + lane] = 0.0f;
     }
 #endif
     TH_SCHED_BARRIER();
@@ -458,11 +487,11 @@ __device__ __forceinline__ void wave_frame(
 // multiple of 128 samples or hop >= n_fft)
 // AMP: store the linear amplitude |X| instead of dB and skip min/max (first half of the mel path;
 // mel_mfma_kernel then applies the filterbank).
-template <int LOG2_NC, int WAVES, int SHIFT, bool AMP, int RES>
+template <int LOG2_NC, int WAVES, int SHIFT, int OUT, int RES>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
-    uint32_t *__restrict__ queue_head) {
+    uint32_t *__restrict__ queue_head, WaveOut wo) {
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
     static_assert(SHIFT >= 0 && SHIFT < P, "shift must leave something to reuse");
@@ -474,6 +503,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     cf32 *t2 = stw + (STW_IN_LDS ? NC : 0);
     cf32 *t3 = t2 + W::T2_LEN;
     cf32 *slabs = t3 + W::T3_LEN;
+    uint32_t *meltab = reinterpret_cast<uint32_t *>(slabs + (size_t)WAVES * W::SLAB_LEN);  // OUT == 2 only
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // wave index is wave-uniform: tell the compiler, so the frame cursor lives in SGPRs / SALU
@@ -483,6 +513,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         if constexpr (STW_IN_LDS) stw[i] = tw[i];
     }
     W::fill_tables(tid, 64 * WAVES, tw, t2, t3);
+    if constexpr (OUT == 2)
+        for (uint32_t i = tid; i < wo.mel_words; i += 64 * WAVES) meltab[i] = wo.mel_tab[i];
     __syncthreads();
 
     cf32 *slab = slabs + (size_t)wave * W::SLAB_LEN;
@@ -508,9 +540,9 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     constexpr bool ROTATE = SHIFT > 0 && P % SHIFT_NZ == 0 && P / SHIFT_NZ <= 4;
     constexpr int NROT = ROTATE ? P / SHIFT : 1;
 #define TH_FRAME(ROT)                                                                                                  \
-    wave_frame<LOG2_NC, SHIFT, AMP, ROTATE, ROTATE ? (ROT) * SHIFT : 0, RES>(                                          \
+    wave_frame<LOG2_NC, SHIFT, OUT, ROTATE, ROTATE ? (ROT) * SHIFT : 0, RES>(                                          \
         g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
-        lmax TH_PROF_ARGS)
+        lmax, meltab, wo TH_PROF_ARGS)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
     cf32 rw[(RES & 1) ? P : 1], rw2[(RES & 2) ? W::R2 - 1 : 1];
     cf32 rwa[(RES & 4) ? W::NQ : 1][W::R3 - 1], rwb[(RES & 4) ? W::NQ : 1][W::R3 - 1], rws[(RES & 8) ? W::NQ : 1][W::R3];
@@ -667,12 +699,12 @@ static size_t wave_lds_bytes() {
     return sizeof(cf32) * ((size_t)(stw_in_lds ? 2 : 1) * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
 }
 
-template <int LOG2_NC, int WAVES, int SHIFT, bool AMP>
+template <int LOG2_NC, int WAVES, int SHIFT, int OUT>
 static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
-    auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, AMP, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
-    const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>();
+                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
+    auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
+    const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>() + (OUT == 2 ? (size_t)out.mel_words * 4 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -680,23 +712,29 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
     const uint32_t wg_needed = (n_tiles + WAVES - 1) / WAVES;
     const uint32_t grid = wg_needed < n_cu ? wg_needed : n_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
-                       d_tw, d_minmax, d_queue_head);
+                       d_tw, d_minmax, d_queue_head, out);
     return hipGetLastError();
 }
 
-// amplitude output (mel path) is only instantiated for the default launch shape of each n_fft
+// amplitude and fused-mel output are only instantiated for the default launch shape of each n_fft (fused mel: n_fft =
+// 2048 only — 1024 has no mirror-local last pass, 4096's 7 waves leave no LDS for the table)
 template <int LOG2_NC, int WAVES, int SHIFT>
 static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, bool amp, hipStream_t s) {
+                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
-        if (amp)
-            return launch_wave_t5<LOG2_NC, WAVES, SHIFT, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
-                                                                       d_tw, nullptr, d_queue_head, n_cu, s);
+        if (out.mode == 1)
+            return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
+                                                                    d_tw, nullptr, d_queue_head, n_cu, out, s);
+        if constexpr (LOG2_NC == 10 && WaveFft<LOG2_NC>::PAIRED) {
+            if (out.mode == 2)
+                return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
+                                                                        d_tw, d_minmax, d_queue_head, n_cu, out, s);
+        }
     }
-    if (amp) return hipErrorInvalidValue;
-    return launch_wave_t5<LOG2_NC, WAVES, SHIFT, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw,
-                                                                d_minmax, d_queue_head, n_cu, s);
+    if (out.mode != 0) return hipErrorInvalidValue;
+    return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw,
+                                                            d_minmax, d_queue_head, n_cu, out, s);
 }
 
 // register-reuse shift of consecutive frames: hop/128 slots when hop is a multiple of 128 samples
@@ -712,7 +750,7 @@ static int wave_shift(const StftGeom &g) {
 template <int LOG2_NC, int WAVES>
 static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, bool amp, hipStream_t s) {
+                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     constexpr int P = WaveFft<LOG2_NC>::P;
     const int sh = wave_shift<LOG2_NC>(g);
     // instantiate the common overlaps only: 75 % (hop = n_fft/4), 50 % and 87.5 %
@@ -720,23 +758,23 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
     if constexpr ((SH) > 0 && (SH) < P)                                                                               \
         if (sh == (SH))                                                                                               \
             return launch_wave_t4<LOG2_NC, WAVES, (SH)>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, \
-                                                                d_minmax, d_queue_head, n_cu, amp, s);
+                                                                d_minmax, d_queue_head, n_cu, out, s);
     TH_SHIFT_CASE(P / 4)
     TH_SHIFT_CASE(P / 2)
     TH_SHIFT_CASE(P / 8)
 #undef TH_SHIFT_CASE
     return launch_wave_t4<LOG2_NC, WAVES, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
-                                                     d_queue_head, n_cu, amp, s);
+                                                     d_queue_head, n_cu, out, s);
 }
 
 template <int LOG2_NC>
 static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, bool amp, hipStream_t s) {
+                                 float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, const WaveOut &out, hipStream_t s) {
 #define TH_WAVE_CASE(WV)                                                                                         \
     case WV:                                                                                                     \
         return launch_wave_t3<LOG2_NC, WV>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, \
-                                                   d_queue_head, n_cu, amp, s);
+                                                   d_queue_head, n_cu, out, s);
     switch (waves) {
         TH_WAVE_CASE(4)
         TH_WAVE_CASE(6)
@@ -754,10 +792,23 @@ static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const
 template <int LOG2_NC>
 static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                 uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
-                                float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, bool amp, hipStream_t s) {
+                                float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves, const WaveOut &out, hipStream_t s) {
     if (waves <= 0) waves = WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES;
     return launch_wave_t2<LOG2_NC>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu,
-                                   waves, amp, s);
+                                   waves, out, s);
+}
+
+uint32_t stft_wave_mel_max_pieces(const StftGeom &g) {
+    if (g.log2_nc != 10) return 0;  // n_fft = 2048: mirror-local layout and room in LDS (1024 is not mirror-local, 4096 is LDS-bound)
+    const uint32_t slab_cf32 = g.nc + g.nc / 16, prf0 = (g.nc + 2) / 2;  // WaveFft::SLAB_LEN, first (r, f) slot
+    const uint32_t cap = (slab_cf32 - prf0) / 64 * 64;                    // whole slots of 64 pieces
+    return cap;
+}
+bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words) {
+    const size_t extra = (size_t)words * 4;
+    if (g.log2_nc != 10) return false;
+    return (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES) &&
+           wave_lds_bytes<10, WaveLaunchCfg<10>::DEFAULT_WAVES>() + extra <= 160 * 1024;
 }
 
 int stft_wave_default_waves(const StftGeom &g) {
@@ -770,13 +821,13 @@ int stft_wave_default_waves(const StftGeom &g) {
 
 hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                             uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
-                            uint32_t *d_queue_head, uint32_t n_cu, int waves, bool amp, hipStream_t s) {
+                            uint32_t *d_queue_head, uint32_t n_cu, int waves, const WaveOut &out, hipStream_t s) {
     if (!n_tiles) return hipSuccess;
     if (!d_queue_head) return hipErrorInvalidValue;
     switch (g.log2_nc) {
-        case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, amp, s);
-        case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, amp, s);
-        case 11: return launch_wave_t<11>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, amp, s);
+        case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
+        case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
+        case 11: return launch_wave_t<11>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
         default: return hipErrorInvalidValue;
     }
 }

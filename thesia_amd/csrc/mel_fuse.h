@@ -1,0 +1,145 @@
+// mel_fuse.h — host-side tables for the mel filterbank fused into the wave STFT kernel's epilogue.
+//
+// Reference: `linspec.dot(&mel_fb)` (src-tauri/src/core/spectrogram.rs:207) with the Slaney filterbank of
+// src-common/src/lib.rs:46-89.  The filters are triangles over consecutive centre frequencies, so every bin k has at
+// most two non-zero weights: the falling edge of filter s-1 and the rising edge of filter s, where "segment" s is the
+// run of bins between centre s and centre s+1.  The product is therefore 2 multiply-adds per bin, not a GEMM:
+//     mel[m] = sum_{k in segment m} amp[k] * rise[k]  +  sum_{k in segment m+1} amp[k] * fall[k]
+// For the 64-lane wave that owns a frame the segments are cut into PIECES of 4 consecutive bins (weights outside the
+// segment are zero), one piece per lane and "slot"; a piece yields the partial sums (r, f), and mel m then adds the r
+// of segment m's pieces and the f of segment m+1's.  Narrow segments (1-2 bins at low frequencies) and wide ones
+// (tens of bins at the top) cost the same per lane this way, which a lane-per-filter loop does not manage.
+//
+// The table is built from the plan's actual filterbank values (not from the centre frequencies), and the structure it
+// relies on is VERIFIED while building: if any bin feeds more than two filters, or two that are not neighbours, or the
+// segments do not ascend, `ok` stays false and the plan uses the matrix-core path instead.
+//
+// Word layout (uint32, copied to LDS by the kernel), S = slots, G = groups of 64 mels:
+//   k0  [64 S]        first bin of piece p = 64 slot + lane (always k0 + 4 <= n_freq)
+//   w   [2 * 256 S]   ((slot * 4 + i) * 64 + lane) * 2 + {0: rise, 1: fall} weight of bin k0 + i      (float bits)
+//   gat [64 G]        mel m = 64 g + lane: first piece | pieces of segment m << 16 | pieces of segment m+1 << 24
+//   gmax[G + (G & 1)] max over the group's lanes of the two piece counts added (the gather loop's trip count)
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace th {
+
+struct MelFuseHost {
+    std::vector<uint32_t> words;
+    uint32_t n_slots = 0, n_groups = 0, n_pieces = 0;
+    bool ok = false;
+};
+
+constexpr uint32_t MEL_PIECE_BINS = 4;
+
+// fb: [n_freq][n_mel] row-major (calc_mel_fb's layout).  max_pieces: capacity of the kernel's per-wave (r, f) buffer.
+inline MelFuseHost build_mel_fuse(const float *fb, uint32_t n_freq, uint32_t n_mel, uint32_t max_pieces) {
+    MelFuseHost out;
+    if (n_freq < MEL_PIECE_BINS || n_mel == 0) return out;
+    auto w = [&](uint32_t k, uint32_t m) { return fb[(size_t)k * n_mel + m]; };
+    // segment of every bin (-1: the bin feeds no filter) and its two weights.  A bin under two filters m, m+1 is on
+    // the falling edge of m and the rising edge of m+1: segment m+1.  A bin under ONE filter m may be filed as
+    // "rising, segment m" or "falling, segment m+1" — its weight reaches mel m either way — whichever keeps the
+    // segments in ascending order.
+    std::vector<int32_t> seg(n_freq, -1);
+    std::vector<float> rise(n_freq, 0.f), fall(n_freq, 0.f);
+    int32_t last_seg = -1;
+    for (uint32_t k = 0; k < n_freq; k++) {
+        int32_t m1 = -1, m2 = -1;
+        for (uint32_t m = 0; m < n_mel; m++) {
+            const float v = w(k, m);
+            if (v == 0.f) continue;
+            if (!(v > 0.f)) return out;  // negative or NaN weight: not a triangle filterbank
+            if (m1 < 0) m1 = (int32_t)m;
+            else if (m2 < 0) m2 = (int32_t)m;
+            else return out;  // three filters at one bin
+        }
+        if (m1 < 0) continue;
+        int32_t s;
+        if (m2 >= 0) {
+            if (m2 != m1 + 1) return out;
+            s = m2;
+            fall[k] = w(k, (uint32_t)m1);
+            rise[k] = w(k, (uint32_t)m2);
+        } else if (last_seg <= m1) {
+            s = m1;
+            rise[k] = w(k, (uint32_t)m1);
+        } else {
+            s = m1 + 1;
+            fall[k] = w(k, (uint32_t)m1);
+        }
+        if (s < last_seg) return out;  // segments must be runs of bins in ascending order
+        last_seg = s;
+        seg[k] = s;
+    }
+    // pieces, segment by segment; pb[s] = first piece of segment s (s = 0 .. n_mel; pb has n_mel + 2 entries)
+    const uint32_t n_seg = n_mel + 1;
+    std::vector<uint32_t> pb(n_seg + 1, 0), pk0;
+    {
+        std::vector<uint32_t> lo(n_seg, n_freq), hi(n_seg, 0);
+        for (uint32_t k = 0; k < n_freq; k++)
+            if (seg[k] >= 0) {
+                lo[seg[k]] = std::min(lo[seg[k]], k);
+                hi[seg[k]] = k + 1;
+            }
+        for (uint32_t s = 0; s < n_seg; s++) {
+            pb[s] = (uint32_t)pk0.size();
+            for (uint32_t k = lo[s]; k < hi[s]; k += MEL_PIECE_BINS) pk0.push_back(k);
+        }
+        pb[n_seg] = (uint32_t)pk0.size();
+    }
+    const uint32_t n_pieces = (uint32_t)pk0.size();
+    if (n_pieces == 0 || n_pieces > max_pieces || n_pieces >= 65536) return out;
+    const uint32_t S = (n_pieces + 63) / 64, G = (n_mel + 63) / 64;
+    if (S > 8 || G > 8) return out;  // MEL_MAX_SLOTS / MEL_MAX_GROUPS of the lane functions (stft_wave.h)
+    std::vector<uint32_t> &t = out.words;
+    t.assign((size_t)64 * S + 512 * S + 64 * G + G + (G & 1), 0);
+    uint32_t *k0 = t.data(), *wt = k0 + 64 * S, *gat = wt + 512 * S, *gmax = gat + 64 * G;
+    // which segment a piece belongs to
+    std::vector<uint32_t> pseg(n_pieces, 0);
+    for (uint32_t s = 0; s < n_seg; s++)
+        for (uint32_t p = pb[s]; p < pb[s + 1]; p++) pseg[p] = s;
+    for (uint32_t p = 0; p < 64 * S; p++) {
+        const uint32_t slot = p / 64, lane = p % 64;
+        if (p >= n_pieces) {  // padding pieces: bins 0..3 against zero weights
+            k0[p] = 0;
+            continue;
+        }
+        const uint32_t first = pk0[p];
+        const uint32_t base = std::min(first, n_freq - MEL_PIECE_BINS);  // keep the 4 reads inside the row
+        k0[p] = base;
+        for (uint32_t i = 0; i < MEL_PIECE_BINS; i++) {
+            const uint32_t k = base + i;
+            const bool mine = k >= first && k < first + MEL_PIECE_BINS && seg[k] == (int32_t)pseg[p];
+            const float wr = mine ? rise[k] : 0.f, wf = mine ? fall[k] : 0.f;
+            const size_t at = ((size_t)(slot * 4 + i) * 64 + lane) * 2;
+            std::memcpy(&wt[at], &wr, 4);
+            std::memcpy(&wt[at + 1], &wf, 4);
+        }
+    }
+    for (uint32_t g = 0; g < G; g++) {
+        uint32_t mx = 0;
+        for (uint32_t lane = 0; lane < 64; lane++) {
+            const uint32_t m = 64 * g + lane;
+            if (m >= n_mel) continue;
+            const uint32_t nr = pb[m + 1] - pb[m], nf = pb[m + 2] - pb[m + 1];
+            if (nr > 255 || nf > 255) {
+                t.clear();
+                return out;
+            }
+            gat[m] = pb[m] | nr << 16 | nf << 24;
+            mx = std::max(mx, nr + nf);
+        }
+        gmax[g] = mx;
+    }
+    out.n_slots = S;
+    out.n_groups = G;
+    out.n_pieces = n_pieces;
+    out.ok = true;
+    return out;
+}
+
+}  // namespace th

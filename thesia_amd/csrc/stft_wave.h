@@ -472,4 +472,94 @@ TH_HD float power_to_amp(float p) {
 #endif
 }
 
+// 20*log10(a) for an amplitude (the fused mel epilogue): a = +0 -> -inf like decibel.rs:189-193
+TH_HD float amp_to_dB_fast(float a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 6.02059991327962390f * __builtin_amdgcn_logf(a);
+#else
+    return 6.02059991327962390f * __builtin_log2f(a);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused mel epilogue (tables: mel_fuse.h).  The wave has written the frame's amplitudes |X[k]| to amp[0 .. n_freq)
+// (floats, in its own exchange slab, which is free after the second exchange).  mel_pieces: lane + 64 slot owns
+// one piece = 4 consecutive bins against (rise, fall) weight pairs -> partial sums (r, f) into prf[].  mel_gather:
+// mel m = lane + 64 g adds the r of segment m's pieces and the f of segment m+1's (consecutive pieces) and hands
+// the filter output to emit(m, value).  The caller synchronises the wave's LDS traffic between the two.
+// ---------------------------------------------------------------------------------------------
+struct MelFuseTab {
+    const uint32_t *k0;    // [64 S]
+    const cf32 *w;         // [256 S]  (rise, fall) of bin k0 + i at (slot * 4 + i) * 64 + lane
+    const uint32_t *gat;   // [64 G]
+    const uint32_t *gmax;  // [G]
+    uint32_t S, G;
+};
+TH_HD MelFuseTab mel_fuse_view(const uint32_t *t, uint32_t S, uint32_t G) {
+    MelFuseTab v;
+    v.k0 = t;
+    v.w = reinterpret_cast<const cf32 *>(t + 64u * S);
+    v.gat = t + 64u * S + 512u * S;
+    v.gmax = v.gat + 64u * G;
+    v.S = S;
+    v.G = G;
+    return v;
+}
+TH_HD constexpr uint32_t mel_fuse_words(uint32_t S, uint32_t G) { return 64u * S + 512u * S + 64u * G + G + (G & 1u); }
+
+// LDS returns in order and a read that is waited for right after its issue exposes the whole LDS latency, so both
+// functions issue their reads in batches: all piece origins first, then two slots' weights and amplitudes at a time;
+// the gather reads four (r, f) pairs per step.  S <= MEL_MAX_SLOTS and G <= MEL_MAX_GROUPS (the host checks).
+constexpr uint32_t MEL_MAX_SLOTS = 8, MEL_MAX_GROUPS = 8;
+TH_HD void mel_pieces(uint32_t lane, const float *amp, cf32 *prf, const MelFuseTab &t) {
+    uint32_t k0[MEL_MAX_SLOTS];
+    TH_UNROLL for (uint32_t s = 0; s < MEL_MAX_SLOTS; s++) k0[s] = t.k0[64u * (s < t.S ? s : t.S - 1u) + lane];
+    TH_UNROLL for (uint32_t s2 = 0; s2 < MEL_MAX_SLOTS; s2 += 2) {
+        if (s2 < t.S) {  // wave-uniform
+            cf32 w[2][4];
+            float a[2][4];
+            uint32_t sj[2];
+            TH_UNROLL for (uint32_t j = 0; j < 2; j++) {
+                sj[j] = s2 + j < t.S ? s2 + j : t.S - 1u;  // odd S: the last slot is simply done twice
+                TH_UNROLL for (uint32_t i = 0; i < 4; i++) w[j][i] = lds_ld(&t.w[(4u * sj[j] + i) * 64u + lane]);
+            }
+            TH_UNROLL for (uint32_t j = 0; j < 2; j++)
+                TH_UNROLL for (uint32_t i = 0; i < 4; i++) a[j][i] = amp[k0[s2 + j] + i];
+            TH_UNROLL for (uint32_t j = 0; j < 2; j++) {
+                cf32 o;
+                o.re = a[j][0] * w[j][0].re + a[j][1] * w[j][1].re + a[j][2] * w[j][2].re + a[j][3] * w[j][3].re;
+                o.im = a[j][0] * w[j][0].im + a[j][1] * w[j][1].im + a[j][2] * w[j][2].im + a[j][3] * w[j][3].im;
+                lds_st(&prf[64u * sj[j] + lane], o);
+            }
+        }
+    }
+}
+
+template <class Emit>
+TH_HD void mel_gather(uint32_t lane, const cf32 *prf, const MelFuseTab &t, Emit emit) {
+    const uint32_t last = 64u * t.S - 1u;
+    uint32_t pk[MEL_MAX_GROUPS];
+    TH_UNROLL for (uint32_t g = 0; g < MEL_MAX_GROUPS; g++) pk[g] = t.gat[64u * (g < t.G ? g : t.G - 1u) + lane];
+    TH_UNROLL for (uint32_t g = 0; g < MEL_MAX_GROUPS; g++) {
+        if (g < t.G) {  // wave-uniform
+            const uint32_t pb = pk[g] & 0xffffu, nr = (pk[g] >> 16) & 0xffu, nrf = nr + (pk[g] >> 24);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t n = __builtin_amdgcn_readfirstlane(t.gmax[g]);
+#else
+            const uint32_t n = t.gmax[g];
+#endif
+            float acc = 0.0f;
+            for (uint32_t i = 0; i < n; i += 4) {
+                cf32 v[4];
+                TH_UNROLL for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t at = pb + i + u;
+                    v[u] = lds_ld(&prf[at < last ? at : last]);
+                }
+                TH_UNROLL for (uint32_t u = 0; u < 4; u++) acc += i + u < nr ? v[u].re : (i + u < nrf ? v[u].im : 0.0f);
+            }
+            emit(64u * g + lane, acc);
+        }
+    }
+}
+
 }  // namespace th
