@@ -15,12 +15,13 @@ dev = torch.device("cuda", 0)
 side = torch.cuda.Stream(dev)
 torch.cuda.set_stream(side)
 ctx = ta.Context(0, side.cuda_stream)
-sr, n_tr, secs = 44100, int(os.environ.get("TRACKS", "32")), 60
+sr, n_tr, secs = int(os.environ.get("SR", "44100")), int(os.environ.get("TRACKS", "32")), 60
+WIN, HOP = int(os.environ.get("WIN", "2048")), int(os.environ.get("HOP", "512"))  # SR=48000 WIN=1920 HOP=480: the app default
 n = sr * secs
 g = torch.Generator(device=dev); g.manual_seed(4)
 wav = (torch.rand((n_tr, n), device=dev, generator=g) * 2 - 1) * 0.25
 for n_mel in (128, 0):
-    plan = ta.Plan(ctx, sr, 2048, 512, 2048, ta.MEL, n_mel)
+    plan = ta.Plan(ctx, sr, WIN, HOP, 2048, ta.MEL, n_mel)
     K = int(os.environ.get("KERNEL", "0"))
     if K:
         plan.set_kernel(K)
@@ -39,7 +40,7 @@ for n_mel in (128, 0):
         ts.append(e0.elapsed_time(e1))
     ms = float(np.median(ts))
     frames = n_tr * T
-    bpf = 4 * 512 + 4 * H
+    bpf = 4 * HOP + 4 * H
     flops = 2.0 * 1025 * H * frames
     print(f"cfg4 mel-{H} ({plan.kernel_name}): {n_tr} tracks x {T} frames: {ms:.3f} ms  {frames / ms / 1e3:.1f} Mframes/s  "
           f"{frames * bpf / ms / 1e6:.0f} GB/s algorithmic ({frames * bpf / ms / 1e6 / 80:.1f}% of 8 TB/s); "

@@ -7,7 +7,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final
 rm -rf "$out"; mkdir -p "$out"
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-single-track > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-single-track > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
+find "$out/trace" -type f ! -name "*kernel_stats.csv" -delete
 scripts/pmc_stft.sh "$out/pmc_stft" > "$out/pmc_stft.log" 2>&1
 TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pmc_img.log" 2>&1
 {
@@ -20,8 +21,8 @@ TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pm
 } > "$out/bench_stft.txt" 2>&1
 python3 scripts/bench_img.py > "$out/bench_img.txt" 2>&1
 python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
-python3 scripts/bench_cfg4.py > "$out/bench_cfg4.txt" 2>&1
-for u in lds_rate valu_rate valu_bank copy_rate; do
+{ python3 scripts/bench_cfg4.py; KERNEL=3 python3 scripts/bench_cfg4.py; SR=48000 WIN=1920 HOP=480 python3 scripts/bench_cfg4.py; } > "$out/bench_cfg4.txt" 2>&1
+for u in lds_rate valu_rate valu_bank copy_rate row_stores; do
   [ -x scripts/ubench/$u ] && timeout 120 scripts/ubench/$u > "$out/ubench_$u.txt" 2>&1
 done
 if [ -f thesia_amd/libthesia_amd_prof.so ]; then

@@ -10,7 +10,7 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS S
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
             "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 ${TH_PMC_SCRIPT:-scripts/bench_stft.py} --reps 3 "$@" > "$out/pass$i.log" 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 ${TH_PMC_SCRIPT:-scripts/bench_stft.py} --reps 3 "$@" > "$out/pass$i.log" 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
@@ -30,3 +30,5 @@ with open(out + "/summary.txt", "w") as fo:
             fo.write(f"  {c:28s} n={len(v):3d} median={v[len(v)//2]:.6g} max={v[-1]:.6g}\n")
 print(open(out + "/summary.txt").read())
 PY
+# the raw per-dispatch tables are large (every torch kernel of the signal generator is in them): keep the summary only
+[ -n "${TH_PMC_KEEP_RAW:-}" ] || rm -rf "$out"/pass*/
