@@ -554,7 +554,14 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     if (wave) {
         uint64_t total = 0;
         for (size_t i = 0; i < n_chan; i++) total += chans[i].n_frames;
-        const uint64_t slots = (uint64_t)c->n_cu * (uint64_t)waves * 2;
+        // about TH_CHUNKS_PER_WAVE chunks per wave (at most 32 frames each): the launch ends when the last chunk does,
+        // so a chunk is the granularity of the load balance, while every chunk costs one full fetch and one atomic on the
+        // queue head (served at ~8 ns each device-wide).  Measured inside bench.py's step: 4 per wave (29 frames)
+        // 0.50-0.515 ms, 6 (19) 0.52, 8 (14) 0.54, 12 (9) 0.69; 32-frame chunks 0.53.
+#if !defined(TH_CHUNKS_PER_WAVE)
+#define TH_CHUNKS_PER_WAVE 4
+#endif
+        const uint64_t slots = (uint64_t)c->n_cu * (uint64_t)waves * TH_CHUNKS_PER_WAVE;
         uint64_t chunk = total / (slots ? slots : 1);
         chunk = chunk < 4 ? 4 : (chunk > 32 ? 32 : chunk);
         g.frames_per_tile = p->wave_chunk > 0 ? (uint32_t)p->wave_chunk : (uint32_t)chunk;
@@ -652,7 +659,9 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
         if (rc == TH_OK) rc = p->edge_tile_start.upload(c->stream, edge_start.data(), edge_start.size() * sizeof(uint32_t));
     }
     if (rc != TH_OK) return rc;
-    TH_HIP(launch_minmax_init(d_minmax, (uint32_t)n_chan, wave ? p->d_queue_head : nullptr, c->stream));
+    // the wave kernel's first chunk per wave is static (chunk = global wave index): the queue starts behind those
+    const uint32_t wave_grid = (uint32_t)std::min<uint64_t>((tiles + waves - 1) / waves, c->n_cu);
+    TH_HIP(launch_minmax_init(d_minmax, (uint32_t)n_chan, wave ? p->d_queue_head : nullptr, wave_grid * (uint32_t)waves, c->stream));
     // optional timing of the dominant kernel alone (th_plan_time_kernel): two events on the launch stream
     const bool timed = p->time_kernel && !p->ev_k0.empty();
     const size_t slot = (size_t)(p->timed_launches % th_plan::TIMER_SLOTS);

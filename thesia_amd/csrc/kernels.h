@@ -12,7 +12,7 @@
 namespace th {
 
 // ---- kernels_stft.hip
-hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queue_head, hipStream_t s);
+hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queue_head, uint32_t queue_init, hipStream_t s);
 hipError_t launch_minmax_reduce(const float *d_minmax, uint32_t n_chan, float *d_out, hipStream_t s);
 size_t stft_generic_lds_bytes(const StftGeom &g);
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,

@@ -30,9 +30,9 @@ __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
     else atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 
-__global__ void minmax_init_kernel(float *minmax, uint32_t n_chan, uint32_t *queue_head) {
+__global__ void minmax_init_kernel(float *minmax, uint32_t n_chan, uint32_t *queue_head, uint32_t queue_init) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && queue_head != nullptr) *queue_head = 0;  // work queue of the wave kernel
+    if (i == 0 && queue_head != nullptr) *queue_head = queue_init;  // work queue of the wave kernel (first chunks are static)
     if (minmax != nullptr && i < n_chan) {
         minmax[2 * i] = __builtin_inff();
         minmax[2 * i + 1] = -__builtin_inff();
@@ -230,11 +230,14 @@ struct FrameCursor {
 // pull the next chunk from the queue; every wave of the grid ends with valid == false
 __device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const ChanJob *__restrict__ jobs,
                                                    const uint32_t *__restrict__ tile_start, uint32_t n_chan,
-                                                   uint32_t n_tiles, uint32_t *__restrict__ queue_head, uint32_t lane) {
+                                                   uint32_t n_tiles, uint32_t *__restrict__ queue_head, uint32_t lane,
+                                                   bool first, uint32_t t_static) {
     FrameCursor c{};
-    uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(queue_head, 1u);
-    t = __builtin_amdgcn_readfirstlane(t);
+    uint32_t t = t_static;  // a wave's first chunk is its global index: no 3072-deep burst on the queue head at start
+    if (!first) {
+        if (lane == 0) t = atomicAdd(queue_head, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+    }
     c.valid = t < n_tiles;
     if (c.valid) {
         const uint32_t chan = find_chan(tile_start, n_chan, t);
@@ -247,15 +250,6 @@ __device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const Chan
         c.fresh = true;
     }
     return c;
-}
-
-__device__ __forceinline__ FrameCursor cursor_next(FrameCursor c, const StftGeom &g, const ChanJob *__restrict__ jobs,
-                                                   const uint32_t *__restrict__ tile_start, uint32_t n_chan,
-                                                   uint32_t n_tiles, uint32_t *__restrict__ queue_head, uint32_t lane) {
-    c.f += 1;
-    c.fresh = false;
-    if (c.f < c.f1) return c;
-    return cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
 }
 
 // frame element 0 sits at signal position f*hop - win/2 - pad_left; the host only hands interior
@@ -561,8 +555,11 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         rw_mid = tw[NC / 2];
     }
     // chunk loop: one queue pull and one full fetch per chunk of up to frames_per_tile consecutive frames
+    bool first_pull = true;
     for (;;) {
-        const FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane);
+        const FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane, first_pull,
+                                            blockIdx.x * WAVES + wave);
+        first_pull = false;
         if (!cur.valid) break;
         if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
             flush_minmax(minmax, mm_slot, lane, lmin, lmax);
@@ -613,11 +610,11 @@ namespace th {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queue_head, hipStream_t s) {
+hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queue_head, uint32_t queue_init, hipStream_t s) {
     if ((!d_minmax || !n_chan) && !d_queue_head) return hipSuccess;
     if (!n_chan) n_chan = 1;
     hipLaunchKernelGGL(minmax_init_kernel, dim3((n_chan + 255) / 256), dim3(256), 0, s, d_minmax, n_chan,
-                       d_queue_head);
+                       d_queue_head, queue_init);
     return hipGetLastError();
 }
 
