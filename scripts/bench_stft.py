@@ -20,6 +20,8 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--nfft", type=int, default=2048)
 ap.add_argument("--win", type=int, default=0)
 ap.add_argument("--hop", type=int, default=0)
+ap.add_argument("--gap-ms", type=float, default=0.0, help="idle time between launches (power-limited kernel: "
+                "back-to-back launches run slower than launches with pauses or lighter kernels in between)")
 ap.add_argument("--noise", action="store_true", help="full-scale white noise instead of the bench's SURVEY 8(d) tracks "
                 "(the kernel is power-limited: noise costs ~30 %% more time for the same work)")
 a = ap.parse_args()
@@ -53,7 +55,10 @@ for K in a.kernel:
         plan.calc_spec_batch_dev(chan, mm.data_ptr())
     torch.cuda.synchronize()
     ts = []
+    import time
     for _ in range(a.reps):
+        if a.gap_ms > 0:
+            time.sleep(a.gap_ms * 1e-3)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         plan.calc_spec_batch_dev(chan, mm.data_ptr())
