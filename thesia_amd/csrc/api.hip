@@ -323,6 +323,7 @@ static void plan_free(th_plan *p) {
     if (p->d_mel_slice) (void)hipFree(p->d_mel_slice);
     if (p->d_mel_fuse) (void)hipFree(p->d_mel_fuse);
     p->amp_buf.release();
+    p->chunk_mm.release();
     p->mel_jobs.release();
     p->mel_tile_start.release();
     if (p->d_window) (void)hipFree(p->d_window);
@@ -561,9 +562,21 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
 #if !defined(TH_CHUNKS_PER_WAVE)
 #define TH_CHUNKS_PER_WAVE 4
 #endif
-        const uint64_t slots = (uint64_t)c->n_cu * (uint64_t)waves * TH_CHUNKS_PER_WAVE;
-        uint64_t chunk = total / (slots ? slots : 1);
-        chunk = chunk < 4 ? 4 : (chunk > 32 ? 32 : chunk);
+        const uint64_t n_waves = (uint64_t)c->n_cu * (uint64_t)waves;
+        uint64_t chunk;
+        if (total <= n_waves * 32) {
+            // small batch (one track ...): one chunk per wave, all of them assigned statically — the kernel then never
+            // touches the queue (3072 waves finding it empty is 25 us of serialised atomics on a 20 us job)
+            chunk = std::max<uint64_t>(1, (total + n_waves - 1) / n_waves);
+            for (;; chunk++) {
+                uint64_t n = 0;
+                for (size_t i = 0; i < n_chan; i++) n += (chans[i].n_frames + chunk - 1) / chunk;
+                if (n <= n_waves || chunk >= 32) break;
+            }
+        } else {
+            chunk = total / (n_waves * TH_CHUNKS_PER_WAVE);
+            chunk = chunk < 12 ? 12 : (chunk > 32 ? 32 : chunk);
+        }
         g.frames_per_tile = p->wave_chunk > 0 ? (uint32_t)p->wave_chunk : (uint32_t)chunk;
     } else {
         g.frames_per_tile = 8;
@@ -676,10 +689,20 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
             wo.mel_groups = p->mel_fuse_groups;
             wo.n_mel = g.n_mel;
         }
+        // min / max: the wave kernel stores one pair per chunk, minmax_chunks_kernel folds them into the channel slots
+        float *chunk_mm = nullptr;
+        if (d_minmax != nullptr && wo.mode != 1 && tiles) {
+            rc = p->chunk_mm.ensure((size_t)tiles * 2 * sizeof(float));
+            if (rc != TH_OK) return rc;
+            chunk_mm = static_cast<float *>(p->chunk_mm.dptr);
+        }
         TH_HIP(launch_stft_wave(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
-                                (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, d_minmax, p->d_queue_head,
+                                (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, chunk_mm, p->d_queue_head,
                                 c->n_cu, waves, wo, c->stream));
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
+        if (chunk_mm)
+            TH_HIP(launch_minmax_chunks((const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
+                                        (uint32_t)jobs.size(), chunk_mm, d_minmax, c->stream));
         if (mel_mfma)
             TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
                                    (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_bt, p->d_mel_band,

@@ -84,6 +84,7 @@ struct th_plan {
     uint32_t mel_kblocks = 0, mel_ntiles = 0, mel_zero_block = 0, mel_slices = 0;
     th::DeviceTable amp_buf, mel_jobs, mel_tile_start;  // amplitude scratch + job tables of mel_mfma_kernel
     size_t amp_zeroed = 0;                               // bytes of amp_buf known to be zero-initialised
+    th::DeviceTable chunk_mm;                            // (min, max) per chunk of the wave kernel's last launch
     bool use_mel_mfma() const;   // mel plan: amplitude rows + mel_mfma_kernel
     bool use_mel_fused() const;  // mel plan: filterbank fused into the wave kernel's epilogue (mel_fuse.h)
     // fused mel epilogue: device copy of the mel_fuse.h word table

@@ -22,6 +22,10 @@ hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const u
 
 bool stft_wave_supported(const StftGeom &g);
 int stft_wave_default_waves(const StftGeom &g);
+// d_minmax of launch_stft_wave is a per-CHUNK (min, max) array (2 floats per tile); launch_minmax_chunks folds it into
+// the per-channel slots afterwards
+hipError_t launch_minmax_chunks(const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, const float *d_chunk_mm,
+                                float *d_minmax, hipStream_t s);
 // What the wave kernel writes: dB rows of the linear spectrum, linear amplitude rows (first half of the matrix-core
 // mel path), or dB rows of the mel spectrum with the filterbank fused into the epilogue (mel_fuse.h tables).
 struct WaveOut {

@@ -220,7 +220,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // A wave's position in the frame stream.  All members are wave-uniform (SGPRs).
 struct FrameCursor {
-    uint32_t f, f1, mm_index, spec_pitch;
+    uint32_t f, f1, mm_index, spec_pitch, t;  // t: chunk index
     gptr<const float> wav;
     gptr<float> spec;
     bool valid;
@@ -244,6 +244,7 @@ __device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const Chan
         c.f = jobs[chan].f_begin + (t - tile_start[chan]) * g.frames_per_tile;
         c.f1 = min(c.f + g.frames_per_tile, jobs[chan].f_end);
         c.mm_index = jobs[chan].mm_index;
+        c.t = t;
         c.spec_pitch = jobs[chan].spec_pitch;
         c.wav = as_global(jobs[chan].wav);
         c.spec = as_global(jobs[chan].spec);
@@ -521,8 +522,6 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     }
 #endif
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
-    uint32_t mm_slot = 0;
-    bool mm_dirty = false;  // a wave that never got a frame must not touch any slot
     const uint32_t lane_wave = lane;
     TH_PROF_DECL();
     // Register rotation instead of register moves: with hop = SHIFT slots, frame f+1 is frame f moved down by
@@ -556,18 +555,15 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     }
     // chunk loop: one queue pull and one full fetch per chunk of up to frames_per_tile consecutive frames
     bool first_pull = true;
+    const bool all_static = gridDim.x * WAVES >= n_tiles;  // every chunk is some wave's first: nobody needs the queue
     for (;;) {
+        if (!first_pull && all_static) break;
         const FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane, first_pull,
                                             blockIdx.x * WAVES + wave);
         first_pull = false;
         if (!cur.valid) break;
-        if (minmax != nullptr && mm_dirty && cur.mm_index != mm_slot) {
-            flush_minmax(minmax, mm_slot, lane, lmin, lmax);
-            lmin = __builtin_inff();
-            lmax = -__builtin_inff();
-        }
-        mm_slot = cur.mm_index;
-        mm_dirty = true;
+        lmin = __builtin_inff();
+        lmax = -__builtin_inff();
         cf32 x[P];  // raw samples of the current frame; the frame body refills it for the next one
         wave_fetch<P, 0>(lane, x, cur.wav, frame_e0(cur, g));
         uint32_t f = cur.f;
@@ -588,9 +584,18 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
                 if (++f >= cur.f1) break;
             }
         }
+        // (min, max) of this chunk: a plain store per chunk, reduced per channel by minmax_chunks_kernel afterwards.
+        // (Float atomics on the channel's slot from every wave are served one at a time, ~8 ns each: 50 us for the
+        // 2800 waves of a single-track launch whose FFT work takes 20.)
+        if (minmax != nullptr) {
+            const float a = wave_min(lmin), b = wave_max(lmax);
+            if (lane == 0) {
+                minmax[2 * (size_t)cur.t] = a;
+                minmax[2 * (size_t)cur.t + 1] = b;
+            }
+        }
     }
 #undef TH_FRAME
-    if (minmax != nullptr && mm_dirty) flush_minmax(minmax, mm_slot, lane, lmin, lmax);
     TH_PROF_FLUSH(lane_wave);
 }
 
@@ -643,6 +648,46 @@ __global__ __launch_bounds__(256) void minmax_reduce_kernel(const float *__restr
 
 hipError_t launch_minmax_reduce(const float *d_minmax, uint32_t n_chan, float *d_out, hipStream_t s) {
     hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(256), 0, s, d_minmax, n_chan, d_out);
+    return hipGetLastError();
+}
+
+// per-channel reduction of the wave kernel's per-chunk (min, max) pairs into the channel slots (which the boundary
+// frames' generic kernel also updates): one wave per interior job
+__global__ __launch_bounds__(256) void minmax_chunks_kernel(const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start,
+                                                            uint32_t n_jobs, const float *__restrict__ chunk_mm,
+                                                            float *__restrict__ minmax) {
+    __shared__ float smn[4], smx[4];
+    const uint32_t j = blockIdx.x, tid = threadIdx.x;
+    const uint32_t t0 = tile_start[j], t1 = tile_start[j + 1];
+    const gptr<const float2> mm = reinterpret_cast<gptr<const float2>>(as_global(chunk_mm));
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    // four independent loads in flight per thread: a long single-track channel (thousands of chunks) is latency-bound
+    for (uint32_t t = t0 + tid; t < t1; t += 4 * 256) {
+        float2 v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) v[u] = mm[min(t + 256u * u, t1 - 1u)];  // clamped repeats do not change min / max
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            mn = nmin(mn, v[u].x);
+            mx = nmax(mx, v[u].y);
+        }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((tid & 63u) == 0) {
+        smn[tid >> 6] = mn;
+        smx[tid >> 6] = mx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        atomic_min_f32(&minmax[2 * jobs[j].mm_index], nmin(nmin(smn[0], smn[1]), nmin(smn[2], smn[3])));
+        atomic_max_f32(&minmax[2 * jobs[j].mm_index + 1], nmax(nmax(smx[0], smx[1]), nmax(smx[2], smx[3])));
+    }
+}
+hipError_t launch_minmax_chunks(const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, const float *d_chunk_mm,
+                                float *d_minmax, hipStream_t s) {
+    if (!n_jobs) return hipSuccess;
+    hipLaunchKernelGGL(minmax_chunks_kernel, dim3(n_jobs), dim3(256), 0, s, d_jobs, d_tile_start, n_jobs, d_chunk_mm, d_minmax);
     return hipGetLastError();
 }
 
