@@ -138,10 +138,12 @@ class Workload:
             ev[1].record()
         # global dB range over every resident spec of every rank (core/mod.rs:169-180), without leaving the device:
         # [min, -max] of this rank -> (N > 1: the path's only exchange step, a 2-float MIN all-reduce) -> clamp
-        self.ctx.minmax_reduce_dev(self.minmax.data_ptr(), self.n_tracks, self.range2.data_ptr())
         if dist is not None:
+            self.ctx.minmax_reduce_dev(self.minmax.data_ptr(), self.n_tracks, self.range2.data_ptr())
             dist.all_reduce(self.range2, op=dist.ReduceOp.MIN)
-        self.ctx.global_db_range_dev(self.range2.data_ptr(), 100.0, self.range_db.data_ptr())
+            self.ctx.global_db_range_dev(self.range2.data_ptr(), 100.0, self.range_db.data_ptr())
+        else:  # one GPU: reduce + clamp in one launch
+            self.ctx.minmax_reduce_range_dev(self.minmax.data_ptr(), self.n_tracks, 100.0, self.range_db.data_ptr())
         if record:
             ev[2].record()
         self.ctx.spec_to_img_batch_ranged(self.imgd, self.range_db.data_ptr(), 258)
@@ -311,6 +313,23 @@ def main():
         single = {"workload": "cfg2: 1 track 48 kHz mono 60 s, n_fft=2048 hop=512, dB + colormap raster",
                   "frames": w1.frames, "ms_per_step": d1 * 1e3, "frames_per_s": w1.frames / d1,
                   "stft_kernel_us": k1 * 1e3, "stft_frames_per_s": w1.frames / (k1 * 1e-3)}
+        # the same step replayed from a HIP graph (th_ctx_capture_*): eight small launches, launch-bound
+        try:
+            w1.plan.time_kernel(False)
+            graph = ctx.capture(lambda: w1.step(None))
+            for _ in range(3):
+                graph.launch()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                graph.launch()
+            torch.cuda.synchronize(dev)
+            dg = (time.perf_counter() - t1) / reps
+            single["ms_per_step_hip_graph"] = dg * 1e3
+            single["frames_per_s_hip_graph"] = w1.frames / dg
+            graph.close()
+        except Exception as e:  # report, do not fail the bench line
+            single["hip_graph_error"] = str(e)[:200]
         del w1
 
     if rank == 0:

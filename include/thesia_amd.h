@@ -127,6 +127,17 @@ TH_API int th_ctx_create(int device, void *hip_stream, th_ctx **out);
 TH_API int th_ctx_create_ex(int device, void *hip_stream, int use_given_stream, th_ctx **out);
 TH_API int th_ctx_destroy(th_ctx *ctx);
 TH_API int th_ctx_synchronize(th_ctx *ctx);
+/* HIP-graph capture of a sequence of this library's stream-ordered calls on the context's stream (a launch-bound
+ * sequence like the 8 small kernels of a single-track update: STFT -> range -> quantise -> raster).  Run the sequence
+ * once normally first: descriptor tables and scratch buffers are uploaded / sized on first use, which needs stream
+ * synchronisation and is refused while capturing (the call then fails with TH_ERR_HIP and the capture must still be
+ * ended).  The graph replays the same launches on the same device pointers; it stays valid while the plans, contexts
+ * and buffers it touched are alive and unchanged.  Capture is per thread (hipStreamCaptureModeThreadLocal). */
+typedef struct th_graph th_graph;
+TH_API int th_ctx_capture_begin(th_ctx *ctx);
+TH_API int th_ctx_capture_end(th_ctx *ctx, th_graph **out); /* *out = NULL and an error if the capture was invalidated */
+TH_API int th_graph_launch(th_graph *graph);                /* stream-ordered on the context's stream, no sync */
+TH_API int th_graph_destroy(th_graph *graph);
 /* device memory helpers for callers without their own allocator (tests, C hosts) */
 TH_API int th_dev_alloc(th_ctx *ctx, size_t bytes, void **dptr);
 TH_API int th_dev_free(th_ctx *ctx, void *dptr);
@@ -158,6 +169,10 @@ TH_API int th_minmax_reduce_dev(th_ctx *ctx, const float *d_minmax, size_t n_cha
  * th_minmax_reduce_dev and a MIN all-reduce leave it) -> d_range = [min_dB, max_dB] (DEVICE) with
  * max_dB = min(max, 0), min_dB = max(min, max_dB - dB_range). */
 TH_API int th_global_db_range_dev(th_ctx *ctx, const float *d_min_negmax, float dB_range, float *d_range);
+/* Both of the above in one launch, for a single GPU (no all-reduce in between): d_range = [min_dB, max_dB];
+ * d_min_negmax (may be NULL) additionally receives [min, -max]. */
+TH_API int th_minmax_reduce_range_dev(th_ctx *ctx, const float *d_minmax, size_t n_chan, float dB_range,
+                                      float *d_min_negmax, float *d_range);
 /* Measurement hook: with enable != 0 every th_calc_spec_batch_dev records two HIP events on the context's stream
  * around its dominant kernel launch (the wave kernel, or the generic one when that is all there is);
  * recording does not synchronise.  th_plan_kernel_ms_history returns the durations of the most recent launches

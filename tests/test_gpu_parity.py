@@ -568,6 +568,12 @@ def test_device_resident_db_range_path(ctx):
         ctx.global_db_range_dev(d_r2.ptr, 100.0, d_rng.ptr)
         got_rng = d_rng.download((2,), np.float32)
         assert (got_rng[0], got_rng[1]) == (np.float32(lo), np.float32(hi)), (case, got_rng, lo, hi)
+        # the one-launch form for a single GPU gives the same two pairs
+        d_r2b, d_rngb = ctx.alloc(8), ctx.alloc(8)
+        ctx.minmax_reduce_range_dev(d_mm.ptr, 1, 100.0, d_rngb.ptr, d_r2b.ptr)
+        assert d_rngb.download((2,), np.float32).tobytes() == got_rng.tobytes()
+        assert d_r2b.download((2,), np.float32).tobytes() == d_r2.download((2,), np.float32).tobytes()
+        d_r2b.free(); d_rngb.free()
         pitch = ta.pitch_u16(T)
         d_img = ctx.alloc(H * pitch * 2)
         ctx.spec_to_img_batch_ranged([_ffi.ImgDesc(d_spec.ptr, d_img.ptr, T, H, 0, H, 0, pitch)], d_rng.ptr, 258)
@@ -759,4 +765,59 @@ def test_foreign_row_pitches_are_never_written_outside_the_row(ctx, extra_f32, e
     assert np.array_equal(s_lib[:, :H], s_for[:, :H]) and np.array_equal(i_lib[:, :T], i_for[:, :T])
     assert (s_for[:, H:] == -12345.0).all() and (i_for[:, T:] == 0x5a5a).all()
     assert np.isin(s_lib[:, H:], (-12345.0, 0.0)).all() and np.isin(i_lib[:, T:], (0x5a5a, 0)).all()
+    plan.close()
+
+
+def test_hip_graph_replay_of_a_single_track_step(ctx, golden_dir):
+    """th_ctx_capture_begin / _end: the launch sequence of one track's update (STFT -> dB range on the device -> u16 image
+    -> level-0 RGBA tiles) captured into a HIP graph and replayed must leave exactly what the direct calls leave."""
+    import torch
+    from thesia_amd import _ffi
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    sr, win, hop, n_fft, n = 48000, 2048, 512, 2048, 20 * 48000
+    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    wav = ((torch.rand(n, device=dev, generator=g) - 0.5) * 0.3 + 0.2 * torch.sin(torch.arange(n, device=dev) * 0.05)).contiguous()
+    T, H = plan.n_frames(n), plan.height
+    sp, ip = ta.pitch_f32(H), ta.pitch_u16(T)
+    spec = torch.zeros((T, sp), dtype=torch.float32, device=dev)
+    mm = torch.zeros((1, 2), dtype=torch.float32, device=dev)
+    r2 = torch.zeros(2, dtype=torch.float32, device=dev)
+    rng_db = torch.zeros(2, dtype=torch.float32, device=dev)
+    img = torch.zeros((H, ip), dtype=torch.int16, device=dev)
+    geoms = [ta.spectrogram_tile_geometry(T, H, 0, 0, tx, ty) for tx in range(-(-T // 512)) for ty in range(-(-H // 512))]
+    slots = [-(-(q.width * q.height) // 64) * 64 for q in geoms]
+    rgba = torch.zeros((sum(slots), 4), dtype=torch.uint8, device=dev)
+    d_cmap = torch.frombuffer(bytearray(cmap), dtype=torch.uint8).to(dev)
+    chan = (ta.ChanDesc * 1)(ta.ChanDesc(wav.data_ptr(), spec.data_ptr(), n, T, sp))
+    imgd = [_ffi.ImgDesc(spec.data_ptr(), img.data_ptr(), T, H, 0, H, sp, ip)]
+    rast, off = [], 0
+    for q, s_ in zip(geoms, slots):
+        rast.append(_ffi.RasterDesc(img.data_ptr(), rgba.data_ptr() + off * 4, T, H, q.origin_x, q.origin_y, q.width, q.height, ip, 0))
+        off += s_
+    torch.cuda.synchronize()
+
+    def step():
+        plan.calc_spec_batch_dev(chan, mm.data_ptr())
+        ctx.minmax_reduce_dev(mm.data_ptr(), 1, r2.data_ptr())
+        ctx.global_db_range_dev(r2.data_ptr(), 100.0, rng_db.data_ptr())
+        ctx.spec_to_img_batch_ranged(imgd, rng_db.data_ptr(), 258)
+        ctx.raster_tiles(rast, d_cmap.data_ptr(), len(cmap) // 4)
+
+    step()  # direct: also uploads the descriptor tables and sizes the scratch buffers
+    ctx.synchronize()
+    want = [t.clone() for t in (spec, mm, rng_db, img, rgba)]
+    assert bool((want[4] != 0).any()) and float(want[2][1]) > float(want[2][0])
+    graph = ctx.capture(step)
+    for t in (spec, mm, r2, rng_db, img, rgba):
+        t.zero_()
+    torch.cuda.synchronize()
+    graph.launch()
+    graph.launch()  # replays are idempotent
+    ctx.synchronize()
+    for got, w in zip((spec, mm, rng_db, img, rgba), want):
+        assert torch.equal(got, w)
+    graph.close()
     plan.close()

@@ -122,6 +122,10 @@ _SIGS = {
     "th_ctx_create_ex": [C.c_int, vp, C.c_int, C.POINTER(vp)],
     "th_ctx_destroy": [vp],
     "th_ctx_synchronize": [vp],
+    "th_ctx_capture_begin": [vp],
+    "th_ctx_capture_end": [vp, C.POINTER(vp)],
+    "th_graph_launch": [vp],
+    "th_graph_destroy": [vp],
     "th_dev_alloc": [vp, C.c_size_t, C.POINTER(vp)],
     "th_dev_free": [vp, vp],
     "th_dev_upload": [vp, vp, vp, C.c_size_t],
@@ -167,6 +171,7 @@ _SIGS = {
     "th_tm_get_waveform_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
     "th_minmax_reduce_dev": [vp, C.c_void_p, C.c_size_t, C.c_void_p],
     "th_global_db_range_dev": [vp, C.c_void_p, C.c_float, C.c_void_p],
+    "th_minmax_reduce_range_dev": [vp, vp, C.c_size_t, C.c_float, vp, vp],
     "th_spec_to_img_batch_dev_ranged": [vp, C.POINTER(ImgDesc), C.c_size_t, C.c_void_p, C.c_uint32],
     "th_plan_time_kernel": [vp, C.c_int],
     "th_plan_last_kernel_ms": [vp, C.POINTER(C.c_float)],

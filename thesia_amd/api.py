@@ -157,6 +157,27 @@ class DeviceBuffer:
             pass
 
 
+class Graph:
+    """A captured launch sequence (Context.capture); launch() replays it on the context's stream."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def launch(self):
+        check(lib.th_graph_launch(self.handle))
+
+    def close(self):
+        if self.handle:
+            lib.th_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """th_ctx: one GPU + one HIP stream.  `stream=None` creates a private stream; an int is used as
     the raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; 0 = legacy default stream)."""
@@ -183,6 +204,21 @@ class Context:
 
     def synchronize(self):
         check(lib.th_ctx_synchronize(self.handle))
+
+    def capture(self, fn) -> "Graph":
+        """Record the library calls `fn()` makes on this context's stream into a HIP graph (th_ctx_capture_begin / _end).
+        Call `fn()` once normally first: tables and scratch buffers are uploaded / sized on first use."""
+        check(lib.th_ctx_capture_begin(self.handle))
+        h = C.c_void_p()
+        try:
+            fn()
+        except BaseException:
+            lib.th_ctx_capture_end(self.handle, C.byref(h))  # leave capture mode; the error of fn() is the one to report
+            if h.value:
+                lib.th_graph_destroy(h)
+            raise
+        check(lib.th_ctx_capture_end(self.handle, C.byref(h)))
+        return Graph(h)
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
@@ -271,6 +307,10 @@ class Context:
     def global_db_range_dev(self, d_min_negmax: int, dB_range: float, d_range: int):
         """[min, -max] -> [min_dB, max_dB] on the device (core/mod.rs:179-180)"""
         check(lib.th_global_db_range_dev(self.handle, d_min_negmax, dB_range, d_range))
+
+    def minmax_reduce_range_dev(self, d_minmax: int, n_chan: int, dB_range: float, d_range: int, d_min_negmax: int = 0):
+        """th_minmax_reduce_dev + th_global_db_range_dev in one launch (single GPU: no all-reduce in between)."""
+        check(lib.th_minmax_reduce_range_dev(self.handle, d_minmax, n_chan, dB_range, d_min_negmax or None, d_range))
 
     def spec_to_img_batch_ranged(self, descs, d_range: int, colormap_len: int):
         arr = descs if isinstance(descs, C.Array) else (ImgDesc * len(descs))(*descs)

@@ -205,6 +205,67 @@ TH_API int th_ctx_synchronize(th_ctx *c) {
     TH_CATCH
 }
 
+struct th_graph {
+    th_ctx *ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+TH_API int th_ctx_capture_begin(th_ctx *c) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    TH_HIP(hipSetDevice(c->device));
+    TH_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_ctx_capture_end(th_ctx *c, th_graph **out) {
+    TH_TRY
+    TH_REQUIRE(c && out, "NULL argument");
+    *out = nullptr;
+    TH_HIP(hipSetDevice(c->device));
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (e != hipSuccess || g == nullptr) {
+        (void)hipGetLastError();
+        if (g) (void)hipGraphDestroy(g);
+        return fail(TH_ERR_HIP, "stream capture failed or was invalidated: %s", hipGetErrorString(e));
+    }
+    hipGraphExec_t x = nullptr;
+    const hipError_t e2 = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e2 != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return fail(TH_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2));
+    }
+    th_graph *gr = new th_graph;
+    gr->ctx = c;
+    gr->graph = g;
+    gr->exec = x;
+    *out = gr;
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_graph_launch(th_graph *g) {
+    TH_TRY
+    TH_REQUIRE(g && g->exec, "graph is NULL");
+    TH_HIP(hipSetDevice(g->ctx->device));
+    TH_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
+    return TH_OK;
+    TH_CATCH
+}
+
+TH_API int th_graph_destroy(th_graph *g) {
+    TH_TRY
+    if (!g) return TH_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return TH_OK;
+    TH_CATCH
+}
+
 TH_API int th_dev_alloc(th_ctx *c, size_t bytes, void **dptr) {
     TH_TRY
     TH_REQUIRE(c && dptr, "NULL argument");
@@ -700,21 +761,27 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
                                 (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, chunk_mm, p->d_queue_head,
                                 c->n_cu, waves, wo, c->stream));
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
-        if (chunk_mm)
-            TH_HIP(launch_minmax_chunks((const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
-                                        (uint32_t)jobs.size(), chunk_mm, d_minmax, c->stream));
         if (mel_mfma)
             TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
                                    (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_bt, p->d_mel_band,
                                    p->d_mel_slice, p->mel_slices, p->mel_zero_block, g.n_mel, d_minmax, c->stream));
-        if (!edge.empty())  // boundary frames: generic kernel (reflect padding; mel reduction included)
-            TH_HIP(launch_stft_generic(ge, (const ChanJob *)p->edge_jobs.dptr, (const uint32_t *)p->edge_tile_start.dptr,
-                                       (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, p->d_mel_fb,
-                                       p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream));
+        // boundary frames: generic kernel (reflect padding; mel reduction included); the same launch carries the blocks
+        // that fold the wave kernel's per-chunk (min, max) into the channel slots (its own small launch if there are no
+        // boundary frames)
+        th::ChunkReduce cr;
+        if (chunk_mm) {
+            cr.jobs = (const ChanJob *)p->jobs.dptr;
+            cr.tile_start = (const uint32_t *)p->tile_start.dptr;
+            cr.chunk_mm = chunk_mm;
+            cr.n_jobs = (uint32_t)jobs.size();
+        }
+        TH_HIP(launch_stft_generic(ge, (const ChanJob *)p->edge_jobs.dptr, (const uint32_t *)p->edge_tile_start.dptr,
+                                   (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, p->d_mel_fb,
+                                   p->d_mel_lo, p->d_mel_hi, d_minmax, cr, c->stream));
     } else {
         TH_HIP(launch_stft_generic(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                    (uint32_t)jobs.size(), (uint32_t)tiles, p->d_window, p->d_tw, p->d_mel_fb,
-                                   p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream));
+                                   p->d_mel_lo, p->d_mel_hi, d_minmax, th::ChunkReduce{}, c->stream));
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
     }
     if (timed) p->timed_launches++;
@@ -729,7 +796,21 @@ TH_API int th_minmax_reduce_dev(th_ctx *c, const float *d_minmax, size_t n_chan,
     TH_REQUIRE(n_chan < (1ull << 31), "too many channels");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     TH_HIP(hipSetDevice(c->device));
-    TH_HIP(launch_minmax_reduce(d_minmax, (uint32_t)n_chan, d_out, c->stream));
+    TH_HIP(launch_minmax_reduce(d_minmax, (uint32_t)n_chan, d_out, 0.0f, nullptr, c->stream));
+    return TH_OK;
+    TH_CATCH
+}
+
+// single-GPU form of th_minmax_reduce_dev + th_global_db_range_dev: one launch instead of two
+TH_API int th_minmax_reduce_range_dev(th_ctx *c, const float *d_minmax, size_t n_chan, float dB_range, float *d_min_negmax,
+                                      float *d_range) {
+    TH_TRY
+    TH_REQUIRE(c && d_range, "NULL argument");
+    TH_REQUIRE(n_chan == 0 || d_minmax, "d_minmax is NULL");
+    TH_REQUIRE(n_chan < (1ull << 31), "too many channels");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    TH_HIP(hipSetDevice(c->device));
+    TH_HIP(launch_minmax_reduce(d_minmax, (uint32_t)n_chan, d_min_negmax, dB_range, d_range, c->stream));
     return TH_OK;
     TH_CATCH
 }

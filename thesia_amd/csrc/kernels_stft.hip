@@ -66,6 +66,40 @@ __device__ __forceinline__ uint32_t find_chan(const uint32_t *__restrict__ tile_
     return lo;
 }
 
+// Per-channel reduction of the wave kernel's per-chunk (min, max) pairs into the channel's slot (256 threads, one
+// interior job per block).  Runs as extra blocks of the boundary-frame launch, or as its own kernel when there are
+// no boundary frames.  red: 8 floats of LDS.
+__device__ __forceinline__ void chunk_minmax_reduce(const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start,
+                                                    uint32_t j, const float *__restrict__ chunk_mm,
+                                                    float *__restrict__ minmax, float *red) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t0 = tile_start[j], t1 = tile_start[j + 1];
+    const gptr<const float2> mm = reinterpret_cast<gptr<const float2>>(as_global(chunk_mm));
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    // four independent loads in flight per thread: a long single-track channel (thousands of chunks) is latency-bound
+    for (uint32_t t = t0 + tid; t < t1; t += 4 * 256) {
+        float2 v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) v[u] = mm[min(t + 256u * u, t1 - 1u)];  // clamped repeats do not change min / max
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            mn = nmin(mn, v[u].x);
+            mx = nmax(mx, v[u].y);
+        }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((tid & 63u) == 0) {
+        red[2 * (tid >> 6)] = mn;
+        red[2 * (tid >> 6) + 1] = mx;
+    }
+    __syncthreads();
+    if (tid == 0 && t1 > t0) {
+        atomic_min_f32(&minmax[2 * jobs[j].mm_index], nmin(nmin(red[0], red[2]), nmin(red[4], red[6])));
+        atomic_max_f32(&minmax[2 * jobs[j].mm_index + 1], nmax(nmax(red[1], red[3]), nmax(red[5], red[7])));
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Generic workgroup kernel: any power-of-two n_fft in [8, 16384].  256 threads work on one frame
 // at a time: LDS ping-pong Stockham radix-4 (+ one radix-2 pass when log2(Nc) is odd), split
@@ -77,11 +111,16 @@ constexpr int GEN_THREADS = 256;
 __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
     const float *__restrict__ window, const cf32 *__restrict__ tw, const float *__restrict__ mel_fb,
-    const uint32_t *__restrict__ mel_lo, const uint32_t *__restrict__ mel_hi, float *__restrict__ minmax) {
+    const uint32_t *__restrict__ mel_lo, const uint32_t *__restrict__ mel_hi, float *__restrict__ minmax,
+    uint32_t n_tiles, ChunkReduce cr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *bufA = reinterpret_cast<cf32 *>(smem_raw);
     cf32 *bufB = bufA + g.nc;
     __shared__ float red[2 * (GEN_THREADS / 64)];
+    if (blockIdx.x >= n_tiles) {  // extra blocks: fold the wave kernel's per-chunk (min, max) into the channel slots
+        chunk_minmax_reduce(cr.jobs, cr.tile_start, blockIdx.x - n_tiles, cr.chunk_mm, minmax, red);
+        return;
+    }
 
     const uint32_t tid = threadIdx.x;
     const uint32_t chan = find_chan(tile_start, n_chan, blockIdx.x);
@@ -626,7 +665,8 @@ hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queu
 // find_min_max over every resident spec (core/mod.rs:169-178): one block reduces the per-channel (min, max) pairs
 // the STFT launch left in d_minmax to out = [min, -max] (so that ONE element-wise MIN all-reduce merges ranks).
 __global__ __launch_bounds__(256) void minmax_reduce_kernel(const float *__restrict__ minmax, uint32_t n_chan,
-                                                            float *__restrict__ out) {
+                                                            float *__restrict__ out, float dB_range,
+                                                            float *__restrict__ out_range) {
     __shared__ float smn[4], smx[4];
     float mn = __builtin_inff(), mx = -__builtin_inff();
     for (uint32_t i = threadIdx.x; i < n_chan; i += 256) {
@@ -641,53 +681,32 @@ __global__ __launch_bounds__(256) void minmax_reduce_kernel(const float *__restr
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[0] = nmin(nmin(smn[0], smn[1]), nmin(smn[2], smn[3]));
-        out[1] = -nmax(nmax(smx[0], smx[1]), nmax(smx[2], smx[3]));
+        mn = nmin(nmin(smn[0], smn[1]), nmin(smn[2], smn[3]));
+        mx = nmax(nmax(smx[0], smx[1]), nmax(smx[2], smx[3]));
+        if (out != nullptr) {
+            out[0] = mn;
+            out[1] = -mx;
+        }
+        if (out_range != nullptr) {  // update_spec_imgs' clamp (core/mod.rs:179-180), as db_range_kernel (kernels_image.hip)
+            mx = fminf(mx, 0.0f);
+            out_range[0] = fmaxf(mn, mx - dB_range);
+            out_range[1] = mx;
+        }
     }
 }
 
-hipError_t launch_minmax_reduce(const float *d_minmax, uint32_t n_chan, float *d_out, hipStream_t s) {
-    hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(256), 0, s, d_minmax, n_chan, d_out);
+hipError_t launch_minmax_reduce(const float *d_minmax, uint32_t n_chan, float *d_out, float dB_range, float *d_range, hipStream_t s) {
+    hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(256), 0, s, d_minmax, n_chan, d_out, dB_range, d_range);
     return hipGetLastError();
 }
 
-// per-channel reduction of the wave kernel's per-chunk (min, max) pairs into the channel slots (which the boundary
-// frames' generic kernel also updates): one wave per interior job
-__global__ __launch_bounds__(256) void minmax_chunks_kernel(const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start,
-                                                            uint32_t n_jobs, const float *__restrict__ chunk_mm,
-                                                            float *__restrict__ minmax) {
-    __shared__ float smn[4], smx[4];
-    const uint32_t j = blockIdx.x, tid = threadIdx.x;
-    const uint32_t t0 = tile_start[j], t1 = tile_start[j + 1];
-    const gptr<const float2> mm = reinterpret_cast<gptr<const float2>>(as_global(chunk_mm));
-    float mn = __builtin_inff(), mx = -__builtin_inff();
-    // four independent loads in flight per thread: a long single-track channel (thousands of chunks) is latency-bound
-    for (uint32_t t = t0 + tid; t < t1; t += 4 * 256) {
-        float2 v[4];
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) v[u] = mm[min(t + 256u * u, t1 - 1u)];  // clamped repeats do not change min / max
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) {
-            mn = nmin(mn, v[u].x);
-            mx = nmax(mx, v[u].y);
-        }
-    }
-    mn = wave_min(mn);
-    mx = wave_max(mx);
-    if ((tid & 63u) == 0) {
-        smn[tid >> 6] = mn;
-        smx[tid >> 6] = mx;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        atomic_min_f32(&minmax[2 * jobs[j].mm_index], nmin(nmin(smn[0], smn[1]), nmin(smn[2], smn[3])));
-        atomic_max_f32(&minmax[2 * jobs[j].mm_index + 1], nmax(nmax(smx[0], smx[1]), nmax(smx[2], smx[3])));
-    }
+__global__ __launch_bounds__(256) void minmax_chunks_kernel(ChunkReduce cr, float *__restrict__ minmax) {
+    __shared__ float red[8];
+    chunk_minmax_reduce(cr.jobs, cr.tile_start, blockIdx.x, cr.chunk_mm, minmax, red);
 }
-hipError_t launch_minmax_chunks(const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, const float *d_chunk_mm,
-                                float *d_minmax, hipStream_t s) {
-    if (!n_jobs) return hipSuccess;
-    hipLaunchKernelGGL(minmax_chunks_kernel, dim3(n_jobs), dim3(256), 0, s, d_jobs, d_tile_start, n_jobs, d_chunk_mm, d_minmax);
+hipError_t launch_minmax_chunks(const ChunkReduce &cr, float *d_minmax, hipStream_t s) {
+    if (!cr.n_jobs) return hipSuccess;
+    hipLaunchKernelGGL(minmax_chunks_kernel, dim3(cr.n_jobs), dim3(256), 0, s, cr, d_minmax);
     return hipGetLastError();
 }
 
@@ -696,19 +715,19 @@ size_t stft_generic_lds_bytes(const StftGeom &g) { return 2 * (size_t)g.nc * siz
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                uint32_t n_chan, uint32_t n_tiles, const float *d_window, const cf32 *d_tw,
                                const float *d_mel_fb, const uint32_t *d_mel_lo, const uint32_t *d_mel_hi,
-                               float *d_minmax, hipStream_t s) {
-    if (!n_tiles) return hipSuccess;
+                               float *d_minmax, const ChunkReduce &cr, hipStream_t s) {
+    if (!n_tiles) return launch_minmax_chunks(cr, d_minmax, s);
     const size_t lds = stft_generic_lds_bytes(g);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_generic_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(stft_generic_kernel, dim3(n_tiles), dim3(GEN_THREADS), lds, s, g, d_jobs, d_tile_start,
-                       n_chan, d_window, d_tw, d_mel_fb, d_mel_lo, d_mel_hi, d_minmax);
+    const uint32_t extra = d_minmax != nullptr ? cr.n_jobs : 0;  // blocks that reduce the wave kernel's chunk (min, max)
+    hipLaunchKernelGGL(stft_generic_kernel, dim3(n_tiles + extra), dim3(GEN_THREADS), lds, s, g, d_jobs, d_tile_start,
+                       n_chan, d_window, d_tw, d_mel_fb, d_mel_lo, d_mel_hi, d_minmax, n_tiles, cr);
     return hipGetLastError();
 }
-
 }  // namespace th
 
 namespace th {
