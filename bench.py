@@ -335,12 +335,9 @@ def main():
     if rank == 0:
         total_frames = wl.frames * world
         bytes_per_frame = 4 * hop + 4 * wl.H            # read 4*hop + write 4*H
-        # frames one launch of the dominant kernel processes: the interior frames (whole n_fft span inside the
-        # channel); the 4 boundary frames per channel go to the generic kernel in the same call
-        pad_left = (n_fft - win) // 2
-        k_lo = -(-(win // 2 + pad_left) // hop)
-        k_hi = (n - n_fft + win // 2 + pad_left) // hop
-        interior = wl.n_tracks * max(0, min(wl.T - 1, k_hi) - k_lo + 1) if wl.plan.kernel_name == "stft_wave_kernel" else wl.frames
+        # frames one launch of the dominant kernel processes: all of them (the wave kernel also takes the 4 boundary
+        # frames per channel, as one-frame chunks with a reflect-indexed fetch)
+        interior = wl.frames
         ach = interior * bytes_per_frame / (stft_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "stft_hbm_traffic.json")

@@ -613,6 +613,19 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     // wave kernel: chunk of consecutive frames one wave walks (the first frame of a chunk loads
     // n_fft samples, the rest only hop new ones).  32 amortises that well on large batches; small
     // batches (one track) get shorter chunks so that every wave of the chip has work.
+    // interior frames [fa, fb) of a channel: the frame's whole n_fft-sample span [e0, e0 + n_fft), e0 = f*hop - win/2 -
+    // pad_left, lies inside the channel (the wave kernel loads it unconditionally); the others are boundary frames
+    auto interior = [&g](const th_chan_desc &d, uint64_t T, uint64_t &fa, uint64_t &fb) {
+        const uint64_t lead = g.win / 2 + g.pad_left, N = d.n_samples;
+        fa = (lead + g.hop - 1) / g.hop;                                  // first f with e0 >= 0
+        fb = N + lead >= g.n_fft ? (N + lead - g.n_fft) / g.hop + 1 : 0;  // one past the last f with e0 + n_fft <= N
+        fa = std::min<uint64_t>(fa, T);
+        fb = std::min<uint64_t>(std::max(fb, fa), T);
+    };
+    // boundary frames of channels with at least n_fft samples also go to the wave kernel (one-frame chunks with a
+    // reflect-indexed fetch): no second launch on the fast path.  Not on the matrix-core mel path (its amplitude rows
+    // are laid out for the interior jobs), not for channels shorter than n_fft (a single reflection is not enough there).
+    const bool edges_in_wave = wave && !mel_mfma;
     if (wave) {
         uint64_t total = 0;
         for (size_t i = 0; i < n_chan; i++) total += chans[i].n_frames;
@@ -631,7 +644,12 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
             chunk = std::max<uint64_t>(1, (total + n_waves - 1) / n_waves);
             for (;; chunk++) {
                 uint64_t n = 0;
-                for (size_t i = 0; i < n_chan; i++) n += (chans[i].n_frames + chunk - 1) / chunk;
+                for (size_t i = 0; i < n_chan; i++) {
+                    uint64_t fa, fb;
+                    interior(chans[i], chans[i].n_frames, fa, fb);
+                    n += (fb - fa + chunk - 1) / chunk;
+                    if (edges_in_wave && chans[i].n_samples >= g.n_fft) n += chans[i].n_frames - (fb - fa);
+                }
                 if (n <= n_waves || chunk >= 32) break;
             }
         } else {
@@ -657,12 +675,13 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     std::vector<uint64_t> amp_row0(n_chan, 0);
     uint64_t mel_tiles = 0, amp_rows = 0;
     auto add = [](std::vector<ChanJob> &v, std::vector<uint32_t> &st, uint64_t &n_tiles, const StftGeom &gg,
-                  const th_chan_desc &d, uint32_t T, uint32_t fb0, uint32_t fe0, uint32_t slot) {
+                  const th_chan_desc &d, uint32_t T, uint32_t fb0, uint32_t fe0, uint32_t slot, bool wave_edge = false) {
         if (fb0 >= fe0) return;
         const uint32_t pitch = d.spec_pitch ? (uint32_t)d.spec_pitch : gg.height;
-        v.push_back(ChanJob{d.wav, d.spec, (uint32_t)d.n_samples, T, fb0, fe0, slot, pitch});
+        v.push_back(ChanJob{d.wav, d.spec, (uint32_t)d.n_samples, T, fb0, fe0, slot, pitch, wave_edge ? 1u : 0u, 0u});
         st.push_back((uint32_t)n_tiles);
-        n_tiles += (fe0 - fb0 + gg.frames_per_tile - 1) / gg.frames_per_tile;
+        const uint32_t fpt = wave_edge ? 1u : gg.frames_per_tile;
+        n_tiles += (fe0 - fb0 + fpt - 1) / fpt;
     };
     for (size_t i = 0; i < n_chan; i++) {
         const th_chan_desc &d = chans[i];
@@ -677,13 +696,8 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
         if (!wave) {
             add(jobs, tile_start, tiles, g, d, (uint32_t)T, 0, (uint32_t)T, (uint32_t)i);
         } else {
-            // interior = the frame's whole n_fft-sample span [e0, e0 + n_fft), e0 = f*hop - win/2 - pad_left,
-            // lies inside the channel (the wave kernel loads it unconditionally)
-            const uint64_t lead = g.win / 2 + g.pad_left, N = d.n_samples;
-            uint64_t fa = (lead + g.hop - 1) / g.hop;                          // first f with e0 >= 0
-            uint64_t fb = N + lead >= g.n_fft ? (N + lead - g.n_fft) / g.hop + 1 : 0;  // one past the last f with e0 + n_fft <= N
-            fa = std::min<uint64_t>(fa, T);
-            fb = std::min<uint64_t>(std::max(fb, fa), T);
+            uint64_t fa, fb;
+            interior(d, T, fa, fb);
             add(jobs, tile_start, tiles, g, d, (uint32_t)T, (uint32_t)fa, (uint32_t)fb, (uint32_t)i);
             if (mel_mfma && fa < fb) {
                 amp_row0[i] = amp_rows;
@@ -693,8 +707,13 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
                 mel_start.push_back((uint32_t)mel_tiles);
                 mel_tiles += (fb - fa + MEL_TILE_FRAMES - 1) / MEL_TILE_FRAMES;
             }
-            add(edge, edge_start, edge_tiles, ge, d, (uint32_t)T, 0, (uint32_t)fa, (uint32_t)i);
-            add(edge, edge_start, edge_tiles, ge, d, (uint32_t)T, (uint32_t)fb, (uint32_t)T, (uint32_t)i);
+            if (edges_in_wave && d.n_samples >= g.n_fft) {
+                add(jobs, tile_start, tiles, g, d, (uint32_t)T, 0, (uint32_t)fa, (uint32_t)i, true);
+                add(jobs, tile_start, tiles, g, d, (uint32_t)T, (uint32_t)fb, (uint32_t)T, (uint32_t)i, true);
+            } else {
+                add(edge, edge_start, edge_tiles, ge, d, (uint32_t)T, 0, (uint32_t)fa, (uint32_t)i);
+                add(edge, edge_start, edge_tiles, ge, d, (uint32_t)T, (uint32_t)fb, (uint32_t)T, (uint32_t)i);
+            }
         }
         TH_REQUIRE(tiles < (1ull << 31) && edge_tiles < (1ull << 31), "batch too large for one launch");
     }

@@ -260,6 +260,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // A wave's position in the frame stream.  All members are wave-uniform (SGPRs).
 struct FrameCursor {
     uint32_t f, f1, mm_index, spec_pitch, t;  // t: chunk index
+    uint32_t n_samples, edge;
     gptr<const float> wav;
     gptr<float> spec;
     bool valid;
@@ -280,8 +281,11 @@ __device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const Chan
     c.valid = t < n_tiles;
     if (c.valid) {
         const uint32_t chan = find_chan(tile_start, n_chan, t);
-        c.f = jobs[chan].f_begin + (t - tile_start[chan]) * g.frames_per_tile;
-        c.f1 = min(c.f + g.frames_per_tile, jobs[chan].f_end);
+        c.edge = jobs[chan].edge;
+        const uint32_t fpt = c.edge ? 1u : g.frames_per_tile;  // boundary frames: one per chunk (no register reuse)
+        c.f = jobs[chan].f_begin + (t - tile_start[chan]) * fpt;
+        c.f1 = min(c.f + fpt, jobs[chan].f_end);
+        c.n_samples = jobs[chan].n_samples;
         c.mm_index = jobs[chan].mm_index;
         c.t = t;
         c.spec_pitch = jobs[chan].spec_pitch;
@@ -325,7 +329,7 @@ __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_
 template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES>
 __device__ __forceinline__ void wave_frame(
     const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
-    uint32_t f, uint32_t f1, gptr<const float> wav, gptr<float> spec, uint32_t spec_pitch, cf32 (&x)[WaveFft<LOG2_NC>::P],
+    uint32_t f, uint32_t f1, gptr<const float> wav, uint32_t n_samples, gptr<float> spec, uint32_t spec_pitch, cf32 (&x)[WaveFft<LOG2_NC>::P],
     const cf32 (&rw)[(RES & 1) ? WaveFft<LOG2_NC>::P : 1], const cf32 (&rw2)[(RES & 2) ? WaveFft<LOG2_NC>::R2 - 1 : 1],
     const cf32 (&rwa)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
     const cf32 (&rwb)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
@@ -365,7 +369,11 @@ __device__ __forceinline__ void wave_frame(
 #if defined(TH_EXP_SMALLWAV)
         const int64_t e0n = ((int64_t)fn * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left) & 0x1FFE;  // experiment: input from L2
 #else
-        const int64_t e0n = (int64_t)fn * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+        // (clamped into the channel: the one-frame chunks of boundary frames prefetch "themselves", and that span is
+        // partly outside; a no-op for interior frames)
+        int64_t e0n = (int64_t)fn * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+        const int64_t e0_max = (int64_t)n_samples - (int64_t)g.n_fft;
+        e0n = e0n < 0 ? 0 : (e0n > e0_max ? e0_max : e0n);
 #endif
         if constexpr (SHIFT == 0) {
             wave_fetch<P, 0>(lane, x, wav, e0n);
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     constexpr int NROT = ROTATE ? P / SHIFT : 1;
 #define TH_FRAME(ROT)                                                                                                  \
     wave_frame<LOG2_NC, SHIFT, OUT, ROTATE, ROTATE ? (ROT) * SHIFT : 0, RES>(                                          \
-        g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
+        g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
         lmax, meltab, wo TH_PROF_ARGS)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
     cf32 rw[(RES & 1) ? P : 1], rw2[(RES & 2) ? W::R2 - 1 : 1];
@@ -604,7 +612,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         lmin = __builtin_inff();
         lmax = -__builtin_inff();
         cf32 x[P];  // raw samples of the current frame; the frame body refills it for the next one
-        wave_fetch<P, 0>(lane, x, cur.wav, frame_e0(cur, g));
+        if (cur.edge) wave_fetch_reflect<P>(lane, x, cur.wav, frame_e0(cur, g), cur.n_samples);  // wave-uniform
+        else wave_fetch<P, 0>(lane, x, cur.wav, frame_e0(cur, g));
         uint32_t f = cur.f;
         // frame loop (steady state: branch-free register flow, see wave_frame)
         for (;;) {

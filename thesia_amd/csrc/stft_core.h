@@ -71,7 +71,10 @@ struct ChanJob {
     uint32_t f_begin, f_end;
     uint32_t mm_index;
     uint32_t spec_pitch;  // floats per spec row (>= height; rows padded to 128 B keep every store line-aligned)
+    uint32_t edge;        // wave kernel: 1 = boundary frames (reflect-padded fetch, one frame per chunk)
+    uint32_t reserved;    // explicit tail padding (tables are compared bytewise before re-upload): always 0
 };
+static_assert(sizeof(ChanJob) == 48, "ChanJob must have no implicit padding");
 
 // numpy-'reflect' index with periodic cycling for pads longer than N-1 (utils.rs:111-138;
 // SURVEY.md Appendix A2).  n == 1 replicates the sample (the reference leaves that pad

@@ -427,6 +427,16 @@ TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0) {
     }
 }
 
+// Boundary frames (part of the span outside [0, n_samples)): numpy-'reflect' indexing per sample (stft.rs:77-95 via
+// utils.rs:111-138); the wave kernel takes them as one-frame chunks of channels with n_samples >= n_fft.
+template <int P, class WavPtr>
+TH_HD void wave_fetch_reflect(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0, uint32_t n_samples) {
+    TH_UNROLL for (int m = 0; m < P; m++) {
+        const int64_t i = e0 + 2 * (int64_t)(lane + 64u * m);
+        x[m] = {wav[reflect_index(i, n_samples)], wav[reflect_index(i + 1, n_samples)]};
+    }
+}
+
 // Rotated variants for the register-rotation frame loop: logical slot m lives in physical x[(m + OFF) % P].
 // wave_fetch_rot loads the S newest logical slots P-S..P-1 of the NEXT frame (rotation OFF + S), which are the
 // physical slots (OFF + i) % P that held the current frame's oldest S slots.
