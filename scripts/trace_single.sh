@@ -7,8 +7,8 @@ python3 - $(ls $out/*/*kernel_trace.csv | head -1) <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in rows if r["Kernel_Name"].startswith(("th::", "void th::"))]
-# last step = kernels after the last minmax_init
-idx = max(i for i, r in enumerate(rows) if "minmax_init" in r["Kernel_Name"])
+# last step = kernels from the last STFT launch on
+idx = max(i for i, r in enumerate(rows) if "stft_wave_kernel" in r["Kernel_Name"])
 t0 = int(rows[idx]["Start_Timestamp"])
 for r in rows[idx:]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0

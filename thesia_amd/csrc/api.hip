@@ -385,6 +385,7 @@ static void plan_free(th_plan *p) {
     if (p->d_mel_fuse) (void)hipFree(p->d_mel_fuse);
     p->amp_buf.release();
     p->chunk_mm.release();
+    p->post_jobs.release();
     p->mel_jobs.release();
     p->mel_tile_start.release();
     if (p->d_window) (void)hipFree(p->d_window);
@@ -451,8 +452,8 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
     }
     if (rc == TH_OK) rc = up((void **)&p->d_window, w.data(), w.size() * sizeof(float));
     if (rc == TH_OK) {
-        const uint32_t zero = 0;
-        rc = up((void **)&p->d_queue_head, &zero, sizeof zero);
+        const uint32_t zero[4] = {0, 0, 0, 0};  // [0] chunk queue, [1] finished workgroups: the wave kernel resets both itself
+        rc = up((void **)&p->d_queue_head, zero, sizeof zero);
     }
     if (rc == TH_OK) rc = up((void **)&p->d_tw, tw.data(), tw.size() * sizeof(cf32));
     if (rc == TH_OK && freq_scale == TH_FREQ_MEL) {
@@ -752,9 +753,10 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
         if (rc == TH_OK) rc = p->edge_tile_start.upload(c->stream, edge_start.data(), edge_start.size() * sizeof(uint32_t));
     }
     if (rc != TH_OK) return rc;
-    // the wave kernel's first chunk per wave is static (chunk = global wave index): the queue starts behind those
-    const uint32_t wave_grid = (uint32_t)std::min<uint64_t>((tiles + waves - 1) / waves, c->n_cu);
-    TH_HIP(launch_minmax_init(d_minmax, (uint32_t)n_chan, wave ? p->d_queue_head : nullptr, wave_grid * (uint32_t)waves, c->stream));
+    // (min, max) slots: when every frame of every channel is in the wave launch, its last workgroup initialises and fills
+    // them (no init launch); otherwise initialise here and let every kernel add with atomics
+    const bool all_in_wave = wave && !mel_mfma && edge.empty() && tiles > 0;
+    if (!all_in_wave) TH_HIP(launch_minmax_init(d_minmax, (uint32_t)n_chan, c->stream));
     // optional timing of the dominant kernel alone (th_plan_time_kernel): two events on the launch stream
     const bool timed = p->time_kernel && !p->ev_k0.empty();
     const size_t slot = (size_t)(p->timed_launches % th_plan::TIMER_SLOTS);
@@ -769,7 +771,7 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
             wo.mel_groups = p->mel_fuse_groups;
             wo.n_mel = g.n_mel;
         }
-        // min / max: the wave kernel stores one pair per chunk, minmax_chunks_kernel folds them into the channel slots
+        // min / max: the wave kernel stores one pair per chunk and its last workgroup folds them into the channel slots
         float *chunk_mm = nullptr;
         if (d_minmax != nullptr && wo.mode != 1 && tiles) {
             rc = p->chunk_mm.ensure((size_t)tiles * 2 * sizeof(float));
@@ -780,27 +782,32 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
                                 (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, chunk_mm, p->d_queue_head,
                                 c->n_cu, waves, wo, c->stream));
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
+        {   // fold the per-chunk (min, max) pairs into the channel slots and rewind the chunk queue
+            std::vector<th::WavePostJob> pj;
+            if (chunk_mm)
+                for (size_t j = 0; j < jobs.size(); j++) {  // a channel's jobs (interior, head, tail) are consecutive
+                    if (!pj.empty() && pj.back().mm_index == jobs[j].mm_index) pj.back().t1 = tile_start[j + 1];
+                    else pj.push_back(th::WavePostJob{tile_start[j], tile_start[j + 1], jobs[j].mm_index, 0u});
+                }
+            if (!pj.empty()) {
+                rc = p->post_jobs.upload(c->stream, pj.data(), pj.size() * sizeof(th::WavePostJob));
+                if (rc != TH_OK) return rc;
+            }
+            TH_HIP(launch_wave_post((const th::WavePostJob *)p->post_jobs.dptr, (uint32_t)pj.size(), chunk_mm, d_minmax,
+                                    all_in_wave, p->d_queue_head, c->stream));
+        }
         if (mel_mfma)
             TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
                                    (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_bt, p->d_mel_band,
                                    p->d_mel_slice, p->mel_slices, p->mel_zero_block, g.n_mel, d_minmax, c->stream));
-        // boundary frames: generic kernel (reflect padding; mel reduction included); the same launch carries the blocks
-        // that fold the wave kernel's per-chunk (min, max) into the channel slots (its own small launch if there are no
-        // boundary frames)
-        th::ChunkReduce cr;
-        if (chunk_mm) {
-            cr.jobs = (const ChanJob *)p->jobs.dptr;
-            cr.tile_start = (const uint32_t *)p->tile_start.dptr;
-            cr.chunk_mm = chunk_mm;
-            cr.n_jobs = (uint32_t)jobs.size();
-        }
-        TH_HIP(launch_stft_generic(ge, (const ChanJob *)p->edge_jobs.dptr, (const uint32_t *)p->edge_tile_start.dptr,
-                                   (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, p->d_mel_fb,
-                                   p->d_mel_lo, p->d_mel_hi, d_minmax, cr, c->stream));
+        if (!edge.empty())  // boundary frames the wave kernel did not take: generic kernel (reflect padding; mel included)
+            TH_HIP(launch_stft_generic(ge, (const ChanJob *)p->edge_jobs.dptr, (const uint32_t *)p->edge_tile_start.dptr,
+                                       (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, p->d_mel_fb,
+                                       p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream));
     } else {
         TH_HIP(launch_stft_generic(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                    (uint32_t)jobs.size(), (uint32_t)tiles, p->d_window, p->d_tw, p->d_mel_fb,
-                                   p->d_mel_lo, p->d_mel_hi, d_minmax, th::ChunkReduce{}, c->stream));
+                                   p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream));
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
     }
     if (timed) p->timed_launches++;

@@ -12,28 +12,26 @@
 namespace th {
 
 // ---- kernels_stft.hip
-hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queue_head, uint32_t queue_init, hipStream_t s);
+hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, hipStream_t s);
 // d_out = [min, -max] and / or d_range = [min_dB, max_dB] (core/mod.rs:179-180); either may be NULL
 hipError_t launch_minmax_reduce(const float *d_minmax, uint32_t n_chan, float *d_out, float dB_range, float *d_range, hipStream_t s);
 size_t stft_generic_lds_bytes(const StftGeom &g);
-// the wave kernel's per-chunk (min, max) pairs of its interior jobs, to be folded into the channel slots
-struct ChunkReduce {
-    const ChanJob *jobs = nullptr;
-    const uint32_t *tile_start = nullptr;
-    const float *chunk_mm = nullptr;
-    uint32_t n_jobs = 0;
-};
-// boundary / fallback frames; with cr.n_jobs != 0 the launch carries cr.n_jobs extra blocks that do the chunk reduction
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                uint32_t n_chan, uint32_t n_tiles, const float *d_window, const cf32 *d_tw,
                                const float *d_mel_fb, const uint32_t *d_mel_lo, const uint32_t *d_mel_hi,
-                               float *d_minmax, const ChunkReduce &cr, hipStream_t s);
-hipError_t launch_minmax_chunks(const ChunkReduce &cr, float *d_minmax, hipStream_t s);
+                               float *d_minmax, hipStream_t s);
 
 bool stft_wave_supported(const StftGeom &g);
 int stft_wave_default_waves(const StftGeom &g);
-// d_minmax of launch_stft_wave is a per-CHUNK (min, max) array (2 floats per tile), folded into the per-channel slots
-// afterwards (ChunkReduce above)
+// d_minmax of launch_stft_wave is a per-CHUNK (min, max) array (2 floats per tile).  launch_wave_post follows every wave
+// launch: per channel it folds the chunk pairs of the channel's tiles [t0, t1) into the channel slot (store = the slot
+// needs no initialisation: every frame of the channel was in the wave launch) and rewinds the queue (d_queue_head[0],
+// zero before the first launch; the kernel counts from 0 behind its statically assigned first chunks).
+struct WavePostJob {
+    uint32_t t0, t1, mm_index, reserved;
+};
+hipError_t launch_wave_post(const WavePostJob *d_pj, uint32_t n_pj, const float *d_chunk_mm, float *d_mm_slots, bool store,
+                            uint32_t *d_queue_head, hipStream_t s);
 // What the wave kernel writes: dB rows of the linear spectrum, linear amplitude rows (first half of the matrix-core
 // mel path), or dB rows of the mel spectrum with the filterbank fused into the epilogue (mel_fuse.h tables).
 struct WaveOut {

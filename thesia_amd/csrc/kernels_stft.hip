@@ -30,9 +30,8 @@ __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
     else atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 
-__global__ void minmax_init_kernel(float *minmax, uint32_t n_chan, uint32_t *queue_head, uint32_t queue_init) {
+__global__ void minmax_init_kernel(float *minmax, uint32_t n_chan) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && queue_head != nullptr) *queue_head = queue_init;  // work queue of the wave kernel (first chunks are static)
     if (minmax != nullptr && i < n_chan) {
         minmax[2 * i] = __builtin_inff();
         minmax[2 * i + 1] = -__builtin_inff();
@@ -66,40 +65,6 @@ __device__ __forceinline__ uint32_t find_chan(const uint32_t *__restrict__ tile_
     return lo;
 }
 
-// Per-channel reduction of the wave kernel's per-chunk (min, max) pairs into the channel's slot (256 threads, one
-// interior job per block).  Runs as extra blocks of the boundary-frame launch, or as its own kernel when there are
-// no boundary frames.  red: 8 floats of LDS.
-__device__ __forceinline__ void chunk_minmax_reduce(const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start,
-                                                    uint32_t j, const float *__restrict__ chunk_mm,
-                                                    float *__restrict__ minmax, float *red) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t t0 = tile_start[j], t1 = tile_start[j + 1];
-    const gptr<const float2> mm = reinterpret_cast<gptr<const float2>>(as_global(chunk_mm));
-    float mn = __builtin_inff(), mx = -__builtin_inff();
-    // four independent loads in flight per thread: a long single-track channel (thousands of chunks) is latency-bound
-    for (uint32_t t = t0 + tid; t < t1; t += 4 * 256) {
-        float2 v[4];
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) v[u] = mm[min(t + 256u * u, t1 - 1u)];  // clamped repeats do not change min / max
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) {
-            mn = nmin(mn, v[u].x);
-            mx = nmax(mx, v[u].y);
-        }
-    }
-    mn = wave_min(mn);
-    mx = wave_max(mx);
-    if ((tid & 63u) == 0) {
-        red[2 * (tid >> 6)] = mn;
-        red[2 * (tid >> 6) + 1] = mx;
-    }
-    __syncthreads();
-    if (tid == 0 && t1 > t0) {
-        atomic_min_f32(&minmax[2 * jobs[j].mm_index], nmin(nmin(red[0], red[2]), nmin(red[4], red[6])));
-        atomic_max_f32(&minmax[2 * jobs[j].mm_index + 1], nmax(nmax(red[1], red[3]), nmax(red[5], red[7])));
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // Generic workgroup kernel: any power-of-two n_fft in [8, 16384].  256 threads work on one frame
 // at a time: LDS ping-pong Stockham radix-4 (+ one radix-2 pass when log2(Nc) is odd), split
@@ -111,16 +76,11 @@ constexpr int GEN_THREADS = 256;
 __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
     const float *__restrict__ window, const cf32 *__restrict__ tw, const float *__restrict__ mel_fb,
-    const uint32_t *__restrict__ mel_lo, const uint32_t *__restrict__ mel_hi, float *__restrict__ minmax,
-    uint32_t n_tiles, ChunkReduce cr) {
+    const uint32_t *__restrict__ mel_lo, const uint32_t *__restrict__ mel_hi, float *__restrict__ minmax) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *bufA = reinterpret_cast<cf32 *>(smem_raw);
     cf32 *bufB = bufA + g.nc;
     __shared__ float red[2 * (GEN_THREADS / 64)];
-    if (blockIdx.x >= n_tiles) {  // extra blocks: fold the wave kernel's per-chunk (min, max) into the channel slots
-        chunk_minmax_reduce(cr.jobs, cr.tile_start, blockIdx.x - n_tiles, cr.chunk_mm, minmax, red);
-        return;
-    }
 
     const uint32_t tid = threadIdx.x;
     const uint32_t chan = find_chan(tile_start, n_chan, blockIdx.x);
@@ -271,12 +231,12 @@ struct FrameCursor {
 __device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const ChanJob *__restrict__ jobs,
                                                    const uint32_t *__restrict__ tile_start, uint32_t n_chan,
                                                    uint32_t n_tiles, uint32_t *__restrict__ queue_head, uint32_t lane,
-                                                   bool first, uint32_t t_static) {
+                                                   bool first, uint32_t t_static, uint32_t t_base) {
     FrameCursor c{};
     uint32_t t = t_static;  // a wave's first chunk is its global index: no 3072-deep burst on the queue head at start
     if (!first) {
         if (lane == 0) t = atomicAdd(queue_head, 1u);
-        t = __builtin_amdgcn_readfirstlane(t);
+        t = __builtin_amdgcn_readfirstlane(t) + t_base;  // the head counts from 0: the first gridDim * WAVES chunks are static
     }
     c.valid = t < n_tiles;
     if (c.valid) {
@@ -606,7 +566,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     for (;;) {
         if (!first_pull && all_static) break;
         const FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane, first_pull,
-                                            blockIdx.x * WAVES + wave);
+                                            blockIdx.x * WAVES + wave, gridDim.x * WAVES);
         first_pull = false;
         if (!cur.valid) break;
         lmin = __builtin_inff();
@@ -663,11 +623,9 @@ namespace th {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, uint32_t *d_queue_head, uint32_t queue_init, hipStream_t s) {
-    if ((!d_minmax || !n_chan) && !d_queue_head) return hipSuccess;
-    if (!n_chan) n_chan = 1;
-    hipLaunchKernelGGL(minmax_init_kernel, dim3((n_chan + 255) / 256), dim3(256), 0, s, d_minmax, n_chan,
-                       d_queue_head, queue_init);
+hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, hipStream_t s) {
+    if (!d_minmax || !n_chan) return hipSuccess;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3((n_chan + 255) / 256), dim3(256), 0, s, d_minmax, n_chan);
     return hipGetLastError();
 }
 
@@ -709,13 +667,54 @@ hipError_t launch_minmax_reduce(const float *d_minmax, uint32_t n_chan, float *d
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void minmax_chunks_kernel(ChunkReduce cr, float *__restrict__ minmax) {
+// After the wave kernel: one block per channel folds the channel's per-chunk (min, max) pairs (its jobs' tiles are
+// one contiguous range) into the channel's slot — a plain store when every frame of the channel was in the wave launch
+// (then nobody has to initialise the slot), atomics when other kernels contribute too — and block 0 rewinds the chunk
+// queue for the next launch.  With chunk_mm == NULL only the queue is rewound.
+__global__ __launch_bounds__(256) void wave_post_kernel(const WavePostJob *__restrict__ pj, const float *__restrict__ chunk_mm,
+                                                        float *__restrict__ mm_slots, int store, uint32_t *__restrict__ queue_head) {
     __shared__ float red[8];
-    chunk_minmax_reduce(cr.jobs, cr.tile_start, blockIdx.x, cr.chunk_mm, minmax, red);
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) *queue_head = 0;
+    if (chunk_mm == nullptr) return;
+    const WavePostJob job = pj[blockIdx.x];
+    const gptr<const float2> mm = reinterpret_cast<gptr<const float2>>(as_global(chunk_mm));
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    // four independent loads in flight per thread: a long single-track channel (thousands of chunks) is latency-bound
+    for (uint32_t t = job.t0 + tid; t < job.t1; t += 4 * 256) {
+        float2 v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) v[u] = mm[min(t + 256u * u, job.t1 - 1u)];  // clamped repeats do not change min / max
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            mn = nmin(mn, v[u].x);
+            mx = nmax(mx, v[u].y);
+        }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((tid & 63u) == 0) {
+        red[2 * (tid >> 6)] = mn;
+        red[2 * (tid >> 6) + 1] = mx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        mn = nmin(nmin(red[0], red[2]), nmin(red[4], red[6]));
+        mx = nmax(nmax(red[1], red[3]), nmax(red[5], red[7]));
+        if (store) {
+            mm_slots[2 * job.mm_index] = mn;
+            mm_slots[2 * job.mm_index + 1] = mx;
+        } else {
+            atomic_min_f32(&mm_slots[2 * job.mm_index], mn);
+            atomic_max_f32(&mm_slots[2 * job.mm_index + 1], mx);
+        }
+    }
 }
-hipError_t launch_minmax_chunks(const ChunkReduce &cr, float *d_minmax, hipStream_t s) {
-    if (!cr.n_jobs) return hipSuccess;
-    hipLaunchKernelGGL(minmax_chunks_kernel, dim3(cr.n_jobs), dim3(256), 0, s, cr, d_minmax);
+hipError_t launch_wave_post(const WavePostJob *d_pj, uint32_t n_pj, const float *d_chunk_mm, float *d_mm_slots, bool store,
+                            uint32_t *d_queue_head, hipStream_t s) {
+    const bool fold = d_chunk_mm != nullptr && n_pj != 0;
+    hipLaunchKernelGGL(wave_post_kernel, dim3(fold ? n_pj : 1), dim3(256), 0, s, d_pj, fold ? d_chunk_mm : nullptr, d_mm_slots,
+                       store ? 1 : 0, d_queue_head);
     return hipGetLastError();
 }
 
@@ -724,17 +723,16 @@ size_t stft_generic_lds_bytes(const StftGeom &g) { return 2 * (size_t)g.nc * siz
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                uint32_t n_chan, uint32_t n_tiles, const float *d_window, const cf32 *d_tw,
                                const float *d_mel_fb, const uint32_t *d_mel_lo, const uint32_t *d_mel_hi,
-                               float *d_minmax, const ChunkReduce &cr, hipStream_t s) {
-    if (!n_tiles) return launch_minmax_chunks(cr, d_minmax, s);
+                               float *d_minmax, hipStream_t s) {
+    if (!n_tiles) return hipSuccess;
     const size_t lds = stft_generic_lds_bytes(g);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_generic_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const uint32_t extra = d_minmax != nullptr ? cr.n_jobs : 0;  // blocks that reduce the wave kernel's chunk (min, max)
-    hipLaunchKernelGGL(stft_generic_kernel, dim3(n_tiles + extra), dim3(GEN_THREADS), lds, s, g, d_jobs, d_tile_start,
-                       n_chan, d_window, d_tw, d_mel_fb, d_mel_lo, d_mel_hi, d_minmax, n_tiles, cr);
+    hipLaunchKernelGGL(stft_generic_kernel, dim3(n_tiles), dim3(GEN_THREADS), lds, s, g, d_jobs, d_tile_start,
+                       n_chan, d_window, d_tw, d_mel_fb, d_mel_lo, d_mel_hi, d_minmax);
     return hipGetLastError();
 }
 }  // namespace th
