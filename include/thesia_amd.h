@@ -157,7 +157,8 @@ TH_API int th_plan_destroy(th_plan *plan);
 /* n_freq = n_fft/2+1; height = n_freq (linear) or n_mel (mel) = columns of the spec */
 TH_API int th_plan_dims(const th_plan *plan, size_t *n_freq, size_t *height);
 /* kernel selection: 0 = auto, 1 = force the generic workgroup kernel, 2 = force the wave kernel, 3 = wave kernel with
- * the matrix-core mel kernel instead of the fused mel epilogue (mel plans; same as 2 for linear ones);
+ * the matrix-core mel kernel instead of the fused mel epilogue (mel plans; same as 2 for linear ones), 4 = wave kernel
+ * without the phased register reuse of hop = 480-style framings (A/B measurements);
  * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
  * frames per queue pull */
 TH_API int th_plan_set_kernel(th_plan *plan, int which);

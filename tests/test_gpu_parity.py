@@ -821,3 +821,29 @@ def test_hip_graph_replay_of_a_single_track_step(ctx, golden_dir):
         assert torch.equal(got, w)
     graph.close()
     plan.close()
+
+
+@pytest.mark.parametrize("win", [1920, 1952, 1800])
+def test_phased_register_reuse_for_hop_480(ctx, win):
+    """hop = 480 (the app's 40 ms / 4 at 48 kHz) with n_fft = 2048: the wave kernel loads every frame from the 128-sample grid
+    below its first window sample (|X| does not change when the windowed frame moves inside its zero padding) and reuses
+    3, 4, 4, 4 register slots between consecutive frames.  Must match the oracle like every other framing, must equal
+    the unphased wave kernel to f32-FFT accuracy, and a ragged batch must equal single launches bit for bit."""
+    sr, hop, n_fft = 48000, 480, 2048
+    wavs = [synth_track(900 + i, sr, n) for i, n in enumerate((131072, 40000, 2048, 2049, 3000, 97531))]
+    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    specs, mm = plan.calc_spec_batch(wavs)
+    plan4 = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    plan4.set_kernel(4)  # wave kernel without the phased mode
+    specs4, mm4 = plan4.calc_spec_batch(wavs)
+    for i, w in enumerate(wavs):
+        want, amp = orc.calc_spec(w, win, hop, n_fft, return_amp=True)
+        assert_spec_close(specs[i], want)
+        assert mm[i, 0] == specs[i].min() and mm[i, 1] == specs[i].max()
+        # against the unphased kernel: same products x * w, different position in the FFT input -> rounding only
+        a, b = np.power(10.0, specs[i].astype(np.float64) / 20), np.power(10.0, specs4[i].astype(np.float64) / 20)
+        assert (np.abs(a - b) / amp.max(axis=1, keepdims=True)).max() <= 2e-6
+        one, mn, mx = plan.calc_spec(w)
+        assert np.array_equal(one, specs[i]) and (mn, mx) == (mm[i, 0], mm[i, 1])
+    plan.close()
+    plan4.close()

@@ -378,6 +378,7 @@ static void plan_free(th_plan *p) {
     for (hipEvent_t e : p->ev_k0) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->ev_k1) (void)hipEventDestroy(e);
     if (p->d_wtab) (void)hipFree(p->d_wtab);
+    if (p->d_wtab_phased) (void)hipFree(p->d_wtab_phased);
     if (p->d_queue_head) (void)hipFree(p->d_queue_head);
     if (p->d_mel_bt) (void)hipFree(p->d_mel_bt);
     if (p->d_mel_band) (void)hipFree(p->d_mel_band);
@@ -449,6 +450,16 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
         std::vector<float> wpad(n_fft, 0.f);
         for (size_t i = 0; i < win; i++) wpad[g.pad_left + i] = 0.5f * w[i];
         rc = up((void **)&p->d_wtab, wpad.data(), wpad.size() * sizeof(float));
+        // phased mode of the wave kernel (hop = 480-style framings, kernels_stft.hip): the same table with the window at
+        // offsets 0, 96, 64, 32 instead of pad_left
+        if (rc == TH_OK && freq_scale != TH_FREQ_MEL && th::stft_wave_phased_supported(g, 0)) {
+            std::vector<float> w4(4 * n_fft, 0.f);
+            for (size_t r = 0; r < 4; r++) {
+                const size_t delta = (96 * r) & 127;
+                for (size_t i = 0; i < win; i++) w4[r * n_fft + delta + i] = 0.5f * w[i];
+            }
+            rc = up((void **)&p->d_wtab_phased, w4.data(), w4.size() * sizeof(float));
+        }
     }
     if (rc == TH_OK) rc = up((void **)&p->d_window, w.data(), w.size() * sizeof(float));
     if (rc == TH_OK) {
@@ -574,9 +585,9 @@ TH_API int th_plan_dims(const th_plan *p, size_t *n_freq, size_t *height) {
 TH_API int th_plan_set_kernel(th_plan *p, int which) {
     TH_TRY
     TH_REQUIRE(p, "plan is NULL");
-    // bits 0-7: 0 auto, 1 generic, 2 wave, 3 wave + matrix-core mel;  bits 8-15 (tuning): waves per workgroup of the wave kernel
+    // bits 0-7: 0 auto, 1 generic, 2 wave, 3 wave + matrix-core mel, 4 wave without the phased mode;  bits 8-15 (tuning): waves per workgroup
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 3, "kernel selector must be 0, 1, 2 or 3");
+    TH_REQUIRE(k >= 0 && k <= 4, "kernel selector must be 0 .. 4");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     p->kernel_choice = k;
@@ -616,7 +627,23 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     // batches (one track) get shorter chunks so that every wave of the chip has work.
     // interior frames [fa, fb) of a channel: the frame's whole n_fft-sample span [e0, e0 + n_fft), e0 = f*hop - win/2 -
     // pad_left, lies inside the channel (the wave kernel loads it unconditionally); the others are boundary frames
-    auto interior = [&g](const th_chan_desc &d, uint64_t T, uint64_t &fa, uint64_t &fb) {
+    // phased mode of the wave kernel (hop = 480-style framings): frames are loaded from the 128-sample grid below their
+    // first window sample; chunks must start on frames that sit exactly on the grid (every fourth)
+    const bool phased = wave && !mel_mfma && !mel_fused && p->kernel_choice != 4 && p->d_wtab_phased != nullptr &&
+                        th::stft_wave_phased_supported(g, p->wave_waves);
+    g.phased = phased ? 1u : 0u;
+    auto interior = [&g, phased](const th_chan_desc &d, uint64_t T, uint64_t &fa, uint64_t &fb) {
+        if (phased) {
+            const int64_t N = (int64_t)d.n_samples, half = (int64_t)(g.win / 2);
+            auto delta = [&](int64_t f) { return (((f * (int64_t)g.hop - half) % 128) + 128) % 128; };
+            auto start = [&](int64_t f) { return f * (int64_t)g.hop - half - delta(f); };
+            int64_t a = 0, b = (int64_t)T;
+            while (a < b && (start(a) < 0 || delta(a) != 0)) a++;
+            while (b > a && start(b - 1) + (int64_t)g.n_fft > N) b--;
+            fa = (uint64_t)a;
+            fb = (uint64_t)b;
+            return;
+        }
         const uint64_t lead = g.win / 2 + g.pad_left, N = d.n_samples;
         fa = (lead + g.hop - 1) / g.hop;                                  // first f with e0 >= 0
         fb = N + lead >= g.n_fft ? (N + lead - g.n_fft) / g.hop + 1 : 0;  // one past the last f with e0 + n_fft <= N
@@ -626,7 +653,7 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     // boundary frames of channels with at least n_fft samples also go to the wave kernel (one-frame chunks with a
     // reflect-indexed fetch): no second launch on the fast path.  Not on the matrix-core mel path (its amplitude rows
     // are laid out for the interior jobs), not for channels shorter than n_fft (a single reflection is not enough there).
-    const bool edges_in_wave = wave && !mel_mfma;
+    const bool edges_in_wave = wave && !mel_mfma && !phased;
     if (wave) {
         uint64_t total = 0;
         for (size_t i = 0; i < n_chan; i++) total += chans[i].n_frames;
@@ -658,6 +685,7 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
             chunk = chunk < 12 ? 12 : (chunk > 32 ? 32 : chunk);
         }
         g.frames_per_tile = p->wave_chunk > 0 ? (uint32_t)p->wave_chunk : (uint32_t)chunk;
+        if (phased) g.frames_per_tile = std::max<uint32_t>(4, (g.frames_per_tile + 3) / 4 * 4);  // chunks start on the grid
     } else {
         g.frames_per_tile = 8;
     }
@@ -779,7 +807,7 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
             chunk_mm = static_cast<float *>(p->chunk_mm.dptr);
         }
         TH_HIP(launch_stft_wave(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
-                                (uint32_t)jobs.size(), (uint32_t)tiles, p->d_wtab, p->d_tw, chunk_mm, p->d_queue_head,
+                                (uint32_t)jobs.size(), (uint32_t)tiles, phased ? p->d_wtab_phased : p->d_wtab, p->d_tw, chunk_mm, p->d_queue_head,
                                 c->n_cu, waves, wo, c->stream));
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
         {   // fold the per-chunk (min, max) pairs into the channel slots and rewind the chunk queue

@@ -60,7 +60,7 @@ struct th_plan {
     th_ctx *ctx = nullptr;
     uint32_t sr = 0;
     int freq_scale = 0;
-    int kernel_choice = 0;  // 0 auto, 1 generic, 2 wave, 3 wave with the matrix-core mel kernel (no fused epilogue)
+    int kernel_choice = 0;  // 0 auto, 1 generic, 2 wave, 3 wave with the matrix-core mel kernel (no fused epilogue), 4 wave without the phased mode
     int wave_waves = 0;     // tuning: waves per workgroup of the wave kernel (0 = default)
     int wave_chunk = 0;     // tuning: frames per chunk of the wave kernel (0 = default)
     // th_plan_time_kernel: a ring of event pairs around the STFT kernel launch (no synchronisation while recording)
@@ -73,6 +73,7 @@ struct th_plan {
     th::cf32 *d_tw = nullptr;
     uint32_t *d_queue_head = nullptr;  // wave kernel: chunk queue head (reset before every launch)
     th::cf32 *d_wtab = nullptr;  // wave kernel: 0.5 * zero-padded window as (even, odd) pairs
+    th::cf32 *d_wtab_phased = nullptr;  // phased mode: four tables, the window shifted to offsets 0, 96, 64, 32 (NULL: not applicable)
     bool use_wave() const;
     float *d_mel_fb = nullptr;
     uint32_t *d_mel_lo = nullptr, *d_mel_hi = nullptr;

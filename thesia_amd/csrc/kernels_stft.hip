@@ -259,7 +259,8 @@ __device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const Chan
 // frame element 0 sits at signal position f*hop - win/2 - pad_left; the host only hands interior
 // frames to this kernel, so every windowed sample is inside the channel
 __device__ __forceinline__ int64_t frame_e0(const FrameCursor &c, const StftGeom &g) {
-    return (int64_t)c.f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+    // (phased mode: chunks start on frames whose window begins on the 128-sample grid, offset 0)
+    return (int64_t)c.f * g.hop - (int64_t)(g.win / 2) - (int64_t)(g.phased ? 0u : g.pad_left);
 }
 
 __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_t slot, uint32_t lane, float lmin,
@@ -286,7 +287,9 @@ __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_
 // RES: which per-lane constant tables the caller keeps resident in registers instead of re-reading them from
 // LDS every frame (bit 0 window, 1 pass-2 twiddles, 2 pass-3 twiddles, 3 split twiddles; 2 and 3 only on the
 // mirror-local path).  Worth it when fewer waves per SIMD leave the VGPRs: LDS is a co-bottleneck of this kernel.
-template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES>
+// PH >= 0: "phased" mode (stft_wave_kernel) — this frame sits at offset delta = (96 PH) mod 128 inside its n_fft-sample
+// load span and wtab is the window table shifted by that much; the next frame's offset is (96 (PH + 1)) mod 128.
+template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH = -1>
 __device__ __forceinline__ void wave_frame(
     const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
     uint32_t f, uint32_t f1, gptr<const float> wav, uint32_t n_samples, gptr<float> spec, uint32_t spec_pitch, cf32 (&x)[WaveFft<LOG2_NC>::P],
@@ -331,7 +334,8 @@ __device__ __forceinline__ void wave_frame(
 #else
         // (clamped into the channel: the one-frame chunks of boundary frames prefetch "themselves", and that span is
         // partly outside; a no-op for interior frames)
-        int64_t e0n = (int64_t)fn * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+        const int64_t lead_n = PH >= 0 ? (int64_t)((96 * (PH + 1)) & 127) : (int64_t)g.pad_left;
+        int64_t e0n = (int64_t)fn * g.hop - (int64_t)(g.win / 2) - lead_n;
         const int64_t e0_max = (int64_t)n_samples - (int64_t)g.n_fft;
         e0n = e0n < 0 ? 0 : (e0n > e0_max ? e0_max : e0n);
 #endif
@@ -496,12 +500,20 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     uint32_t *__restrict__ queue_head, WaveOut wo) {
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
-    static_assert(SHIFT >= 0 && SHIFT < P, "shift must leave something to reuse");
+    // SHIFT = -1: "phased" mode for hop = 3 * 128 + 96 samples (the app's 40 ms / 4 at 48 kHz = 480) with n_fft - win
+    // >= 96.  |X| does not change when the windowed frame moves inside its zero padding, so every frame is loaded from
+    // the 128-sample grid point below its first window sample; its offset from there cycles 0, 96, 64, 32 and four
+    // window tables shifted by that much sit in LDS.  Consecutive frames then differ by 3, 4, 4, 4 whole register slots:
+    // the rotation scheme below with one extra slot move per four frames.  Chunks start on offset-0 frames (host).
+    constexpr bool PHASED = SHIFT < 0;
+    static_assert(PHASED || (SHIFT >= 0 && SHIFT < P), "shift must leave something to reuse");
+    static_assert(!PHASED || (P == 16 && OUT == 0), "phased mode: n_fft = 2048, linear output");
+    constexpr int NWT = PHASED ? 4 : 1;  // window tables
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *wtab = reinterpret_cast<cf32 *>(smem_raw);
     // the split-twiddle table is not kept in LDS when the lanes hold their entries in registers (RES bit 3)
     constexpr bool STW_IN_LDS = !((RES & 8) && W::PAIRED);
-    cf32 *stw = wtab + NC;
+    cf32 *stw = wtab + NWT * NC;
     cf32 *t2 = stw + (STW_IN_LDS ? NC : 0);
     cf32 *t3 = t2 + W::T2_LEN;
     cf32 *slabs = t3 + W::T3_LEN;
@@ -511,7 +523,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // wave index is wave-uniform: tell the compiler, so the frame cursor lives in SGPRs / SALU
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
-        wtab[i] = wtab_g[i];
+#pragma unroll
+        for (int r = 0; r < NWT; r++) wtab[r * NC + i] = wtab_g[r * NC + i];
         if constexpr (STW_IN_LDS) stw[i] = tw[i];
     }
     W::fill_tables(tid, 64 * WAVES, tw, t2, t3);
@@ -537,23 +550,27 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // the next frame's SHIFT new slots over the ones that just went out of the window.  A new chunk (all P
     // slots loaded) always starts at rotation 0.
     constexpr int SHIFT_NZ = SHIFT > 0 ? SHIFT : 1;  // (keeps the constant expression below free of a % 0)
-    constexpr bool ROTATE = SHIFT > 0 && P % SHIFT_NZ == 0 && P / SHIFT_NZ <= 4;
-    constexpr int NROT = ROTATE ? P / SHIFT : 1;
+    constexpr bool ROTATE = PHASED || (SHIFT > 0 && P % SHIFT_NZ == 0 && P / SHIFT_NZ <= 4);
+    constexpr int NROT = PHASED ? 4 : (ROTATE ? P / SHIFT : 1);
+    constexpr int RESK = PHASED ? (RES & ~1) : RES;  // phased: the window changes every frame, it stays in LDS
+    // slots reused / rotation offset / window table of body ROT
+#define TH_BODY_SHIFT(ROT) (PHASED ? ((ROT) == 0 ? 3 : 4) : SHIFT)
+#define TH_BODY_OFF(ROT) (PHASED ? ((ROT) == 0 ? 0 : 4 * (ROT) - 1) : (ROTATE ? (ROT) * SHIFT : 0))
 #define TH_FRAME(ROT)                                                                                                  \
-    wave_frame<LOG2_NC, SHIFT, OUT, ROTATE, ROTATE ? (ROT) * SHIFT : 0, RES>(                                          \
-        g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
+    wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : -1>(                 \
+        g, wtab + (PHASED ? (ROT) * NC : 0), stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
         lmax, meltab, wo TH_PROF_ARGS)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
-    cf32 rw[(RES & 1) ? P : 1], rw2[(RES & 2) ? W::R2 - 1 : 1];
-    cf32 rwa[(RES & 4) ? W::NQ : 1][W::R3 - 1], rwb[(RES & 4) ? W::NQ : 1][W::R3 - 1], rws[(RES & 8) ? W::NQ : 1][W::R3];
-    if constexpr (RES & 1) {
+    cf32 rw[(RESK & 1) ? P : 1], rw2[(RESK & 2) ? W::R2 - 1 : 1];
+    cf32 rwa[(RESK & 4) ? W::NQ : 1][W::R3 - 1], rwb[(RESK & 4) ? W::NQ : 1][W::R3 - 1], rws[(RESK & 8) ? W::NQ : 1][W::R3];
+    if constexpr (RESK & 1) {
 #pragma unroll
         for (int m = 0; m < P; m++) rw[m] = wtab[lane + 64u * m];
     }
-    if constexpr (RES & 2) W::load_t2(lane, rw2, t2);
-    if constexpr (RES & 4) W::load_t3_paired(lane, rwa, rwb, t3);
+    if constexpr (RESK & 2) W::load_t2(lane, rw2, t2);
+    if constexpr (RESK & 4) W::load_t3_paired(lane, rwa, rwb, t3);
     cf32 rw_mid = {0.0f, 0.0f};
-    if constexpr ((RES & 8) != 0 && W::PAIRED) {  // straight from the global table: no LDS copy exists
+    if constexpr ((RESK & 8) != 0 && W::PAIRED) {  // straight from the global table: no LDS copy exists
 #pragma unroll
         for (int q = 0; q < W::NQ; q++)
 #pragma unroll
@@ -591,6 +608,12 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
                 TH_FRAME(3);
                 if (++f >= cur.f1) break;
             }
+            if constexpr (PHASED) {  // 3 + 4 + 4 + 4 = 15 slots in four frames: one slot move restores rotation 0
+                const cf32 t = x[P - 1];
+#pragma unroll
+                for (int m = P - 1; m > 0; m--) x[m] = x[m - 1];
+                x[0] = t;
+            }
         }
         // (min, max) of this chunk: a plain store per chunk, reduced per channel by minmax_chunks_kernel afterwards.
         // (Float atomics on the channel's slot from every wave are served one at a time, ~8 ns each: 50 us for the
@@ -604,6 +627,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         }
     }
 #undef TH_FRAME
+#undef TH_BODY_SHIFT
+#undef TH_BODY_OFF
     TH_PROF_FLUSH(lane_wave);
 }
 
@@ -772,7 +797,8 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
-    const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>() + (OUT == 2 ? (size_t)out.mel_words * 4 : 0);
+    const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>() + (OUT == 2 ? (size_t)out.mel_words * 4 : 0) +
+                       (SHIFT < 0 ? 3 * sizeof(cf32) * (size_t)WaveFft<LOG2_NC>::NC : 0);  // phased: four window tables
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -790,7 +816,7 @@ template <int LOG2_NC, int WAVES, int SHIFT>
 static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
-    if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
+    if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES && SHIFT >= 0) {
         if (out.mode == 1)
             return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                                                                     d_tw, nullptr, d_queue_head, n_cu, out, s);
@@ -820,6 +846,12 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     constexpr int P = WaveFft<LOG2_NC>::P;
+    if (g.phased) {  // hop = 480-style framing (see stft_wave_kernel): only the default shape of n_fft = 2048 is instantiated
+        if constexpr (LOG2_NC == 10 && WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES)
+            return launch_wave_t4<LOG2_NC, WAVES, -1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
+                                                      d_queue_head, n_cu, out, s);
+        return hipErrorInvalidValue;
+    }
     const int sh = wave_shift<LOG2_NC>(g);
     // instantiate the common overlaps only: 75 % (hop = n_fft/4), 50 % and 87.5 %
 #define TH_SHIFT_CASE(SH)                                                                                             \
@@ -864,6 +896,14 @@ static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const 
     if (waves <= 0) waves = WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES;
     return launch_wave_t2<LOG2_NC>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu,
                                    waves, out, s);
+}
+
+// phased mode (stft_wave_kernel, SHIFT = -1): hop = 3 * 128 + 96 samples, at least 96 samples of zero padding, n_fft =
+// 2048, linear output, default launch shape, and room in LDS for three more window tables
+bool stft_wave_phased_supported(const StftGeom &g, int waves) {
+    if (g.log2_nc != 10 || g.n_mel != 0 || g.hop != 3 * 128 + 96 || g.n_fft - g.win < 96 || (g.win & 1u)) return false;
+    if (!(waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES)) return false;
+    return wave_lds_bytes<10, WaveLaunchCfg<10>::DEFAULT_WAVES>() + 3 * sizeof(cf32) * (size_t)WaveFft<10>::NC <= 160 * 1024;
 }
 
 uint32_t stft_wave_mel_max_pieces(const StftGeom &g) {

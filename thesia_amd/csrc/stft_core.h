@@ -59,6 +59,7 @@ struct StftGeom {
     uint32_t height;     // columns of the output spec: n_freq (linear) or n_mel
     uint32_t n_mel;      // 0 = linear
     uint32_t frames_per_tile;
+    uint32_t phased;     // wave kernel: 1 = frames are loaded from the 128-sample grid below their start (hop % 128 == 96)
 };
 
 // One frame range of one channel of the batch (device pointers).  A launch processes frames
