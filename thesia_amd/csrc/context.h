@@ -73,7 +73,7 @@ struct th_plan {
     th::cf32 *d_tw = nullptr;
     uint32_t *d_queue_head = nullptr;  // wave kernel: chunk queue head (reset before every launch)
     th::cf32 *d_wtab = nullptr;  // wave kernel: 0.5 * zero-padded window as (even, odd) pairs
-    th::cf32 *d_wtab_phased = nullptr;  // phased mode: four tables, the window shifted to offsets 0, 96, 64, 32 (NULL: not applicable)
+    th::cf32 *d_wtab_phased = nullptr;  // phased mode: 48 zero pairs + the table with the window at offset 0 (NULL: not applicable)
     bool use_wave() const;
     float *d_mel_fb = nullptr;
     uint32_t *d_mel_lo = nullptr, *d_mel_hi = nullptr;

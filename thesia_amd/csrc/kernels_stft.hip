@@ -502,18 +502,19 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     constexpr int P = W::P, NC = W::NC;
     // SHIFT = -1: "phased" mode for hop = 3 * 128 + 96 samples (the app's 40 ms / 4 at 48 kHz = 480) with n_fft - win
     // >= 96.  |X| does not change when the windowed frame moves inside its zero padding, so every frame is loaded from
-    // the 128-sample grid point below its first window sample; its offset from there cycles 0, 96, 64, 32 and four
-    // window tables shifted by that much sit in LDS.  Consecutive frames then differ by 3, 4, 4, 4 whole register slots:
-    // the rotation scheme below with one extra slot move per four frames.  Chunks start on offset-0 frames (host).
+    // the 128-sample grid point below its first window sample; its offset from there cycles 0, 96, 64, 32, and the window
+    // table (window at offset 0, 48 zero pairs in front) is read that many samples lower.  Consecutive frames then differ
+    // by 3, 4, 4, 4 whole register slots: the rotation scheme below with one extra slot move per four frames.  Chunks
+    // start on offset-0 frames (host).
     constexpr bool PHASED = SHIFT < 0;
     static_assert(PHASED || (SHIFT >= 0 && SHIFT < P), "shift must leave something to reuse");
-    static_assert(!PHASED || (P == 16 && OUT == 0), "phased mode: n_fft = 2048, linear output");
-    constexpr int NWT = PHASED ? 4 : 1;  // window tables
+    static_assert(!PHASED || (P == 16 && OUT != 1), "phased mode: n_fft = 2048, dB output (linear or fused mel)");
+    constexpr int WPAD = PHASED ? 48 : 0;  // zero pairs in front of the window table: room to read it 96 samples lower
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *wtab = reinterpret_cast<cf32 *>(smem_raw);
     // the split-twiddle table is not kept in LDS when the lanes hold their entries in registers (RES bit 3)
     constexpr bool STW_IN_LDS = !((RES & 8) && W::PAIRED);
-    cf32 *stw = wtab + NWT * NC;
+    cf32 *stw = wtab + NC + WPAD;
     cf32 *t2 = stw + (STW_IN_LDS ? NC : 0);
     cf32 *t3 = t2 + W::T2_LEN;
     cf32 *slabs = t3 + W::T3_LEN;
@@ -523,10 +524,10 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // wave index is wave-uniform: tell the compiler, so the frame cursor lives in SGPRs / SALU
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
-#pragma unroll
-        for (int r = 0; r < NWT; r++) wtab[r * NC + i] = wtab_g[r * NC + i];
+        wtab[WPAD + i] = wtab_g[WPAD + i];
         if constexpr (STW_IN_LDS) stw[i] = tw[i];
     }
+    if (tid < WPAD) wtab[tid] = wtab_g[tid];
     W::fill_tables(tid, 64 * WAVES, tw, t2, t3);
     if constexpr (OUT == 2)
         for (uint32_t i = tid; i < wo.mel_words; i += 64 * WAVES) meltab[i] = wo.mel_tab[i];
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #define TH_BODY_OFF(ROT) (PHASED ? ((ROT) == 0 ? 0 : 4 * (ROT) - 1) : (ROTATE ? (ROT) * SHIFT : 0))
 #define TH_FRAME(ROT)                                                                                                  \
     wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : -1>(                 \
-        g, wtab + (PHASED ? (ROT) * NC : 0), stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
+        g, wtab + (PHASED ? WPAD - ((96 * (ROT)) & 127) / 2 : 0), stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
         lmax, meltab, wo TH_PROF_ARGS)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
     cf32 rw[(RESK & 1) ? P : 1], rw2[(RESK & 2) ? W::R2 - 1 : 1];
@@ -798,7 +799,7 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
     const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>() + (OUT == 2 ? (size_t)out.mel_words * 4 : 0) +
-                       (SHIFT < 0 ? 3 * sizeof(cf32) * (size_t)WaveFft<LOG2_NC>::NC : 0);  // phased: four window tables
+                       (SHIFT < 0 ? 48 * sizeof(cf32) : 0);  // phased: zero pairs in front of the window table
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -816,10 +817,12 @@ template <int LOG2_NC, int WAVES, int SHIFT>
 static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
-    if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES && SHIFT >= 0) {
-        if (out.mode == 1)
-            return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
-                                                                    d_tw, nullptr, d_queue_head, n_cu, out, s);
+    if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
+        if constexpr (SHIFT >= 0) {
+            if (out.mode == 1)
+                return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
+                                                                        d_tw, nullptr, d_queue_head, n_cu, out, s);
+        }
         if constexpr (LOG2_NC == 10 && WaveFft<LOG2_NC>::PAIRED) {
             if (out.mode == 2)
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
@@ -899,11 +902,10 @@ static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const 
 }
 
 // phased mode (stft_wave_kernel, SHIFT = -1): hop = 3 * 128 + 96 samples, at least 96 samples of zero padding, n_fft =
-// 2048, linear output, default launch shape, and room in LDS for three more window tables
+// 2048, default launch shape; dB output (linear or fused mel)
 bool stft_wave_phased_supported(const StftGeom &g, int waves) {
-    if (g.log2_nc != 10 || g.n_mel != 0 || g.hop != 3 * 128 + 96 || g.n_fft - g.win < 96 || (g.win & 1u)) return false;
-    if (!(waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES)) return false;
-    return wave_lds_bytes<10, WaveLaunchCfg<10>::DEFAULT_WAVES>() + 3 * sizeof(cf32) * (size_t)WaveFft<10>::NC <= 160 * 1024;
+    if (g.log2_nc != 10 || g.hop != 3 * 128 + 96 || g.n_fft - g.win < 96 || (g.win & 1u)) return false;
+    return waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES;
 }
 
 uint32_t stft_wave_mel_max_pieces(const StftGeom &g) {
@@ -916,7 +918,7 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words) {
     const size_t extra = (size_t)words * 4;
     if (g.log2_nc != 10) return false;
     return (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES) &&
-           wave_lds_bytes<10, WaveLaunchCfg<10>::DEFAULT_WAVES>() + extra <= 160 * 1024;
+           wave_lds_bytes<10, WaveLaunchCfg<10>::DEFAULT_WAVES>() + extra + 48 * sizeof(cf32) <= 160 * 1024;  // (+ phased pad)
 }
 
 int stft_wave_default_waves(const StftGeom &g) {
