@@ -450,12 +450,22 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
         std::vector<float> wpad(n_fft, 0.f);
         for (size_t i = 0; i < win; i++) wpad[g.pad_left + i] = 0.5f * w[i];
         rc = up((void **)&p->d_wtab, wpad.data(), wpad.size() * sizeof(float));
-        // phased mode of the wave kernel (hop = 480-style framings, kernels_stft.hip): the same table with the window at
-        // offset 0 instead of pad_left, behind 48 zero pairs (the kernel reads it 0, 96, 64 or 32 samples lower)
-        if (rc == TH_OK && th::stft_wave_phased_supported(g, 0)) {
+        // grid-aligned modes of the wave kernel (kernels_stft.hip): the window at offset 0 instead of pad_left.
+        // phased (hop 480): behind 48 zero pairs (read 0, 96, 64 or 32 samples lower);  dynamic (e.g. hop 441): behind 64
+        // zero pairs, followed by the same with every pair shifted by one sample (odd offsets)
+        const int pm = th::stft_wave_phased_mode(g, 0);
+        if (rc == TH_OK && pm == 1) {
             std::vector<float> w4(96 + n_fft, 0.f);
             for (size_t i = 0; i < win; i++) w4[96 + i] = 0.5f * w[i];
             rc = up((void **)&p->d_wtab_phased, w4.data(), w4.size() * sizeof(float));
+        } else if (rc == TH_OK && pm == 2) {
+            std::vector<float> t0(n_fft + 2, 0.f), w2(2 * (128 + n_fft), 0.f);
+            for (size_t i = 0; i < win; i++) t0[i] = 0.5f * w[i];
+            for (size_t i = 0; i < n_fft; i++) {
+                w2[128 + i] = t0[i];                       // even table: pairs (t0[2n], t0[2n+1])
+                w2[128 + n_fft + 128 + i] = t0[i + 1];     // odd table:  pairs (t0[2n+1], t0[2n+2])
+            }
+            rc = up((void **)&p->d_wtab_phased, w2.data(), w2.size() * sizeof(float));
         }
     }
     if (rc == TH_OK) rc = up((void **)&p->d_window, w.data(), w.size() * sizeof(float));
@@ -628,16 +638,17 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     // first window sample; chunks must start on frames that sit exactly on the grid (every fourth)
     // (not with the fused mel epilogue: measured no gain there — 0.534 vs 0.536 ms on the app default — the window then
     // comes from LDS instead of registers and the mel kernel is not bound by its loads)
-    const bool phased = wave && !mel_mfma && !mel_fused && p->kernel_choice != 4 && p->d_wtab_phased != nullptr &&
-                        th::stft_wave_phased_supported(g, p->wave_waves);
-    g.phased = phased ? 1u : 0u;
-    auto interior = [&g, phased](const th_chan_desc &d, uint64_t T, uint64_t &fa, uint64_t &fb) {
+    const int phase_mode = (wave && !mel_mfma && !mel_fused && p->kernel_choice != 4 && p->d_wtab_phased != nullptr)
+                               ? th::stft_wave_phased_mode(g, p->wave_waves) : 0;
+    const bool phased = phase_mode != 0;
+    g.phased = (uint32_t)phase_mode;
+    auto interior = [&g, phased, phase_mode](const th_chan_desc &d, uint64_t T, uint64_t &fa, uint64_t &fb) {
         if (phased) {
             const int64_t N = (int64_t)d.n_samples, half = (int64_t)(g.win / 2);
             auto delta = [&](int64_t f) { return (((f * (int64_t)g.hop - half) % 128) + 128) % 128; };
             auto start = [&](int64_t f) { return f * (int64_t)g.hop - half - delta(f); };
             int64_t a = 0, b = (int64_t)T;
-            while (a < b && (start(a) < 0 || delta(a) != 0)) a++;
+            while (a < b && (start(a) < 0 || (phase_mode == 1 && delta(a) != 0))) a++;  // phased chunks start on the grid
             while (b > a && start(b - 1) + (int64_t)g.n_fft > N) b--;
             fa = (uint64_t)a;
             fb = (uint64_t)b;
@@ -684,7 +695,7 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
             chunk = chunk < 12 ? 12 : (chunk > 32 ? 32 : chunk);
         }
         g.frames_per_tile = p->wave_chunk > 0 ? (uint32_t)p->wave_chunk : (uint32_t)chunk;
-        if (phased) g.frames_per_tile = std::max<uint32_t>(4, (g.frames_per_tile + 3) / 4 * 4);  // chunks start on the grid
+        if (phase_mode == 1) g.frames_per_tile = std::max<uint32_t>(4, (g.frames_per_tile + 3) / 4 * 4);  // chunks start on the grid
     } else {
         g.frames_per_tile = 8;
     }

@@ -41,7 +41,7 @@ struct WaveOut {
 };
 // pieces the per-wave (r, f) buffer of the fused mel epilogue can hold for this n_fft (0: not supported), and whether
 // the launch shape leaves room in LDS for a table of `words`
-bool stft_wave_phased_supported(const StftGeom &g, int waves);
+int stft_wave_phased_mode(const StftGeom &g, int waves);  // 0 no, 1 phased (hop 480), 2 dynamic (e.g. 441)
 uint32_t stft_wave_mel_max_pieces(const StftGeom &g);
 bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words);
 // waves: waves per workgroup (4, 8, 12 or 16; <= 0 selects the default for this n_fft)

@@ -259,8 +259,9 @@ __device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const Chan
 // frame element 0 sits at signal position f*hop - win/2 - pad_left; the host only hands interior
 // frames to this kernel, so every windowed sample is inside the channel
 __device__ __forceinline__ int64_t frame_e0(const FrameCursor &c, const StftGeom &g) {
-    // (phased mode: chunks start on frames whose window begins on the 128-sample grid, offset 0)
-    return (int64_t)c.f * g.hop - (int64_t)(g.win / 2) - (int64_t)(g.phased ? 0u : g.pad_left);
+    // (phased / dynamic mode: the load span starts on the 128-sample grid at or below the first window sample)
+    const int64_t s0 = (int64_t)c.f * g.hop - (int64_t)(g.win / 2);
+    return g.phased ? s0 - (s0 & 127) : s0 - (int64_t)g.pad_left;
 }
 
 __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_t slot, uint32_t lane, float lmin,
@@ -289,6 +290,9 @@ __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_
 // mirror-local path).  Worth it when fewer waves per SIMD leave the VGPRs: LDS is a co-bottleneck of this kernel.
 // PH >= 0: "phased" mode (stft_wave_kernel) — this frame sits at offset delta = (96 PH) mod 128 inside its n_fft-sample
 // load span and wtab is the window table shifted by that much; the next frame's offset is (96 (PH + 1)) mod 128.
+// PH == -2: "dynamic" mode — any hop in (128 SHIFT, 128 (SHIFT + 1)): the offset and the number of reused slots (SHIFT or
+// SHIFT + 1) are computed per frame (wave-uniform), registers are moved instead of rotated, wtab = even table, the odd
+// one (pairs shifted by one sample) NC + 64 entries behind it, each with 64 zero pairs in front.
 template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH = -1>
 __device__ __forceinline__ void wave_frame(
     const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
@@ -315,7 +319,11 @@ __device__ __forceinline__ void wave_frame(
     // pass-1 arithmetic, pass-3 and split twiddles together with the reads of exchange 2.
     cf32 z[P];
     cf32 w2[W::R2 - 1];
-    if constexpr (RES & 1) {
+    constexpr bool DYN = PH == -2;
+    if constexpr (DYN) {
+        const uint32_t d = (uint32_t)((int64_t)f * g.hop - (int64_t)(g.win / 2)) & 127u;  // first window sample above the grid
+        wave_window_rot<P, 0>(lane, z, x, wtab + 64 + ((d & 1u) ? NC + 64 : 0) - ((d + 1u) >> 1));
+    } else if constexpr (RES & 1) {
 #pragma unroll
         for (int m = 0; m < P; m++) {
             const cf32 v = x[(m + OFF) % P];
@@ -334,12 +342,28 @@ __device__ __forceinline__ void wave_frame(
 #else
         // (clamped into the channel: the one-frame chunks of boundary frames prefetch "themselves", and that span is
         // partly outside; a no-op for interior frames)
-        const int64_t lead_n = PH >= 0 ? (int64_t)((96 * (PH + 1)) & 127) : (int64_t)g.pad_left;
-        int64_t e0n = (int64_t)fn * g.hop - (int64_t)(g.win / 2) - lead_n;
+        const int64_t s_n = (int64_t)fn * g.hop - (int64_t)(g.win / 2);  // first window sample of the next frame
+        const int64_t lead_n = DYN ? (s_n & 127) : PH >= 0 ? (int64_t)((96 * (PH + 1)) & 127) : (int64_t)g.pad_left;
+        int64_t e0n = s_n - lead_n;
+        bool one_more = false;  // dynamic mode: the next frame's load span starts SHIFT + 1 slots further, not SHIFT
+        if constexpr (DYN) {
+            const int64_t s_c = (int64_t)f * g.hop - (int64_t)(g.win / 2);
+            one_more = e0n - (s_c - (s_c & 127)) > 128 * SHIFT;
+        }
         const int64_t e0_max = (int64_t)n_samples - (int64_t)g.n_fft;
         e0n = e0n < 0 ? 0 : (e0n > e0_max ? e0_max : e0n);
 #endif
-        if constexpr (SHIFT == 0) {
+        if constexpr (DYN) {
+            if (one_more) {  // wave-uniform
+#pragma unroll
+                for (int m = 0; m + SHIFT + 1 < P; m++) x[m] = x[m + SHIFT + 1];
+                wave_fetch<P, P - SHIFT - 1>(lane, x, wav, e0n);
+            } else {
+#pragma unroll
+                for (int m = 0; m + SHIFT < P; m++) x[m] = x[m + SHIFT];
+                wave_fetch<P, P - SHIFT>(lane, x, wav, e0n);
+            }
+        } else if constexpr (SHIFT == 0) {
             wave_fetch<P, 0>(lane, x, wav, e0n);
         } else if constexpr (ROTATE) {
             wave_fetch_rot<P, SHIFT, OFF>(lane, x, wav, e0n);
@@ -506,10 +530,14 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // table (window at offset 0, 48 zero pairs in front) is read that many samples lower.  Consecutive frames then differ
     // by 3, 4, 4, 4 whole register slots: the rotation scheme below with one extra slot move per four frames.  Chunks
     // start on offset-0 frames (host).
-    constexpr bool PHASED = SHIFT < 0;
-    static_assert(PHASED || (SHIFT >= 0 && SHIFT < P), "shift must leave something to reuse");
-    static_assert(!PHASED || (P == 16 && OUT != 1), "phased mode: n_fft = 2048, dB output (linear or fused mel)");
-    constexpr int WPAD = PHASED ? 48 : 0;  // zero pairs in front of the window table: room to read it 96 samples lower
+    // SHIFT = -2: "dynamic" mode for any other hop in (384, 512) with n_fft - win >= 127 (44.1 kHz: 1764 / 441): the same
+    // idea with the offset (any value in [0, 128), odd ones served by a second table whose pairs are shifted by one sample)
+    // and the reuse (3 or 4 slots) decided per frame; registers are moved, not rotated (the offsets have no short cycle).
+    constexpr bool PHASED = SHIFT == -1, DYN = SHIFT == -2;
+    static_assert(PHASED || DYN || (SHIFT >= 0 && SHIFT < P), "shift must leave something to reuse");
+    static_assert(!(PHASED || DYN) || (P == 16 && OUT != 1), "phased / dynamic mode: n_fft = 2048, dB output");
+    // zero pairs in front of the window table(s): room to read them up to 96 (127) samples lower; DYN: even + odd table
+    constexpr int WPAD = PHASED ? 48 : DYN ? 64 + NC + 64 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *wtab = reinterpret_cast<cf32 *>(smem_raw);
     // the split-twiddle table is not kept in LDS when the lanes hold their entries in registers (RES bit 3)
@@ -527,7 +555,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         wtab[WPAD + i] = wtab_g[WPAD + i];
         if constexpr (STW_IN_LDS) stw[i] = tw[i];
     }
-    if (tid < WPAD) wtab[tid] = wtab_g[tid];
+    for (uint32_t i = tid; i < WPAD; i += 64 * WAVES) wtab[i] = wtab_g[i];
     W::fill_tables(tid, 64 * WAVES, tw, t2, t3);
     if constexpr (OUT == 2)
         for (uint32_t i = tid; i < wo.mel_words; i += 64 * WAVES) meltab[i] = wo.mel_tab[i];
@@ -553,12 +581,12 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     constexpr int SHIFT_NZ = SHIFT > 0 ? SHIFT : 1;  // (keeps the constant expression below free of a % 0)
     constexpr bool ROTATE = PHASED || (SHIFT > 0 && P % SHIFT_NZ == 0 && P / SHIFT_NZ <= 4);
     constexpr int NROT = PHASED ? 4 : (ROTATE ? P / SHIFT : 1);
-    constexpr int RESK = PHASED ? (RES & ~1) : RES;  // phased: the window changes every frame, it stays in LDS
+    constexpr int RESK = (PHASED || DYN) ? (RES & ~1) : RES;  // phased: the window changes every frame, it stays in LDS
     // slots reused / rotation offset / window table of body ROT
-#define TH_BODY_SHIFT(ROT) (PHASED ? ((ROT) == 0 ? 3 : 4) : SHIFT)
+#define TH_BODY_SHIFT(ROT) (PHASED ? ((ROT) == 0 ? 3 : 4) : DYN ? 3 : SHIFT)
 #define TH_BODY_OFF(ROT) (PHASED ? ((ROT) == 0 ? 0 : 4 * (ROT) - 1) : (ROTATE ? (ROT) * SHIFT : 0))
 #define TH_FRAME(ROT)                                                                                                  \
-    wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : -1>(                 \
+    wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : DYN ? -2 : -1>(      \
         g, wtab + (PHASED ? WPAD - ((96 * (ROT)) & 127) / 2 : 0), stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
         lmax, meltab, wo TH_PROF_ARGS)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
@@ -799,7 +827,8 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
     const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>() + (OUT == 2 ? (size_t)out.mel_words * 4 : 0) +
-                       (SHIFT < 0 ? 48 * sizeof(cf32) : 0);  // phased: zero pairs in front of the window table
+                       (SHIFT == -1 ? 48 * sizeof(cf32) : 0) +  // phased: zero pairs in front of the window table
+                       (SHIFT == -2 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -849,10 +878,14 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     constexpr int P = WaveFft<LOG2_NC>::P;
-    if (g.phased) {  // hop = 480-style framing (see stft_wave_kernel): only the default shape of n_fft = 2048 is instantiated
-        if constexpr (LOG2_NC == 10 && WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES)
-            return launch_wave_t4<LOG2_NC, WAVES, -1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
+    if (g.phased) {  // grid-aligned loads (see stft_wave_kernel): only the default shape of n_fft = 2048 is instantiated
+        if constexpr (LOG2_NC == 10 && WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
+            if (g.phased == 1)
+                return launch_wave_t4<LOG2_NC, WAVES, -1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
+                                                          d_queue_head, n_cu, out, s);
+            return launch_wave_t4<LOG2_NC, WAVES, -2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
                                                       d_queue_head, n_cu, out, s);
+        }
         return hipErrorInvalidValue;
     }
     const int sh = wave_shift<LOG2_NC>(g);
@@ -901,11 +934,14 @@ static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const 
                                    waves, out, s);
 }
 
-// phased mode (stft_wave_kernel, SHIFT = -1): hop = 3 * 128 + 96 samples, at least 96 samples of zero padding, n_fft =
-// 2048, default launch shape; dB output (linear or fused mel)
-bool stft_wave_phased_supported(const StftGeom &g, int waves) {
-    if (g.log2_nc != 10 || g.hop != 3 * 128 + 96 || g.n_fft - g.win < 96 || (g.win & 1u)) return false;
-    return waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES;
+// grid-aligned register reuse for hops that are not multiples of 128 samples (stft_wave_kernel): 0 = not applicable, 1 =
+// phased (hop = 3 * 128 + 96, n_fft - win >= 96), 2 = dynamic (any other hop in (384, 512), n_fft - win >= 127); n_fft =
+// 2048, default launch shape, dB output
+int stft_wave_phased_mode(const StftGeom &g, int waves) {
+    if (g.log2_nc != 10 || (g.win & 1u) || !(waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES)) return 0;
+    if (g.hop == 3 * 128 + 96 && g.n_fft - g.win >= 96) return 1;                                   // phased: rotation
+    if (g.hop > 3 * 128 && g.hop < 4 * 128 && g.n_fft - g.win >= 127) return 2;                     // dynamic: moves
+    return 0;
 }
 
 uint32_t stft_wave_mel_max_pieces(const StftGeom &g) {
