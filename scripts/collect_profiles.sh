@@ -15,7 +15,11 @@ TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pm
   python3 scripts/bench_stft.py --reps 30 --kernel 0 1
   python3 scripts/bench_stft.py --reps 30 --nfft 1024
   python3 scripts/bench_stft.py --reps 30 --nfft 4096
-  python3 scripts/bench_stft.py --reps 30 --win 1920 --hop 480
+  python3 scripts/bench_stft.py --reps 30 --win 1920 --hop 480 --kernel 0 4   # phased mode vs plain wave kernel
+  python3 scripts/bench_stft.py --reps 30 --win 1764 --hop 441 --kernel 0 4   # dynamic mode vs plain wave kernel
+  python3 scripts/bench_stft.py --reps 30 --win 1920 --hop 480 --gap-ms 1
+  python3 scripts/bench_stft.py --reps 30 --win 1764 --hop 441 --gap-ms 1
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1
   python3 scripts/bench_stft.py --reps 30 --hop 1024
   python3 scripts/bench_stft.py --reps 30 --kernel $((2+(8<<8)+(32<<16))) $((2+(12<<8)+(32<<16))) $((2+(16<<8)+(32<<16)))
 } > "$out/bench_stft.txt" 2>&1
