@@ -16,6 +16,7 @@ side = torch.cuda.Stream(dev)
 torch.cuda.set_stream(side)
 ctx = ta.Context(0, side.cuda_stream)
 sr, n_tr, secs = int(os.environ.get("SR", "44100")), int(os.environ.get("TRACKS", "32")), 60
+GAP_MS = float(os.environ.get("GAP_MS", "0"))  # idle time between launches (the kernels are power-limited)
 WIN, HOP = int(os.environ.get("WIN", "2048")), int(os.environ.get("HOP", "512"))  # SR=48000 WIN=1920 HOP=480: the app default
 n = sr * secs
 g = torch.Generator(device=dev); g.manual_seed(4)
@@ -36,6 +37,9 @@ for n_mel in (128, 0):
     ts = []
     for _ in range(15):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if GAP_MS > 0:
+            import time
+            time.sleep(GAP_MS * 1e-3)
         e0.record(); plan.calc_spec_batch_dev(chan, mm.data_ptr()); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     ms = float(np.median(ts))

@@ -594,7 +594,7 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     TH_REQUIRE(p, "plan is NULL");
     // bits 0-7: 0 auto, 1 generic, 2 wave, 3 wave + matrix-core mel, 4 wave without the phased mode;  bits 8-15 (tuning): waves per workgroup
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 4, "kernel selector must be 0 .. 4");
+    TH_REQUIRE(k >= 0 && k <= 5, "kernel selector must be 0 .. 5");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     p->kernel_choice = k;
@@ -636,9 +636,10 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     // pad_left, lies inside the channel (the wave kernel loads it unconditionally); the others are boundary frames
     // phased mode of the wave kernel (hop = 480-style framings): frames are loaded from the 128-sample grid below their
     // first window sample; chunks must start on frames that sit exactly on the grid (every fourth)
-    // (not with the fused mel epilogue: measured no gain there — 0.534 vs 0.536 ms on the app default — the window then
-    // comes from LDS instead of registers and the mel kernel is not bound by its loads)
-    const int phase_mode = (wave && !mel_mfma && !mel_fused && p->kernel_choice != 4 && p->d_wtab_phased != nullptr)
+    // (not with the fused mel epilogue unless selector 5 asks for it: measured no gain there, with or without idle gaps —
+    // 48 kHz / 347 mels 0.522 vs 0.521 ms, 44.1 kHz / 370 mels 0.513 vs 0.541 — the window then comes from LDS instead of
+    // registers and the mel kernel is not bound by its loads)
+    const int phase_mode = (wave && !mel_mfma && (!mel_fused || p->kernel_choice == 5) && p->kernel_choice != 4 && p->d_wtab_phased != nullptr)
                                ? th::stft_wave_phased_mode(g, p->wave_waves) : 0;
     const bool phased = phase_mode != 0;
     g.phased = (uint32_t)phase_mode;
