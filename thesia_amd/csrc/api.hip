@@ -817,24 +817,25 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
             if (rc != TH_OK) return rc;
             chunk_mm = static_cast<float *>(p->chunk_mm.dptr);
         }
+        uint32_t n_post = 0;
+        if (chunk_mm) {  // per-channel tile ranges for wave_post_kernel: a channel's jobs (interior, head, tail) are consecutive
+            std::vector<th::WavePostJob> pj;
+            for (size_t j = 0; j < jobs.size(); j++) {
+                if (!pj.empty() && pj.back().mm_index == jobs[j].mm_index) pj.back().t1 = tile_start[j + 1];
+                else pj.push_back(th::WavePostJob{tile_start[j], tile_start[j + 1], jobs[j].mm_index, 0u});
+            }
+            rc = p->post_jobs.upload(c->stream, pj.data(), pj.size() * sizeof(th::WavePostJob));
+            if (rc != TH_OK) return rc;
+            n_post = (uint32_t)pj.size();
+        }
         TH_HIP(launch_stft_wave(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                 (uint32_t)jobs.size(), (uint32_t)tiles, phased ? p->d_wtab_phased : p->d_wtab, p->d_tw, chunk_mm, p->d_queue_head,
                                 c->n_cu, waves, wo, c->stream));
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
-        {   // fold the per-chunk (min, max) pairs into the channel slots and rewind the chunk queue
-            std::vector<th::WavePostJob> pj;
-            if (chunk_mm)
-                for (size_t j = 0; j < jobs.size(); j++) {  // a channel's jobs (interior, head, tail) are consecutive
-                    if (!pj.empty() && pj.back().mm_index == jobs[j].mm_index) pj.back().t1 = tile_start[j + 1];
-                    else pj.push_back(th::WavePostJob{tile_start[j], tile_start[j + 1], jobs[j].mm_index, 0u});
-                }
-            if (!pj.empty()) {
-                rc = p->post_jobs.upload(c->stream, pj.data(), pj.size() * sizeof(th::WavePostJob));
-                if (rc != TH_OK) return rc;
-            }
-            TH_HIP(launch_wave_post((const th::WavePostJob *)p->post_jobs.dptr, (uint32_t)pj.size(), chunk_mm, d_minmax,
-                                    all_in_wave, p->d_queue_head, c->stream));
-        }
+        // fold the per-chunk (min, max) pairs into the channel slots and rewind the chunk queue (nothing that can fail sits
+        // between the two launches: a queue left un-rewound would make the next launch skip chunks)
+        TH_HIP(launch_wave_post((const th::WavePostJob *)p->post_jobs.dptr, n_post, chunk_mm, d_minmax, all_in_wave,
+                                p->d_queue_head, c->stream));
         if (mel_mfma)
             TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
                                    (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_bt, p->d_mel_band,
