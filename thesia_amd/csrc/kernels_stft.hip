@@ -456,8 +456,22 @@ __device__ __forceinline__ void wave_frame(
             cf32 *const prf = slab + (NC + 2) / 2;
             const MelFuseTab mt = mel_fuse_view(meltab, wo.mel_slots, wo.mel_groups);
             wave_lds_sync();
+#if !defined(TH_MEL_ABL_NOPIECES)
             mel_pieces(lane, slab_f, prf, mt);
+#endif
             wave_lds_sync();
+#if defined(TH_MEL_ABL_NOGATHER)  // ablation (wrong results): one value per mel straight from the (r, f) buffer
+            for (uint32_t gq = 0; gq < mt.G; gq++) {
+                const uint32_t m = 64u * gq + lane;
+                if (m < wo.n_mel) {
+                    const float d = amp_to_dB_fast(prf[m & 255u].re);
+                    row[m] = d;
+                    lmin = nmin(lmin, d);
+                    lmax = nmax(lmax, d);
+                }
+            }
+            if (false)
+#endif
             mel_gather(lane, prf, mt, [&](uint32_t m, float v) {
                 if (m < wo.n_mel) {
                     const float d = amp_to_dB_fast(v);
