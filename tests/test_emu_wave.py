@@ -92,3 +92,32 @@ def test_fused_mel_epilogue_tables(emu, sr, n_fft, n_mel):
         assert np.all(np.abs(out - want) <= 4e-6 * want + 1e-30), np.abs(out / np.maximum(want, 1e-300) - 1).max()
     # the pieces cost about what the non-zeros do: 2 weights per bin, 4 bins per piece
     assert info[0] <= F / 4 + M + 2, info
+
+
+def test_fused_mel_tables_refuse_what_is_not_a_triangle_filterbank(emu):
+    """build_mel_fuse (mel_fuse.h) verifies the structure it relies on and reports "not fusable" (the plan then keeps the
+    matrix-core path) for: a dense matrix, three filters at one bin, two non-neighbouring filters at one bin, segments
+    that go backwards, a negative weight, too many pieces for the (r, f) buffer."""
+    f32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    emu.emu_mel_fuse.argtypes = [f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p]
+    F, M = 257, 20
+    good = np.ascontiguousarray(orc.calc_mel_fb(16000, 512, M), np.float32)
+    assert good.shape == (F, M)
+
+    def rc(fb, max_pieces=512):
+        fb = np.ascontiguousarray(fb, np.float32)
+        amp, out, info = np.ones(F, np.float32), np.empty(M, np.float32), np.zeros(3, np.uint32)
+        return emu.emu_mel_fuse(amp.ctypes.data_as(f32p), fb.ctypes.data_as(f32p), F, M, max_pieces,
+                                out.ctypes.data_as(f32p), info.ctypes.data_as(u32p))
+
+    assert rc(good) == 0
+    assert rc(np.random.default_rng(0).uniform(0.1, 1, (F, M))) == 1            # dense
+    bad = good.copy(); k = int(np.argmax(good[:, 10])); bad[k, 3] = 0.5; bad[k, 4] = 0.5
+    assert rc(bad) == 1                                                         # more filters at one bin
+    bad = np.zeros_like(good); bad[50, 2] = 1; bad[50, 7] = 1
+    assert rc(bad) == 1                                                         # two that are not neighbours
+    bad = np.zeros_like(good); bad[10, 9] = 1; bad[20, 3] = 1
+    assert rc(bad) == 1                                                         # segments go backwards
+    bad = good.copy(); bad[k, 10] = -bad[k, 10]
+    assert rc(bad) == 1                                                         # negative weight
+    assert rc(good, max_pieces=8) == 1                                          # does not fit the (r, f) buffer
