@@ -402,6 +402,13 @@ def test_track_manager_flow(ctx, golden_dir):
     tm.set_setting(2048 / 48, 4, 1, ta.LINEAR)
     assert tm.spec(2, 0).shape == (orc.stft_n_frames(40000, 2048, 512), 1025)
     assert_spec_close(tm.spec(2, 1), orc.calc_spec(tracks[2][2][1], 2048, 512, 2048))
+    # the app's own 40 ms window with a linear scale: 48 kHz -> 1920 / 480 / 2048 (phased register reuse), 44.1 kHz ->
+    # 1764 / 441 / 2048 (dynamic), 8 kHz -> 320 / 80 / 512 (generic kernel)
+    tm.set_setting(40.0, 4, 1, ta.LINEAR)
+    for tid, sr, wav in tracks:
+        hop, win, n_fft = orc.calc_framing_params(40.0, 4, 1, sr)
+        for ch in range(wav.shape[0]):
+            assert_spec_close(tm.spec(tid, ch), orc.calc_spec(wav[ch], win, hop, n_fft))
     tm.remove_track(0)
     with pytest.raises(ta.ThError) as e:
         tm.spec(0, 0)
