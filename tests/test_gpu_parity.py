@@ -830,15 +830,18 @@ def test_hip_graph_replay_of_a_single_track_step(ctx, golden_dir):
     plan.close()
 
 
-@pytest.mark.parametrize("win,hop", [(1920, 480), (1952, 480), (1800, 480), (1764, 441), (1700, 400), (1900, 500), (1920, 479)])
-def test_phased_register_reuse_for_hop_480(ctx, win, hop):
+@pytest.mark.parametrize("win,hop,n_fft", [(1920, 480, 2048), (1952, 480, 2048), (1800, 480, 2048), (1764, 441, 2048),
+                                           (1700, 400, 2048), (1900, 500, 2048), (1920, 479, 2048), (1280, 320, 2048),
+                                           (1200, 300, 2048), (640, 160, 1024), (884, 221, 1024), (800, 255, 1024)])
+def test_phased_register_reuse_for_hop_480(ctx, win, hop, n_fft):
     """hop = 480 (the app's 40 ms / 4 at 48 kHz) with n_fft = 2048: the wave kernel loads every frame from the 128-sample grid
     below its first window sample (|X| does not change when the windowed frame moves inside its zero padding) and reuses
     3, 4, 4, 4 register slots between consecutive frames.  Must match the oracle like every other framing, must equal
     the unphased wave kernel to f32-FFT accuracy, and a ragged batch must equal single launches bit for bit."""
     # (hop 480: "phased" — offsets cycle 0, 96, 64, 32, slot rotation; other hops in (384, 512), e.g. 441 at 44.1 kHz:
     # "dynamic" — offset and reuse decided per frame, odd offsets through the one-sample-shifted window table)
-    sr, n_fft = 48000, 2048
+    # (also n_fft = 2048 with hops in (256, 384), 32 kHz: 1280 / 320, and n_fft = 1024 with hops in (128, 256), 16 kHz: 640 / 160)
+    sr = 48000
     wavs = [synth_track(900 + i, sr, n) for i, n in enumerate((131072, 40000, 2048, 2049, 3000, 97531))]
     plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
     specs, mm = plan.calc_spec_batch(wavs)

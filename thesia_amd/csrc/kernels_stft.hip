@@ -547,9 +547,12 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // SHIFT = -2: "dynamic" mode for any other hop in (384, 512) with n_fft - win >= 127 (44.1 kHz: 1764 / 441): the same
     // idea with the offset (any value in [0, 128), odd ones served by a second table whose pairs are shifted by one sample)
     // and the reuse (3 or 4 slots) decided per frame; registers are moved, not rotated (the offsets have no short cycle).
-    constexpr bool PHASED = SHIFT == -1, DYN = SHIFT == -2;
+    // (SHIFT = -16 - K encodes the dynamic mode for hops in (128 K, 128 (K + 1)): K or K + 1 slots are reused)
+    constexpr bool PHASED = SHIFT == -1, DYN = SHIFT <= -16;
+    constexpr int DYN_K = DYN ? -SHIFT - 16 : 0;
     static_assert(PHASED || DYN || (SHIFT >= 0 && SHIFT < P), "shift must leave something to reuse");
-    static_assert(!(PHASED || DYN) || (P == 16 && OUT != 1), "phased / dynamic mode: n_fft = 2048, dB output");
+    static_assert(!PHASED || (P == 16 && OUT != 1), "phased mode: n_fft = 2048, dB output");
+    static_assert(!DYN || (DYN_K >= 1 && DYN_K + 1 < P && OUT != 1), "dynamic mode: something to reuse, dB output");
     // zero pairs in front of the window table(s): room to read them up to 96 (127) samples lower; DYN: even + odd table
     constexpr int WPAD = PHASED ? 48 : DYN ? 64 + NC + 64 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     constexpr int NROT = PHASED ? 4 : (ROTATE ? P / SHIFT : 1);
     constexpr int RESK = (PHASED || DYN) ? (RES & ~1) : RES;  // phased: the window changes every frame, it stays in LDS
     // slots reused / rotation offset / window table of body ROT
-#define TH_BODY_SHIFT(ROT) (PHASED ? ((ROT) == 0 ? 3 : 4) : DYN ? 3 : SHIFT)
+#define TH_BODY_SHIFT(ROT) (PHASED ? ((ROT) == 0 ? 3 : 4) : DYN ? DYN_K : SHIFT)
 #define TH_BODY_OFF(ROT) (PHASED ? ((ROT) == 0 ? 0 : 4 * (ROT) - 1) : (ROTATE ? (ROT) * SHIFT : 0))
 #define TH_FRAME(ROT)                                                                                                  \
     wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : DYN ? -2 : -1>(      \
@@ -842,7 +845,7 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
     auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
     const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>() + (OUT == 2 ? (size_t)out.mel_words * 4 : 0) +
                        (SHIFT == -1 ? 48 * sizeof(cf32) : 0) +  // phased: zero pairs in front of the window table
-                       (SHIFT == -2 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes
+                       (SHIFT <= -16 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -892,13 +895,22 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     constexpr int P = WaveFft<LOG2_NC>::P;
-    if (g.phased) {  // grid-aligned loads (see stft_wave_kernel): only the default shape of n_fft = 2048 is instantiated
-        if constexpr (LOG2_NC == 10 && WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
-            if (g.phased == 1)
-                return launch_wave_t4<LOG2_NC, WAVES, -1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
-                                                          d_queue_head, n_cu, out, s);
-            return launch_wave_t4<LOG2_NC, WAVES, -2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax,
-                                                      d_queue_head, n_cu, out, s);
+    if (g.phased) {  // grid-aligned loads (see stft_wave_kernel): only the default launch shapes are instantiated
+        if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
+            const uint32_t k = g.hop / 128;
+#define TH_DYN_CASE(L2, K)                                                                                            \
+    if constexpr (LOG2_NC == (L2))                                                                                    \
+        if (g.phased == 2 && k == (K))                                                                                \
+            return launch_wave_t4<LOG2_NC, WAVES, -16 - (K)>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw,   \
+                                                             d_minmax, d_queue_head, n_cu, out, s);
+            if constexpr (LOG2_NC == 10)
+                if (g.phased == 1)
+                    return launch_wave_t4<LOG2_NC, WAVES, -1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw,
+                                                              d_minmax, d_queue_head, n_cu, out, s);
+            TH_DYN_CASE(10, 3)  // 44.1 kHz: 1764 / 441
+            TH_DYN_CASE(10, 2)  // 32 kHz: 1280 / 320
+            TH_DYN_CASE(9, 1)   // 16 kHz: 640 / 160, 22.05 kHz: 884 / 221
+#undef TH_DYN_CASE
         }
         return hipErrorInvalidValue;
     }
@@ -949,12 +961,17 @@ static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const 
 }
 
 // grid-aligned register reuse for hops that are not multiples of 128 samples (stft_wave_kernel): 0 = not applicable, 1 =
-// phased (hop = 3 * 128 + 96, n_fft - win >= 96), 2 = dynamic (any other hop in (384, 512), n_fft - win >= 127); n_fft =
-// 2048, default launch shape, dB output
+// phased (n_fft 2048, hop = 3 * 128 + 96, n_fft - win >= 96), 2 = dynamic (n_fft 2048: any other hop in (256, 512), n_fft
+// 1024: hop in (128, 256); n_fft - win >= 127); default launch shapes, dB output
 int stft_wave_phased_mode(const StftGeom &g, int waves) {
-    if (g.log2_nc != 10 || (g.win & 1u) || !(waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES)) return 0;
-    if (g.hop == 3 * 128 + 96 && g.n_fft - g.win >= 96) return 1;                                   // phased: rotation
-    if (g.hop > 3 * 128 && g.hop < 4 * 128 && g.n_fft - g.win >= 127) return 2;                     // dynamic: moves
+    if ((g.win & 1u) || g.hop % 128 == 0) return 0;
+    const uint32_t k = g.hop / 128;
+    if (g.log2_nc == 10 && (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES)) {
+        if (g.hop == 3 * 128 + 96 && g.n_fft - g.win >= 96) return 1;     // phased: rotation
+        if ((k == 2 || k == 3) && g.n_fft - g.win >= 127) return 2;         // dynamic: moves
+    }
+    if (g.log2_nc == 9 && (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) && k == 1 && g.n_fft - g.win >= 127)
+        return 2;
     return 0;
 }
 
