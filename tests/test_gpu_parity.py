@@ -859,3 +859,45 @@ def test_phased_register_reuse_for_hop_480(ctx, win, hop, n_fft):
         assert np.array_equal(one, specs[i]) and (mn, mx) == (mm[i, 0], mm[i, 1])
     plan.close()
     plan4.close()
+
+
+@pytest.mark.parametrize("win,hop,n_fft,scale,n_mel", [(2048, 512, 2048, "lin", 0), (1920, 480, 2048, "lin", 0),
+                                                       (1764, 441, 2048, "lin", 0), (2048, 512, 2048, "mel", 128),
+                                                       (4096, 1024, 4096, "mel", 64), (256, 64, 256, "lin", 0)])
+def test_calc_spec_without_minmax_and_back_to_back(ctx, win, hop, n_fft, scale, n_mel):
+    """d_minmax = NULL is allowed (no min / max wanted); the spec must not depend on it, and launches of different batch
+    shapes in a row must not disturb each other (the wave kernel's chunk queue is rewound by every launch)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    plan = ta.Plan(ctx, 48000, win, hop, n_fft, ta.MEL if scale == "mel" else ta.LINEAR, n_mel)
+    H = plan.height
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+
+    def run(lengths, with_mm):
+        wavs = [((torch.rand(n, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + i)) - 0.5) * 0.5).contiguous()
+                for i, n in enumerate(lengths)]
+        Ts = [plan.n_frames(n) for n in lengths]
+        specs = [torch.full((T, H), -777.0, dtype=torch.float32, device=dev) for T in Ts]
+        mm = torch.zeros((len(lengths), 2), dtype=torch.float32, device=dev)
+        chan = (ta.ChanDesc * len(lengths))(*[ta.ChanDesc(w.data_ptr(), s.data_ptr(), n, T, 0)
+                                              for w, s, n, T in zip(wavs, specs, lengths, Ts)])
+        torch.cuda.synchronize()
+        plan.calc_spec_batch_dev(chan, mm.data_ptr() if with_mm else None)
+        ctx.synchronize()
+        return [s.cpu().numpy() for s in specs], mm.cpu().numpy()
+
+    big, small = (90000, 5000, 33333, 70001), (12000,)
+    a, mm_a = run(big, True)
+    b, _ = run(small, False)          # a different shape in between, without min / max
+    c, mm_c = run(big, False)
+    d, mm_d = run(big, True)
+    for x, y, z in zip(a, c, d):
+        assert not (x == -777.0).any()
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    assert np.array_equal(mm_a, mm_d) and not mm_c.any()
+    for i, x in enumerate(a):
+        assert mm_a[i, 0] == x.min() and mm_a[i, 1] == x.max()
+    b2, _ = run(small, True)
+    assert np.array_equal(b[0], b2[0])
+    plan.close()
