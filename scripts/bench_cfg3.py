@@ -85,7 +85,7 @@ byt = samples * 4 + n_ch * tot * 4
 print(f"cfg3 waveform pyramid (one pass, levels 0..12): {ms:.3f} ms  {samples / ms / 1e3:.0f} Msamples/s  "
       f"{byt / ms / 1e6:.0f} GB/s algorithmic ({byt / ms / 1e6 / 80:.1f}% of 8 TB/s; 4 B read + {n_ch * tot * 4 / samples:.2f} B written per sample)")
 # where the time goes: the same pass with fewer levels (1 = the one-sample bins only: 16 B per sample)
-for nl in (1, 2, 5):
+for nl in (1, 2, 5, 6, 8, 11, 12):
     totl = ta.api.pyramid_offset(n, nl)
     pl = torch.empty((n_ch, totl), dtype=torch.float32, device=dev)
     pdl = (_ffi.PyramidDesc * n_ch)(*[_ffi.PyramidDesc(wav[c].data_ptr(), pl[c].data_ptr(), n, nl, 0) for c in range(n_ch)])
