@@ -8,6 +8,8 @@
 // SURVEY.md A12).  Pure HBM streaming: 4 B read per sample.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "stft_core.h"
 
@@ -154,6 +156,10 @@ __device__ __forceinline__ void pyr_emit(float *stage, uint32_t lane, const floa
 // grid: (segments of the longest channel, channels); shorter channels leave early
 __global__ __launch_bounds__(256) void pyramid_base_kernel(const PyrJob *__restrict__ jobs) {
     __shared__ float stage_all[4][64 * PYR_LDS_STRIDE];
+    __shared__ float wtot[4][3];
+    __shared__ uint32_t waves_done;
+    if (threadIdx.x == 0) waves_done = 0;
+    __syncthreads();  // (at the start, where the four waves are still in step: costs nothing)
     const PyrJob job = jobs[blockIdx.y];
     // Workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous run of segments instead of every
     // eighth one (the segment may then lie past the channel's end: checked right below).  Measured on config 3: levels 0
@@ -265,13 +271,35 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const PyrJob *__restr
     // levels 5..10 (bins of 32 .. 1024 samples = 2 .. 64 lanes): xor-butterfly inside the wave — min of mins, max
     // of maxes, pairwise sums; the first lane of every group writes the bin.  (12-byte strided stores: these
     // levels together are 3 % of the bytes.)
+    // (only the first lane of a group of 2^k lanes keeps a meaningful value, and it needs the lane 2^(k-1) above it:
+    // inside a 16-lane row that is a DPP row shift at register speed — `row_shl:n` gives lane i the value of lane i + n —
+    // and only the two cross-row steps go through ds_bpermute; commutative operations, so the result is bit for bit the
+    // xor-butterfly's)
     float mn = mn16, mx = mx16, sum = sum16;
+    auto up = [](float v, auto kc) -> float {
+        constexpr uint32_t K = decltype(kc)::value;
+        if constexpr (K <= 4) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + (1 << (K - 1)), 0xf, 0xf, false));
+        } else {
+            return __shfl_down(v, 1 << (K - 1), 64);
+        }
+    };
 #pragma unroll
-    for (uint32_t k = 1; k <= 6; k++) {
+    for (uint32_t kk = 1; kk <= 6; kk++) {
+        const uint32_t k = kk;
         const uint32_t level = 4 + k;
-        mn = fminf(mn, __shfl_xor(mn, 1 << (k - 1), 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 1 << (k - 1), 64));
-        sum = sum + __shfl_xor(sum, 1 << (k - 1), 64);
+        float pmn, pmx, psum;
+        switch (kk) {  // (the DPP control word must be a compile-time constant)
+            case 1: pmn = up(mn, std::integral_constant<uint32_t, 1>{}); pmx = up(mx, std::integral_constant<uint32_t, 1>{}); psum = up(sum, std::integral_constant<uint32_t, 1>{}); break;
+            case 2: pmn = up(mn, std::integral_constant<uint32_t, 2>{}); pmx = up(mx, std::integral_constant<uint32_t, 2>{}); psum = up(sum, std::integral_constant<uint32_t, 2>{}); break;
+            case 3: pmn = up(mn, std::integral_constant<uint32_t, 3>{}); pmx = up(mx, std::integral_constant<uint32_t, 3>{}); psum = up(sum, std::integral_constant<uint32_t, 3>{}); break;
+            case 4: pmn = up(mn, std::integral_constant<uint32_t, 4>{}); pmx = up(mx, std::integral_constant<uint32_t, 4>{}); psum = up(sum, std::integral_constant<uint32_t, 4>{}); break;
+            case 5: pmn = up(mn, std::integral_constant<uint32_t, 5>{}); pmx = up(mx, std::integral_constant<uint32_t, 5>{}); psum = up(sum, std::integral_constant<uint32_t, 5>{}); break;
+            default: pmn = up(mn, std::integral_constant<uint32_t, 6>{}); pmx = up(mx, std::integral_constant<uint32_t, 6>{}); psum = up(sum, std::integral_constant<uint32_t, 6>{}); break;
+        }
+        mn = fminf(mn, pmn);
+        mx = fmaxf(mx, pmx);
+        sum = sum + psum;
         const uint64_t s0 = wave_base + (uint64_t)(lane >> k << k) * PYR_SPT;  // first sample of the group's bin
         if (level < job.n_levels && (lane & ((1u << k) - 1)) == 0 && s0 < n) {
             const uint64_t len = min(n, s0 + ((uint64_t)PYR_SPT << k)) - s0;
@@ -281,16 +309,23 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const PyrJob *__restr
             d[2] = sum / (float)len;
         }
     }
-    // levels 11, 12 (2 and 4 waves) through LDS; the level-12 sums feed pyramid_up_kernel for levels >= 13
-    __shared__ float wtot[4][3];
+    // levels 11, 12 (2 and 4 waves) through LDS; the level-12 sums feed pyramid_up_kernel for levels >= 13.  No
+    // workgroup barrier here: every wave leaves its totals and counts itself (LDS atomic), and the wave that arrives last
+    // writes the three bins — the other three are gone by then instead of waiting (the barrier version spent 7 % of the
+    // kernel on these 36 bytes per block).
     if (lane == 0) {
         wtot[wv][0] = mn;
         wtot[wv][1] = mx;
         wtot[wv][2] = sum;
     }
-    __syncthreads();
-    if (threadIdx.x < 2) {  // level 11: waves (0,1) and (2,3)
-        const uint32_t a = 2 * threadIdx.x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&waves_done, 1u);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived != 3) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < 2) {  // level 11: waves (0,1) and (2,3)
+        const uint32_t a = 2 * lane;
         const uint64_t s0 = (uint64_t)seg * PYR_SEG + (uint64_t)a * 64 * PYR_SPT;
         if (11 < job.n_levels && s0 < n) {
             const uint64_t len = min(n, s0 + 2048) - s0;
@@ -299,7 +334,7 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const PyrJob *__restr
             d[1] = fmaxf(wtot[a][1], wtot[a + 1][1]);
             d[2] = (wtot[a][2] + wtot[a + 1][2]) / (float)len;
         }
-    } else if (threadIdx.x == 64) {  // level 12: the whole block
+    } else if (lane == 2) {  // level 12: the whole block
         const uint64_t s0 = (uint64_t)seg * PYR_SEG;
         const float s = (wtot[0][2] + wtot[1][2]) + (wtot[2][2] + wtot[3][2]);
         if (12 < job.n_levels) {
