@@ -351,7 +351,9 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const PyrJob *__restr
 // level L (>= 13) from level L-1: thread per destination bin (a few bins per channel)
 __global__ __launch_bounds__(256) void pyramid_up_kernel(const PyrJob *__restrict__ jobs, uint32_t level,
                                                          uint32_t parity) {
-    const PyrJob job = jobs[blockIdx.y];
+    // (a reference, not a copy: level_off is indexed with the run-time level, and a by-value struct indexed dynamically
+    // is put into scratch memory)
+    const PyrJob &job = jobs[blockIdx.y];
     const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t n = job.n_samples;
     const uint64_t nb = pyramid_dev_bins(n, level);
