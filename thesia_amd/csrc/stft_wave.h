@@ -428,12 +428,18 @@ TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0) {
 }
 
 // Boundary frames (part of the span outside [0, n_samples)): numpy-'reflect' indexing per sample (stft.rs:77-95 via
-// utils.rs:111-138); the wave kernel takes them as one-frame chunks of channels with n_samples >= n_fft.
+// utils.rs:111-138); the wave kernel takes them as one-frame chunks of channels with n_samples >= n_fft.  With at
+// least n_fft samples a position is at most one reflection away (-(n-1) <= i <= 2(n-1)), so the general index with its
+// modulo (reflect_index: 64-bit divisions, ~3000 instructions for the 32 samples of a lane) is not needed here.
+TH_HD uint32_t reflect_once(int32_t i, int32_t n) {
+    i = i < 0 ? -i : i;
+    return (uint32_t)(i >= n ? 2 * (n - 1) - i : i);
+}
 template <int P, class WavPtr>
 TH_HD void wave_fetch_reflect(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0, uint32_t n_samples) {
     TH_UNROLL for (int m = 0; m < P; m++) {
-        const int64_t i = e0 + 2 * (int64_t)(lane + 64u * m);
-        x[m] = {wav[reflect_index(i, n_samples)], wav[reflect_index(i + 1, n_samples)]};
+        const int32_t i = (int32_t)e0 + 2 * (int32_t)(lane + 64u * m);
+        x[m] = {wav[reflect_once(i, (int32_t)n_samples)], wav[reflect_once(i + 1, (int32_t)n_samples)]};
     }
 }
 
