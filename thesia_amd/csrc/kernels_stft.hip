@@ -661,7 +661,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
                 x[0] = t;
             }
         }
-        // (min, max) of this chunk: a plain store per chunk, reduced per channel by minmax_chunks_kernel afterwards.
+        // (min, max) of this chunk: a plain store per chunk, folded per channel by wave_post_kernel afterwards.
         // (Float atomics on the channel's slot from every wave are served one at a time, ~8 ns each: 50 us for the
         // 2800 waves of a single-track launch whose FFT work takes 20.)
         if (minmax != nullptr) {
