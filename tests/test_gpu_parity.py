@@ -144,7 +144,8 @@ def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
 
 @pytest.mark.parametrize("sr,win,hop,n_fft,n_mel", [(44100, 2048, 512, 2048, 128), (48000, 1920, 480, 2048, 0),
                                                     (48000, 4096, 1024, 4096, 0), (48000, 1024, 256, 1024, 500),
-                                                    (44100, 2048, 512, 2048, 17)])
+                                                    (44100, 2048, 512, 2048, 17), (16000, 640, 160, 1024, 0),
+                                                    (22050, 884, 221, 1024, 0), (48000, 1024, 256, 1024, 128)])
 def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     """The three mel paths against the oracle on a ragged batch: the filterbank fused into the wave kernel's epilogue
     (n_fft = 2048), the matrix-core path (wave FFT kernel -> amplitudes -> v_mfma_f32_16x16x4_f32 filterbank) and the
@@ -154,14 +155,21 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     wavs = [synth_track(31 + i, sr, n) for i, n in enumerate((50000, 9000, win // 2, 23456))]
     want = [orc.calc_spec(w, win, hop, n_fft, mel_fb=fb) for w in wavs]
     mfma = "stft_wave_kernel+mel_mfma_kernel" if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
-    auto = "stft_wave_kernel(fused mel)" if n_fft == 2048 else mfma
-    for which, name in ((1, "stft_generic_kernel"), (3, mfma), (0, auto)):
+    # auto: the fused epilogue for n_fft 2048 and (when the piece table fits: <= 512 pieces) 1024, else the matrix-core path
+    fused = "stft_wave_kernel(fused mel)"
+    for which, name in ((1, "stft_generic_kernel"), (3, mfma), (0, None)):
         if which == 3 and name == "stft_generic_kernel":
             continue  # more than 512 mels: there is no matrix-core path to force
         plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
         if which:
             plan.set_kernel(which)
-        assert plan.kernel_name == name and plan.height == want_n_mel
+        if name is None:
+            assert plan.kernel_name == fused if n_fft == 2048 else plan.kernel_name in (fused, mfma)
+            if (n_fft, want_n_mel) in ((1024, 128), (1024, 385), (1024, 308)):
+                assert plan.kernel_name == fused  # incl. the default mel counts of 16 and 22.05 kHz audio
+        else:
+            assert plan.kernel_name == name
+        assert plan.height == want_n_mel
         specs, mm = plan.calc_spec_batch(wavs)
         for i, (s, w) in enumerate(zip(specs, want)):
             assert_spec_close(s, w)

@@ -273,6 +273,8 @@ __device__ __forceinline__ void flush_minmax(float *__restrict__ minmax, uint32_
     }
 }
 
+constexpr uint32_t MEL_PRF_1024 = 512;  // pieces of the per-wave (r, f) buffer of the fused mel epilogue at n_fft = 1024
+
 // One frame of the wave kernel (see stft_wave_kernel).  OFF = register rotation of x[] (logical slot m lives
 // in physical x[(m + OFF) % P]); ROTATE = the caller instantiates one body per rotation instead of moving
 // registers.  All state is passed as separate by-reference scalars / arrays: the body is always inlined and
@@ -301,7 +303,7 @@ __device__ __forceinline__ void wave_frame(
     const cf32 (&rwa)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
     const cf32 (&rwb)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
     const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], cf32 rw_mid, float &lmin, float &lmax,
-    const uint32_t *meltab, const WaveOut &wo TH_PROF_PARAMS) {
+    const uint32_t *meltab, cf32 *mel_prf, const WaveOut &wo TH_PROF_PARAMS) {
     constexpr bool AMP = OUT == 1, MELF = OUT == 2;
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
@@ -450,40 +452,7 @@ __device__ __forceinline__ void wave_frame(
         };
         if constexpr (RES & 8) W::split_paired_w(lane, za, zb, rws, rw_mid, emit);
         else W::split_paired_w(lane, za, zb, ws, stw[NC / 2], emit);
-        if constexpr (MELF) {
-            // fused mel filterbank (stft_wave.h / mel_fuse.h): pieces of 4 bins -> (r, f) partial sums -> one mel per lane
-            // and group; the (r, f) buffer sits behind the amplitude row in the same slab
-            cf32 *const prf = slab + (NC + 2) / 2;
-            const MelFuseTab mt = mel_fuse_view(meltab, wo.mel_slots, wo.mel_groups);
-            wave_lds_sync();
-#if !defined(TH_MEL_ABL_NOPIECES)
-            mel_pieces(lane, slab_f, prf, mt);
-#endif
-            wave_lds_sync();
-#if defined(TH_MEL_ABL_NOGATHER)  // ablation (wrong results): one value per mel straight from the (r, f) buffer
-            for (uint32_t gq = 0; gq < mt.G; gq++) {
-                const uint32_t m = 64u * gq + lane;
-                if (m < wo.n_mel) {
-                    const float d = amp_to_dB_fast(prf[m & 255u].re);
-                    row[m] = d;
-                    lmin = nmin(lmin, d);
-                    lmax = nmax(lmax, d);
-                }
-            }
-            if (false)
-#endif
-            mel_gather(lane, prf, mt, [&](uint32_t m, float v) {
-                if (m < wo.n_mel) {
-                    const float d = amp_to_dB_fast(v);
-                    row[m] = d;
-                    lmin = nmin(lmin, d);
-                    lmax = nmax(lmax, d);
-                }
-            });
-            wave_lds_sync();  // the next frame's pass 1 rewrites the slab
-        }
     } else {
-        static_assert(!MELF, "the fused mel epilogue needs the mirror-local layout");
         W::pass2_dft(lane, z, slab);
         wave_lds_sync();
         TH_SCHED_BARRIER();
@@ -493,25 +462,63 @@ __device__ __forceinline__ void wave_frame(
         W::write_z(lane, z, slab);
         wave_lds_sync();
         TH_SCHED_BARRIER();
+        float pa[P + 1];  // fused mel: the amplitudes wait in registers until the mirror reads are done with the slab
 #pragma unroll
         for (int m = 0; m < P; m++) {
             const uint32_t k = lane + 64u * m;
             const cf32 zm = W::read_mirror(lane, m, slab);  // mirror partner Z[Nc - k]
             const float pw = split_power(z[m], zm, stw[k]);
-            const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
-            row[k] = d;
-            lmin = nmin(lmin, d);
-            lmax = nmax(lmax, d);
+            if constexpr (MELF) {
+                pa[m] = power_to_amp(pw);
+            } else {
+                const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
+                row[k] = d;
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            }
         }
-        if (lane == 0) {  // Nyquist bin k = Nc: partner of Z[0] is Z[0], W^Nc = -1
+        {   // Nyquist bin k = Nc: partner of Z[0] is Z[0], W^Nc = -1 (lane 0 only keeps it)
             const cf32 wn = {-1.0f, 0.0f};
             const float pw = split_power(z[0], z[0], wn);
-            const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
-            row[NC] = d;
-            lmin = nmin(lmin, d);
-            lmax = nmax(lmax, d);
+            if constexpr (MELF) {
+                pa[P] = power_to_amp(pw);
+            } else if (lane == 0) {
+                const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
+                row[NC] = d;
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            }
         }
-        wave_lds_sync();  // the slab is rewritten by the next frame's pass 1
+        wave_lds_sync();  // the slab is free: the next frame's pass 1 (or the mel epilogue) rewrites it
+        if constexpr (MELF) {
+            float *const slab_f = reinterpret_cast<float *>(slab);
+#pragma unroll
+            for (int m = 0; m < P; m++) slab_f[lane + 64u * m] = pa[m];
+            if (lane == 0) slab_f[NC] = pa[P];
+        }
+    }
+    if constexpr (MELF) {
+        // fused mel filterbank (stft_wave.h / mel_fuse.h): the frame's amplitudes sit in the wave's slab; pieces of 4 bins
+        // -> (r, f) partial sums -> one mel per lane and group; the (r, f) buffer sits behind the amplitude row
+        float *const slab_f = reinterpret_cast<float *>(slab);
+        // the (r, f) buffer: behind the amplitude row in the slab (n_fft 2048: room for 512 pieces), or the wave's own
+        // region behind the mel table (n_fft 1024: the slab would only hold 256 pieces, the default mel counts need ~400)
+        cf32 *const prf = mel_prf != nullptr ? mel_prf : slab + (NC + 2) / 2;
+        const MelFuseTab mt = mel_fuse_view(meltab, wo.mel_slots, wo.mel_groups);
+        wave_lds_sync();
+#if !defined(TH_MEL_ABL_NOPIECES)
+        mel_pieces(lane, slab_f, prf, mt);
+#endif
+        wave_lds_sync();
+        mel_gather(lane, prf, mt, [&](uint32_t m, float v) {
+            if (m < wo.n_mel) {
+                const float d = amp_to_dB_fast(v);
+                row[m] = d;
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            }
+        });
+        wave_lds_sync();  // the next frame's pass 1 rewrites the slab
     }
 #if !defined(TH_EXP_NO_TAILFILL) && !defined(TH_EXP_NOSTORE)
     // Rows at the library's padded pitch (th_pitch_f32): bin Nc would be the only dword written in its 128-byte line, and
@@ -579,6 +586,10 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     __syncthreads();
 
     cf32 *slab = slabs + (size_t)wave * W::SLAB_LEN;
+    // fused mel at n_fft 1024: a (r, f) buffer of MEL_PRF_1024 pieces per wave behind the mel table (see wave_frame)
+    cf32 *mel_prf = nullptr;
+    if constexpr (OUT == 2 && LOG2_NC == 9)
+        mel_prf = reinterpret_cast<cf32 *>(meltab + ((wo.mel_words + 1u) & ~1u)) + (size_t)wave * MEL_PRF_1024;
 #if defined(TH_EXP_PRIO)
     {   // experiment: distinct static issue priorities for the waves that share a SIMD
         const uint32_t pr = TH_EXP_PRIO == 1 ? (wave >> 2) & 3u : wave & 3u;
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #define TH_FRAME(ROT)                                                                                                  \
     wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : DYN ? -2 : -1>(      \
         g, wtab + (PHASED ? WPAD - ((96 * (ROT)) & 127) / 2 : 0), stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
-        lmax, meltab, wo TH_PROF_ARGS)
+        lmax, meltab, mel_prf, wo TH_PROF_ARGS)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
     cf32 rw[(RESK & 1) ? P : 1], rw2[(RESK & 2) ? W::R2 - 1 : 1];
     cf32 rwa[(RESK & 4) ? W::NQ : 1][W::R3 - 1], rwb[(RESK & 4) ? W::NQ : 1][W::R3 - 1], rws[(RESK & 8) ? W::NQ : 1][W::R3];
@@ -843,7 +854,8 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
-    const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>() + (OUT == 2 ? (size_t)out.mel_words * 4 : 0) +
+    const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>() + (OUT == 2 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
+                       (OUT == 2 && LOG2_NC == 9 ? (size_t)WAVES * MEL_PRF_1024 * sizeof(cf32) : 0) +
                        (SHIFT == -1 ? 48 * sizeof(cf32) : 0) +  // phased: zero pairs in front of the window table
                        (SHIFT <= -16 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -869,7 +881,7 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                                                                         d_tw, nullptr, d_queue_head, n_cu, out, s);
         }
-        if constexpr (LOG2_NC == 10 && WaveFft<LOG2_NC>::PAIRED) {
+        if constexpr (LOG2_NC <= 10) {
             if (out.mode == 2)
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                                                                         d_tw, d_minmax, d_queue_head, n_cu, out, s);
@@ -976,16 +988,22 @@ int stft_wave_phased_mode(const StftGeom &g, int waves) {
 }
 
 uint32_t stft_wave_mel_max_pieces(const StftGeom &g) {
-    if (g.log2_nc != 10) return 0;  // n_fft = 2048: mirror-local layout and room in LDS (1024 is not mirror-local, 4096 is LDS-bound)
+    if (g.log2_nc != 9 && g.log2_nc != 10) return 0;  // n_fft = 1024, 2048 (4096 is LDS-bound: no room for the table)
+    if (g.log2_nc == 9) return MEL_PRF_1024;                              // its own LDS region per wave
     const uint32_t slab_cf32 = g.nc + g.nc / 16, prf0 = (g.nc + 2) / 2;  // WaveFft::SLAB_LEN, first (r, f) slot
     const uint32_t cap = (slab_cf32 - prf0) / 64 * 64;                    // whole slots of 64 pieces
     return cap;
 }
 bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words) {
     const size_t extra = (size_t)words * 4;
-    if (g.log2_nc != 10) return false;
-    return (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES) &&
-           wave_lds_bytes<10, WaveLaunchCfg<10>::DEFAULT_WAVES>() + extra + 48 * sizeof(cf32) <= 160 * 1024;  // (+ phased pad)
+    if (g.log2_nc == 10)
+        return (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES) &&
+               wave_lds_bytes<10, WaveLaunchCfg<10>::DEFAULT_WAVES>() + extra + 48 * sizeof(cf32) <= 160 * 1024;  // (+ phased pad)
+    if (g.log2_nc == 9)
+        return (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) &&
+               wave_lds_bytes<9, WaveLaunchCfg<9>::DEFAULT_WAVES>() + extra + (512 + 128) * sizeof(cf32) +
+                       (size_t)WaveLaunchCfg<9>::DEFAULT_WAVES * MEL_PRF_1024 * sizeof(cf32) <= 160 * 1024;
+    return false;
 }
 
 int stft_wave_default_waves(const StftGeom &g) {
