@@ -297,6 +297,29 @@ def main():
                 "frac": (smp * 4 + wl.n_tracks * tot * 4) / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del pyr
 
+    # other framings of the same path on the same tracks (extras, not the metric): the mel spectrogram of BASELINE config
+    # 4's shape (n_fft 2048 / hop 512, 128 mels: filterbank fused into the FFT kernel) and the app's own default framing
+    # (40 ms window / 4 at 48 kHz = 1920 / 480 / 2048, linear: grid-aligned register reuse), STFT -> dB stage only
+    other = None
+    if rank == 0 and not args.no_single_track:
+        other = []
+        for label, (w_, h_, scale, n_mel) in (("mel-128, n_fft 2048 / hop 512", (2048, 512, ta.MEL, 128)),
+                                               ("linear, 1920 / 480 / 2048 (app default framing)", (1920, 480, ta.LINEAR, 0))):
+            try:
+                pl = ta.Plan(ctx, sr, w_, h_, 2048, scale, n_mel)
+                T_, H_ = pl.n_frames(n), pl.height
+                sp_ = ta.pitch_f32(H_)
+                spec_ = torch.empty((wl.n_tracks, T_, sp_), dtype=torch.float32, device=dev)
+                ch_ = (ta.ChanDesc * wl.n_tracks)(*[ta.ChanDesc(wl.wav[i].data_ptr(), spec_[i].data_ptr(), n, T_, sp_)
+                                                    for i in range(wl.n_tracks)])
+                ms_ = time_stage(lambda: pl.calc_spec_batch_dev(ch_, wl.minmax.data_ptr()))
+                other.append({"workload": f"{label}, {wl.n_tracks} tracks x {n} samples", "kernel": pl.kernel_name, "frames": wl.n_tracks * T_,
+                              "ms": ms_, "frames_per_s": wl.n_tracks * T_ / (ms_ * 1e-3)})
+                pl.close()
+                del spec_
+            except Exception as e:  # extras must not break the bench line
+                other.append({"workload": label, "error": str(e)[:200]})
+
     single = None
     if rank == 0 and not args.no_single_track:
         w1 = Workload(torch, ta, ctx, dev, [0], sr, 60 * sr, win, hop, n_fft, args.kernel, cmap_bytes)
@@ -394,6 +417,8 @@ def main():
             out["single_track_cfg2"] = single
         if wave is not None:
             out["waveform_pyramid"] = wave
+        if other:
+            out["other_framings"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft)
         try:  # RCCL prints a version banner through C stdio; push it out first so that the JSON is the last stdout line
