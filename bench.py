@@ -133,7 +133,10 @@ class Workload:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
         if record:
             ev[0].record()
-        self.plan.calc_spec_batch_dev(self.chan, self.minmax.data_ptr())
+        if dist is None:  # one GPU: STFT + the global dB range in one call (th_calc_spec_batch_ranged_dev)
+            self.plan.calc_spec_batch_ranged_dev(self.chan, self.minmax.data_ptr(), 100.0, self.range_db.data_ptr())
+        else:
+            self.plan.calc_spec_batch_dev(self.chan, self.minmax.data_ptr())
         if record:
             ev[1].record()
         # global dB range over every resident spec of every rank (core/mod.rs:169-180), without leaving the device:
@@ -142,8 +145,7 @@ class Workload:
             self.ctx.minmax_reduce_dev(self.minmax.data_ptr(), self.n_tracks, self.range2.data_ptr())
             dist.all_reduce(self.range2, op=dist.ReduceOp.MIN)
             self.ctx.global_db_range_dev(self.range2.data_ptr(), 100.0, self.range_db.data_ptr())
-        else:  # one GPU: reduce + clamp in one launch
-            self.ctx.minmax_reduce_range_dev(self.minmax.data_ptr(), self.n_tracks, 100.0, self.range_db.data_ptr())
+
         if record:
             ev[2].record()
         self.ctx.spec_to_img_batch_ranged(self.imgd, self.range_db.data_ptr(), 258)

@@ -211,6 +211,11 @@ typedef struct {
  * d_minmax (DEVICE, 2*n_chan f32, may be NULL) receives per-channel (min, max) of the dB values
  * (find_min_max, simd.rs:14-36), fused into the same launch.  Stream-ordered, no sync. */
 TH_API int th_calc_spec_batch_dev(th_plan *plan, const th_chan_desc *chans, size_t n_chan, float *d_minmax);
+/* The same, and the global dB range of these channels — max_dB = min(max, 0), min_dB = max(min, max_dB - dB_range),
+ * core/mod.rs:169-180 — into d_range (DEVICE, 2 floats) in the same call: for a single GPU whose batch is the whole
+ * project (one launch fewer than th_calc_spec_batch_dev + th_minmax_reduce_range_dev when the batch is one channel). */
+TH_API int th_calc_spec_batch_ranged_dev(th_plan *plan, const th_chan_desc *chans, size_t n_chan, float *d_minmax,
+                                         float dB_range, float *d_range);
 
 /* Single-channel convenience with HOST buffers (upload, compute, download; synchronous).
  * out_spec[n_frames * height]; out_min/out_max may be NULL. */

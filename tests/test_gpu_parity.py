@@ -909,3 +909,36 @@ def test_calc_spec_without_minmax_and_back_to_back(ctx, win, hop, n_fft, scale, 
     b2, _ = run(small, True)
     assert np.array_equal(b[0], b2[0])
     plan.close()
+
+
+def test_calc_spec_batch_ranged_equals_the_separate_calls(ctx):
+    """th_calc_spec_batch_ranged_dev = th_calc_spec_batch_dev + th_minmax_reduce_range_dev: one channel (range folded into
+    the wave kernel's follow-up launch), several channels, a channel shorter than n_fft (generic kernel) and mel."""
+    import torch
+    dev = torch.device("cuda", 0)
+    for scale, n_mel, lengths in ((ta.LINEAR, 0, (70000,)), (ta.LINEAR, 0, (70000, 3000, 41000)), (ta.LINEAR, 0, (1500,)),
+                                  (ta.MEL, 128, (50000,)), (ta.MEL, 128, (50000, 900))):
+        plan = ta.Plan(ctx, 48000, 2048, 512, 2048, scale, n_mel)
+        H = plan.height
+        wavs = [((torch.rand(n, device=dev, generator=torch.Generator(device=dev).manual_seed(7 + i)) - 0.5) * 0.3).contiguous()
+                for i, n in enumerate(lengths)]
+        Ts = [plan.n_frames(n) for n in lengths]
+        out = []
+        for fused in (False, True):
+            specs = [torch.zeros((T, H), dtype=torch.float32, device=dev) for T in Ts]
+            mm = torch.zeros((len(lengths), 2), dtype=torch.float32, device=dev)
+            rng_db = torch.zeros(2, dtype=torch.float32, device=dev)
+            chan = (ta.ChanDesc * len(lengths))(*[ta.ChanDesc(w.data_ptr(), s.data_ptr(), n, T, 0)
+                                                  for w, s, n, T in zip(wavs, specs, lengths, Ts)])
+            torch.cuda.synchronize()
+            if fused:
+                plan.calc_spec_batch_ranged_dev(chan, mm.data_ptr(), 80.0, rng_db.data_ptr())
+            else:
+                plan.calc_spec_batch_dev(chan, mm.data_ptr())
+                ctx.minmax_reduce_range_dev(mm.data_ptr(), len(lengths), 80.0, rng_db.data_ptr())
+            ctx.synchronize()
+            out.append(([s.cpu().numpy() for s in specs], mm.cpu().numpy(), rng_db.cpu().numpy()))
+        (sa, ma, ra), (sb, mb, rb) = out
+        assert all(np.array_equal(x, y) for x, y in zip(sa, sb)) and np.array_equal(ma, mb)
+        assert ra.tobytes() == rb.tobytes() and rb[1] <= 0 and rb[0] <= rb[1], (scale, lengths, ra, rb)
+        plan.close()

@@ -138,6 +138,7 @@ _SIGS = {
     "th_plan_set_kernel": [vp, C.c_int],
     "th_plan_kernel_name": [vp],
     "th_calc_spec_batch_dev": [vp, C.POINTER(ChanDesc), C.c_size_t, vp],
+    "th_calc_spec_batch_ranged_dev": [vp, C.POINTER(ChanDesc), C.c_size_t, vp, C.c_float, vp],
     "th_calc_spec_host": [vp, c_f32p, C.c_size_t, c_f32p, C.c_size_t, c_szp, c_f32p, c_f32p],
     "th_spec_to_img_dev": [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
                            C.c_uint32, vp],

@@ -394,6 +394,11 @@ class Plan:
         arr = descs if isinstance(descs, C.Array) else (ChanDesc * len(descs))(*descs)
         check(lib.th_calc_spec_batch_dev(self.handle, arr, len(arr), d_minmax))
 
+    def calc_spec_batch_ranged_dev(self, descs: Sequence[ChanDesc], d_minmax: int, dB_range: float, d_range: int):
+        """calc_spec_batch_dev + the global dB range of the batch into d_range (single GPU), one call."""
+        arr = descs if isinstance(descs, C.Array) else (ChanDesc * len(descs))(*descs)
+        check(lib.th_calc_spec_batch_ranged_dev(self.handle, arr, len(arr), d_minmax, dB_range, d_range))
+
     def calc_spec(self, wav: np.ndarray):
         """calc_spec for one channel with host buffers -> (T x H f32 dB, min, max)."""
         wav = _f32(wav)

@@ -615,9 +615,13 @@ TH_API size_t th_pitch_f32(size_t n) { return (n + 31) / 32 * 32; }
 TH_API size_t th_pitch_u16(size_t n) { return (n + 63) / 64 * 64; }
 
 // ------------------------------------------------------------------------------------------ calc_spec
-TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t n_chan, float *d_minmax) {
+// d_range != NULL: also leave the global dB range [min_dB, max_dB] of these channels (core/mod.rs:169-180) in d_range —
+// folded into the wave kernel's follow-up launch when the batch is one channel, else one more small launch
+static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_chan, float *d_minmax, float dB_range,
+                                float *d_range) {
     TH_TRY
     TH_REQUIRE(p, "plan is NULL");
+    TH_REQUIRE(d_range == nullptr || d_minmax != nullptr, "d_range needs d_minmax");
     if (n_chan == 0) return TH_OK;
     TH_REQUIRE(chans, "chans is NULL");
     TH_REQUIRE(n_chan < (1u << 24), "too many channels");
@@ -764,6 +768,7 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     TH_HIP(hipSetDevice(c->device));
     int rc = TH_OK;
+    bool range_done = false;
     if (mel_mfma && amp_rows) {
         const size_t need = (size_t)amp_rows * amp_pitch * sizeof(float);
         if (need > p->amp_buf.cap || p->amp_zeroed < need) {
@@ -834,8 +839,9 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
         // fold the per-chunk (min, max) pairs into the channel slots and rewind the chunk queue (nothing that can fail sits
         // between the two launches: a queue left un-rewound would make the next launch skip chunks)
+        range_done = d_range != nullptr && all_in_wave && n_post == 1 && n_chan == 1;
         TH_HIP(launch_wave_post((const th::WavePostJob *)p->post_jobs.dptr, n_post, chunk_mm, d_minmax, all_in_wave,
-                                p->d_queue_head, c->stream));
+                                p->d_queue_head, dB_range, range_done ? d_range : nullptr, c->stream));
         if (mel_mfma)
             TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
                                    (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_bt, p->d_mel_band,
@@ -851,8 +857,20 @@ TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t 
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
     }
     if (timed) p->timed_launches++;
+    if (d_range != nullptr && !range_done)
+        TH_HIP(launch_minmax_reduce(d_minmax, (uint32_t)n_chan, nullptr, dB_range, d_range, c->stream));
     return TH_OK;
     TH_CATCH
+}
+
+TH_API int th_calc_spec_batch_dev(th_plan *p, const th_chan_desc *chans, size_t n_chan, float *d_minmax) {
+    return calc_spec_batch_impl(p, chans, n_chan, d_minmax, 0.0f, nullptr);
+}
+
+TH_API int th_calc_spec_batch_ranged_dev(th_plan *p, const th_chan_desc *chans, size_t n_chan, float *d_minmax, float dB_range,
+                                         float *d_range) {
+    if (!d_range) return fail(TH_ERR_INVALID_ARG, "d_range is NULL");
+    return calc_spec_batch_impl(p, chans, n_chan, d_minmax, dB_range, d_range);
 }
 
 TH_API int th_minmax_reduce_dev(th_ctx *c, const float *d_minmax, size_t n_chan, float *d_out) {

@@ -30,8 +30,9 @@ int stft_wave_default_waves(const StftGeom &g);
 struct WavePostJob {
     uint32_t t0, t1, mm_index, reserved;
 };
+// d_range (may be NULL; single-job launches with store only): [min_dB, max_dB] of the one channel, clamped by dB_range
 hipError_t launch_wave_post(const WavePostJob *d_pj, uint32_t n_pj, const float *d_chunk_mm, float *d_mm_slots, bool store,
-                            uint32_t *d_queue_head, hipStream_t s);
+                            uint32_t *d_queue_head, float dB_range, float *d_range, hipStream_t s);
 // What the wave kernel writes: dB rows of the linear spectrum, linear amplitude rows (first half of the matrix-core
 // mel path), or dB rows of the mel spectrum with the filterbank fused into the epilogue (mel_fuse.h tables).
 struct WaveOut {

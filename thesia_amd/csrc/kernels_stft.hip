@@ -754,7 +754,8 @@ hipError_t launch_minmax_reduce(const float *d_minmax, uint32_t n_chan, float *d
 // (then nobody has to initialise the slot), atomics when other kernels contribute too — and block 0 rewinds the chunk
 // queue for the next launch.  With chunk_mm == NULL only the queue is rewound.
 __global__ __launch_bounds__(256) void wave_post_kernel(const WavePostJob *__restrict__ pj, const float *__restrict__ chunk_mm,
-                                                        float *__restrict__ mm_slots, int store, uint32_t *__restrict__ queue_head) {
+                                                        float *__restrict__ mm_slots, int store, uint32_t *__restrict__ queue_head,
+                                                        float dB_range, float *__restrict__ d_range) {
     __shared__ float red[8];
     const uint32_t tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) *queue_head = 0;
@@ -786,6 +787,11 @@ __global__ __launch_bounds__(256) void wave_post_kernel(const WavePostJob *__res
         if (store) {
             mm_slots[2 * job.mm_index] = mn;
             mm_slots[2 * job.mm_index + 1] = mx;
+            if (d_range != nullptr) {  // single-channel batch: the global range is this channel's (core/mod.rs:179-180)
+                const float hi = fminf(mx, 0.0f);
+                d_range[0] = fmaxf(mn, hi - dB_range);
+                d_range[1] = hi;
+            }
         } else {
             atomic_min_f32(&mm_slots[2 * job.mm_index], mn);
             atomic_max_f32(&mm_slots[2 * job.mm_index + 1], mx);
@@ -793,10 +799,10 @@ __global__ __launch_bounds__(256) void wave_post_kernel(const WavePostJob *__res
     }
 }
 hipError_t launch_wave_post(const WavePostJob *d_pj, uint32_t n_pj, const float *d_chunk_mm, float *d_mm_slots, bool store,
-                            uint32_t *d_queue_head, hipStream_t s) {
+                            uint32_t *d_queue_head, float dB_range, float *d_range, hipStream_t s) {
     const bool fold = d_chunk_mm != nullptr && n_pj != 0;
     hipLaunchKernelGGL(wave_post_kernel, dim3(fold ? n_pj : 1), dim3(256), 0, s, d_pj, fold ? d_chunk_mm : nullptr, d_mm_slots,
-                       store ? 1 : 0, d_queue_head);
+                       store ? 1 : 0, d_queue_head, dB_range, (fold && store && n_pj == 1) ? d_range : nullptr);
     return hipGetLastError();
 }
 
