@@ -18,7 +18,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = ta.Context(0)
 cmap = open(os.path.join(ROOT, "tests", "golden", "colormap_inferno_rgba258.bin"), "rb").read()
 t_end = time.time() + budget
-n_cases = 0
+n_cases = n_lod = 0
 while time.time() < t_end:
     T, H = int(rng.integers(1, 1400)), int(rng.choice([1, 2, 40, 127, 128, 129, 130, 257, 513, 1025, int(rng.integers(1, 1200))]))
     spec = rng.uniform(-150, 20, (T, H)).astype(np.float32)
@@ -42,5 +42,15 @@ while time.time() < t_end:
         a = ctx.encode_spectrogram_tile(img, cmap, 5, 0, 0, tx, ty)
         b = orc.encode_spectrogram_tile(img, cmap, 5, 0, 0, tx, ty)
         assert a == b, (W_, H_, tx, ty)
+    if n_cases % 16 == 0 and got.shape[0] >= 2 and got.shape[1] >= 2:  # LOD > 0: the restated separable Lanczos3
+        lx, ly = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        if lx or ly:
+            wl, hl = -(-got.shape[1] >> lx) if lx else got.shape[1], -(-got.shape[0] >> ly) if ly else got.shape[0]
+            wl, hl = -(-got.shape[1] // (1 << lx)), -(-got.shape[0] // (1 << ly))
+            tx, ty = int(rng.integers(0, -(-wl // 512))), int(rng.integers(0, -(-hl // 512)))
+            a = ctx.encode_spectrogram_tile(got, cmap, 9, lx, ly, tx, ty)
+            b = orc.encode_spectrogram_tile(got, cmap, 9, lx, ly, tx, ty)
+            assert a == b, ("lod", got.shape, lx, ly, tx, ty)
+            n_lod += 1
     n_cases += 1
-print(f"{n_cases} random cases: u16 images and level-0 tiles bit-identical to the oracle")
+print(f"{n_cases} random cases ({n_lod} LOD tiles): u16 images and tiles bit-identical to the oracle")
