@@ -942,3 +942,44 @@ def test_calc_spec_batch_ranged_equals_the_separate_calls(ctx):
         assert all(np.array_equal(x, y) for x, y in zip(sa, sb)) and np.array_equal(ma, mb)
         assert ra.tobytes() == rb.tobytes() and rb[1] <= 0 and rb[0] <= rb[1], (scale, lengths, ra, rb)
         plan.close()
+
+
+def test_concurrent_tile_readers(ctx, golden_dir):
+    """The reference serves tile requests from many IPC threads under a read lock (lib.rs:345,378): 8 threads hammer
+    th_tm_get_spectrogram_tile / th_tm_get_waveform_tile (level 0 and LOD, two tracks) concurrently; every reply must
+    be byte-identical to the one a single thread gets."""
+    import threading
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    tm = ta.TrackManager(ctx)
+    tm.set_colormap(cmap)
+    tm.add_tracks([(0, 48000, synth_track(70, 48000, 90000)[None]),
+                   (1, 44100, np.stack([synth_track(71, 44100, 60000), synth_track(72, 44100, 60000)]))])
+    tm.apply_track_list_changes()
+    reqs = [("s", 0, 0, 0, 0, 0, 0), ("s", 1, 1, 0, 0, 0, 0), ("s", 0, 0, 1, 1, 0, 0), ("s", 1, 0, 2, 1, 0, 0),
+            ("w", 0, 0, 0, 3), ("w", 1, 1, 4, 0), ("w", 0, 0, 7, 0), ("w", 1, 0, 2, 5)]
+
+    def get(r):
+        if r[0] == "s":
+            return tm.get_spectrogram_tile(*r[1:])
+        return tm.get_waveform_tile(*r[1:])
+
+    want = [get(r) for r in reqs]
+    errors = []
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for _ in range(60):
+                i = int(rng.integers(0, len(reqs)))
+                if get(reqs[i]) != want[i]:
+                    errors.append((seed, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    tm.close()
