@@ -1,0 +1,274 @@
+// Micro-benchmark (development tool): the memory skeleton of the wave STFT kernel — persistent waves, chunk queue,
+// per frame: the input loads of one hop (prefetched a frame ahead), optional stand-in compute (dependent FMA rounds and
+// LDS write/read rounds), the output row stores in several shapes.  No FFT: what is the floor the access pattern
+// itself sets, and what does each load / store shape cost next to a given amount of VALU / LDS work?
+//   LOADM  0 none | 1 four 8-byte loads per lane (lane + 64 m layout) | 2 two 16-byte loads per lane
+//   STOREM 0 none | 1 kernel pattern (8 aligned + 8 mirrored dword stores + bin 512 + tail line) | 2 16 aligned dword
+//          stores + tail | 3 four 16-byte stores + tail line
+//   FMA    dependent-FMA rounds of 16 instructions per frame         LDSR  rounds of (8 ds_write_b128 + 16 ds_read_b64)
+// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o stft_skeleton stft_skeleton.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <algorithm>
+#include <ctime>
+#include <vector>
+
+using gf = __attribute__((address_space(1))) float;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+using gf2 = __attribute__((address_space(1))) v2f;
+using gf4 = __attribute__((address_space(1))) v4f;
+
+constexpr uint32_t N_FFT = 2048, HOP = 512, H = 1025, PITCH = 1056, CHUNK = 32;
+
+template <int LOADM, int STOREM, int FMA, int LDSR, int WAVES, int LDSM = 0>
+__global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_, uint32_t n_chan, uint32_t n_samples,
+                                                uint32_t T, uint32_t chunks_per_chan, uint32_t *queue, float seed) {
+    extern __shared__ v2f lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    v2f *slab = lds + wave * 1100;
+    const uint32_t n_chunks = n_chan * chunks_per_chan;
+    bool first = true;
+    for (;;) {
+        uint32_t c = blockIdx.x * WAVES + wave;
+        if (!first) {
+            if (lane == 0) c = atomicAdd(queue, 1u);
+            c = __builtin_amdgcn_readfirstlane(c) + gridDim.x * WAVES;
+        }
+        first = false;
+        if (c >= n_chunks) break;
+        const uint32_t ch = c / chunks_per_chan, f0 = 2 + (c % chunks_per_chan) * CHUNK;  // interior frames only
+        const uint32_t f1 = min(f0 + CHUNK, T - 2);
+        const gf *wav = (const gf *)(wav_ + (size_t)ch * n_samples);
+        gf *spec = (gf *)(spec_ + (size_t)ch * T * PITCH);
+        v2f x[16];
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            x[i] = v2f{0.f, 0.f};
+            acc[i] = seed + i;
+        }
+        {
+            const int64_t e0 = (int64_t)f0 * HOP - N_FFT / 2;
+            if (LOADM == 1 || LOADM == 3) {
+                const uint32_t L = LOADM == 3 ? 4 * (lane & 15) + (lane >> 4) : lane;  // 3: 8-byte loads at a 32-byte lane stride
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = *(const gf2 *)(wav + e0 + 2 * (L + 64 * m));
+            } else if (LOADM == 2) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const v4f v = *(const gf4 *)(wav + e0 + 4 * (lane + 64 * m));
+                    x[2 * m] = v2f{v.x, v.y};
+                    x[2 * m + 1] = v2f{v.z, v.w};
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t f = f0; f < f1; f++) {
+            // consume the frame in registers: fold all 16 slots into the accumulators (stands for the window multiply)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = acc[i] * 0.999f + (x[i].x + x[i].y);
+            // prefetch the next frame's new hop (slots 12..15 after a shift by 4)
+            const uint32_t fn = f + 1 < f1 ? f + 1 : f;
+            const int64_t e0n = (int64_t)fn * HOP - N_FFT / 2;
+#pragma unroll
+            for (int m = 0; m < 12; m++) x[m] = x[m + 4];
+            if (LOADM == 1 || LOADM == 3) {
+                const uint32_t L = LOADM == 3 ? 4 * (lane & 15) + (lane >> 4) : lane;
+#pragma unroll
+                for (int m = 12; m < 16; m++) x[m] = *(const gf2 *)(wav + e0n + 2 * (L + 64 * m));
+            } else if (LOADM == 2) {
+#pragma unroll
+                for (int m = 6; m < 8; m++) {
+                    const v4f v = *(const gf4 *)(wav + e0n + 4 * (lane + 64 * m));
+                    x[2 * m] = v2f{v.x, v.y};
+                    x[2 * m + 1] = v2f{v.z, v.w};
+                }
+            }
+            // stand-in compute
+#pragma unroll 1
+            for (int r = 0; r < FMA; r++) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[i] = __builtin_fmaf(acc[i], 1.0001f, 0.25f);
+            }
+#pragma unroll 1
+            for (int r = 0; r < LDSR; r++) {
+                if (LDSM == 0) {  // the kernel's exchange 1: 8 x ds_write_b128 (2-way bank conflicts), 16 x ds_read_b64
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        *(v4f *)&slab[(lane * 16 + 2 * (lane >> 1)) + 2 * i] = v4f{acc[2 * i], acc[2 * i + 1], acc[2 * i], acc[2 * i + 1]};
+                } else if (LDSM == 3) {  // 16 x ds_write_b64, pitch 17 slots per lane: conflict-free writes
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint64_t u = (uint64_t)__builtin_bit_cast(uint32_t, acc[i]) | ((uint64_t)__builtin_bit_cast(uint32_t, acc[15 - i]) << 32);
+                        *(volatile __attribute__((address_space(3))) uint64_t *)(&slab[lane * 17 + i]) = u;
+                    }
+                } else {  // 32 x ds_write_addtid_b32 into 32 planes of 64 (+4) dwords
+                    const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)slab);
+#define WA(i, o) "ds_write_addtid_b32 %" #i " offset:" #o "\n\t"
+                    asm volatile("s_mov_b32 m0, %16\n\t" WA(0, 0) WA(1, 272) WA(2, 544) WA(3, 816) WA(4, 1088) WA(5, 1360) WA(6, 1632) WA(7, 1904)
+                                 WA(8, 2176) WA(9, 2448) WA(10, 2720) WA(11, 2992) WA(12, 3264) WA(13, 3536) WA(14, 3808) WA(15, 4080)
+                                 :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]),
+                                 "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15]),
+                                 "s"(base) : "memory");
+                    asm volatile("s_mov_b32 m0, %16\n\t" WA(0, 4352) WA(1, 4624) WA(2, 4896) WA(3, 5168) WA(4, 5440) WA(5, 5712) WA(6, 5984) WA(7, 6256)
+                                 WA(8, 6528) WA(9, 6800) WA(10, 7072) WA(11, 7344) WA(12, 7616) WA(13, 7888) WA(14, 8160) WA(15, 8432)
+                                 :: "v"(acc[15]), "v"(acc[14]), "v"(acc[13]), "v"(acc[12]), "v"(acc[11]), "v"(acc[10]), "v"(acc[9]), "v"(acc[8]),
+                                 "v"(acc[7]), "v"(acc[6]), "v"(acc[5]), "v"(acc[4]), "v"(acc[3]), "v"(acc[2]), "v"(acc[1]), "v"(acc[0]),
+                                 "s"(base) : "memory");
+#undef WA
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (LDSM == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint64_t v = *(volatile __attribute__((address_space(3))) uint64_t *)(&slab[lane + 2 * (lane >> 5) + 68 * i]);
+                        acc[i] += __builtin_bit_cast(float, (uint32_t)v);
+                    }
+                } else if (LDSM == 3) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint32_t idx = lane + 64 * i;
+                        const uint64_t v = *(volatile __attribute__((address_space(3))) uint64_t *)(&slab[(idx >> 4) * 17 + (lane & 15)]);
+                        acc[i] += __builtin_bit_cast(float, (uint32_t)v);
+                    }
+                } else if (LDSM == 1) {  // 32 x ds_read_b32: plane c = lane >> 2 (+ 16), element 4 r + (lane & 3)
+                    const float *sf = reinterpret_cast<const float *>(slab);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const float v0 = *(volatile __attribute__((address_space(3))) float *)(&sf[(lane >> 2) * 68 + 4 * i + (lane & 3)]);
+                        const float v1 = *(volatile __attribute__((address_space(3))) float *)(&sf[(16 + (lane >> 2)) * 68 + 4 * i + (lane & 3)]);
+                        acc[i] += v0 + v1;
+                    }
+                } else {  // 8 x ds_read_b128: 4 consecutive dwords of 8 planes
+                    const float *sf = reinterpret_cast<const float *>(slab);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const v4f v = *(const v4f *)(&sf[(4 * i + (lane >> 4)) * 68 + 4 * (lane & 15)]);
+                        acc[2 * i] += v.x + v.y;
+                        acc[2 * i + 1] += v.z + v.w;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            gf *row = spec + (size_t)f * PITCH;
+            if (STOREM == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) row[lane + 64 * j] = acc[j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) row[1024 - lane - 64 * j] = acc[8 + j];
+                if (lane == 0) row[512] = acc[0];
+                if (lane - 1u < 31u) row[1024 + lane] = 0.f;
+            } else if (STOREM == 4 || STOREM == 5) {
+                // adjacent-bin pairs: A side 4 aligned 8-byte stores (bins 2 l + 256 s, + 1); B side the mirrored pairs
+                // (bins 1023 - 2 l - 256 s, + 1): 4 misaligned 8-byte stores (mode 4) or 8 dword stores (mode 5)
+                typedef v2f __attribute__((aligned(4))) v2f_u;
+                using gf2u = __attribute__((address_space(1))) v2f_u;
+#pragma unroll
+                for (int j = 0; j < 4; j++) *(gf2 *)(row + 2 * lane + 256 * j) = v2f{acc[2 * j], acc[2 * j + 1]};
+                if (STOREM == 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) *(gf2u *)(row + 1023 - 2 * lane - 256 * j) = v2f{acc[8 + 2 * j], acc[9 + 2 * j]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        row[1023 - 2 * lane - 256 * j] = acc[8 + 2 * j];
+                        row[1024 - 2 * lane - 256 * j] = acc[9 + 2 * j];
+                    }
+                }
+                if (lane == 0) row[512] = acc[0];
+                if (lane - 1u < 31u) row[1024 + lane] = 0.f;
+            } else if (STOREM == 2) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) row[lane + 64 * j] = acc[j];
+                if (lane < 32u) row[1024 + lane] = lane ? 0.f : acc[0];
+            } else if (STOREM == 3) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *(gf4 *)(row + 4 * (lane + 64 * j)) = v4f{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+                if (lane < 32u) row[1024 + lane] = lane ? 0.f : acc[0];
+            } else {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) s += acc[i];
+                if (s == 12345.678f) row[lane] = s;
+            }
+        }
+    }
+}
+
+template <int LOADM, int STOREM, int FMA, int LDSR, int WAVES, int LDSM = 0>
+static void run(const char *name, const float *wav, float *spec, uint32_t n_chan, uint32_t n_samples, uint32_t T, uint32_t *q,
+                int gap_us) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const uint32_t cpc = (T - 4 + CHUNK - 1) / CHUNK;
+    auto kern = k<LOADM, STOREM, FMA, LDSR, WAVES, LDSM>;
+    const size_t lds = (size_t)WAVES * 1100 * sizeof(v2f);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    std::vector<float> ts;
+    for (int i = 0; i < 24; i++) {
+        hipMemsetAsync(q, 0, 4, 0);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WAVES), lds, 0, wav, spec, n_chan, n_samples, T, cpc, q, 1.0f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (i >= 4) ts.push_back(ms);
+        if (gap_us) {
+            hipDeviceSynchronize();
+            struct timespec t = {0, gap_us * 1000};
+            nanosleep(&t, nullptr);
+        }
+    }
+    std::sort(ts.begin(), ts.end());
+    const double med = ts[ts.size() / 2];
+    const double frames = (double)n_chan * (T - 4);
+    const double bytes = frames * ((LOADM ? 2048.0 : 0.0) + (STOREM ? 4100.0 : 0.0));
+    printf("%-4s ldsm %d load %d store %d fma %3d ldsr %d waves %2d: median %.3f ms min %.3f  %.0f GB/s\n", name, LDSM, LOADM, STOREM, FMA * 16,
+           LDSR, WAVES, med, ts[0], bytes / med / 1e6);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+    const int gap_us = argc > 1 ? atoi(argv[1]) : 0;
+    const uint32_t n_chan = 128, n_samples = 1440000, T = n_samples / HOP + 1;
+    float *wav, *spec;
+    uint32_t *q;
+    hipMalloc(&wav, (size_t)n_chan * n_samples * 4);
+    hipMalloc(&spec, (size_t)n_chan * T * PITCH * 4);
+    hipMalloc(&q, 4);
+    {   // pseudo-random input (bit toggling matters on a power-limited part)
+        std::vector<float> h((size_t)n_samples);
+        uint32_t s = 12345;
+        for (auto &v : h) {
+            s = s * 1664525u + 1013904223u;
+            v = ((int32_t)s) * (0.3f / 2147483648.0f);
+        }
+        for (uint32_t c = 0; c < n_chan; c++) hipMemcpy(wav + (size_t)c * n_samples, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    }
+    printf("# gap between launches: %d us\n", gap_us);
+#define R(L, S, F, D, W, M) run<L, S, F, D, W, M>("", wav, spec, n_chan, n_samples, T, q, gap_us)
+    R(0, 1, 0, 0, 12, 0);
+    R(0, 4, 0, 0, 12, 0);
+    R(0, 5, 0, 0, 12, 0);
+    R(0, 3, 0, 0, 12, 0);
+    R(3, 1, 48, 0, 12, 0);
+    R(3, 4, 48, 0, 12, 0);
+    R(3, 5, 48, 0, 12, 0);
+    R(3, 3, 48, 0, 12, 0);
+    R(3, 1, 48, 2, 12, 2);
+    R(3, 4, 48, 2, 12, 2);
+    R(3, 5, 48, 2, 12, 2);
+    R(3, 3, 48, 2, 12, 2);
+    R(3, 1, 48, 2, 12, 2);
+    R(3, 4, 48, 2, 12, 2);
+    return 0;
+}

@@ -22,8 +22,9 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
     std::vector<cf32> t2(W::T2_LEN), t3(W::T3_LEN);
     const int64_t e0 = (int64_t)frame * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
     for (uint32_t t = 0; t < 256; t++) W::fill_tables(t, 256, tw, t2.data(), t3.data());
-    for (uint32_t l = 0; l < 64; l++) wave_fetch<P, 0>(l, x[l], wav, e0);
-    for (uint32_t l = 0; l < 64; l++) wave_window<P>(l, z[l], x[l], wtab);
+    // (a lane's column of the frame is W::lane_col(lane): the plane exchanges of n_fft = 2048 deal the columns out permuted)
+    for (uint32_t l = 0; l < 64; l++) wave_fetch<P, 0>(W::lane_col(l), x[l], wav, e0);
+    for (uint32_t l = 0; l < 64; l++) wave_window<P>(W::lane_col(l), z[l], x[l], wtab);
     for (uint32_t l = 0; l < 64; l++) W::pass1(l, z[l], slab.data());
     for (uint32_t l = 0; l < 64; l++) W::read1(l, z[l], slab.data());
     for (uint32_t l = 0; l < 64; l++) W::pass2(l, z[l], t2.data(), slab.data());

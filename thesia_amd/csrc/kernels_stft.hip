@@ -316,6 +316,7 @@ __device__ __forceinline__ void wave_frame(
     asm volatile("" : "+v"(lane));
 #endif
     lane &= 63u;
+    const uint32_t col = W::lane_col(lane);  // the lane's column of the frame: complex points col + 64 m (stft_wave.h)
     // LDS reads return in order and a read issued next to its use exposes the whole LDS latency, so all
     // table reads are issued ahead of their use (lds_ld keeps program order): pass-2 twiddles before the
     // pass-1 arithmetic, pass-3 and split twiddles together with the reads of exchange 2.
@@ -324,7 +325,7 @@ __device__ __forceinline__ void wave_frame(
     constexpr bool DYN = PH == -2;
     if constexpr (DYN) {
         const uint32_t d = (uint32_t)((int64_t)f * g.hop - (int64_t)(g.win / 2)) & 127u;  // first window sample above the grid
-        wave_window_rot<P, 0>(lane, z, x, wtab + 64 + ((d & 1u) ? NC + 64 : 0) - ((d + 1u) >> 1));
+        wave_window_rot<P, 0>(col, z, x, wtab + 64 + ((d & 1u) ? NC + 64 : 0) - ((d + 1u) >> 1));
     } else if constexpr (RES & 1) {
 #pragma unroll
         for (int m = 0; m < P; m++) {
@@ -332,16 +333,13 @@ __device__ __forceinline__ void wave_frame(
             z[m] = {v.re * rw[m].re, v.im * rw[m].im};
         }
     } else {
-        wave_window_rot<P, OFF>(lane, z, x, wtab);
+        wave_window_rot<P, OFF>(col, z, x, wtab);
     }
     // Request the next frame of the chunk now: its samples land while this frame is transformed.  The fetch
     // is unconditional (branch-free register flow: no copies of x[]); on the last frame of a chunk it simply
     // re-reads this frame's span, which is in bounds, and the result is never used.
     {
         const uint32_t fn = f + 1 < f1 ? f + 1 : f;
-#if defined(TH_EXP_SMALLWAV)
-        const int64_t e0n = ((int64_t)fn * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left) & 0x1FFE;  // experiment: input from L2
-#else
         // (clamped into the channel: the one-frame chunks of boundary frames prefetch "themselves", and that span is
         // partly outside; a no-op for interior frames)
         const int64_t s_n = (int64_t)fn * g.hop - (int64_t)(g.win / 2);  // first window sample of the next frame
@@ -354,32 +352,27 @@ __device__ __forceinline__ void wave_frame(
         }
         const int64_t e0_max = (int64_t)n_samples - (int64_t)g.n_fft;
         e0n = e0n < 0 ? 0 : (e0n > e0_max ? e0_max : e0n);
-#endif
         if constexpr (DYN) {
             if (one_more) {  // wave-uniform
 #pragma unroll
                 for (int m = 0; m + SHIFT + 1 < P; m++) x[m] = x[m + SHIFT + 1];
-                wave_fetch<P, P - SHIFT - 1>(lane, x, wav, e0n);
+                wave_fetch<P, P - SHIFT - 1>(col, x, wav, e0n);
             } else {
 #pragma unroll
                 for (int m = 0; m + SHIFT < P; m++) x[m] = x[m + SHIFT];
-                wave_fetch<P, P - SHIFT>(lane, x, wav, e0n);
+                wave_fetch<P, P - SHIFT>(col, x, wav, e0n);
             }
         } else if constexpr (SHIFT == 0) {
-            wave_fetch<P, 0>(lane, x, wav, e0n);
+            wave_fetch<P, 0>(col, x, wav, e0n);
         } else if constexpr (ROTATE) {
-            wave_fetch_rot<P, SHIFT, OFF>(lane, x, wav, e0n);
+            wave_fetch_rot<P, SHIFT, OFF>(col, x, wav, e0n);
         } else {
 #pragma unroll
             for (int m = 0; m + SHIFT < P; m++) x[m] = x[m + SHIFT];
-            wave_fetch<P, P - SHIFT>(lane, x, wav, e0n);
+            wave_fetch<P, P - SHIFT>(col, x, wav, e0n);
         }
     }
     TH_SCHED_BARRIER();
-#if defined(TH_EXP_WAITLOADS)
-    TH_PROF_MARK(7);                     // experiment: expose the global-load latency in phase 0
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#endif
     TH_PROF_MARK(0);
     if constexpr (!(RES & 2)) W::load_t2(lane, w2, t2);  // lands during the pass-1 arithmetic
     W::pass1(lane, z, slab);
@@ -392,11 +385,7 @@ __device__ __forceinline__ void wave_frame(
     if constexpr (RES & 2) W::pass2_twiddle(z, rw2);
     else W::pass2_twiddle(z, w2);
 
-#if defined(TH_EXP_SMALLROW)
-    const gptr<float> row = spec + (size_t)(f & 7u) * spec_pitch;  // experiment: L2-resident output
-#else
     const gptr<float> row = spec + (size_t)f * spec_pitch;
-#endif
     if constexpr (W::PAIRED) {
         // mirror-local last pass: every Z[k] / Z[Nc-k] pair ends up in one lane's registers
         W::pass2_dft(lane, z, slab);
@@ -406,16 +395,7 @@ __device__ __forceinline__ void wave_frame(
         cf32 wa[W::NQ][W::R3 - 1], wb[W::NQ][W::R3 - 1];
         if constexpr (!(RES & 4)) W::load_t3_paired(lane, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
         cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
-#if defined(TH_ABL_NO_EX2)
-        // ablation (wrong results): no second exchange
-        for (int q = 0; q < W::NQ; q++)
-            for (int r = 0; r < W::R3; r++) {
-                za[q][r] = z[(W::R3 * q + r) % P];
-                zb[q][r] = z[(W::R3 * (q + W::NQ) + r) % P];
-            }
-#else
         W::read2_paired(lane, za, zb, slab);
-#endif
         wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
         constexpr bool PRELOAD_STW = W::NQ * W::R3 <= 8;  // 16 VGPRs at n_fft = 2048; too many at 4096
         cf32 ws[W::NQ][W::R3];
@@ -434,18 +414,8 @@ __device__ __forceinline__ void wave_frame(
             } else if constexpr (AMP) {
                 row[k] = power_to_amp(p);
             } else {
-#if defined(TH_EXP_NOLOG)
-                const float d = p;
-#else
                 const float d = power_to_dB(p);
-#endif
-#if defined(TH_EXP_NOSTORE)
-                if (d == 12345.678f) row[k] = d;  // experiment: (almost) never stores
-#elif defined(TH_EXP_NT_STORE)
-                __builtin_nontemporal_store(d, &row[k]);
-#else
                 row[k] = d;
-#endif
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }
@@ -506,9 +476,7 @@ __device__ __forceinline__ void wave_frame(
         cf32 *const prf = mel_prf != nullptr ? mel_prf : slab + (NC + 2) / 2;
         const MelFuseTab mt = mel_fuse_view(meltab, wo.mel_slots, wo.mel_groups);
         wave_lds_sync();
-#if !defined(TH_MEL_ABL_NOPIECES)
         mel_pieces(lane, slab_f, prf, mt);
-#endif
         wave_lds_sync();
         mel_gather(lane, prf, mt, [&](uint32_t m, float v) {
             if (m < wo.n_mel) {
@@ -520,7 +488,6 @@ __device__ __forceinline__ void wave_frame(
         });
         wave_lds_sync();  // the next frame's pass 1 rewrites the slab
     }
-#if !defined(TH_EXP_NO_TAILFILL) && !defined(TH_EXP_NOSTORE)
     // Rows at the library's padded pitch (th_pitch_f32): bin Nc would be the only dword written in its 128-byte line, and
     // a partially written line costs HBM a read-modify-write (scripts/ubench/row_stores.hip: 3.9 -> 5.4 TB/s for this row
     // shape).  The padding is ours, so complete the line with zeros.
@@ -529,7 +496,6 @@ __device__ __forceinline__ void wave_frame(
         const uint32_t pad = spec_pitch - height;
         if (lane - 1u < ((pad < 32u && spec_pitch % 32u == 0) ? pad : 0u)) row[height - 1u + lane] = 0.0f;
     }
-#endif
     TH_SCHED_BARRIER();
     TH_PROF_MARK(6);
 }
@@ -590,14 +556,6 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     cf32 *mel_prf = nullptr;
     if constexpr (OUT == 2 && LOG2_NC == 9)
         mel_prf = reinterpret_cast<cf32 *>(meltab + ((wo.mel_words + 1u) & ~1u)) + (size_t)wave * MEL_PRF_1024;
-#if defined(TH_EXP_PRIO)
-    {   // experiment: distinct static issue priorities for the waves that share a SIMD
-        const uint32_t pr = TH_EXP_PRIO == 1 ? (wave >> 2) & 3u : wave & 3u;
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    }
-#endif
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
     const uint32_t lane_wave = lane;
     TH_PROF_DECL();
@@ -622,7 +580,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     cf32 rwa[(RESK & 4) ? W::NQ : 1][W::R3 - 1], rwb[(RESK & 4) ? W::NQ : 1][W::R3 - 1], rws[(RESK & 8) ? W::NQ : 1][W::R3];
     if constexpr (RESK & 1) {
 #pragma unroll
-        for (int m = 0; m < P; m++) rw[m] = wtab[lane + 64u * m];
+        for (int m = 0; m < P; m++) rw[m] = wtab[W::lane_col(lane) + 64u * m];
     }
     if constexpr (RESK & 2) W::load_t2(lane, rw2, t2);
     if constexpr (RESK & 4) W::load_t3_paired(lane, rwa, rwb, t3);
@@ -646,8 +604,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         lmin = __builtin_inff();
         lmax = -__builtin_inff();
         cf32 x[P];  // raw samples of the current frame; the frame body refills it for the next one
-        if (cur.edge) wave_fetch_reflect<P>(lane, x, cur.wav, frame_e0(cur, g), cur.n_samples);  // wave-uniform
-        else wave_fetch<P, 0>(lane, x, cur.wav, frame_e0(cur, g));
+        if (cur.edge) wave_fetch_reflect<P>(W::lane_col(lane), x, cur.wav, frame_e0(cur, g), cur.n_samples);  // wave-uniform
+        else wave_fetch<P, 0>(W::lane_col(lane), x, cur.wav, frame_e0(cur, g));
         uint32_t f = cur.f;
         // frame loop (steady state: branch-free register flow, see wave_frame)
         for (;;) {

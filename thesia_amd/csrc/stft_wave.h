@@ -47,6 +47,61 @@ TH_HD void lds_st(cf32 *p, cf32 v) {
 #endif
 }
 
+// 16-byte LDS read (ds_read_b128, 16-byte aligned address), as four scalars (no vector-typed arithmetic downstream)
+struct f32x4 {
+    float a, b, c, d;
+};
+TH_HD f32x4 lds_ld4(const float *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *(const volatile __attribute__((address_space(3))) u32x4 *)(p);
+    // (scalar copies first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 for every element)
+    const uint32_t x = v.x, y = v.y, z = v.z, w = v.w;
+    return {__builtin_bit_cast(float, x), __builtin_bit_cast(float, y), __builtin_bit_cast(float, z),
+            __builtin_bit_cast(float, w)};
+#else
+    return {p[0], p[1], p[2], p[3]};
+#endif
+}
+
+// "Plane" stores: ds_write_addtid_b32 writes one dword per lane at LDS address M0 + offset + 4 * lane — no address
+// VGPR, so the store moves one source dword per lane instead of three (ds_write_b64) or five (ds_write_b128): 2
+// cycles per 256 bytes against 6 per 512 / 13 per 1024, and 64 consecutive dwords can never bank-conflict.  Four
+// complex values (v0..v3) of every lane go to the dword planes at byte offsets RE0 + i * STEP (real parts) and
+// IM0 + i * STEP (imaginary parts) of the wave's slab.  `slab` must be wave-uniform.  The compiler does not know these
+// are LDS stores: wave_lds_sync() (a compiler fence) must separate them from the reads of the same data, and since
+// LDS executes one wave's DS instructions in order and s_waitcnt lgkmcnt(N) waits for all but the N youngest, the
+// untracked stores can only make a later compiler-generated wait longer, never too short.
+template <int RE0, int IM0, int STEP>
+TH_HD void lds_st_planes4(float *slab, uint32_t lane, cf32 v0, cf32 v1, cf32 v2, cf32 v3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)slab);
+    asm volatile(
+        "s_mov_b32 m0, %8\n\t"
+        "s_nop 0\n\t"  // an SALU write of M0 needs one wait state before an LDS "add-TID" instruction (no interlock)
+        "ds_write_addtid_b32 %0 offset:%9\n\t"
+        "ds_write_addtid_b32 %1 offset:%10\n\t"
+        "ds_write_addtid_b32 %2 offset:%11\n\t"
+        "ds_write_addtid_b32 %3 offset:%12\n\t"
+        "ds_write_addtid_b32 %4 offset:%13\n\t"
+        "ds_write_addtid_b32 %5 offset:%14\n\t"
+        "ds_write_addtid_b32 %6 offset:%15\n\t"
+        "ds_write_addtid_b32 %7 offset:%16"
+        :
+        : "v"(v0.re), "v"(v0.im), "v"(v1.re), "v"(v1.im), "v"(v2.re), "v"(v2.im), "v"(v3.re), "v"(v3.im), "s"(base),
+          "n"(RE0), "n"(IM0), "n"(RE0 + STEP), "n"(IM0 + STEP), "n"(RE0 + 2 * STEP), "n"(IM0 + 2 * STEP),
+          "n"(RE0 + 3 * STEP), "n"(IM0 + 3 * STEP)
+        : "memory");
+    (void)lane;
+#else
+    const cf32 v[4] = {v0, v1, v2, v3};
+    for (int i = 0; i < 4; i++) {
+        slab[(RE0 + i * STEP) / 4 + lane] = v[i].re;
+        slab[(IM0 + i * STEP) / 4 + lane] = v[i].im;
+    }
+#endif
+}
+
 // full unrolling is required everywhere below: register arrays must never be indexed dynamically
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TH_UNROLL _Pragma("unroll")
@@ -80,7 +135,10 @@ TH_HD constexpr int dft8_slot(int k) { return (k >> 2) + 2 * (k & 3); }
 
 // DFT-16 as 4 x 4: n = n1 + 4*n2, k = 4*k1 + k2
 //   v[n1 + 4*k2] <- DFT4 over n2 of v[n1 + 4*n2];  *= W16^(n1*k2);  DFT4 over n1 -> X[4*k1+k2] in v[k1 + 4*k2]
-TH_HD void dft16(cf32 (&v)[16]) {
+// dft16 = dft16_head (first four radix-4 butterflies + the W16 twiddles) followed by dft16_tail<G>, G = 0..3: the
+// butterfly that produces X[G], X[4 + G], X[8 + G], X[12 + G] in v[4 G .. 4 G + 3] — callers that store the outputs
+// can do so group by group.
+TH_HD void dft16_head(cf32 (&v)[16]) {
     const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;  // cos, sin(pi/8)
     const float h = 0.70710678118654752440f;
     fft4(v[0], v[4], v[8], v[12]);
@@ -97,10 +155,17 @@ TH_HD void dft16(cf32 (&v)[16]) {
     v[7] = cmul_c(v[7], s1, -c1);                                   // n1=3,k2=1: W^3
     v[11] = {h * (v[11].im - v[11].re), -h * (v[11].re + v[11].im)};  // n1=3,k2=2: W^6
     v[15] = cmul_c(v[15], -c1, s1);                                 // n1=3,k2=3: W^9
-    fft4(v[0], v[1], v[2], v[3]);
-    fft4(v[4], v[5], v[6], v[7]);
-    fft4(v[8], v[9], v[10], v[11]);
-    fft4(v[12], v[13], v[14], v[15]);
+}
+template <int G>
+TH_HD void dft16_tail(cf32 (&v)[16]) {
+    fft4(v[4 * G], v[4 * G + 1], v[4 * G + 2], v[4 * G + 3]);
+}
+TH_HD void dft16(cf32 (&v)[16]) {
+    dft16_head(v);
+    dft16_tail<0>(v);
+    dft16_tail<1>(v);
+    dft16_tail<2>(v);
+    dft16_tail<3>(v);
 }
 // natural output X[k], k = 4*k1 + k2, sits in slot k1 + 4*k2
 TH_HD constexpr int dft16_slot(int k) { return (k >> 2) + 4 * (k & 3); }
@@ -187,33 +252,88 @@ struct WaveFft {
         }
     }
 
-    // pass 1 (Ns = 1, no twiddles): registers -> LDS slab (swizzled)
+    // -----------------------------------------------------------------------------------------
+    // Plane exchanges (n_fft = 2048: R1 = R2 = 16, one butterfly per lane and pass).  Both exchanges store with
+    // ds_write_addtid_b32 (lds_st_planes4) into 32 dword planes — plane k / 16 + k = real / imaginary parts of
+    // butterfly output k of every lane, in hardware-lane order — and read back with ds_read_b128, four consecutive
+    // lanes' values of one plane per load.  For the reads to be consecutive the butterflies are dealt to the hardware
+    // lanes in a permuted order:
+    //   pass 1: lane l owns column lane_col(l) = 4 (l & 15) + (l >> 4) of the input (complex points col + 64 m): the
+    //           global loads of a 16-lane group step by 32 bytes, the wave still covers whole 512-byte spans.
+    //   pass 2: lane l owns butterfly j = 16 a + c, a = l & 3, c = l >> 2 (twiddle index k = c).  Its inputs
+    //           in[j + 64 r] = pass-1 output c of column 4 r + a = plane c, lanes 16 a + r: 16 consecutive dwords.
+    //   pass 3: natural (mirror-local pairs of lane l: butterflies A_q = 64 q + l, B_q = 256 - A_q).  Input
+    //           in[jj + 256 r] = pass-2 output jj >> 4 of butterfly 16 r + (jj & 15) = plane jj >> 4, lanes
+    //           4 (jj & 15) + r: one 16-byte load per butterfly and component.
+    // Plane pitch: 68 dwords for exchange 1 (the 16-lane groups of a ds_read_b128 then cover all 64 banks: quad
+    // index (c + 4 a + t) mod 16 is distinct over {0-3, 12-15, 20-27} etc.), 64 for exchange 2 (quad = l & 15 for the
+    // A reads, -l & 15 for the B reads: distinct).  LDS-array cycles per frame and exchange: 64 (stores) + 32 (loads)
+    // against 128 + 32 for the 16-byte stores of the slot layout below (which 2-way bank-conflict: writes are banked
+    // mod 32 dwords), scripts/ubench/stft_skeleton.hip.
+    // -----------------------------------------------------------------------------------------
+    static constexpr bool PLANES = (R1 == 16 && R2 == 16 && P == 16);
+    static constexpr int PITCH1 = 68, PITCH2 = 64;
+    static TH_HD uint32_t lane_col(uint32_t lane) { return PLANES ? 4u * (lane & 15u) + (lane >> 4) : lane; }
+    template <int PITCH, int G>
+    static TH_HD void st_group(float *slab, uint32_t lane, cf32 (&v)[16]) {
+        lds_st_planes4<G * PITCH * 4, (16 + G) * PITCH * 4, 16 * PITCH>(slab, lane, v[4 * G], v[4 * G + 1], v[4 * G + 2],
+                                                                            v[4 * G + 3]);
+    }
+    template <int PITCH>
+    static TH_HD void dft16_to_planes(uint32_t lane, cf32 (&v)[16], cf32 *slab) {
+        float *const sf = reinterpret_cast<float *>(slab);
+        dft16_head(v);
+        dft16_tail<0>(v);
+        st_group<PITCH, 0>(sf, lane, v);
+        dft16_tail<1>(v);
+        st_group<PITCH, 1>(sf, lane, v);
+        dft16_tail<2>(v);
+        st_group<PITCH, 2>(sf, lane, v);
+        dft16_tail<3>(v);
+        st_group<PITCH, 3>(sf, lane, v);
+    }
+
+    // pass 1 (Ns = 1, no twiddles): registers -> LDS slab
     static TH_HD void pass1(uint32_t lane, cf32 (&z)[P], cf32 *slab) {
-#if defined(TH_ABL_NO_EX1)
-        return;  // ablation (wrong results): no pass-1 arithmetic output exchange
-#endif
-        TH_UNROLL for (int b = 0; b < B1; b++) {
-            cf32 v[R1];
-            TH_UNROLL for (int r = 0; r < R1; r++) v[r] = z[b + B1 * r];
-#if !defined(TH_ABL_NO_DFT)
-            RegDft<R1>::run(v);
-#endif
-            const uint32_t jj = lane + 64u * b;
-            TH_UNROLL for (int r = 0; r < R1; r++) lds_st(&slab[pad1(jj * R1) + r], v[RegDft<R1>::slot(r)]);  // = pad1(jj*R1 + r)
+        if constexpr (PLANES) {
+            cf32 v[16];
+            TH_UNROLL for (int r = 0; r < 16; r++) v[r] = z[r];
+            dft16_to_planes<PITCH1>(lane, v, slab);
+        } else {
+            TH_UNROLL for (int b = 0; b < B1; b++) {
+                cf32 v[R1];
+                TH_UNROLL for (int r = 0; r < R1; r++) v[r] = z[b + B1 * r];
+                RegDft<R1>::run(v);
+                const uint32_t jj = lane + 64u * b;
+                TH_UNROLL for (int r = 0; r < R1; r++) lds_st(&slab[pad1(jj * R1) + r], v[RegDft<R1>::slot(r)]);  // = pad1(jj*R1 + r)
+            }
         }
     }
     static TH_HD void read1(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
-#if defined(TH_ABL_NO_EX1)
-        return;
-#endif
-        TH_UNROLL for (int m = 0; m < P; m++) z[m] = lds_ld(&slab[pad1(lane) + 68u * m]);  // = pad1(lane + 64*m)
+        if constexpr (PLANES) {
+            const float *const sf = reinterpret_cast<const float *>(slab) + (lane >> 2) * PITCH1 + 16u * (lane & 3u);
+            f32x4 re[4], im[4];
+            TH_UNROLL for (int t = 0; t < 4; t++) {
+                re[t] = lds_ld4(sf + 4 * t);
+                im[t] = lds_ld4(sf + 16 * PITCH1 + 4 * t);
+            }
+            TH_UNROLL for (int t = 0; t < 4; t++) {
+                z[4 * t] = {re[t].a, im[t].a};
+                z[4 * t + 1] = {re[t].b, im[t].b};
+                z[4 * t + 2] = {re[t].c, im[t].c};
+                z[4 * t + 3] = {re[t].d, im[t].d};
+            }
+        } else {
+            TH_UNROLL for (int m = 0; m < P; m++) z[m] = lds_ld(&slab[pad1(lane) + 68u * m]);  // = pad1(lane + 64*m)
+        }
     }
 
     // pass 2 (Ns = R1): registers -> LDS slab (linear).  In three pieces so that the kernel can issue the
     // twiddle reads long before their use (LDS returns in order: a read issued next to its use exposes
     // the whole LDS latency): load_t2 -> pass2_twiddle -> pass2_dft.  pass2() is the composition.
     static TH_HD void load_t2(uint32_t lane, cf32 (&w2)[R2 - 1], const cf32 *t2) {
-        const uint32_t k = lane & (NS2 - 1);  // NS2 <= 64: the same twiddles for every butterfly of the lane
+        // NS2 <= 64: the same twiddles for every butterfly of the lane
+        const uint32_t k = PLANES ? lane >> 2 : lane & (NS2 - 1);
         TH_UNROLL for (int r = 1; r < R2; r++) w2[r - 1] = lds_ld(&t2[(r - 1) * NS2 + k]);
     }
     static TH_HD void pass2_twiddle(cf32 (&z)[P], const cf32 (&w2)[R2 - 1]) {
@@ -221,20 +341,17 @@ struct WaveFft {
             TH_UNROLL for (int r = 1; r < R2; r++) z[b + B2 * r] = cmul(z[b + B2 * r], w2[r - 1]);
     }
     static TH_HD void pass2_dft(uint32_t lane, cf32 (&z)[P], cf32 *slab) {
-        TH_UNROLL for (int b = 0; b < B2; b++) {
-            const uint32_t jj = lane + 64u * b, k = jj & (NS2 - 1);
-            cf32 v[R2];
-            TH_UNROLL for (int r = 0; r < R2; r++) v[r] = z[b + B2 * r];
-#if !defined(TH_ABL_NO_DFT)
-            RegDft<R2>::run(v);
-#endif
-            const uint32_t j0 = (jj - k) * R2 + k;
-#if defined(TH_ABL_NO_EX2)
-            TH_UNROLL for (int r = 0; r < R2; r++) z[b + B2 * r] = v[RegDft<R2>::slot(r)];  // ablation: keep in registers
-            (void)j0;
-#else
-            TH_UNROLL for (int r = 0; r < R2; r++) lds_st(&slab[j0 + r * NS2], v[RegDft<R2>::slot(r)]);
-#endif
+        if constexpr (PLANES) {
+            dft16_to_planes<PITCH2>(lane, z, slab);
+        } else {
+            TH_UNROLL for (int b = 0; b < B2; b++) {
+                const uint32_t jj = lane + 64u * b, k = jj & (NS2 - 1);
+                cf32 v[R2];
+                TH_UNROLL for (int r = 0; r < R2; r++) v[r] = z[b + B2 * r];
+                RegDft<R2>::run(v);
+                const uint32_t j0 = (jj - k) * R2 + k;
+                TH_UNROLL for (int r = 0; r < R2; r++) lds_st(&slab[j0 + r * NS2], v[RegDft<R2>::slot(r)]);
+            }
         }
     }
     static TH_HD void pass2(uint32_t lane, cf32 (&z)[P], const cf32 *t2, cf32 *slab) {
@@ -264,6 +381,7 @@ struct WaveFft {
     // index (Nc - lane - 64*(P-1)) + 64*(P-1-m) = per-lane base + immediate.
     static_assert(32 % R1 == 0, "pad1 needs R1 | 32");
     static constexpr int SLAB_LEN = NC + NC / 16;  // padded pass-1 image is the largest (>= NC + 1)
+    static_assert(!PLANES || 2 * SLAB_LEN >= 32 * PITCH1, "slab holds the 32 planes of exchange 1");
     static TH_HD void write_z(uint32_t lane, const cf32 (&z)[P], cf32 *slab) {
         TH_UNROLL for (int m = 0; m < P; m++) slab[lane + 64u * m] = z[m];
         if (lane == 0) slab[NC] = z[0];
@@ -289,11 +407,35 @@ struct WaveFft {
     }
     // exchange-2 read in the paired layout: za[q][r] = in[A_q + r*Ns3], zb[q][r] = in[B_q + r*Ns3]
     static TH_HD void read2_paired(uint32_t lane, cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 *slab) {
-        TH_UNROLL for (int q = 0; q < NQ; q++) {
-            const uint32_t a = jj_a(lane, q), b = jj_b(lane, q);
-            TH_UNROLL for (int r = 0; r < R3; r++) {
-                za[q][r] = lds_ld(&slab[a + (uint32_t)r * NS3]);
-                zb[q][r] = lds_ld(&slab[b + (uint32_t)r * NS3]);
+        if constexpr (PLANES) {
+            static_assert(!PLANES || R3 == 4, "one 16-byte load per butterfly and component");
+            const float *const sf = reinterpret_cast<const float *>(slab);
+            f32x4 ar[NQ], ai[NQ], br[NQ], bi[NQ];
+            TH_UNROLL for (int q = 0; q < NQ; q++) {
+                const uint32_t a = jj_a(lane, q), b = jj_b(lane, q);
+                const float *const pa = sf + (a >> 4) * PITCH2 + 4u * (a & 15u), *const pb = sf + (b >> 4) * PITCH2 + 4u * (b & 15u);
+                ar[q] = lds_ld4(pa);
+                ai[q] = lds_ld4(pa + 16 * PITCH2);
+                br[q] = lds_ld4(pb);
+                bi[q] = lds_ld4(pb + 16 * PITCH2);
+            }
+            TH_UNROLL for (int q = 0; q < NQ; q++) {
+                za[q][0] = {ar[q].a, ai[q].a};
+                za[q][1 % R3] = {ar[q].b, ai[q].b};
+                za[q][2 % R3] = {ar[q].c, ai[q].c};
+                za[q][3 % R3] = {ar[q].d, ai[q].d};
+                zb[q][0] = {br[q].a, bi[q].a};
+                zb[q][1 % R3] = {br[q].b, bi[q].b};
+                zb[q][2 % R3] = {br[q].c, bi[q].c};
+                zb[q][3 % R3] = {br[q].d, bi[q].d};
+            }
+        } else {
+            TH_UNROLL for (int q = 0; q < NQ; q++) {
+                const uint32_t a = jj_a(lane, q), b = jj_b(lane, q);
+                TH_UNROLL for (int r = 0; r < R3; r++) {
+                    za[q][r] = lds_ld(&slab[a + (uint32_t)r * NS3]);
+                    zb[q][r] = lds_ld(&slab[b + (uint32_t)r * NS3]);
+                }
             }
         }
     }
@@ -367,11 +509,7 @@ struct WaveFft {
                 const float tr = di * w.re + dr * w.im, ti = di * w.im - dr * w.re;
                 const float xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
                 emit(k, xr * xr + xi * xi);
-#if defined(TH_EXP_ALIGNED_MIRROR)
-                emit(NC - k - 1, yr * yr + yi * yi);  // experiment (wrong bins): 256-B aligned mirrored stores
-#else
                 emit(NC - k, yr * yr + yi * yi);
-#endif
             }
         }
         if (l0) {  // the self-mirrored bin Nc/2 = output R3/2 of butterfly 0
