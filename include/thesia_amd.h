@@ -32,8 +32,11 @@
  *   - "_dev" entries take DEVICE pointers, enqueue on the context's HIP stream and do not
  *     synchronise unless they return data to the host.  All other entries take HOST pointers.
  *   - Compute entries (th_calc_spec_*, th_tm_* mutators) may assume exclusive access, like the
- *     reference's single write-lock worker (interface.rs:12-56).  Tile getters are re-entrant
- *     with respect to each other (internal mutex on the stream).
+ *     reference's single write-lock worker (interface.rs:12-56).  th_tm_* tile getters run
+ *     concurrently with each other (each request has its own HIP stream and pinned staging buffer)
+ *     and are excluded only while a th_tm_* mutator runs (reader / writer lock, as the reference's
+ *     RwLock<TrackManager>, lib.rs:345,378); the context-level th_encode_*_tile_dev entries share
+ *     the context stream and serialise on an internal mutex.
  *   - There is NO CPU fallback: compute entries fail with TH_ERR_NO_DEVICE without a GPU.
  */
 #ifndef THESIA_AMD_H
@@ -344,7 +347,11 @@ TH_API int th_tm_create(th_ctx *ctx, th_tm **out);
 TH_API int th_tm_destroy(th_tm *tm);
 /* init(colormap_rgba) — lib.rs:51-98, render_tiles.rs:80-85; sets colormap_length = bytes/4 */
 TH_API int th_tm_set_colormap(th_tm *tm, const uint8_t *rgba, size_t bytes);
-/* TrackManager::set_setting — core/mod.rs:107-115 (recomputes every resident track) */
+/* TrackManager::set_setting — core/mod.rs:107-115 (recomputes every resident track).  Transactional: when the new
+ * setting cannot be planned (this library needs n_fft = next_pow2(win) * f_overlap to be a power of two in
+ * [8, 16384]; the reference's realfft takes any even length, so e.g. f_overlap = 3 or 192 kHz with f_overlap = 4 are
+ * valid there and TH_ERR_UNSUPPORTED here) or memory runs out, the call fails and the manager — settings, plans,
+ * specs, images, revisions — is exactly as before.  th_tm_add_tracks gives the same guarantee. */
 TH_API int th_tm_set_setting(th_tm *tm, double win_ms, uint32_t t_overlap, uint32_t f_overlap, int freq_scale);
 /* TrackManager::set_dB_range — core/mod.rs:123-126 */
 TH_API int th_tm_set_dB_range(th_tm *tm, float dB_range);
@@ -392,5 +399,17 @@ TH_API int th_tm_get_audio_render_metadata(th_tm *tm, size_t id, uint32_t ch, do
                                            th_render_metadata *out);
 /* the RenderTileCache in front of get_waveform_tile (lib.rs:350-366): borrowed, owned by tm */
 TH_API int th_tm_tile_cache(th_tm *tm, th_tile_cache **out);
+/* Spectrogram tiles with level_x or level_y > 0 (resize_spectrogram_tile, render_tiles.rs:354-393).
+ * Default (per_request = 0): every channel's image gets a mip pyramid when it is (re)made — the whole image resized
+ * to ceil(W / 2^lx) x ceil(H / 2^ly) with the separable Lanczos3 — and a LOD tile is a crop of that level + colour
+ * LUT, like a level-0 tile.  per_request = 1: the reference's own flow, the tile's crop box is
+ * resampled from the level-0 image on every request (also used for levels the pyramid does not hold: images
+ * smaller than 16 px at that level).  The two differ in the 4-pixel gutter (a per-request resize clips the filter at
+ * the crop box, the pyramid at the image) and, rarely, by one u16 step elsewhere (f64 rounding of the tap centres).
+ * PARITY UNPINNED against fast_image_resize in both modes. */
+TH_API int th_tm_set_lod_source(th_tm *tm, int per_request);
+/* shape of (and, with out != NULL, a dense copy of) one resident mip level; (0, 0) is the image itself */
+TH_API int th_tm_mip_level(th_tm *tm, size_t id, uint32_t ch, uint32_t level_x, uint32_t level_y, uint16_t *out,
+                           size_t capacity_px, size_t *width, size_t *height);
 
 #endif /* THESIA_AMD_H */

@@ -462,11 +462,101 @@ def test_track_manager_waveform_tile_cache_and_lod_tiles(ctx, golden_dir):
     w2, s2 = tm.revisions()
     assert w2 > w_rev and s2 > s_rev and cache.stats()["entries"] == 0
     assert tm.get_waveform_tile(3, 0, 2, 1) == orc.encode_waveform_tile(wav, w2, 2, 1)
-    # LOD tiles through the manager
+    # LOD tiles through the manager, resampled per request (the reference's flow): the restated Lanczos3 exactly
     img = tm.img(3, 0)
+    tm.set_lod_source(per_request=True)
     for lx, ly, tx, ty in [(1, 0, 0, 0), (0, 1, 1, 0), (2, 1, 0, 0)]:
         got = tm.get_spectrogram_tile(3, 0, lx, ly, tx, ty)
         assert got == orc.encode_spectrogram_tile(img, cmap, s2, lx, ly, tx, ty), (lx, ly, tx, ty)
+    tm.close()
+
+
+def _identity_colormap() -> bytes:
+    """65536 colours with RGBA = (v & 255, v >> 8, 0, 255): the colour index (v * 65535 + 32767) / 65535 is v itself, so a
+    tile's RGBA bytes carry the u16 image exactly."""
+    v = np.arange(65536, dtype=np.uint32)
+    return np.stack([v & 255, v >> 8, np.zeros_like(v), np.full_like(v, 255)], 1).astype(np.uint8).tobytes()
+
+
+def _tile_u16(tile: bytes):
+    w, h = np.frombuffer(tile[8:16], np.uint32)
+    px = np.frombuffer(tile[40:], np.uint8).reshape(h, w, 4).astype(np.uint32)
+    return (px[..., 0] | (px[..., 1] << 8)).astype(np.int64), np.frombuffer(tile[32:40], np.uint32)
+
+
+def test_lod_mip_pyramid(ctx):
+    """every channel's image gets a mip pyramid (the whole image resized per level with the separable
+    Lanczos3 of render_tiles.rs:354-393) and LOD > 0 tiles are crops of it.  (a) Where a level is a single tile, crop box
+    = whole image, so the pyramid level is byte-identical to the restated per-request resize.  (b) On a multi-tile image
+    the pyramid tiles equal the per-request tiles inside the 512-pixel core up to one u16 step in rare pixels (f64
+    rounding of the tap centres); the 4-pixel gutter differs by design (filter clipped at the image, not at the crop).
+    PARITY UNPINNED against fast_image_resize 6.0.0 in both modes."""
+    ident = _identity_colormap()
+    tm = ta.TrackManager(ctx)
+    tm.set_setting(40.0, 4, 1, ta.MEL)
+    tm.set_colormap(ident)
+    small = synth_track(31, 48000, 150000)          # 313 frames x 347 mel bins: every level is a single tile
+    big = synth_track(32, 48000, 48000 * 30)         # 3001 frames: six level-0 tile columns
+    tm.add_tracks([(1, 48000, small[None]), (2, 48000, big[None])])
+    tm.apply_track_list_changes()
+    _, s_rev = tm.revisions()
+    img = tm.img(1, 0)
+    assert img.shape[0] <= 512 and img.shape[1] <= 512
+    for lx, ly in [(1, 0), (2, 0), (0, 1), (1, 1), (3, 2), (4, 1)]:
+        mip = tm.mip_level(1, 0, lx, ly)
+        assert mip.shape == (-(-img.shape[0] // (1 << ly)), -(-img.shape[1] // (1 << lx)))
+        # one tile covers the level: the oracle's tile (0, 0) is the whole-image resize
+        want, _ = _tile_u16(orc.encode_spectrogram_tile(img, ident, s_rev, lx, ly, 0, 0))
+        assert np.array_equal(mip[::-1].astype(np.int64), want), (lx, ly)  # (tile rows: highest frequency first)
+    # (b) multi-tile image: pyramid tiles vs per-request tiles
+    img2 = tm.img(2, 0)
+    worst, n_diff, n_px = 0, 0, 0
+    for lx, ly, tx, ty in [(1, 0, 0, 0), (1, 0, 2, 0), (1, 1, 1, 0), (2, 0, 1, 0), (0, 1, 3, 0), (2, 1, 0, 0)]:
+        tm.set_lod_source(per_request=False)
+        a, (ox, oy) = _tile_u16(tm.get_spectrogram_tile(2, 0, lx, ly, tx, ty))
+        mip = tm.mip_level(2, 0, lx, ly)
+        assert np.array_equal(a, mip[::-1].astype(np.int64)[mip.shape[0] - oy - a.shape[0]: mip.shape[0] - oy, ox: ox + a.shape[1]])
+        tm.set_lod_source(per_request=True)
+        b, _ = _tile_u16(tm.get_spectrogram_tile(2, 0, lx, ly, tx, ty))
+        assert b.tobytes() == _tile_u16(orc.encode_spectrogram_tile(img2, ident, s_rev, lx, ly, tx, ty))[0].tobytes()
+        assert a.shape == b.shape and a.size > 0
+        core = (slice(4, a.shape[0] - 4), slice(4, a.shape[1] - 4))
+        d = np.abs(a[core] - b[core])
+        worst, n_diff, n_px = max(worst, int(d.max())), n_diff + int((d > 0).sum()), n_px + d.size
+    assert worst <= 1 and n_diff <= 1e-3 * n_px, (worst, n_diff, n_px)
+    tm.close()
+
+
+def test_track_manager_failed_setting_changes_nothing(ctx, golden_dir):
+    """a setting this library cannot plan (f_overlap = 3 -> n_fft not a power of two; the reference's realfft
+    would take it) must fail WITHOUT touching the manager: settings, specs, images, db state, tiles and revisions are
+    as before, and later calls keep working with the old setting."""
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    tm = ta.TrackManager(ctx)
+    tm.set_setting(40.0, 4, 1, ta.LINEAR)
+    tm.set_colormap(cmap)
+    x = synth_track(41, 48000, 60000)
+    tm.add_tracks([(7, 48000, x[None])])
+    tm.apply_track_list_changes()
+    before = (tm.spec(7, 0).copy(), tm.img(7, 0).copy(), tm.db_state(), tm.revisions(), tm.get_spectrogram_tile(7, 0, 0, 0, 0, 0),
+              tm.get_waveform_tile(7, 0, 3, 0))
+    for bad in [(40.0, 4, 3, ta.LINEAR), (40.0, 4, 16, ta.MEL)]:  # n_fft 6144; 32768 (> 16384)
+        with pytest.raises(ta.ThError) as e:
+            tm.set_setting(*bad)
+        assert e.value.code == -2, e.value
+    after = (tm.spec(7, 0), tm.img(7, 0), tm.db_state(), tm.revisions(), tm.get_spectrogram_tile(7, 0, 0, 0, 0, 0),
+             tm.get_waveform_tile(7, 0, 3, 0))
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    assert before[2:] == after[2:]
+    # the old setting is still the one in force: a new track gets the same shape of spec
+    tm.add_tracks([(8, 48000, synth_track(42, 48000, 60000)[None])])
+    tm.apply_track_list_changes()
+    assert tm.spec(8, 0).shape == before[0].shape
+    # a failing add (empty channel) changes nothing either and leaves the waveform tiles of the resident track cached
+    w_rev = tm.revisions()[0]
+    with pytest.raises(ta.ThError):
+        tm.add_tracks([(7, 48000, np.zeros((1, 0), np.float32))])
+    assert tm.revisions()[0] == w_rev and np.array_equal(tm.spec(7, 0), before[0])
     tm.close()
 
 

@@ -568,6 +568,19 @@ class TrackManager:
                                              _ptr(out, c_u8p), out.size, C.byref(n)))
         return out[: n.value].tobytes()
 
+    def set_lod_source(self, per_request: bool) -> None:
+        """LOD > 0 tiles from the resident mip pyramid (False, default) or resampled per request (True)."""
+        check(lib.th_tm_set_lod_source(self.handle, int(per_request)))
+
+    def mip_level(self, track_id: int, ch: int, level_x: int, level_y: int) -> np.ndarray:
+        """Dense copy of one resident level of the channel's LOD mip pyramid ((0, 0): the image itself)."""
+        w, h = C.c_size_t(), C.c_size_t()
+        check(lib.th_tm_mip_level(self.handle, track_id, ch, level_x, level_y, None, 0, C.byref(w), C.byref(h)))
+        out = np.empty((h.value, w.value), np.uint16)
+        check(lib.th_tm_mip_level(self.handle, track_id, ch, level_x, level_y, _ptr(out, c_u16p), out.size, C.byref(w),
+                                  C.byref(h)))
+        return out
+
     def render_metadata(self, track_id: int, ch: int, track_sec: float, is_clipped: bool) -> dict:
         """AudioRenderMetadata of get_audio_render_metadata (lib.rs:321-340)."""
         m = _ffi.RenderMetadata()

@@ -1188,45 +1188,6 @@ TH_API int th_encode_spectrogram_tile_dev(th_ctx *c, const uint16_t *d_img, size
         const double left = (double)g.origin_x * W / (double)g.lod_w, top = (double)g.origin_y * Hh / (double)g.lod_h;
         const double cw = (double)(g.origin_x + dw) * W / (double)g.lod_w - left;
         const double chh = (double)(g.origin_y + dh) * Hh / (double)g.lod_h - top;
-        auto lanczos3 = [](double x) -> double {
-            if (x == 0.0) return 1.0;
-            if (x <= -3.0 || x >= 3.0) return 0.0;
-            const double px = M_PI * x;
-            return 3.0 * std::sin(px) * std::sin(px / 3.0) / (px * px);
-        };
-        struct Axis {
-            std::vector<int32_t> start, count;
-            std::vector<double> wsum, w;
-            uint32_t max_taps = 0;
-        };
-        auto build = [&](double origin, double extent, size_t n_out, long lo, long hi, Axis &ax) {
-            const double sc = extent / (double)n_out, f = sc < 1.0 ? 1.0 : sc, sup = 3.0 * f;
-            ax.start.resize(n_out);
-            ax.count.resize(n_out);
-            ax.wsum.resize(n_out);
-            for (size_t o = 0; o < n_out; o++) {
-                const double center = origin + ((double)o + 0.5) * sc;
-                long i0 = (long)std::floor(center - sup), i1 = (long)std::ceil(center + sup);
-                if (i0 < lo) i0 = lo;
-                if (i1 > hi) i1 = hi;
-                if (i1 < i0) i1 = i0;
-                ax.start[o] = (int32_t)i0;
-                ax.count[o] = (int32_t)(i1 - i0);
-                ax.max_taps = std::max<uint32_t>(ax.max_taps, (uint32_t)(i1 - i0));
-            }
-            if (ax.max_taps == 0) ax.max_taps = 1;
-            ax.w.assign(n_out * (size_t)ax.max_taps, 0.0);
-            for (size_t o = 0; o < n_out; o++) {
-                const double center = origin + ((double)o + 0.5) * sc;
-                double ws = 0.0;
-                for (int32_t t = 0; t < ax.count[o]; t++) {
-                    const double wv = lanczos3(((double)(ax.start[o] + t) + 0.5 - center) / f);
-                    ax.w[o * (size_t)ax.max_taps + t] = wv;
-                    ws += wv;
-                }
-                ax.wsum[o] = ws;
-            }
-        };
         const double scy = chh / (double)dh, fy = scy < 1.0 ? 1.0 : scy, supy = 3.0 * fy;
         long y_lo = (long)std::floor(top - supy) - 1, y_hi = (long)std::ceil(top + chh + supy) + 1;
         if (y_lo < 0) y_lo = 0;
@@ -1236,21 +1197,14 @@ TH_API int th_encode_spectrogram_tile_dev(th_ctx *c, const uint16_t *d_img, size
         const double est_taps = 6.0 * std::max(cw / (double)dw, chh / (double)dh) + 4.0;
         if (est_taps * 8.0 * (double)std::max(dw, dh) > 256.0 * 1024 * 1024)
             return fail(TH_ERR_UNSUPPORTED, "LOD level (%u,%u) needs a tap table beyond 256 MB", level_x, level_y);
-        Axis ax, ay;
-        build(left, cw, dw, 0, (long)img_width, ax);
-        build(top, chh, dh, y_lo, y_hi, ay);
+        LodAxisHost ax, ay;
+        build_lod_axis(left, cw, dw, 0, (long)img_width, ax);
+        build_lod_axis(top, chh, dh, y_lo, y_hi, ay);
         // one blob: [x: start,count,wsum,w][y: start,count,wsum,w], 8-byte aligned sections
-        auto sect = [](size_t n_out, uint32_t taps) { return n_out * 8 /*start+count*/ + n_out * 8 + n_out * (size_t)taps * 8; };
-        const size_t bx = sect(dw, ax.max_taps), by = sect(dh, ay.max_taps);
+        const size_t bx = ax.blob_bytes(dw), by = ay.blob_bytes(dh);
         std::vector<unsigned char> blob(bx + by);
-        auto pack = [](unsigned char *p, const Axis &a, size_t n_out) {
-            std::memcpy(p, a.start.data(), n_out * 4);
-            std::memcpy(p + n_out * 4, a.count.data(), n_out * 4);
-            std::memcpy(p + n_out * 8, a.wsum.data(), n_out * 8);
-            std::memcpy(p + n_out * 16, a.w.data(), a.w.size() * 8);
-        };
-        pack(blob.data(), ax, dw);
-        pack(blob.data() + bx, ay, dh);
+        ax.pack(blob.data(), dw);
+        ay.pack(blob.data() + bx, dh);
         rc = c->lod_tabs.upload(c->stream, blob.data(), blob.size());
         if (rc != TH_OK) return rc;
         rc = c->lod_tmp.ensure((n_rows * dw + dw * dh) * sizeof(uint16_t) + 64);
@@ -1269,8 +1223,9 @@ TH_API int th_encode_spectrogram_tile_dev(th_ctx *c, const uint16_t *d_img, size
         uint16_t *d_tmp = static_cast<uint16_t *>(c->lod_tmp.dptr);
         uint16_t *d_lod = d_tmp + ((n_rows * dw + 3) / 4) * 4;
         TH_HIP(launch_lod_hpass(d_img, pitch, (uint32_t)y_lo, (uint32_t)n_rows, axis_dev(dtab, dw, ax.max_taps), d_tmp,
-                                c->stream));
-        TH_HIP(launch_lod_vpass(d_tmp, (uint32_t)y_lo, axis_dev(dtab + bx, dh, ay.max_taps), (uint32_t)dw, d_lod, c->stream));
+                                (uint32_t)dw, c->stream));
+        TH_HIP(launch_lod_vpass(d_tmp, (uint32_t)dw, (uint32_t)y_lo, axis_dev(dtab + bx, dh, ay.max_taps), (uint32_t)dw, d_lod,
+                                (uint32_t)dw, c->stream));
         th_raster_desc d{d_lod, (uint8_t *)c->tile_out.dptr, (uint32_t)dw, (uint32_t)dh, 0, 0, (uint32_t)dw, (uint32_t)dh,
                          (uint32_t)dw, 0};
         rc = th_raster_tiles_dev(c, &d, 1, (const uint8_t *)c->colormap.dptr, n_colors);

@@ -210,4 +210,48 @@ void waveform_tile_geometry(size_t n, uint32_t level, uint32_t tile, size_t *sta
     *bins = st >= en ? 0 : div_ceil(en - st, s);
 }
 
+static double lanczos3(double x) {
+    if (x == 0.0) return 1.0;
+    if (x <= -3.0 || x >= 3.0) return 0.0;
+    const double px = M_PI * x;
+    return 3.0 * std::sin(px) * std::sin(px / 3.0) / (px * px);
+}
+
+void build_lod_axis(double origin, double extent, size_t n_out, long lo, long hi, LodAxisHost &ax) {
+    const double sc = extent / (double)n_out, f = sc < 1.0 ? 1.0 : sc, sup = 3.0 * f;
+    ax.start.resize(n_out);
+    ax.count.resize(n_out);
+    ax.wsum.resize(n_out);
+    ax.max_taps = 0;
+    for (size_t o = 0; o < n_out; o++) {
+        const double center = origin + ((double)o + 0.5) * sc;
+        long i0 = (long)std::floor(center - sup), i1 = (long)std::ceil(center + sup);
+        if (i0 < lo) i0 = lo;
+        if (i1 > hi) i1 = hi;
+        if (i1 < i0) i1 = i0;
+        ax.start[o] = (int32_t)i0;
+        ax.count[o] = (int32_t)(i1 - i0);
+        ax.max_taps = std::max<uint32_t>(ax.max_taps, (uint32_t)(i1 - i0));
+    }
+    if (ax.max_taps == 0) ax.max_taps = 1;
+    ax.w.assign(n_out * (size_t)ax.max_taps, 0.0);
+    for (size_t o = 0; o < n_out; o++) {
+        const double center = origin + ((double)o + 0.5) * sc;
+        double ws = 0.0;
+        for (int32_t t = 0; t < ax.count[o]; t++) {
+            const double wv = lanczos3(((double)(ax.start[o] + t) + 0.5 - center) / f);
+            ax.w[o * (size_t)ax.max_taps + t] = wv;
+            ws += wv;
+        }
+        ax.wsum[o] = ws;
+    }
+}
+
+void LodAxisHost::pack(unsigned char *p, size_t n_out) const {
+    std::memcpy(p, start.data(), n_out * 4);
+    std::memcpy(p + n_out * 4, count.data(), n_out * 4);
+    std::memcpy(p + n_out * 8, wsum.data(), n_out * 8);
+    std::memcpy(p + n_out * 16, w.data(), w.size() * 8);
+}
+
 }  // namespace th

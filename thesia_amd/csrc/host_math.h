@@ -26,6 +26,19 @@ struct TileGeom {
 TileGeom spectrogram_tile_geometry(size_t W, size_t Hh, uint32_t lx, uint32_t ly, uint32_t tx, uint32_t ty);
 void waveform_tile_geometry(size_t n, uint32_t level, uint32_t tile, size_t *start, size_t *bins, size_t *spb);
 
+// Lanczos3 tap table of one axis of resize_spectrogram_tile (render_tiles.rs:354-393; PARITY UNPINNED against
+// fast_image_resize 6.0.0, whose source is not vendored: the textbook filter, exactly as oracle/thesia_oracle.c builds
+// it).  n_out outputs over the source interval [origin, origin + extent); output o: taps for the source indices
+// start[o] .. start[o] + count[o] - 1 (clamped to [lo, hi)), weights w[o * max_taps + t], their sum wsum[o].
+struct LodAxisHost {
+    std::vector<int32_t> start, count;
+    std::vector<double> wsum, w;
+    uint32_t max_taps = 0;
+    size_t blob_bytes(size_t n_out) const { return n_out * 16 + n_out * (size_t)max_taps * 8; }
+    void pack(unsigned char *p, size_t n_out) const;  // [start i32][count i32][wsum f64][w f64], as LodAxis reads it
+};
+void build_lod_axis(double origin, double extent, size_t n_out, long lo, long hi, LodAxisHost &ax);
+
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 inline unsigned ilog2(size_t n) {
     unsigned l = 0;

@@ -112,10 +112,15 @@ struct LodAxis {             // device pointers into one uploaded blob
     uint32_t n_out, max_taps;
 };
 // horizontal pass: tmp[r][ox] for the source rows y_lo + r, r < n_rows; vertical pass: lod[oy][ox]
+// (tmp_pitch / lod_pitch: elements per row of the intermediate and of the result)
 hipError_t launch_lod_hpass(const uint16_t *d_img, uint32_t img_pitch, uint32_t y_lo, uint32_t n_rows, LodAxis ax,
-                            uint16_t *d_tmp, hipStream_t s);
-hipError_t launch_lod_vpass(const uint16_t *d_tmp, uint32_t y_lo, LodAxis ay, uint32_t dw, uint16_t *d_lod,
-                            hipStream_t s);
+                            uint16_t *d_tmp, uint32_t tmp_pitch, hipStream_t s);
+hipError_t launch_lod_vpass(const uint16_t *d_tmp, uint32_t tmp_pitch, uint32_t y_lo, LodAxis ay, uint32_t dw,
+                            uint16_t *d_lod, uint32_t lod_pitch, hipStream_t s);
+// one tile rectangle of one image -> RGBA, job passed by value (tile requests: nothing to upload)
+hipError_t launch_raster_tile(const uint16_t *d_img, uint32_t img_width, uint32_t img_height, uint32_t img_pitch,
+                              uint32_t origin_x, uint32_t origin_y, uint32_t width, uint32_t height, uint8_t *d_rgba,
+                              const uint8_t *d_colormap, uint32_t n_colors, hipStream_t s);
 
 // ---- kernels_waveform.hip
 struct WaveJob {  // device-visible copy of th_wave_desc

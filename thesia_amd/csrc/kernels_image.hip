@@ -165,11 +165,7 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     const bool rows_al = (reinterpret_cast<uintptr_t>(job.img) & 3u) == 0 && job.img_pitch % 2 == 0;
     // Rows at the library's padded pitch (th_pitch_u16): the padding is ours, and the tile holds zeros there (NaN -> 0), so
     // store the whole last 128-byte line of every row — a partially written line costs HBM a read-modify-write.
-#if defined(TH_EXP_NO_TAILFILL)
-    const uint32_t t_lim = job.n_frames;
-#else
     const uint32_t t_lim = (job.img_pitch % IMG_TILE_T == 0 && job.img_pitch - job.n_frames < IMG_TILE_T) ? job.img_pitch : job.n_frames;
-#endif
 #pragma unroll
     for (uint32_t i = 0; i < NST; i++) {
         const uint32_t r = r0 + 2 * (wv + 4 * i) + half;
@@ -278,11 +274,7 @@ __device__ __forceinline__ void raster_quads(const RasterJob &job, uint32_t base
             const uint32_t r = job.quads_per_row == 1 ? q : __umulhi(q, job.inv_qpr);  // 2^32/1 does not fit inv_qpr
             const uint32_t c = (q - r * job.quads_per_row) * 4;
             const uint32_t src_row = job.origin_y + (job.height - 1 - r);  // first output row = highest frequency
-#if defined(TH_EXP_RASTER_LINEAR)
-            const gptr<const uint16_t> src = img + (size_t)blockIdx.x * RASTER_QUADS_PER_BLOCK * 4 % ((size_t)job.img_pitch * job.img_height - 8192) + (size_t)(it * RASTER_THREADS + threadIdx.x) * 4 + 0 * src_row;  // experiment
-#else
             const gptr<const uint16_t> src = img + ((size_t)src_row * job.img_pitch + job.origin_x + c);
-#endif
             const uint32_t o = r * job.width + c;
             uint32_t v0, v1, v2, v3;
             if (src_al) {  // 8-byte aligned quads (uniform per job): one load instead of four 2-byte loads
@@ -297,11 +289,7 @@ __device__ __forceinline__ void raster_quads(const RasterJob &job, uint32_t base
                 v2 = src[2];
                 v3 = src[3];
             }
-#if defined(TH_EXP_RASTER_NOLUT)
-            const uint32_t p0 = v0 * 0x10101u, p1 = v1 * 0x10101u, p2 = v2 * 0x10101u, p3 = v3 * 0x10101u;  // experiment
-#else
             const uint32_t p0 = look(v0), p1 = look(v1), p2 = look(v2), p3 = look(v3);
-#endif
             if (base_aligned) {
                 *reinterpret_cast<gptr<uint4>>(out + o) = make_uint4(p0, p1, p2, p3);
             } else {
@@ -360,11 +348,7 @@ __global__ __launch_bounds__(RASTER_THREADS) void raster_level0_kernel(const Ras
                                                             uint32_t n_chunks, const uint32_t *__restrict__ colormap,
                                                             uint32_t n_colors) {
     __shared__ uint32_t lut[1024];
-#if defined(TH_EXP_RASTER_GLOBAL_LUT)
-    const bool use_lds = false;  // experiment: gather the colours from the (L1-resident) global table
-#else
     const bool use_lds = n_colors <= 1024;
-#endif
     if (use_lds) {
         for (uint32_t i = threadIdx.x; i < n_colors; i += RASTER_THREADS) lut[i] = colormap[i];
         __syncthreads();
@@ -377,6 +361,34 @@ __global__ __launch_bounds__(RASTER_THREADS) void raster_level0_kernel(const Ras
         if (use_lds) raster_quads<true>(job, base, lut, as_global(colormap), n_colors);
         else raster_quads<false>(job, base, lut, as_global(colormap), n_colors);
     }
+}
+
+// One tile, job passed by value (the tile-request path of the TrackManager: no descriptor tables to upload)
+__global__ __launch_bounds__(RASTER_THREADS) void raster_tile_kernel(RasterJob job, const uint32_t *__restrict__ colormap,
+                                                                      uint32_t n_colors) {
+    __shared__ uint32_t lut[1024];
+    const bool use_lds = n_colors <= 1024;
+    if (use_lds) {
+        for (uint32_t i = threadIdx.x; i < n_colors; i += RASTER_THREADS) lut[i] = colormap[i];
+        __syncthreads();
+    }
+    const uint32_t base = blockIdx.x * RASTER_QUADS_PER_BLOCK;
+    if (use_lds) raster_quads<true>(job, base, lut, as_global(colormap), n_colors);
+    else raster_quads<false>(job, base, lut, as_global(colormap), n_colors);
+}
+
+hipError_t launch_raster_tile(const uint16_t *d_img, uint32_t img_width, uint32_t img_height, uint32_t img_pitch,
+                              uint32_t origin_x, uint32_t origin_y, uint32_t width, uint32_t height, uint8_t *d_rgba,
+                              const uint8_t *d_colormap, uint32_t n_colors, hipStream_t s) {
+    if (!width || !height) return hipSuccess;
+    const uint32_t qpr = (width + 3) / 4;
+    const uint32_t inv = qpr > 1 ? (uint32_t)((1ull << 32) / qpr) + 1u : 0u;
+    const uint32_t inv_w = width > 1 ? (uint32_t)((1ull << 32) / width) + 1u : 0u;
+    const uint32_t nb = (uint32_t)(((uint64_t)qpr * height + 1 + RASTER_QUADS_PER_BLOCK - 1) / RASTER_QUADS_PER_BLOCK);
+    const RasterJob job{d_img, d_rgba, img_width, img_height, origin_x, origin_y, width, height, img_pitch, qpr, inv, inv_w, 0u};
+    hipLaunchKernelGGL(raster_tile_kernel, dim3(nb), dim3(RASTER_THREADS), 0, s, job,
+                       reinterpret_cast<const uint32_t *>(d_colormap), n_colors);
+    return hipGetLastError();
 }
 
 hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block_job, uint32_t n_jobs,
@@ -407,7 +419,8 @@ __device__ __forceinline__ uint16_t lod_round(double acc, double wsum) {
 }
 
 __global__ __launch_bounds__(256) void lod_hpass_kernel(const uint16_t *__restrict__ img, uint32_t img_pitch,
-                                                        uint32_t y_lo, LodAxis ax, uint16_t *__restrict__ tmp) {
+                                                        uint32_t y_lo, LodAxis ax, uint16_t *__restrict__ tmp,
+                                                        uint32_t tmp_pitch) {
     const uint32_t ox = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
     if (ox >= ax.n_out) return;
     const gptr<const uint16_t> row = as_global(img) + (size_t)(y_lo + r) * img_pitch + ax.start[ox];
@@ -415,33 +428,35 @@ __global__ __launch_bounds__(256) void lod_hpass_kernel(const uint16_t *__restri
     const int32_t n = ax.count[ox];
     double acc = 0.0;
     for (int32_t t = 0; t < n; t++) acc += w[t] * (double)row[t];
-    as_global(tmp)[(size_t)r * ax.n_out + ox] = lod_round(acc, ax.wsum[ox]);
+    as_global(tmp)[(size_t)r * tmp_pitch + ox] = lod_round(acc, ax.wsum[ox]);
 }
 
-__global__ __launch_bounds__(256) void lod_vpass_kernel(const uint16_t *__restrict__ tmp, uint32_t y_lo, LodAxis ay,
-                                                        uint32_t dw, uint16_t *__restrict__ lod) {
+__global__ __launch_bounds__(256) void lod_vpass_kernel(const uint16_t *__restrict__ tmp, uint32_t tmp_pitch, uint32_t y_lo,
+                                                        LodAxis ay, uint32_t dw, uint16_t *__restrict__ lod,
+                                                        uint32_t lod_pitch) {
     const uint32_t ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
     if (ox >= dw) return;
-    const gptr<const uint16_t> col = as_global(tmp) + (size_t)(ay.start[oy] - (int32_t)y_lo) * dw + ox;
+    const gptr<const uint16_t> col = as_global(tmp) + (size_t)(ay.start[oy] - (int32_t)y_lo) * tmp_pitch + ox;
     const gptr<const double> w = as_global(ay.w) + (size_t)oy * ay.max_taps;
     const int32_t n = ay.count[oy];
     double acc = 0.0;
-    for (int32_t t = 0; t < n; t++) acc += w[t] * (double)col[(size_t)t * dw];
-    as_global(lod)[(size_t)oy * dw + ox] = lod_round(acc, ay.wsum[oy]);
+    for (int32_t t = 0; t < n; t++) acc += w[t] * (double)col[(size_t)t * tmp_pitch];
+    as_global(lod)[(size_t)oy * lod_pitch + ox] = lod_round(acc, ay.wsum[oy]);
 }
 
 hipError_t launch_lod_hpass(const uint16_t *d_img, uint32_t img_pitch, uint32_t y_lo, uint32_t n_rows, LodAxis ax,
-                            uint16_t *d_tmp, hipStream_t s) {
+                            uint16_t *d_tmp, uint32_t tmp_pitch, hipStream_t s) {
     if (!n_rows || !ax.n_out) return hipSuccess;
     hipLaunchKernelGGL(lod_hpass_kernel, dim3((ax.n_out + 255) / 256, n_rows), dim3(256), 0, s, d_img, img_pitch, y_lo, ax,
-                       d_tmp);
+                       d_tmp, tmp_pitch);
     return hipGetLastError();
 }
 
-hipError_t launch_lod_vpass(const uint16_t *d_tmp, uint32_t y_lo, LodAxis ay, uint32_t dw, uint16_t *d_lod,
-                            hipStream_t s) {
+hipError_t launch_lod_vpass(const uint16_t *d_tmp, uint32_t tmp_pitch, uint32_t y_lo, LodAxis ay, uint32_t dw,
+                            uint16_t *d_lod, uint32_t lod_pitch, hipStream_t s) {
     if (!ay.n_out || !dw) return hipSuccess;
-    hipLaunchKernelGGL(lod_vpass_kernel, dim3((dw + 255) / 256, ay.n_out), dim3(256), 0, s, d_tmp, y_lo, ay, dw, d_lod);
+    hipLaunchKernelGGL(lod_vpass_kernel, dim3((dw + 255) / 256, ay.n_out), dim3(256), 0, s, d_tmp, tmp_pitch, y_lo, ay, dw,
+                       d_lod, lod_pitch);
     return hipGetLastError();
 }
 

@@ -12,9 +12,12 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
+#include <shared_mutex>
 #include <tuple>
 #include <vector>
 
@@ -28,15 +31,43 @@ using namespace th;
 
 namespace {
 
+// One level of a channel's LOD mip pyramid: the whole u16 image resized to ceil(W / 2^lx) x ceil(H / 2^ly) with the
+// separable Lanczos3 of resize_spectrogram_tile (render_tiles.rs:354-393).  A LOD tile is then a crop of it.
+struct MipLevel {
+    uint16_t *d = nullptr;
+    uint32_t w = 0, h = 0, pitch = 0;
+};
+
 struct Channel {
     float *d_wav = nullptr;
     size_t n = 0;
+    float *d_pyr = nullptr;      // resident waveform pyramid: every level's (min, max, mean) bins, th_waveform_pyramid_offset
+    uint32_t pyr_levels = 0;     // levels 0 .. pyr_levels - 1 (the last one has a single bin)
     float *d_spec = nullptr;
     size_t T = 0, H = 0, spec_pitch = 0;   // rows padded to 128 B (th_pitch_f32)
     uint16_t *d_img = nullptr;
     size_t img_h = 0, img_w = 0, img_pitch = 0;  // rows padded to 128 B (th_pitch_u16)
+    std::map<std::pair<uint32_t, uint32_t>, MipLevel> mips;  // (level_x, level_y) != (0, 0)
     float mn = INFINITY, mx = -INFINITY;  // find_min_max of this spec (simd.rs:14-36)
     bool has_spec = false;
+};
+
+// Tile requests (lib.rs:342-389) are served concurrently, as the reference's IPC readers are (RwLock::read, lib.rs:345,378;
+// thread-local Resizer, render_tiles.rs:366-368): each request borrows a reader slot — its own HIP stream, a device tile
+// buffer and a pinned host staging buffer — so that no request waits for another's kernel or copy.
+struct ReaderSlot {
+    hipStream_t stream = nullptr;
+    uint8_t *d_tile = nullptr;
+    uint8_t *h_tile = nullptr;  // pinned
+    bool busy = false;
+};
+constexpr size_t TILE_BYTES_MAX = 520 * 520 * 4;  // 512 core + 2 x 4 gutter (render_tiles.rs:15-16); >= 1024 * 12 waveform bins
+constexpr size_t MAX_READER_SLOTS = 16;
+
+// Lanczos tap table of one image axis at one LOD level, resident on the device (shared by every channel of that size)
+struct AxisTable {
+    void *d_blob = nullptr;
+    uint32_t n_out = 0, max_taps = 0;
 };
 
 struct Track {
@@ -64,7 +95,19 @@ struct th_tm {
     std::map<PlanKey, th_plan *> plans;  // SpectrogramAnalyzer caches, spectrogram.rs:101-105
     // RenderTileCache state that the tile encoders need — render_tiles.rs:68-96
     std::vector<uint8_t> colormap_rgba{0, 0, 0, 255, 255, 255, 255, 255};
+    uint8_t *d_colormap = nullptr;  // device copy of colormap_rgba (uploaded when it changes, not per tile request)
     th_tile_cache cache{th_tile_cache::DEFAULT_BUDGET};  // revisions + waveform-tile LRU, render_tiles.rs:51-230
+    // Writers (every mutator) take `rw` exclusively, tile readers share it — the reference's RwLock<TrackManager>.
+    // A mutator leaves the context stream idle before it releases the lock, so readers never see half-made images.
+    mutable std::shared_mutex rw;
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    std::vector<std::unique_ptr<ReaderSlot>> slots;
+    // 0: LOD > 0 tiles are crops of the pre-built mip pyramid (default); 1: resampled per request from the level-0 image
+    // (the reference's own flow; kept as the comparison path).  Levels the pyramid does not hold always use 1.
+    int lod_source = 0;
+    std::map<std::pair<uint32_t, uint32_t>, AxisTable> axis_tabs;  // (source length, level) -> taps
+    uint64_t stat_tiles_served = 0;
 
     void invalidate_waveform() { cache.invalidate_waveform(); }
     void invalidate_spectrogram() { cache.invalidate_spectrogram(); }
@@ -81,26 +124,51 @@ struct th_tm {
 
 namespace {
 
+void free_mips(Channel &c) {
+    for (auto &kv : c.mips)
+        if (kv.second.d) (void)hipFree(kv.second.d);
+    c.mips.clear();
+}
+
 void free_channel(Channel &c) {
     if (c.d_wav) (void)hipFree(c.d_wav);
+    if (c.d_pyr) (void)hipFree(c.d_pyr);
     if (c.d_spec) (void)hipFree(c.d_spec);
     if (c.d_img) (void)hipFree(c.d_img);
+    free_mips(c);
     c = Channel();
 }
 
-int get_plan(th_tm *tm, uint32_t sr, th_plan **out) {
+struct Setting {
+    double win_ms;
+    uint32_t t_overlap, f_overlap;
+    int freq_scale;
+};
+Setting setting_of(const th_tm *tm) { return Setting{tm->win_ms, tm->t_overlap, tm->f_overlap, tm->freq_scale}; }
+
+PlanKey plan_key(const Setting &st, uint32_t sr) {
     size_t hop, win, n_fft;
-    calc_framing_params(tm->win_ms, tm->t_overlap, tm->f_overlap, sr, &hop, &win, &n_fft);
-    const PlanKey key{sr, win, hop, n_fft, tm->freq_scale};
+    calc_framing_params(st.win_ms, st.t_overlap, st.f_overlap, sr, &hop, &win, &n_fft);
+    return PlanKey{sr, win, hop, n_fft, st.freq_scale};
+}
+
+// the plan of (setting, sr): the cached one, or a new one recorded in `created` (the caller commits or destroys those)
+int get_plan(th_tm *tm, const Setting &st, uint32_t sr, std::map<PlanKey, th_plan *> &created, th_plan **out) {
+    const PlanKey key = plan_key(st, sr);
     auto it = tm->plans.find(key);
     if (it != tm->plans.end()) {
         *out = it->second;
         return TH_OK;
     }
+    auto ic = created.find(key);
+    if (ic != created.end()) {
+        *out = ic->second;
+        return TH_OK;
+    }
     th_plan *p = nullptr;
-    int rc = th_plan_create(tm->ctx, sr, win, hop, n_fft, tm->freq_scale, 0, &p);
+    int rc = th_plan_create(tm->ctx, sr, std::get<1>(key), std::get<2>(key), std::get<3>(key), st.freq_scale, 0, &p);
     if (rc != TH_OK) return rc;
-    tm->plans[key] = p;
+    created[key] = p;
     *out = p;
     return TH_OK;
 }
@@ -108,11 +176,8 @@ int get_plan(th_tm *tm, uint32_t sr, th_plan **out) {
 // SpectrogramAnalyzer::retain — spectrogram.rs:156-185: drop plans no resident track needs
 void retain_plans(th_tm *tm) {
     std::set<PlanKey> need;
-    for (auto &kv : tm->tracks) {
-        size_t hop, win, n_fft;
-        calc_framing_params(tm->win_ms, tm->t_overlap, tm->f_overlap, kv.second.sr, &hop, &win, &n_fft);
-        need.insert(PlanKey{kv.second.sr, win, hop, n_fft, tm->freq_scale});
-    }
+    const Setting st = setting_of(tm);
+    for (auto &kv : tm->tracks) need.insert(plan_key(st, kv.second.sr));
     for (auto it = tm->plans.begin(); it != tm->plans.end();) {
         if (!need.count(it->first)) {
             th_plan_destroy(it->second);
@@ -123,35 +188,46 @@ void retain_plans(th_tm *tm) {
     }
 }
 
-// TrackManager::update_specs — core/mod.rs:137-164: one batched launch per plan
-int update_specs(th_tm *tm, const std::vector<size_t> &ids) {
+// A freshly computed spec of one channel, not yet attached to it
+struct NewSpec {
+    Channel *ch = nullptr;
+    float *d_spec = nullptr;
+    size_t T = 0, H = 0, pitch = 0;
+    float mn = INFINITY, mx = -INFINITY;
+};
+void free_new_specs(std::vector<NewSpec> &v) {
+    for (NewSpec &n : v)
+        if (n.d_spec) (void)hipFree(n.d_spec);
+    v.clear();
+}
+
+// TrackManager::update_specs — core/mod.rs:137-164: one batched launch per plan, INTO FRESH BUFFERS.  Nothing the
+// manager owns is touched: the caller attaches the results (commit_specs) once every launch has succeeded, so a
+// failure (unsupported n_fft, out of memory) leaves settings, specs and has_spec exactly as they were.
+int compute_specs(th_tm *tm, const Setting &st, const std::vector<std::pair<uint32_t, Channel *>> &chans,
+                  std::map<PlanKey, th_plan *> &created, std::vector<NewSpec> *out) {
     th_ctx *c = tm->ctx;
     std::map<th_plan *, std::vector<Channel *>> groups;
-    for (size_t id : ids) {
-        auto it = tm->tracks.find(id);
-        if (it == tm->tracks.end()) continue;
+    for (auto &sc : chans) {
         th_plan *p = nullptr;
-        int rc = get_plan(tm, it->second.sr, &p);
+        int rc = get_plan(tm, st, sc.first, created, &p);
         if (rc != TH_OK) return rc;
-        for (Channel &ch : it->second.ch) groups[p].push_back(&ch);
+        groups[p].push_back(sc.second);
     }
     for (auto &kv : groups) {
         th_plan *p = kv.first;
         std::vector<Channel *> &chs = kv.second;
         std::vector<th_chan_desc> descs(chs.size());
+        const size_t first = out->size();
         for (size_t i = 0; i < chs.size(); i++) {
-            Channel &ch = *chs[i];
-            const size_t T = stft_n_frames(ch.n, p->g.win, p->g.hop), H = p->g.height;
-            if (ch.d_spec && (ch.T != T || ch.H != H)) {
-                TH_HIP(hipFree(ch.d_spec));
-                ch.d_spec = nullptr;
-            }
-            const size_t pitch = th_pitch_f32(H);
-            if (!ch.d_spec) TH_HIP(hipMalloc((void **)&ch.d_spec, std::max<size_t>(1, T * pitch) * sizeof(float)));
-            ch.T = T;
-            ch.H = H;
-            ch.spec_pitch = pitch;
-            descs[i] = th_chan_desc{ch.d_wav, ch.d_spec, ch.n, T, pitch};
+            NewSpec ns;
+            ns.ch = chs[i];
+            ns.T = stft_n_frames(chs[i]->n, p->g.win, p->g.hop);
+            ns.H = p->g.height;
+            ns.pitch = th_pitch_f32(ns.H);
+            out->push_back(ns);  // (recorded before the allocation: the caller frees whatever is in *out)
+            TH_HIP(hipMalloc((void **)&out->back().d_spec, std::max<size_t>(1, ns.T * ns.pitch) * sizeof(float)));
+            descs[i] = th_chan_desc{chs[i]->d_wav, out->back().d_spec, chs[i]->n, ns.T, ns.pitch};
         }
         float *d_mm = nullptr;
         TH_HIP(hipMalloc((void **)&d_mm, 2 * chs.size() * sizeof(float)));
@@ -166,9 +242,109 @@ int update_specs(th_tm *tm, const std::vector<size_t> &ids) {
         if (rc != TH_OK) return rc;
         TH_HIP(e);
         for (size_t i = 0; i < chs.size(); i++) {
-            chs[i]->mn = mm[2 * i];
-            chs[i]->mx = mm[2 * i + 1];
-            chs[i]->has_spec = true;
+            (*out)[first + i].mn = mm[2 * i];
+            (*out)[first + i].mx = mm[2 * i + 1];
+        }
+    }
+    return TH_OK;
+}
+
+void commit_specs(std::vector<NewSpec> &v) {
+    for (NewSpec &n : v) {
+        Channel &ch = *n.ch;
+        if (ch.d_spec) (void)hipFree(ch.d_spec);
+        ch.d_spec = n.d_spec;
+        ch.T = n.T;
+        ch.H = n.H;
+        ch.spec_pitch = n.pitch;
+        ch.mn = n.mn;
+        ch.mx = n.mx;
+        ch.has_spec = true;
+        n.d_spec = nullptr;
+    }
+    v.clear();
+}
+
+// ---------------------------------------------------------------------------------------------- LOD mip pyramid
+constexpr uint32_t MIP_MAX_LX = 12, MIP_MAX_LY = 6, MIP_MIN_DIM = 16;
+
+int axis_table(th_tm *tm, uint32_t n_in, uint32_t level, AxisTable **out) {
+    const auto key = std::make_pair(n_in, level);
+    auto it = tm->axis_tabs.find(key);
+    if (it == tm->axis_tabs.end()) {
+        const size_t n_out = (n_in + ((size_t)1 << level) - 1) >> level;
+        LodAxisHost ax;
+        // the whole axis as the crop box: origin 0, extent n_in (resize_spectrogram_tile with the full image as the crop)
+        build_lod_axis(0.0, (double)n_in, n_out, 0, (long)n_in, ax);
+        std::vector<unsigned char> blob(ax.blob_bytes(n_out));
+        ax.pack(blob.data(), n_out);
+        AxisTable t;
+        TH_HIP(hipMalloc(&t.d_blob, blob.size()));
+        hipError_t e = hipMemcpyAsync(t.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, tm->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(tm->ctx->stream);  // blob is a local
+        if (e != hipSuccess) {
+            (void)hipFree(t.d_blob);
+            TH_HIP(e);
+        }
+        t.n_out = (uint32_t)n_out;
+        t.max_taps = ax.max_taps;
+        it = tm->axis_tabs.emplace(key, t).first;
+    }
+    *out = &it->second;
+    return TH_OK;
+}
+
+LodAxis axis_view(const AxisTable &t) {
+    unsigned char *base = static_cast<unsigned char *>(t.d_blob);
+    LodAxis a;
+    a.start = reinterpret_cast<const int32_t *>(base);
+    a.count = reinterpret_cast<const int32_t *>(base + (size_t)t.n_out * 4);
+    a.wsum = reinterpret_cast<const double *>(base + (size_t)t.n_out * 8);
+    a.w = reinterpret_cast<const double *>(base + (size_t)t.n_out * 16);
+    a.n_out = t.n_out;
+    a.max_taps = t.max_taps;
+    return a;
+}
+
+// Build every (lx, ly) level of one channel's image: horizontal pass from level 0 for each lx, vertical pass from
+// (lx, 0) for each ly — the same order and the same one-rounding-per-pass as the per-request resize.
+int build_mips(th_tm *tm, Channel &ch) {
+    free_mips(ch);
+    if (!ch.d_img || !ch.img_w || !ch.img_h) return TH_OK;
+    hipStream_t s = tm->ctx->stream;
+    const uint32_t W = (uint32_t)ch.img_w, Hh = (uint32_t)ch.img_h;
+    uint32_t Lx = 0, Ly = 0;
+    while (Lx < MIP_MAX_LX && ((W + (2u << Lx) - 1) >> (Lx + 1)) >= MIP_MIN_DIM) Lx++;
+    while (Ly < MIP_MAX_LY && ((Hh + (2u << Ly) - 1) >> (Ly + 1)) >= MIP_MIN_DIM) Ly++;
+    for (uint32_t lx = 0; lx <= Lx; lx++) {
+        const uint16_t *src = ch.d_img;
+        uint32_t src_w = W, src_pitch = (uint32_t)ch.img_pitch;
+        if (lx > 0) {
+            AxisTable *tx = nullptr;
+            int rc = axis_table(tm, W, lx, &tx);
+            if (rc != TH_OK) return rc;
+            MipLevel m;
+            m.w = tx->n_out;
+            m.h = Hh;
+            m.pitch = (uint32_t)th_pitch_u16(m.w);
+            TH_HIP(hipMalloc((void **)&m.d, (size_t)m.h * m.pitch * sizeof(uint16_t)));
+            ch.mips[{lx, 0u}] = m;
+            TH_HIP(launch_lod_hpass(ch.d_img, (uint32_t)ch.img_pitch, 0, Hh, axis_view(*tx), m.d, m.pitch, s));
+            src = m.d;
+            src_w = m.w;
+            src_pitch = m.pitch;
+        }
+        for (uint32_t ly = 1; ly <= Ly; ly++) {
+            AxisTable *ty = nullptr;
+            int rc = axis_table(tm, Hh, ly, &ty);
+            if (rc != TH_OK) return rc;
+            MipLevel m;
+            m.w = src_w;
+            m.h = ty->n_out;
+            m.pitch = (uint32_t)th_pitch_u16(m.w);
+            TH_HIP(hipMalloc((void **)&m.d, (size_t)m.h * m.pitch * sizeof(uint16_t)));
+            ch.mips[{lx, ly}] = m;
+            TH_HIP(launch_lod_vpass(src, src_pitch, 0, axis_view(*ty), src_w, m.d, m.pitch, s));
         }
     }
     return TH_OK;
@@ -220,8 +396,10 @@ int update_spec_imgs(th_tm *tm, bool force_update_all, std::vector<size_t> *upda
                     TH_HIP(hipFree(ch.d_img));
                     ch.d_img = nullptr;
                     ch.img_h = ch.img_w = 0;
+                    free_mips(ch);
                 }
     std::vector<th_img_desc> descs;
+    std::vector<Channel *> made;
     for (size_t id : ids) {
         auto it = tm->tracks.find(id);
         if (it == tm->tracks.end()) continue;  // filter over specs: ids without a spec are skipped
@@ -240,15 +418,79 @@ int update_spec_imgs(th_tm *tm, bool force_update_all, std::vector<size_t> *upda
             ch.img_w = w;
             ch.img_pitch = ipitch;
             descs.push_back(th_img_desc{ch.d_spec, ch.d_img, ch.T, ch.H, i0, i1, ch.spec_pitch, ipitch});
+            made.push_back(&ch);
         }
     }
-    return th_spec_to_img_batch_dev(tm->ctx, descs.data(), descs.size(), tm->min_dB, tm->max_dB, tm->colormap_length);
+    int rc = th_spec_to_img_batch_dev(tm->ctx, descs.data(), descs.size(), tm->min_dB, tm->max_dB, tm->colormap_length);
+    if (rc != TH_OK) return rc;
+    // the LOD mip pyramid of every image that was just re-made (render_tiles.rs:290-313,354-393)
+    for (Channel *ch : made) {
+        rc = build_mips(tm, *ch);
+        if (rc != TH_OK) return rc;
+    }
+    return TH_OK;
 }
 
 Channel *find_channel(th_tm *tm, size_t id, uint32_t ch) {
     auto it = tm->tracks.find(id);
     if (it == tm->tracks.end() || ch >= it->second.ch.size()) return nullptr;
     return &it->second.ch[ch];
+}
+
+// ---------------------------------------------------------------------------------------------- reader slots
+struct SlotLease {
+    th_tm *tm;
+    ReaderSlot *slot;
+    ~SlotLease() {
+        if (slot) {
+            {
+                std::lock_guard<std::mutex> lk(tm->slot_mu);
+                slot->busy = false;
+            }
+            tm->slot_cv.notify_one();
+        }
+    }
+};
+
+int acquire_slot(th_tm *tm, ReaderSlot **out) {
+    std::unique_lock<std::mutex> lk(tm->slot_mu);
+    for (;;) {
+        for (auto &sp : tm->slots)
+            if (!sp->busy) {
+                sp->busy = true;
+                *out = sp.get();
+                return TH_OK;
+            }
+        if (tm->slots.size() < MAX_READER_SLOTS) {
+            std::unique_ptr<ReaderSlot> sl(new ReaderSlot());
+            hipError_t e = hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipMalloc((void **)&sl->d_tile, TILE_BYTES_MAX);
+            if (e == hipSuccess) e = hipHostMalloc((void **)&sl->h_tile, TILE_BYTES_MAX, hipHostMallocDefault);
+            if (e != hipSuccess) {
+                if (sl->h_tile) (void)hipHostFree(sl->h_tile);
+                if (sl->d_tile) (void)hipFree(sl->d_tile);
+                if (sl->stream) (void)hipStreamDestroy(sl->stream);
+                if (tm->slots.empty()) TH_HIP(e);
+                // out of resources with slots in use: wait for one of those instead
+            } else {
+                sl->busy = true;
+                *out = sl.get();
+                tm->slots.push_back(std::move(sl));
+                return TH_OK;
+            }
+        }
+        tm->slot_cv.wait(lk);
+    }
+}
+
+void put_u32(uint8_t *p, uint32_t v) { std::memcpy(p, &v, 4); }  // little-endian host (x86-64)
+void put_u64(uint8_t *p, uint64_t v) { std::memcpy(p, &v, 8); }
+
+// a mutator's last act before it releases the write lock: readers use their own streams
+int writer_done(th_tm *tm, int rc) {
+    hipError_t e = hipStreamSynchronize(tm->ctx->stream);
+    if (rc == TH_OK && e != hipSuccess) TH_HIP(e);
+    return rc;
 }
 
 }  // namespace
@@ -268,26 +510,52 @@ TH_API int th_tm_destroy(th_tm *tm) {
     if (!tm) return TH_OK;
     (void)hipSetDevice(tm->ctx->device);
     (void)hipStreamSynchronize(tm->ctx->stream);
+    for (auto &sp : tm->slots) {
+        (void)hipStreamSynchronize(sp->stream);
+        (void)hipStreamDestroy(sp->stream);
+        (void)hipFree(sp->d_tile);
+        (void)hipHostFree(sp->h_tile);
+    }
     for (auto &kv : tm->tracks)
         for (Channel &ch : kv.second.ch) free_channel(ch);
     for (auto &kv : tm->plans) th_plan_destroy(kv.second);
+    for (auto &kv : tm->axis_tabs) (void)hipFree(kv.second.d_blob);
+    if (tm->d_colormap) (void)hipFree(tm->d_colormap);
     delete tm;
     return TH_OK;
     TH_CATCH
 }
 
+namespace {
+int upload_colormap(th_tm *tm) {
+    if (tm->d_colormap) {
+        TH_HIP(hipFree(tm->d_colormap));
+        tm->d_colormap = nullptr;
+    }
+    TH_HIP(hipMalloc((void **)&tm->d_colormap, tm->colormap_rgba.size()));
+    TH_HIP(hipMemcpyAsync(tm->d_colormap, tm->colormap_rgba.data(), tm->colormap_rgba.size(), hipMemcpyHostToDevice,
+                          tm->ctx->stream));
+    TH_HIP(hipStreamSynchronize(tm->ctx->stream));
+    return TH_OK;
+}
+}  // namespace
+
 TH_API int th_tm_set_colormap(th_tm *tm, const uint8_t *rgba, size_t bytes) {
     TH_TRY
     TH_REQUIRE(tm && rgba, "NULL argument");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    std::unique_lock<std::shared_mutex> wl(tm->rw);
     TH_HIP(hipSetDevice(tm->ctx->device));
     // RenderTileCache::set_colormap keeps the old map for malformed input — render_tiles.rs:80-85
-    if (bytes >= 4 && bytes % 4 == 0) tm->colormap_rgba.assign(rgba, rgba + bytes);
+    if (bytes >= 4 && bytes % 4 == 0) {
+        tm->colormap_rgba.assign(rgba, rgba + bytes);
+        int rc = upload_colormap(tm);
+        if (rc != TH_OK) return rc;
+    }
     tm->invalidate_spectrogram();
     // init: TM.set_colormap_length(len / 4) → update_spec_imgs(force) — lib.rs:61, core/mod.rs:128-131
     tm->colormap_length = (uint32_t)(bytes / 4);
     std::vector<size_t> upd;
-    return update_spec_imgs(tm, true, &upd);
+    return writer_done(tm, update_spec_imgs(tm, true, &upd));
     TH_CATCH
 }
 
@@ -296,21 +564,36 @@ TH_API int th_tm_set_setting(th_tm *tm, double win_ms, uint32_t t_overlap, uint3
     TH_REQUIRE(tm, "tm is NULL");
     TH_REQUIRE(win_ms > 0. && t_overlap >= 1 && f_overlap >= 1, "invalid SpecSetting (lib.rs:275-277)");
     TH_REQUIRE(freq_scale == TH_FREQ_LINEAR || freq_scale == TH_FREQ_MEL, "bad freq_scale");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    std::unique_lock<std::shared_mutex> wl(tm->rw);
     TH_HIP(hipSetDevice(tm->ctx->device));
+    // Transactional: plans and specs of the NEW setting are made first, into fresh buffers; the manager's own state
+    // changes only when all of it exists.  (The reference cannot fail here: realfft takes any even length.  This
+    // library's plans need n_fft = a power of two in [8, 16384]; e.g. f_overlap = 3 is refused and leaves everything
+    // as it was.)
+    const Setting st{win_ms, t_overlap, f_overlap, freq_scale};
+    std::vector<std::pair<uint32_t, Channel *>> chans;
+    for (auto &kv : tm->tracks)
+        for (Channel &ch : kv.second.ch) chans.push_back({kv.second.sr, &ch});
+    std::map<PlanKey, th_plan *> created;
+    std::vector<NewSpec> fresh;
+    int rc = compute_specs(tm, st, chans, created, &fresh);
+    if (rc != TH_OK) {
+        (void)hipStreamSynchronize(tm->ctx->stream);
+        free_new_specs(fresh);
+        for (auto &kv : created) th_plan_destroy(kv.second);
+        return rc;
+    }
     tm->win_ms = win_ms;
     tm->t_overlap = t_overlap;
     tm->f_overlap = f_overlap;
     tm->freq_scale = freq_scale;
+    for (auto &kv : created) tm->plans[kv.first] = kv.second;
+    commit_specs(fresh);
     retain_plans(tm);  // spec_analyzer.retain(...)  core/mod.rs:111-112
-    std::vector<size_t> ids;
-    for (auto &kv : tm->tracks) ids.push_back(kv.first);
-    int rc = update_specs(tm, ids);
-    if (rc != TH_OK) return rc;
     std::vector<size_t> upd;
     rc = update_spec_imgs(tm, true, &upd);
     tm->invalidate_spectrogram();  // lib.rs:284
-    return rc;
+    return writer_done(tm, rc);
     TH_CATCH
 }
 
@@ -318,13 +601,13 @@ TH_API int th_tm_set_dB_range(th_tm *tm, float dB_range) {
     TH_TRY
     TH_REQUIRE(tm, "tm is NULL");
     TH_REQUIRE(dB_range > 0.f, "dB_range must be > 0 (lib.rs:259)");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    std::unique_lock<std::shared_mutex> wl(tm->rw);
     TH_HIP(hipSetDevice(tm->ctx->device));
     tm->dB_range = dB_range;
     std::vector<size_t> upd;
     int rc = update_spec_imgs(tm, true, &upd);
     tm->invalidate_spectrogram();  // lib.rs:265
-    return rc;
+    return writer_done(tm, rc);
     TH_CATCH
 }
 
@@ -333,32 +616,81 @@ TH_API int th_tm_add_tracks(th_tm *tm, size_t n_tracks, const size_t *ids, const
     TH_TRY
     TH_REQUIRE(tm && ids && srs && n_channels && channels_flat && n_samples, "NULL argument");
     TH_REQUIRE(n_tracks >= 1, "no tracks (lib.rs:182)");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    {   // validate everything before anything is allocated
+        size_t flat = 0;
+        for (size_t t = 0; t < n_tracks; t++) {
+            TH_REQUIRE(srs[t] > 0 && n_channels[t] >= 1 && n_samples[t] >= 1, "track %zu: empty or invalid", ids[t]);
+            for (uint32_t k = 0; k < n_channels[t]; k++, flat++)
+                TH_REQUIRE(channels_flat[flat], "track %zu channel %u: NULL data", ids[t], k);
+        }
+    }
+    std::unique_lock<std::shared_mutex> wl(tm->rw);
     th_ctx *c = tm->ctx;
     TH_HIP(hipSetDevice(c->device));
+    // Transactional: the new tracks are staged (audio upload, waveform pyramid, spec) beside the resident ones and
+    // swapped in when everything has succeeded.  A failure frees the staging area and changes nothing.
+    std::map<size_t, Track> staged;
+    std::map<PlanKey, th_plan *> created;
+    std::vector<NewSpec> fresh;
+    auto abort_staging = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        free_new_specs(fresh);
+        for (auto &kv : staged)
+            for (Channel &ch : kv.second.ch) free_channel(ch);
+        for (auto &kv : created) th_plan_destroy(kv.second);
+    };
+    int rc = TH_OK;
+    hipError_t e = hipSuccess;
     size_t flat = 0;
     std::vector<size_t> added;
-    for (size_t t = 0; t < n_tracks; t++) {
-        TH_REQUIRE(srs[t] > 0 && n_channels[t] >= 1 && n_samples[t] >= 1, "track %zu: empty or invalid", ids[t]);
-        Track &tr = tm->tracks[ids[t]];  // re-adding an id replaces it (reload_tracks, core/mod.rs:73-82)
+    std::vector<th_pyramid_desc> pdescs;
+    for (size_t t = 0; t < n_tracks && e == hipSuccess; t++) {
+        Track &tr = staged[ids[t]];  // the same id twice in one call: the later one wins, as sequential adds would
         for (Channel &ch : tr.ch) free_channel(ch);
         tr.sr = srs[t];
         tr.ch.assign(n_channels[t], Channel());
-        for (uint32_t k = 0; k < n_channels[t]; k++, flat++) {
-            TH_REQUIRE(channels_flat[flat], "track %zu channel %u: NULL data", ids[t], k);
+        for (uint32_t k = 0; k < n_channels[t] && e == hipSuccess; k++, flat++) {
             Channel &ch = tr.ch[k];
             ch.n = n_samples[t];
-            TH_HIP(hipMalloc((void **)&ch.d_wav, ch.n * sizeof(float)));
-            TH_HIP(hipMemcpyAsync(ch.d_wav, channels_flat[flat], ch.n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            e = hipMalloc((void **)&ch.d_wav, ch.n * sizeof(float));
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(ch.d_wav, channels_flat[flat], ch.n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+            // resident waveform pyramid: levels up to the one whose single bin spans the channel (render_tiles.rs:232-259)
+            uint32_t lv = 1;
+            while (lv < PYR_MAX_LEVELS && ((uint64_t)1 << (lv - 1)) < ch.n) lv++;
+            ch.pyr_levels = lv;
+            if (e == hipSuccess) e = hipMalloc((void **)&ch.d_pyr, th_waveform_pyramid_offset(ch.n, lv) * sizeof(float));
         }
         added.push_back(ids[t]);
     }
-    TH_HIP(hipStreamSynchronize(c->stream));  // inputs are borrowed for this call only
-    int rc = update_specs(tm, added);
-    if (rc != TH_OK) return rc;
-    tm->no_spec_img_ids.insert(tm->no_spec_img_ids.end(), added.begin(), added.end());  // core/mod.rs:70
-    tm->invalidate_all();                                                                // lib.rs:192
-    return TH_OK;
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // inputs are borrowed for this call only
+    if (e != hipSuccess) {
+        abort_staging();
+        TH_HIP(e);
+    }
+    std::vector<std::pair<uint32_t, Channel *>> chans;
+    for (auto &kv : staged)
+        for (Channel &ch : kv.second.ch) {
+            chans.push_back({kv.second.sr, &ch});
+            pdescs.push_back(th_pyramid_desc{ch.d_wav, ch.d_pyr, ch.n, ch.pyr_levels, 0});
+        }
+    rc = th_waveform_pyramid_dev(c, pdescs.data(), pdescs.size());
+    if (rc == TH_OK) rc = compute_specs(tm, setting_of(tm), chans, created, &fresh);
+    if (rc != TH_OK) {
+        abort_staging();
+        return rc;
+    }
+    commit_specs(fresh);  // (into the staged channels)
+    for (auto &kv : created) tm->plans[kv.first] = kv.second;
+    for (auto &kv : staged) {
+        Track &dst = tm->tracks[kv.first];  // re-adding an id replaces it (reload_tracks, core/mod.rs:73-82)
+        for (Channel &ch : dst.ch) free_channel(ch);
+        dst = std::move(kv.second);
+    }
+    std::set<size_t> uniq(added.begin(), added.end());
+    tm->no_spec_img_ids.insert(tm->no_spec_img_ids.end(), uniq.begin(), uniq.end());  // core/mod.rs:70
+    tm->invalidate_all();                                                             // lib.rs:192
+    return writer_done(tm, TH_OK);
     TH_CATCH
 }
 
@@ -370,7 +702,7 @@ TH_API int th_tm_add_track(th_tm *tm, size_t id, uint32_t sr, uint32_t n_channel
 TH_API int th_tm_remove_track(th_tm *tm, size_t id) {
     TH_TRY
     TH_REQUIRE(tm, "tm is NULL");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    std::unique_lock<std::shared_mutex> wl(tm->rw);
     TH_HIP(hipSetDevice(tm->ctx->device));
     auto it = tm->tracks.find(id);
     if (it == tm->tracks.end()) return fail(TH_ERR_NOT_FOUND, "Track %zu does not exist", id);
@@ -387,10 +719,10 @@ TH_API int th_tm_apply_track_list_changes(th_tm *tm, size_t *updated_ids, size_t
                                           uint32_t *max_sr) {
     TH_TRY
     TH_REQUIRE(tm, "tm is NULL");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    std::unique_lock<std::shared_mutex> wl(tm->rw);
     TH_HIP(hipSetDevice(tm->ctx->device));
     std::vector<size_t> upd;
-    int rc = update_spec_imgs(tm, false, &upd);
+    int rc = writer_done(tm, update_spec_imgs(tm, false, &upd));
     if (rc != TH_OK) return rc;
     if (n_updated) *n_updated = upd.size();
     if (updated_ids)
@@ -404,6 +736,7 @@ TH_API int th_tm_apply_track_list_changes(th_tm *tm, size_t *updated_ids, size_t
 TH_API int th_tm_get_db_state(const th_tm *tm, float *min_dB, float *max_dB, uint32_t *max_sr) {
     TH_TRY
     TH_REQUIRE(tm, "tm is NULL");
+    std::shared_lock<std::shared_mutex> rl(tm->rw);
     if (min_dB) *min_dB = tm->min_dB;
     if (max_dB) *max_dB = tm->max_dB;
     if (max_sr) *max_sr = tm->max_sr;
@@ -414,6 +747,7 @@ TH_API int th_tm_get_db_state(const th_tm *tm, float *min_dB, float *max_dB, uin
 TH_API int th_tm_spec_shape(const th_tm *tm, size_t id, uint32_t ch, size_t *n_frames, size_t *height) {
     TH_TRY
     TH_REQUIRE(tm, "tm is NULL");
+    std::shared_lock<std::shared_mutex> rl(tm->rw);
     const Channel *c = find_channel(const_cast<th_tm *>(tm), id, ch);
     if (!c || !c->has_spec) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
     if (n_frames) *n_frames = c->T;
@@ -425,6 +759,7 @@ TH_API int th_tm_spec_shape(const th_tm *tm, size_t id, uint32_t ch, size_t *n_f
 TH_API int th_tm_img_shape(const th_tm *tm, size_t id, uint32_t ch, size_t *img_height, size_t *img_width) {
     TH_TRY
     TH_REQUIRE(tm, "tm is NULL");
+    std::shared_lock<std::shared_mutex> rl(tm->rw);
     const Channel *c = find_channel(const_cast<th_tm *>(tm), id, ch);
     if (!c || !c->d_img) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
     if (img_height) *img_height = c->img_h;
@@ -436,7 +771,7 @@ TH_API int th_tm_img_shape(const th_tm *tm, size_t id, uint32_t ch, size_t *img_
 TH_API int th_tm_copy_spec(th_tm *tm, size_t id, uint32_t ch, float *out, size_t cap) {
     TH_TRY
     TH_REQUIRE(tm && out, "NULL argument");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    std::unique_lock<std::shared_mutex> wl(tm->rw);  // uses the context stream: exclusive, like a mutator
     TH_HIP(hipSetDevice(tm->ctx->device));
     Channel *c = find_channel(tm, id, ch);
     if (!c || !c->has_spec) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
@@ -453,7 +788,7 @@ TH_API int th_tm_copy_spec(th_tm *tm, size_t id, uint32_t ch, float *out, size_t
 TH_API int th_tm_copy_img(th_tm *tm, size_t id, uint32_t ch, uint16_t *out, size_t cap) {
     TH_TRY
     TH_REQUIRE(tm && out, "NULL argument");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    std::unique_lock<std::shared_mutex> wl(tm->rw);
     TH_HIP(hipSetDevice(tm->ctx->device));
     Channel *c = find_channel(tm, id, ch);
     if (!c || !c->d_img) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
@@ -475,26 +810,93 @@ TH_API int th_tm_revisions(const th_tm *tm, uint64_t *waveform_revision, uint64_
     TH_CATCH
 }
 
-// get_spectrogram_tile — lib.rs:369-389 → RenderTileCache::spectrogram_tile (render_tiles.rs:171-188)
+TH_API int th_tm_set_lod_source(th_tm *tm, int per_request) {
+    TH_TRY
+    TH_REQUIRE(tm, "tm is NULL");
+    std::unique_lock<std::shared_mutex> wl(tm->rw);
+    tm->lod_source = per_request ? 1 : 0;
+    return TH_OK;
+    TH_CATCH
+}
+
+// get_spectrogram_tile — lib.rs:369-389 → RenderTileCache::spectrogram_tile (render_tiles.rs:171-188).
+// Level (0, 0): a crop of the u16 image; LOD > 0: a crop of the pre-built mip level — either way one
+// raster launch on the request's own stream, one copy into pinned memory, no table upload, no lock shared with other
+// requests.
 TH_API int th_tm_get_spectrogram_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t level_x, uint32_t level_y,
                                       uint32_t tile_x, uint32_t tile_y, uint8_t *out, size_t cap, size_t *out_len) {
     TH_TRY
     TH_REQUIRE(tm && out && out_len, "NULL argument");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    std::shared_lock<std::shared_mutex> rl(tm->rw);
     Channel *c = find_channel(tm, id, ch);
     if (!c || !c->d_img) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
-    return th_encode_spectrogram_tile_dev(tm->ctx, c->d_img, c->img_h, c->img_w, c->img_pitch, tm->colormap_rgba.data(),
-                                          tm->colormap_rgba.size(), tm->spectrogram_revision(), level_x, level_y,
-                                          tile_x, tile_y, out, cap, out_len);
+    const uint64_t revision = tm->spectrogram_revision();
+    const uint16_t *src = c->d_img;
+    uint32_t src_w = (uint32_t)c->img_w, src_h = (uint32_t)c->img_h, src_pitch = (uint32_t)c->img_pitch;
+    if (level_x != 0 || level_y != 0) {
+        auto im = c->mips.find({level_x, level_y});
+        if (tm->lod_source != 0 || im == c->mips.end()) {
+            // per-request resampling of the crop box from the level-0 image (the reference's own flow): the
+            // context-stream path, serialised by the context mutex
+            return th_encode_spectrogram_tile_dev(tm->ctx, c->d_img, c->img_h, c->img_w, c->img_pitch,
+                                                  tm->colormap_rgba.data(), tm->colormap_rgba.size(), revision, level_x,
+                                                  level_y, tile_x, tile_y, out, cap, out_len);
+        }
+        src = im->second.d;
+        src_w = im->second.w;
+        src_h = im->second.h;
+        src_pitch = im->second.pitch;
+    }
+    const TileGeom g = spectrogram_tile_geometry(c->img_w, c->img_h, level_x, level_y, tile_x, tile_y);
+    const size_t px_bytes = g.width * g.height * 4, need = 40 + px_bytes;
+    *out_len = need;
+    if (cap < need) return fail(TH_ERR_BUFFER_TOO_SMALL, "need %zu bytes", need);
+    put_u64(out, revision);
+    put_u32(out + 8, (uint32_t)g.width);
+    put_u32(out + 12, (uint32_t)g.height);
+    put_u32(out + 16, level_x);
+    put_u32(out + 20, level_y);
+    put_u32(out + 24, tile_x);
+    put_u32(out + 28, tile_y);
+    put_u32(out + 32, (uint32_t)g.origin_x);
+    put_u32(out + 36, (uint32_t)g.origin_y);
+    if (g.width == 0 || g.height == 0) return TH_OK;
+    if (g.lod_w != src_w || g.lod_h != src_h) return fail(TH_ERR_INTERNAL, "mip level (%u, %u) has the wrong shape", level_x, level_y);
+    if (px_bytes > TILE_BYTES_MAX) return fail(TH_ERR_INTERNAL, "tile larger than a reader slot");
+    if (!tm->d_colormap) {  // no th_tm_set_colormap yet: the default two-colour map
+        rl.unlock();
+        {
+            std::unique_lock<std::shared_mutex> wl(tm->rw);
+            TH_HIP(hipSetDevice(tm->ctx->device));
+            if (!tm->d_colormap) {
+                int rc = upload_colormap(tm);
+                if (rc != TH_OK) return rc;
+            }
+        }
+        return th_tm_get_spectrogram_tile(tm, id, ch, level_x, level_y, tile_x, tile_y, out, cap, out_len);
+    }
+    TH_HIP(hipSetDevice(tm->ctx->device));
+    SlotLease lease{tm, nullptr};
+    int rc = acquire_slot(tm, &lease.slot);
+    if (rc != TH_OK) return rc;
+    ReaderSlot &sl = *lease.slot;
+    TH_HIP(launch_raster_tile(src, src_w, src_h, src_pitch, (uint32_t)g.origin_x, (uint32_t)g.origin_y, (uint32_t)g.width,
+                              (uint32_t)g.height, sl.d_tile, tm->d_colormap, (uint32_t)(tm->colormap_rgba.size() / 4),
+                              sl.stream));
+    TH_HIP(hipMemcpyAsync(sl.h_tile, sl.d_tile, px_bytes, hipMemcpyDeviceToHost, sl.stream));
+    TH_HIP(hipStreamSynchronize(sl.stream));
+    std::memcpy(out + 40, sl.h_tile, px_bytes);
+    return TH_OK;
     TH_CATCH
 }
 
-// get_waveform_tile — lib.rs:342-367: cache lookup (:350-355), encode on a miss, store (:358-365)
+// get_waveform_tile — lib.rs:342-367: cache lookup (:350-355); on a miss the tile's bins are a contiguous piece of the
+// channel's resident pyramid level (built once at add_tracks from one pass over the audio): one copy, no kernel.
 TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t level, uint32_t tile_index,
                                    uint8_t *out, size_t cap, size_t *out_len) {
     TH_TRY
     TH_REQUIRE(tm && out && out_len, "NULL argument");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    std::shared_lock<std::shared_mutex> rl(tm->rw);
     Channel *c = find_channel(tm, id, ch);
     if (!c) return fail(TH_ERR_NOT_FOUND, "Track %zu does not exist", id);
     uint64_t revision = 0;
@@ -505,9 +907,33 @@ TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t l
         std::memcpy(out, cached.data(), cached.size());
         return TH_OK;
     }
-    const int rc = th_encode_waveform_tile_dev(tm->ctx, c->d_wav, c->n, revision, level, tile_index, out, cap, out_len);
-    if (rc == TH_OK) tm->cache.store(id, ch, revision, level, tile_index, out, *out_len);
-    return rc;
+    size_t start, bins, spb;
+    waveform_tile_geometry(c->n, level, tile_index, &start, &bins, &spb);
+    const size_t need = 24 + bins * 12;
+    *out_len = need;
+    if (cap < need) return fail(TH_ERR_BUFFER_TOO_SMALL, "need %zu bytes", need);
+    put_u64(out, revision);
+    put_u32(out + 8, (uint32_t)bins);
+    put_u32(out + 12, spb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)spb);
+    put_u32(out + 16, tile_index);
+    put_u32(out + 20, 0);
+    if (bins) {
+        if (!c->d_pyr || !c->pyr_levels) return fail(TH_ERR_INTERNAL, "channel %zu_%u has no waveform pyramid", id, ch);
+        // a level above the pyramid's last one still has exactly one bin, over the same samples
+        const uint32_t lv = level < c->pyr_levels ? level : c->pyr_levels - 1;
+        const size_t first_bin = lv == level ? (size_t)tile_index * 1024 : 0;
+        const float *d_src = c->d_pyr + th_waveform_pyramid_offset(c->n, lv) + 3 * first_bin;
+        TH_HIP(hipSetDevice(tm->ctx->device));
+        SlotLease lease{tm, nullptr};
+        int rc = acquire_slot(tm, &lease.slot);
+        if (rc != TH_OK) return rc;
+        ReaderSlot &sl = *lease.slot;
+        TH_HIP(hipMemcpyAsync(sl.h_tile, d_src, bins * 12, hipMemcpyDeviceToHost, sl.stream));
+        TH_HIP(hipStreamSynchronize(sl.stream));
+        std::memcpy(out + 24, sl.h_tile, bins * 12);
+    }
+    tm->cache.store(id, ch, revision, level, tile_index, out, need);
+    return TH_OK;
     TH_CATCH
 }
 
@@ -516,7 +942,7 @@ TH_API int th_tm_get_audio_render_metadata(th_tm *tm, size_t id, uint32_t ch, do
                                            th_render_metadata *out) {
     TH_TRY
     TH_REQUIRE(tm && out, "NULL argument");
-    std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);
+    std::shared_lock<std::shared_mutex> rl(tm->rw);
     auto it = tm->tracks.find(id);
     if (it == tm->tracks.end() || ch >= it->second.ch.size()) return fail(TH_ERR_NOT_FOUND, "Track %zu does not exist", id);
     const Channel &c = it->second.ch[ch];
@@ -539,6 +965,37 @@ TH_API int th_tm_tile_cache(th_tm *tm, th_tile_cache **out) {
     TH_TRY
     TH_REQUIRE(tm && out, "NULL argument");
     *out = &tm->cache;
+    return TH_OK;
+    TH_CATCH
+}
+
+// device pointer + shape of one level of a channel's LOD mip pyramid ((0, 0) = the image itself): parity tests
+TH_API int th_tm_mip_level(th_tm *tm, size_t id, uint32_t ch, uint32_t level_x, uint32_t level_y, uint16_t *out, size_t cap,
+                           size_t *width, size_t *height) {
+    TH_TRY
+    TH_REQUIRE(tm, "NULL argument");
+    std::unique_lock<std::shared_mutex> wl(tm->rw);
+    TH_HIP(hipSetDevice(tm->ctx->device));
+    Channel *c = find_channel(tm, id, ch);
+    if (!c || !c->d_img) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
+    const uint16_t *src = c->d_img;
+    size_t w = c->img_w, h = c->img_h, pitch = c->img_pitch;
+    if (level_x || level_y) {
+        auto im = c->mips.find({level_x, level_y});
+        if (im == c->mips.end()) return fail(TH_ERR_NOT_FOUND, "mip level (%u, %u) is not resident", level_x, level_y);
+        src = im->second.d;
+        w = im->second.w;
+        h = im->second.h;
+        pitch = im->second.pitch;
+    }
+    if (width) *width = w;
+    if (height) *height = h;
+    if (!out) return TH_OK;
+    if (cap < w * h) return fail(TH_ERR_BUFFER_TOO_SMALL, "need %zu pixels", w * h);
+    if (w && h)
+        TH_HIP(hipMemcpy2DAsync(out, w * sizeof(uint16_t), src, pitch * sizeof(uint16_t), w * sizeof(uint16_t), h,
+                                hipMemcpyDeviceToHost, tm->ctx->stream));
+    TH_HIP(hipStreamSynchronize(tm->ctx->stream));
     return TH_OK;
     TH_CATCH
 }
