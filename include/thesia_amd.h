@@ -237,7 +237,13 @@ typedef struct {
     uint16_t *img;     /* DEVICE */
     uint64_t n_frames, height, i_start, i_end;
     uint64_t spec_pitch; /* floats per spec row, 0 = dense (height) */
-    uint64_t img_pitch;  /* u16 per image row, 0 = dense (n_frames); multiples of 64 recommended (th_pitch_u16) */
+    uint64_t img_pitch;  /* u16 per image row, 0 = dense (n_frames); multiples of 64 recommended (th_pitch_u16).
+                          * NOTE: when img_pitch is a multiple of 64 and img_pitch - n_frames < 64 — i.e. exactly the
+                          * library's own padded pitch th_pitch_u16(n_frames) — the kernel owns the row padding and
+                          * writes zeros into columns [n_frames, img_pitch) (a whole 128-byte line per store instead of a
+                          * read-modify-write).  An image that is a sub-rectangle of a wider surface must therefore use a
+                          * pitch with at least 64 columns to the right of it, or a pitch that is not a multiple of 64;
+                          * with any such pitch nothing outside [0, n_frames) of a row is written. */
 } th_img_desc;
 /* batched form: one launch for many channels sharing (min_dB, max_dB, colormap_len) — core/mod.rs:204-227 */
 TH_API int th_spec_to_img_batch_dev(th_ctx *ctx, const th_img_desc *descs, size_t n, float min_dB, float max_dB,

@@ -75,7 +75,7 @@ extern "C" __attribute__((visibility("default"))) int emu_stft_wave(const float 
         tw[i] = {(float)std::cos(a), (float)std::sin(a)};
     }
     std::vector<float> wpad(n_fft, 0.0f);
-    for (uint32_t i = 0; i < win; i++) wpad[g.pad_left + i] = 0.5f * window[i];
+    for (uint32_t i = 0; i < win; i++) wpad[g.pad_left + i] = 0.5f * WAVE_PRESCALE * window[i];  // as api.hip builds the table
     for (uint32_t n = 0; n < g.nc; n++) wtab[n] = {wpad[2 * n], wpad[2 * n + 1]};
     for (uint32_t f = 0; f < n_frames; f++) {
         float *row = out + (size_t)f * g.n_freq;

@@ -279,6 +279,7 @@ TH_API int th_dev_free(th_ctx *c, void *dptr) {
     TH_TRY
     TH_REQUIRE(c, "ctx is NULL");
     if (dptr) {
+        TH_HIP(hipSetDevice(c->device));
         TH_HIP(hipStreamSynchronize(c->stream));
         TH_HIP(hipFree(dptr));
     }
@@ -289,6 +290,7 @@ TH_API int th_dev_upload(th_ctx *c, void *dst, const void *src, size_t bytes) {
     TH_TRY
     TH_REQUIRE(c && (bytes == 0 || (dst && src)), "NULL argument");
     if (bytes) {
+        TH_HIP(hipSetDevice(c->device));
         TH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
         TH_HIP(hipStreamSynchronize(c->stream));
     }
@@ -299,6 +301,7 @@ TH_API int th_dev_download(th_ctx *c, void *dst, const void *src, size_t bytes) 
     TH_TRY
     TH_REQUIRE(c && (bytes == 0 || (dst && src)), "NULL argument");
     if (bytes) {
+        TH_HIP(hipSetDevice(c->device));
         TH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
         TH_HIP(hipStreamSynchronize(c->stream));
     }
@@ -308,6 +311,7 @@ TH_API int th_dev_download(th_ctx *c, void *dst, const void *src, size_t bytes) 
 TH_API int th_timer_start(th_ctx *c) {
     TH_TRY
     TH_REQUIRE(c, "ctx is NULL");
+    TH_HIP(hipSetDevice(c->device));
     TH_HIP(hipEventRecord(c->ev0, c->stream));
     return TH_OK;
     TH_CATCH
@@ -315,6 +319,7 @@ TH_API int th_timer_start(th_ctx *c) {
 TH_API int th_timer_stop_ms(th_ctx *c, float *ms) {
     TH_TRY
     TH_REQUIRE(c && ms, "NULL argument");
+    TH_HIP(hipSetDevice(c->device));
     TH_HIP(hipEventRecord(c->ev1, c->stream));
     TH_HIP(hipEventSynchronize(c->ev1));
     TH_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -446,9 +451,11 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
     };
     {
         // wave-kernel window table: wtab[n] = 0.5 * (wpad[2n], wpad[2n+1]), wpad = zero-padded window
-        // (the 1/2 of the real-FFT split pass is folded in here; exact, a power of two)
+        // (the 1/2 of the real-FFT split pass and the kernel's 2^32 pre-scale (stft_wave.h: WAVE_PRESCALE, undone in the
+        // dB conversion) are folded in here; exact, powers of two)
+        const float half = 0.5f * th::WAVE_PRESCALE;
         std::vector<float> wpad(n_fft, 0.f);
-        for (size_t i = 0; i < win; i++) wpad[g.pad_left + i] = 0.5f * w[i];
+        for (size_t i = 0; i < win; i++) wpad[g.pad_left + i] = half * w[i];
         rc = up((void **)&p->d_wtab, wpad.data(), wpad.size() * sizeof(float));
         // grid-aligned modes of the wave kernel (kernels_stft.hip): the window at offset 0 instead of pad_left.
         // phased (hop 480): behind 48 zero pairs (read 0, 96, 64 or 32 samples lower);  dynamic (e.g. hop 441): behind 64
@@ -456,11 +463,11 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
         const int pm = th::stft_wave_phased_mode(g, 0);
         if (rc == TH_OK && pm == 1) {
             std::vector<float> w4(96 + n_fft, 0.f);
-            for (size_t i = 0; i < win; i++) w4[96 + i] = 0.5f * w[i];
+            for (size_t i = 0; i < win; i++) w4[96 + i] = half * w[i];
             rc = up((void **)&p->d_wtab_phased, w4.data(), w4.size() * sizeof(float));
         } else if (rc == TH_OK && pm == 2) {
             std::vector<float> t0(n_fft + 2, 0.f), w2(2 * (128 + n_fft), 0.f);
-            for (size_t i = 0; i < win; i++) t0[i] = 0.5f * w[i];
+            for (size_t i = 0; i < win; i++) t0[i] = half * w[i];
             for (size_t i = 0; i < n_fft; i++) {
                 w2[128 + i] = t0[i];                       // even table: pairs (t0[2n], t0[2n+1])
                 w2[128 + n_fft + 128 + i] = t0[i + 1];     // odd table:  pairs (t0[2n+1], t0[2n+2])
@@ -470,7 +477,7 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
     }
     if (rc == TH_OK) rc = up((void **)&p->d_window, w.data(), w.size() * sizeof(float));
     if (rc == TH_OK) {
-        const uint32_t zero[4] = {0, 0, 0, 0};  // [0] chunk queue, [1] finished workgroups: the wave kernel resets both itself
+        const uint32_t zero[4] = {0, 0, 0, 0};  // [0] chunk queue head (rewound by wave_post_kernel after every launch), [1..3] spare
         rc = up((void **)&p->d_queue_head, zero, sizeof zero);
     }
     if (rc == TH_OK) rc = up((void **)&p->d_tw, tw.data(), tw.size() * sizeof(cf32));
@@ -833,15 +840,20 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
             if (rc != TH_OK) return rc;
             n_post = (uint32_t)pj.size();
         }
+        // The chunk queue head is rewound by wave_post_kernel right behind the wave kernel.  Should anything between the
+        // two launches fail (the event record, the post launch itself), queue_dirty stays set and the next launch zeroes
+        // the head itself — a stale head would make it skip chunks and leave spectrogram rows unwritten without an error.
+        if (p->queue_dirty) TH_HIP(hipMemsetAsync(p->d_queue_head, 0, sizeof(uint32_t), c->stream));
+        p->queue_dirty = true;
         TH_HIP(launch_stft_wave(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                 (uint32_t)jobs.size(), (uint32_t)tiles, phased ? p->d_wtab_phased : p->d_wtab, p->d_tw, chunk_mm, p->d_queue_head,
                                 c->n_cu, waves, wo, c->stream));
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
-        // fold the per-chunk (min, max) pairs into the channel slots and rewind the chunk queue (nothing that can fail sits
-        // between the two launches: a queue left un-rewound would make the next launch skip chunks)
+        // fold the per-chunk (min, max) pairs into the channel slots and rewind the chunk queue
         range_done = d_range != nullptr && all_in_wave && n_post == 1 && n_chan == 1;
         TH_HIP(launch_wave_post((const th::WavePostJob *)p->post_jobs.dptr, n_post, chunk_mm, d_minmax, all_in_wave,
                                 p->d_queue_head, dB_range, range_done ? d_range : nullptr, c->stream));
+        p->queue_dirty = false;
         if (mel_mfma)
             TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
                                    (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_bt, p->d_mel_band,

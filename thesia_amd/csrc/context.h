@@ -71,7 +71,8 @@ struct th_plan {
     th::StftGeom g{};
     float *d_window = nullptr;
     th::cf32 *d_tw = nullptr;
-    uint32_t *d_queue_head = nullptr;  // wave kernel: chunk queue head (reset before every launch)
+    uint32_t *d_queue_head = nullptr;  // wave kernel: chunk queue head (rewound by wave_post_kernel after every launch)
+    bool queue_dirty = false;          // a wave launch went out whose rewind did not: the next launch zeroes the head first
     th::cf32 *d_wtab = nullptr;  // wave kernel: 0.5 * zero-padded window as (even, odd) pairs
     th::cf32 *d_wtab_phased = nullptr;  // phased mode: 48 zero pairs + the table with the window at offset 0 (NULL: not applicable)
     bool use_wave() const;

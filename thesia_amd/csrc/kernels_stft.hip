@@ -410,7 +410,7 @@ __device__ __forceinline__ void wave_frame(
         float *const slab_f = reinterpret_cast<float *>(slab);
         auto emit = [&](int32_t k, float p) {
             if constexpr (MELF) {
-                slab_f[k] = power_to_amp(p);  // the slab is free after the second exchange: amplitude row for mel_pieces
+                slab_f[k] = power_to_amp_scaled(p);  // the slab is free after the second exchange: amplitude row for mel_pieces
             } else if constexpr (AMP) {
                 row[k] = power_to_amp(p);
             } else {
@@ -439,7 +439,7 @@ __device__ __forceinline__ void wave_frame(
             const cf32 zm = W::read_mirror(lane, m, slab);  // mirror partner Z[Nc - k]
             const float pw = split_power(z[m], zm, stw[k]);
             if constexpr (MELF) {
-                pa[m] = power_to_amp(pw);
+                pa[m] = power_to_amp_scaled(pw);
             } else {
                 const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
                 row[k] = d;
@@ -451,7 +451,7 @@ __device__ __forceinline__ void wave_frame(
             const cf32 wn = {-1.0f, 0.0f};
             const float pw = split_power(z[0], z[0], wn);
             if constexpr (MELF) {
-                pa[P] = power_to_amp(pw);
+                pa[P] = power_to_amp_scaled(pw);
             } else if (lane == 0) {
                 const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
                 row[NC] = d;

@@ -43,6 +43,11 @@ TH_HD gptr<T> as_global(T *p) {
     return (gptr<T>)p;
 }
 
+// Exact power-of-two factor carried by the wave kernel's window table and by the generic kernel's magnitude: |X|^2
+// would otherwise underflow below |X| ~ 1e-19 where the reference's hypot (spectrogram.rs:200) is finite (stft_wave.h).
+constexpr float WAVE_PRESCALE = 4294967296.0f;          // 2^32
+constexpr float WAVE_PRESCALE_DB = 192.65919722494797f;  // 20 log10(2^32)
+
 TH_HD cf32 cadd(cf32 a, cf32 b) { return {a.re + b.re, a.im + b.im}; }
 TH_HD cf32 csub(cf32 a, cf32 b) { return {a.re - b.re, a.im - b.im}; }
 TH_HD cf32 cmul(cf32 a, cf32 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
@@ -176,9 +181,11 @@ TH_HD void split_pair(cf32 zk, cf32 zm, cf32 w, float &mag_k, float &mag_m) {
     const cf32 d = {0.5f * (zk.re - zm.re), 0.5f * (zk.im + zm.im)};
     const cf32 o = cmul_negi(d);
     const cf32 t = cmul(o, w);
+    // (scaled by 2^32 before squaring, exact: re^2 + im^2 must not underflow where the reference's hypot does not)
     const cf32 xk = cadd(e, t), xm = csub(e, t);
-    mag_k = __builtin_sqrtf(xk.re * xk.re + xk.im * xk.im);  // correctly rounded (no fast-math)
-    mag_m = __builtin_sqrtf(xm.re * xm.re + xm.im * xm.im);
+    const float kr = xk.re * WAVE_PRESCALE, ki = xk.im * WAVE_PRESCALE, mr = xm.re * WAVE_PRESCALE, mi = xm.im * WAVE_PRESCALE;
+    mag_k = __builtin_sqrtf(kr * kr + ki * ki) * (1.0f / WAVE_PRESCALE);  // correctly rounded (no fast-math)
+    mag_m = __builtin_sqrtf(mr * mr + mi * mi) * (1.0f / WAVE_PRESCALE);
 }
 
 // dB_from_amp_inplace_default for one element — decibel.rs:179-202 (amin = 0, ref = 1):

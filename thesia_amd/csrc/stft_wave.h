@@ -608,30 +608,45 @@ TH_HD void wave_window(uint32_t lane, cf32 (&z)[P], const cf32 (&x)[P], const cf
     }
 }
 
-// 10*log10(p) with p = |X|^2  ==  20*log10(|X|)  (decibel.rs:170-214 with amin = 0: p = +0 -> -inf)
+// The wave kernel takes dB from the POWER |X|^2 (one v_log_f32, no square root).  Squaring halves the exponent range:
+// with the plain window |X| < ~1e-19 would square to zero (-inf) where the reference's hypot -> log10
+// (spectrogram.rs:200, decibel.rs:186-194) is still finite.  The kernel's window table therefore carries an exact factor
+// 2^32 (host: WAVE_PRESCALE), every spectrum value is 2^32 too large, and the 20 log10(2^32) comes off in the same
+// multiply-add that converts log2 to dB: finite down to |X| ~ 2.5e-29, overflow only beyond |X| ~ 4e9 (samples are <= 1).
+// (WAVE_PRESCALE = 2^32 and WAVE_PRESCALE_DB = 20 log10(2^32) live in stft_core.h: the host builds the table with them)
+TH_HD float fma_rn(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a, b, c);
+#else
+    return __builtin_fmaf(a, b, c);
+#endif
+}
+// 10*log10(p / 2^64) with p = |2^32 X|^2  ==  20*log10(|X|)  (decibel.rs:170-214 with amin = 0: p = +0 -> -inf)
 TH_HD float power_to_dB(float p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return 3.01029995663981195f * __builtin_amdgcn_logf(p);  // v_log_f32 (log2), <= 1 ulp
+    return fma_rn(__builtin_amdgcn_logf(p), 3.01029995663981195f, -WAVE_PRESCALE_DB);  // v_log_f32 (log2), <= 1 ulp
 #else
-    return 3.01029995663981195f * __builtin_log2f(p);
+    return fma_rn(__builtin_log2f(p), 3.01029995663981195f, -WAVE_PRESCALE_DB);
 #endif
 }
 
-// |X| from |X|^2 for the mel path (the mel filterbank is applied to amplitudes, spectrogram.rs:200-207)
-TH_HD float power_to_amp(float p) {
+// 2^32 |X| from |2^32 X|^2 for the fused mel epilogue (the filterbank is linear: the factor comes off in amp_to_dB_fast)
+TH_HD float power_to_amp_scaled(float p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_sqrtf(p);  // v_sqrt_f32, <= 1 ulp
 #else
     return __builtin_sqrtf(p);
 #endif
 }
+// |X| itself: the amplitude rows of the matrix-core mel path (the mel filterbank is applied to amplitudes, spectrogram.rs:200-207)
+TH_HD float power_to_amp(float p) { return power_to_amp_scaled(p) * (1.0f / WAVE_PRESCALE); }
 
-// 20*log10(a) for an amplitude (the fused mel epilogue): a = +0 -> -inf like decibel.rs:189-193
+// 20*log10(a / 2^32) for a pre-scaled amplitude (the fused mel epilogue): a = +0 -> -inf like decibel.rs:189-193
 TH_HD float amp_to_dB_fast(float a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return 6.02059991327962390f * __builtin_amdgcn_logf(a);
+    return fma_rn(__builtin_amdgcn_logf(a), 6.02059991327962390f, -WAVE_PRESCALE_DB);
 #else
-    return 6.02059991327962390f * __builtin_log2f(a);
+    return fma_rn(__builtin_log2f(a), 6.02059991327962390f, -WAVE_PRESCALE_DB);
 #endif
 }
 
