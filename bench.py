@@ -45,7 +45,8 @@ def parse_args():
     ap.add_argument("--tracks-per-gpu", type=int, default=128)
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single-track", action="store_true")
+    ap.add_argument("--no-single-track", action="store_true", help="skip the extras (single track, other framings, tile latency, ...)")
+    ap.add_argument("--no-full-cfg5", action="store_true", help="skip the strong-scaling anchor (all 1024 tracks of config 5 on one GPU)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 wave")
     return ap.parse_args()
 
@@ -72,7 +73,7 @@ def synth_on_gpu(torch, dev, track_ids, sr: int, n: int):
 class Workload:
     """Device-resident batch + descriptor tables for one GPU."""
 
-    def __init__(self, torch, ta, ctx, dev, track_ids, sr, n, win, hop, n_fft, kernel, cmap_bytes):
+    def __init__(self, torch, ta, ctx, dev, track_ids, sr, n, win, hop, n_fft, kernel, cmap_bytes, base=None):
         self.torch, self.ta, self.ctx = torch, ta, ctx
         n_tracks = len(track_ids)
         self.n_tracks, self.n = n_tracks, n
@@ -80,7 +81,10 @@ class Workload:
         if kernel:
             self.plan.set_kernel(kernel)
         self.T, self.H = self.plan.n_frames(n), self.plan.height
-        self.wav = synth_on_gpu(torch, dev, track_ids, sr, n)
+        # base: another Workload whose audio is reused round-robin (the 1024-track strong-scaling extra: synthesising 1024
+        # tracks would take longer than the whole bench; every track still gets its own spec, image and tiles)
+        self.wav = synth_on_gpu(torch, dev, track_ids, sr, n) if base is None else base.wav
+        wav_of = (lambda i: self.wav[i]) if base is None else (lambda i: self.wav[i % base.n_tracks])
         # HBM layout: rows padded to 128 B (th_pitch_*); the dense reference layout is what copy-out returns
         self.sp, self.ip = ta.pitch_f32(self.H), ta.pitch_u16(self.T)
         self.spec = torch.empty((n_tracks, self.T, self.sp), dtype=torch.float32, device=dev)
@@ -109,7 +113,7 @@ class Workload:
         self.tile_slots = sum(-(-(g.width * g.height) // 64) * 64 for g in geoms)
         self.rgba = torch.empty((n_tracks, self.tile_slots, 4), dtype=torch.uint8, device=dev)
         self.chan = (ta.ChanDesc * n_tracks)(*[
-            ta.ChanDesc(self.wav[i].data_ptr(), self.spec[i].data_ptr(), n, self.T, self.sp) for i in range(n_tracks)])
+            ta.ChanDesc(wav_of(i).data_ptr(), self.spec[i].data_ptr(), n, self.T, self.sp) for i in range(n_tracks)])
         self.imgd = (ta.ImgDesc * n_tracks)(*[
             ta.ImgDesc(self.spec[i].data_ptr(), self.img[i].data_ptr(), self.T, self.H, 0, self.H, self.sp, self.ip)
             for i in range(n_tracks)])
@@ -200,6 +204,121 @@ def cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft, target_s=15.0):
             "sample": f"{n_tasks} tracks x {n_s / sr:.0f} s 48 kHz mono, n_fft={n_fft} hop={hop}, "
                       f"same step (STFT->dB->min/max->u16->level-0 RGBA), {wall:.1f} s wall; "
                       "CPU restatement of the reference algorithm (f32 radix-2 FFT), not rustfft"}
+
+
+def tm_end_to_end_and_latency(torch, ta, ctx, wl, sr, cmap_bytes, n_tracks=32):
+    """(1) PCIe-inclusive end to end through the C ABI's TrackManager mirror: host f32 tracks -> th_tm_add_tracks (upload,
+    waveform pyramid, STFT) -> th_tm_apply_track_list_changes (dB range, u16 images, LOD mip pyramid) -> every level-0 tile
+    of every track fetched to host memory.  (2) The tile-request latency path (lib.rs:342-389): per-request wall time of
+    th_tm_get_spectrogram_tile / th_tm_get_waveform_tile at 1 and 8 reader threads, next to the oracle's CPU time for the
+    same tiles."""
+    import ctypes as C
+    import threading
+
+    from oracle import oracle as orc
+    from thesia_amd import _ffi
+    lib = _ffi.lib
+    host = wl.wav[:n_tracks].cpu().numpy()
+    n = host.shape[1]
+    tm = ta.TrackManager(ctx)
+    tm.set_setting(2048 / 48, 4, 1, ta.LINEAR)
+    tm.set_colormap(cmap_bytes)
+    t0 = time.perf_counter()
+    tm.add_tracks([(i, sr, host[i][None]) for i in range(n_tracks)])
+    t1 = time.perf_counter()
+    tm.apply_track_list_changes()
+    t2 = time.perf_counter()
+    ih, iw = tm.img(0, 0).shape
+    tiles_xy = [(tx, ty) for tx in range(-(-iw // 512)) for ty in range(-(-ih // 512))]
+    buf = np.empty(ta.api.SPECTROGRAM_TILE_MAX_BYTES, np.uint8)
+    bp = buf.ctypes.data_as(_ffi.c_u8p)
+    ln = C.c_size_t()
+    t3 = time.perf_counter()
+    nbytes = 0
+    for i in range(n_tracks):
+        for tx, ty in tiles_xy:
+            _ffi.check(lib.th_tm_get_spectrogram_tile(tm.handle, i, 0, 0, 0, tx, ty, bp, buf.size, C.byref(ln)))
+            nbytes += ln.value
+    t4 = time.perf_counter()
+    frames = n_tracks * ta.stft_n_frames(n, 2048, 512)
+    e2e = {"workload": f"{n_tracks} tracks x {n / sr:.0f} s 48 kHz mono from pageable host memory, n_fft=2048 hop=512: th_tm_add_tracks "
+                       "-> th_tm_apply_track_list_changes -> every level-0 tile to host memory",
+           "frames": frames, "upload_pyramid_stft_ms": (t1 - t0) * 1e3, "range_quantise_mips_ms": (t2 - t1) * 1e3,
+           "all_level0_tiles_ms": (t4 - t3) * 1e3, "tile_bytes": nbytes,
+           "frames_per_s_compute_only": frames / (t2 - t0), "frames_per_s_with_tile_fetch": frames / ((t2 - t0) + (t4 - t3)),
+           "host_input_GBs": host.nbytes / (t1 - t0) / 1e9}
+
+    rng = np.random.default_rng(1)
+    n_wave_tiles = -(-n // 1024)
+
+    def requests(kind, count):
+        out = []
+        for _ in range(count):
+            i = int(rng.integers(0, n_tracks))
+            if kind == "spec_level0":
+                tx, ty = tiles_xy[int(rng.integers(0, len(tiles_xy)))]
+                out.append(("s", i, 0, 0, tx, ty))
+            elif kind == "spec_lod_1_0":
+                out.append(("s", i, 1, 0, int(rng.integers(0, -(-(-(-iw // 2)) // 512))), int(rng.integers(0, -(-ih // 512)))))
+            elif kind == "spec_lod_2_1":
+                out.append(("s", i, 2, 1, int(rng.integers(0, -(-(-(-iw // 4)) // 512))), int(rng.integers(0, -(-(-(-ih // 2)) // 512)))))
+            else:  # waveform tiles: a different tile every time (the LRU in front would otherwise answer)
+                lvl = int(rng.integers(0, 6))
+                out.append(("w", i, lvl, int(rng.integers(0, max(1, -(-n_wave_tiles // (1 << lvl)))))))
+        return out
+
+    def run(reqs, lat):
+        b = np.empty(ta.api.SPECTROGRAM_TILE_MAX_BYTES, np.uint8)
+        p = b.ctypes.data_as(_ffi.c_u8p)
+        m = C.c_size_t()
+        for r in reqs:
+            t = time.perf_counter()
+            if r[0] == "s":
+                rc = lib.th_tm_get_spectrogram_tile(tm.handle, r[1], 0, r[2], r[3], r[4], r[5], p, b.size, C.byref(m))
+            else:
+                rc = lib.th_tm_get_waveform_tile(tm.handle, r[1], 0, r[2], r[3], p, b.size, C.byref(m))
+            lat.append(time.perf_counter() - t)
+            if rc != 0:
+                raise RuntimeError(_ffi.lib.th_last_error())
+
+    def measure(kind, threads, per_thread=120):
+        cache = tm.tile_cache()
+        cache.set_budget(1)  # every waveform request misses the LRU: the latency of the path behind it
+        lats = [[] for _ in range(threads)]
+        run(requests(kind, 10), [])  # warm-up (reader slots, mip tables)
+        ths = [threading.Thread(target=run, args=(requests(kind, per_thread), lats[k])) for k in range(threads)]
+        t = time.perf_counter()
+        for th_ in ths:
+            th_.start()
+        for th_ in ths:
+            th_.join()
+        wall = time.perf_counter() - t
+        a = np.sort(np.concatenate([np.asarray(x) for x in lats])) * 1e6
+        return {"p50_us": float(a[len(a) // 2]), "p99_us": float(a[min(len(a) - 1, int(len(a) * 0.99))]),
+                "requests_per_s": len(a) / wall}
+
+    latency = {"what": "wall time per request at the C ABI (ctypes), pinned staging + one stream per request; "
+                       "LOD tiles are crops of the resident mip pyramid", "image": [int(ih), int(iw)]}
+    for kind in ("spec_level0", "spec_lod_1_0", "spec_lod_2_1", "waveform"):
+        latency[kind] = {"threads_1": measure(kind, 1), "threads_8": measure(kind, 8)}
+    tm.set_lod_source(per_request=True)
+    latency["spec_lod_1_0_per_request_resize"] = {"threads_1": measure("spec_lod_1_0", 1, 40)}
+    tm.set_lod_source(per_request=False)
+    # the oracle (CPU restatement, one core) on the same kinds of tile
+    img = tm.img(0, 0)
+    cpu = {}
+    for kind, args_ in (("spec_level0", (0, 0, 1, 0)), ("spec_lod_1_0", (1, 0, 0, 0)), ("spec_lod_2_1", (2, 1, 0, 0))):
+        t = time.perf_counter()
+        for _ in range(3):
+            orc.encode_spectrogram_tile(img, cmap_bytes, 1, *args_)
+        cpu[kind + "_us"] = (time.perf_counter() - t) / 3 * 1e6
+    t = time.perf_counter()
+    for k in range(20):
+        orc.encode_waveform_tile(host[0], 1, 3, k)
+    cpu["waveform_level3_us"] = (time.perf_counter() - t) / 20 * 1e6
+    latency["cpu_oracle_one_core"] = cpu
+    tm.close()
+    return e2e, latency
 
 
 def main():
@@ -299,28 +418,42 @@ def main():
                 "frac": (smp * 4 + wl.n_tracks * tot * 4) / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del pyr
 
-    # other framings of the same path on the same tracks (extras, not the metric): the mel spectrogram of BASELINE config
-    # 4's shape (n_fft 2048 / hop 512, 128 mels: filterbank fused into the FFT kernel) and the app's own default framing
-    # (40 ms window / 4 at 48 kHz = 1920 / 480 / 2048, linear: grid-aligned register reuse), STFT -> dB stage only
-    other = None
+    # The other BASELINE configs' STFT stages on this GPU, same definition as `roofline` (algorithmic bytes of SURVEY 8(d) /
+    # HIP-event duration): config 3 (64 stereo 48 kHz tracks = 128 channels, n_fft 4096 / hop 1024) and config 4 (32 tracks
+    # 44.1 kHz, n_fft 2048 / hop 512, 128 mels, filterbank fused into the FFT kernel); plus the app's own default framing
+    # (40 ms window / 4 at 48 kHz = 1920 / 480 / 2048, linear: grid-aligned register reuse).
+    other, roof_cfg = None, []
     if rank == 0 and not args.no_single_track:
         other = []
-        for label, (w_, h_, scale, n_mel) in (("mel-128, n_fft 2048 / hop 512", (2048, 512, ta.MEL, 128)),
-                                               ("linear, 1920 / 480 / 2048 (app default framing)", (1920, 480, ta.LINEAR, 0))):
+        wav44 = synth_on_gpu(torch, dev, list(range(2000, 2032)), 44100, int(round(args.seconds * 44100)))
+        cases = (("cfg3: 64 stereo 48 kHz tracks, n_fft 4096 / hop 1024, linear dB", wl.wav, 48000, (4096, 1024, 4096, ta.LINEAR, 0)),
+                 ("cfg4: 32 tracks 44.1 kHz, n_fft 2048 / hop 512, mel-128 dB", wav44, 44100, (2048, 512, 2048, ta.MEL, 128)),
+                 ("app default framing: 48 kHz, 1920 / 480 / 2048, linear dB", wl.wav, 48000, (1920, 480, 2048, ta.LINEAR, 0)))
+        for label, wav_, sr_, (w_, h_, nf_, scale, n_mel) in cases:
             try:
-                pl = ta.Plan(ctx, sr, w_, h_, 2048, scale, n_mel)
-                T_, H_ = pl.n_frames(n), pl.height
+                pl = ta.Plan(ctx, sr_, w_, h_, nf_, scale, n_mel)
+                n_ = wav_.shape[1]
+                T_, H_ = pl.n_frames(n_), pl.height
                 sp_ = ta.pitch_f32(H_)
-                spec_ = torch.empty((wl.n_tracks, T_, sp_), dtype=torch.float32, device=dev)
-                ch_ = (ta.ChanDesc * wl.n_tracks)(*[ta.ChanDesc(wl.wav[i].data_ptr(), spec_[i].data_ptr(), n, T_, sp_)
-                                                    for i in range(wl.n_tracks)])
-                ms_ = time_stage(lambda: pl.calc_spec_batch_dev(ch_, wl.minmax.data_ptr()))
-                other.append({"workload": f"{label}, {wl.n_tracks} tracks x {n} samples", "kernel": pl.kernel_name, "frames": wl.n_tracks * T_,
-                              "ms": ms_, "frames_per_s": wl.n_tracks * T_ / (ms_ * 1e-3)})
+                spec_ = torch.empty((wav_.shape[0], T_, sp_), dtype=torch.float32, device=dev)
+                mm_ = torch.empty((wav_.shape[0], 2), dtype=torch.float32, device=dev)
+                ch_ = (ta.ChanDesc * wav_.shape[0])(*[ta.ChanDesc(wav_[i].data_ptr(), spec_[i].data_ptr(), n_, T_, sp_)
+                                                      for i in range(wav_.shape[0])])
+                pl.time_kernel(True)
+                ms_ = time_stage(lambda: pl.calc_spec_batch_dev(ch_, mm_.data_ptr()), 20)
+                k_ms = float(np.mean(pl.kernel_ms_history()[-20:]))   # the dominant kernel launch alone
+                frames_ = wav_.shape[0] * T_
+                bpf = 4 * h_ + 4 * H_
+                e = {"workload": f"{label}; {wav_.shape[0]} channels x {n_} samples", "kernel": pl.kernel_name, "frames": frames_,
+                     "stage_ms": ms_, "avg_launch_ms": k_ms, "frames_per_s": frames_ / (ms_ * 1e-3), "bound": "hbm",
+                     "algorithmic_bytes_per_frame": bpf, "achieved": frames_ * bpf / (k_ms * 1e-3) / 1e9, "unit": "GB/s"}
+                e["frac"] = e["achieved"] / HBM_PEAK_GBS
+                (roof_cfg if label.startswith("cfg") else other).append(e)
                 pl.close()
                 del spec_
             except Exception as e:  # extras must not break the bench line
                 other.append({"workload": label, "error": str(e)[:200]})
+        del wav44
 
     single = None
     if rank == 0 and not args.no_single_track:
@@ -357,6 +490,57 @@ def main():
             single["hip_graph_error"] = str(e)[:200]
         del w1
 
+    # ---- the image-tile gather to the root (outside the timed step, reported separately): every rank's RGBA
+    # tile buffer, device to device, one point-to-point transfer per peer posted at once
+    gather = None
+    if dist is not None:
+        from thesia_amd import dist as tdist
+        barrier()
+        t0 = time.perf_counter()
+        got = tdist.gather_tensor_to_root(wl.rgba.view(-1), dist, root=0)
+        barrier()
+        g_dt = time.perf_counter() - t0
+        if rank == 0:
+            inbound = sum(int(t.numel()) for r, t in enumerate(got) if r != 0)
+            gather = {"what": "level-0 RGBA tiles of every track, device-resident send/recv to rank 0 (batch_isend_irecv)",
+                      "ms": g_dt * 1e3, "bytes_per_rank": int(wl.rgba.numel()), "inbound_bytes_root": inbound,
+                      "inbound_GBs": inbound / g_dt / 1e9 if inbound else None, "ranks": world}
+        del got
+
+    # ---- PCIe-inclusive end to end + the tile-request latency path, through the TrackManager (th_tm_*): host buffers in,
+    # tiles out.  Never `value` (inputs start in host memory here).
+    e2e = latency = None
+    if rank == 0 and not args.no_single_track:
+        try:
+            e2e, latency = tm_end_to_end_and_latency(torch, ta, ctx, wl, sr, cmap_bytes)
+        except Exception as e:  # extras must not break the bench line
+            e2e = {"error": str(e)[:300]}
+
+    # ---- strong-scaling anchor: ALL of BASELINE config 5 (1024 tracks x 30 s) resident on this one GPU, same step
+    full5 = None
+    if rank == 0 and world == 1 and not args.no_single_track and not args.no_full_cfg5 and args.tracks_per_gpu == 128:
+        try:
+            t_s = time.perf_counter()
+            del wl.rgba  # (rebuilt below at the larger size; the 128-track line above is complete)
+            w5 = Workload(torch, ta, ctx, dev, list(range(1024)), sr, n, win, hop, n_fft, args.kernel, cmap_bytes, base=wl)
+            for _ in range(2):
+                w5.step(None)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            reps5 = 5
+            for _ in range(reps5):
+                w5.step(None)
+            torch.cuda.synchronize(dev)
+            d5 = (time.perf_counter() - t1) / reps5
+            full5 = {"workload": "cfg5 complete on ONE GPU: 1024 tracks x 30 s 48 kHz mono, n_fft=2048 hop=512, same step "
+                                 "(tracks 128.. reuse the audio of tracks 0..127: eight spec / image / tile sets per waveform)",
+                     "frames": w5.frames, "ms_per_step": d5 * 1e3, "frames_per_s": w5.frames / d5,
+                     "resident_GB": (w5.spec.numel() * 4 + w5.img.numel() * 2 + w5.rgba.numel() + wl.wav.numel() * 4) / 1e9,
+                     "setup_s": time.perf_counter() - t_s}
+            del w5
+        except Exception as e:
+            full5 = {"error": str(e)[:300]}
+
     if rank == 0:
         total_frames = wl.frames * world
         bytes_per_frame = 4 * hop + 4 * wl.H            # read 4*hop + write 4*H
@@ -364,27 +548,33 @@ def main():
         # frames per channel, as one-frame chunks with a reflect-indexed fetch)
         interior = wl.frames
         ach = interior * bytes_per_frame / (stft_ms * 1e-3) / 1e9
-        traffic = None
+        # PMC-measured HBM bytes per launch cannot be collected inside this run (separate rocprofv3 --pmc passes): a static
+        # figure with its provenance, not a run value
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "stft_hbm_traffic.json")
-        if os.path.exists(tpath):  # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes)
+        if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("bytes_per_launch")
+                traffic_source = f"profiles/stft_hbm_traffic.json (static: {tj.get('method', 'rocprofv3 --pmc')}; {tj.get('date', '?')}, commit {tj.get('commit', '?')})"
             except Exception:
                 traffic = None
-        # a measured device-to-device copy on this box in the same run, beside the vendor peak
+        # a measured device-to-device copy on this box in the same run, beside the vendor peak — the
+        # library's own 16-byte-per-lane streaming kernel (th_dev_copy), 1 GiB each way
         copy_gbs = None
         try:
             a_ = torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB
             b_ = torch.empty_like(a_)
+            nb_ = a_.numel() * 4
             for _ in range(2):
-                b_.copy_(a_)
+                ctx.dev_copy(b_.data_ptr(), a_.data_ptr(), nb_)
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record()
             for _ in range(5):
-                b_.copy_(a_)
+                ctx.dev_copy(b_.data_ptr(), a_.data_ptr(), nb_)
             c1.record()
             torch.cuda.synchronize()
-            copy_gbs = 5 * 2 * a_.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            copy_gbs = 5 * 2 * nb_ / (c0.elapsed_time(c1) * 1e-3) / 1e9
             del a_, b_
         except Exception:
             copy_gbs = None
@@ -401,11 +591,12 @@ def main():
             "raster_mpixels_per_s": wl.pixels * world / 1e6 / (img_ms * 1e-3),
             "stft_kernel": wl.plan.kernel_name,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": wl.plan.kernel_name, "avg_launch_ms": stft_ms, "stage_ms_incl_init_and_boundary_frames": stft_stage_ms,
                          "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": interior,
                          "read_only_frac": interior * 4 * hop / (stft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": (ach / copy_gbs) if copy_gbs else None},
+                         "measured_copy_GBs": copy_gbs, "measured_copy_kernel": "th_dev_copy (16 B per lane, 1 GiB -> 1 GiB)",
+                         "frac_of_measured_copy": (ach / copy_gbs) if copy_gbs else None},
             # the two other kernels of the step, same definition (algorithmic bytes / HIP-event duration)
             "roofline_other": [
                 {"kernel": "spec_to_img_kernel", "bound": "hbm", "avg_launch_ms": quant_ms,
@@ -413,8 +604,16 @@ def main():
                  "frac": wl.pixels * 6 / (quant_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"},
                 {"kernel": "raster_level0_kernel", "bound": "hbm", "avg_launch_ms": rast_ms,
                  "algorithmic_bytes_per_pixel": 6, "achieved": wl.n_tracks * wl.tile_px * 6 / (rast_ms * 1e-3) / 1e9,
-                 "frac": wl.n_tracks * wl.tile_px * 6 / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}],
+                 "frac": wl.n_tracks * wl.tile_px * 6 / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}] + roof_cfg,
         }
+        if gather is not None:
+            out["tile_gather"] = gather
+        if e2e is not None:
+            out["end_to_end_pcie_inclusive"] = e2e
+        if latency is not None:
+            out["tile_latency"] = latency
+        if full5 is not None:
+            out["strong_scaling_anchor_cfg5_1gpu"] = full5
         if single is not None:
             out["single_track_cfg2"] = single
         if wave is not None:

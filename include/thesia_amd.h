@@ -147,6 +147,9 @@ TH_API int th_dev_free(th_ctx *ctx, void *dptr);
 TH_API int th_dev_upload(th_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 TH_API int th_dev_download(th_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 /* HIP-event timing on the context's stream (bench.py roofline leg) */
+/* stream-ordered device-to-device copy with the library's own 16-byte-per-lane streaming kernel (pointers and size
+ * multiples of 16): the copy-bandwidth yardstick bench.py reports beside the roofline fractions */
+TH_API int th_dev_copy(th_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 TH_API int th_timer_start(th_ctx *ctx);
 TH_API int th_timer_stop_ms(th_ctx *ctx, float *ms);
 

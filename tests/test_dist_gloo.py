@@ -51,7 +51,13 @@ def _worker(rank, world, port, q):
             img = orc.convert_spectrogram_to_img(specs[i], (0, specs[i].shape[1]), (lo, hi), 258)
             tiles.append(i.to_bytes(4, "little") + orc.encode_spectrogram_tile(img, cmap, 1, 0, 0, 0, 1))
         got = tdist.gather_bytes_to_root(tiles, dist, root=0)
-        q.put((rank, owner.tolist(), (lo, hi), got))
+        # the device-resident form (on GPUs: the RGBA buffers themselves; here CPU tensors over gloo): one tensor per rank
+        import torch
+        mine_t = torch.frombuffer(bytearray(b"".join(tiles)) or bytearray(1), dtype=torch.uint8)[: sum(map(len, tiles))]
+        got_t = tdist.gather_tensor_to_root(mine_t, dist, root=0)
+        if got_t is not None:
+            got_t = [t.numpy().tobytes() for t in got_t]
+        q.put((rank, owner.tolist(), (lo, hi), got, got_t))
     finally:
         dist.destroy_process_group()
 
@@ -82,6 +88,8 @@ def test_two_rank_pipeline_matches_single_process():
     assert owner == res[1][1] and set(owner) == {0, 1}
     assert res[0][2] == res[1][2] == (lo, hi)          # both ranks agree on the global dB range
     assert res[1][3] is None                           # only the root receives the gather
+    # the tensor gather delivers the same bytes, rank by rank
+    assert res[1][4] is None and res[0][4] == [b"".join(parts) for parts in res[0][3]]
     gathered = {}
     for r, parts in enumerate(res[0][3]):
         for b in parts:

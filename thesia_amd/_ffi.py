@@ -130,6 +130,7 @@ _SIGS = {
     "th_dev_free": [vp, vp],
     "th_dev_upload": [vp, vp, vp, C.c_size_t],
     "th_dev_download": [vp, vp, vp, C.c_size_t],
+    "th_dev_copy": [vp, vp, vp, C.c_size_t],
     "th_timer_start": [vp],
     "th_timer_stop_ms": [vp, c_f32p],
     "th_plan_create": [vp, C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.POINTER(vp)],

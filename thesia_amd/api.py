@@ -227,6 +227,10 @@ class Context:
         a = np.ascontiguousarray(a)
         return DeviceBuffer(self, max(a.nbytes, 1)).upload(a)
 
+    def dev_copy(self, dst_ptr: int, src_ptr: int, nbytes: int):
+        """Stream-ordered device copy with the library's 16-byte-per-lane streaming kernel (the bench's bandwidth yardstick)."""
+        check(lib.th_dev_copy(self.handle, dst_ptr, src_ptr, nbytes))
+
     def timer_start(self):
         check(lib.th_timer_start(self.handle))
 

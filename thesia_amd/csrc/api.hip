@@ -308,6 +308,16 @@ TH_API int th_dev_download(th_ctx *c, void *dst, const void *src, size_t bytes) 
     return TH_OK;
     TH_CATCH
 }
+TH_API int th_dev_copy(th_ctx *c, void *d_dst, const void *d_src, size_t bytes) {
+    TH_TRY
+    TH_REQUIRE(c && (bytes == 0 || (d_dst && d_src)), "NULL argument");
+    TH_REQUIRE(((reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(d_src) | bytes) & 15u) == 0,
+               "pointers and size must be multiples of 16 bytes");
+    TH_HIP(hipSetDevice(c->device));
+    TH_HIP(launch_copy_f4(d_src, d_dst, bytes, c->stream));
+    return TH_OK;
+    TH_CATCH
+}
 TH_API int th_timer_start(th_ctx *c) {
     TH_TRY
     TH_REQUIRE(c, "ctx is NULL");

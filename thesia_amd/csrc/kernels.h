@@ -122,6 +122,9 @@ hipError_t launch_raster_tile(const uint16_t *d_img, uint32_t img_width, uint32_
                               uint32_t origin_x, uint32_t origin_y, uint32_t width, uint32_t height, uint8_t *d_rgba,
                               const uint8_t *d_colormap, uint32_t n_colors, hipStream_t s);
 
+// streaming 16-byte-per-lane device copy of bytes / 16 * 16 bytes (the bandwidth yardstick of bench.py)
+hipError_t launch_copy_f4(const void *d_src, void *d_dst, uint64_t bytes, hipStream_t s);
+
 // ---- kernels_waveform.hip
 struct WaveJob {  // device-visible copy of th_wave_desc
     const float *wav;

@@ -460,4 +460,21 @@ hipError_t launch_lod_vpass(const uint16_t *d_tmp, uint32_t tmp_pitch, uint32_t 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Streaming device-to-device copy, one 16-byte load and store per thread, a block per 4 KiB: the yardstick bench.py
+// measures beside every roofline figure (what a pure read + write stream reaches on this box, this run; the shape
+// scripts/ubench/copy_rate.hip found fastest: 6.2 TB/s, a persistent grid-stride loop 4.9).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_f4_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) as_global(dst)[i] = as_global(src)[i];
+}
+hipError_t launch_copy_f4(const void *d_src, void *d_dst, uint64_t bytes, hipStream_t s) {
+    const uint64_t n = bytes / 16;
+    if (!n) return hipSuccess;
+    if ((n + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(copy_f4_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const uint4 *)d_src, (uint4 *)d_dst, n);
+    return hipGetLastError();
+}
+
 }  // namespace th

@@ -47,7 +47,8 @@ struct Channel {
     size_t T = 0, H = 0, spec_pitch = 0;   // rows padded to 128 B (th_pitch_f32)
     uint16_t *d_img = nullptr;
     size_t img_h = 0, img_w = 0, img_pitch = 0;  // rows padded to 128 B (th_pitch_u16)
-    std::map<std::pair<uint32_t, uint32_t>, MipLevel> mips;  // (level_x, level_y) != (0, 0)
+    std::map<std::pair<uint32_t, uint32_t>, MipLevel> mips;  // (level_x, level_y) != (0, 0): views into d_mips
+    uint16_t *d_mips = nullptr;                               // one allocation for every level
     float mn = INFINITY, mx = -INFINITY;  // find_min_max of this spec (simd.rs:14-36)
     bool has_spec = false;
 };
@@ -125,8 +126,8 @@ struct th_tm {
 namespace {
 
 void free_mips(Channel &c) {
-    for (auto &kv : c.mips)
-        if (kv.second.d) (void)hipFree(kv.second.d);
+    if (c.d_mips) (void)hipFree(c.d_mips);
+    c.d_mips = nullptr;
     c.mips.clear();
 }
 
@@ -266,7 +267,9 @@ void commit_specs(std::vector<NewSpec> &v) {
 }
 
 // ---------------------------------------------------------------------------------------------- LOD mip pyramid
-constexpr uint32_t MIP_MAX_LX = 12, MIP_MAX_LY = 6, MIP_MIN_DIM = 16;
+// (levels beyond these are resampled per request: the frontend's level = floor(log2(source pixels per screen pixel)),
+// AudioTrackViewport.tsx:91,406,439 — rows are hundreds of pixels high, so level_y rarely exceeds 2)
+constexpr uint32_t MIP_MAX_LX = 12, MIP_MAX_LY = 3, MIP_MIN_DIM = 16;
 
 int axis_table(th_tm *tm, uint32_t n_in, uint32_t level, AxisTable **out) {
     const auto key = std::make_pair(n_in, level);
@@ -316,6 +319,26 @@ int build_mips(th_tm *tm, Channel &ch) {
     uint32_t Lx = 0, Ly = 0;
     while (Lx < MIP_MAX_LX && ((W + (2u << Lx) - 1) >> (Lx + 1)) >= MIP_MIN_DIM) Lx++;
     while (Ly < MIP_MAX_LY && ((Hh + (2u << Ly) - 1) >> (Ly + 1)) >= MIP_MIN_DIM) Ly++;
+    // shapes first, then ONE allocation for all levels (a hipMalloc per level cost more than the resampling)
+    size_t total = 0;
+    for (uint32_t lx = 0; lx <= Lx; lx++)
+        for (uint32_t ly = 0; ly <= Ly; ly++) {
+            if (!lx && !ly) continue;
+            MipLevel m;
+            m.w = (W + (1u << lx) - 1) >> lx;
+            m.h = (Hh + (1u << ly) - 1) >> ly;
+            m.pitch = (uint32_t)th_pitch_u16(m.w);
+            m.d = reinterpret_cast<uint16_t *>(total);  // offset for now
+            total += ((size_t)m.h * m.pitch + 127) / 128 * 128;
+            ch.mips[{lx, ly}] = m;
+        }
+    if (!total) return TH_OK;
+    hipError_t e = hipMalloc((void **)&ch.d_mips, total * sizeof(uint16_t));
+    if (e != hipSuccess) {
+        ch.mips.clear();
+        TH_HIP(e);
+    }
+    for (auto &kv : ch.mips) kv.second.d = ch.d_mips + reinterpret_cast<size_t>(kv.second.d);
     for (uint32_t lx = 0; lx <= Lx; lx++) {
         const uint16_t *src = ch.d_img;
         uint32_t src_w = W, src_pitch = (uint32_t)ch.img_pitch;
@@ -323,12 +346,7 @@ int build_mips(th_tm *tm, Channel &ch) {
             AxisTable *tx = nullptr;
             int rc = axis_table(tm, W, lx, &tx);
             if (rc != TH_OK) return rc;
-            MipLevel m;
-            m.w = tx->n_out;
-            m.h = Hh;
-            m.pitch = (uint32_t)th_pitch_u16(m.w);
-            TH_HIP(hipMalloc((void **)&m.d, (size_t)m.h * m.pitch * sizeof(uint16_t)));
-            ch.mips[{lx, 0u}] = m;
+            const MipLevel &m = ch.mips[{lx, 0u}];
             TH_HIP(launch_lod_hpass(ch.d_img, (uint32_t)ch.img_pitch, 0, Hh, axis_view(*tx), m.d, m.pitch, s));
             src = m.d;
             src_w = m.w;
@@ -338,12 +356,7 @@ int build_mips(th_tm *tm, Channel &ch) {
             AxisTable *ty = nullptr;
             int rc = axis_table(tm, Hh, ly, &ty);
             if (rc != TH_OK) return rc;
-            MipLevel m;
-            m.w = src_w;
-            m.h = ty->n_out;
-            m.pitch = (uint32_t)th_pitch_u16(m.w);
-            TH_HIP(hipMalloc((void **)&m.d, (size_t)m.h * m.pitch * sizeof(uint16_t)));
-            ch.mips[{lx, ly}] = m;
+            const MipLevel &m = ch.mips[{lx, ly}];
             TH_HIP(launch_lod_vpass(src, src_pitch, 0, axis_view(*ty), src_w, m.d, m.pitch, s));
         }
     }

@@ -67,3 +67,36 @@ def gather_bytes_to_root(payloads: Sequence[bytes], dist, root: int = 0, group=N
             off += n
         out.append(parts)
     return out
+
+
+def gather_tensor_to_root(local, dist, root: int = 0, group=None):
+    """Device-resident form of the image-tile gather: every rank contributes ONE contiguous tensor that already lives
+    where the collective runs (on GPUs: the RGBA tile buffer th_raster_tiles_dev wrote, no host hop, no `bytes`); the root
+    gets a list of world tensors (its own entry is `local` itself), the others get None.  Sizes go first (one 1-element
+    all-gather), then one point-to-point transfer per peer, all posted at once (batch_isend_irecv): on xGMI the root's
+    seven inbound links run concurrently instead of a ring that would be bound by one link (core/mod.rs:169-180 is the
+    path's only coupling; this gather is the viewer-side collection of the results, outside the timed step)."""
+    import torch
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    flat = local.contiguous().view(-1)
+    n_local = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    if rank != root:
+        if flat.numel():
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, root, group)]):
+                req.wait()
+        return None
+    out, ops = [None] * world, []
+    for r in range(world):
+        n = int(counts[r].item())
+        if r == root:
+            out[r] = flat
+            continue
+        out[r] = torch.empty(n, dtype=flat.dtype, device=flat.device)
+        if n:
+            ops.append(dist.P2POp(dist.irecv, out[r], r, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
