@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../thesia_amd/csrc/stft_wave.h"
+#include "../../thesia_amd/csrc/stft_wave_multi.h"
 #include "../../thesia_amd/csrc/mel_fuse.h"
 
 using namespace th;
@@ -54,6 +55,100 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
         }
     const cf32 wn = {-1.0f, 0.0f};
     row[NC] = power_to_dB(split_power(z[0][0], z[0][0], wn));
+}
+
+// G frames of one wave of the multi-frame plan (stft_wave_multi.h): group g of the lanes computes frame frames[g]
+template <int LOG2_NC>
+static void emu_frames_multi(const float *wav, const uint32_t *frames, const StftGeom &g, const cf32 *wtab, const cf32 *tw,
+                             float *const *rows) {
+    using W = WaveFftM<LOG2_NC>;
+    constexpr int P = W::P, NC = W::NC;
+    std::vector<cf32> slab(W::SLAB_LEN);
+    static cf32 x[64][P], z[64][P];
+    std::vector<cf32> t2(W::T2_LEN), t3(W::T3_LEN + 1);
+    for (uint32_t t = 0; t < 256; t++) W::fill_tables(t, 256, tw, t2.data(), t3.data());
+    for (uint32_t l = 0; l < 64; l++) {
+        const int64_t e0 = (int64_t)frames[W::grp(l)] * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+        // slot m of a lane = complex point col + L m of its frame
+        for (int m = 0; m < P; m++) {
+            const uint32_t n = W::lane_col(l) + (uint32_t)W::L * m;
+            x[l][m] = {wav[e0 + 2 * n], wav[e0 + 2 * n + 1]};
+            const cf32 w = wtab[n];
+            z[l][m] = {x[l][m].re * w.re, x[l][m].im * w.im};
+        }
+    }
+    for (uint32_t l = 0; l < 64; l++) W::pass1(l, z[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++) W::read1(l, z[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++) {
+        cf32 w2[15];
+        W::load_t2(l, w2, t2.data());
+        W::pass2_twiddle(z[l], w2);
+    }
+    for (uint32_t l = 0; l < 64; l++) W::pass2_dft(l, z[l], slab.data());
+    static cf32 za[64][W::NQ][W::R3], zb[64][W::NQ][W::R3];
+    for (uint32_t l = 0; l < 64; l++) W::read2_paired(l, za[l], zb[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++) {
+        cf32 wa[W::NW3], wb[W::NW3];
+        W::load_t3_paired(l, wa, wb, t3.data());
+        W::pass3_paired_w(za[l], zb[l], wa, wb);
+    }
+    std::vector<int> hits((size_t)W::G * (NC + 1), 0);
+    for (uint32_t l = 0; l < 64; l++) {
+        cf32 ws[W::NQ][W::R3];
+        W::load_stw_paired(l, ws, tw);
+        const uint32_t gi = W::grp(l);
+        W::split_paired_w(l, za[l], zb[l], ws, tw[NC / 2], [&](int32_t k, float p) {
+            rows[gi][k] = power_to_dB(p);
+            hits[gi * (NC + 1) + k]++;
+        });
+    }
+    for (int gi = 0; gi < W::G; gi++)
+        for (int k = 0; k <= NC; k++)
+            if (hits[gi * (NC + 1) + k] != 1) rows[gi][k] = NAN;  // every bin exactly once per frame
+}
+
+// the multi-frame plan (n_fft = 512, 1024): out as emu_stft_wave
+extern "C" __attribute__((visibility("default"))) int emu_stft_wave_multi(const float *wav, uint32_t n_samples, uint32_t win,
+                                                                           uint32_t hop, uint32_t n_fft, const float *window,
+                                                                           uint32_t n_frames, float *out) {
+    if (n_fft != 512 && n_fft != 1024) return -1;
+    StftGeom g{};
+    g.hop = hop;
+    g.win = win;
+    g.n_fft = n_fft;
+    g.pad_left = (n_fft - win) / 2;
+    g.nc = n_fft / 2;
+    g.n_freq = n_fft / 2 + 1;
+    g.height = g.n_freq;
+    std::vector<cf32> tw(n_fft), wtab(g.nc);
+    for (uint32_t i = 0; i < n_fft; i++) {
+        const double a = -2.0 * M_PI * (double)i / (double)n_fft;
+        tw[i] = {(float)std::cos(a), (float)std::sin(a)};
+    }
+    std::vector<float> wpad(n_fft, 0.0f);
+    for (uint32_t i = 0; i < win; i++) wpad[g.pad_left + i] = 0.5f * WAVE_PRESCALE * window[i];
+    for (uint32_t n = 0; n < g.nc; n++) wtab[n] = {wpad[2 * n], wpad[2 * n + 1]};
+    std::vector<uint32_t> interior;
+    for (uint32_t f = 0; f < n_frames; f++) {
+        const int64_t e0 = (int64_t)f * hop - (int64_t)(win / 2) - (int64_t)g.pad_left;
+        if (e0 < 0 || e0 + (int64_t)n_fft > (int64_t)n_samples)
+            for (uint32_t k = 0; k < g.n_freq; k++) out[(size_t)f * g.n_freq + k] = NAN;
+        else interior.push_back(f);
+    }
+    const uint32_t G = 1024 / g.nc;
+    std::vector<float> scratch(g.n_freq);
+    for (size_t i = 0; i < interior.size(); i += G) {
+        uint32_t fr[4];
+        float *rows[4];
+        for (uint32_t k = 0; k < G; k++) {
+            const bool valid = i + k < interior.size();
+            fr[k] = interior[valid ? i + k : interior.size() - 1];  // the kernel clamps: a duplicate frame, computed again
+            rows[k] = valid ? out + (size_t)fr[k] * g.n_freq : scratch.data();
+        }
+        if (n_fft == 1024) emu_frames_multi<9>(wav, fr, g, wtab.data(), tw.data(), rows);
+        else emu_frames_multi<8>(wav, fr, g, wtab.data(), tw.data(), rows);
+    }
+    return 0;
 }
 
 // out: n_frames x (n_fft/2+1).  window: normalised window (len win).  Returns 0 on success.

@@ -20,6 +20,7 @@ def emu():
     lib = C.CDLL(os.path.join(HERE, "emu", "_build", "libemu_stft.so"))
     f32p = C.POINTER(C.c_float)
     lib.emu_stft_wave.argtypes = [f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p, C.c_uint32, f32p]
+    lib.emu_stft_wave_multi.argtypes = lib.emu_stft_wave.argtypes
     return lib
 
 
@@ -44,6 +45,28 @@ def test_emulated_wave_kernel_matches_oracle(emu, win, hop, n_fft, n):
         assert interior.sum() >= T - 6
     got_amp = np.power(10.0, out[interior].astype(np.float64) / 20.0)
     rel = (np.abs(got_amp - amp[interior]) / amp[interior].max(axis=1, keepdims=True)).max() if interior.any() else 0
+    assert rel <= 2e-6, rel
+
+
+@pytest.mark.parametrize("win,hop,n_fft,n", [(1024, 256, 1024, 5000), (1000, 250, 1024, 5003), (512, 128, 512, 3000),
+                                             (320, 80, 512, 2500), (480, 120, 512, 2600), (511, 300, 512, 4000)])
+def test_emulated_multi_frame_plan_matches_oracle(emu, win, hop, n_fft, n):
+    """stft_wave_multi.h: two (n_fft 1024) or four (n_fft 512) frames per wave, 16 points per lane, plane exchanges —
+    the lane functions run on the CPU against the oracle."""
+    x = synth_track(n_fft + win + 1, 48000, n)
+    w = orc.calc_normalized_win(win, n_fft)
+    T = orc.stft_n_frames(n, win, hop)
+    out = np.empty((T, n_fft // 2 + 1), np.float32)
+    f32p = C.POINTER(C.c_float)
+    rc = emu.emu_stft_wave_multi(x.ctypes.data_as(f32p), n, win, hop, n_fft, w.ctypes.data_as(f32p), T, out.ctypes.data_as(f32p))
+    assert rc == 0
+    want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+    interior = ~np.isnan(out[:, 0])
+    e0 = np.arange(T) * hop - win // 2 - (n_fft - win) // 2
+    assert np.array_equal(interior, (e0 >= 0) & (e0 + n_fft <= n)) and interior.sum() >= T - 8
+    assert not np.isnan(out[interior]).any()   # every bin of every interior frame emitted exactly once
+    got_amp = np.power(10.0, out[interior].astype(np.float64) / 20.0)
+    rel = (np.abs(got_amp - amp[interior]) / amp[interior].max(axis=1, keepdims=True)).max()
     assert rel <= 2e-6, rel
 
 

@@ -134,6 +134,31 @@ def test_tiny_and_huge_magnitudes(ctx, scale, win, hop, n_fft):
         assert mn == spec.min() and mx == spec.max()
 
 
+@pytest.mark.parametrize("win,hop,n_fft,which", [(512, 128, 512, 0), (320, 80, 512, 0), (500, 77, 512, 2), (512, 512, 512, 2),
+                                                 (1024, 256, 1024, 6), (1000, 250, 1024, 6), (1024, 100, 1024, 6)])
+def test_multi_frame_wave_kernel(ctx, win, hop, n_fft, which):
+    """stft_wave_multi.h: four frames per wave at n_fft 512 (the default there: the app's own framing at 8 kHz is 320 / 80 /
+    512), two at n_fft 1024 (selector 6) — against the oracle and against the generic kernel, on a ragged batch whose
+    channels end in every position of a group (chunk tails recompute the last frame) and include one shorter than n_fft."""
+    lens = [40000 + win, 40000 + win + hop, 40000 + win + 2 * hop + 1, 40000 + win + 3 * hop + 2, 3 * n_fft + 5, n_fft // 2 + 3]
+    wavs = [synth_track(200 + i, 48000, n) for i, n in enumerate(lens)]
+    plan, ref = ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR), ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR)
+    if which:
+        plan.set_kernel(which)
+    ref.set_kernel(1)
+    assert plan.kernel_name == "stft_wave_kernel" and ref.kernel_name == "stft_generic_kernel"
+    a, mma = plan.calc_spec_batch(wavs)
+    b, _ = ref.calc_spec_batch(wavs)
+    for i, x in enumerate(wavs):
+        want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+        assert_spec_close(a[i], want, amp)
+        ga, gb = np.power(10.0, a[i].astype(np.float64) / 20), np.power(10.0, b[i].astype(np.float64) / 20)
+        assert (np.abs(ga - gb) / np.maximum(gb.max(axis=1, keepdims=True), 1e-30)).max() <= 5e-6
+        assert mma[i, 0] == a[i].min() and mma[i, 1] == a[i].max()
+    plan.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("n", [2, 3, 5, 100, 511, 1023, 1024, 1025, 2047])
 def test_calc_spec_short_inputs(ctx, n):
     """N < win (stft.rs:50-76): reflect padding cycles; frame count follows the same formula."""

@@ -609,9 +609,10 @@ TH_API int th_plan_dims(const th_plan *p, size_t *n_freq, size_t *height) {
 TH_API int th_plan_set_kernel(th_plan *p, int which) {
     TH_TRY
     TH_REQUIRE(p, "plan is NULL");
-    // bits 0-7: 0 auto, 1 generic, 2 wave, 3 wave + matrix-core mel, 4 wave without the phased mode;  bits 8-15 (tuning): waves per workgroup
+    // bits 0-7: 0 auto, 1 generic, 2 wave, 3 wave + matrix-core mel, 4 wave without the phased mode, 5 phased mode also with the
+    // fused mel epilogue, 6 wave with the two-frames-per-wave plan at n_fft 1024;  bits 8-15 (tuning): waves per workgroup
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 5, "kernel selector must be 0 .. 5");
+    TH_REQUIRE(k >= 0 && k <= 6, "kernel selector must be 0 .. 6");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     p->kernel_choice = k;
@@ -646,7 +647,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     const bool wave = p->use_wave();
     const bool mel_mfma = p->use_mel_mfma(), mel_fused = p->use_mel_fused();
     if (p->kernel_choice >= 2 && !wave)
-        return fail(TH_ERR_UNSUPPORTED, "the wave kernel covers n_fft in {1024, 2048, 4096} (mel: n_mel <= 512)");
+        return fail(TH_ERR_UNSUPPORTED, "the wave kernel covers n_fft in {512 (linear only), 1024, 2048, 4096} (mel: n_mel <= 512)");
     StftGeom g = p->g;       // main launch
     StftGeom ge = p->g;      // edge launch (generic kernel)
     const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);
@@ -843,6 +844,10 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     if (wave) {
         th::WaveOut wo;
         wo.mode = mel_mfma ? 1 : (mel_fused ? 2 : 0);
+        // n_fft 512, linear dB: four frames per wave (stft_wave_multi.h).  The same plan with two frames per wave exists for
+        // n_fft 1024 (selector 6) but measures 0.72 ms against 0.64 for the one-frame plan on the bench tracks (it reloads
+        // every frame in full: 16 loads per iteration against 4), so 1024 keeps the one-frame kernel by default.
+        wo.multi = (th::stft_wave_multi_applies(g, wo.mode) && (g.log2_nc == 8 || p->kernel_choice == 6)) ? 1 : 0;
         if (mel_fused) {
             wo.mel_tab = p->d_mel_fuse;
             wo.mel_words = p->mel_fuse_words;

@@ -22,6 +22,8 @@ hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const u
                                float *d_minmax, hipStream_t s);
 
 bool stft_wave_supported(const StftGeom &g);
+// the multi-frame kernel (two / four frames per wave) takes this launch: n_fft 512 or 1024, dB output, no grid-aligned mode
+bool stft_wave_multi_applies(const StftGeom &g, int out_mode);
 int stft_wave_default_waves(const StftGeom &g);
 // d_minmax of launch_stft_wave is a per-CHUNK (min, max) array (2 floats per tile).  launch_wave_post follows every wave
 // launch: per channel it folds the chunk pairs of the channel's tiles [t0, t1) into the channel slot (store = the slot
@@ -37,6 +39,7 @@ hipError_t launch_wave_post(const WavePostJob *d_pj, uint32_t n_pj, const float 
 // mel path), or dB rows of the mel spectrum with the filterbank fused into the epilogue (mel_fuse.h tables).
 struct WaveOut {
     int mode = 0;                     // 0 dB linear, 1 amplitude, 2 fused mel
+    int multi = 0;                    // 1: the multi-frame kernel (n_fft 512 / 1024, stft_wave_multi.h; mode 0 only)
     const uint32_t *mel_tab = nullptr;  // DEVICE: mel_fuse.h word table
     uint32_t mel_words = 0, mel_slots = 0, mel_groups = 0, n_mel = 0;
 };

@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "stft_core.h"
 #include "stft_wave.h"
+#include "stft_wave_multi.h"
 
 namespace th {
 
@@ -647,6 +648,172 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     TH_PROF_FLUSH(lane_wave);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Multi-frame wave kernel (stft_wave_multi.h): n_fft = 1024 -> two frames per wave, n_fft = 512 -> four; every lane
+// holds 16 complex points, the instruction stream is that of the 2048-point plan.  Same launch shape, chunk queue, job
+// tables and (min, max) protocol as stft_wave_kernel.  Group g of the lanes takes frame f + g of the wave's chunk; in
+// the last iteration of a chunk the groups past its end recompute (and re-store, identically) the chunk's last frame,
+// so control flow, LDS traffic and stores stay wave-uniform.  Every frame is loaded in full (no register reuse across
+// iterations: a group advances by G hops); the loads for the next iteration are issued right after the window multiply
+// and land during the transform.  dB output only (mel plans at these sizes use the one-frame kernel / generic kernel).
+// ------------------------------------------------------------------------------------------
+template <int LOG2_NC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
+    uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
+    uint32_t *__restrict__ queue_head) {
+    using W = WaveFftM<LOG2_NC>;
+    constexpr int P = W::P, NC = W::NC, G = W::G, L = W::L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf32 *wtab = reinterpret_cast<cf32 *>(smem_raw);
+    cf32 *stw = wtab + NC;
+    cf32 *t2 = stw + NC;
+    cf32 *t3 = t2 + W::T2_LEN;
+    cf32 *slabs = t3 + W::T3_LEN;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
+        wtab[i] = wtab_g[i];
+        stw[i] = tw[i];
+    }
+    W::fill_tables(tid, 64 * WAVES, tw, t2, t3);
+    __syncthreads();
+    cf32 *slab = slabs + (size_t)wave * W::SLAB_LEN;
+    const uint32_t lane_wave = tid & 63u;
+    const cf32 w_mid = stw[NC / 2];
+    bool first_pull = true;
+    const bool all_static = gridDim.x * WAVES >= n_tiles;
+    for (;;) {
+        if (!first_pull && all_static) break;
+        const FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane_wave, first_pull,
+                                            blockIdx.x * WAVES + wave, gridDim.x * WAVES);
+        first_pull = false;
+        if (!cur.valid) break;
+        float lmin = __builtin_inff(), lmax = -__builtin_inff();
+        const int32_t lead = (int32_t)(g.win / 2 + g.pad_left);
+        // samples of the lane's frame: x[m] = (s[2 n], s[2 n + 1]), n = col + L m, s = the frame's n_fft-sample span.
+        // Wave-uniform base (SGPRs) + a small per-lane offset: the group's frame starts dg hops further.  The span is clamped
+        // into the channel: a no-op for interior frames; the one-frame chunks of boundary frames "prefetch themselves" in
+        // the loop below, that span is partly outside, and the result is never used.
+        auto fetch = [&](cf32(&x)[P], uint32_t f_it, uint32_t lane) {
+            const uint32_t grp = W::grp(lane), col = W::lane_col(lane);
+            const uint32_t last = cur.f1 - 1u - f_it;  // groups past the chunk's end repeat its last frame
+            const uint32_t dg = grp < last ? grp : last;
+            const int32_t e0_max = (int32_t)cur.n_samples - (int32_t)g.n_fft;
+            int32_t e0 = (int32_t)((int64_t)(f_it + dg) * g.hop) - lead;
+            e0 = e0 < 0 ? 0 : (e0 > e0_max ? e0_max : e0);
+            const gptr<const float> base = cur.wav + (uint32_t)e0 + 2u * col;
+#pragma unroll
+            for (int m = 0; m < P; m++) {
+                const gptr<const float> p = base + 2u * (uint32_t)L * m;
+                x[m] = {p[0], p[1]};
+            }
+        };
+        cf32 x[P];
+        if (cur.edge) {  // wave-uniform: boundary frame (one-frame chunk), numpy-'reflect' indexing per sample
+            const uint32_t col = W::lane_col(lane_wave);
+            const int32_t e0 = (int32_t)((int64_t)cur.f * g.hop) - lead;
+#pragma unroll
+            for (int m = 0; m < P; m++) {
+                const int32_t i = e0 + 2 * (int32_t)(col + (uint32_t)L * m);
+                x[m] = {cur.wav[reflect_once(i, (int32_t)cur.n_samples)], cur.wav[reflect_once(i + 1, (int32_t)cur.n_samples)]};
+            }
+        } else {
+            fetch(x, cur.f, lane_wave);
+        }
+        for (uint32_t f = cur.f; f < cur.f1; f += G) {
+            uint32_t lane = lane_wave;
+            asm volatile("" : "+v"(lane));  // per-iteration copy: keeps the lane-derived addresses out of the loop-invariant set
+            lane &= 63u;
+            cf32 z[P];
+            {   // window pairs from LDS (slot m = complex point col + L m of the group's frame): one read serves G frames'
+                // worth of lanes, and keeping them in registers instead would push the kernel over its 168 VGPRs
+                const uint32_t col = W::lane_col(lane);
+                cf32 w[P];
+#pragma unroll
+                for (int m = 0; m < P; m++) w[m] = lds_ld(&wtab[col + (uint32_t)L * m]);
+#pragma unroll
+                for (int m = 0; m < P; m++) z[m] = {x[m].re * w[m].re, x[m].im * w[m].im};
+            }
+            {   // the next iteration's frames now (branch-free: the last iteration re-reads its own)
+                const uint32_t fn = f + G < cur.f1 ? f + G : f;
+                fetch(x, fn, lane);
+            }
+            TH_SCHED_BARRIER();
+            cf32 w2[15];
+            W::load_t2(lane, w2, t2);
+            W::pass1(lane, z, slab);
+            wave_lds_sync();
+            TH_SCHED_BARRIER();
+            W::read1(lane, z, slab);
+            wave_lds_sync();
+            W::pass2_twiddle(z, w2);
+            W::pass2_dft(lane, z, slab);
+            wave_lds_sync();
+            TH_SCHED_BARRIER();
+            cf32 wa[W::NW3], wb[W::NW3];
+            W::load_t3_paired(lane, wa, wb, t3);
+            cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
+            W::read2_paired(lane, za, zb, slab);
+            wave_lds_sync();  // the slab is free again
+            cf32 ws[W::NQ][W::R3];
+            W::load_stw_paired(lane, ws, stw);
+            TH_SCHED_BARRIER();
+            W::pass3_paired_w(za, zb, wa, wb);
+            TH_SCHED_BARRIER();
+            const uint32_t grp = W::grp(lane), last = cur.f1 - 1u - f, dg = grp < last ? grp : last;
+            const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch + (size_t)dg * cur.spec_pitch;
+            W::split_paired_w(lane, za, zb, ws, w_mid, [&](int32_t k, float p) {
+                const float d = power_to_dB(p);
+                row[k] = d;
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            });
+            {   // complete the row's last 128-byte line (see wave_frame)
+                const uint32_t height = (uint32_t)(NC + 1), pad = cur.spec_pitch - height, l = W::lig(lane);
+                if (l - 1u < ((pad < 32u && cur.spec_pitch % 32u == 0) ? pad : 0u)) row[height - 1u + l] = 0.0f;
+            }
+            TH_SCHED_BARRIER();
+        }
+        if (minmax != nullptr) {
+            const float a = wave_min(lmin), b = wave_max(lmax);
+            if (lane_wave == 0) {
+                minmax[2 * (size_t)cur.t] = a;
+                minmax[2 * (size_t)cur.t + 1] = b;
+            }
+        }
+    }
+}
+
+template <int LOG2_NC, int WAVES>
+static hipError_t launch_wave_multi_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
+                                      uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
+                                      uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
+    using W = WaveFftM<LOG2_NC>;
+    auto kern = stft_wave_multi_kernel<LOG2_NC, WAVES>;
+    const size_t lds = sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint32_t wg_needed = (n_tiles + WAVES - 1) / WAVES;
+    const uint32_t grid = wg_needed < n_cu ? wg_needed : n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw,
+                       d_minmax, d_queue_head);
+    return hipGetLastError();
+}
+template <int LOG2_NC>
+static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
+                                    uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
+                                    uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s) {
+    switch (waves <= 0 ? 12 : waves) {
+        case 8: return launch_wave_multi_t<LOG2_NC, 8>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+        case 12: return launch_wave_multi_t<LOG2_NC, 12>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+        case 16: return launch_wave_multi_t<LOG2_NC, 16>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 #if defined(TH_PHASE_PROF)
 }  // namespace th
 extern "C" __attribute__((visibility("default"))) int th_debug_phase_prof(unsigned long long *out, int reset) {
@@ -785,7 +952,11 @@ hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const u
 
 namespace th {
 
-bool stft_wave_supported(const StftGeom &g) { return g.log2_nc >= 9 && g.log2_nc <= 11 && g.n_mel <= 512; }
+// n_fft 512 (multi-frame kernel): linear dB only
+bool stft_wave_supported(const StftGeom &g) {
+    return (g.log2_nc >= 9 && g.log2_nc <= 11 && g.n_mel <= 512) || (g.log2_nc == 8 && g.n_mel == 0);
+}
+bool stft_wave_multi_applies(const StftGeom &g, int out_mode) { return out_mode == 0 && g.phased == 0 && (g.log2_nc == 8 || g.log2_nc == 9); }
 
 // Waves per workgroup (one persistent workgroup per CU).  Bounded by LDS (tables + one slab per
 // wave <= 160 KB) and by the VGPR file (64*WAVES threads => 512/(WAVES/4) VGPRs per lane).
@@ -974,6 +1145,7 @@ int stft_wave_default_waves(const StftGeom &g) {
     switch (g.log2_nc) {
         case 11: return WaveLaunchCfg<11>::DEFAULT_WAVES;
         case 10: return WaveLaunchCfg<10>::DEFAULT_WAVES;
+        case 8: return 12;
         default: return WaveLaunchCfg<9>::DEFAULT_WAVES;
     }
 }
@@ -983,6 +1155,11 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
                             uint32_t *d_queue_head, uint32_t n_cu, int waves, const WaveOut &out, hipStream_t s) {
     if (!n_tiles) return hipSuccess;
     if (!d_queue_head) return hipErrorInvalidValue;
+    if (out.multi) {  // several short frames per wave (stft_wave_multi.h)
+        if (!stft_wave_multi_applies(g, out.mode)) return hipErrorInvalidValue;
+        if (g.log2_nc == 8) return launch_wave_multi<8>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
+        return launch_wave_multi<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
+    }
     switch (g.log2_nc) {
         case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
         case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);

@@ -47,6 +47,15 @@ TH_HD void lds_st(cf32 *p, cf32 v) {
 #endif
 }
 
+// 4-byte LDS read in program order (volatile, explicit LDS address space; see lds_ld)
+TH_HD float lds_ldf(const float *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(float, *(const volatile __attribute__((address_space(3))) uint32_t *)(p));
+#else
+    return *p;
+#endif
+}
+
 // 16-byte LDS read (ds_read_b128, 16-byte aligned address), as four scalars (no vector-typed arithmetic downstream)
 struct f32x4 {
     float a, b, c, d;
