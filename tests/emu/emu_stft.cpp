@@ -35,7 +35,8 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
         for (uint32_t l = 0; l < 64; l++) W::pass3_paired(l, za[l], zb[l], t3.data());
         std::vector<int> hits(NC + 1, 0);
         for (uint32_t l = 0; l < 64; l++)
-            W::split_paired(l, za[l], zb[l], tw, [&](uint32_t k, float p) {
+            W::split_paired(l, za[l], zb[l], tw, [&](uint32_t kb, int kc, float p) {
+                const uint32_t k = kb + (uint32_t)kc;
                 row[k] = power_to_dB(p);
                 hits[k]++;
             });

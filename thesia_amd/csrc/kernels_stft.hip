@@ -394,9 +394,10 @@ __device__ __forceinline__ void wave_frame(
         TH_SCHED_BARRIER();
         TH_PROF_MARK(3);
         cf32 wa[W::NQ][W::R3 - 1], wb[W::NQ][W::R3 - 1];
-        if constexpr (!(RES & 4)) W::load_t3_paired(lane, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
+        const typename W::PairBase pbs = W::pair_base(lane);  // the lane's butterfly pairs as base + immediate (once per frame)
+        if constexpr (!(RES & 4)) W::load_t3_paired(pbs, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
         cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
-        W::read2_paired(lane, za, zb, slab);
+        W::read2_paired(lane, pbs, za, zb, slab);
         wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
         constexpr bool PRELOAD_STW = W::NQ * W::R3 <= 8;  // 16 VGPRs at n_fft = 2048; too many at 4096
         cf32 ws[W::NQ][W::R3];
@@ -409,14 +410,19 @@ __device__ __forceinline__ void wave_frame(
         TH_PROF_MARK(5);
         if constexpr (!PRELOAD_STW && !(RES & 8)) W::load_stw_paired(lane, ws, stw);
         float *const slab_f = reinterpret_cast<float *>(slab);
-        auto emit = [&](int32_t k, float p) {
+        // bin kb + kc: per-lane base (opaque, split_base) + compile-time constant.  The global address is formed as
+        // "row (SGPRs) + zext(4 kb) + 4 kc" in 64 bits, which is exactly global_store's saddr + voffset + immediate.
+        auto row_at = [&](uint32_t kb, int kc) -> gptr<float> {
+            return (gptr<float>)((gptr<char>)row + (uint64_t)(kb << 2) + (int64_t)(4 * kc));
+        };
+        auto emit = [&](uint32_t kb, int kc, float p) {
             if constexpr (MELF) {
-                slab_f[k] = power_to_amp_scaled(p);  // the slab is free after the second exchange: amplitude row for mel_pieces
+                slab_f[kb + (uint32_t)kc] = power_to_amp_scaled(p);  // the slab is free after the second exchange: amplitude row for mel_pieces
             } else if constexpr (AMP) {
-                row[k] = power_to_amp(p);
+                *row_at(kb, kc) = power_to_amp(p);
             } else {
                 const float d = power_to_dB(p);
-                row[k] = d;
+                *row_at(kb, kc) = d;
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }

@@ -414,15 +414,37 @@ struct WaveFft {
     static TH_HD uint32_t jj_b(uint32_t lane, int q) {
         return (q == 0 && lane == 0) ? (uint32_t)NS3 / 2 : (uint32_t)NS3 - 64u * q - lane;
     }
+    // The same butterfly indices as "per-lane base + compile-time constant" (every LDS address of the last pass is then
+    // one shift of a base plus an immediate offset): A_q = a + 64 q;  B_q = b_last + 64 (NQ - 1 - q) for q > 0, B_0 = b0.
+    struct PairBase {
+        uint32_t a, b0, b_last;
+    };
+    static TH_HD PairBase pair_base(uint32_t lane) {
+        const uint32_t l6 = lane & 63u;
+        PairBase pb;
+        pb.a = l6;
+        pb.b_last = (l6 ^ 63u) + (uint32_t)(NS3 - 64 * (NQ - 1) - 63);  // Ns3 - 64 (NQ - 1) - lane
+        pb.b0 = l6 == 0 ? (uint32_t)NS3 / 2 : pb.b_last + 64u * (NQ - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(pb.b0), "+v"(pb.b_last));  // opaque: keep "base + immediate" (see split_base)
+#endif
+        return pb;
+    }
+    static TH_HD uint32_t pb_b(const PairBase &pb, int q, uint32_t scale, uint32_t extra) {  // scale * B_q + extra
+        return q == 0 ? pb.b0 * scale + extra : pb.b_last * scale + (scale * 64u * (uint32_t)(NQ - 1 - q) + extra);
+    }
     // exchange-2 read in the paired layout: za[q][r] = in[A_q + r*Ns3], zb[q][r] = in[B_q + r*Ns3]
     static TH_HD void read2_paired(uint32_t lane, cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 *slab) {
+        read2_paired(lane, pair_base(lane), za, zb, slab);
+    }
+    static TH_HD void read2_paired(uint32_t lane, const PairBase &pbs, cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 *slab) {
         if constexpr (PLANES) {
             static_assert(!PLANES || R3 == 4, "one 16-byte load per butterfly and component");
+            static_assert(!PLANES || PITCH2 == 64, "plane (j >> 4) + quad (j & 15) of butterfly j = float offset 4 j");
             const float *const sf = reinterpret_cast<const float *>(slab);
             f32x4 ar[NQ], ai[NQ], br[NQ], bi[NQ];
             TH_UNROLL for (int q = 0; q < NQ; q++) {
-                const uint32_t a = jj_a(lane, q), b = jj_b(lane, q);
-                const float *const pa = sf + (a >> 4) * PITCH2 + 4u * (a & 15u), *const pb = sf + (b >> 4) * PITCH2 + 4u * (b & 15u);
+                const float *const pa = sf + (pbs.a * 4u + 256u * (uint32_t)q), *const pb = sf + pb_b(pbs, q, 4u, 0u);
                 ar[q] = lds_ld4(pa);
                 ai[q] = lds_ld4(pa + 16 * PITCH2);
                 br[q] = lds_ld4(pb);
@@ -450,11 +472,13 @@ struct WaveFft {
     }
     // last-pass twiddles of the lane's butterflies: wa[q][r-1] = W^(r*A_q), wb[q][r-1] = W^(r*B_q)
     static TH_HD void load_t3_paired(uint32_t lane, cf32 (&wa)[NQ][R3 - 1], cf32 (&wb)[NQ][R3 - 1], const cf32 *t3) {
+        load_t3_paired(pair_base(lane), wa, wb, t3);
+    }
+    static TH_HD void load_t3_paired(const PairBase &pbs, cf32 (&wa)[NQ][R3 - 1], cf32 (&wb)[NQ][R3 - 1], const cf32 *t3) {
         TH_UNROLL for (int q = 0; q < NQ; q++) {
-            const uint32_t a = jj_a(lane, q), b = jj_b(lane, q);
             TH_UNROLL for (int r = 1; r < R3; r++) {
-                wa[q][r - 1] = lds_ld(&t3[(r - 1) * NS3 + a]);
-                wb[q][r - 1] = lds_ld(&t3[(r - 1) * NS3 + b]);
+                wa[q][r - 1] = lds_ld(&t3[pbs.a + (uint32_t)((r - 1) * NS3 + 64 * q)]);
+                wb[q][r - 1] = lds_ld(&t3[pb_b(pbs, q, 1u, (uint32_t)((r - 1) * NS3))]);
             }
         }
     }
@@ -485,20 +509,50 @@ struct WaveFft {
         const int32_t lane_lo = (int32_t)lane, lane_hi = lane == 0 ? -(int32_t)((R3 - 1) * NS3 / 2) : lane_lo;
         return (q == 0 && s >= R3 / 2 ? lane_hi : lane_lo) + 64 * q + s * NS3;
     }
+    // Output addressing of the split pass.  Every bin index a lane emits is "per-lane base + compile-time constant", and
+    // the bases are built so that the compiler can prove their range (a 6-bit lane, xor / select / add of small
+    // constants): row[base + C] then becomes one store with an immediate offset off a base computed once per frame.
+    // (Written as row[k] / row[Nc - k] with k = lane + C, every mirrored store cost an or + sub + shift: 45 of the
+    // kernel's 760 VALU instructions per frame.)
+    //   pair (q, s), s <  R3/2 or q > 0:  k = lo + C,   Nc - k = mlo + (CMAX - C),   C = 64 q + s Ns3
+    //   pair (0, s), s >= R3/2         :  k = hi + C',  Nc - k = mhi + (Ns3 (R3/2 - 1) - C'),  C' = (s - R3/2) Ns3
+    // lo = lane, mlo = Nc - CMAX - lane; hi / mhi are lo / mlo shifted by R3/2 Ns3 for every lane but 0, whose second
+    // self-mirrored butterfly Ns3/2 starts at bin Ns3/2.
+    static constexpr int CMAX = 64 * (NQ - 1) + (R3 - 1) * NS3;
+    struct SplitBase {
+        uint32_t lo, hi, mlo, mhi;
+    };
+    static TH_HD SplitBase split_base(uint32_t lane) {
+        const uint32_t l6 = lane & 63u, rl = l6 ^ 63u;  // rl = 63 - lane
+        SplitBase b;
+        b.lo = l6;
+        b.mlo = rl + (uint32_t)(NC - CMAX - 63);
+        b.hi = l6 == 0 ? (uint32_t)NS3 / 2 : l6 + (uint32_t)(R3 / 2) * NS3;
+        b.mhi = l6 == 0 ? (uint32_t)(NC - NS3 / 2 - (R3 / 2 - 1) * NS3) : rl + (uint32_t)(NC - (R3 - 1) * NS3 - 63);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // opaque: the optimiser would otherwise fold the constants back in ("0x400 - (lane | C)": one or + sub + shift per store)
+        asm volatile("" : "+v"(b.hi), "+v"(b.mlo), "+v"(b.mhi));
+#endif
+        return b;
+    }
     // split twiddles of the lane's pairs: ws[q][s] = stw[k(q, s)], ws_mid = stw[Nc/2] (only lane 0 uses it)
     static TH_HD void load_stw_paired(uint32_t lane, cf32 (&ws)[NQ][R3], const cf32 *stw) {
+        const SplitBase sb = split_base(lane);  // = stw[split_k(lane, q, s)], as base + immediate
         TH_UNROLL for (int q = 0; q < NQ; q++)
-            TH_UNROLL for (int s = 0; s < R3; s++) ws[q][s] = lds_ld(&stw[split_k(lane, q, s)]);
+            TH_UNROLL for (int s = 0; s < R3; s++)
+                ws[q][s] = (q == 0 && s >= R3 / 2) ? lds_ld(&stw[sb.hi + (uint32_t)((s - R3 / 2) * NS3)])
+                                                   : lds_ld(&stw[sb.lo + (uint32_t)(64 * q + s * NS3)]);
     }
     // w_mid = stw[Nc/2] (the twiddle of the self-mirrored bin; only lane 0 uses it)
+    // emit(base, C, |X[base + C]|^2): once for every bin this lane owns
     template <class Emit>
     static TH_HD void split_paired_w(uint32_t lane, const cf32 (&za)[NQ][R3], const cf32 (&zb)[NQ][R3],
                                      const cf32 (&ws)[NQ][R3], cf32 w_mid, Emit emit) {
-        const bool l0 = lane == 0;
+        const bool l0 = (lane & 63u) == 0;
+        const SplitBase sb = split_base(lane);
         TH_UNROLL for (int q = 0; q < NQ; q++) {
             TH_UNROLL for (int s = 0; s < R3; s++) {
                 cf32 zk = za[q][s], zm = zb[q][R3 - 1 - s];
-                const int32_t k = split_k(lane, q, s);
                 if (q == 0) {
                     const int rp = s - R3 / 2;
                     const cf32 zk0 = s < R3 / 2 ? za[0][s] : zb[0][rp];
@@ -517,8 +571,13 @@ struct WaveFft {
                 const float dr = zk.re - zm.re, di = zk.im + zm.im;
                 const float tr = di * w.re + dr * w.im, ti = di * w.im - dr * w.re;
                 const float xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
-                emit(k, xr * xr + xi * xi);
-                emit(NC - k, yr * yr + yi * yi);
+                if (q == 0 && s >= R3 / 2) {
+                    emit(sb.hi, (s - R3 / 2) * NS3, xr * xr + xi * xi);
+                    emit(sb.mhi, (R3 - 1 - s) * NS3, yr * yr + yi * yi);
+                } else {
+                    emit(sb.lo, 64 * q + s * NS3, xr * xr + xi * xi);
+                    emit(sb.mlo, CMAX - (64 * q + s * NS3), yr * yr + yi * yi);
+                }
             }
         }
         if (l0) {  // the self-mirrored bin Nc/2 = output R3/2 of butterfly 0
@@ -526,10 +585,10 @@ struct WaveFft {
             const cf32 w = w_mid;
             const float er = 2.0f * z.re, di = 2.0f * z.im;  // zm = zk: e = (2 re, 0), d = (0, 2 im)
             const float xr = er + di * w.re, xi = di * w.im;
-            emit(NC / 2, xr * xr + xi * xi);
+            emit((uint32_t)NC / 2, 0, xr * xr + xi * xi);
         }
     }
-    // Split pass on lane-local pairs.  emit(k, |X[k]|^2) is called once for every bin this lane owns
+    // Split pass on lane-local pairs.  emit(base, C, |X[base + C]|^2) is called once for every bin this lane owns
     // (k in [0, Nc]; lane 0 owns 17 of the 1025 at Nc = 1024, every other lane 16).
     // stw[k] = W_{n_fft}^k = exp(-2 pi i k / (2 Nc)), k < Nc.
     template <class Emit>
