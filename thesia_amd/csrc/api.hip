@@ -827,7 +827,20 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         if (rc != TH_OK) return rc;
     }
     rc = p->jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(ChanJob));
-    if (rc == TH_OK) rc = p->tile_start.upload(c->stream, tile_start.data(), tile_start.size() * sizeof(uint32_t));
+    if (wave) {
+        // the wave kernels look a chunk up directly: (job, first frame) per chunk (cursor_at, kernels_stft.hip)
+        std::vector<uint32_t> chunk_tab((size_t)tiles * 2);
+        for (size_t j = 0; j < jobs.size(); j++) {
+            const uint32_t fpt = jobs[j].edge ? 1u : g.frames_per_tile;
+            for (uint32_t t = tile_start[j]; t < tile_start[j + 1]; t++) {
+                chunk_tab[2 * (size_t)t] = (uint32_t)j;
+                chunk_tab[2 * (size_t)t + 1] = jobs[j].f_begin + (t - tile_start[j]) * fpt;
+            }
+        }
+        if (rc == TH_OK) rc = p->tile_start.upload(c->stream, chunk_tab.data(), chunk_tab.size() * sizeof(uint32_t));
+    } else if (rc == TH_OK) {
+        rc = p->tile_start.upload(c->stream, tile_start.data(), tile_start.size() * sizeof(uint32_t));
+    }
     if (rc == TH_OK && !edge.empty()) {
         rc = p->edge_jobs.upload(c->stream, edge.data(), edge.size() * sizeof(ChanJob));
         if (rc == TH_OK) rc = p->edge_tile_start.upload(c->stream, edge_start.data(), edge_start.size() * sizeof(uint32_t));

@@ -209,6 +209,23 @@ __device__ unsigned long long th_phase_prof_dev[16];
 #define TH_PROF_MARK(i) ((void)0)
 #define TH_PROF_FLUSH(lane) ((void)0)
 #endif
+// Development instrumentation (variant builds with -DTH_WAVE_TIMES only, scripts/wave_times.py): per wave of the last
+// launch the 100 MHz wall clock at kernel entry, at the first frame and at exit, and the number of frames it took.
+#if defined(TH_WAVE_TIMES)
+__device__ unsigned long long th_wave_times_dev[6 * 256 * 16];
+#define TH_WT_STORE(slot, v)                                                                                 \
+    do {                                                                                                     \
+        if (lane == 0) th_wave_times_dev[6 * (blockIdx.x * WAVES + wave) + (slot)] = (v);                    \
+    } while (0)
+#else
+#define TH_WT_STORE(slot, v) ((void)0)
+#endif
+
+#if defined(TH_NO_SETPRIO)
+#define TH_SETPRIO(P) ((void)0)
+#else
+#define TH_SETPRIO(P) __builtin_amdgcn_s_setprio(P)
+#endif
 
 // Orders this wave's LDS writes before its later LDS reads (and vice versa) for the compiler; the
 // hardware already executes one wave's DS instructions in order, so no instruction is needed.
@@ -228,23 +245,18 @@ struct FrameCursor {
     bool fresh;  // first frame of a chunk: nothing of it is in registers yet
 };
 
-// pull the next chunk from the queue; every wave of the grid ends with valid == false
-__device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const ChanJob *__restrict__ jobs,
-                                                   const uint32_t *__restrict__ tile_start, uint32_t n_chan,
-                                                   uint32_t n_tiles, uint32_t *__restrict__ queue_head, uint32_t lane,
-                                                   bool first, uint32_t t_static, uint32_t t_base) {
+// Chunk t of the launch -> frame cursor.  chunk_tab[2 t] = job, chunk_tab[2 t + 1] = first frame (built by the host: one
+// scalar load instead of a binary search over the jobs' first chunks — seven dependent loads from L2 per chunk start, which
+// together with the queue atomic made a chunk start cost as much as 2.5 frames, scripts/wave_times.py).  t is wave-uniform.
+__device__ __forceinline__ FrameCursor cursor_at(const StftGeom &g, const ChanJob *__restrict__ jobs,
+                                                 const uint32_t *__restrict__ chunk_tab, uint32_t n_tiles, uint32_t t) {
     FrameCursor c{};
-    uint32_t t = t_static;  // a wave's first chunk is its global index: no 3072-deep burst on the queue head at start
-    if (!first) {
-        if (lane == 0) t = atomicAdd(queue_head, 1u);
-        t = __builtin_amdgcn_readfirstlane(t) + t_base;  // the head counts from 0: the first gridDim * WAVES chunks are static
-    }
     c.valid = t < n_tiles;
     if (c.valid) {
-        const uint32_t chan = find_chan(tile_start, n_chan, t);
+        const uint32_t chan = chunk_tab[2 * (size_t)t];
+        c.f = chunk_tab[2 * (size_t)t + 1];
         c.edge = jobs[chan].edge;
         const uint32_t fpt = c.edge ? 1u : g.frames_per_tile;  // boundary frames: one per chunk (no register reuse)
-        c.f = jobs[chan].f_begin + (t - tile_start[chan]) * fpt;
         c.f1 = min(c.f + fpt, jobs[chan].f_end);
         c.n_samples = jobs[chan].n_samples;
         c.mm_index = jobs[chan].mm_index;
@@ -256,6 +268,46 @@ __device__ __forceinline__ FrameCursor cursor_pull(const StftGeom &g, const Chan
     }
     return c;
 }
+
+// The chunk schedule of a persistent wave (both wave kernels).  A wave's first chunk is its own index in the grid (no
+// 3072-deep burst on the queue head at start); the rest come from the device-wide queue, one returning atomicAdd per chunk
+// (the head counts from 0 behind the W static chunks, W = waves of the grid).  The pull is issued TH_PULL_AHEAD frames
+// before the current chunk ends — late, so that the launch's last chunks still go to whoever runs ahead, but early enough
+// that the atomic's round trip (served one at a time, ~8 ns each device-wide, and the waves of a launch tend to finish their
+// chunks together) is over when the chunk is.
+//     WaveSched s; TH_SCHED_INIT(s, wave index);
+//     while (s.cur.valid) { fetch(s.cur); for (frames f) { TH_SCHED_PULL(s, f, lane); ... } TH_SCHED_ADVANCE(s); }
+#if !defined(TH_PULL_AHEAD)
+#define TH_PULL_AHEAD 2u
+#endif
+struct WaveSched {
+    FrameCursor cur;
+    uint32_t pull_f, pulled, n_waves;
+    bool use_queue, armed;
+};
+#define TH_SCHED_ARM(S) /* the frame at (or after) whose start the next chunk's index is pulled */          \
+    ((S).pull_f = (S).cur.f1 - (S).cur.f > TH_PULL_AHEAD ? (S).cur.f1 - TH_PULL_AHEAD : (S).cur.f, (S).armed = (S).use_queue)
+#define TH_SCHED_INIT(S, WAVE_INDEX)                                                                       \
+    do {                                                                                                   \
+        (S).n_waves = gridDim.x * WAVES;                                                                   \
+        (S).use_queue = (S).n_waves < n_tiles; /* else: every chunk is some wave's first */                \
+        (S).cur = cursor_at(g, jobs, chunk_tab, n_tiles, (WAVE_INDEX));                                    \
+        (S).pulled = 0;                                                                                    \
+        TH_SCHED_ARM(S);                                                                                   \
+    } while (0)
+#define TH_SCHED_PULL(S, F, LANE)                                                                          \
+    do {                                                                                                   \
+        if ((S).armed && (F) >= (S).pull_f) {                                                              \
+            (S).armed = false;                                                                             \
+            if ((LANE) == 0) (S).pulled = atomicAdd(queue_head, 1u);                                       \
+        }                                                                                                  \
+    } while (0)
+#define TH_SCHED_ADVANCE(S)                                                                                \
+    do {                                                                                                   \
+        const uint32_t t_ = (S).use_queue ? __builtin_amdgcn_readfirstlane((S).pulled) + (S).n_waves : n_tiles; \
+        (S).cur = cursor_at(g, jobs, chunk_tab, n_tiles, t_);                                              \
+        TH_SCHED_ARM(S);                                                                                   \
+    } while (0)
 
 // frame element 0 sits at signal position f*hop - win/2 - pad_left; the host only hands interior
 // frames to this kernel, so every windowed sample is inside the channel
@@ -513,7 +565,7 @@ __device__ __forceinline__ void wave_frame(
 // mel_mfma_kernel then applies the filterbank).
 template <int LOG2_NC, int WAVES, int SHIFT, int OUT, int RES>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
-    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
     uint32_t *__restrict__ queue_head, WaveOut wo) {
     using W = WaveFft<LOG2_NC>;
@@ -548,6 +600,15 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // wave index is wave-uniform: tell the compiler, so the frame cursor lives in SGPRs / SALU
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    TH_WT_STORE(0, wall_clock64());
+#if defined(TH_WAVE_TIMES)
+    {
+        uint32_t hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        TH_WT_STORE(4, ((unsigned long long)xcc_id << 32) | hw_id);
+    }
+#endif
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
         wtab[WPAD + i] = wtab_g[WPAD + i];
         if constexpr (STW_IN_LDS) stw[i] = tw[i];
@@ -600,33 +661,54 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         rw_mid = tw[NC / 2];
     }
     // chunk loop: one queue pull and one full fetch per chunk of up to frames_per_tile consecutive frames
-    bool first_pull = true;
-    const bool all_static = gridDim.x * WAVES >= n_tiles;  // every chunk is some wave's first: nobody needs the queue
-    for (;;) {
-        if (!first_pull && all_static) break;
-        const FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane, first_pull,
-                                            blockIdx.x * WAVES + wave, gridDim.x * WAVES);
-        first_pull = false;
-        if (!cur.valid) break;
+    TH_WT_STORE(1, wall_clock64());
+#if defined(TH_WAVE_TIMES)
+    unsigned long long wt_frames = 0, wt_start = 0, wt_chunks = 0;
+#endif
+    WaveSched sch;
+    TH_SCHED_INIT(sch, blockIdx.x * WAVES + wave);
+    while (sch.cur.valid) {
+#if defined(TH_WAVE_TIMES)
+        const unsigned long long wt_pull0 = wall_clock64();
+#endif
+        const FrameCursor &cur = sch.cur;
         lmin = __builtin_inff();
         lmax = -__builtin_inff();
         cf32 x[P];  // raw samples of the current frame; the frame body refills it for the next one
         if (cur.edge) wave_fetch_reflect<P>(W::lane_col(lane), x, cur.wav, frame_e0(cur, g), cur.n_samples);  // wave-uniform
         else wave_fetch<P, 0>(W::lane_col(lane), x, cur.wav, frame_e0(cur, g));
+#if defined(TH_WAVE_TIMES)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (instrumented build only: chunk-start time up to the arrival of the first frame)
+        wt_start += wall_clock64() - wt_pull0;
+        wt_chunks++;
+#endif
         uint32_t f = cur.f;
         // frame loop (steady state: branch-free register flow, see wave_frame)
+        // Issue priority rotates with the frame body.  The instruction arbiter serves the oldest wave of a SIMD first, and
+        // strictly: of the three waves of a SIMD the first-launched ran a frame in 4.4 us, the second in 5.5, the third in
+        // 8.1 (scripts/wave_times.py) — the slow ones then hold the launch's last chunks for twice as long as anyone else
+        // (10 % of the launch was waves waiting for them).  With the priority cycling 0..NROT-1 from frame to frame every
+        // wave spends the same share of its time at every level and the waves advance at the same pace.
         for (;;) {
+            TH_SCHED_PULL(sch, f, lane);
+            TH_SETPRIO(0);
             TH_FRAME(0);
             if (++f >= cur.f1) break;
             if constexpr (NROT > 1) {
+                TH_SCHED_PULL(sch, f, lane);
+                TH_SETPRIO(1);
                 TH_FRAME(1);
                 if (++f >= cur.f1) break;
             }
             if constexpr (NROT > 2) {
+                TH_SCHED_PULL(sch, f, lane);
+                TH_SETPRIO(2);
                 TH_FRAME(2);
                 if (++f >= cur.f1) break;
             }
             if constexpr (NROT > 3) {
+                TH_SCHED_PULL(sch, f, lane);
+                TH_SETPRIO(3);
                 TH_FRAME(3);
                 if (++f >= cur.f1) break;
             }
@@ -647,7 +729,15 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
                 minmax[2 * (size_t)cur.t + 1] = b;
             }
         }
+#if defined(TH_WAVE_TIMES)
+        wt_frames += cur.f1 - cur.f;
+#endif
+        TH_SCHED_ADVANCE(sch);
     }
+    TH_WT_STORE(2, wall_clock64());
+#if defined(TH_WAVE_TIMES)
+    TH_WT_STORE(3, wt_frames | (wt_chunks << 16) | (wt_start << 32));
+#endif
 #undef TH_FRAME
 #undef TH_BODY_SHIFT
 #undef TH_BODY_OFF
@@ -666,7 +756,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 // ------------------------------------------------------------------------------------------
 template <int LOG2_NC, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
-    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
     uint32_t *__restrict__ queue_head) {
     using W = WaveFftM<LOG2_NC>;
@@ -688,14 +778,10 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
     cf32 *slab = slabs + (size_t)wave * W::SLAB_LEN;
     const uint32_t lane_wave = tid & 63u;
     const cf32 w_mid = stw[NC / 2];
-    bool first_pull = true;
-    const bool all_static = gridDim.x * WAVES >= n_tiles;
-    for (;;) {
-        if (!first_pull && all_static) break;
-        const FrameCursor cur = cursor_pull(g, jobs, tile_start, n_chan, n_tiles, queue_head, lane_wave, first_pull,
-                                            blockIdx.x * WAVES + wave, gridDim.x * WAVES);
-        first_pull = false;
-        if (!cur.valid) break;
+    WaveSched sch;
+    TH_SCHED_INIT(sch, blockIdx.x * WAVES + wave);
+    while (sch.cur.valid) {
+        const FrameCursor &cur = sch.cur;
         float lmin = __builtin_inff(), lmax = -__builtin_inff();
         const int32_t lead = (int32_t)(g.win / 2 + g.pad_left);
         // samples of the lane's frame: x[m] = (s[2 n], s[2 n + 1]), n = col + L m, s = the frame's n_fft-sample span.
@@ -729,6 +815,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
             fetch(x, cur.f, lane_wave);
         }
         for (uint32_t f = cur.f; f < cur.f1; f += G) {
+            TH_SCHED_PULL(sch, f, lane_wave);
             uint32_t lane = lane_wave;
             asm volatile("" : "+v"(lane));  // per-iteration copy: keeps the lane-derived addresses out of the loop-invariant set
             lane &= 63u;
@@ -789,6 +876,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
                 minmax[2 * (size_t)cur.t + 1] = b;
             }
         }
+        TH_SCHED_ADVANCE(sch);
     }
 }
 
@@ -820,6 +908,13 @@ static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, co
     }
 }
 
+#if defined(TH_WAVE_TIMES)
+}  // namespace th
+extern "C" __attribute__((visibility("default"))) int th_debug_wave_times(unsigned long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(th::th_wave_times_dev), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+namespace th {
+#endif
 #if defined(TH_PHASE_PROF)
 }  // namespace th
 extern "C" __attribute__((visibility("default"))) int th_debug_phase_prof(unsigned long long *out, int reset) {
