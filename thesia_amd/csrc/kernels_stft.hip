@@ -221,10 +221,11 @@ __device__ unsigned long long th_wave_times_dev[6 * 256 * 16];
 #define TH_WT_STORE(slot, v) ((void)0)
 #endif
 
-#if defined(TH_NO_SETPRIO)
-#define TH_SETPRIO(P) ((void)0)
-#else
+// Optional (variant builds with -DTH_ROTATE_PRIO): issue priority rotating with the frame body, see the frame loop.
+#if defined(TH_ROTATE_PRIO)
 #define TH_SETPRIO(P) __builtin_amdgcn_s_setprio(P)
+#else
+#define TH_SETPRIO(P) ((void)0)
 #endif
 
 // Orders this wave's LDS writes before its later LDS reads (and vice versa) for the compiler; the
@@ -352,9 +353,9 @@ template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH
 __device__ __forceinline__ void wave_frame(
     const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
     uint32_t f, uint32_t f1, gptr<const float> wav, uint32_t n_samples, gptr<float> spec, uint32_t spec_pitch, cf32 (&x)[WaveFft<LOG2_NC>::P],
-    const cf32 (&rw)[(RES & 1) ? WaveFft<LOG2_NC>::P : 1], const cf32 (&rw2)[(RES & 2) ? WaveFft<LOG2_NC>::R2 - 1 : 1],
-    const cf32 (&rwa)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
-    const cf32 (&rwb)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3 - 1],
+    const cf32 (&rw)[(RES & 1) ? WaveFft<LOG2_NC>::P : 1], const cf32 (&rw2)[(RES & 2) ? WaveFft<LOG2_NC>::NT2 : 1],
+    const cf32 (&rwa)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::NT3],
+    const cf32 (&rwb)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::NT3],
     const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], cf32 rw_mid, float &lmin, float &lmax,
     const uint32_t *meltab, cf32 *mel_prf, const WaveOut &wo TH_PROF_PARAMS) {
     constexpr bool AMP = OUT == 1, MELF = OUT == 2;
@@ -374,7 +375,7 @@ __device__ __forceinline__ void wave_frame(
     // table reads are issued ahead of their use (lds_ld keeps program order): pass-2 twiddles before the
     // pass-1 arithmetic, pass-3 and split twiddles together with the reads of exchange 2.
     cf32 z[P];
-    cf32 w2[W::R2 - 1];
+    cf32 w2[W::NT2];
     constexpr bool DYN = PH == -2;
     if constexpr (DYN) {
         const uint32_t d = (uint32_t)((int64_t)f * g.hop - (int64_t)(g.win / 2)) & 127u;  // first window sample above the grid
@@ -435,17 +436,16 @@ __device__ __forceinline__ void wave_frame(
     W::read1(lane, z, slab);
     wave_lds_sync();
     TH_PROF_MARK(2);
-    if constexpr (RES & 2) W::pass2_twiddle(z, rw2);
-    else W::pass2_twiddle(z, w2);
 
     const gptr<float> row = spec + (size_t)f * spec_pitch;
     if constexpr (W::PAIRED) {
         // mirror-local last pass: every Z[k] / Z[Nc-k] pair ends up in one lane's registers
-        W::pass2_dft(lane, z, slab);
+        if constexpr (RES & 2) W::pass2_w(lane, z, rw2, slab);
+        else W::pass2_w(lane, z, w2, slab);
         wave_lds_sync();
         TH_SCHED_BARRIER();
         TH_PROF_MARK(3);
-        cf32 wa[W::NQ][W::R3 - 1], wb[W::NQ][W::R3 - 1];
+        cf32 wa[W::NQ][W::NT3], wb[W::NQ][W::NT3];
         const typename W::PairBase pbs = W::pair_base(lane);  // the lane's butterfly pairs as base + immediate (once per frame)
         if constexpr (!(RES & 4)) W::load_t3_paired(pbs, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
         cf32 za[W::NQ][W::R3], zb[W::NQ][W::R3];
@@ -482,7 +482,8 @@ __device__ __forceinline__ void wave_frame(
         if constexpr (RES & 8) W::split_paired_w(lane, za, zb, rws, rw_mid, emit);
         else W::split_paired_w(lane, za, zb, ws, stw[NC / 2], emit);
     } else {
-        W::pass2_dft(lane, z, slab);
+        if constexpr (RES & 2) W::pass2_w(lane, z, rw2, slab);
+        else W::pass2_w(lane, z, w2, slab);
         wave_lds_sync();
         TH_SCHED_BARRIER();
         W::read2(lane, z, slab);
@@ -644,8 +645,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         g, wtab + (PHASED ? WPAD - ((96 * (ROT)) & 127) / 2 : 0), stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
         lmax, meltab, mel_prf, wo TH_PROF_ARGS)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
-    cf32 rw[(RESK & 1) ? P : 1], rw2[(RESK & 2) ? W::R2 - 1 : 1];
-    cf32 rwa[(RESK & 4) ? W::NQ : 1][W::R3 - 1], rwb[(RESK & 4) ? W::NQ : 1][W::R3 - 1], rws[(RESK & 8) ? W::NQ : 1][W::R3];
+    cf32 rw[(RESK & 1) ? P : 1], rw2[(RESK & 2) ? W::NT2 : 1];
+    cf32 rwa[(RESK & 4) ? W::NQ : 1][W::NT3], rwb[(RESK & 4) ? W::NQ : 1][W::NT3], rws[(RESK & 8) ? W::NQ : 1][W::R3];
     if constexpr (RESK & 1) {
 #pragma unroll
         for (int m = 0; m < P; m++) rw[m] = wtab[W::lane_col(lane) + 64u * m];
@@ -684,11 +685,11 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #endif
         uint32_t f = cur.f;
         // frame loop (steady state: branch-free register flow, see wave_frame)
-        // Issue priority rotates with the frame body.  The instruction arbiter serves the oldest wave of a SIMD first, and
-        // strictly: of the three waves of a SIMD the first-launched ran a frame in 4.4 us, the second in 5.5, the third in
-        // 8.1 (scripts/wave_times.py) — the slow ones then hold the launch's last chunks for twice as long as anyone else
-        // (10 % of the launch was waves waiting for them).  With the priority cycling 0..NROT-1 from frame to frame every
-        // wave spends the same share of its time at every level and the waves advance at the same pace.
+        // (TH_SETPRIO: measurement switch, off by default.  The instruction arbiter serves the oldest wave of a SIMD first,
+        // and strictly: of the three waves of a SIMD the first-launched runs a frame in 4.4 us, the second in 5.5, the third
+        // in 8.1 (scripts/wave_times.py).  Cycling the priority 0..NROT-1 from frame to frame makes all waves advance at the
+        // same pace (5.4 / 5.7 / 6.0 us) — and the launch 1.5 % slower: the sum of the rates is what counts, the dynamic
+        // chunk queue already absorbs the different speeds, and the kernel is bound by its total work, not by its tail.)
         for (;;) {
             TH_SCHED_PULL(sch, f, lane);
             TH_SETPRIO(0);

@@ -124,6 +124,28 @@ TH_HD void lds_st_planes4(float *slab, uint32_t lane, cf32 v0, cf32 v1, cf32 v2,
 // ---------------------------------------------------------------------------------------------
 TH_HD cf32 cmul_c(cf32 a, float wr, float wi) { return {a.re * wr - a.im * wi, a.re * wi + a.im * wr}; }
 
+// Twiddled butterflies in fused multiply-adds.  A radix-2 butterfly whose second input carries a twiddle,
+//   s = x + t y,   d = x - t y = 2 x - s,
+// is six FMAs (two per component of s, one per component of d) where "multiply, then add and subtract" is eight
+// operations; x and y are replaced by s and d.
+TH_HD float th_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+TH_HD void bfly2_tw(cf32 &x, cf32 &y, float tr, float ti) {
+    const float sr = th_fma(-ti, y.im, th_fma(tr, y.re, x.re));
+    const float si = th_fma(ti, y.re, th_fma(tr, y.im, x.im));
+    y = {th_fma(2.0f, x.re, -sr), th_fma(2.0f, x.im, -si)};
+    x = {sr, si};
+}
+// Radix-4 decimation-in-time butterfly with the input twiddles (1, t, t^2, t^3), as two levels of bfly2_tw: the second
+// level's twiddles relative to the first are t^2 again (t^3 / t), then t and -i t, so t^3 is never needed.  24 FMAs
+// against 28 operations for three complex multiplies plus an untwiddled radix-4.  In: (a, b, c, d) = inputs 0..3.
+// Out: a = X0, c = X1, b = X2, d = X3.
+TH_HD void bfly4_tw(cf32 &a, cf32 &b, cf32 &c, cf32 &d, cf32 t, cf32 t2) {
+    bfly2_tw(a, c, t2.re, t2.im);  // a = a + t^2 c, c = a - t^2 c
+    bfly2_tw(b, d, t2.re, t2.im);  // b = b + t^2 d, d = b - t^2 d
+    bfly2_tw(a, b, t.re, t.im);    // X0, X2
+    bfly2_tw(c, d, t.im, -t.re);   // X1, X3  (twiddle -i t)
+}
+
 // DFT-8 as 2 x 4: n = n1 + 2*n2 (n1 in 0..1, n2 in 0..3), k = 4*k1 + k2
 //   v[n1 + 2*k2] <- DFT4 over n2 of v[n1 + 2*n2];  *= W8^(n1*k2);  DFT2 over n1  -> X[4*k1+k2] in v[k1 + 2*k2]
 TH_HD void dft8(cf32 (&v)[8]) {
@@ -247,13 +269,30 @@ struct WaveFft {
     // Twiddle tables (LDS in the kernel): a lane reads W_{Ns*R}^{r*k} for its own k = jj mod Ns.
     //   t2[(r-1)*NS2 + k], k < NS2 (NS2 <= 64 so k does not depend on the butterfly index b)
     //   t3[(r-1)*NS3 + jj], jj < NS3 (last pass: k = jj)
-    static constexpr int T2_LEN = (R2 - 1) * NS2, T3_LEN = (R3 - 1) * NS3;
+    // The n_fft = 2048 plan (R1 = R2 = 16, R3 = 4, one radix-16 butterfly per lane and pass) runs its twiddled passes as
+    // fused-multiply-add butterflies (bfly4_tw): pass 2 = 4 x 4 decimation in time with the pass twiddle w = W^k folded in,
+    //     X[m' + 4 m''] = sum_b (w W16^m')^b W4^(b m'')  sum_a (w^4)^a W4^(a m') z[4 a + b],
+    // i.e. four inner butterflies with t = w^4 and four outer ones with t = w W16^m' — 10 table entries per lane
+    // (w^4, w^8, then t, t^2 for m' = 0..3) instead of 15, 192 FMAs instead of 60 + 160 operations.  Pass 3 needs (t, t^2)
+    // per butterfly instead of (t, t^2, t^3).
+    static constexpr bool FMA_TW = (R1 == 16 && R2 == 16 && P == 16 && R3 == 4);
+    static constexpr int NT2 = FMA_TW ? 10 : R2 - 1;  // pass-2 twiddles per lane
+    static constexpr int NT3 = FMA_TW ? 2 : R3 - 1;   // pass-3 twiddles per butterfly
+    static constexpr int T2_LEN = NT2 * NS2, T3_LEN = NT3 * NS3;
     static_assert(NS2 <= 64, "pass-2 twiddle index must be butterfly independent");
     // tw[i] = exp(-2 pi i * i / n_fft), n_fft = 2*NC  ->  W_{M}^{e} = tw[e * (2*NC / M)]
     static TH_HD void fill_tables(uint32_t tid, uint32_t nthr, const cf32 *tw, cf32 *t2, cf32 *t3) {
         for (uint32_t i = tid; i < (uint32_t)T2_LEN; i += nthr) {
             const uint32_t r = i / NS2 + 1, k = i % NS2;
-            t2[i] = tw[(r * k) * (2 * NC / (NS2 * R2))];
+            if constexpr (FMA_TW) {
+                // w = W_{Ns2 R2}^k = tw[k S], S = 2 Nc / (Ns2 R2);  W16 = tw[2 Nc / 16]
+                constexpr uint32_t S = 2 * NC / (NS2 * R2), S16 = 2 * NC / 16, M = 2 * NC;
+                const uint32_t e = i / NS2;  // 0: w^4, 1: w^8, 2 + 2 m': t = w W16^m', 3 + 2 m': t^2
+                const uint32_t mp = e >= 2 ? (e - 2) / 2 : 0, pw = e < 2 ? 4u * (e + 1u) : 1u + ((e - 2) & 1u);
+                t2[i] = tw[(pw * k * S + (e >= 2 ? pw * mp * S16 : 0u)) % M];
+            } else {
+                t2[i] = tw[(r * k) * (2 * NC / (NS2 * R2))];
+            }
         }
         for (uint32_t i = tid; i < (uint32_t)T3_LEN; i += nthr) {
             const uint32_t r = i / NS3 + 1, k = i % NS3;
@@ -340,14 +379,34 @@ struct WaveFft {
     // pass 2 (Ns = R1): registers -> LDS slab (linear).  In three pieces so that the kernel can issue the
     // twiddle reads long before their use (LDS returns in order: a read issued next to its use exposes
     // the whole LDS latency): load_t2 -> pass2_twiddle -> pass2_dft.  pass2() is the composition.
-    static TH_HD void load_t2(uint32_t lane, cf32 (&w2)[R2 - 1], const cf32 *t2) {
+    static TH_HD void load_t2(uint32_t lane, cf32 (&w2)[NT2], const cf32 *t2) {
         // NS2 <= 64: the same twiddles for every butterfly of the lane
         const uint32_t k = PLANES ? lane >> 2 : lane & (NS2 - 1);
-        TH_UNROLL for (int r = 1; r < R2; r++) w2[r - 1] = lds_ld(&t2[(r - 1) * NS2 + k]);
+        TH_UNROLL for (int r = 0; r < NT2; r++) w2[r] = lds_ld(&t2[r * NS2 + k]);
     }
-    static TH_HD void pass2_twiddle(cf32 (&z)[P], const cf32 (&w2)[R2 - 1]) {
-        TH_UNROLL for (int b = 0; b < B2; b++)
-            TH_UNROLL for (int r = 1; r < R2; r++) z[b + B2 * r] = cmul(z[b + B2 * r], w2[r - 1]);
+    static TH_HD void pass2_twiddle(cf32 (&z)[P], const cf32 (&w2)[NT2]) {
+        if constexpr (!FMA_TW) {  // (the FMA plan folds the twiddles into pass2_dft_tw)
+            TH_UNROLL for (int b = 0; b < B2; b++)
+                TH_UNROLL for (int r = 1; r < R2; r++) z[b + B2 * r] = cmul(z[b + B2 * r], w2[r - 1]);
+        }
+    }
+    // FMA plan: twiddled radix-16 butterfly of pass 2 straight into the planes of exchange 2 (see FMA_TW above)
+    static TH_HD void pass2_dft_tw(uint32_t lane, cf32 (&v)[P], const cf32 (&w)[NT2], cf32 *slab) {
+        if constexpr (FMA_TW) {
+            float *const sf = reinterpret_cast<float *>(slab);
+            // inner butterflies over a (inputs v[b + 4 a]), t = w^4: y_b[m'] ends up in v[b + 4 pi(m')], pi = (0, 2, 1, 3)
+            TH_UNROLL for (int b = 0; b < 4; b++) bfly4_tw(v[b], v[4 + b], v[8 + b], v[12 + b], w[0], w[1]);
+            // outer butterfly m' over b (inputs y_b[m']), t = w W16^m': X[m' + 4 m''], m'' = 0..3 -> planes m' + 4 m''
+#define TH_OUTER(MP, PI)                                                                                          \
+    bfly4_tw(v[4 * (PI)], v[4 * (PI) + 1], v[4 * (PI) + 2], v[4 * (PI) + 3], w[2 + 2 * (MP)], w[3 + 2 * (MP)]);  \
+    lds_st_planes4<(MP) * PITCH2 * 4, (16 + (MP)) * PITCH2 * 4, 16 * PITCH2>(sf, lane, v[4 * (PI)], v[4 * (PI) + 2],  \
+                                                                              v[4 * (PI) + 1], v[4 * (PI) + 3])
+            TH_OUTER(0, 0);
+            TH_OUTER(1, 2);
+            TH_OUTER(2, 1);
+            TH_OUTER(3, 3);
+#undef TH_OUTER
+        }
     }
     static TH_HD void pass2_dft(uint32_t lane, cf32 (&z)[P], cf32 *slab) {
         if constexpr (PLANES) {
@@ -363,11 +422,19 @@ struct WaveFft {
             }
         }
     }
+    // twiddles + butterflies + stores of pass 2 (either plan)
+    static TH_HD void pass2_w(uint32_t lane, cf32 (&z)[P], const cf32 (&w2)[NT2], cf32 *slab) {
+        if constexpr (FMA_TW) {
+            pass2_dft_tw(lane, z, w2, slab);
+        } else {
+            pass2_twiddle(z, w2);
+            pass2_dft(lane, z, slab);
+        }
+    }
     static TH_HD void pass2(uint32_t lane, cf32 (&z)[P], const cf32 *t2, cf32 *slab) {
-        cf32 w2[R2 - 1];
+        cf32 w2[NT2];
         load_t2(lane, w2, t2);
-        pass2_twiddle(z, w2);
-        pass2_dft(lane, z, slab);
+        pass2_w(lane, z, w2, slab);
     }
     static TH_HD void read2(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
         TH_UNROLL for (int m = 0; m < P; m++) z[m] = slab[lane + 64u * m];
@@ -471,34 +538,41 @@ struct WaveFft {
         }
     }
     // last-pass twiddles of the lane's butterflies: wa[q][r-1] = W^(r*A_q), wb[q][r-1] = W^(r*B_q)
-    static TH_HD void load_t3_paired(uint32_t lane, cf32 (&wa)[NQ][R3 - 1], cf32 (&wb)[NQ][R3 - 1], const cf32 *t3) {
+    static TH_HD void load_t3_paired(uint32_t lane, cf32 (&wa)[NQ][NT3], cf32 (&wb)[NQ][NT3], const cf32 *t3) {
         load_t3_paired(pair_base(lane), wa, wb, t3);
     }
-    static TH_HD void load_t3_paired(const PairBase &pbs, cf32 (&wa)[NQ][R3 - 1], cf32 (&wb)[NQ][R3 - 1], const cf32 *t3) {
+    static TH_HD void load_t3_paired(const PairBase &pbs, cf32 (&wa)[NQ][NT3], cf32 (&wb)[NQ][NT3], const cf32 *t3) {
         TH_UNROLL for (int q = 0; q < NQ; q++) {
-            TH_UNROLL for (int r = 1; r < R3; r++) {
+            TH_UNROLL for (int r = 1; r <= NT3; r++) {
                 wa[q][r - 1] = lds_ld(&t3[pbs.a + (uint32_t)((r - 1) * NS3 + 64 * q)]);
                 wb[q][r - 1] = lds_ld(&t3[pb_b(pbs, q, 1u, (uint32_t)((r - 1) * NS3))]);
             }
         }
     }
-    static TH_HD void bfly3(cf32 (&v)[R3], const cf32 (&w3)[R3 - 1]) {
+    static TH_HD void bfly3(cf32 (&v)[R3], const cf32 (&w3)[NT3]) {
+        if constexpr (FMA_TW) {  // (t, t^2): a = X0, c = X1, b = X2, d = X3
+            bfly4_tw(v[0], v[1 % R3], v[2 % R3], v[3 % R3], w3[0], w3[1 % NT3]);
+            const cf32 x1 = v[2 % R3];
+            v[2 % R3] = v[1 % R3];
+            v[1 % R3] = x1;
+            return;
+        }
         cf32 w[R3];
         w[0] = v[0];
-        TH_UNROLL for (int r = 1; r < R3; r++) w[r] = cmul(v[r], w3[r - 1]);
+        TH_UNROLL for (int r = 1; r < R3; r++) w[r] = cmul(v[r], w3[(r - 1) % NT3]);
         RegDft<R3>::run(w);
         TH_UNROLL for (int r = 0; r < R3; r++) v[r] = w[RegDft<R3>::slot(r)];
     }
     // last pass: za[q][r] <- Z[A_q + r*Ns3], zb[q][r] <- Z[B_q + r*Ns3]
-    static TH_HD void pass3_paired_w(cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 (&wa)[NQ][R3 - 1],
-                                     const cf32 (&wb)[NQ][R3 - 1]) {
+    static TH_HD void pass3_paired_w(cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 (&wa)[NQ][NT3],
+                                     const cf32 (&wb)[NQ][NT3]) {
         TH_UNROLL for (int q = 0; q < NQ; q++) {
             bfly3(za[q], wa[q]);
             bfly3(zb[q], wb[q]);
         }
     }
     static TH_HD void pass3_paired(uint32_t lane, cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 *t3) {
-        cf32 wa[NQ][R3 - 1], wb[NQ][R3 - 1];
+        cf32 wa[NQ][NT3], wb[NQ][NT3];
         load_t3_paired(lane, wa, wb, t3);
         pass3_paired_w(za, zb, wa, wb);
     }
@@ -567,10 +641,11 @@ struct WaveFft {
                 const cf32 w = ws[q][s];
                 // e = Z[k] + conj Z[Nc-k];  d = Z[k] - conj Z[Nc-k];  t = W^k * (-i d)
                 // X[k] = e + t,  X[Nc-k] = conj(e - t)
+                // (x = e + t in two FMAs per component, y = e - t = 2 e - x in one)
                 const float er = zk.re + zm.re, ei = zk.im - zm.im;
                 const float dr = zk.re - zm.re, di = zk.im + zm.im;
-                const float tr = di * w.re + dr * w.im, ti = di * w.im - dr * w.re;
-                const float xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
+                const float xr = th_fma(di, w.re, th_fma(dr, w.im, er)), xi = th_fma(di, w.im, th_fma(-dr, w.re, ei));
+                const float yr = th_fma(2.0f, er, -xr), yi = th_fma(2.0f, ei, -xi);
                 if (q == 0 && s >= R3 / 2) {
                     emit(sb.hi, (s - R3 / 2) * NS3, xr * xr + xi * xi);
                     emit(sb.mhi, (R3 - 1 - s) * NS3, yr * yr + yi * yi);
