@@ -1,6 +1,6 @@
 #!/bin/bash
-# Development tool: build thesia_amd/libthesia_amd_<tag>.so with extra -D flags (A/B on one GPU box:
-# THESIA_AMD_LIB=thesia_amd/libthesia_amd_<tag>.so python scripts/bench_stft.py).
+# Development tool: build scripts/variants/libthesia_amd_<tag>.so (outside the package directory) with extra -D flags (A/B on one GPU box:
+# THESIA_AMD_LIB=scripts/variants/libthesia_amd_<tag>.so python scripts/bench_stft.py).
 # usage: scripts/build_variant.sh <tag> [flags...]     (run after __graft_entry__.build())
 # By default only kernels_stft.hip is recompiled; VARIANT_SOURCES="kernels_image.hip api.hip" picks others.
 set -e
@@ -21,5 +21,5 @@ for f in api.hip track_manager.hip kernels_stft.hip kernels_mel.hip kernels_imag
     objs="$objs build/$f.o"
   fi
 done
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../libthesia_amd_$tag.so $objs
-echo built thesia_amd/libthesia_amd_$tag.so
+mkdir -p ../../scripts/variants && hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scripts/variants/libthesia_amd_$tag.so $objs
+echo built scripts/variants/libthesia_amd_$tag.so

@@ -26,10 +26,33 @@ TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pm
 python3 scripts/bench_img.py > "$out/bench_img.txt" 2>&1
 python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
 { python3 scripts/bench_cfg4.py; KERNEL=3 python3 scripts/bench_cfg4.py; SR=48000 WIN=1920 HOP=480 python3 scripts/bench_cfg4.py; } > "$out/bench_cfg4.txt" 2>&1
+{
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 512
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 512 --win 320 --hop 80
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 1024
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 4096
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 8192
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 16384
+  python3 scripts/bench_stft.py --reps 30 --tracks 1 --seconds 60
+} >> "$out/bench_stft.txt" 2>&1
+# the RCCL path on one GPU (world size 1): the line bench.py prints with the process group up
+TH_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline --no-single-track --no-full-cfg5 2> /dev/null | grep '^{' | tail -1 > "$out/bench_line_force_dist.json"
+# package power / clocks next to the kernel loop and next to plain memory streams (scripts/power_probe.sh)
+{
+  for k in stft copy store; do
+    if [ $k = stft ]; then bash scripts/power_probe.sh "$out/pw_$k" python3 scripts/bench_stft.py --reps 20000
+    else bash scripts/power_probe.sh "$out/pw_$k" python3 scripts/power_loops.py $k 12; fi
+    echo "== $k loop: $(tail -1 $out/pw_$k.cmd)"; grep -E "Power|sclk" "$out/pw_$k" | tail -4
+  done
+  echo "== idle"; grep -E "Max Graphics|Package Power" "$out/pw_stft.idle"
+} > "$out/power.txt" 2>&1
+if [ -f scripts/variants/libthesia_amd_wt.so ]; then
+  THESIA_AMD_LIB=scripts/variants/libthesia_amd_wt.so python3 scripts/wave_times.py > "$out/wave_times.txt" 2>&1
+fi
 for u in lds_rate valu_rate valu_bank copy_rate row_stores; do
   [ -x scripts/ubench/$u ] && timeout 120 scripts/ubench/$u > "$out/ubench_$u.txt" 2>&1
 done
-if [ -f thesia_amd/libthesia_amd_prof.so ]; then
-  THESIA_AMD_LIB=thesia_amd/libthesia_amd_prof.so python3 scripts/phase_prof.py > "$out/phase_prof.txt" 2>&1
+if [ -f scripts/variants/libthesia_amd_prof.so ]; then
+  THESIA_AMD_LIB=scripts/variants/libthesia_amd_prof.so python3 scripts/phase_prof.py > "$out/phase_prof.txt" 2>&1
 fi
 ls -la "$out"

@@ -2,10 +2,12 @@
 """Turn the raw output of scripts/collect_profiles.sh (gpurun_out/final) into the tracked summaries under profiles/.
 usage: python scripts/make_profiles.py gpurun_out/final r01"""
 import csv
+import datetime
 import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
@@ -73,12 +75,17 @@ if os.path.exists(p):
                    "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
                    "correction": "gfx950 FETCH_SIZE x2 (calibrated, profiles/r01_fetch_calibration.txt); WRITE_SIZE exact",
                    "workload": "128 tracks x 30 s 48 kHz mono, n_fft=2048 hop=512 (scripts/bench_stft.py, same shapes as bench.py)",
-                   "algorithmic_bytes_per_launch": frames * bpf, "source": f"profiles/{tag}_stft_pmc_summary.txt"},
+                   "algorithmic_bytes_per_launch": frames * bpf, "source": f"profiles/{tag}_stft_pmc_summary.txt",
+                   "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes (scripts/pmc_stft.sh)",
+                   "date": datetime.date.today().isoformat(),
+                   "commit": subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                            text=True).stdout.strip() or "?"},
                   open(f"{dst}/stft_hbm_traffic.json", "w"), indent=1)
 
 # 5. plain-text measurement logs
 for f in ("bench_stft.txt", "bench_img.txt", "bench_cfg3.txt", "bench_cfg4.txt", "phase_prof.txt", "ubench_lds_rate.txt",
-          "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt"):
+          "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt", "wave_times.txt", "power.txt",
+          "bench_line_force_dist.json", "gputest.txt"):
     if os.path.exists(f"{src}/{f}"):
         txt = "\n".join(l for l in open(f"{src}/{f}").read().splitlines() if "amdgpu.ids" not in l) + "\n"
         open(f"{dst}/{tag}_{f}", "w").write(txt)

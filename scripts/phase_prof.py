@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development tool: per-phase shader-clock breakdown of the wave STFT kernel's frame loop.
 Build the instrumented variant first:  scripts/build_variant.sh prof -DTH_PHASE_PROF
-run:  THESIA_AMD_LIB=thesia_amd/libthesia_amd_prof.so python scripts/phase_prof.py [--nfft 2048]"""
+run:  THESIA_AMD_LIB=scripts/variants/libthesia_amd_prof.so python scripts/phase_prof.py [--nfft 2048]"""
 import argparse
 import ctypes
 import os

@@ -3,9 +3,9 @@
 out=gpurun_out/sched.txt
 : > $out
 timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/sched_tests.log 2>&1; echo "pytest rc=$?" >> $out; tail -3 gpurun_out/sched_tests.log >> $out
-THESIA_AMD_LIB=thesia_amd/libthesia_amd_wt.so timeout 300 python scripts/wave_times.py >> $out 2>&1
+THESIA_AMD_LIB=scripts/variants/libthesia_amd_wt.so timeout 300 python scripts/wave_times.py >> $out 2>&1
 for i in 1 2 3; do
-  for lib in thesia_amd/libthesia_amd_base.so thesia_amd/libthesia_amd.so; do
+  for lib in scripts/variants/libthesia_amd_base.so thesia_amd/libthesia_amd.so; do
     echo -n "$(basename $lib): " >> $out
     THESIA_AMD_LIB=$lib timeout 300 python scripts/bench_stft.py --reps 30 --gap-ms 1 2>&1 | tail -1 >> $out
   done

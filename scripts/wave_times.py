@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development tool: when does every wave of the wave STFT kernel start its frame loop and when does it finish?
 Build the instrumented variant first:  scripts/build_variant.sh wt -DTH_WAVE_TIMES
-run:  THESIA_AMD_LIB=thesia_amd/libthesia_amd_wt.so python scripts/wave_times.py [--nfft 2048]"""
+run:  THESIA_AMD_LIB=scripts/variants/libthesia_amd_wt.so python scripts/wave_times.py [--nfft 2048]"""
 import argparse
 import ctypes
 import os

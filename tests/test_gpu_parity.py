@@ -813,7 +813,7 @@ def _batch_on_gpu(ctx, plan, n_tr, n, seed):
     return wav, spec, mm
 
 
-@pytest.mark.parametrize("cfg", ["cfg5_shard", "cfg3", "cfg4_mel"])
+@pytest.mark.parametrize("cfg", ["cfg5_shard", "cfg3", "cfg4_mel", "queue_512", "queue_512_odd", "queue_1024", "queue_2048_odd"])
 def test_baseline_sizes_properties(ctx, cfg):
     """BASELINE.json configs at FULL size (the oracle cannot run these in test time): the batched launch must equal
     single-track launches of sampled tracks bit for bit (no cross-talk, chunk seams, boundary frames), agree with
@@ -823,12 +823,26 @@ def test_baseline_sizes_properties(ctx, cfg):
         sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (2048, 512, 2048), 128, 30 * 48000, ta.LINEAR, 0
     elif cfg == "cfg3":
         sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (4096, 1024, 4096), 128, 60 * 48000, ta.LINEAR, 0
-    else:
+    elif cfg == "cfg4_mel":
         sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 44100, (2048, 512, 2048), 32, 60 * 44100, ta.MEL, 128
+    # batches with (many) more chunks than the grid has waves, so that most chunks come from the device-wide queue, in the
+    # kernels and framings the BASELINE sizes do not reach: four / two frames per wave (a frame loop that advances by
+    # several frames), chunk lengths that are not multiples of that step, a hop that is no multiple of 128 samples
+    elif cfg == "queue_512":
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (320, 80, 512), 48, 20 * 48000, ta.LINEAR, 0
+    elif cfg == "queue_512_odd":
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (511, 127, 512), 37, 1200007, ta.LINEAR, 0
+    elif cfg == "queue_1024":
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (1000, 250, 1024), 60, 40 * 48000 + 11, ta.LINEAR, 0
+    else:
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (1801, 601, 2048), 53, 80 * 48000 + 5, ta.LINEAR, 0
     plan = ta.Plan(ctx, sr, win, hop, n_fft, scale, n_mel)
     wav, spec, mm = _batch_on_gpu(ctx, plan, n_tr, n, 123)
     T, H = plan.n_frames(n), plan.height
-    assert (n_tr * T) in (360064, 165376)
+    if cfg.startswith("cfg"):
+        assert (n_tr * T) in (360064, 165376)
+    else:
+        assert n_tr * T > 3 * 3072 * 32       # several rounds of chunks for every wave of the grid
     # every real cell written; the padding of a th_pitch_f32 row belongs to the library: either untouched or zeros up to
     # the end of the 128-byte line of the last bin (the wave kernel completes that line: a partial line costs HBM a
     # read-modify-write), never anything else

@@ -276,20 +276,21 @@ __device__ __forceinline__ FrameCursor cursor_at(const StftGeom &g, const ChanJo
 // before the current chunk ends — late, so that the launch's last chunks still go to whoever runs ahead, but early enough
 // that the atomic's round trip (served one at a time, ~8 ns each device-wide, and the waves of a launch tend to finish their
 // chunks together) is over when the chunk is.
-//     WaveSched s; TH_SCHED_INIT(s, wave index);
-//     while (s.cur.valid) { fetch(s.cur); for (frames f) { TH_SCHED_PULL(s, f, lane); ... } TH_SCHED_ADVANCE(s); }
+//     WaveSched s; TH_SCHED_INIT(s, wave index, frames ahead);
+//     while (s.cur.valid) { fetch(s.cur); for (frames f) { TH_SCHED_PULL(s, f, lane); ... } TH_SCHED_ADVANCE(s, lane); }
 #if !defined(TH_PULL_AHEAD)
 #define TH_PULL_AHEAD 2u
 #endif
 struct WaveSched {
     FrameCursor cur;
-    uint32_t pull_f, pulled, n_waves;
+    uint32_t pull_f, pulled, n_waves, ahead;
     bool use_queue, armed;
 };
 #define TH_SCHED_ARM(S) /* the frame at (or after) whose start the next chunk's index is pulled */          \
-    ((S).pull_f = (S).cur.f1 - (S).cur.f > TH_PULL_AHEAD ? (S).cur.f1 - TH_PULL_AHEAD : (S).cur.f, (S).armed = (S).use_queue)
-#define TH_SCHED_INIT(S, WAVE_INDEX)                                                                       \
+    ((S).pull_f = (S).cur.f1 - (S).cur.f > (S).ahead ? (S).cur.f1 - (S).ahead : (S).cur.f, (S).armed = (S).use_queue)
+#define TH_SCHED_INIT(S, WAVE_INDEX, AHEAD) /* AHEAD >= the frame loop's step, so that the loop cannot step over pull_f */ \
     do {                                                                                                   \
+        (S).ahead = (AHEAD);                                                                               \
         (S).n_waves = gridDim.x * WAVES;                                                                   \
         (S).use_queue = (S).n_waves < n_tiles; /* else: every chunk is some wave's first */                \
         (S).cur = cursor_at(g, jobs, chunk_tab, n_tiles, (WAVE_INDEX));                                    \
@@ -303,8 +304,11 @@ struct WaveSched {
             if ((LANE) == 0) (S).pulled = atomicAdd(queue_head, 1u);                                       \
         }                                                                                                  \
     } while (0)
-#define TH_SCHED_ADVANCE(S)                                                                                \
+#define TH_SCHED_ADVANCE(S, LANE)                                                                          \
     do {                                                                                                   \
+        /* still armed: the frame loop never reached pull_f (a loop that advances by several frames may step over it; \
+           without this pull the wave would walk the same chunk again, forever) */                         \
+        if ((S).armed && (LANE) == 0) (S).pulled = atomicAdd(queue_head, 1u);                               \
         const uint32_t t_ = (S).use_queue ? __builtin_amdgcn_readfirstlane((S).pulled) + (S).n_waves : n_tiles; \
         (S).cur = cursor_at(g, jobs, chunk_tab, n_tiles, t_);                                              \
         TH_SCHED_ARM(S);                                                                                   \
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     unsigned long long wt_frames = 0, wt_start = 0, wt_chunks = 0;
 #endif
     WaveSched sch;
-    TH_SCHED_INIT(sch, blockIdx.x * WAVES + wave);
+    TH_SCHED_INIT(sch, blockIdx.x * WAVES + wave, TH_PULL_AHEAD);
     while (sch.cur.valid) {
 #if defined(TH_WAVE_TIMES)
         const unsigned long long wt_pull0 = wall_clock64();
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #if defined(TH_WAVE_TIMES)
         wt_frames += cur.f1 - cur.f;
 #endif
-        TH_SCHED_ADVANCE(sch);
+        TH_SCHED_ADVANCE(sch, lane);
     }
     TH_WT_STORE(2, wall_clock64());
 #if defined(TH_WAVE_TIMES)
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
     const uint32_t lane_wave = tid & 63u;
     const cf32 w_mid = stw[NC / 2];
     WaveSched sch;
-    TH_SCHED_INIT(sch, blockIdx.x * WAVES + wave);
+    TH_SCHED_INIT(sch, blockIdx.x * WAVES + wave, (uint32_t)G > TH_PULL_AHEAD ? (uint32_t)G : TH_PULL_AHEAD);
     while (sch.cur.valid) {
         const FrameCursor &cur = sch.cur;
         float lmin = __builtin_inff(), lmax = -__builtin_inff();
@@ -877,7 +881,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
                 minmax[2 * (size_t)cur.t + 1] = b;
             }
         }
-        TH_SCHED_ADVANCE(sch);
+        TH_SCHED_ADVANCE(sch, lane_wave);
     }
 }
 

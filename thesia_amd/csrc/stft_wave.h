@@ -275,9 +275,11 @@ struct WaveFft {
     // i.e. four inner butterflies with t = w^4 and four outer ones with t = w W16^m' — 10 table entries per lane
     // (w^4, w^8, then t, t^2 for m' = 0..3) instead of 15, 192 FMAs instead of 60 + 160 operations.  Pass 3 needs (t, t^2)
     // per butterfly instead of (t, t^2, t^3).
-    static constexpr bool FMA_TW = (R1 == 16 && R2 == 16 && P == 16 && R3 == 4);
-    static constexpr int NT2 = FMA_TW ? 10 : R2 - 1;  // pass-2 twiddles per lane
-    static constexpr int NT3 = FMA_TW ? 2 : R3 - 1;   // pass-3 twiddles per butterfly
+    // n_fft = 4096 (R1 = R2 = 16, R3 = 8, two radix-16 butterflies per lane and pass) runs the same way; its radix-8 last
+    // pass is two bfly4_tw (base t^2) and four bfly2_tw with t W8^m': table entries (t, t^2, t^4, t W8) instead of t .. t^7.
+    static constexpr bool FMA_TW = (R1 == 16 && R2 == 16 && ((P == 16 && R3 == 4) || (P == 32 && R3 == 8)));
+    static constexpr int NT2 = FMA_TW ? 10 : R2 - 1;                  // pass-2 twiddles per lane
+    static constexpr int NT3 = FMA_TW ? (R3 == 4 ? 2 : 4) : R3 - 1;   // pass-3 twiddles per butterfly
     static constexpr int T2_LEN = NT2 * NS2, T3_LEN = NT3 * NS3;
     static_assert(NS2 <= 64, "pass-2 twiddle index must be butterfly independent");
     // tw[i] = exp(-2 pi i * i / n_fft), n_fft = 2*NC  ->  W_{M}^{e} = tw[e * (2*NC / M)]
@@ -296,7 +298,13 @@ struct WaveFft {
         }
         for (uint32_t i = tid; i < (uint32_t)T3_LEN; i += nthr) {
             const uint32_t r = i / NS3 + 1, k = i % NS3;
-            t3[i] = tw[(r * k) * (2 * NC / (NS3 * R3))];
+            if constexpr (FMA_TW && R3 == 8) {
+                // t = W_Nc^k = tw[2 k]: entries t, t^2, t^4, t W8
+                const uint32_t e = i / NS3;
+                t3[i] = tw[(e < 3 ? (2u << e) * k : 2u * k + (uint32_t)(2 * NC / 8)) % (uint32_t)(2 * NC)];
+            } else {
+                t3[i] = tw[(r * k) * (2 * NC / (NS3 * R3))];
+            }
         }
     }
 
@@ -320,25 +328,42 @@ struct WaveFft {
     // mod 32 dwords), scripts/ubench/stft_skeleton.hip.
     // -----------------------------------------------------------------------------------------
     static constexpr bool PLANES = (R1 == 16 && R2 == 16 && P == 16);
+    // -----------------------------------------------------------------------------------------
+    // The same for n_fft = 4096 (P = 32: two radix-16 butterflies per lane in passes 1 and 2, radix 8 last): 32 + 32 planes
+    // per exchange, plane 16 b + c = output c of a lane's butterfly b.
+    //   pass 1: lane l owns column lane_col(l) = (l >> 3) + 8 (l & 7); butterfly b takes its points col + 64 (b + 2 r).
+    //   pass 2: lane l owns butterflies j = 16 a + c, c = l >> 2 (twiddle index), a = 2 (l & 3) + b, b = 0, 1.  Inputs
+    //           in[j + 128 r] = pass-1 output c of column a + 8 (r & 7), butterfly r >> 3 = plane 16 (r >> 3) + c, lanes
+    //           8 a .. 8 a + 7: two 16-byte loads.  (a = 2 (l & 3) + b and not (l & 3) + 4 b: the quad index of a load is then
+    //           17 c + 4 (l & 3) + const mod 16 — distinct over a 16-lane group, no bank conflicts at pitch 68.)
+    //   pass 3: natural mirror-local pairs; in[jj + 256 r] = pass-2 output jj >> 4 of butterfly 16 r + (jj & 15), which
+    //           lane 4 (jj & 15) + (r >> 1) computed as its butterfly r & 1 = plane 16 (r & 1) + (jj >> 4), lanes
+    //           4 (jj & 15) .. + 3: one 16-byte load per butterfly, component and r parity; float offset 1024 (r & 1) + 4 jj.
+    // -----------------------------------------------------------------------------------------
+    static constexpr bool PLANES32 = (R1 == 16 && R2 == 16 && P == 32 && R3 == 8);
+    static constexpr bool ANYPLANES = PLANES || PLANES32;
+    static constexpr int NPL = PLANES32 ? 32 : 16;  // planes per component
     static constexpr int PITCH1 = 68, PITCH2 = 64;
-    static TH_HD uint32_t lane_col(uint32_t lane) { return PLANES ? 4u * (lane & 15u) + (lane >> 4) : lane; }
-    template <int PITCH, int G>
-    static TH_HD void st_group(float *slab, uint32_t lane, cf32 (&v)[16]) {
-        lds_st_planes4<G * PITCH * 4, (16 + G) * PITCH * 4, 16 * PITCH>(slab, lane, v[4 * G], v[4 * G + 1], v[4 * G + 2],
-                                                                            v[4 * G + 3]);
+    static TH_HD uint32_t lane_col(uint32_t lane) {
+        return PLANES ? 4u * (lane & 15u) + (lane >> 4) : PLANES32 ? (lane >> 3) + 8u * (lane & 7u) : lane;
     }
-    template <int PITCH>
+    // outputs 4 i + G (i = 0..3) of a radix-16 butterfly (held in v0..v3) -> planes B0 + G + 4 i
+    template <int PITCH, int B0, int G>
+    static TH_HD void st_group4(float *slab, uint32_t lane, cf32 v0, cf32 v1, cf32 v2, cf32 v3) {
+        lds_st_planes4<(B0 + G) * PITCH * 4, (NPL + B0 + G) * PITCH * 4, 16 * PITCH>(slab, lane, v0, v1, v2, v3);
+    }
+    template <int PITCH, int B0 = 0>
     static TH_HD void dft16_to_planes(uint32_t lane, cf32 (&v)[16], cf32 *slab) {
         float *const sf = reinterpret_cast<float *>(slab);
         dft16_head(v);
         dft16_tail<0>(v);
-        st_group<PITCH, 0>(sf, lane, v);
+        st_group4<PITCH, B0, 0>(sf, lane, v[0], v[1], v[2], v[3]);
         dft16_tail<1>(v);
-        st_group<PITCH, 1>(sf, lane, v);
+        st_group4<PITCH, B0, 1>(sf, lane, v[4], v[5], v[6], v[7]);
         dft16_tail<2>(v);
-        st_group<PITCH, 2>(sf, lane, v);
+        st_group4<PITCH, B0, 2>(sf, lane, v[8], v[9], v[10], v[11]);
         dft16_tail<3>(v);
-        st_group<PITCH, 3>(sf, lane, v);
+        st_group4<PITCH, B0, 3>(sf, lane, v[12], v[13], v[14], v[15]);
     }
 
     // pass 1 (Ns = 1, no twiddles): registers -> LDS slab
@@ -347,6 +372,17 @@ struct WaveFft {
             cf32 v[16];
             TH_UNROLL for (int r = 0; r < 16; r++) v[r] = z[r];
             dft16_to_planes<PITCH1>(lane, v, slab);
+        } else if constexpr (PLANES32) {
+            {
+                cf32 v[16];
+                TH_UNROLL for (int r = 0; r < 16; r++) v[r] = z[2 * r];
+                dft16_to_planes<PITCH1, 0>(lane, v, slab);
+            }
+            {
+                cf32 v[16];
+                TH_UNROLL for (int r = 0; r < 16; r++) v[r] = z[2 * r + 1];
+                dft16_to_planes<PITCH1, 16>(lane, v, slab);
+            }
         } else {
             TH_UNROLL for (int b = 0; b < B1; b++) {
                 cf32 v[R1];
@@ -371,6 +407,22 @@ struct WaveFft {
                 z[4 * t + 2] = {re[t].c, im[t].c};
                 z[4 * t + 3] = {re[t].d, im[t].d};
             }
+        } else if constexpr (PLANES32) {
+            // input r of the lane's butterfly b -> z[b + 2 r]: plane 16 (r >> 3) + c, lane 16 (l & 3) + 8 b + (r & 7)
+            const float *const sf = reinterpret_cast<const float *>(slab) + (lane >> 2) * PITCH1 + 16u * (lane & 3u);
+            TH_UNROLL for (int b = 0; b < 2; b++) {
+                f32x4 re[4], im[4];
+                TH_UNROLL for (int h = 0; h < 4; h++) {  // h = 2 (r >> 3) + ((r & 7) >> 2)
+                    re[h] = lds_ld4(sf + (16 * (h >> 1)) * PITCH1 + 8 * b + 4 * (h & 1));
+                    im[h] = lds_ld4(sf + (NPL + 16 * (h >> 1)) * PITCH1 + 8 * b + 4 * (h & 1));
+                }
+                TH_UNROLL for (int h = 0; h < 4; h++) {
+                    z[b + 2 * (4 * h)] = {re[h].a, im[h].a};
+                    z[b + 2 * (4 * h + 1)] = {re[h].b, im[h].b};
+                    z[b + 2 * (4 * h + 2)] = {re[h].c, im[h].c};
+                    z[b + 2 * (4 * h + 3)] = {re[h].d, im[h].d};
+                }
+            }
         } else {
             TH_UNROLL for (int m = 0; m < P; m++) z[m] = lds_ld(&slab[pad1(lane) + 68u * m]);  // = pad1(lane + 64*m)
         }
@@ -381,7 +433,7 @@ struct WaveFft {
     // the whole LDS latency): load_t2 -> pass2_twiddle -> pass2_dft.  pass2() is the composition.
     static TH_HD void load_t2(uint32_t lane, cf32 (&w2)[NT2], const cf32 *t2) {
         // NS2 <= 64: the same twiddles for every butterfly of the lane
-        const uint32_t k = PLANES ? lane >> 2 : lane & (NS2 - 1);
+        const uint32_t k = ANYPLANES ? lane >> 2 : lane & (NS2 - 1);
         TH_UNROLL for (int r = 0; r < NT2; r++) w2[r] = lds_ld(&t2[r * NS2 + k]);
     }
     static TH_HD void pass2_twiddle(cf32 (&z)[P], const cf32 (&w2)[NT2]) {
@@ -390,36 +442,46 @@ struct WaveFft {
                 TH_UNROLL for (int r = 1; r < R2; r++) z[b + B2 * r] = cmul(z[b + B2 * r], w2[r - 1]);
         }
     }
-    // FMA plan: twiddled radix-16 butterfly of pass 2 straight into the planes of exchange 2 (see FMA_TW above)
-    static TH_HD void pass2_dft_tw(uint32_t lane, cf32 (&v)[P], const cf32 (&w)[NT2], cf32 *slab) {
-        if constexpr (FMA_TW) {
-            float *const sf = reinterpret_cast<float *>(slab);
-            // inner butterflies over a (inputs v[b + 4 a]), t = w^4: y_b[m'] ends up in v[b + 4 pi(m')], pi = (0, 2, 1, 3)
-            TH_UNROLL for (int b = 0; b < 4; b++) bfly4_tw(v[b], v[4 + b], v[8 + b], v[12 + b], w[0], w[1]);
-            // outer butterfly m' over b (inputs y_b[m']), t = w W16^m': X[m' + 4 m''], m'' = 0..3 -> planes m' + 4 m''
+    // FMA plan: twiddled radix-16 butterfly of pass 2 straight into the planes B0 .. B0 + 15 of exchange 2 (see FMA_TW above)
+    template <int B0>
+    static TH_HD void dft16_tw_to_planes(uint32_t lane, cf32 (&v)[16], const cf32 (&w)[NT2], cf32 *slab) {
+        float *const sf = reinterpret_cast<float *>(slab);
+        // inner butterflies over a (inputs v[b + 4 a]), t = w^4: y_b[m'] ends up in v[b + 4 pi(m')], pi = (0, 2, 1, 3)
+        TH_UNROLL for (int b = 0; b < 4; b++) bfly4_tw(v[b], v[4 + b], v[8 + b], v[12 + b], w[0], w[1 % NT2]);
+        // outer butterfly m' over b (inputs y_b[m']), t = w W16^m': X[m' + 4 m''], m'' = 0..3 -> planes m' + 4 m''
 #define TH_OUTER(MP, PI)                                                                                          \
-    bfly4_tw(v[4 * (PI)], v[4 * (PI) + 1], v[4 * (PI) + 2], v[4 * (PI) + 3], w[2 + 2 * (MP)], w[3 + 2 * (MP)]);  \
-    lds_st_planes4<(MP) * PITCH2 * 4, (16 + (MP)) * PITCH2 * 4, 16 * PITCH2>(sf, lane, v[4 * (PI)], v[4 * (PI) + 2],  \
-                                                                              v[4 * (PI) + 1], v[4 * (PI) + 3])
-            TH_OUTER(0, 0);
-            TH_OUTER(1, 2);
-            TH_OUTER(2, 1);
-            TH_OUTER(3, 3);
+    bfly4_tw(v[4 * (PI)], v[4 * (PI) + 1], v[4 * (PI) + 2], v[4 * (PI) + 3], w[(2 + 2 * (MP)) % NT2], w[(3 + 2 * (MP)) % NT2]); \
+    st_group4<PITCH2, B0, (MP)>(sf, lane, v[4 * (PI)], v[4 * (PI) + 2], v[4 * (PI) + 1], v[4 * (PI) + 3])
+        TH_OUTER(0, 0);
+        TH_OUTER(1, 2);
+        TH_OUTER(2, 1);
+        TH_OUTER(3, 3);
 #undef TH_OUTER
+    }
+    static TH_HD void pass2_dft_tw(uint32_t lane, cf32 (&z)[P], const cf32 (&w)[NT2], cf32 *slab) {
+        if constexpr (PLANES) {
+            dft16_tw_to_planes<0>(lane, z, w, slab);
+        } else if constexpr (PLANES32) {
+            {
+                cf32 v[16];
+                TH_UNROLL for (int r = 0; r < 16; r++) v[r] = z[2 * r];
+                dft16_tw_to_planes<0>(lane, v, w, slab);
+            }
+            {
+                cf32 v[16];
+                TH_UNROLL for (int r = 0; r < 16; r++) v[r] = z[2 * r + 1];
+                dft16_tw_to_planes<16>(lane, v, w, slab);
+            }
         }
     }
-    static TH_HD void pass2_dft(uint32_t lane, cf32 (&z)[P], cf32 *slab) {
-        if constexpr (PLANES) {
-            dft16_to_planes<PITCH2>(lane, z, slab);
-        } else {
-            TH_UNROLL for (int b = 0; b < B2; b++) {
-                const uint32_t jj = lane + 64u * b, k = jj & (NS2 - 1);
-                cf32 v[R2];
-                TH_UNROLL for (int r = 0; r < R2; r++) v[r] = z[b + B2 * r];
-                RegDft<R2>::run(v);
-                const uint32_t j0 = (jj - k) * R2 + k;
-                TH_UNROLL for (int r = 0; r < R2; r++) lds_st(&slab[j0 + r * NS2], v[RegDft<R2>::slot(r)]);
-            }
+    static TH_HD void pass2_dft(uint32_t lane, cf32 (&z)[P], cf32 *slab) {  // (plans without FMA_TW)
+        TH_UNROLL for (int b = 0; b < B2; b++) {
+            const uint32_t jj = lane + 64u * b, k = jj & (NS2 - 1);
+            cf32 v[R2];
+            TH_UNROLL for (int r = 0; r < R2; r++) v[r] = z[b + B2 * r];
+            RegDft<R2>::run(v);
+            const uint32_t j0 = (jj - k) * R2 + k;
+            TH_UNROLL for (int r = 0; r < R2; r++) lds_st(&slab[j0 + r * NS2], v[RegDft<R2>::slot(r)]);
         }
     }
     // twiddles + butterflies + stores of pass 2 (either plan)
@@ -457,7 +519,7 @@ struct WaveFft {
     // index (Nc - lane - 64*(P-1)) + 64*(P-1-m) = per-lane base + immediate.
     static_assert(32 % R1 == 0, "pad1 needs R1 | 32");
     static constexpr int SLAB_LEN = NC + NC / 16;  // padded pass-1 image is the largest (>= NC + 1)
-    static_assert(!PLANES || 2 * SLAB_LEN >= 32 * PITCH1, "slab holds the 32 planes of exchange 1");
+    static_assert(!ANYPLANES || 2 * SLAB_LEN >= 2 * NPL * PITCH1, "slab holds the planes of exchange 1");
     static TH_HD void write_z(uint32_t lane, const cf32 (&z)[P], cf32 *slab) {
         TH_UNROLL for (int m = 0; m < P; m++) slab[lane + 64u * m] = z[m];
         if (lane == 0) slab[NC] = z[0];
@@ -527,6 +589,29 @@ struct WaveFft {
                 zb[q][2 % R3] = {br[q].c, bi[q].c};
                 zb[q][3 % R3] = {br[q].d, bi[q].d};
             }
+        } else if constexpr (PLANES32) {
+            // input r of butterfly jj: component planes 16 (r & 1) + (jj >> 4), quad r >> 1 of the 16 bytes at float 4 jj
+            const float *const sf = reinterpret_cast<const float *>(slab);
+            TH_UNROLL for (int q = 0; q < NQ; q++) {
+                const float *const pa = sf + (pbs.a * 4u + 256u * (uint32_t)q), *const pb = sf + pb_b(pbs, q, 4u, 0u);
+                f32x4 ar[2], ai[2], br[2], bi[2];
+                TH_UNROLL for (int b = 0; b < 2; b++) {
+                    ar[b] = lds_ld4(pa + 16 * b * PITCH2);
+                    ai[b] = lds_ld4(pa + (NPL + 16 * b) * PITCH2);
+                    br[b] = lds_ld4(pb + 16 * b * PITCH2);
+                    bi[b] = lds_ld4(pb + (NPL + 16 * b) * PITCH2);
+                }
+                TH_UNROLL for (int b = 0; b < 2; b++) {
+                    za[q][(0 + b) % R3] = {ar[b].a, ai[b].a};
+                    za[q][(2 + b) % R3] = {ar[b].b, ai[b].b};
+                    za[q][(4 + b) % R3] = {ar[b].c, ai[b].c};
+                    za[q][(6 + b) % R3] = {ar[b].d, ai[b].d};
+                    zb[q][(0 + b) % R3] = {br[b].a, bi[b].a};
+                    zb[q][(2 + b) % R3] = {br[b].b, bi[b].b};
+                    zb[q][(4 + b) % R3] = {br[b].c, bi[b].c};
+                    zb[q][(6 + b) % R3] = {br[b].d, bi[b].d};
+                }
+            }
         } else {
             TH_UNROLL for (int q = 0; q < NQ; q++) {
                 const uint32_t a = jj_a(lane, q), b = jj_b(lane, q);
@@ -550,11 +635,27 @@ struct WaveFft {
         }
     }
     static TH_HD void bfly3(cf32 (&v)[R3], const cf32 (&w3)[NT3]) {
-        if constexpr (FMA_TW) {  // (t, t^2): a = X0, c = X1, b = X2, d = X3
+        if constexpr (FMA_TW && R3 == 4) {  // (t, t^2): a = X0, c = X1, b = X2, d = X3
             bfly4_tw(v[0], v[1 % R3], v[2 % R3], v[3 % R3], w3[0], w3[1 % NT3]);
             const cf32 x1 = v[2 % R3];
             v[2 % R3] = v[1 % R3];
             v[1 % R3] = x1;
+            return;
+        }
+        if constexpr (FMA_TW && R3 == 8) {
+            // X[m' + 4 m''] = Y0[m'] + (-1)^m'' (t W8^m') Y1[m'],  Yb[m'] = sum_a (t^2)^a W4^(a m') x[2 a + b];  w3 = (t, t^2, t^4, t W8)
+            const cf32 t = w3[0], t2 = w3[1 % NT3], t4 = w3[2 % NT3], t8 = w3[3 % NT3];
+            bfly4_tw(v[0], v[2 % R3], v[4 % R3], v[6 % R3], t2, t4);  // Y0[0..3] in v0, v4, v2, v6
+            bfly4_tw(v[1 % R3], v[3 % R3], v[5 % R3], v[7 % R3], t2, t4);  // Y1[0..3] in v1, v5, v3, v7
+            bfly2_tw(v[0], v[1 % R3], t.re, t.im);           // X0, X4
+            bfly2_tw(v[4 % R3], v[5 % R3], t8.re, t8.im);    // X1, X5
+            bfly2_tw(v[2 % R3], v[3 % R3], t.im, -t.re);     // X2, X6   (-i t)
+            bfly2_tw(v[6 % R3], v[7 % R3], t8.im, -t8.re);   // X3, X7   (-i t W8)
+            const cf32 x1 = v[4 % R3], x3 = v[6 % R3], x4 = v[1 % R3], x6 = v[3 % R3];
+            v[1 % R3] = x1;
+            v[3 % R3] = x3;
+            v[4 % R3] = x4;
+            v[6 % R3] = x6;
             return;
         }
         cf32 w[R3];
