@@ -391,7 +391,7 @@ __device__ __forceinline__ void wave_frame(
             z[m] = {v.re * rw[m].re, v.im * rw[m].im};
         }
     } else {
-        wave_window_rot<P, OFF>(col, z, x, wtab);
+        wave_window_rot<P, OFF>(W::PLANES32 ? lane : col, z, x, wtab);  // (4096: table stored in lane order, see the kernel)
     }
     // Request the next frame of the chunk now: its samples land while this frame is transformed.  The fetch
     // is unconditional (branch-free register flow: no copies of x[]); on the last frame of a chunk it simply
@@ -614,8 +614,13 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         TH_WT_STORE(4, ((unsigned long long)xcc_id << 32) | hw_id);
     }
 #endif
+    // n_fft 4096: the window pairs are stored in the order the lanes read them (lane l reads the pair of column
+    // lane_col(l) = (l >> 3) + 8 (l & 7): consecutive lanes would be 64 bytes apart, a 2-way bank conflict on all 32 reads)
+    constexpr bool WPERM = W::PLANES32;
+    static_assert(!WPERM || (!PHASED && !DYN), "the shifted window tables are read by column");
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
-        wtab[WPAD + i] = wtab_g[WPAD + i];
+        const uint32_t col = i & 63u, li = WPERM ? (i & ~63u) + 8u * (col & 7u) + (col >> 3) : i;
+        wtab[WPAD + li] = wtab_g[WPAD + i];
         if constexpr (STW_IN_LDS) stw[i] = tw[i];
     }
     for (uint32_t i = tid; i < WPAD; i += 64 * WAVES) wtab[i] = wtab_g[i];
@@ -653,7 +658,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     cf32 rwa[(RESK & 4) ? W::NQ : 1][W::NT3], rwb[(RESK & 4) ? W::NQ : 1][W::NT3], rws[(RESK & 8) ? W::NQ : 1][W::R3];
     if constexpr (RESK & 1) {
 #pragma unroll
-        for (int m = 0; m < P; m++) rw[m] = wtab[W::lane_col(lane) + 64u * m];
+        for (int m = 0; m < P; m++) rw[m] = wtab[(WPERM ? lane : W::lane_col(lane)) + 64u * m];
     }
     if constexpr (RESK & 2) W::load_t2(lane, rw2, t2);
     if constexpr (RESK & 4) W::load_t3_paired(lane, rwa, rwb, t3);
