@@ -6,7 +6,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final
 rm -rf "$out"; mkdir -p "$out"
-python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
+echo "bench" >> "$out/progress.txt"; python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-single-track > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 find "$out/trace" -type f ! -name "*kernel_stats.csv" -delete
 scripts/pmc_stft.sh "$out/pmc_stft" > "$out/pmc_stft.log" 2>&1
@@ -36,7 +36,7 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 30 --tracks 1 --seconds 60
 } >> "$out/bench_stft.txt" 2>&1
 # the RCCL path on one GPU (world size 1): the line bench.py prints with the process group up
-TH_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu-baseline --no-single-track --no-full-cfg5 2> /dev/null | grep '^{' | tail -1 > "$out/bench_line_force_dist.json"
+TH_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-single-track --no-full-cfg5 > "$out/force_dist.out" 2> "$out/force_dist.err"; grep "^{" "$out/force_dist.out" | tail -1 > "$out/bench_line_force_dist.json"
 # package power / clocks next to the kernel loop and next to plain memory streams (scripts/power_probe.sh)
 {
   for k in stft copy store; do

@@ -80,12 +80,11 @@ static void emu_frames_multi(const float *wav, const uint32_t *frames, const Stf
     }
     for (uint32_t l = 0; l < 64; l++) W::pass1(l, z[l], slab.data());
     for (uint32_t l = 0; l < 64; l++) W::read1(l, z[l], slab.data());
-    for (uint32_t l = 0; l < 64; l++) {
-        cf32 w2[15];
-        W::load_t2(l, w2, t2.data());
-        W::pass2_twiddle(z[l], w2);
+    {
+        static cf32 w2[64][W::NT2];
+        for (uint32_t l = 0; l < 64; l++) W::load_t2(l, w2[l], t2.data());
+        for (uint32_t l = 0; l < 64; l++) W::pass2_w(l, z[l], w2[l], slab.data());
     }
-    for (uint32_t l = 0; l < 64; l++) W::pass2_dft(l, z[l], slab.data());
     static cf32 za[64][W::NQ][W::R3], zb[64][W::NQ][W::R3];
     for (uint32_t l = 0; l < 64; l++) W::read2_paired(l, za[l], zb[l], slab.data());
     for (uint32_t l = 0; l < 64; l++) {
@@ -98,7 +97,8 @@ static void emu_frames_multi(const float *wav, const uint32_t *frames, const Stf
         cf32 ws[W::NQ][W::R3];
         W::load_stw_paired(l, ws, tw);
         const uint32_t gi = W::grp(l);
-        W::split_paired_w(l, za[l], zb[l], ws, tw[NC / 2], [&](int32_t k, float p) {
+        W::split_paired_w(l, za[l], zb[l], ws, tw[NC / 2], [&](uint32_t kb, int kc, float p) {
+            const uint32_t k = kb + (uint32_t)kc;
             rows[gi][k] = power_to_dB(p);
             hits[gi * (NC + 1) + k]++;
         });

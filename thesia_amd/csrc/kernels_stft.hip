@@ -606,6 +606,22 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // wave index is wave-uniform: tell the compiler, so the frame cursor lives in SGPRs / SALU
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     TH_WT_STORE(0, wall_clock64());
+    // The wave's first chunk is known from its index alone: look it up and request its first frame before anything else,
+    // so that the samples travel while the workgroup fills its LDS tables (a single-track launch is one or two frames per
+    // wave: its run time is this start-up).
+    WaveSched sch;
+    TH_SCHED_INIT(sch, blockIdx.x * WAVES + wave, TH_PULL_AHEAD);
+    cf32 x[P];  // raw samples of the current frame; the frame body refills it for the next one
+#define TH_FETCH_FIRST()                                                                                                   \
+    do {                                                                                                                   \
+        if (sch.cur.valid) {                                                                                               \
+            if (sch.cur.edge) /* wave-uniform */                                                                           \
+                wave_fetch_reflect<P>(W::lane_col(lane), x, sch.cur.wav, frame_e0(sch.cur, g), sch.cur.n_samples);         \
+            else                                                                                                           \
+                wave_fetch<P, 0>(W::lane_col(lane), x, sch.cur.wav, frame_e0(sch.cur, g));                                 \
+        }                                                                                                                  \
+    } while (0)
+    TH_FETCH_FIRST();
 #if defined(TH_WAVE_TIMES)
     {
         uint32_t hw_id, xcc_id;
@@ -675,18 +691,13 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #if defined(TH_WAVE_TIMES)
     unsigned long long wt_frames = 0, wt_start = 0, wt_chunks = 0;
 #endif
-    WaveSched sch;
-    TH_SCHED_INIT(sch, blockIdx.x * WAVES + wave, TH_PULL_AHEAD);
-    while (sch.cur.valid) {
 #if defined(TH_WAVE_TIMES)
-        const unsigned long long wt_pull0 = wall_clock64();
+    unsigned long long wt_pull0 = wall_clock64();
 #endif
+    while (sch.cur.valid) {
         const FrameCursor &cur = sch.cur;
         lmin = __builtin_inff();
         lmax = -__builtin_inff();
-        cf32 x[P];  // raw samples of the current frame; the frame body refills it for the next one
-        if (cur.edge) wave_fetch_reflect<P>(W::lane_col(lane), x, cur.wav, frame_e0(cur, g), cur.n_samples);  // wave-uniform
-        else wave_fetch<P, 0>(W::lane_col(lane), x, cur.wav, frame_e0(cur, g));
 #if defined(TH_WAVE_TIMES)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (instrumented build only: chunk-start time up to the arrival of the first frame)
         wt_start += wall_clock64() - wt_pull0;
@@ -742,8 +753,13 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #if defined(TH_WAVE_TIMES)
         wt_frames += cur.f1 - cur.f;
 #endif
+#if defined(TH_WAVE_TIMES)
+        wt_pull0 = wall_clock64();
+#endif
         TH_SCHED_ADVANCE(sch, lane);
+        TH_FETCH_FIRST();  // the next chunk's first frame
     }
+#undef TH_FETCH_FIRST
     TH_WT_STORE(2, wall_clock64());
 #if defined(TH_WAVE_TIMES)
     TH_WT_STORE(3, wt_frames | (wt_chunks << 16) | (wt_start << 32));
@@ -844,15 +860,14 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
                 fetch(x, fn, lane);
             }
             TH_SCHED_BARRIER();
-            cf32 w2[15];
+            cf32 w2[W::NT2];
             W::load_t2(lane, w2, t2);
             W::pass1(lane, z, slab);
             wave_lds_sync();
             TH_SCHED_BARRIER();
             W::read1(lane, z, slab);
             wave_lds_sync();
-            W::pass2_twiddle(z, w2);
-            W::pass2_dft(lane, z, slab);
+            W::pass2_w(lane, z, w2, slab);
             wave_lds_sync();
             TH_SCHED_BARRIER();
             cf32 wa[W::NW3], wb[W::NW3];
@@ -867,9 +882,9 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
             TH_SCHED_BARRIER();
             const uint32_t grp = W::grp(lane), last = cur.f1 - 1u - f, dg = grp < last ? grp : last;
             const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch + (size_t)dg * cur.spec_pitch;
-            W::split_paired_w(lane, za, zb, ws, w_mid, [&](int32_t k, float p) {
+            W::split_paired_w(lane, za, zb, ws, w_mid, [&](uint32_t kb, int kc, float p) {
                 const float d = power_to_dB(p);
-                row[k] = d;
+                *(gptr<float>)((gptr<char>)row + (uint64_t)(kb << 2) + (int64_t)(4 * kc)) = d;  // base + immediate (split_base)
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             });

@@ -39,12 +39,17 @@ struct WaveFftM {
     static constexpr int NQ = 8 / R3;     // mirror pairs of butterflies per lane
     static constexpr int PITCH1 = 68, PITCH2 = 64;  // dwords per plane (2-way conflicts at worst on the 16-/8-byte reads)
     static constexpr int SLAB_LEN = 16 * PITCH1;    // cf32 units: 32 planes of PITCH1 dwords (exchange 1 is the larger)
-    static constexpr int T2_LEN = 15 * 16, T3_LEN = (R3 - 1) * NS3;
+    // pass 2 runs as the fused-multiply-add butterflies of the 2048 plan (WaveFft<10>::dft16_tw_to_planes): 10 table
+    // entries per twiddle index c — w^4, w^8, then t, t^2 for t = w W16^m', m' = 0..3, w = W_256^c
+    static constexpr int NT2 = 10;
+    static constexpr int T2_LEN = NT2 * 16, T3_LEN = (R3 - 1) * NS3;
     // tw[i] = exp(-2 pi i * i / n_fft), n_fft = 2 Nc
     static TH_HD void fill_tables(uint32_t tid, uint32_t nthr, const cf32 *tw, cf32 *t2, cf32 *t3) {
+        constexpr uint32_t S = 2 * NC / 256, S16 = 2 * NC / 16, M = 2 * NC;
         for (uint32_t i = tid; i < (uint32_t)T2_LEN; i += nthr) {
-            const uint32_t r = i / 16 + 1, k = i % 16;
-            t2[i] = tw[(r * k) * (2 * NC / 256)];  // W_256^(r k)
+            const uint32_t e = i / 16, k = i % 16;
+            const uint32_t mp = e >= 2 ? (e - 2) / 2 : 0, pw = e < 2 ? 4u * (e + 1u) : 1u + ((e - 2) & 1u);
+            t2[i] = tw[(pw * k * S + (e >= 2 ? pw * mp * S16 : 0u)) % M];
         }
         for (uint32_t i = tid; i < (uint32_t)T3_LEN; i += nthr) t3[i] = tw[2 * i];  // W_Nc^jj (R3 = 2)
     }
@@ -71,14 +76,15 @@ struct WaveFftM {
             z[4 * t + 3] = {re[t].d, im[t].d};
         }
     }
-    static TH_HD void load_t2(uint32_t lane, cf32 (&w2)[15], const cf32 *t2) {
+    static TH_HD void load_t2(uint32_t lane, cf32 (&w2)[NT2], const cf32 *t2) {
         const uint32_t c = lig(lane) / S;
-        TH_UNROLL for (int r = 1; r < 16; r++) w2[r - 1] = lds_ld(&t2[(r - 1) * 16 + c]);
+        TH_UNROLL for (int r = 0; r < NT2; r++) w2[r] = lds_ld(&t2[r * 16 + c]);
     }
-    static TH_HD void pass2_twiddle(cf32 (&z)[P], const cf32 (&w2)[15]) {
-        TH_UNROLL for (int r = 1; r < 16; r++) z[r] = cmul(z[r], w2[r - 1]);
+    // twiddles + radix-16 butterfly + stores into the planes of exchange 2
+    static TH_HD void pass2_w(uint32_t lane, cf32 (&z)[P], const cf32 (&w2)[NT2], cf32 *slab) {
+        static_assert(WaveFft<10>::PITCH2 == PITCH2 && WaveFft<10>::NT2 == NT2, "shares the 2048 plan's butterfly");
+        WaveFft<10>::template dft16_tw_to_planes<0>(lane, z, w2, slab);
     }
-    static TH_HD void pass2_dft(uint32_t lane, cf32 (&z)[P], cf32 *slab) { WaveFft<10>::template dft16_to_planes<PITCH2>(lane, z, slab); }
 
     static TH_HD uint32_t jj_a(uint32_t l, int q) { return (uint32_t)L * q + l; }
     static TH_HD uint32_t jj_b(uint32_t l, int q) { return (q == 0 && l == 0) ? (uint32_t)NS3 / 2 : (uint32_t)NS3 - (uint32_t)L * q - l; }
@@ -116,12 +122,8 @@ struct WaveFftM {
     static TH_HD void pass3_paired_w(cf32 (&za)[NQ][R3], cf32 (&zb)[NQ][R3], const cf32 (&wa)[NW3], const cf32 (&wb)[NW3]) {
         if constexpr (R3 == 2) {
             TH_UNROLL for (int q = 0; q < NQ; q++) {
-                const cf32 ta = cmul(za[q][1], wa[q]), tb = cmul(zb[q][1], wb[q]);
-                const cf32 a0 = za[q][0], b0 = zb[q][0];
-                za[q][0] = cadd(a0, ta);
-                za[q][1] = csub(a0, ta);
-                zb[q][0] = cadd(b0, tb);
-                zb[q][1] = csub(b0, tb);
+                bfly2_tw(za[q][0], za[q][R3 - 1], wa[q].re, wa[q].im);
+                bfly2_tw(zb[q][0], zb[q][R3 - 1], wb[q].re, wb[q].im);
             }
         }
     }
@@ -137,20 +139,42 @@ struct WaveFftM {
         TH_UNROLL for (int q = 0; q < NQ; q++)
             TH_UNROLL for (int s = 0; s < R3; s++) ws[q][s] = lds_ld(&stw[split_k(l, q, s)]);
     }
-    // Split pass on lane-local pairs: emit(k, |X[k]|^2) once for every bin of the lane's frame that this lane owns.
+    // Output addressing as in WaveFft::split_base: every bin index is "per-lane base + compile-time constant" with opaque
+    // bases, so that a store is one instruction with an immediate offset.  k = lo + C (or hi + C' for q = 0, s >= R3/2),
+    // Nc - k = mlo + (CMAX - C) (or mhi + ...), C = L q + s Ns3.
+    static constexpr int CMAX = L * (NQ - 1) + (R3 - 1) * NS3;
+    struct SplitBase {
+        uint32_t lo, hi, mlo, mhi;
+    };
+    static TH_HD SplitBase split_base(uint32_t lane) {
+        const uint32_t l = lig(lane), rl = l ^ (uint32_t)(L - 1);  // rl = L - 1 - l
+        SplitBase b;
+        b.lo = l;
+        b.mlo = rl + (uint32_t)(NC - CMAX - (L - 1));
+        b.hi = l == 0 ? (uint32_t)NS3 / 2 : l + (uint32_t)(R3 / 2) * NS3;
+        b.mhi = l == 0 ? (uint32_t)(NC - NS3 / 2 - (R3 / 2 > 0 ? R3 / 2 - 1 : 0) * NS3) : rl + (uint32_t)(NC - (R3 - 1) * NS3 - (L - 1));
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(b.hi), "+v"(b.mlo), "+v"(b.mhi));
+#endif
+        return b;
+    }
+    // Split pass on lane-local pairs: emit(base, C, |X[base + C]|^2) once for every bin of the lane's frame that this lane owns.
     // stw[k] = exp(-2 pi i k / n_fft), w_mid = stw[Nc/2].
     template <class Emit>
     static TH_HD void split_paired_w(uint32_t lane, const cf32 (&za)[NQ][R3], const cf32 (&zb)[NQ][R3], const cf32 (&ws)[NQ][R3],
                                      cf32 w_mid, Emit emit) {
         const uint32_t l = lig(lane);
         const bool l0 = l == 0;
-        auto pair = [&](cf32 zk, cf32 zm, cf32 w, int32_t k, bool both) {
+        const SplitBase sb = split_base(lane);
+        auto pair = [&](cf32 zk, cf32 zm, cf32 w, uint32_t kb, int kc, uint32_t mb, int mc, bool both) {
             const float er = zk.re + zm.re, ei = zk.im - zm.im;
             const float dr = zk.re - zm.re, di = zk.im + zm.im;
-            const float tr = di * w.re + dr * w.im, ti = di * w.im - dr * w.re;
-            const float xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
-            emit(k, xr * xr + xi * xi);
-            if (both) emit(NC - k, yr * yr + yi * yi);
+            const float xr = th_fma(di, w.re, th_fma(dr, w.im, er)), xi = th_fma(di, w.im, th_fma(-dr, w.re, ei));
+            emit(kb, kc, xr * xr + xi * xi);
+            if (both) {
+                const float yr = th_fma(2.0f, er, -xr), yi = th_fma(2.0f, ei, -xi);
+                emit(mb, mc, yr * yr + yi * yi);
+            }
         };
         if constexpr (R3 == 1) {
             // lane l: pairs (Z[L q + l], Z[256 - L q - l]); lane 0, q = 0: Z[0] against itself (bins 0 and Nc) and, from
@@ -161,9 +185,9 @@ struct WaveFftM {
                     zm.re = l0 ? za[0][0].re : zm.re;
                     zm.im = l0 ? za[0][0].im : zm.im;
                 }
-                pair(za[q][0], zm, ws[q][0], split_k(l, q, 0), true);
+                pair(za[q][0], zm, ws[q][0], sb.lo, L * q, sb.mlo, CMAX - L * q, true);
             }
-            if (l0) pair(zb[0][0], zb[0][0], w_mid, NC / 2, false);
+            if (l0) pair(zb[0][0], zb[0][0], w_mid, (uint32_t)NC / 2, 0, 0u, 0, false);
         } else {
             TH_UNROLL for (int q = 0; q < NQ; q++) {
                 TH_UNROLL for (int s = 0; s < R3; s++) {
@@ -179,12 +203,13 @@ struct WaveFftM {
                         zm.re = l0 ? zm0.re : zm.re;
                         zm.im = l0 ? zm0.im : zm.im;
                     }
-                    pair(zk, zm, ws[q][s], split_k(l, q, s), true);
+                    if (q == 0 && s >= R3 / 2) pair(zk, zm, ws[q][s], sb.hi, (s - R3 / 2) * NS3, sb.mhi, (R3 - 1 - s) * NS3, true);
+                    else pair(zk, zm, ws[q][s], sb.lo, L * q + s * NS3, sb.mlo, CMAX - (L * q + s * NS3), true);
                 }
             }
             if (l0) {  // the self-mirrored bin Nc/2 = output R3/2 of butterfly 0
                 const cf32 z = za[0][R3 / 2];
-                pair(z, z, w_mid, NC / 2, false);
+                pair(z, z, w_mid, (uint32_t)NC / 2, 0, 0u, 0, false);
             }
         }
     }
