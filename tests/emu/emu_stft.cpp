@@ -9,6 +9,7 @@
 
 #include "../../thesia_amd/csrc/stft_wave.h"
 #include "../../thesia_amd/csrc/stft_wave_multi.h"
+#include "../../thesia_amd/csrc/stft_block.h"
 #include "../../thesia_amd/csrc/mel_fuse.h"
 
 using namespace th;
@@ -56,6 +57,54 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
         }
     const cf32 wn = {-1.0f, 0.0f};
     row[NC] = power_to_dB(split_power(z[0][0], z[0][0], wn));
+}
+
+// One frame of the workgroup-per-frame plan (stft_block.h): the T threads run every phase one after the other, a phase
+// boundary stands for the workgroup barrier.
+template <int LOG2_NC>
+static void emu_frame_block(const float *wav, uint32_t frame, const StftGeom &g, const cf32 *wtab, const cf32 *tw, float *row) {
+    using B = BlockFft<LOG2_NC>;
+    constexpr int T = B::T, NC = B::NC;
+    std::vector<cf32> buf(B::BUF_LEN);
+    static cf32 z[T][16];
+    const int64_t e0 = (int64_t)frame * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+    for (uint32_t t = 0; t < (uint32_t)T; t++)
+        for (int m = 0; m < 16; m++) {
+            const uint32_t n = t + (uint32_t)T * m;
+            z[t][m] = {wav[e0 + 2 * n] * wtab[n].re, wav[e0 + 2 * n + 1] * wtab[n].im};
+        }
+    for (uint32_t t = 0; t < (uint32_t)T; t++) B::pass_first(t, z[t], buf.data());
+    for (uint32_t t = 0; t < (uint32_t)T; t++) B::template read_in<B::FIRST_LAYOUT>(t, z[t], buf.data());
+    if (B::R2_FIRST) {
+        for (uint32_t t = 0; t < (uint32_t)T; t++) {
+            cf32 w[B::NTW];
+            B::template load_tw<B::NS_A>(t, w, tw);
+            B::template pass_mid_compute<B::NS_A>(z[t], w);
+        }
+        for (uint32_t t = 0; t < (uint32_t)T; t++) B::template pass_mid_store<B::NS_A>(t, z[t], buf.data());
+        for (uint32_t t = 0; t < (uint32_t)T; t++) B::template read_in<B::NS_A>(t, z[t], buf.data());
+    }
+    for (uint32_t t = 0; t < (uint32_t)T; t++) {
+        cf32 w[B::NTW];
+        B::template load_tw<B::NS_B>(t, w, tw);
+        B::template pass_mid_compute<B::NS_B>(z[t], w);
+    }
+    for (uint32_t t = 0; t < (uint32_t)T; t++) B::template pass_mid_store<B::NS_B>(t, z[t], buf.data());
+    for (uint32_t t = 0; t < (uint32_t)T; t++) B::template read_in<B::NS_B>(t, z[t], buf.data());
+    for (uint32_t t = 0; t < (uint32_t)T; t++) {
+        cf32 w[B::NTW];
+        B::template load_tw<B::NS_C>(t, w, tw);
+        B::pass_last(z[t], w);
+    }
+    for (uint32_t t = 0; t < (uint32_t)T; t++) B::write_z(t, z[t], buf.data());
+    std::vector<int> hits(NC + 1, 0);
+    for (uint32_t t = 0; t < (uint32_t)T; t++)
+        B::split(t, z[t], buf.data(), tw[t], [&](uint32_t k, float p) {
+            row[k] = power_to_dB(p);
+            hits[k]++;
+        });
+    for (int k = 0; k <= NC; k++)
+        if (hits[k] != 1) row[k] = NAN;  // every bin exactly once
 }
 
 // G frames of one wave of the multi-frame plan (stft_wave_multi.h): group g of the lanes computes frame frames[g]
@@ -184,6 +233,8 @@ extern "C" __attribute__((visibility("default"))) int emu_stft_wave(const float 
             case 1024: emu_frame<9>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
             case 2048: emu_frame<10>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
             case 4096: emu_frame<11>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
+            case 8192: emu_frame_block<12>(wav, f, g, wtab.data(), tw.data(), row); break;
+            case 16384: emu_frame_block<13>(wav, f, g, wtab.data(), tw.data(), row); break;
             default: return -1;
         }
     }

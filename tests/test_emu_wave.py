@@ -27,7 +27,10 @@ def emu():
 @pytest.mark.parametrize("win,hop,n_fft,n", [(2048, 512, 2048, 9000), (1920, 480, 2048, 9000), (1764, 441, 2048, 7000),
                                              (2048, 512, 2048, 700), (1024, 256, 1024, 5000), (1000, 250, 1024, 5000),
                                              (4096, 1024, 4096, 14000), (3001, 3001, 4096, 14000),
-                                             (2047, 2047, 2048, 9000)])
+                                             (2047, 2047, 2048, 9000),
+                                             # the workgroup-per-frame plan (stft_block.h)
+                                             (8192, 2048, 8192, 30000), (7680, 1920, 8192, 30000), (16384, 4096, 16384, 60000),
+                                             (15001, 5000, 16384, 70000)])
 def test_emulated_wave_kernel_matches_oracle(emu, win, hop, n_fft, n):
     x = synth_track(n_fft + win, 48000, n)
     w = orc.calc_normalized_win(win, n_fft)

@@ -72,10 +72,11 @@ def test_stft_impulse_known_answer(ctx):
 @pytest.mark.parametrize("win,hop,n_fft", [(8, 2, 8), (16, 4, 16), (30, 10, 32), (64, 16, 64), (256, 64, 256),
                                            (480, 120, 512), (1024, 256, 1024), (1920, 480, 2048),
                                            (1764, 441, 2048), (2048, 512, 2048), (4096, 1024, 4096),
-                                           (8192, 2048, 8192), (2048, 2048, 2048), (2048, 64, 2048), (15, 5, 16)])
+                                           (8192, 2048, 8192), (7680, 1920, 8192), (16384, 4096, 16384), (15001, 5000, 16384),
+                                           (2048, 2048, 2048), (2048, 64, 2048), (15, 5, 16)])
 def test_calc_spec_linear_parity(ctx, win, hop, n_fft):
     plan = ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR)
-    n = min(6 * win + 3 * hop + 17, 60000)
+    n = min(6 * win + 3 * hop + 17, 60000 if n_fft <= 8192 else 110000)
     x = synth_track(win + hop, 48000, n)
     spec, mn, mx = plan.calc_spec(x)
     want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
@@ -87,14 +88,16 @@ def test_calc_spec_linear_parity(ctx, win, hop, n_fft):
 
 @pytest.mark.parametrize("win,hop,n_fft", [(1024, 256, 1024), (1000, 250, 1024), (2048, 512, 2048), (1920, 480, 2048),
                                            (1764, 441, 2048), (2047, 2047, 2048), (4096, 1024, 4096),
-                                           (3001, 3001, 4096), (2048, 128, 2048)])
+                                           (3001, 3001, 4096), (2048, 128, 2048), (8192, 2048, 8192), (8000, 1000, 8192),
+                                           (16384, 4096, 16384), (12000, 3000, 16384)])
 def test_wave_and_generic_kernels(ctx, win, hop, n_fft):
-    """Both STFT kernels against the oracle on the same input; the wave kernel takes the interior
-    frames, the generic kernel the reflect-padded boundary frames of the same launch."""
-    n = 40000 + win
+    """Both STFT kernels against the oracle on the same input; the wave kernel (n_fft 8192 / 16384: the workgroup-per-frame
+    block kernel) takes the interior frames, the generic kernel the reflect-padded boundary frames of the same launch."""
+    n = 40000 + win if n_fft <= 4096 else 8 * n_fft + 4321
     x = synth_track(n_fft + hop, 48000, n)
     want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
-    for which, name in ((1, "stft_generic_kernel"), (2, "stft_wave_kernel")):
+    fast = "stft_wave_kernel" if n_fft <= 4096 else "stft_block_kernel"
+    for which, name in ((1, "stft_generic_kernel"), (2, fast)):
         plan = ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR)
         plan.set_kernel(which)
         assert plan.kernel_name == name
@@ -103,7 +106,7 @@ def test_wave_and_generic_kernels(ctx, win, hop, n_fft):
         assert mn == spec.min() and mx == spec.max()
         plan.close()
     plan = ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR)
-    assert plan.kernel_name == "stft_wave_kernel"  # auto picks the fast path for these sizes
+    assert plan.kernel_name == fast  # auto picks the fast path for these sizes
     plan.close()
 
 
@@ -813,7 +816,7 @@ def _batch_on_gpu(ctx, plan, n_tr, n, seed):
     return wav, spec, mm
 
 
-@pytest.mark.parametrize("cfg", ["cfg5_shard", "cfg3", "cfg4_mel", "queue_512", "queue_512_odd", "queue_1024", "queue_2048_odd"])
+@pytest.mark.parametrize("cfg", ["cfg5_shard", "cfg3", "cfg4_mel", "queue_512", "queue_512_odd", "queue_1024", "queue_2048_odd", "block_8192", "block_16384"])
 def test_baseline_sizes_properties(ctx, cfg):
     """BASELINE.json configs at FULL size (the oracle cannot run these in test time): the batched launch must equal
     single-track launches of sampled tracks bit for bit (no cross-talk, chunk seams, boundary frames), agree with
@@ -834,6 +837,10 @@ def test_baseline_sizes_properties(ctx, cfg):
         sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (511, 127, 512), 37, 1200007, ta.LINEAR, 0
     elif cfg == "queue_1024":
         sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (1000, 250, 1024), 60, 40 * 48000 + 11, ta.LINEAR, 0
+    elif cfg == "block_8192":   # 96 kHz with f_overlap 2: one workgroup per frame (stft_block.h)
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 96000, (3840, 960, 8192), 24, 30 * 96000 + 3, ta.LINEAR, 0
+    elif cfg == "block_16384":
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (16384, 4096, 16384), 16, 60 * 48000, ta.LINEAR, 0
     else:
         sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (1801, 601, 2048), 53, 80 * 48000 + 5, ta.LINEAR, 0
     plan = ta.Plan(ctx, sr, win, hop, n_fft, scale, n_mel)
@@ -841,7 +848,7 @@ def test_baseline_sizes_properties(ctx, cfg):
     T, H = plan.n_frames(n), plan.height
     if cfg.startswith("cfg"):
         assert (n_tr * T) in (360064, 165376)
-    else:
+    elif cfg.startswith("queue"):
         assert n_tr * T > 3 * 3072 * 32       # several rounds of chunks for every wave of the grid
     # every real cell written; the padding of a th_pitch_f32 row belongs to the library: either untouched or zeros up to
     # the end of the 128-byte line of the last bin (the wave kernel completes that line: a partial line costs HBM a

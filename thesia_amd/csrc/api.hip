@@ -626,6 +626,7 @@ TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (!p) return "";
     if (p->use_mel_fused()) return "stft_wave_kernel(fused mel)";
     if (p->use_mel_mfma()) return "stft_wave_kernel+mel_mfma_kernel";
+    if (p->use_wave() && th::stft_is_block_plan(p->g)) return "stft_block_kernel";
     return p->use_wave() ? "stft_wave_kernel" : "stft_generic_kernel";
 }
 
@@ -647,7 +648,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     const bool wave = p->use_wave();
     const bool mel_mfma = p->use_mel_mfma(), mel_fused = p->use_mel_fused();
     if (p->kernel_choice >= 2 && !wave)
-        return fail(TH_ERR_UNSUPPORTED, "the wave kernel covers n_fft in {512 (linear only), 1024, 2048, 4096} (mel: n_mel <= 512)");
+        return fail(TH_ERR_UNSUPPORTED, "the wave kernels cover n_fft in {512 (linear only), 1024, 2048, 4096} (mel: n_mel <= 512) and 8192 / 16384 (linear only)");
     StftGeom g = p->g;       // main launch
     StftGeom ge = p->g;      // edge launch (generic kernel)
     const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);
@@ -686,7 +687,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     // boundary frames of channels with at least n_fft samples also go to the wave kernel (one-frame chunks with a
     // reflect-indexed fetch): no second launch on the fast path.  Not on the matrix-core mel path (its amplitude rows
     // are laid out for the interior jobs), not for channels shorter than n_fft (a single reflection is not enough there).
-    const bool edges_in_wave = wave && !mel_mfma && !phased;
+    const bool edges_in_wave = wave && !mel_mfma && !phased && !th::stft_is_block_plan(g);
     if (wave) {
         uint64_t total = 0;
         for (size_t i = 0; i < n_chan; i++) total += chans[i].n_frames;

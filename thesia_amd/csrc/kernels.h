@@ -22,6 +22,9 @@ hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const u
                                float *d_minmax, hipStream_t s);
 
 bool stft_wave_supported(const StftGeom &g);
+// n_fft 8192 / 16384: launch_stft_wave runs the workgroup-per-frame kernel (stft_block.h): interior frames only, the
+// boundary frames always go to the generic kernel
+bool stft_is_block_plan(const StftGeom &g);
 // the multi-frame kernel (two / four frames per wave) takes this launch: n_fft 512 or 1024, dB output, no grid-aligned mode
 bool stft_wave_multi_applies(const StftGeom &g, int out_mode);
 int stft_wave_default_waves(const StftGeom &g);

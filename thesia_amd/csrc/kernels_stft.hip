@@ -13,6 +13,7 @@
 #include "stft_core.h"
 #include "stft_wave.h"
 #include "stft_wave_multi.h"
+#include "stft_block.h"
 
 namespace th {
 
@@ -933,6 +934,113 @@ static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, co
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Block kernel (stft_block.h): n_fft = 8192 / 16384, one workgroup of T = Nc / 16 threads per frame, 16 points per thread,
+// radix-16 passes in registers with LDS exchanges between them.  One workgroup per chunk of frames_per_tile consecutive
+// interior frames (chunk table as for the wave kernels; the hardware dispatcher balances the workgroups); boundary frames
+// and channels shorter than n_fft go to the generic kernel.  Per-pass twiddle constants (10 per pass, FMA butterflies)
+// and, for n_fft 8192, the thread's 16 window pairs live in registers for the whole chunk.  dB output, linear scale only.
+// ------------------------------------------------------------------------------------------
+template <int LOG2_NC>
+__global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_tiles,
+    const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax) {
+    using B = BlockFft<LOG2_NC>;
+    constexpr int T = B::T, NC = B::NC;
+    constexpr bool WIN_REGS = LOG2_NC == 12;  // 32 VGPRs: with three sets of pass constants (n_fft 16384) they do not fit
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // BUF_LEN cf32 (n_fft 16384: 68 KB) + the (min, max) scratch
+    cf32 *const buf = reinterpret_cast<cf32 *>(smem_raw);
+    float *const red = reinterpret_cast<float *>(buf + B::BUF_LEN);
+    const uint32_t t = threadIdx.x;
+    const FrameCursor cur = cursor_at(g, jobs, chunk_tab, n_tiles, blockIdx.x);
+    if (!cur.valid) return;
+    cf32 wA[B::NTW], wB[B::NTW], wC[B::NTW];
+    if constexpr (B::R2_FIRST) B::template load_tw<B::NS_A>(t, wA, tw);
+    B::template load_tw<B::NS_B>(t, wB, tw);
+    B::template load_tw<B::NS_C>(t, wC, tw);
+    const cf32 stw_t = tw[t];
+    cf32 rw[WIN_REGS ? 16 : 1];
+    if constexpr (WIN_REGS) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) rw[m] = wtab_g[t + (uint32_t)T * m];
+    }
+    float lmin = __builtin_inff(), lmax = -__builtin_inff();
+    for (uint32_t f = cur.f; f < cur.f1; f++) {
+        // the frame's n_fft-sample span starts at e0 (interior frames only: the whole span is inside the channel)
+        const int64_t e0 = (int64_t)f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+        cf32 z[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const gptr<const float> p = cur.wav + (e0 + 2 * (int64_t)(t + (uint32_t)T * m));
+            cf32 w;
+            if constexpr (WIN_REGS) w = rw[m];
+            else w = wtab_g[t + (uint32_t)T * m];
+            z[m] = {p[0] * w.re, p[1] * w.im};
+        }
+        __syncthreads();  // the previous frame's mirror reads are done: the buffer may be rewritten
+        B::pass_first(t, z, buf);
+        __syncthreads();
+        B::template read_in<B::FIRST_LAYOUT>(t, z, buf);
+        if constexpr (B::R2_FIRST) {
+            B::template pass_mid_compute<B::NS_A>(z, wA);
+            __syncthreads();
+            B::template pass_mid_store<B::NS_A>(t, z, buf);
+            __syncthreads();
+            B::template read_in<B::NS_A>(t, z, buf);
+        }
+        B::template pass_mid_compute<B::NS_B>(z, wB);
+        __syncthreads();
+        B::template pass_mid_store<B::NS_B>(t, z, buf);
+        __syncthreads();
+        B::template read_in<B::NS_B>(t, z, buf);
+        B::pass_last(z, wC);
+        __syncthreads();
+        B::write_z(t, z, buf);
+        __syncthreads();
+        const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch;
+        B::split(t, z, buf, stw_t, [&](uint32_t k, float p) {
+            const float d = power_to_dB(p);
+            row[k] = d;
+            lmin = nmin(lmin, d);
+            lmax = nmax(lmax, d);
+        });
+        {   // complete the row's last 128-byte line (see wave_frame)
+            const uint32_t height = (uint32_t)(NC + 1), padn = cur.spec_pitch - height;
+            if (t - 1u < ((padn < 32u && cur.spec_pitch % 32u == 0) ? padn : 0u)) row[height - 1u + t] = 0.0f;
+        }
+    }
+    if (minmax != nullptr) {  // one (min, max) pair per chunk, folded per channel by wave_post_kernel
+        lmin = wave_min(lmin);
+        lmax = wave_max(lmax);
+        if ((t & 63u) == 0) {
+            red[2 * (t >> 6)] = lmin;
+            red[2 * (t >> 6) + 1] = lmax;
+        }
+        __syncthreads();
+        if (t == 0) {
+            float a = red[0], b = red[1];
+            for (int w = 1; w < T / 64; w++) {
+                a = nmin(a, red[2 * w]);
+                b = nmax(b, red[2 * w + 1]);
+            }
+            minmax[2 * (size_t)cur.t] = a;
+            minmax[2 * (size_t)cur.t + 1] = b;
+        }
+    }
+}
+
+template <int LOG2_NC>
+static hipError_t launch_block(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
+                               const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
+    using B = BlockFft<LOG2_NC>;
+    auto kern = stft_block_kernel<LOG2_NC>;
+    const size_t lds = sizeof(cf32) * B::BUF_LEN + sizeof(float) * 2 * (B::T / 64);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(B::T), lds, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax);
+    return hipGetLastError();
+}
+
 #if defined(TH_WAVE_TIMES)
 }  // namespace th
 extern "C" __attribute__((visibility("default"))) int th_debug_wave_times(unsigned long long *out, int n) {
@@ -1080,8 +1188,10 @@ namespace th {
 
 // n_fft 512 (multi-frame kernel): linear dB only
 bool stft_wave_supported(const StftGeom &g) {
-    return (g.log2_nc >= 9 && g.log2_nc <= 11 && g.n_mel <= 512) || (g.log2_nc == 8 && g.n_mel == 0);
+    return (g.log2_nc >= 9 && g.log2_nc <= 11 && g.n_mel <= 512) || (g.log2_nc == 8 && g.n_mel == 0) ||
+           ((g.log2_nc == 12 || g.log2_nc == 13) && g.n_mel == 0);  // n_fft 8192 / 16384: the block kernel, linear dB
 }
+bool stft_is_block_plan(const StftGeom &g) { return g.log2_nc >= 12; }
 bool stft_wave_multi_applies(const StftGeom &g, int out_mode) { return out_mode == 0 && g.phased == 0 && (g.log2_nc == 8 || g.log2_nc == 9); }
 
 // Waves per workgroup (one persistent workgroup per CU).  Bounded by LDS (tables + one slab per
@@ -1272,6 +1382,7 @@ int stft_wave_default_waves(const StftGeom &g) {
         case 11: return WaveLaunchCfg<11>::DEFAULT_WAVES;
         case 10: return WaveLaunchCfg<10>::DEFAULT_WAVES;
         case 8: return 12;
+        case 12: case 13: return 12;  // (block kernel: only sizes the chunks, 12 x CUs of them per round)
         default: return WaveLaunchCfg<9>::DEFAULT_WAVES;
     }
 }
@@ -1285,6 +1396,12 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
         if (!stft_wave_multi_applies(g, out.mode)) return hipErrorInvalidValue;
         if (g.log2_nc == 8) return launch_wave_multi<8>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
         return launch_wave_multi<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
+    }
+    if (g.log2_nc >= 12) {  // one workgroup per frame (stft_block.h): dB output, linear scale
+        if (out.mode != 0 || g.phased) return hipErrorInvalidValue;
+        if (g.log2_nc == 12) return launch_block<12>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+        if (g.log2_nc == 13) return launch_block<13>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+        return hipErrorInvalidValue;
     }
     switch (g.log2_nc) {
         case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);

@@ -1,0 +1,151 @@
+// stft_block.h — one WORKGROUP per frame: the packed real FFT of the long transforms, n_fft = 8192 (Nc = 4096) and
+// 16384 (Nc = 8192), which do not fit one wave's registers (stft_wave.h stops at n_fft = 4096).
+//
+// T = Nc / 16 threads (256 or 512) work on one frame, 16 complex points per thread.  Stockham autosort, decimation in
+// time, radix-16 passes in registers with an LDS exchange (and a workgroup barrier) between passes:
+//
+//     Nc = 4096:          16 (Ns = 1)  x 16 (Ns = 16)  x 16 (Ns = 256)
+//     Nc = 8192:  2 (Ns = 1) x 16 (Ns = 2)  x 16 (Ns = 32)  x 16 (Ns = 512)
+//
+// A pass with sub-transform size Ns: thread t owns butterfly j = t, k = t mod Ns,
+//     v_r = in[t + T r] * W_{16 Ns}^{r k}   (r = 0..15),     out[(t - k) 16 + k + Ns c] = DFT16(v)_c
+// (the radix-2 first pass of Nc = 8192: butterflies j = t + T m', m' < 8, on the points the thread loaded itself,
+// out[2 j + r]).  The twiddled passes run as the fused-multiply-add butterflies of stft_wave.h (bfly4_tw): 10 per-thread
+// constants per pass, held in registers for the whole launch.  After the last pass thread t holds Z[t + T c], c = 0..15;
+// Z goes through LDS once more so that every thread can read the mirror partners Z[Nc - k] of its bins k = t + T c, c < 8,
+// and emit X[k] and X[Nc - k] of the real-FFT split pass together.
+//
+// LDS layout per exchange (slot = one cf32): after the Ns <= 2 pass pad1 (two pad slots per 32: a thread writes 16 / 2
+// consecutive slots), after the Ns = 16 pass i + 16 (i >> 8) (the four 16-lane groups of a wave land on different bank
+// halves), after the Ns = 32 pass and for Z the identity.  Every read is "in[t + T r]": per-thread base + immediate.
+//
+// Like stft_wave.h this header compiles for gfx950 (hipcc) and for the CPU lane emulator in tests/emu (g++).
+#pragma once
+#include "stft_wave.h"
+
+namespace th {
+
+template <int LOG2_NC>
+struct BlockFft {
+    static_assert(LOG2_NC == 12 || LOG2_NC == 13, "n_fft = 8192 or 16384");
+    static constexpr int NC = 1 << LOG2_NC;
+    static constexpr int T = NC / 16;           // threads per frame
+    static constexpr bool R2_FIRST = (LOG2_NC == 13);
+    static constexpr int NS_A = R2_FIRST ? 2 : 1;      // sub-transform sizes of the three radix-16 passes
+    static constexpr int NS_B = 16 * NS_A, NS_C = 16 * NS_B;
+    static_assert(16 * NS_C == NC, "last pass completes the transform");
+    static constexpr int NTW = 10;                       // FMA-plan constants per twiddled pass (WaveFft::FMA_TW)
+    static constexpr int BUF_LEN = NC + NC / 16 + 2;     // cf32 slots: padded image + the copy of Z[0] at slot Nc
+
+    template <int NS>
+    static TH_HD uint32_t pad(uint32_t i) {
+        if constexpr (NS <= 2) return pad1(i);
+        else if constexpr (NS == 16) return i + 16u * (i >> 8);
+        else return i;
+    }
+    // pad<NS>(t + T r) = pad<NS>(t) + PSTEP<NS> r  (T is a multiple of 256)
+    template <int NS>
+    static constexpr uint32_t pstep() {
+        return NS <= 2 ? (uint32_t)(T + T / 16) : NS == 16 ? (uint32_t)(T + 16 * (T / 256)) : (uint32_t)T;
+    }
+
+    // the 10 constants of a twiddled pass for twiddle index k: w = W_{16 Ns}^k = tw[k S], S = 2 Nc / (16 Ns)
+    // (tw[i] = exp(-2 pi i * i / n_fft), n_fft = 2 Nc): w^4, w^8, then t, t^2 for t = w W16^m', m' = 0..3
+    template <int NS>
+    static TH_HD void load_tw(uint32_t t, cf32 (&w)[NTW], const cf32 *tw) {
+        constexpr uint32_t S = 2 * NC / (16 * NS), S16 = 2 * NC / 16, M = 2 * NC;
+        const uint32_t k = t & (uint32_t)(NS - 1);
+        TH_UNROLL for (int e = 0; e < NTW; e++) {
+            const uint32_t mp = e >= 2 ? (uint32_t)(e - 2) / 2 : 0u, pw = e < 2 ? 4u * (uint32_t)(e + 1) : 1u + ((uint32_t)(e - 2) & 1u);
+            w[e] = tw[(pw * k * S + (e >= 2 ? pw * mp * S16 : 0u)) % M];
+        }
+    }
+
+    // twiddled radix-16 butterfly in place (WaveFft<10>::dft16_tw_to_planes without the stores): natural output c ends
+    // up in v[slot_tw(c)]
+    static TH_HD void dft16_tw(cf32 (&v)[16], const cf32 (&w)[NTW]) {
+        TH_UNROLL for (int b = 0; b < 4; b++) bfly4_tw(v[b], v[4 + b], v[8 + b], v[12 + b], w[0], w[1]);
+        bfly4_tw(v[0], v[1], v[2], v[3], w[2], w[3]);      // m' = 0: inputs y_b[0] in v[b]
+        bfly4_tw(v[8], v[9], v[10], v[11], w[4], w[5]);    // m' = 1: y_b[1] in v[8 + b]
+        bfly4_tw(v[4], v[5], v[6], v[7], w[6], w[7]);      // m' = 2: y_b[2] in v[4 + b]
+        bfly4_tw(v[12], v[13], v[14], v[15], w[8], w[9]);  // m' = 3
+    }
+    // output c = m' + 4 m'' of dft16_tw: group base 4 pi(m'), pi = (0, 2, 1, 3); inside a group (X0, X2, X1, X3)
+    static TH_HD constexpr int slot_tw(int c) {
+        const int mp = c & 3, mpp = c >> 2;
+        const int base = 4 * (mp == 1 ? 2 : mp == 2 ? 1 : mp);
+        return base + (mpp == 1 ? 2 : mpp == 2 ? 1 : mpp);
+    }
+
+    // ---- first pass(es): z[m] = windowed point t + T m of the frame -> LDS (exchange 1)
+    static TH_HD void pass_first(uint32_t t, cf32 (&z)[16], cf32 *buf) {
+        if constexpr (R2_FIRST) {
+            // radix 2, Ns = 1: butterfly j = t + T m' pairs the points j and j + Nc/2 = slots m', m' + 8; out[2 j + r]
+            TH_UNROLL for (int m = 0; m < 8; m++) {
+                fft2(z[m], z[m + 8]);
+                const uint32_t o = 2u * (t + (uint32_t)T * m);
+                buf[o] = z[m];
+                buf[o + 1] = z[m + 8];
+            }
+        } else {
+            // radix 16, Ns = 1: butterfly j = t on the thread's own 16 points; out[16 t + c]
+            dft16(z);
+            TH_UNROLL for (int c = 0; c < 16; c++) buf[pad1(16u * t) + c] = z[dft16_slot(c)];
+        }
+    }
+    // layout tag of the exchange the first pass writes (see pad<>): pad1 after the radix-16 first pass, linear after the radix-2 one
+    static constexpr int FIRST_LAYOUT = R2_FIRST ? 64 : 1;
+    // read in[t + T r] of the exchange written by the pass with sub-size NS_PREV (layout pad<NS_PREV>)
+    template <int NS_PREV>
+    static TH_HD void read_in(uint32_t t, cf32 (&z)[16], const cf32 *buf) {
+        const uint32_t b = pad<NS_PREV>(t);
+        TH_UNROLL for (int r = 0; r < 16; r++) z[r] = buf[b + pstep<NS_PREV>() * (uint32_t)r];
+    }
+    // twiddled radix-16 pass with sub-size NS (not the last): registers -> LDS, out[(t - k) 16 + k + NS c]
+    template <int NS>
+    static TH_HD void pass_mid_compute(cf32 (&z)[16], const cf32 (&w)[NTW]) { dft16_tw(z, w); }
+    template <int NS>
+    static TH_HD void pass_mid_store(uint32_t t, const cf32 (&z)[16], cf32 *buf) {
+        const uint32_t k = t & (uint32_t)(NS - 1), o = (t - k) * 16u + k;
+        TH_UNROLL for (int c = 0; c < 16; c++) buf[pad<NS>(o + (uint32_t)(NS * c))] = z[slot_tw(c)];
+    }
+    // last pass: z <- Z[t + T c] in natural slot order
+    static TH_HD void pass_last(cf32 (&z)[16], const cf32 (&w)[NTW]) {
+        dft16_tw(z, w);
+        cf32 o[16];
+        TH_UNROLL for (int c = 0; c < 16; c++) o[c] = z[slot_tw(c)];
+        TH_UNROLL for (int c = 0; c < 16; c++) z[c] = o[c];
+    }
+    // publish Z (natural order, plus Z[0] again at slot Nc so that the mirror of bin 0 needs no wrap-around)
+    static TH_HD void write_z(uint32_t t, const cf32 (&z)[16], cf32 *buf) {
+        TH_UNROLL for (int c = 0; c < 16; c++) buf[t + (uint32_t)T * c] = z[c];
+        if (t == 0) buf[NC] = z[0];
+    }
+    // Split pass: thread t owns the pairs (k, Nc - k), k = t + T c, c < 8, and — thread 0 — the self-mirrored bin Nc/2.
+    // stw_t = W_{n_fft}^t; W^{t + T c} = stw_t * omega^c, omega = exp(-i pi / 16).  emit(bin, |X[bin]|^2).
+    template <class Emit>
+    static TH_HD void split(uint32_t t, const cf32 (&z)[16], const cf32 *buf, cf32 stw_t, Emit emit) {
+        constexpr float OC[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                                 0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                                 0.19509032201612826785f, 0.0f};  // cos(pi c / 16); sin(pi c / 16) = OC[8 - c]
+        cf32 zm[8];
+        TH_UNROLL for (int c = 0; c < 8; c++) zm[c] = buf[(uint32_t)NC - t - (uint32_t)T * c];
+        TH_UNROLL for (int c = 0; c < 8; c++) {
+            const cf32 w = cmul_c(stw_t, OC[c], -OC[8 - c]);
+            const cf32 zk = z[c];
+            const float er = zk.re + zm[c].re, ei = zk.im - zm[c].im;
+            const float dr = zk.re - zm[c].re, di = zk.im + zm[c].im;
+            const float xr = th_fma(di, w.re, th_fma(dr, w.im, er)), xi = th_fma(di, w.im, th_fma(-dr, w.re, ei));
+            const float yr = th_fma(2.0f, er, -xr), yi = th_fma(2.0f, ei, -xi);
+            emit(t + (uint32_t)T * c, xr * xr + xi * xi);
+            emit((uint32_t)NC - t - (uint32_t)T * c, yr * yr + yi * yi);
+        }
+        if (t == 0) {  // bin Nc/2 = Z[8 T] of thread 0: its own mirror, W^(Nc/2) = -i
+            const cf32 zh = z[8];
+            const float xr = 2.0f * zh.re, xi = -2.0f * zh.im;  // e = (2 re, 0), d = (0, 2 im): X = e + (-i)(-i d) ... = (2 re, -2 im)
+            emit((uint32_t)NC / 2, xr * xr + xi * xi);
+        }
+    }
+};
+
+}  // namespace th
