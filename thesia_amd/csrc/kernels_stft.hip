@@ -940,6 +940,9 @@ static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, co
 // interior frames (chunk table as for the wave kernels; the hardware dispatcher balances the workgroups); boundary frames
 // and channels shorter than n_fft go to the generic kernel.  Per-pass twiddle constants (10 per pass, FMA butterflies)
 // and, for n_fft 8192, the thread's 16 window pairs live in registers for the whole chunk.  dB output, linear scale only.
+// 167 / 196 VGPRs: three workgroups (12 waves) per CU at n_fft 8192, one (8 waves) at 16384.  Measured and not adopted:
+// the mid-pass constants from LDS tables, the window from global memory at 8192 (both within +-3 %), forcing four waves
+// per SIMD with amdgpu_waves_per_eu (128 VGPRs, 140-240 bytes of scratch: 0.77 -> 1.32 ms and 1.33 -> 1.62 ms).
 // ------------------------------------------------------------------------------------------
 template <int LOG2_NC>
 __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
