@@ -22,10 +22,12 @@ ap.add_argument("--win", type=int, default=0)
 ap.add_argument("--hop", type=int, default=0)
 ap.add_argument("--gap-ms", type=float, default=0.0, help="idle time between launches (power-limited kernel: "
                 "back-to-back launches run slower than launches with pauses or lighter kernels in between)")
+ap.add_argument("--mel", type=int, default=None, help="mel plan with this many bins (0 = the reference's default count)")
+ap.add_argument("--sr", type=int, default=48000)
 ap.add_argument("--noise", action="store_true", help="full-scale white noise instead of the bench's SURVEY 8(d) tracks "
                 "(the kernel is power-limited: noise costs ~30 %% more time for the same work)")
 a = ap.parse_args()
-sr = 48000
+sr = a.sr
 n_fft = a.nfft
 win = a.win or n_fft
 hop = a.hop or win // 4
@@ -43,7 +45,7 @@ else:
     wav = synth_on_gpu(torch, dev, list(range(a.tracks)), sr, n)
     torch.cuda.synchronize()
 for K in a.kernel:
-    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR) if a.mel is None else ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, a.mel)
     if K:
         plan.set_kernel(K)
     T, H = plan.n_frames(n), plan.height

@@ -183,12 +183,14 @@ def test_calc_spec_silence_is_neg_inf(ctx):
 
 @pytest.mark.parametrize("sr,win,hop,n_fft,n_mel", [(44100, 2048, 512, 2048, 128), (48000, 1920, 480, 2048, 0),
                                                     (44100, 1764, 441, 2048, 0), (16000, 512, 128, 512, 40),
-                                                    (48000, 1024, 256, 1024, 80)])
+                                                    (48000, 1024, 256, 1024, 80), (8000, 320, 80, 512, 0),
+                                                    (192000, 7680, 1920, 8192, 0), (96000, 3840, 960, 8192, 128),
+                                                    (48000, 16384, 4096, 16384, 0)])
 def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
     plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
     want_n_mel = n_mel or orc.mel_default_n_mel(sr, n_fft)
     assert plan.height == want_n_mel
-    x = synth_track(7, sr, 30000)
+    x = synth_track(7, sr, max(30000, 6 * n_fft + 1234))
     spec, mn, mx = plan.calc_spec(x)
     fb = orc.calc_mel_fb(sr, n_fft, want_n_mel)
     want = orc.calc_spec(x, win, hop, n_fft, mel_fb=fb)
@@ -200,16 +202,20 @@ def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
 @pytest.mark.parametrize("sr,win,hop,n_fft,n_mel", [(44100, 2048, 512, 2048, 128), (48000, 1920, 480, 2048, 0),
                                                     (48000, 4096, 1024, 4096, 0), (48000, 1024, 256, 1024, 500),
                                                     (44100, 2048, 512, 2048, 17), (16000, 640, 160, 1024, 0),
-                                                    (22050, 884, 221, 1024, 0), (48000, 1024, 256, 1024, 128)])
+                                                    (22050, 884, 221, 1024, 0), (48000, 1024, 256, 1024, 128),
+                                                    (8000, 320, 80, 512, 0), (16000, 512, 128, 512, 64),
+                                                    (192000, 7680, 1920, 8192, 0), (48000, 16384, 4096, 16384, 200)])
 def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     """The three mel paths against the oracle on a ragged batch: the filterbank fused into the wave kernel's epilogue
     (n_fft = 2048), the matrix-core path (wave FFT kernel -> amplitudes -> v_mfma_f32_16x16x4_f32 filterbank) and the
     generic kernel's banded VALU reduction."""
     want_n_mel = n_mel or orc.mel_default_n_mel(sr, n_fft)
     fb = orc.calc_mel_fb(sr, n_fft, want_n_mel)
-    wavs = [synth_track(31 + i, sr, n) for i, n in enumerate((50000, 9000, win // 2, 23456))]
+    lens = (50000, 9000, win // 2, 23456) if n_fft <= 4096 else (5 * n_fft + 777, n_fft + 99, win // 2, 3 * n_fft)
+    wavs = [synth_track(31 + i, sr, n) for i, n in enumerate(lens)]
     want = [orc.calc_spec(w, win, hop, n_fft, mel_fb=fb) for w in wavs]
-    mfma = "stft_wave_kernel+mel_mfma_kernel" if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
+    fft_kernel = "stft_wave_kernel" if n_fft <= 4096 else "stft_block_kernel"  # (n_fft 512: the multi-frame wave kernel)
+    mfma = fft_kernel + "+mel_mfma_kernel" if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
     # auto: the fused epilogue for n_fft 2048 and (when the piece table fits: <= 512 pieces) 1024, else the matrix-core path
     fused = "stft_wave_kernel(fused mel)"
     for which, name in ((1, "stft_generic_kernel"), (3, mfma), (0, None)):

@@ -625,7 +625,7 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
 TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (!p) return "";
     if (p->use_mel_fused()) return "stft_wave_kernel(fused mel)";
-    if (p->use_mel_mfma()) return "stft_wave_kernel+mel_mfma_kernel";
+    if (p->use_mel_mfma()) return th::stft_is_block_plan(p->g) ? "stft_block_kernel+mel_mfma_kernel" : "stft_wave_kernel+mel_mfma_kernel";
     if (p->use_wave() && th::stft_is_block_plan(p->g)) return "stft_block_kernel";
     return p->use_wave() ? "stft_wave_kernel" : "stft_generic_kernel";
 }

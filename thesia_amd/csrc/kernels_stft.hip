@@ -781,7 +781,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 // iterations: a group advances by G hops); the loads for the next iteration are issued right after the window multiply
 // and land during the transform.  dB output only (mel plans at these sizes use the one-frame kernel / generic kernel).
 // ------------------------------------------------------------------------------------------
-template <int LOG2_NC, int WAVES>
+template <int LOG2_NC, int WAVES, bool AMP>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
@@ -884,10 +884,15 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
             const uint32_t grp = W::grp(lane), last = cur.f1 - 1u - f, dg = grp < last ? grp : last;
             const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch + (size_t)dg * cur.spec_pitch;
             W::split_paired_w(lane, za, zb, ws, w_mid, [&](uint32_t kb, int kc, float p) {
-                const float d = power_to_dB(p);
-                *(gptr<float>)((gptr<char>)row + (uint64_t)(kb << 2) + (int64_t)(4 * kc)) = d;  // base + immediate (split_base)
-                lmin = nmin(lmin, d);
-                lmax = nmax(lmax, d);
+                const gptr<float> dst = (gptr<float>)((gptr<char>)row + (uint64_t)(kb << 2) + (int64_t)(4 * kc));  // base + immediate (split_base)
+                if constexpr (AMP) {  // amplitude rows for the matrix-core mel path (spectrogram.rs:200-207)
+                    *dst = power_to_amp(p);
+                } else {
+                    const float d = power_to_dB(p);
+                    *dst = d;
+                    lmin = nmin(lmin, d);
+                    lmax = nmax(lmax, d);
+                }
             });
             {   // complete the row's last 128-byte line (see wave_frame)
                 const uint32_t height = (uint32_t)(NC + 1), pad = cur.spec_pitch - height, l = W::lig(lane);
@@ -906,12 +911,12 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
     }
 }
 
-template <int LOG2_NC, int WAVES>
+template <int LOG2_NC, int WAVES, bool AMP>
 static hipError_t launch_wave_multi_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                                       uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
                                       uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
     using W = WaveFftM<LOG2_NC>;
-    auto kern = stft_wave_multi_kernel<LOG2_NC, WAVES>;
+    auto kern = stft_wave_multi_kernel<LOG2_NC, WAVES, AMP>;
     const size_t lds = sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -922,14 +927,14 @@ static hipError_t launch_wave_multi_t(const StftGeom &g, const ChanJob *d_jobs, 
                        d_minmax, d_queue_head);
     return hipGetLastError();
 }
-template <int LOG2_NC>
+template <int LOG2_NC, bool AMP>
 static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                                     uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
                                     uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s) {
     switch (waves <= 0 ? 12 : waves) {
-        case 8: return launch_wave_multi_t<LOG2_NC, 8>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
-        case 12: return launch_wave_multi_t<LOG2_NC, 12>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
-        case 16: return launch_wave_multi_t<LOG2_NC, 16>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+        case 8: return launch_wave_multi_t<LOG2_NC, 8, AMP>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+        case 12: return launch_wave_multi_t<LOG2_NC, 12, AMP>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+        case 16: return launch_wave_multi_t<LOG2_NC, 16, AMP>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -939,12 +944,13 @@ static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, co
 // radix-16 passes in registers with LDS exchanges between them.  One workgroup per chunk of frames_per_tile consecutive
 // interior frames (chunk table as for the wave kernels; the hardware dispatcher balances the workgroups); boundary frames
 // and channels shorter than n_fft go to the generic kernel.  Per-pass twiddle constants (10 per pass, FMA butterflies)
-// and, for n_fft 8192, the thread's 16 window pairs live in registers for the whole chunk.  dB output, linear scale only.
+// and, for n_fft 8192, the thread's 16 window pairs live in registers for the whole chunk.  Output: dB rows (linear scale)
+// or amplitude rows (AMP: first half of the matrix-core mel path).
 // 167 / 196 VGPRs: three workgroups (12 waves) per CU at n_fft 8192, one (8 waves) at 16384.  Measured and not adopted:
 // the mid-pass constants from LDS tables, the window from global memory at 8192 (both within +-3 %), forcing four waves
 // per SIMD with amdgpu_waves_per_eu (128 VGPRs, 140-240 bytes of scratch: 0.77 -> 1.32 ms and 1.33 -> 1.62 ms).
 // ------------------------------------------------------------------------------------------
-template <int LOG2_NC>
+template <int LOG2_NC, bool AMP>
 __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_tiles,
     const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax) {
@@ -1002,10 +1008,14 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
         __syncthreads();
         const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch;
         B::split(t, z, buf, stw_t, [&](uint32_t k, float p) {
-            const float d = power_to_dB(p);
-            row[k] = d;
-            lmin = nmin(lmin, d);
-            lmax = nmax(lmax, d);
+            if constexpr (AMP) {  // amplitude rows for the matrix-core mel path
+                row[k] = power_to_amp(p);
+            } else {
+                const float d = power_to_dB(p);
+                row[k] = d;
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            }
         });
         {   // complete the row's last 128-byte line (see wave_frame)
             const uint32_t height = (uint32_t)(NC + 1), padn = cur.spec_pitch - height;
@@ -1032,11 +1042,11 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     }
 }
 
-template <int LOG2_NC>
+template <int LOG2_NC, bool AMP>
 static hipError_t launch_block(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
                                const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
     using B = BlockFft<LOG2_NC>;
-    auto kern = stft_block_kernel<LOG2_NC>;
+    auto kern = stft_block_kernel<LOG2_NC, AMP>;
     const size_t lds = sizeof(cf32) * B::BUF_LEN + sizeof(float) * 2 * (B::T / 64);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1191,11 +1201,14 @@ namespace th {
 
 // n_fft 512 (multi-frame kernel): linear dB only
 bool stft_wave_supported(const StftGeom &g) {
-    return (g.log2_nc >= 9 && g.log2_nc <= 11 && g.n_mel <= 512) || (g.log2_nc == 8 && g.n_mel == 0) ||
-           ((g.log2_nc == 12 || g.log2_nc == 13) && g.n_mel == 0);  // n_fft 8192 / 16384: the block kernel, linear dB
+    // n_fft 512 (multi-frame kernel) ... 4096 (one frame per wave), 8192 / 16384 (block kernel); mel plans up to 512
+    // mels (fused epilogue at n_fft 1024 / 2048 where the tables fit, else amplitude rows + the matrix-core kernel)
+    return g.log2_nc >= 8 && g.log2_nc <= 13 && g.n_mel <= 512;
 }
 bool stft_is_block_plan(const StftGeom &g) { return g.log2_nc >= 12; }
-bool stft_wave_multi_applies(const StftGeom &g, int out_mode) { return out_mode == 0 && g.phased == 0 && (g.log2_nc == 8 || g.log2_nc == 9); }
+bool stft_wave_multi_applies(const StftGeom &g, int out_mode) {
+    return g.phased == 0 && ((out_mode == 0 && (g.log2_nc == 8 || g.log2_nc == 9)) || (out_mode == 1 && g.log2_nc == 8));
+}
 
 // Waves per workgroup (one persistent workgroup per CU).  Bounded by LDS (tables + one slab per
 // wave <= 160 KB) and by the VGPR file (64*WAVES threads => 512/(WAVES/4) VGPRs per lane).
@@ -1397,13 +1410,21 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
     if (!d_queue_head) return hipErrorInvalidValue;
     if (out.multi) {  // several short frames per wave (stft_wave_multi.h)
         if (!stft_wave_multi_applies(g, out.mode)) return hipErrorInvalidValue;
-        if (g.log2_nc == 8) return launch_wave_multi<8>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
-        return launch_wave_multi<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
+        if (out.mode == 1)  // amplitude rows (mel on the matrix cores): n_fft 512 only, 1024 has the one-frame kernel for that
+            return g.log2_nc == 8 ? launch_wave_multi<8, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, nullptr, d_queue_head, n_cu, waves, s)
+                                  : hipErrorInvalidValue;
+        if (g.log2_nc == 8) return launch_wave_multi<8, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
+        return launch_wave_multi<9, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
     }
     if (g.log2_nc >= 12) {  // one workgroup per frame (stft_block.h): dB output, linear scale
-        if (out.mode != 0 || g.phased) return hipErrorInvalidValue;
-        if (g.log2_nc == 12) return launch_block<12>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
-        if (g.log2_nc == 13) return launch_block<13>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+        if (out.mode > 1 || g.phased) return hipErrorInvalidValue;
+        if (out.mode == 1) {  // amplitude rows, no (min, max)
+            if (g.log2_nc == 12) return launch_block<12, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
+            if (g.log2_nc == 13) return launch_block<13, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
+            return hipErrorInvalidValue;
+        }
+        if (g.log2_nc == 12) return launch_block<12, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+        if (g.log2_nc == 13) return launch_block<13, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
         return hipErrorInvalidValue;
     }
     switch (g.log2_nc) {
