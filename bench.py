@@ -428,7 +428,10 @@ def main():
         wav44 = synth_on_gpu(torch, dev, list(range(2000, 2032)), 44100, int(round(args.seconds * 44100)))
         cases = (("cfg3: 64 stereo 48 kHz tracks, n_fft 4096 / hop 1024, linear dB", wl.wav, 48000, (4096, 1024, 4096, ta.LINEAR, 0)),
                  ("cfg4: 32 tracks 44.1 kHz, n_fft 2048 / hop 512, mel-128 dB", wav44, 44100, (2048, 512, 2048, ta.MEL, 128)),
-                 ("app default framing: 48 kHz, 1920 / 480 / 2048, linear dB", wl.wav, 48000, (1920, 480, 2048, ta.LINEAR, 0)))
+                 ("app default framing: 48 kHz, 1920 / 480 / 2048, linear dB", wl.wav, 48000, (1920, 480, 2048, ta.LINEAR, 0)),
+                 ("short transform: n_fft 512 / hop 128, linear dB (four frames per wave)", wl.wav, 48000, (512, 128, 512, ta.LINEAR, 0)),
+                 ("long transform: n_fft 8192 / hop 2048, linear dB (one workgroup per frame)", wl.wav, 48000, (8192, 2048, 8192, ta.LINEAR, 0)),
+                 ("long transform: n_fft 16384 / hop 4096, linear dB (one workgroup per frame)", wl.wav, 48000, (16384, 4096, 16384, ta.LINEAR, 0)))
         for label, wav_, sr_, (w_, h_, nf_, scale, n_mel) in cases:
             try:
                 pl = ta.Plan(ctx, sr_, w_, h_, nf_, scale, n_mel)

@@ -168,14 +168,15 @@ def fuzz_track_manager(ctx, seed=1, max_cases=10 ** 9, max_seconds=30.0):
 
 
 def fuzz_stft(ctx, seed=1, max_cases=10 ** 9, max_seconds=60.0, big=False):
-    """Random framings / lengths / batch shapes through the auto-selected kernel (wave kernel with all its modes: register
-    reuse, phased, dynamic, boundary frames, fused mel) against the generic kernel, which shares none of that code."""
+    """Random framings / lengths / batch shapes through the auto-selected kernel (the wave kernels with all their modes —
+    register reuse, phased, dynamic, boundary frames, fused mel, several frames per wave — the block kernel of n_fft 8192 /
+    16384, the matrix-core mel path) against the generic kernel, which shares none of that code."""
     rng = np.random.default_rng(seed)
     t_end = time.time() + max_seconds
     n_cases = 0
     worst = 0.0
     while time.time() < t_end and n_cases < max_cases:
-        n_fft = int(rng.choice([1024, 2048, 2048, 4096]))
+        n_fft = int(rng.choice([512, 1024, 2048, 2048, 4096, 8192, 16384]))  # multi-frame, one-frame and block kernels
         win = int(rng.integers(n_fft // 2 + 1, n_fft + 1))
         if rng.random() < 0.5:
             win = n_fft if rng.random() < 0.5 else win // 2 * 2
@@ -183,16 +184,16 @@ def fuzz_stft(ctx, seed=1, max_cases=10 ** 9, max_seconds=60.0, big=False):
         hop = max(1, min(hop, win))
         mel = rng.random() < 0.35
         n_mel = int(rng.choice([0, 40, 128, 200])) if mel else 0
-        sr = int(rng.choice([16000, 22050, 44100, 48000]))
+        sr = int(rng.choice([16000, 22050, 44100, 48000])) if n_fft <= 4096 else int(rng.choice([48000, 96000, 192000]))
         try:
             plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if mel else ta.LINEAR, n_mel)
             ref = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if mel else ta.LINEAR, n_mel)
         except ta.ThError:
             continue
         ref.set_kernel(1)
-        lens = [int(rng.integers(1, 6 * n_fft)) for _ in range(int(rng.integers(1, 5)))] + [int(rng.integers(n_fft, 40 * n_fft))]
+        lens = [int(rng.integers(1, 6 * n_fft)) for _ in range(int(rng.integers(1, 5)))] + [int(rng.integers(n_fft, min(40 * n_fft, 200000)))]
         if big:
-            lens += [int(rng.integers(200 * n_fft, 1500 * n_fft)) for _ in range(int(rng.integers(1, 4)))]
+            lens += [int(rng.integers(min(200 * n_fft, 1000000), min(1500 * n_fft, 4000000))) for _ in range(int(rng.integers(1, 4)))]
             hop = max(hop, 64)
         if hop < 8:
             lens = [min(v, 3 * n_fft) for v in lens]
