@@ -33,6 +33,9 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 4096
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 8192
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 16384
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 8192 --win 3840 --hop 960 --sr 96000
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 --kernel 0 1
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 192000 --nfft 8192 --win 7680 --hop 1920 --mel 0 --seconds 8 --kernel 0 1
   python3 scripts/bench_stft.py --reps 30 --tracks 1 --seconds 60
 } >> "$out/bench_stft.txt" 2>&1
 # the RCCL path on one GPU (world size 1): the line bench.py prints with the process group up

@@ -974,17 +974,35 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
         for (int m = 0; m < 16; m++) rw[m] = wtab_g[t + (uint32_t)T * m];
     }
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
-    for (uint32_t f = cur.f; f < cur.f1; f++) {
+    // raw samples of the frame about to be transformed: requested a frame ahead — between the mirror reads and the
+    // arithmetic of the previous frame's split pass, when only half of the transform's registers are still in use
+    cf32 x[16];
+    auto fetch = [&](uint32_t f) {
         // the frame's n_fft-sample span starts at e0 (interior frames only: the whole span is inside the channel)
         const int64_t e0 = (int64_t)f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
-        cf32 z[16];
 #pragma unroll
         for (int m = 0; m < 16; m++) {
             const gptr<const float> p = cur.wav + (e0 + 2 * (int64_t)(t + (uint32_t)T * m));
+            x[m] = {p[0], p[1]};
+        }
+    };
+#if defined(TH_BLOCK_PREFETCH_12)
+    constexpr bool PREFETCH = true;
+#else
+    // n_fft 16384 runs one workgroup per CU whatever it does (196 -> 240 VGPRs); at 8192 the 32 extra registers would cost
+    // the third workgroup per CU
+    constexpr bool PREFETCH = LOG2_NC == 13;
+#endif
+    if constexpr (PREFETCH) fetch(cur.f);
+    for (uint32_t f = cur.f; f < cur.f1; f++) {
+        if constexpr (!PREFETCH) fetch(f);
+        cf32 z[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
             cf32 w;
             if constexpr (WIN_REGS) w = rw[m];
             else w = wtab_g[t + (uint32_t)T * m];
-            z[m] = {p[0] * w.re, p[1] * w.im};
+            z[m] = {x[m].re * w.re, x[m].im * w.im};
         }
         __syncthreads();  // the previous frame's mirror reads are done: the buffer may be rewritten
         B::pass_first(t, z, buf);
@@ -1006,8 +1024,11 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
         __syncthreads();
         B::write_z(t, z, buf);
         __syncthreads();
+        cf32 zm[8];
+        B::split_read(t, buf, zm);
+        if constexpr (PREFETCH) fetch(f + 1 < cur.f1 ? f + 1 : f);  // (the last frame of a chunk re-reads its own span: in bounds, never used)
         const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch;
-        B::split(t, z, buf, stw_t, [&](uint32_t k, float p) {
+        B::split_compute(t, z, zm, stw_t, [&](uint32_t k, float p) {
             if constexpr (AMP) {  // amplitude rows for the matrix-core mel path
                 row[k] = power_to_amp(p);
             } else {

@@ -123,13 +123,21 @@ struct BlockFft {
     }
     // Split pass: thread t owns the pairs (k, Nc - k), k = t + T c, c < 8, and — thread 0 — the self-mirrored bin Nc/2.
     // stw_t = W_{n_fft}^t; W^{t + T c} = stw_t * omega^c, omega = exp(-i pi / 16).  emit(bin, |X[bin]|^2).
+    // (in two steps, so that the kernel can request the next frame's samples between the LDS reads and the arithmetic)
+    static TH_HD void split_read(uint32_t t, const cf32 *buf, cf32 (&zm)[8]) {
+        TH_UNROLL for (int c = 0; c < 8; c++) zm[c] = buf[(uint32_t)NC - t - (uint32_t)T * c];
+    }
     template <class Emit>
     static TH_HD void split(uint32_t t, const cf32 (&z)[16], const cf32 *buf, cf32 stw_t, Emit emit) {
+        cf32 zm[8];
+        split_read(t, buf, zm);
+        split_compute(t, z, zm, stw_t, emit);
+    }
+    template <class Emit>
+    static TH_HD void split_compute(uint32_t t, const cf32 (&z)[16], const cf32 (&zm)[8], cf32 stw_t, Emit emit) {
         constexpr float OC[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
                                  0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
                                  0.19509032201612826785f, 0.0f};  // cos(pi c / 16); sin(pi c / 16) = OC[8 - c]
-        cf32 zm[8];
-        TH_UNROLL for (int c = 0; c < 8; c++) zm[c] = buf[(uint32_t)NC - t - (uint32_t)T * c];
         TH_UNROLL for (int c = 0; c < 8; c++) {
             const cf32 w = cmul_c(stw_t, OC[c], -OC[8 - c]);
             const cf32 zk = z[c];
