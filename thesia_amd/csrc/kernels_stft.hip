@@ -948,7 +948,8 @@ static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, co
 // or amplitude rows (AMP: first half of the matrix-core mel path).
 // 167 / 196 VGPRs: three workgroups (12 waves) per CU at n_fft 8192, one (8 waves) at 16384.  Measured and not adopted:
 // the mid-pass constants from LDS tables, the window from global memory at 8192 (both within +-3 %), forcing four waves
-// per SIMD with amdgpu_waves_per_eu (128 VGPRs, 140-240 bytes of scratch: 0.77 -> 1.32 ms and 1.33 -> 1.62 ms).
+// per SIMD with amdgpu_waves_per_eu (128 VGPRs, 140-240 bytes of scratch: 0.77 -> 1.32 ms and 1.33 -> 1.62 ms), requesting
+// the next frame's samples during the split pass (32 more VGPRs: n_fft 16384 +-0, 8192 loses its third workgroup: 0.78 -> 0.93 ms).
 // ------------------------------------------------------------------------------------------
 template <int LOG2_NC, bool AMP>
 __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
