@@ -975,9 +975,7 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
         for (int m = 0; m < 16; m++) rw[m] = wtab_g[t + (uint32_t)T * m];
     }
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
-    // raw samples of the frame about to be transformed: requested a frame ahead — between the mirror reads and the
-    // arithmetic of the previous frame's split pass, when only half of the transform's registers are still in use
-    cf32 x[16];
+    cf32 x[16];  // raw samples of the frame
     auto fetch = [&](uint32_t f) {
         // the frame's n_fft-sample span starts at e0 (interior frames only: the whole span is inside the channel)
         const int64_t e0 = (int64_t)f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
@@ -987,16 +985,8 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
             x[m] = {p[0], p[1]};
         }
     };
-#if defined(TH_BLOCK_PREFETCH_12)
-    constexpr bool PREFETCH = true;
-#else
-    // n_fft 16384 runs one workgroup per CU whatever it does (196 -> 240 VGPRs); at 8192 the 32 extra registers would cost
-    // the third workgroup per CU
-    constexpr bool PREFETCH = LOG2_NC == 13;
-#endif
-    if constexpr (PREFETCH) fetch(cur.f);
     for (uint32_t f = cur.f; f < cur.f1; f++) {
-        if constexpr (!PREFETCH) fetch(f);
+        fetch(f);
         cf32 z[16];
 #pragma unroll
         for (int m = 0; m < 16; m++) {
@@ -1027,7 +1017,6 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
         __syncthreads();
         cf32 zm[8];
         B::split_read(t, buf, zm);
-        if constexpr (PREFETCH) fetch(f + 1 < cur.f1 ? f + 1 : f);  // (the last frame of a chunk re-reads its own span: in bounds, never used)
         const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch;
         B::split_compute(t, z, zm, stw_t, [&](uint32_t k, float p) {
             if constexpr (AMP) {  // amplitude rows for the matrix-core mel path
