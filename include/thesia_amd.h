@@ -311,7 +311,8 @@ TH_API int th_channel_stats_dev(th_ctx *ctx, const th_stats_desc *descs, size_t 
 /* Waveform pyramid: every decimation level of a channel from one pass over the audio.  Level L
  * (samples per bin 2^L, exactly the bins encode_waveform_tile emits for that level — render_tiles.rs:232-279)
  * has th_waveform_pyramid_bins(n, L) = ceil(n / 2^L) bins of (min, max, mean) f32 and starts at float offset
- * th_waveform_pyramid_offset(n, L) of `out`; tile t of level L is bins [1024 t, 1024 (t + 1)) of that level.
+ * th_waveform_pyramid_offset(n, L) of `out` (every level starts on a 128-byte boundary: the offsets are multiples of 32
+ * floats, with up to 31 unused floats behind a level); tile t of level L is bins [1024 t, 1024 (t + 1)) of that level.
  * `out` must hold th_waveform_pyramid_offset(n, n_levels) floats. */
 typedef struct {
     const float *wav; /* DEVICE */

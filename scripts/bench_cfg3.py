@@ -98,7 +98,7 @@ off = 0
 ok = True
 for level in range(n_levels):
     nb = ta.api.pyramid_bins(n, level)
-    p = pyr[0, ta.api.pyramid_offset(n, level): ta.api.pyramid_offset(n, level + 1)].reshape(-1, 3)
+    p = pyr[0, ta.api.pyramid_offset(n, level): ta.api.pyramid_offset(n, level) + 3 * nb].reshape(-1, 3)
     t = a[off * 3:(off + nb) * 3].reshape(-1, 3)
     off += nb
     ok &= bool(torch.equal(p[:, :2], t[:, :2])) and float((p[:, 2] - t[:, 2]).abs().max()) <= 1e-6 * 0.25

@@ -345,7 +345,8 @@ class Context:
         finally:
             d.free()
             o.free()
-        return [flat[pyramid_offset(wav.size, l): pyramid_offset(wav.size, l + 1)].reshape(-1, 3) for l in range(n_levels)]
+        return [flat[pyramid_offset(wav.size, l): pyramid_offset(wav.size, l) + 3 * pyramid_bins(wav.size, l)].reshape(-1, 3)
+                for l in range(n_levels)]
 
 
 # ------------------------------------------------------------------ SpectrogramAnalyzer plan

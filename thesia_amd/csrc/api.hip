@@ -1399,11 +1399,7 @@ TH_API int th_waveform_pyramid_dev(th_ctx *c, const th_pyramid_desc *descs, size
         j.n_samples = d.n_levels ? d.n_samples : 0;
         j.n_levels = d.n_levels;
         j.aligned16 = (reinterpret_cast<uintptr_t>(d.wav) & 15u) == 0;
-        uint64_t off = 0;
-        for (uint32_t l = 0; l < PYR_MAX_LEVELS; l++) {
-            j.level_off[l] = off;
-            off += 3 * pyramid_bins(d.n_samples, l);
-        }
+        for (uint32_t l = 0; l < PYR_MAX_LEVELS; l++) j.level_off[l] = pyramid_offset(d.n_samples, l);
         j.sums_half = pyramid_bins(d.n_samples, 12);
         sums_total += 2 * j.sums_half;
         max_samples = std::max<uint64_t>(max_samples, j.n_samples);
