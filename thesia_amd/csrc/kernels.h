@@ -125,6 +125,15 @@ hipError_t launch_lod_hpass(const uint16_t *d_img, uint32_t img_pitch, uint32_t 
                             uint16_t *d_tmp, uint32_t tmp_pitch, hipStream_t s);
 hipError_t launch_lod_vpass(const uint16_t *d_tmp, uint32_t tmp_pitch, uint32_t y_lo, LodAxis ay, uint32_t dw,
                             uint16_t *d_lod, uint32_t lod_pitch, hipStream_t s);
+// the vertical pass over many images of one shape (whole images: source rows from 0): one launch, grid z = job
+struct LodPassJob {
+    const uint16_t *src;
+    uint16_t *dst;
+    uint32_t src_pitch, dst_pitch;
+};
+hipError_t launch_lod_vpass_batch(const LodPassJob *d_jobs, uint32_t n_jobs, LodAxis ay, uint32_t dw, hipStream_t s);
+// dst[x][y] = src[y][x] for w x h images (src_pitch / dst_pitch in elements)
+hipError_t launch_transpose_u16_batch(const LodPassJob *d_jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s);
 // one tile rectangle of one image -> RGBA, job passed by value (tile requests: nothing to upload)
 hipError_t launch_raster_tile(const uint16_t *d_img, uint32_t img_width, uint32_t img_height, uint32_t img_pitch,
                               uint32_t origin_x, uint32_t origin_y, uint32_t width, uint32_t height, uint8_t *d_rgba,

@@ -444,6 +444,53 @@ __global__ __launch_bounds__(256) void lod_vpass_kernel(const uint16_t *__restri
     as_global(lod)[(size_t)oy * lod_pitch + ox] = lod_round(acc, ay.wsum[oy]);
 }
 
+// The vertical pass over MANY images of one shape in one launch (the mip pyramids of a batch of tracks: a launch per
+// level instead of a launch per level and channel; the horizontal pass is this one on the transposed image, see
+// transpose_u16_batch_kernel); blockIdx.z picks the job.
+__global__ __launch_bounds__(256) void lod_vpass_batch_kernel(const LodPassJob *__restrict__ jobs, LodAxis ay, uint32_t dw) {
+    const uint32_t ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= dw) return;
+    const LodPassJob job = jobs[blockIdx.z];
+    const gptr<const uint16_t> col = as_global(job.src) + (size_t)ay.start[oy] * job.src_pitch + ox;
+    const gptr<const double> w = as_global(ay.w) + (size_t)oy * ay.max_taps;
+    const int32_t n = ay.count[oy];
+    double acc = 0.0;
+    for (int32_t t = 0; t < n; t++) acc += w[t] * (double)col[(size_t)t * job.src_pitch];
+    as_global(job.dst)[(size_t)oy * job.dst_pitch + ox] = lod_round(acc, ay.wsum[oy]);
+}
+// u16 transpose of many images of one shape: dst[x][y] = src[y][x], 64 x 64 tiles through LDS (both sides coalesced).
+// The mip builder runs the horizontal Lanczos pass as a vertical pass over the transposed image: a thread per output
+// column that walks its taps along a row reads a different cache line in every lane (the upper levels, hundreds of taps
+// per output, took 1-3 ms each for 32 images), a thread that walks them down a column reads 128 contiguous bytes per wave.
+__global__ __launch_bounds__(256) void transpose_u16_batch_kernel(const LodPassJob *__restrict__ jobs, uint32_t w, uint32_t h) {
+    __shared__ uint16_t tile[64][66];
+    const LodPassJob job = jobs[blockIdx.z];
+    const uint32_t x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+    for (uint32_t j = ty; j < 64; j += 4) {
+        const uint32_t x = x0 + tx, y = y0 + j;
+        tile[j][tx] = (x < w && y < h) ? as_global(job.src)[(size_t)y * job.src_pitch + x] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (uint32_t j = ty; j < 64; j += 4) {
+        const uint32_t x = x0 + j, y = y0 + tx;
+        if (x < w && y < h) as_global(job.dst)[(size_t)x * job.dst_pitch + y] = tile[tx][j];
+    }
+}
+hipError_t launch_transpose_u16_batch(const LodPassJob *d_jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s) {
+    if (!n_jobs || !w || !h) return hipSuccess;
+    if (n_jobs > 65535u || (h + 63) / 64 > 65535u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(transpose_u16_batch_kernel, dim3((w + 63) / 64, (h + 63) / 64, n_jobs), dim3(256), 0, s, d_jobs, w, h);
+    return hipGetLastError();
+}
+
+hipError_t launch_lod_vpass_batch(const LodPassJob *d_jobs, uint32_t n_jobs, LodAxis ay, uint32_t dw, hipStream_t s) {
+    if (!n_jobs || !ay.n_out || !dw) return hipSuccess;
+    if (ay.n_out > 65535u || n_jobs > 65535u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lod_vpass_batch_kernel, dim3((dw + 255) / 256, ay.n_out, n_jobs), dim3(256), 0, s, d_jobs, ay, dw);
+    return hipGetLastError();
+}
+
 hipError_t launch_lod_hpass(const uint16_t *d_img, uint32_t img_pitch, uint32_t y_lo, uint32_t n_rows, LodAxis ax,
                             uint16_t *d_tmp, uint32_t tmp_pitch, hipStream_t s) {
     if (!n_rows || !ax.n_out) return hipSuccess;

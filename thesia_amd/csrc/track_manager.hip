@@ -49,6 +49,7 @@ struct Channel {
     size_t img_h = 0, img_w = 0, img_pitch = 0;  // rows padded to 128 B (th_pitch_u16)
     std::map<std::pair<uint32_t, uint32_t>, MipLevel> mips;  // (level_x, level_y) != (0, 0): views into d_mips
     uint16_t *d_mips = nullptr;                               // one allocation for every level
+    size_t mips_elems = 0;                                    // its size (re-made images of the same shape reuse it)
     float mn = INFINITY, mx = -INFINITY;  // find_min_max of this spec (simd.rs:14-36)
     bool has_spec = false;
 };
@@ -108,6 +109,8 @@ struct th_tm {
     // (the reference's own flow; kept as the comparison path).  Levels the pyramid does not hold always use 1.
     int lod_source = 0;
     std::map<std::pair<uint32_t, uint32_t>, AxisTable> axis_tabs;  // (source length, level) -> taps
+    th::DeviceTable mip_jobs;                                       // job table of the batched mip-pyramid passes
+    th::DeviceTable mip_scratch;                                    // transposed images of one chunk of the batch
     uint64_t stat_tiles_served = 0;
 
     void invalidate_waveform() { cache.invalidate_waveform(); }
@@ -128,6 +131,7 @@ namespace {
 void free_mips(Channel &c) {
     if (c.d_mips) (void)hipFree(c.d_mips);
     c.d_mips = nullptr;
+    c.mips_elems = 0;
     c.mips.clear();
 }
 
@@ -309,55 +313,142 @@ LodAxis axis_view(const AxisTable &t) {
     return a;
 }
 
-// Build every (lx, ly) level of one channel's image: horizontal pass from level 0 for each lx, vertical pass from
-// (lx, 0) for each ly — the same order and the same one-rounding-per-pass as the per-request resize.
-int build_mips(th_tm *tm, Channel &ch) {
-    free_mips(ch);
-    if (!ch.d_img || !ch.img_w || !ch.img_h) return TH_OK;
+// Build every (lx, ly) level of the images of `chans`: horizontal pass from level 0 for each lx, vertical pass from
+// (lx, 0) for each ly — the same order and the same one-rounding-per-pass as the per-request resize.  Images of one shape
+// go through every pass together (grid z = image): a launch per level, not per level and channel (32 tracks: ~1000 launches
+// of a few microseconds of work each took 27 ms of the 28 ms an apply_track_list_changes spent behind the STFT).
+int build_mips(th_tm *tm, const std::vector<Channel *> &chans) {
     hipStream_t s = tm->ctx->stream;
-    const uint32_t W = (uint32_t)ch.img_w, Hh = (uint32_t)ch.img_h;
-    uint32_t Lx = 0, Ly = 0;
-    while (Lx < MIP_MAX_LX && ((W + (2u << Lx) - 1) >> (Lx + 1)) >= MIP_MIN_DIM) Lx++;
-    while (Ly < MIP_MAX_LY && ((Hh + (2u << Ly) - 1) >> (Ly + 1)) >= MIP_MIN_DIM) Ly++;
-    // shapes first, then ONE allocation for all levels (a hipMalloc per level cost more than the resampling)
-    size_t total = 0;
-    for (uint32_t lx = 0; lx <= Lx; lx++)
-        for (uint32_t ly = 0; ly <= Ly; ly++) {
-            if (!lx && !ly) continue;
-            MipLevel m;
-            m.w = (W + (1u << lx) - 1) >> lx;
-            m.h = (Hh + (1u << ly) - 1) >> ly;
-            m.pitch = (uint32_t)th_pitch_u16(m.w);
-            m.d = reinterpret_cast<uint16_t *>(total);  // offset for now
-            total += ((size_t)m.h * m.pitch + 127) / 128 * 128;
-            ch.mips[{lx, ly}] = m;
+    struct Shape {
+        uint32_t w, h, pitch;
+        bool operator<(const Shape &o) const { return std::tie(w, h, pitch) < std::tie(o.w, o.h, o.pitch); }
+    };
+    std::map<Shape, std::vector<Channel *>> groups;
+    for (Channel *ch : chans) {
+        if (!ch->d_img || !ch->img_w || !ch->img_h) {
+            free_mips(*ch);
+            continue;
         }
-    if (!total) return TH_OK;
-    hipError_t e = hipMalloc((void **)&ch.d_mips, total * sizeof(uint16_t));
-    if (e != hipSuccess) {
-        ch.mips.clear();
-        TH_HIP(e);
+        ch->mips.clear();
+        const uint32_t W = (uint32_t)ch->img_w, Hh = (uint32_t)ch->img_h;
+        uint32_t Lx = 0, Ly = 0;
+        while (Lx < MIP_MAX_LX && ((W + (2u << Lx) - 1) >> (Lx + 1)) >= MIP_MIN_DIM) Lx++;
+        while (Ly < MIP_MAX_LY && ((Hh + (2u << Ly) - 1) >> (Ly + 1)) >= MIP_MIN_DIM) Ly++;
+        // shapes first, then ONE allocation for all levels (a hipMalloc per level cost more than the resampling)
+        size_t total = 0;
+        for (uint32_t lx = 0; lx <= Lx; lx++)
+            for (uint32_t ly = 0; ly <= Ly; ly++) {
+                if (!lx && !ly) continue;
+                MipLevel m;
+                m.w = (W + (1u << lx) - 1) >> lx;
+                m.h = (Hh + (1u << ly) - 1) >> ly;
+                m.pitch = (uint32_t)th_pitch_u16(m.w);
+                m.d = reinterpret_cast<uint16_t *>(total);  // offset for now
+                total += ((size_t)m.h * m.pitch + 127) / 128 * 128;
+                ch->mips[{lx, ly}] = m;
+            }
+        if (!total) {
+            free_mips(*ch);
+            continue;
+        }
+        // (a dB-range or colour-map change re-makes every image at its old shape: keep the allocation — hipFree
+        // synchronises the device and a hipMalloc of this size takes longer than the resampling)
+        if (!ch->d_mips || ch->mips_elems != total) {
+            const std::map<std::pair<uint32_t, uint32_t>, MipLevel> views = ch->mips;
+            free_mips(*ch);
+            hipError_t e = hipMalloc((void **)&ch->d_mips, total * sizeof(uint16_t));
+            if (e != hipSuccess) TH_HIP(e);
+            ch->mips = views;
+            ch->mips_elems = total;
+        }
+        for (auto &kv : ch->mips) kv.second.d = ch->d_mips + reinterpret_cast<size_t>(kv.second.d);
+        groups[Shape{W, Hh, (uint32_t)ch->img_pitch}].push_back(ch);
     }
-    for (auto &kv : ch.mips) kv.second.d = ch.d_mips + reinterpret_cast<size_t>(kv.second.d);
-    for (uint32_t lx = 0; lx <= Lx; lx++) {
-        const uint16_t *src = ch.d_img;
-        uint32_t src_w = W, src_pitch = (uint32_t)ch.img_pitch;
-        if (lx > 0) {
-            AxisTable *tx = nullptr;
-            int rc = axis_table(tm, W, lx, &tx);
-            if (rc != TH_OK) return rc;
-            const MipLevel &m = ch.mips[{lx, 0u}];
-            TH_HIP(launch_lod_hpass(ch.d_img, (uint32_t)ch.img_pitch, 0, Hh, axis_view(*tx), m.d, m.pitch, s));
-            src = m.d;
-            src_w = m.w;
-            src_pitch = m.pitch;
+    // One job table for all launches (uploaded once), then the launches in dependency order per shape.  The horizontal
+    // pass runs as transpose -> vertical pass along x -> transpose back (kernels_image.hip: same taps, same order, same
+    // rounding: bit-identical to lod_hpass_kernel); the transposed level-0 image and the transposed result of one level
+    // live in a scratch buffer of the manager, MIP_CHUNK images at a time.
+    enum Kind { TRANSPOSE, VPASS };
+    struct Launch {
+        Kind kind;
+        uint32_t level, first, count, n_in, a, b;  // TRANSPOSE: a x b image;  VPASS: axis of length n_in at `level`, dw = a
+    };
+    constexpr size_t MIP_CHUNK = 32;
+    std::vector<LodPassJob> jobs;
+    std::vector<Launch> launches;
+    size_t scratch_elems = 0;
+    for (auto &g : groups) {
+        const uint32_t W = g.first.w, Hh = g.first.h;
+        uint32_t Lx = 0;
+        for (auto &kv : g.second[0]->mips) Lx = std::max(Lx, kv.first.first);
+        if (Lx == 0) continue;
+        const size_t pT = th_pitch_u16(Hh);  // row pitch of the transposed images (rows = x, columns = y)
+        const size_t per_img = (size_t)W * pT + (size_t)((W + 1) / 2) * pT;
+        scratch_elems = std::max(scratch_elems, per_img * std::min(MIP_CHUNK, g.second.size()));
+    }
+    if (scratch_elems) {
+        int rc = tm->mip_scratch.ensure(scratch_elems * sizeof(uint16_t));
+        if (rc != TH_OK) return rc;
+    }
+    uint16_t *const scratch = static_cast<uint16_t *>(tm->mip_scratch.dptr);
+    for (auto &g : groups) {
+        const uint32_t W = g.first.w, Hh = g.first.h;
+        uint32_t Lx = 0, Ly = 0;
+        for (auto &kv : g.second[0]->mips) {
+            Lx = std::max(Lx, kv.first.first);
+            Ly = std::max(Ly, kv.first.second);
         }
-        for (uint32_t ly = 1; ly <= Ly; ly++) {
-            AxisTable *ty = nullptr;
-            int rc = axis_table(tm, Hh, ly, &ty);
+        const uint32_t pT = (uint32_t)th_pitch_u16(Hh);
+        const size_t t0_elems = (size_t)W * pT, per_img = t0_elems + (size_t)((W + 1) / 2) * pT;
+        for (size_t c0 = 0; c0 < g.second.size(); c0 += MIP_CHUNK) {
+            const std::vector<Channel *> cs(g.second.begin() + c0, g.second.begin() + std::min(g.second.size(), c0 + MIP_CHUNK));
+            const uint32_t nc = (uint32_t)cs.size();
+            auto t0 = [&](size_t i) { return scratch + i * per_img; };            // transposed level 0: W rows of Hh
+            auto tl = [&](size_t i) { return scratch + i * per_img + t0_elems; };  // transposed level lx: w_lx rows of Hh
+            if (Lx > 0) {
+                launches.push_back(Launch{TRANSPOSE, 0, (uint32_t)jobs.size(), nc, 0, W, Hh});
+                for (size_t i = 0; i < nc; i++) jobs.push_back(LodPassJob{cs[i]->d_img, t0(i), (uint32_t)cs[i]->img_pitch, pT});
+            }
+            for (uint32_t lx = 0; lx <= Lx; lx++) {
+                if (lx > 0) {
+                    const uint32_t wl = cs[0]->mips[{lx, 0u}].w;
+                    launches.push_back(Launch{VPASS, lx, (uint32_t)jobs.size(), nc, W, Hh, 0});  // along x, Hh columns
+                    for (size_t i = 0; i < nc; i++) jobs.push_back(LodPassJob{t0(i), tl(i), pT, pT});
+                    launches.push_back(Launch{TRANSPOSE, 0, (uint32_t)jobs.size(), nc, 0, Hh, wl});  // (Hh x wl)^T -> wl x Hh image
+                    for (size_t i = 0; i < nc; i++) {
+                        const MipLevel &m = cs[i]->mips[{lx, 0u}];
+                        jobs.push_back(LodPassJob{tl(i), m.d, pT, m.pitch});
+                    }
+                }
+                for (uint32_t ly = 1; ly <= Ly; ly++) {
+                    const uint32_t src_w = lx > 0 ? cs[0]->mips[{lx, 0u}].w : W;
+                    launches.push_back(Launch{VPASS, ly, (uint32_t)jobs.size(), nc, Hh, src_w, 0});
+                    for (Channel *ch : cs) {
+                        const MipLevel &m = ch->mips[{lx, ly}];
+                        if (lx > 0) {
+                            const MipLevel &src = ch->mips[{lx, 0u}];
+                            jobs.push_back(LodPassJob{src.d, m.d, src.pitch, m.pitch});
+                        } else {
+                            jobs.push_back(LodPassJob{ch->d_img, m.d, (uint32_t)ch->img_pitch, m.pitch});
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (launches.empty()) return TH_OK;
+    int rc = tm->mip_jobs.upload(s, jobs.data(), jobs.size() * sizeof(LodPassJob));
+    if (rc != TH_OK) return rc;
+    const LodPassJob *dj = static_cast<const LodPassJob *>(tm->mip_jobs.dptr);
+    for (const Launch &l : launches) {
+        if (l.kind == TRANSPOSE) {
+            // a x b: the SOURCE has b rows of a elements (dst[x][y] = src[y][x], x < a, y < b)
+            TH_HIP(launch_transpose_u16_batch(dj + l.first, l.count, l.a, l.b, s));
+        } else {
+            AxisTable *t = nullptr;
+            rc = axis_table(tm, l.n_in, l.level, &t);
             if (rc != TH_OK) return rc;
-            const MipLevel &m = ch.mips[{lx, ly}];
-            TH_HIP(launch_lod_vpass(src, src_pitch, 0, axis_view(*ty), src_w, m.d, m.pitch, s));
+            TH_HIP(launch_lod_vpass_batch(dj + l.first, l.count, axis_view(*t), l.a, s));
         }
     }
     return TH_OK;
@@ -437,11 +528,7 @@ int update_spec_imgs(th_tm *tm, bool force_update_all, std::vector<size_t> *upda
     int rc = th_spec_to_img_batch_dev(tm->ctx, descs.data(), descs.size(), tm->min_dB, tm->max_dB, tm->colormap_length);
     if (rc != TH_OK) return rc;
     // the LOD mip pyramid of every image that was just re-made (render_tiles.rs:290-313,354-393)
-    for (Channel *ch : made) {
-        rc = build_mips(tm, *ch);
-        if (rc != TH_OK) return rc;
-    }
-    return TH_OK;
+    return build_mips(tm, made);
 }
 
 Channel *find_channel(th_tm *tm, size_t id, uint32_t ch) {
@@ -533,6 +620,8 @@ TH_API int th_tm_destroy(th_tm *tm) {
         for (Channel &ch : kv.second.ch) free_channel(ch);
     for (auto &kv : tm->plans) th_plan_destroy(kv.second);
     for (auto &kv : tm->axis_tabs) (void)hipFree(kv.second.d_blob);
+    tm->mip_jobs.release();
+    tm->mip_scratch.release();
     if (tm->d_colormap) (void)hipFree(tm->d_colormap);
     delete tm;
     return TH_OK;
