@@ -20,7 +20,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 using gf2 = __attribute__((address_space(1))) v2f;
 using gf4 = __attribute__((address_space(1))) v4f;
 
-constexpr uint32_t N_FFT = 2048, HOP = 512, H = 1025, PITCH = 1056, CHUNK = 32;
+#if !defined(CHUNK_FRAMES)
+#define CHUNK_FRAMES 32
+#endif
+constexpr uint32_t N_FFT = 2048, HOP = 512, H = 1025, PITCH = 1056, CHUNK = CHUNK_FRAMES;
 
 template <int LOADM, int STOREM, int FMA, int LDSR, int WAVES, int LDSM = 0>
 __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_, uint32_t n_chan, uint32_t n_samples,
@@ -30,12 +33,21 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_,
     v2f *slab = lds + wave * 1100;
     const uint32_t n_chunks = n_chan * chunks_per_chan;
     bool first = true;
+    uint32_t round_no = 0;
+    (void)round_no;
     for (;;) {
         uint32_t c = blockIdx.x * WAVES + wave;
+#if defined(STATIC_ROUNDS)
+        // chunk t goes to wave t mod W in round t / W, no queue: waves that advance at the same pace write neighbouring rows
+        // at the same time (DRAM locality of the store stream)
+        c += round_no * gridDim.x * WAVES;
+        round_no++;
+#else
         if (!first) {
             if (lane == 0) c = atomicAdd(queue, 1u);
             c = __builtin_amdgcn_readfirstlane(c) + gridDim.x * WAVES;
         }
+#endif
         first = false;
         if (c >= n_chunks) break;
         const uint32_t ch = c / chunks_per_chan, f0 = 2 + (c % chunks_per_chan) * CHUNK;  // interior frames only
@@ -64,6 +76,20 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_,
                 }
             }
         }
+#if defined(LOOKAHEAD2)
+        // the new hop of frame f + 1 was requested TWO frames ago (buffers ya / yb alternate): gfx9 has one in-order
+        // vmcnt for loads and stores, so a wait for loads issued one frame ago also waits for the stores of the frame
+        // before that
+        const uint32_t LL = LOADM == 3 ? 4 * (lane & 15) + (lane >> 4) : lane;
+        v2f ya[4], yb[4];
+        {
+            const uint32_t fa = min(f0 + 1, f1 - 1), fb = min(f0 + 2, f1 - 1);
+#pragma unroll
+            for (int m = 0; m < 4; m++) ya[m] = *(const gf2 *)(wav + ((int64_t)fa * HOP - N_FFT / 2) + 2 * (LL + 64 * (12 + m)));
+#pragma unroll
+            for (int m = 0; m < 4; m++) yb[m] = *(const gf2 *)(wav + ((int64_t)fb * HOP - N_FFT / 2) + 2 * (LL + 64 * (12 + m)));
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (uint32_t f = f0; f < f1; f++) {
             // consume the frame in registers: fold all 16 slots into the accumulators (stands for the window multiply)
@@ -74,7 +100,26 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_,
             const int64_t e0n = (int64_t)fn * HOP - N_FFT / 2;
 #pragma unroll
             for (int m = 0; m < 12; m++) x[m] = x[m + 4];
+#if defined(LOOKAHEAD2)
+            {
+                const uint32_t f3 = min(f + 3, f1 - 1);
+                const int64_t e3 = (int64_t)f3 * HOP - N_FFT / 2;
+                if (((f - f0) & 1u) == 0) {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) x[12 + m] = ya[m];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) ya[m] = *(const gf2 *)(wav + e3 + 2 * (LL + 64 * (12 + m)));
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) x[12 + m] = yb[m];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) yb[m] = *(const gf2 *)(wav + e3 + 2 * (LL + 64 * (12 + m)));
+                }
+            }
+            if (false) {
+#else
             if (LOADM == 1 || LOADM == 3) {
+#endif
                 const uint32_t L = LOADM == 3 ? 4 * (lane & 15) + (lane >> 4) : lane;
 #pragma unroll
                 for (int m = 12; m < 16; m++) x[m] = *(const gf2 *)(wav + e0n + 2 * (L + 64 * m));
@@ -273,6 +318,73 @@ int main(int argc, char **argv) {
     }
     printf("# gap between launches: %d us\n", gap_us);
 #define R(L, S, F, D, W, M) run<L, S, F, D, W, M>("", wav, spec, n_chan, n_samples, T, q, gap_us)
+    if (argc > 2 && atoi(argv[2]) == 1) {
+        // store shapes next to the kernel's amount of VALU / LDS work: the kernel's pattern (1), 16 aligned dword stores
+        // (2), four 16-byte stores (3; with a third LDS round standing for the transposition that would feed them),
+        // adjacent-bin pairs (4)
+        for (int rep = 0; rep < 3; rep++) {
+            R(3, 1, 42, 2, 12, 2);
+            R(3, 2, 42, 2, 12, 2);
+            R(3, 3, 42, 2, 12, 2);
+            R(3, 3, 42, 3, 12, 2);
+            R(3, 4, 42, 2, 12, 2);
+        }
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == 5) {  // with the kernel's amount of work: waves per CU, 16-byte loads / stores
+        for (int rep = 0; rep < 3; rep++) {
+            R(3, 1, 42, 2, 12, 2);
+            R(3, 1, 42, 2, 8, 2);
+            R(3, 1, 42, 2, 10, 2);
+            R(2, 1, 42, 2, 12, 2);
+            R(2, 3, 42, 2, 12, 2);
+            R(2, 3, 42, 2, 8, 2);
+            R(2, 3, 42, 2, 10, 2);
+        }
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == 4) {  // chunk-length builds (-DCHUNK_FRAMES=n): stores alone, memory skeleton, with the kernel's work
+        printf("# chunk %u frames\n", CHUNK);
+        for (int rep = 0; rep < 2; rep++) {
+            R(0, 1, 0, 0, 12, 2);
+            R(3, 1, 0, 0, 12, 2);
+            R(3, 1, 42, 2, 12, 2);
+        }
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == 3) {
+        // the memory skeleton alone (no VALU / LDS work): load shapes x store shapes x waves per CU
+        for (int rep = 0; rep < 2; rep++) {
+            R(3, 1, 0, 0, 12, 2);
+            R(1, 1, 0, 0, 12, 2);
+            R(2, 1, 0, 0, 12, 2);
+            R(3, 2, 0, 0, 12, 2);
+            R(3, 3, 0, 0, 12, 2);
+            R(2, 3, 0, 0, 12, 2);
+            R(3, 1, 0, 0, 8, 2);
+            R(3, 1, 0, 0, 16, 2);
+            R(2, 3, 0, 0, 16, 2);
+            R(0, 1, 0, 0, 12, 2);
+            R(0, 3, 0, 0, 12, 2);
+            R(3, 0, 0, 0, 12, 2);
+        }
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == 2) {
+        // what an amount of VALU or LDS work is worth in launch time, next to the kernel's memory traffic (power-capped part)
+        for (int rep = 0; rep < 2; rep++) {
+            R(3, 1, 42, 2, 12, 2);
+            R(3, 1, 36, 2, 12, 2);
+            R(3, 1, 30, 2, 12, 2);
+            R(3, 1, 21, 2, 12, 2);
+            R(3, 1, 42, 1, 12, 2);
+            R(3, 1, 42, 0, 12, 2);
+            R(3, 1, 0, 2, 12, 2);
+            R(3, 1, 0, 0, 12, 2);
+            R(3, 1, -42, 2, 12, 2);
+        }
+        return 0;
+    }
     R(0, 0, 48, 0, 12, 0);
     R(0, 0, -48, 0, 12, 0);
     R(0, 0, 48, 2, 12, 2);
