@@ -114,8 +114,8 @@ def fuzz_track_manager(ctx, seed=1, max_cases=10 ** 9, max_seconds=30.0):
             if op == "add" or not tracks:
                 new = []
                 for _ in range(int(rng.integers(1, 3))):
-                    sr = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
-                    n = int(rng.integers(200, 30000))
+                    sr = int(rng.choice([8000, 16000, 22050, 44100, 48000, 96000, 192000]))  # n_fft 512 .. 16384 with f_overlap 1 / 2
+                    n = int(rng.integers(200, 30000 if sr <= 48000 else 90000))
                     wav = (rng.standard_normal((int(rng.integers(1, 3)), n)) * 0.1).astype(np.float32)
                     new.append((next_id, sr, wav))
                     tracks[next_id] = (sr, wav)
