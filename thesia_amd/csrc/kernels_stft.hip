@@ -598,8 +598,11 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // the split-twiddle table is not kept in LDS when the lanes hold their entries in registers (RES bit 3)
     constexpr bool STW_IN_LDS = !((RES & 8) && W::PAIRED);
     cf32 *stw = wtab + NC + WPAD;
+    // (the pass-2 constants leave LDS too when the lanes hold them in registers, RES bit 1: at n_fft 4096 those 1280 bytes
+    // are what an eighth wave per CU needs)
+    constexpr bool T2_IN_LDS = !(RES & 2);
     cf32 *t2 = stw + (STW_IN_LDS ? NC : 0);
-    cf32 *t3 = t2 + W::T2_LEN;
+    cf32 *t3 = t2 + (T2_IN_LDS ? W::T2_LEN : 0);
     cf32 *slabs = t3 + W::T3_LEN;
     uint32_t *meltab = reinterpret_cast<uint32_t *>(slabs + (size_t)WAVES * W::SLAB_LEN);  // OUT == 2 only
 
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         if constexpr (STW_IN_LDS) stw[i] = tw[i];
     }
     for (uint32_t i = tid; i < WPAD; i += 64 * WAVES) wtab[i] = wtab_g[i];
-    W::fill_tables(tid, 64 * WAVES, tw, t2, t3);
+    W::fill_tables(tid, 64 * WAVES, tw, T2_IN_LDS ? t2 : nullptr, t3);
     if constexpr (OUT == 2)
         for (uint32_t i = tid; i < wo.mel_words; i += 64 * WAVES) meltab[i] = wo.mel_tab[i];
     __syncthreads();
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #pragma unroll
         for (int m = 0; m < P; m++) rw[m] = wtab[(WPERM ? lane : W::lane_col(lane)) + 64u * m];
     }
-    if constexpr (RESK & 2) W::load_t2(lane, rw2, t2);
+    if constexpr (RESK & 2) W::load_t2_from_tw(lane, rw2, tw);
     if constexpr (RESK & 4) W::load_t3_paired(lane, rwa, rwb, t3);
     cf32 rw_mid = {0.0f, 0.0f};
     if constexpr ((RESK & 8) != 0 && W::PAIRED) {  // straight from the global table: no LDS copy exists
@@ -1227,14 +1230,16 @@ bool stft_wave_multi_applies(const StftGeom &g, int out_mode) {
 #define TH_RES12 1
 #endif
 #if !defined(TH_WAVES_4096)
-#define TH_WAVES_4096 7
+#define TH_WAVES_4096 8
 #endif
 template <int LOG2_NC>
 struct WaveLaunchCfg {
-    static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? TH_WAVES_4096 : 12;  // n_fft = 4096: LDS-bound (17 KB slab per wave)
+    static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? TH_WAVES_4096 : 12;  // n_fft = 4096: LDS-bound (17 KB slab per wave): 8 waves = 160 KB exactly
     // register-resident tables by VGPR budget (512 / waves per SIMD); mirror-local path only for bits 2, 3
     static constexpr int resident(int waves) {
-        if (LOG2_NC == 11) return waves <= 7 ? 8 : 0;  // 206 + 32 VGPRs of 256; frees the 16 KB table: 7 waves fit
+        // n_fft 4096: split twiddles in registers (32 VGPRs) free their 16 KB table; with the pass-2 constants too (20
+        // more) the eighth wave's slab fits exactly (160 KB)
+        if (LOG2_NC == 11) return waves <= 7 ? 8 : waves == 8 ? 10 : 0;
         if (LOG2_NC != 10) return 0;
         return waves <= 8 ? 15 : waves <= 12 ? TH_RES12 : 0;
     }
@@ -1244,7 +1249,8 @@ template <int LOG2_NC, int WAVES>
 static size_t wave_lds_bytes() {
     using W = WaveFft<LOG2_NC>;
     const bool stw_in_lds = !((WaveLaunchCfg<LOG2_NC>::resident(WAVES) & 8) && W::PAIRED);
-    return sizeof(cf32) * ((size_t)(stw_in_lds ? 2 : 1) * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
+    const bool t2_in_lds = !(WaveLaunchCfg<LOG2_NC>::resident(WAVES) & 2);
+    return sizeof(cf32) * ((size_t)(stw_in_lds ? 2 : 1) * W::NC + (t2_in_lds ? W::T2_LEN : 0) + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
 }
 
 template <int LOG2_NC, int WAVES, int SHIFT, int OUT>

@@ -283,19 +283,22 @@ struct WaveFft {
     static constexpr int T2_LEN = NT2 * NS2, T3_LEN = NT3 * NS3;
     static_assert(NS2 <= 64, "pass-2 twiddle index must be butterfly independent");
     // tw[i] = exp(-2 pi i * i / n_fft), n_fft = 2*NC  ->  W_{M}^{e} = tw[e * (2*NC / M)]
-    static TH_HD void fill_tables(uint32_t tid, uint32_t nthr, const cf32 *tw, cf32 *t2, cf32 *t3) {
-        for (uint32_t i = tid; i < (uint32_t)T2_LEN; i += nthr) {
-            const uint32_t r = i / NS2 + 1, k = i % NS2;
-            if constexpr (FMA_TW) {
-                // w = W_{Ns2 R2}^k = tw[k S], S = 2 Nc / (Ns2 R2);  W16 = tw[2 Nc / 16]
-                constexpr uint32_t S = 2 * NC / (NS2 * R2), S16 = 2 * NC / 16, M = 2 * NC;
-                const uint32_t e = i / NS2;  // 0: w^4, 1: w^8, 2 + 2 m': t = w W16^m', 3 + 2 m': t^2
-                const uint32_t mp = e >= 2 ? (e - 2) / 2 : 0, pw = e < 2 ? 4u * (e + 1u) : 1u + ((e - 2) & 1u);
-                t2[i] = tw[(pw * k * S + (e >= 2 ? pw * mp * S16 : 0u)) % M];
-            } else {
-                t2[i] = tw[(r * k) * (2 * NC / (NS2 * R2))];
-            }
+    // index into tw of pass-2 table entry e for twiddle index k
+    static TH_HD uint32_t t2_index(uint32_t e, uint32_t k) {
+        if constexpr (FMA_TW) {
+            // w = W_{Ns2 R2}^k = tw[k S], S = 2 Nc / (Ns2 R2);  W16 = tw[2 Nc / 16]
+            // e = 0: w^4, 1: w^8, 2 + 2 m': t = w W16^m', 3 + 2 m': t^2
+            constexpr uint32_t S = 2 * NC / (NS2 * R2), S16 = 2 * NC / 16, M = 2 * NC;
+            const uint32_t mp = e >= 2 ? (e - 2) / 2 : 0, pw = e < 2 ? 4u * (e + 1u) : 1u + ((e - 2) & 1u);
+            return (pw * k * S + (e >= 2 ? pw * mp * S16 : 0u)) % M;
+        } else {
+            return ((e + 1) * k) * (2 * NC / (NS2 * R2));
         }
+    }
+    // t2 == nullptr: the pass-2 constants are not kept in LDS (every lane holds its own in registers, load_t2_from_tw)
+    static TH_HD void fill_tables(uint32_t tid, uint32_t nthr, const cf32 *tw, cf32 *t2, cf32 *t3) {
+        if (t2 != nullptr)
+            for (uint32_t i = tid; i < (uint32_t)T2_LEN; i += nthr) t2[i] = tw[t2_index(i / NS2, i % NS2)];
         for (uint32_t i = tid; i < (uint32_t)T3_LEN; i += nthr) {
             const uint32_t r = i / NS3 + 1, k = i % NS3;
             if constexpr (FMA_TW && R3 == 8) {
@@ -431,6 +434,10 @@ struct WaveFft {
     // pass 2 (Ns = R1): registers -> LDS slab (linear).  In three pieces so that the kernel can issue the
     // twiddle reads long before their use (LDS returns in order: a read issued next to its use exposes
     // the whole LDS latency): load_t2 -> pass2_twiddle -> pass2_dft.  pass2() is the composition.
+    static TH_HD void load_t2_from_tw(uint32_t lane, cf32 (&w2)[NT2], const cf32 *tw) {  // straight from the global table
+        const uint32_t k = ANYPLANES ? lane >> 2 : lane & (NS2 - 1);
+        TH_UNROLL for (int r = 0; r < NT2; r++) w2[r] = tw[t2_index((uint32_t)r, k)];
+    }
     static TH_HD void load_t2(uint32_t lane, cf32 (&w2)[NT2], const cf32 *t2) {
         // NS2 <= 64: the same twiddles for every butterfly of the lane
         const uint32_t k = ANYPLANES ? lane >> 2 : lane & (NS2 - 1);
