@@ -1267,7 +1267,12 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
                                        (int)lds);
     if (e != hipSuccess) return e;
     const uint32_t wg_needed = (n_tiles + WAVES - 1) / WAVES;
-    const uint32_t grid = wg_needed < n_cu ? wg_needed : n_cu;
+    // workgroups per CU: a workgroup holds at most 16 waves; the small n_fft 1024 kernel (69 VGPRs, 4 KB slab per wave) is
+    // bound by latency and runs two workgroups per CU when LDS allows
+    // (measured, 1024/256 on the bench tracks: 8 / 10 / 12 / 14 / 16 waves in one workgroup 0.78 / 0.71 / 0.66 / 0.64 / 0.63 ms,
+    // 2 x 12 waves 0.59, 3 x 12 0.58)
+    const uint32_t per_cu = (LOG2_NC == 9 && 2 * lds <= 160 * 1024) ? 2u : 1u;
+    const uint32_t grid = wg_needed < n_cu * per_cu ? wg_needed : n_cu * per_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                        d_tw, d_minmax, d_queue_head, out);
     return hipGetLastError();
