@@ -264,6 +264,7 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_,
     }
 }
 
+static uint32_t g_grid = 0;  // 0: one workgroup per CU (persistent); else this many workgroups (argv[3])
 template <int LOADM, int STOREM, int FMA, int LDSR, int WAVES, int LDSM = 0>
 static void run(const char *name, const float *wav, float *spec, uint32_t n_chan, uint32_t n_samples, uint32_t T, uint32_t *q,
                 int gap_us) {
@@ -278,7 +279,7 @@ static void run(const char *name, const float *wav, float *spec, uint32_t n_chan
     for (int i = 0; i < 24; i++) {
         hipMemsetAsync(q, 0, 4, 0);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WAVES), lds, 0, wav, spec, n_chan, n_samples, T, cpc, q, 1.0f);
+        hipLaunchKernelGGL(kern, dim3(g_grid ? g_grid : 256), dim3(64 * WAVES), lds, 0, wav, spec, n_chan, n_samples, T, cpc, q, 1.0f);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -301,6 +302,7 @@ static void run(const char *name, const float *wav, float *spec, uint32_t n_chan
 
 int main(int argc, char **argv) {
     const int gap_us = argc > 1 ? atoi(argv[1]) : 0;
+    if (argc > 3) g_grid = (uint32_t)atoi(argv[3]);
     const uint32_t n_chan = 128, n_samples = 1440000, T = n_samples / HOP + 1;
     float *wav, *spec;
     uint32_t *q;
@@ -328,6 +330,17 @@ int main(int argc, char **argv) {
             R(3, 3, 42, 2, 12, 2);
             R(3, 3, 42, 3, 12, 2);
             R(3, 4, 42, 2, 12, 2);
+        }
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == 6) {  // grid-size runs (argv[3]): stores alone in two shapes, skeleton, with work; 4-wave workgroups too
+        for (int rep = 0; rep < 2; rep++) {
+            R(0, 1, 0, 0, 12, 2);
+            R(0, 3, 0, 0, 12, 2);
+            R(3, 1, 0, 0, 12, 2);
+            R(3, 1, 42, 2, 12, 2);
+            R(0, 3, 0, 0, 4, 2);
+            R(3, 1, 0, 0, 4, 2);
         }
         return 0;
     }
