@@ -949,18 +949,24 @@ static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, co
 // and channels shorter than n_fft go to the generic kernel.  Per-pass twiddle constants (10 per pass, FMA butterflies)
 // and, for n_fft 8192, the thread's 16 window pairs live in registers for the whole chunk.  Output: dB rows (linear scale)
 // or amplitude rows (AMP: first half of the matrix-core mel path).
-// 167 / 196 VGPRs: three workgroups (12 waves) per CU at n_fft 8192, one (8 waves) at 16384.  Measured and not adopted:
+// Full-reload variant 167 / 196 VGPRs (three workgroups per CU at n_fft 8192, one at 16384), reuse variant 198 / 216 (two /
+// one): 8192/2048 0.78 -> 0.72 ms, 16384/4096 1.32 -> 1.11 ms.  Measured and not adopted:
 // the mid-pass constants from LDS tables, the window from global memory at 8192 (both within +-3 %), forcing four waves
 // per SIMD with amdgpu_waves_per_eu (128 VGPRs, 140-240 bytes of scratch: 0.77 -> 1.32 ms and 1.33 -> 1.62 ms), requesting
 // the next frame's samples during the split pass (32 more VGPRs: n_fft 16384 +-0, 8192 loses its third workgroup: 0.78 -> 0.93 ms).
 // ------------------------------------------------------------------------------------------
-template <int LOG2_NC, bool AMP>
+// REUSE (hop = n_fft / 4): frame f + 1 is frame f moved by four of the thread's 16 slots, so the raw samples stay in
+// registers, move down four slots and only the new hop is loaded — requested right behind the window multiply, a whole
+// transform ahead of its use.  Without it every frame is loaded in full and three quarters of that are re-reads that the
+// L2 (4 MB per XCD against 96 workgroups streaming 48 KB per frame each) mostly misses: PMC 1.87 GB fetched per launch for
+// 0.74 GB of audio.  The 32 registers come from the window pairs, which are read from the (L2-resident) table instead.
+template <int LOG2_NC, bool AMP, bool REUSE>
 __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_tiles,
     const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax) {
     using B = BlockFft<LOG2_NC>;
     constexpr int T = B::T, NC = B::NC;
-    constexpr bool WIN_REGS = LOG2_NC == 12;  // 32 VGPRs: with three sets of pass constants (n_fft 16384) they do not fit
+    constexpr bool WIN_REGS = LOG2_NC == 12 && !REUSE;  // 32 VGPRs: with three sets of pass constants (n_fft 16384) or the resident samples they do not fit
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // BUF_LEN cf32 (n_fft 16384: 68 KB) + the (min, max) scratch
     cf32 *const buf = reinterpret_cast<cf32 *>(smem_raw);
     float *const red = reinterpret_cast<float *>(buf + B::BUF_LEN);
@@ -988,8 +994,9 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
             x[m] = {p[0], p[1]};
         }
     };
+    if constexpr (REUSE) fetch(cur.f);
     for (uint32_t f = cur.f; f < cur.f1; f++) {
-        fetch(f);
+        if constexpr (!REUSE) fetch(f);
         cf32 z[16];
 #pragma unroll
         for (int m = 0; m < 16; m++) {
@@ -997,6 +1004,17 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
             if constexpr (WIN_REGS) w = rw[m];
             else w = wtab_g[t + (uint32_t)T * m];
             z[m] = {x[m].re * w.re, x[m].im * w.im};
+        }
+        if constexpr (REUSE) {  // the next frame: four slots down, the new hop requested now
+#pragma unroll
+            for (int m = 0; m < 12; m++) x[m] = x[m + 4];
+            const uint32_t fn = f + 1 < cur.f1 ? f + 1 : f;  // (the last frame of a chunk re-reads its own hop: in bounds, never used)
+            const int64_t e0n = (int64_t)fn * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+#pragma unroll
+            for (int m = 12; m < 16; m++) {
+                const gptr<const float> p = cur.wav + (e0n + 2 * (int64_t)(t + (uint32_t)T * m));
+                x[m] = {p[0], p[1]};
+            }
         }
         __syncthreads();  // the previous frame's mirror reads are done: the buffer may be rewritten
         B::pass_first(t, z, buf);
@@ -1056,16 +1074,24 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     }
 }
 
-template <int LOG2_NC, bool AMP>
-static hipError_t launch_block(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
+template <int LOG2_NC, bool AMP, bool REUSE>
+static hipError_t launch_block_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
                                const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
     using B = BlockFft<LOG2_NC>;
-    auto kern = stft_block_kernel<LOG2_NC, AMP>;
+    auto kern = stft_block_kernel<LOG2_NC, AMP, REUSE>;
     const size_t lds = sizeof(cf32) * B::BUF_LEN + sizeof(float) * 2 * (B::T / 64);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(B::T), lds, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax);
     return hipGetLastError();
+}
+
+template <int LOG2_NC, bool AMP>
+static hipError_t launch_block(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
+                               const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
+    // (every frame of a chunk then sits exactly four slots behind its predecessor)
+    if (g.hop * 4 == g.n_fft) return launch_block_t<LOG2_NC, AMP, true>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
+    return launch_block_t<LOG2_NC, AMP, false>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
 }
 
 #if defined(TH_WAVE_TIMES)
