@@ -392,7 +392,7 @@ __device__ __forceinline__ void wave_frame(
             z[m] = {v.re * rw[m].re, v.im * rw[m].im};
         }
     } else {
-        wave_window_rot<P, OFF>(W::PLANES32 ? lane : col, z, x, wtab);  // (4096: table stored in lane order, see the kernel)
+        wave_window_rot<P, OFF>((W::PLANES32 || (W::PLANES8 && PH == -1)) ? lane : col, z, x, wtab);  // (4096, 1024: table stored in lane order, see the kernel)
     }
     // Request the next frame of the chunk now: its samples land while this frame is transformed.  The fetch
     // is unconditional (branch-free register flow: no copies of x[]); on the last frame of a chunk it simply
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #endif
     // n_fft 4096: the window pairs are stored in the order the lanes read them (lane l reads the pair of column
     // lane_col(l) = (l >> 3) + 8 (l & 7): consecutive lanes would be 64 bytes apart, a 2-way bank conflict on all 32 reads)
-    constexpr bool WPERM = W::PLANES32;
+    constexpr bool WPERM = W::PLANES32 || (W::PLANES8 && !PHASED && !DYN);  // (n_fft 1024: the same column order)
     static_assert(!WPERM || (!PHASED && !DYN), "the shifted window tables are read by column");
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
         const uint32_t col = i & 63u, li = WPERM ? (i & ~63u) + 8u * (col & 7u) + (col >> 3) : i;

@@ -277,15 +277,22 @@ struct WaveFft {
     // per butterfly instead of (t, t^2, t^3).
     // n_fft = 4096 (R1 = R2 = 16, R3 = 8, two radix-16 butterflies per lane and pass) runs the same way; its radix-8 last
     // pass is two bfly4_tw (base t^2) and four bfly2_tw with t W8^m': table entries (t, t^2, t^4, t W8) instead of t .. t^7.
-    static constexpr bool FMA_TW = (R1 == 16 && R2 == 16 && ((P == 16 && R3 == 4) || (P == 32 && R3 == 8)));
-    static constexpr int NT2 = FMA_TW ? 10 : R2 - 1;                  // pass-2 twiddles per lane
+    // n_fft = 1024 (8 x 8 x 8, one radix-8 butterfly per lane and pass): both twiddled passes are that radix-8 FMA butterfly
+    // (bfly8_tw), four constants each.
+    static constexpr bool FMA8 = (R1 == 8 && R2 == 8 && R3 == 8 && P == 8);
+    static constexpr bool FMA_TW = (R1 == 16 && R2 == 16 && ((P == 16 && R3 == 4) || (P == 32 && R3 == 8))) || FMA8;
+    static constexpr int NT2 = FMA8 ? 4 : FMA_TW ? 10 : R2 - 1;       // pass-2 twiddles per lane
     static constexpr int NT3 = FMA_TW ? (R3 == 4 ? 2 : 4) : R3 - 1;   // pass-3 twiddles per butterfly
     static constexpr int T2_LEN = NT2 * NS2, T3_LEN = NT3 * NS3;
     static_assert(NS2 <= 64, "pass-2 twiddle index must be butterfly independent");
     // tw[i] = exp(-2 pi i * i / n_fft), n_fft = 2*NC  ->  W_{M}^{e} = tw[e * (2*NC / M)]
     // index into tw of pass-2 table entry e for twiddle index k
     static TH_HD uint32_t t2_index(uint32_t e, uint32_t k) {
-        if constexpr (FMA_TW) {
+        if constexpr (FMA8) {
+            // t = W_{Ns2 R2}^k = tw[k S]: entries t, t^2, t^4, t W8
+            constexpr uint32_t S = 2 * NC / (NS2 * R2), M = 2 * NC;
+            return (e < 3 ? (1u << e) * k * S : k * S + M / 8) % M;
+        } else if constexpr (FMA_TW) {
             // w = W_{Ns2 R2}^k = tw[k S], S = 2 Nc / (Ns2 R2);  W16 = tw[2 Nc / 16]
             // e = 0: w^4, 1: w^8, 2 + 2 m': t = w W16^m', 3 + 2 m': t^2
             constexpr uint32_t S = 2 * NC / (NS2 * R2), S16 = 2 * NC / 16, M = 2 * NC;
@@ -344,11 +351,60 @@ struct WaveFft {
     //           4 (jj & 15) .. + 3: one 16-byte load per butterfly, component and r parity; float offset 1024 (r & 1) + 4 jj.
     // -----------------------------------------------------------------------------------------
     static constexpr bool PLANES32 = (R1 == 16 && R2 == 16 && P == 32 && R3 == 8);
-    static constexpr bool ANYPLANES = PLANES || PLANES32;
-    static constexpr int NPL = PLANES32 ? 32 : 16;  // planes per component
-    static constexpr int PITCH1 = 68, PITCH2 = 64;
+    // -----------------------------------------------------------------------------------------
+    // And for n_fft = 1024 (P = 8: one radix-8 butterfly per lane and pass): 8 + 8 planes per exchange, pitch 68 for both.
+    //   pass 1: lane l owns column lane_col(l) = (l >> 3) + 8 (l & 7) (points col + 64 m); output c -> plane c.
+    //   pass 2: lane l owns butterfly j = 8 a + c, a = l & 7, c = l >> 3 (twiddle index k = c).  Inputs in[j + 64 r] =
+    //           pass-1 output c of column a + 8 r = plane c, lanes 8 a .. 8 a + 7: two 16-byte loads per component (quad
+    //           index 17 c + 2 a + t mod 16: c in {2 g, 2 g + 1} and a = 0..7 over a 16-lane group = all 16 quads).
+    //           Output rr = out[64 a + c + 8 rr] -> plane rr, lane l.
+    //   pass 3: natural, butterfly jj = lane (no mirror-local pairs with one butterfly per lane): in[jj + 64 r] = pass-2
+    //           output jj >> 3 of butterfly a = r, c = jj & 7 = plane jj >> 3, lanes 8 (jj & 7) .. + 7: two 16-byte loads,
+    //           quad index 17 (jj >> 3) + 2 (jj & 7) + t: conflict-free for the same reason.
+    // The split exchange (Z through LDS for the mirror reads) keeps the slot layout.
+    // -----------------------------------------------------------------------------------------
+    static constexpr bool PLANES8 = FMA8;
+    static constexpr bool ANYPLANES = PLANES || PLANES32;  // the radix-16 plane plans (twiddle index lane >> 2)
+    static constexpr int NPL = PLANES32 ? 32 : PLANES8 ? 8 : 16;  // planes per component
+    static constexpr int PITCH1 = 68, PITCH2 = PLANES8 ? 68 : 64;
     static TH_HD uint32_t lane_col(uint32_t lane) {
-        return PLANES ? 4u * (lane & 15u) + (lane >> 4) : PLANES32 ? (lane >> 3) + 8u * (lane & 7u) : lane;
+        return PLANES ? 4u * (lane & 15u) + (lane >> 4) : (PLANES32 || PLANES8) ? (lane >> 3) + 8u * (lane & 7u) : lane;
+    }
+    static TH_HD uint32_t t2_k(uint32_t lane) { return ANYPLANES ? lane >> 2 : PLANES8 ? lane >> 3 : lane & (NS2 - 1); }
+    // natural outputs X0..X7 (in v[0..7]) of a lane's radix-8 butterfly -> planes 0..7 of either exchange
+    template <int PITCH>
+    static TH_HD void st_planes8(float *sf, uint32_t lane, const cf32 (&v)[8]) {
+        lds_st_planes4<0, 8 * PITCH * 4, 4 * PITCH>(sf, lane, v[0], v[1], v[2], v[3]);
+        lds_st_planes4<4 * PITCH * 4, 12 * PITCH * 4, 4 * PITCH>(sf, lane, v[4], v[5], v[6], v[7]);
+    }
+    // 8 consecutive dwords of plane `pl` (both components) starting at lane position 8 g -> z[0..7]
+    template <int PITCH>
+    static TH_HD void ld_planes8(const float *sf, uint32_t pl, uint32_t g, cf32 (&z)[8]) {
+        const float *const p = sf + pl * (uint32_t)PITCH + 8u * g;
+        const f32x4 r0 = lds_ld4(p), r1 = lds_ld4(p + 4), i0 = lds_ld4(p + 8 * PITCH), i1 = lds_ld4(p + 8 * PITCH + 4);
+        z[0] = {r0.a, i0.a};
+        z[1] = {r0.b, i0.b};
+        z[2] = {r0.c, i0.c};
+        z[3] = {r0.d, i0.d};
+        z[4] = {r1.a, i1.a};
+        z[5] = {r1.b, i1.b};
+        z[6] = {r1.c, i1.c};
+        z[7] = {r1.d, i1.d};
+    }
+    // twiddled radix-8 FMA butterfly, natural order in and out; w = (t, t^2, t^4, t W8):
+    // X[m' + 4 m''] = Y0[m'] + (-1)^m'' (t W8^m') Y1[m'],  Yb[m'] = sum_a (t^2)^a W4^(a m') x[2 a + b]
+    static TH_HD void bfly8_tw(cf32 (&v)[8], cf32 t, cf32 t2, cf32 t4, cf32 t8) {
+        bfly4_tw(v[0], v[2], v[4], v[6], t2, t4);  // Y0[0..3] in v0, v4, v2, v6
+        bfly4_tw(v[1], v[3], v[5], v[7], t2, t4);  // Y1[0..3] in v1, v5, v3, v7
+        bfly2_tw(v[0], v[1], t.re, t.im);          // X0, X4
+        bfly2_tw(v[4], v[5], t8.re, t8.im);        // X1, X5
+        bfly2_tw(v[2], v[3], t.im, -t.re);         // X2, X6   (-i t)
+        bfly2_tw(v[6], v[7], t8.im, -t8.re);       // X3, X7   (-i t W8)
+        const cf32 x1 = v[4], x3 = v[6], x4 = v[1], x6 = v[3];
+        v[1] = x1;
+        v[3] = x3;
+        v[4] = x4;
+        v[6] = x6;
     }
     // outputs 4 i + G (i = 0..3) of a radix-16 butterfly (held in v0..v3) -> planes B0 + G + 4 i
     template <int PITCH, int B0, int G>
@@ -386,6 +442,12 @@ struct WaveFft {
                 TH_UNROLL for (int r = 0; r < 16; r++) v[r] = z[2 * r + 1];
                 dft16_to_planes<PITCH1, 16>(lane, v, slab);
             }
+        } else if constexpr (PLANES8) {
+            cf32 v[8], o[8];
+            TH_UNROLL for (int r = 0; r < 8; r++) v[r] = z[r % P];
+            dft8(v);
+            TH_UNROLL for (int c = 0; c < 8; c++) o[c] = v[dft8_slot(c)];
+            st_planes8<PITCH1>(reinterpret_cast<float *>(slab), lane, o);
         } else {
             TH_UNROLL for (int b = 0; b < B1; b++) {
                 cf32 v[R1];
@@ -426,6 +488,10 @@ struct WaveFft {
                     z[b + 2 * (4 * h + 3)] = {re[h].d, im[h].d};
                 }
             }
+        } else if constexpr (PLANES8) {
+            cf32 v[8];
+            ld_planes8<PITCH1>(reinterpret_cast<const float *>(slab), lane >> 3, lane & 7u, v);
+            TH_UNROLL for (int r = 0; r < 8; r++) z[r % P] = v[r];
         } else {
             TH_UNROLL for (int m = 0; m < P; m++) z[m] = lds_ld(&slab[pad1(lane) + 68u * m]);  // = pad1(lane + 64*m)
         }
@@ -435,12 +501,12 @@ struct WaveFft {
     // twiddle reads long before their use (LDS returns in order: a read issued next to its use exposes
     // the whole LDS latency): load_t2 -> pass2_twiddle -> pass2_dft.  pass2() is the composition.
     static TH_HD void load_t2_from_tw(uint32_t lane, cf32 (&w2)[NT2], const cf32 *tw) {  // straight from the global table
-        const uint32_t k = ANYPLANES ? lane >> 2 : lane & (NS2 - 1);
+        const uint32_t k = t2_k(lane);
         TH_UNROLL for (int r = 0; r < NT2; r++) w2[r] = tw[t2_index((uint32_t)r, k)];
     }
     static TH_HD void load_t2(uint32_t lane, cf32 (&w2)[NT2], const cf32 *t2) {
         // NS2 <= 64: the same twiddles for every butterfly of the lane
-        const uint32_t k = ANYPLANES ? lane >> 2 : lane & (NS2 - 1);
+        const uint32_t k = t2_k(lane);
         TH_UNROLL for (int r = 0; r < NT2; r++) w2[r] = lds_ld(&t2[r * NS2 + k]);
     }
     static TH_HD void pass2_twiddle(cf32 (&z)[P], const cf32 (&w2)[NT2]) {
@@ -479,6 +545,11 @@ struct WaveFft {
                 TH_UNROLL for (int r = 0; r < 16; r++) v[r] = z[2 * r + 1];
                 dft16_tw_to_planes<16>(lane, v, w, slab);
             }
+        } else if constexpr (PLANES8) {
+            cf32 v[8];
+            TH_UNROLL for (int r = 0; r < 8; r++) v[r] = z[r % P];
+            bfly8_tw(v, w[0], w[1 % NT2], w[2 % NT2], w[3 % NT2]);
+            st_planes8<PITCH2>(reinterpret_cast<float *>(slab), lane, v);
         }
     }
     static TH_HD void pass2_dft(uint32_t lane, cf32 (&z)[P], cf32 *slab) {  // (plans without FMA_TW)
@@ -506,11 +577,25 @@ struct WaveFft {
         pass2_w(lane, z, w2, slab);
     }
     static TH_HD void read2(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
-        TH_UNROLL for (int m = 0; m < P; m++) z[m] = slab[lane + 64u * m];
+        if constexpr (PLANES8) {
+            cf32 v[8];
+            ld_planes8<PITCH2>(reinterpret_cast<const float *>(slab), lane >> 3, lane & 7u, v);
+            TH_UNROLL for (int r = 0; r < 8; r++) z[r % P] = v[r];
+        } else {
+            TH_UNROLL for (int m = 0; m < P; m++) z[m] = slab[lane + 64u * m];
+        }
     }
 
     // pass 3 (Ns = R1*R2, last): registers -> registers, lane j ends with Z[j + 64*m] in z[m]
     static TH_HD void pass3(uint32_t lane, cf32 (&z)[P], const cf32 *t3) {
+        if constexpr (FMA8) {
+            cf32 w[4], v[8];
+            TH_UNROLL for (int e = 0; e < 4; e++) w[e] = lds_ld(&t3[(e % NT3) * NS3 + lane]);
+            TH_UNROLL for (int r = 0; r < 8; r++) v[r] = z[r % P];
+            bfly8_tw(v, w[0], w[1], w[2], w[3]);
+            TH_UNROLL for (int r = 0; r < 8; r++) z[r % P] = v[r];
+            return;
+        }
         TH_UNROLL for (int b = 0; b < B3; b++) {
             const uint32_t jj = lane + 64u * b;
             cf32 v[R3];
@@ -526,7 +611,7 @@ struct WaveFft {
     // index (Nc - lane - 64*(P-1)) + 64*(P-1-m) = per-lane base + immediate.
     static_assert(32 % R1 == 0, "pad1 needs R1 | 32");
     static constexpr int SLAB_LEN = NC + NC / 16;  // padded pass-1 image is the largest (>= NC + 1)
-    static_assert(!ANYPLANES || 2 * SLAB_LEN >= 2 * NPL * PITCH1, "slab holds the planes of exchange 1");
+    static_assert(!(ANYPLANES || PLANES8) || 2 * SLAB_LEN >= 2 * NPL * PITCH1, "slab holds the planes of exchange 1");
     static TH_HD void write_z(uint32_t lane, const cf32 (&z)[P], cf32 *slab) {
         TH_UNROLL for (int m = 0; m < P; m++) slab[lane + 64u * m] = z[m];
         if (lane == 0) slab[NC] = z[0];
