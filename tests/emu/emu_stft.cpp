@@ -20,7 +20,7 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
     std::vector<cf32> slab(W::SLAB_LEN);
-    static cf32 x[64][P], z[64][P], zm[64][P];
+    static cf32 x[64][P], z[64][P];
     std::vector<cf32> t2(W::T2_LEN), t3(W::T3_LEN);
     const int64_t e0 = (int64_t)frame * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
     for (uint32_t t = 0; t < 256; t++) W::fill_tables(t, 256, tw, t2.data(), t3.data());
@@ -45,18 +45,29 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
             if (hits[k] != 1) row[k] = NAN;  // every bin must be emitted exactly once
         return;
     }
-    for (uint32_t l = 0; l < 64; l++) W::read2(l, z[l], slab.data());
-    for (uint32_t l = 0; l < 64; l++) W::pass3(l, z[l], t3.data());
-    for (uint32_t l = 0; l < 64; l++) W::write_z(l, z[l], slab.data());
-    for (uint32_t l = 0; l < 64; l++)
-        for (int m = 0; m < P; m++) zm[l][m] = W::read_mirror(l, m, slab.data());
-    for (uint32_t l = 0; l < 64; l++)
-        for (int m = 0; m < P; m++) {
-            const uint32_t k = l + 64u * m;
-            row[k] = power_to_dB(split_power(z[l][m], zm[l][m], tw[k]));
+    if constexpr (W::SWAP8) {  // n_fft 1024: the wave's halves swap registers for the split pass (v_permlane32_swap on the GPU)
+        static cf32 z256[64];
+        typename W::Swap8Lane sl[64];
+        for (uint32_t l = 0; l < 64; l++) sl[l] = W::swap8_lane(l);
+        for (uint32_t l = 0; l < 64; l++) W::read2_sw(sl[l], z[l], slab.data());
+        for (uint32_t l = 0; l < 64; l++) {
+            cf32 w3[4];
+            W::load_t3_sw(sl[l], w3, t3.data());
+            W::pass3_sw(sl[l], z[l], w3, z256[l]);
         }
-    const cf32 wn = {-1.0f, 0.0f};
-    row[NC] = power_to_dB(split_power(z[0][0], z[0][0], wn));
+        // swap(a = z[i], b = z[7 - i]): lanes 32..63 of a <-> lanes 0..31 of b, lanes 0 and 32 masked out
+        for (uint32_t l = 1; l < 32; l++)
+            for (int i = 0; i < 4; i++) std::swap(z[32 + l][i % P], z[l][(7 - i) % P]);
+        std::vector<int> hits(NC + 1, 0);
+        for (uint32_t l = 0; l < 64; l++)
+            W::split_sw(sl[l], z[l], z256[l], tw, [&](uint32_t kb, int kc, float p) {
+                const uint32_t k = kb + (uint32_t)kc;
+                row[k] = power_to_dB(p);
+                hits[k]++;
+            });
+        for (int k = 0; k <= NC; k++)
+            if (hits[k] != 1) row[k] = NAN;  // every bin must be emitted exactly once
+    }
 }
 
 // One frame of the workgroup-per-frame plan (stft_block.h): the T threads run every phase one after the other, a phase

@@ -487,50 +487,33 @@ __device__ __forceinline__ void wave_frame(
         if constexpr (RES & 8) W::split_paired_w(lane, za, zb, rws, rw_mid, emit);
         else W::split_paired_w(lane, za, zb, ws, stw[NC / 2], emit);
     } else {
+        // n_fft = 1024: one last-pass butterfly per lane; the halves of the wave swap registers for the split pass (no third
+        // exchange, stft_wave.h)
+        static_assert(W::SWAP8, "plans without mirror-local pairs use the half-wave swap");
         if constexpr (RES & 2) W::pass2_w(lane, z, rw2, slab);
         else W::pass2_w(lane, z, w2, slab);
         wave_lds_sync();
         TH_SCHED_BARRIER();
-        W::read2(lane, z, slab);
-        W::pass3(lane, z, t3);
-        wave_lds_sync();
-        W::write_z(lane, z, slab);
-        wave_lds_sync();
+        const typename W::Swap8Lane sl = W::swap8_lane(lane);
+        cf32 w3[4], z256;
+        W::load_t3_sw(sl, w3, t3);
+        W::read2_sw(sl, z, slab);
+        wave_lds_sync();  // the slab is free: the next frame's pass 1 (or the amplitude row of the mel epilogue) rewrites it
         TH_SCHED_BARRIER();
-        float pa[P + 1];  // fused mel: the amplitudes wait in registers until the mirror reads are done with the slab
-#pragma unroll
-        for (int m = 0; m < P; m++) {
-            const uint32_t k = lane + 64u * m;
-            const cf32 zm = W::read_mirror(lane, m, slab);  // mirror partner Z[Nc - k]
-            const float pw = split_power(z[m], zm, stw[k]);
+        W::pass3_sw(sl, z, w3, z256);
+        W::mirror_swap(sl, z);
+        float *const slab_f = reinterpret_cast<float *>(slab);
+        auto emit = [&](uint32_t kb, int kc, float p) {  // bin kb + kc: per-lane base + compile-time constant
             if constexpr (MELF) {
-                pa[m] = power_to_amp_scaled(pw);
+                slab_f[kb + (uint32_t)kc] = power_to_amp_scaled(p);
             } else {
-                const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
-                row[k] = d;
+                const float d = AMP ? power_to_amp(p) : power_to_dB(p);
+                *(gptr<float>)((gptr<char>)row + (uint64_t)(kb << 2) + (int64_t)(4 * kc)) = d;
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }
-        }
-        {   // Nyquist bin k = Nc: partner of Z[0] is Z[0], W^Nc = -1 (lane 0 only keeps it)
-            const cf32 wn = {-1.0f, 0.0f};
-            const float pw = split_power(z[0], z[0], wn);
-            if constexpr (MELF) {
-                pa[P] = power_to_amp_scaled(pw);
-            } else if (lane == 0) {
-                const float d = AMP ? power_to_amp(pw) : power_to_dB(pw);
-                row[NC] = d;
-                lmin = nmin(lmin, d);
-                lmax = nmax(lmax, d);
-            }
-        }
-        wave_lds_sync();  // the slab is free: the next frame's pass 1 (or the mel epilogue) rewrites it
-        if constexpr (MELF) {
-            float *const slab_f = reinterpret_cast<float *>(slab);
-#pragma unroll
-            for (int m = 0; m < P; m++) slab_f[lane + 64u * m] = pa[m];
-            if (lane == 0) slab_f[NC] = pa[P];
-        }
+        };
+        W::split_sw(sl, z, z256, stw, emit);
     }
     if constexpr (MELF) {
         // fused mel filterbank (stft_wave.h / mel_fuse.h): the frame's amplitudes sit in the wave's slab; pieces of 4 bins

@@ -576,48 +576,125 @@ struct WaveFft {
         load_t2(lane, w2, t2);
         pass2_w(lane, z, w2, slab);
     }
-    static TH_HD void read2(uint32_t lane, cf32 (&z)[P], const cf32 *slab) {
-        if constexpr (PLANES8) {
-            cf32 v[8];
-            ld_planes8<PITCH2>(reinterpret_cast<const float *>(slab), lane >> 3, lane & 7u, v);
-            TH_UNROLL for (int r = 0; r < 8; r++) z[r % P] = v[r];
-        } else {
-            TH_UNROLL for (int m = 0; m < P; m++) z[m] = slab[lane + 64u * m];
-        }
-    }
-
-    // pass 3 (Ns = R1*R2, last): registers -> registers, lane j ends with Z[j + 64*m] in z[m]
-    static TH_HD void pass3(uint32_t lane, cf32 (&z)[P], const cf32 *t3) {
-        if constexpr (FMA8) {
-            cf32 w[4], v[8];
-            TH_UNROLL for (int e = 0; e < 4; e++) w[e] = lds_ld(&t3[(e % NT3) * NS3 + lane]);
-            TH_UNROLL for (int r = 0; r < 8; r++) v[r] = z[r % P];
-            bfly8_tw(v, w[0], w[1], w[2], w[3]);
-            TH_UNROLL for (int r = 0; r < 8; r++) z[r % P] = v[r];
-            return;
-        }
-        TH_UNROLL for (int b = 0; b < B3; b++) {
-            const uint32_t jj = lane + 64u * b;
-            cf32 v[R3];
-            v[0] = z[b];
-            TH_UNROLL for (int r = 1; r < R3; r++) v[r] = cmul(z[b + B3 * r], t3[(r - 1) * NS3 + jj]);
-            RegDft<R3>::run(v);
-            TH_UNROLL for (int r = 0; r < R3; r++) z[b + B3 * r] = v[RegDft<R3>::slot(r)];
-        }
-    }
-
-    // split exchange: publish Z (plus Z[0] again at slot Nc, so the mirror index Nc - k needs no
-    // wrap-around), then every lane fetches the partner Z[Nc - k] of each own k = lane + 64*m:
-    // index (Nc - lane - 64*(P-1)) + 64*(P-1-m) = per-lane base + immediate.
     static_assert(32 % R1 == 0, "pad1 needs R1 | 32");
     static constexpr int SLAB_LEN = NC + NC / 16;  // padded pass-1 image is the largest (>= NC + 1)
     static_assert(!(ANYPLANES || PLANES8) || 2 * SLAB_LEN >= 2 * NPL * PITCH1, "slab holds the planes of exchange 1");
-    static TH_HD void write_z(uint32_t lane, const cf32 (&z)[P], cf32 *slab) {
-        TH_UNROLL for (int m = 0; m < P; m++) slab[lane + 64u * m] = z[m];
-        if (lane == 0) slab[NC] = z[0];
+
+    // -----------------------------------------------------------------------------------------
+    // n_fft = 1024 (one last-pass butterfly per lane: no mirror-local pairs): the split pass without a third exchange.
+    // The wave's halves trade registers instead (v_permlane32_swap, no LDS).  Lane l = 1..31 runs last-pass butterfly l,
+    // z[m] = Z[l + 64 m]; lane 32 + l runs butterfly 64 - l, whose outputs are the mirror partners, in the order
+    // z[m] = conj Z[Nc - l - 64 m]:  W_Nc^((64 - l) s) = W8^s conj(t)^s with t = W_Nc^l, so
+    //     Z[64 - l + 64 r] = Y[(r + 1) & 7],  Y[q] = sum_s x_s conj(t)^s W8^(s q) = conj( sum_s conj(x_s) t^s W8^(-s q) ),
+    // i.e. the SAME butterfly with the same twiddles on the conjugated inputs yields conj Z[Nc - l - 64 m] in slot m.
+    // Swapping (z[i] of the upper half) with (z[7 - i] of the lower half), i < 4, leaves every lane with four pairs
+    // (z[i], z[7 - i]) = (Z[k], conj Z[Nc - k]):  k = l + 64 i in lane l,  k = l + 64 (7 - i) in lane 32 + l.
+    // Lanes 0 and 32 run the self-mirrored butterflies 0 and 32 (plain) and sit the swap out (EXEC): lane 32 already holds
+    // its pairs as (z[i], z[7 - i]), k = 32 + 64 i; lane 0 moves z[5], z[6], z[7], z[0] into z[4..7] — pairs k = 64 i, the
+    // first one (Z[0], Z[0]) = bins 0 and Nc — and computes bin Nc/2 from Z[256] on top.
+    // Stores: every pair yields X[k] and X[Nc - k].  Store S1_i takes X[k] from the lower half (and lane 32) and X[Nc - k]
+    // from the upper half: bins jr + 64 i = the 64 consecutive bins from 64 i on; store S2_i takes the other output:
+    // bins 448 - 64 i .. 511 - 64 i, where lane 0 supplies bin 448 - 64 i (X[Nc - k] of its NEXT pair; bin 256 for i = 3).
+    // Both are whole 256-byte spans per instruction, "per-lane base + immediate"; bin Nc is lane 0's own ninth store.
+    // (Each lane storing its own two outputs per pair touched 3-4 lines per instruction: 27 % more L2 requests and a
+    // slower kernel than with the third exchange.)
+    // -----------------------------------------------------------------------------------------
+    static constexpr bool SWAP8 = PLANES8;
+    struct Swap8Lane {
+        uint32_t jr, jt;   // butterfly whose inputs the lane reads; twiddle index
+        uint32_t cj, sp;   // sign-bit masks: conjugate the inputs (upper half) / the partner of the unswapped lanes 0, 32
+        uint32_t kb;       // bin of pair i: kb + i ks
+        int32_t ks;
+        uint32_t b1, b2;   // store S1_i -> bin b1 + 64 i, store S2_i -> bin b2 + 64 (3 - i)
+        bool l0, hi, swaps;
+    };
+    static TH_HD Swap8Lane swap8_lane(uint32_t lane) {
+        const uint32_t l = lane & 63u;
+        Swap8Lane s;
+        s.hi = l > 32u;
+        s.jr = s.hi ? 96u - l : l;
+        s.jt = s.hi ? l - 32u : l;
+        s.cj = s.hi ? 0x80000000u : 0u;
+        s.swaps = (l & 31u) != 0u;
+        s.sp = s.swaps ? 0u : 0x80000000u;
+        s.l0 = l == 0u;
+        s.kb = s.hi ? l + 416u : l;  // upper half: (l - 32) + 64 * 7
+        s.ks = s.hi ? -64 : 64;
+        s.b1 = s.jr;
+        s.b2 = s.l0 ? 256u : (s.hi ? l + 224u : 320u - l);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(s.b1), "+v"(s.b2));  // opaque: the stores stay "base + immediate" (see split_base)
+#endif
+        return s;
     }
-    static TH_HD cf32 read_mirror(uint32_t lane, int m, const cf32 *slab) {
-        return slab[(NC - 64u * (P - 1) - lane) + 64u * (P - 1 - m)];
+    static TH_HD float flip_sign(float v, uint32_t mask) {
+        uint32_t u;
+        __builtin_memcpy(&u, &v, 4);
+        u ^= mask;
+        __builtin_memcpy(&v, &u, 4);
+        return v;
+    }
+    static TH_HD void read2_sw(const Swap8Lane &s, cf32 (&z)[P], const cf32 *slab) {
+        cf32 v[8];
+        ld_planes8<PITCH2>(reinterpret_cast<const float *>(slab), s.jr >> 3, s.jr & 7u, v);
+        TH_UNROLL for (int r = 0; r < 8; r++) z[r % P] = v[r];
+    }
+    static TH_HD void load_t3_sw(const Swap8Lane &s, cf32 (&w)[4], const cf32 *t3) {
+        TH_UNROLL for (int e = 0; e < 4; e++) w[e] = lds_ld(&t3[(e % NT3) * NS3 + s.jt]);
+    }
+    // last pass; z256 <- Z[Nc/2] (lane 0)
+    static TH_HD void pass3_sw(const Swap8Lane &s, cf32 (&z)[P], const cf32 (&w)[4], cf32 &z256) {
+        cf32 v[8];
+        TH_UNROLL for (int r = 0; r < 8; r++) v[r] = {z[r % P].re, flip_sign(z[r % P].im, s.cj)};
+        bfly8_tw(v, w[0], w[1], w[2], w[3]);
+        z256 = v[4];
+        TH_UNROLL for (int m = 4; m < 8; m++) {  // lane 0: z[4..7] <- Z[320], Z[384], Z[448], Z[0]
+            v[m].re = s.l0 ? v[(m + 1) & 7].re : v[m].re;
+            v[m].im = s.l0 ? v[(m + 1) & 7].im : v[m].im;
+        }
+        TH_UNROLL for (int r = 0; r < 8; r++) z[r % P] = v[r];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // lanes 32..63 of a <-> lanes 0..31 of b
+    static __device__ __forceinline__ void swap_halves(float &a, float &b) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]);
+        b = __uint_as_float(r[1]);
+    }
+    static __device__ __forceinline__ void mirror_swap(const Swap8Lane &s, cf32 (&z)[P]) {
+        if (s.swaps) {
+            TH_UNROLL for (int i = 0; i < 4; i++) {
+                swap_halves(z[i % P].re, z[(7 - i) % P].re);
+                swap_halves(z[i % P].im, z[(7 - i) % P].im);
+            }
+        }
+    }
+#else
+    // (host pass of the kernel source; the CPU emulator swaps at wave level, tests/emu/emu_stft.cpp)
+    static void mirror_swap(const Swap8Lane &, cf32 (&)[P]) {}
+#endif
+    // emit(base, constant, |X[base + constant]|^2): every bin 0..Nc exactly once
+    template <class Emit>
+    static TH_HD void split_sw(const Swap8Lane &s, const cf32 (&z)[P], cf32 z256, const cf32 *stw, Emit emit) {
+        cf32 w[4];
+        TH_UNROLL for (int i = 0; i < 4; i++) w[i] = lds_ld(&stw[s.kb + (uint32_t)(i * s.ks)]);
+        float px[4], py[4];
+        TH_UNROLL for (int i = 0; i < 4; i++) {
+            const cf32 zk = z[i % P], c = {z[(7 - i) % P].re, flip_sign(z[(7 - i) % P].im, s.sp)};  // c = conj Z[Nc - k]
+            const float er = zk.re + c.re, ei = zk.im + c.im, dr = zk.re - c.re, di = zk.im - c.im;
+            const float xr = th_fma(di, w[i].re, th_fma(dr, w[i].im, er)), xi = th_fma(di, w[i].im, th_fma(-dr, w[i].re, ei));
+            const float yr = th_fma(2.0f, er, -xr), yi = th_fma(2.0f, ei, -xi);
+            px[i] = xr * xr + xi * xi;
+            py[i] = yr * yr + yi * yi;
+        }
+        const float p256 = 4.0f * (z256.re * z256.re + z256.im * z256.im);  // Z[Nc/2] is its own partner, W^(Nc/2) = -i
+        TH_UNROLL for (int i = 0; i < 4; i++) {
+            const float p1 = s.hi ? py[i] : px[i];
+            const float p2 = s.l0 ? (i < 3 ? py[(i + 1) & 3] : p256) : (s.hi ? px[i] : py[i]);
+            emit(s.b1, 64 * i, p1);
+            emit(s.b2, 64 * (3 - i), p2);
+        }
+        if (s.l0) emit((uint32_t)NC, 0, py[0]);
     }
 
     // -----------------------------------------------------------------------------------------
