@@ -766,8 +766,13 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 // so control flow, LDS traffic and stores stay wave-uniform.  Every frame is loaded in full (no register reuse across
 // iterations: a group advances by G hops); the loads for the next iteration are issued right after the window multiply
 // and land during the transform.  dB output only (mel plans at these sizes use the one-frame kernel / generic kernel).
+// NLD > 0 (n_fft 512, even hop <= 256): the G frames of an iteration overlap, and every group loading its own copy made
+// the kernel issue 4.6x the load instructions of the 2048 plan for the same audio (PMC, round 2).  The wave instead loads
+// the (G - 1) hop + n_fft samples the iteration spans ONCE — NLD 16-byte loads per lane, 1 KB per instruction, into
+// NLD * 4 registers instead of 32 — and at the start of the next iteration passes them through its (free) exchange slab:
+// ds_write_b128, then each lane reads the 16 sample pairs of its own frame.
 // ------------------------------------------------------------------------------------------
-template <int LOG2_NC, int WAVES, bool AMP>
+template <int LOG2_NC, int WAVES, bool AMP, int NLD>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
@@ -815,6 +820,23 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
                 x[m] = {p[0], p[1]};
             }
         };
+        // NLD > 0: the samples from the first frame's start on, lane i holds samples 4 i + 256 m .. + 3 of that span in raw[m]
+        // (indices clamped into the channel: beyond the span the iteration needs, and never used there)
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // global side: any 4-byte aligned span
+        typedef float f32x4a __attribute__((ext_vector_type(4)));              // LDS side: 16-byte aligned
+        constexpr int NRAW = NLD > 0 ? NLD : 1;
+        f32x4u raw[NRAW];
+        auto fetch_raw = [&](uint32_t f_it, uint32_t lane) {
+            int32_t e0 = (int32_t)((int64_t)f_it * g.hop) - lead;
+            e0 = e0 < 0 ? 0 : e0;
+            const uint32_t lim = cur.n_samples - 4u;
+#pragma unroll
+            for (int m = 0; m < NRAW; m++) {
+                uint32_t idx = (uint32_t)e0 + 4u * lane + 256u * (uint32_t)m;
+                idx = idx < lim ? idx : lim;
+                raw[m] = *(gptr<const f32x4u>)(cur.wav + idx);
+            }
+        };
         cf32 x[P];
         if (cur.edge) {  // wave-uniform: boundary frame (one-frame chunk), numpy-'reflect' indexing per sample
             const uint32_t col = W::lane_col(lane_wave);
@@ -824,6 +846,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
                 const int32_t i = e0 + 2 * (int32_t)(col + (uint32_t)L * m);
                 x[m] = {cur.wav[reflect_once(i, (int32_t)cur.n_samples)], cur.wav[reflect_once(i + 1, (int32_t)cur.n_samples)]};
             }
+        } else if constexpr (NLD > 0) {
+            fetch_raw(cur.f, lane_wave);
         } else {
             fetch(x, cur.f, lane_wave);
         }
@@ -833,6 +857,20 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
             asm volatile("" : "+v"(lane));  // per-iteration copy: keeps the lane-derived addresses out of the loop-invariant set
             lane &= 63u;
             cf32 z[P];
+            if constexpr (NLD > 0) {
+                if (!cur.edge) {  // wave-uniform: the iteration's samples through the slab (free since the last read of exchange 2)
+                    float *const stage = reinterpret_cast<float *>(slab);
+#pragma unroll
+                    for (int m = 0; m < NRAW; m++)
+                        *(__attribute__((address_space(3))) f32x4a *)(stage + 4u * lane + 256u * (uint32_t)m) = (f32x4a)raw[m];
+                    wave_lds_sync();
+                    const uint32_t grp = W::grp(lane), last = cur.f1 - 1u - f, dg = grp < last ? grp : last;
+                    const cf32 *const src = reinterpret_cast<const cf32 *>(stage + dg * g.hop) + W::lane_col(lane);
+#pragma unroll
+                    for (int m = 0; m < P; m++) x[m] = lds_ld(&src[(uint32_t)L * m]);
+                    wave_lds_sync();  // pass 1 rewrites the slab
+                }
+            }
             {   // window pairs from LDS (slot m = complex point col + L m of the group's frame): one read serves G frames'
                 // worth of lanes, and keeping them in registers instead would push the kernel over its 168 VGPRs
                 const uint32_t col = W::lane_col(lane);
@@ -844,7 +882,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
             }
             {   // the next iteration's frames now (branch-free: the last iteration re-reads its own)
                 const uint32_t fn = f + G < cur.f1 ? f + G : f;
-                fetch(x, fn, lane);
+                if constexpr (NLD > 0) fetch_raw(fn, lane);
+                else fetch(x, fn, lane);
             }
             TH_SCHED_BARRIER();
             cf32 w2[W::NT2];
@@ -897,21 +936,37 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
     }
 }
 
-template <int LOG2_NC, int WAVES, bool AMP>
-static hipError_t launch_wave_multi_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
+template <int LOG2_NC, int WAVES, bool AMP, int NLD>
+static hipError_t launch_wave_multi_n(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                                       uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
                                       uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
     using W = WaveFftM<LOG2_NC>;
-    auto kern = stft_wave_multi_kernel<LOG2_NC, WAVES, AMP>;
+    auto kern = stft_wave_multi_kernel<LOG2_NC, WAVES, AMP, NLD>;
+    static_assert(NLD * 1024 <= (int)(sizeof(cf32) * W::SLAB_LEN), "the staged samples fit the wave's slab");
     const size_t lds = sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint32_t wg_needed = (n_tiles + WAVES - 1) / WAVES;
-    const uint32_t grid = wg_needed < n_cu ? wg_needed : n_cu;
+    const uint32_t per_cu = 2 * lds <= 160 * 1024 ? 2u : 1u;  // (8 waves: two independent workgroups per CU)
+    const uint32_t grid = wg_needed < n_cu * per_cu ? wg_needed : n_cu * per_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw,
                        d_minmax, d_queue_head);
     return hipGetLastError();
+}
+// staged loads (see the kernel): n_fft 512, even hop (8-byte LDS reads), span (G - 1) hop + n_fft within NLD KB of samples
+template <int LOG2_NC, int WAVES, bool AMP>
+static hipError_t launch_wave_multi_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
+                                      uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
+                                      uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
+    if constexpr (LOG2_NC == 8) {
+        const uint32_t span = 3u * g.hop + g.n_fft;
+        if (g.hop % 2u == 0 && span <= 1024u)
+            return launch_wave_multi_n<LOG2_NC, WAVES, AMP, 4>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+        if (g.hop % 2u == 0 && span <= 1280u)
+            return launch_wave_multi_n<LOG2_NC, WAVES, AMP, 5>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+    }
+    return launch_wave_multi_n<LOG2_NC, WAVES, AMP, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
 }
 template <int LOG2_NC, bool AMP>
 static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
@@ -1428,7 +1483,9 @@ int stft_wave_default_waves(const StftGeom &g) {
     switch (g.log2_nc) {
         case 11: return WaveLaunchCfg<11>::DEFAULT_WAVES;
         case 10: return WaveLaunchCfg<10>::DEFAULT_WAVES;
-        case 8: return 12;
+        // n_fft 512 (four frames per wave, staged loads): measured 12 / 2 x 8 / 16 waves per CU — 512/128: 0.77 / 0.70-0.74 /
+        // 0.68-0.72 ms, 320/80 (8 kHz default): 1.16-1.18 / 1.21-1.26 / 1.24 ms
+        case 8: return g.hop >= 128 ? 16 : 12;
         case 12: case 13: return 12;  // (block kernel: only sizes the chunks, 12 x CUs of them per round)
         default: return WaveLaunchCfg<9>::DEFAULT_WAVES;
     }
