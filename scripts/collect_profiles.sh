@@ -11,6 +11,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace"
 find "$out/trace" -type f ! -name "*kernel_stats.csv" -delete
 scripts/pmc_stft.sh "$out/pmc_stft" > "$out/pmc_stft.log" 2>&1
 TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pmc_img.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_stft1024" --nfft 1024 > "$out/pmc_stft1024.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_stft512_multi" --nfft 512 > "$out/pmc_stft512_multi.log" 2>&1
 {
   python3 scripts/bench_stft.py --reps 30 --kernel 0 1
   python3 scripts/bench_stft.py --reps 30 --nfft 1024

@@ -50,7 +50,8 @@ hdr = ("# rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python3
        "# per-dispatch medians over the launches of each kernel; SQ_* in quad-cycles summed over waves, FETCH_SIZE/WRITE_SIZE in KB.\n"
        "# gfx950: FETCH_SIZE reports exactly 1/2 of streamed bytes for 4/8/16-byte-per-lane reads "
        "(profiles/r01_fetch_calibration.txt); WRITE_SIZE is exact.\n")
-for name, script in (("stft", "scripts/bench_stft.py"), ("img", "scripts/bench_img.py")):
+for name, script in (("stft", "scripts/bench_stft.py"), ("img", "scripts/bench_img.py"),
+                     ("stft1024", "scripts/bench_stft.py --nfft 1024"), ("stft512_multi", "scripts/bench_stft.py --nfft 512")):
     p = f"{src}/pmc_{name}/summary.txt"
     if os.path.exists(p):
         open(f"{dst}/{tag}_{name}_pmc_summary.txt", "w").write(hdr.format(script=script) + open(p).read())

@@ -90,9 +90,6 @@ __global__ __launch_bounds__(256) void spec_to_img_kernel(const ImgJob *__restri
     const uint32_t per_xcd = (n_local + 7) / 8;
     uint32_t local = (local0 % 8) * per_xcd + local0 / 8;  // bijective when n_local % 8 == 0
     if (n_local % 8 != 0) local = local0;                   // ragged tail: plain order
-#if defined(TH_IMG_PLAIN_ORDER)
-    local = local0;
-#endif
     const uint32_t tiles_r = (out_h + IMG_TILE_F - 1) / IMG_TILE_F;
     const uint32_t r0 = (local % tiles_r) * IMG_TILE_F;  // image row (relative to i_start)
     const uint32_t t0 = (local / tiles_r) * IMG_TILE_T;
@@ -394,11 +391,7 @@ hipError_t launch_raster_tile(const uint16_t *d_img, uint32_t img_width, uint32_
 hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block_job, uint32_t n_jobs,
                                 uint32_t n_blocks, const uint8_t *d_colormap, uint32_t n_colors, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
-#if defined(TH_RASTER_PERSIST)
-    const uint32_t grid = n_blocks < 256u * TH_RASTER_PERSIST ? n_blocks : 256u * TH_RASTER_PERSIST;
-#else
     const uint32_t grid = n_blocks;
-#endif
     hipLaunchKernelGGL(raster_level0_kernel, dim3(grid), dim3(RASTER_THREADS), 0, s, d_jobs, d_block_job, n_blocks,
                        reinterpret_cast<const uint32_t *>(d_colormap), n_colors);
     return hipGetLastError();

@@ -133,13 +133,6 @@ __global__ __launch_bounds__(256) void mel_mfma_kernel(const MelJob *__restrict_
                 for (int t = 0; t < MEL_MT; t++)
 #pragma unroll
                     for (int u = 0; u < MEL_UNROLL; u++) a[t][u] = *reinterpret_cast<const f32x4 *>(&lds_a[wave][t][li][16 * u + 4 * kq]);
-#if defined(TH_MEL_EXP_NOMFMA)
-#pragma unroll
-                for (int u = 0; u < MEL_UNROLL; u++)  // experiment: loads only
-#pragma unroll
-                    for (int t = 0; t < MEL_MT; t++) acc[t][0] += a[t][u].x * b[u].x + a[t][u].y * b[u].y + a[t][u].z * b[u].z + a[t][u].w * b[u].w;
-                continue;
-#endif
 #pragma unroll
                 for (int u = 0; u < MEL_UNROLL; u++) {
 #pragma unroll

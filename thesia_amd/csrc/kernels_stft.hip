@@ -178,11 +178,7 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
 // their use.  HBM traffic per frame: 4*hop B read (+ (n_fft - hop)*4 B once per chunk) and
 // 4*n_freq B written.
 // ------------------------------------------------------------------------------------------
-#if defined(TH_NO_SCHED_BARRIER)
-#define TH_SCHED_BARRIER() ((void)0)
-#else
 #define TH_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 // Development instrumentation (variant builds with -DTH_PHASE_PROF only, scripts/phase_prof.py): per-phase
 // shader-clock totals of the wave kernel's frame loop, summed over all waves.
@@ -220,13 +216,6 @@ __device__ unsigned long long th_wave_times_dev[6 * 256 * 16];
     } while (0)
 #else
 #define TH_WT_STORE(slot, v) ((void)0)
-#endif
-
-// Optional (variant builds with -DTH_ROTATE_PRIO): issue priority rotating with the frame body, see the frame loop.
-#if defined(TH_ROTATE_PRIO)
-#define TH_SETPRIO(P) __builtin_amdgcn_s_setprio(P)
-#else
-#define TH_SETPRIO(P) ((void)0)
 #endif
 
 // Orders this wave's LDS writes before its later LDS reads (and vice versa) for the compiler; the
@@ -692,31 +681,27 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #endif
         uint32_t f = cur.f;
         // frame loop (steady state: branch-free register flow, see wave_frame)
-        // (TH_SETPRIO: measurement switch, off by default.  The instruction arbiter serves the oldest wave of a SIMD first,
-        // and strictly: of the three waves of a SIMD the first-launched runs a frame in 4.4 us, the second in 5.5, the third
-        // in 8.1 (scripts/wave_times.py).  Cycling the priority 0..NROT-1 from frame to frame makes all waves advance at the
-        // same pace (5.4 / 5.7 / 6.0 us) — and the launch 1.5 % slower: the sum of the rates is what counts, the dynamic
-        // chunk queue already absorbs the different speeds, and the kernel is bound by its total work, not by its tail.)
+        // (The instruction arbiter serves the oldest wave of a SIMD first, and strictly: of the three waves of a SIMD the
+        // first-launched runs a frame in 4.4 us, the second in 5.5, the third in 8.1 (scripts/wave_times.py).  Cycling
+        // s_setprio 0..NROT-1 from frame to frame made all waves advance at the same pace (5.4 / 5.7 / 6.0 us) — and the
+        // launch 1.5 % slower: the sum of the rates is what counts, the dynamic chunk queue already absorbs the different
+        // speeds, and the kernel is bound by its total work, not by its tail.  Measured in round 2, not kept.)
         for (;;) {
             TH_SCHED_PULL(sch, f, lane);
-            TH_SETPRIO(0);
             TH_FRAME(0);
             if (++f >= cur.f1) break;
             if constexpr (NROT > 1) {
                 TH_SCHED_PULL(sch, f, lane);
-                TH_SETPRIO(1);
                 TH_FRAME(1);
                 if (++f >= cur.f1) break;
             }
             if constexpr (NROT > 2) {
                 TH_SCHED_PULL(sch, f, lane);
-                TH_SETPRIO(2);
                 TH_FRAME(2);
                 if (++f >= cur.f1) break;
             }
             if constexpr (NROT > 3) {
                 TH_SCHED_PULL(sch, f, lane);
-                TH_SETPRIO(3);
                 TH_FRAME(3);
                 if (++f >= cur.f1) break;
             }

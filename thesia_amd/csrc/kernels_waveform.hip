@@ -170,12 +170,8 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const PyrJob *__restr
     // eighth one (the segment may then lie past the channel's end: checked right below).  Measured on config 3: levels 0
     // only 1.08 -> 0.98 ms (6.0 TB/s), all levels 2.15 -> 2.05 ms — each XCD then streams through its own region of the
     // output (and the small upper-level bins that share a 128-byte line are written through one L2, not eight).
-#if defined(TH_PYR_PLAIN_ORDER)
-    const uint32_t seg = blockIdx.x;
-#else
     const uint32_t per_xcd = gridDim.x / 8;  // the launch rounds the grid up to a multiple of 8: the map is a bijection
     const uint32_t seg = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-#endif
     if ((uint64_t)seg * PYR_SEG >= job.n_samples) return;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     float *stage = stage_all[wv];

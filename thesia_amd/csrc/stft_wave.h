@@ -25,7 +25,7 @@ namespace th {
 // wave-instruction; two separate ds_read_b64 take 2 x 2.2 (scripts/ubench/lds_rate.hip).  A volatile
 // access is left alone by the load/store optimiser and still gets exact s_waitcnt tracking.
 TH_HD cf32 lds_ld(const cf32 *p) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(TH_LDS_PAIRED_READS)
+#if defined(__HIP_DEVICE_COMPILE__)
     // LDS address space, explicit: address-space inference does not look through volatile accesses
     // (they would become flat loads).  Loaded as one 64-bit integer and split, not as a float2 vector:
     // vector-typed values make the backend pick half-rate v_pk_*_f32 for the arithmetic that follows.
@@ -36,16 +36,8 @@ TH_HD cf32 lds_ld(const cf32 *p) {
 #endif
 }
 
-// 8-byte LDS write that may not be fused with a neighbour (experiment switch TH_LDS_UNPAIRED_WRITES: hipcc pairs
-// adjacent stores into ds_write2_b64, 13 cycles per wave-instruction against 2 x 6 for two ds_write_b64)
-TH_HD void lds_st(cf32 *p, cf32 v) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(TH_LDS_UNPAIRED_WRITES)
-    const uint64_t u = (uint64_t)__builtin_bit_cast(uint32_t, v.re) | ((uint64_t)__builtin_bit_cast(uint32_t, v.im) << 32);
-    *(volatile __attribute__((address_space(3))) uint64_t *)(p) = u;
-#else
-    *p = v;
-#endif
-}
+// 8-byte LDS write (the slot-layout exchanges of the generic plans)
+TH_HD void lds_st(cf32 *p, cf32 v) { *p = v; }
 
 // 4-byte LDS read in program order (volatile, explicit LDS address space; see lds_ld)
 TH_HD float lds_ldf(const float *p) {
