@@ -138,6 +138,7 @@ def test_tiny_and_huge_magnitudes(ctx, scale, win, hop, n_fft):
 
 
 @pytest.mark.parametrize("win,hop,n_fft,which", [(512, 128, 512, 0), (320, 80, 512, 0), (500, 77, 512, 2), (512, 512, 512, 2),
+                                                 (512, 256, 512, 0), (400, 200, 512, 0), (330, 66, 512, 0),  # staged loads: 5 / 5 / 4 per lane
                                                  (1024, 256, 1024, 6), (1000, 250, 1024, 6), (1024, 100, 1024, 6)])
 def test_multi_frame_wave_kernel(ctx, win, hop, n_fft, which):
     """stft_wave_multi.h: four frames per wave at n_fft 512 (the default there: the app's own framing at 8 kHz is 320 / 80 /
