@@ -983,6 +983,7 @@ static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, co
 // transform ahead of its use.  Without it every frame is loaded in full and three quarters of that are re-reads that the
 // L2 (4 MB per XCD against 96 workgroups streaming 48 KB per frame each) mostly misses: PMC 1.87 GB fetched per launch for
 // 0.74 GB of audio.  The 32 registers come from the window pairs, which are read from the (L2-resident) table instead.
+constexpr bool block_double_buffered(int log2_nc) { return log2_nc == 13; }
 template <int LOG2_NC, bool AMP, bool REUSE>
 __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_tiles,
@@ -990,9 +991,24 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     using B = BlockFft<LOG2_NC>;
     constexpr int T = B::T, NC = B::NC;
     constexpr bool WIN_REGS = LOG2_NC == 12 && !REUSE;  // 32 VGPRs: with three sets of pass constants (n_fft 16384) or the resident samples they do not fit
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // BUF_LEN cf32 (n_fft 16384: 68 KB) + the (min, max) scratch
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // BUF_LEN cf32 (n_fft 16384: 2 x 68 KB) + the (min, max) scratch
+    // n_fft 16384 (one workgroup per CU either way): two exchange buffers used alternately, see the frame loop.  n_fft 8192
+    // keeps one: a second would cost its full-reload variant the third workgroup per CU (3.2 -> 3.6 ms on 3840/960/8192)
+    // and gains nothing at two (0.72 ms either way).
+    constexpr bool DBUF = block_double_buffered(LOG2_NC);
     cf32 *const buf = reinterpret_cast<cf32 *>(smem_raw);
-    float *const red = reinterpret_cast<float *>(buf + B::BUF_LEN);
+    float *const red = reinterpret_cast<float *>(buf + (DBUF ? 2 : 1) * B::BUF_LEN);
+    cf32 *wr = buf, *nx = buf + (DBUF ? B::BUF_LEN : 0);
+#define TH_BLOCK_SWAP()                                                                        \
+    do {                                                                                       \
+        if constexpr (DBUF) {                                                                  \
+            cf32 *const tmp_ = wr;                                                             \
+            wr = nx;                                                                           \
+            nx = tmp_;                                                                         \
+        } else {                                                                               \
+            __syncthreads(); /* one buffer: its reads are done before the next writes */      \
+        }                                                                                      \
+    } while (0)
     const uint32_t t = threadIdx.x;
     const FrameCursor cur = cursor_at(g, jobs, chunk_tab, n_tiles, blockIdx.x);
     if (!cur.valid) return;
@@ -1039,28 +1055,32 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
                 x[m] = {p[0], p[1]};
             }
         }
-        __syncthreads();  // the previous frame's mirror reads are done: the buffer may be rewritten
-        B::pass_first(t, z, buf);
+        // DBUF: exchange n goes through buffer n mod 2: a thread that has passed the barrier of exchange n - 1 knows that
+        // every thread is done reading exchange n - 2, so ONE barrier per exchange (between its writes and its reads) is
+        // enough; with a single buffer TH_BLOCK_SWAP is the second barrier, before the next writes (n_fft 16384: 4 barriers
+        // per frame instead of 8, 1.12 -> 1.01 ms).
+        B::pass_first(t, z, wr);
         __syncthreads();
-        B::template read_in<B::FIRST_LAYOUT>(t, z, buf);
+        B::template read_in<B::FIRST_LAYOUT>(t, z, wr);
+        TH_BLOCK_SWAP();
         if constexpr (B::R2_FIRST) {
             B::template pass_mid_compute<B::NS_A>(z, wA);
+            B::template pass_mid_store<B::NS_A>(t, z, wr);
             __syncthreads();
-            B::template pass_mid_store<B::NS_A>(t, z, buf);
-            __syncthreads();
-            B::template read_in<B::NS_A>(t, z, buf);
+            B::template read_in<B::NS_A>(t, z, wr);
+            TH_BLOCK_SWAP();
         }
         B::template pass_mid_compute<B::NS_B>(z, wB);
+        B::template pass_mid_store<B::NS_B>(t, z, wr);
         __syncthreads();
-        B::template pass_mid_store<B::NS_B>(t, z, buf);
-        __syncthreads();
-        B::template read_in<B::NS_B>(t, z, buf);
+        B::template read_in<B::NS_B>(t, z, wr);
+        TH_BLOCK_SWAP();
         B::pass_last(z, wC);
-        __syncthreads();
-        B::write_z(t, z, buf);
+        B::write_z(t, z, wr);
         __syncthreads();
         cf32 zm[8];
-        B::split_read(t, buf, zm);
+        B::split_read(t, wr, zm);
+        TH_BLOCK_SWAP();
         const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch;
         B::split_compute(t, z, zm, stw_t, [&](uint32_t k, float p) {
             if constexpr (AMP) {  // amplitude rows for the matrix-core mel path
@@ -1097,12 +1117,15 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     }
 }
 
+#undef TH_BLOCK_SWAP
+
 template <int LOG2_NC, bool AMP, bool REUSE>
 static hipError_t launch_block_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
                                const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
     using B = BlockFft<LOG2_NC>;
     auto kern = stft_block_kernel<LOG2_NC, AMP, REUSE>;
-    const size_t lds = sizeof(cf32) * B::BUF_LEN + sizeof(float) * 2 * (B::T / 64);
+    const size_t lds = sizeof(cf32) * (block_double_buffered(LOG2_NC) ? 2 : 1) * B::BUF_LEN + sizeof(float) * 2 * (B::T / 64);
+    static_assert(sizeof(cf32) * (block_double_buffered(LOG2_NC) ? 2 : 1) * B::BUF_LEN + 64 <= 160 * 1024, "the exchange buffers fit the CU's LDS");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(B::T), lds, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax);
