@@ -118,6 +118,9 @@ struct LodAxis {             // device pointers into one uploaded blob
     const double *wsum;      // [n_out] sum of the taps
     const double *w;         // [n_out][max_taps]
     uint32_t n_out, max_taps;
+    // batched pass only (launch_lod_vpass_batch): rows spanned by the tap windows of R consecutive outputs, maximum over
+    // the aligned groups of R = 8, 4, 2 outputs (0: unknown, one output per thread)
+    uint32_t span[3] = {0, 0, 0};
 };
 // horizontal pass: tmp[r][ox] for the source rows y_lo + r, r < n_rows; vertical pass: lod[oy][ox]
 // (tmp_pitch / lod_pitch: elements per row of the intermediate and of the result)

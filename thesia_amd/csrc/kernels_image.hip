@@ -440,56 +440,67 @@ __global__ __launch_bounds__(256) void lod_vpass_kernel(const uint16_t *__restri
 // The vertical pass over MANY images of one shape in one launch (the mip pyramids of a batch of tracks: a launch per
 // level instead of a launch per level and channel; the horizontal pass is this one on the transposed image, see
 // transpose_u16_batch_kernel); blockIdx.z picks the job.
-// A thread owns one column and LOD_R consecutive output rows.  Their tap windows overlap (a level-l output spans 6 * 2^l
+// A thread owns one column and R consecutive output rows.  Their tap windows overlap (a level-l output spans 6 * 2^l
 // source rows, its neighbour starts 2^l further down), so the thread walks the union of the windows once — one u16 load
-// and one conversion per source row, LOD_R independent accumulators — where a thread per output loaded and converted
-// every row six times and waited on one dependent f64 chain (5.8 ms per pyramid rebuild of 32 images, 92 % of
-// set_dB_range).  The taps of the block's rows sit in LDS (read as a broadcast); every output still adds its taps in
-// ascending order, mul then add: bit-identical to lod_vpass_kernel and to the oracle.
-// LOD_R = 8 while the taps fit 64 KB of LDS (up to level 7, 769 taps), then 4, 2, 1; beyond level 10 (more than 8192 taps
-// per output) the taps are read from the global table.
-template <uint32_t LOD_R, bool W_IN_LDS>
-__global__ __launch_bounds__(256) void lod_vpass_batch_kernel(const LodPassJob *__restrict__ jobs, LodAxis ay, uint32_t dw) {
-    extern __shared__ __attribute__((aligned(16))) double lod_w_lds[];  // [LOD_R][max_taps]
-    const uint32_t oy0 = blockIdx.y * LOD_R;
-    const uint32_t n_rows = min(LOD_R, ay.n_out - oy0);
-    if constexpr (W_IN_LDS) {
-        for (uint32_t i = threadIdx.x; i < n_rows * ay.max_taps; i += 256) lod_w_lds[i] = ay.w[(size_t)oy0 * ay.max_taps + i];
-        __syncthreads();
-    }
-    const double *const lod_w = lod_w_lds;
-    const gptr<const double> lod_wg = as_global(ay.w) + (size_t)oy0 * ay.max_taps;
-    const uint32_t ox = blockIdx.x * 256 + threadIdx.x;
-    if (ox >= dw) return;
-    const LodPassJob job = jobs[blockIdx.z];
-    int32_t st[LOD_R], cn[LOD_R];  // block-uniform
+// and one conversion per source row, R independent accumulators — where a thread per output loaded and converted every
+// row six times and waited on one dependent f64 chain (5.8 ms per pyramid rebuild of 32 images, 92 % of set_dB_range).
+// The block's taps sit in LDS as R rows over the union, ZERO outside each output's own window: the inner loop is then
+// branch-free (acc + 0.0 * v == acc exactly: v is a finite non-negative pixel), reads its taps as broadcasts, and every
+// output still adds its taps in ascending order, mul then add: bit-identical to lod_vpass_kernel and to the oracle.
+// R = 8 / 4 / 2 by what fits 64 KB of LDS and leaves the launch a thousand blocks; else one output per thread, taps from
+// the global table (lod_vpass_batch1_kernel).
+template <uint32_t R>
+__global__ __launch_bounds__(256) void lod_vpass_batch_kernel(const LodPassJob *__restrict__ jobs, LodAxis ay, uint32_t dw, uint32_t span) {
+    extern __shared__ __attribute__((aligned(16))) double lod_wz[];  // [R][span]
+    const uint32_t oy0 = blockIdx.y * R;
+    const uint32_t n_rows = min(R, ay.n_out - oy0);
+    int32_t st[R], cn[R];  // block-uniform
     int32_t t_hi = 0;
 #pragma unroll
-    for (uint32_t o = 0; o < LOD_R; o++) {
+    for (uint32_t o = 0; o < R; o++) {
         const uint32_t oy = min(oy0 + o, ay.n_out - 1u);
         st[o] = __builtin_amdgcn_readfirstlane(ay.start[oy]);
         cn[o] = o < n_rows ? __builtin_amdgcn_readfirstlane(ay.count[oy]) : 0;
         t_hi = max(t_hi, st[o] + cn[o]);
     }
-    double acc[LOD_R];
+    const int32_t t_lo = st[0];  // (starts ascend: the first row any of the outputs needs)
+    const uint32_t len = min((uint32_t)(t_hi - t_lo), span);  // == t_hi - t_lo (span is the maximum over the axis)
 #pragma unroll
-    for (uint32_t o = 0; o < LOD_R; o++) acc[o] = 0.0;
-    const gptr<const uint16_t> col = as_global(job.src) + ox;
-    for (int32_t t = st[0]; t < t_hi; t++) {  // (starts ascend: st[0] is the first row any of the outputs needs)
-        const double v = (double)col[(size_t)t * job.src_pitch];
-#pragma unroll
-        for (uint32_t o = 0; o < LOD_R; o++) {
-            const int32_t rel = t - st[o];
-            if ((uint32_t)rel < (uint32_t)cn[o]) {  // uniform branch
-                const uint32_t at = o * ay.max_taps + (uint32_t)rel;
-                if constexpr (W_IN_LDS) acc[o] += lod_w[at] * v;
-                else acc[o] += lod_wg[at] * v;
-            }
+    for (uint32_t o = 0; o < R; o++) {
+        const gptr<const double> wo = as_global(ay.w) + (size_t)min(oy0 + o, ay.n_out - 1u) * ay.max_taps;
+        for (uint32_t j = threadIdx.x; j < len; j += 256) {
+            const int32_t rel = t_lo + (int32_t)j - st[o];
+            lod_wz[o * span + j] = (uint32_t)rel < (uint32_t)cn[o] ? wo[rel] : 0.0;
         }
     }
+    __syncthreads();
+    const uint32_t ox = blockIdx.x * 256 + threadIdx.x;
+    if (ox >= dw) return;
+    const LodPassJob job = jobs[blockIdx.z];
+    double acc[R];
 #pragma unroll
-    for (uint32_t o = 0; o < LOD_R; o++)
+    for (uint32_t o = 0; o < R; o++) acc[o] = 0.0;
+    const gptr<const uint16_t> col = as_global(job.src) + (size_t)t_lo * job.src_pitch + ox;
+#pragma unroll 4
+    for (uint32_t j = 0; j < len; j++) {
+        const double v = (double)col[(size_t)j * job.src_pitch];
+#pragma unroll
+        for (uint32_t o = 0; o < R; o++) acc[o] += lod_wz[o * span + j] * v;
+    }
+#pragma unroll
+    for (uint32_t o = 0; o < R; o++)
         if (o < n_rows) as_global(job.dst)[(size_t)(oy0 + o) * job.dst_pitch + ox] = lod_round(acc[o], ay.wsum[oy0 + o]);
+}
+__global__ __launch_bounds__(256) void lod_vpass_batch1_kernel(const LodPassJob *__restrict__ jobs, LodAxis ay, uint32_t dw) {
+    const uint32_t ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= dw) return;
+    const LodPassJob job = jobs[blockIdx.z];
+    const gptr<const uint16_t> col = as_global(job.src) + (size_t)ay.start[oy] * job.src_pitch + ox;
+    const gptr<const double> w = as_global(ay.w) + (size_t)oy * ay.max_taps;
+    const int32_t n = ay.count[oy];
+    double acc = 0.0;
+    for (int32_t t = 0; t < n; t++) acc += w[t] * (double)col[(size_t)t * job.src_pitch];
+    as_global(job.dst)[(size_t)oy * job.dst_pitch + ox] = lod_round(acc, ay.wsum[oy]);
 }
 // u16 transpose of many images of one shape: dst[x][y] = src[y][x], 64 x 64 tiles through LDS (both sides coalesced).
 // The mip builder runs the horizontal Lanczos pass as a vertical pass over the transposed image: a thread per output
@@ -520,18 +531,25 @@ hipError_t launch_transpose_u16_batch(const LodPassJob *d_jobs, uint32_t n_jobs,
 hipError_t launch_lod_vpass_batch(const LodPassJob *d_jobs, uint32_t n_jobs, LodAxis ay, uint32_t dw, hipStream_t s) {
     if (!n_jobs || !ay.n_out || !dw) return hipSuccess;
     if (n_jobs > 65535u) return hipErrorInvalidValue;
-    const uint32_t cap = 64 * 1024 / sizeof(double);  // taps that fit the LDS table
-    const uint32_t r = ay.max_taps * 8 <= cap ? 8u : ay.max_taps * 4 <= cap ? 4u : ay.max_taps * 2 <= cap ? 2u : 1u;
-    const bool in_lds = ay.max_taps * r <= cap;
+    const uint32_t bx = (dw + 255) / 256;
+    uint32_t r = 1, span = 0;
+    for (int k = 0; k < 3; k++) {  // R = 8, 4, 2: the largest that fits the LDS and keeps ~1000 blocks in the launch
+        const uint32_t rk = 8u >> k;
+        const uint64_t blocks = (uint64_t)bx * ((ay.n_out + rk - 1) / rk) * n_jobs;
+        if (ay.span[k] != 0 && (size_t)rk * ay.span[k] * sizeof(double) <= 64 * 1024 && (blocks >= 1024 || rk == 2)) {
+            r = rk;
+            span = ay.span[k];
+            break;
+        }
+    }
     const uint32_t n_blk = (ay.n_out + r - 1) / r;
     if (n_blk > 65535u) return hipErrorInvalidValue;
-    const dim3 grid((dw + 255) / 256, n_blk, n_jobs);
-    const size_t lds = in_lds ? sizeof(double) * r * ay.max_taps : 0;
-    if (r == 8) hipLaunchKernelGGL((lod_vpass_batch_kernel<8, true>), grid, dim3(256), lds, s, d_jobs, ay, dw);
-    else if (r == 4) hipLaunchKernelGGL((lod_vpass_batch_kernel<4, true>), grid, dim3(256), lds, s, d_jobs, ay, dw);
-    else if (r == 2) hipLaunchKernelGGL((lod_vpass_batch_kernel<2, true>), grid, dim3(256), lds, s, d_jobs, ay, dw);
-    else if (in_lds) hipLaunchKernelGGL((lod_vpass_batch_kernel<1, true>), grid, dim3(256), lds, s, d_jobs, ay, dw);
-    else hipLaunchKernelGGL((lod_vpass_batch_kernel<1, false>), grid, dim3(256), lds, s, d_jobs, ay, dw);
+    const dim3 grid(bx, n_blk, n_jobs);
+    const size_t lds = (size_t)r * span * sizeof(double);
+    if (r == 8) hipLaunchKernelGGL((lod_vpass_batch_kernel<8>), grid, dim3(256), lds, s, d_jobs, ay, dw, span);
+    else if (r == 4) hipLaunchKernelGGL((lod_vpass_batch_kernel<4>), grid, dim3(256), lds, s, d_jobs, ay, dw, span);
+    else if (r == 2) hipLaunchKernelGGL((lod_vpass_batch_kernel<2>), grid, dim3(256), lds, s, d_jobs, ay, dw, span);
+    else hipLaunchKernelGGL(lod_vpass_batch1_kernel, grid, dim3(256), 0, s, d_jobs, ay, dw);
     return hipGetLastError();
 }
 

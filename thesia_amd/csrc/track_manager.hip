@@ -70,6 +70,7 @@ constexpr size_t MAX_READER_SLOTS = 16;
 struct AxisTable {
     void *d_blob = nullptr;
     uint32_t n_out = 0, max_taps = 0;
+    uint32_t span[3] = {0, 0, 0};  // LodAxis::span
 };
 
 struct Track {
@@ -295,6 +296,16 @@ int axis_table(th_tm *tm, uint32_t n_in, uint32_t level, AxisTable **out) {
         }
         t.n_out = (uint32_t)n_out;
         t.max_taps = ax.max_taps;
+        for (int k = 0; k < 3; k++) {  // source rows under the tap windows of R = 8, 4, 2 consecutive outputs
+            const size_t r = (size_t)8 >> k;
+            int64_t span = 0;
+            for (size_t o0 = 0; o0 < n_out; o0 += r) {
+                int64_t hi = 0;
+                for (size_t o = o0; o < std::min(n_out, o0 + r); o++) hi = std::max<int64_t>(hi, (int64_t)ax.start[o] + ax.count[o]);
+                span = std::max(span, hi - (int64_t)ax.start[o0]);
+            }
+            t.span[k] = (uint32_t)span;
+        }
         it = tm->axis_tabs.emplace(key, t).first;
     }
     *out = &it->second;
@@ -310,6 +321,7 @@ LodAxis axis_view(const AxisTable &t) {
     a.w = reinterpret_cast<const double *>(base + (size_t)t.n_out * 16);
     a.n_out = t.n_out;
     a.max_taps = t.max_taps;
+    for (int k = 0; k < 3; k++) a.span[k] = t.span[k];
     return a;
 }
 
