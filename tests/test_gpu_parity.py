@@ -600,6 +600,35 @@ def test_lod_mip_pyramid(ctx):
     tm.close()
 
 
+def test_lod_mip_pyramid_long_track(ctx):
+    """The upper levels of a long track's pyramid (hundreds to thousands of Lanczos taps per output): the batched pass then
+    runs with 4, 2 or 1 output rows per thread (what fits the LDS tap table) instead of 8 — same tiles as the per-request
+    resize inside the core, as in test_lod_mip_pyramid (b)."""
+    ident = _identity_colormap()
+    tm = ta.TrackManager(ctx)
+    tm.set_setting(40.0, 4, 1, ta.MEL)
+    tm.set_colormap(ident)
+    long_track = synth_track(33, 48000, 48000 * 240)  # 24001 frames: level_x up to 10
+    tm.add_tracks([(1, 48000, long_track[None])])
+    tm.apply_track_list_changes()
+    img = tm.img(1, 0)
+    assert img.shape[1] == 24001
+    worst, n_diff, n_px = 0, 0, 0
+    for lx, ly, tx in [(7, 0, 0), (8, 0, 0), (9, 1, 0), (10, 0, 0), (6, 2, 0)]:
+        mip = tm.mip_level(1, 0, lx, ly)
+        assert mip.shape == (-(-img.shape[0] // (1 << ly)), -(-img.shape[1] // (1 << lx)))
+        tm.set_lod_source(per_request=False)
+        a, (ox, oy) = _tile_u16(tm.get_spectrogram_tile(1, 0, lx, ly, tx, 0))
+        assert np.array_equal(a, mip[::-1].astype(np.int64)[mip.shape[0] - oy - a.shape[0]: mip.shape[0] - oy, ox: ox + a.shape[1]])
+        tm.set_lod_source(per_request=True)
+        b, _ = _tile_u16(tm.get_spectrogram_tile(1, 0, lx, ly, tx, 0))
+        assert a.shape == b.shape and a.size > 0
+        d = np.abs(a - b)  # (one tile covers these levels: the crop box is the whole image, no gutter to differ in)
+        worst, n_diff, n_px = max(worst, int(d.max())), n_diff + int((d > 0).sum()), n_px + d.size
+    assert worst <= 1 and n_diff <= 1e-3 * n_px, (worst, n_diff, n_px)
+    tm.close()
+
+
 def test_track_manager_failed_setting_changes_nothing(ctx, golden_dir):
     """a setting this library cannot plan (f_overlap = 3 -> n_fft not a power of two; the reference's realfft
     would take it) must fail WITHOUT touching the manager: settings, specs, images, db state, tiles and revisions are
