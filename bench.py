@@ -303,7 +303,7 @@ def tm_end_to_end_and_latency(torch, ta, ctx, wl, sr, cmap_bytes, n_tracks=32):
         return {"p50_us": float(a[len(a) // 2]), "p99_us": float(a[min(len(a) - 1, int(len(a) * 0.99))]),
                 "requests_per_s": len(a) / wall}
 
-    latency = {"what": "wall time per request at the C ABI (ctypes), pinned staging + one stream per request; "
+    latency = {"what": "wall time per request at the C ABI (ctypes), one stream + one mapped pinned buffer per request (the raster kernel writes it directly); "
                        "LOD tiles are crops of the resident mip pyramid", "image": [int(ih), int(iw)]}
     for kind in ("spec_level0", "spec_lod_1_0", "spec_lod_2_1", "waveform"):
         latency[kind] = {"threads_1": measure(kind, 1), "threads_8": measure(kind, 8)}

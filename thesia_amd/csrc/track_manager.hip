@@ -59,8 +59,8 @@ struct Channel {
 // buffer and a pinned host staging buffer — so that no request waits for another's kernel or copy.
 struct ReaderSlot {
     hipStream_t stream = nullptr;
-    uint8_t *d_tile = nullptr;
-    uint8_t *h_tile = nullptr;  // pinned
+    uint8_t *h_tile = nullptr;  // pinned, mapped into the device's address space
+    uint8_t *h_tile_dev = nullptr;  // its device-side address
     bool busy = false;
 };
 constexpr size_t TILE_BYTES_MAX = 520 * 520 * 4;  // 512 core + 2 x 4 gutter (render_tiles.rs:15-16); >= 1024 * 12 waveform bins
@@ -576,11 +576,10 @@ int acquire_slot(th_tm *tm, ReaderSlot **out) {
         if (tm->slots.size() < MAX_READER_SLOTS) {
             std::unique_ptr<ReaderSlot> sl(new ReaderSlot());
             hipError_t e = hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipMalloc((void **)&sl->d_tile, TILE_BYTES_MAX);
-            if (e == hipSuccess) e = hipHostMalloc((void **)&sl->h_tile, TILE_BYTES_MAX, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipHostMalloc((void **)&sl->h_tile, TILE_BYTES_MAX, hipHostMallocMapped);
+            if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&sl->h_tile_dev, sl->h_tile, 0);
             if (e != hipSuccess) {
                 if (sl->h_tile) (void)hipHostFree(sl->h_tile);
-                if (sl->d_tile) (void)hipFree(sl->d_tile);
                 if (sl->stream) (void)hipStreamDestroy(sl->stream);
                 if (tm->slots.empty()) TH_HIP(e);
                 // out of resources with slots in use: wait for one of those instead
@@ -625,7 +624,6 @@ TH_API int th_tm_destroy(th_tm *tm) {
     for (auto &sp : tm->slots) {
         (void)hipStreamSynchronize(sp->stream);
         (void)hipStreamDestroy(sp->stream);
-        (void)hipFree(sp->d_tile);
         (void)hipHostFree(sp->h_tile);
     }
     for (auto &kv : tm->tracks)
@@ -994,10 +992,11 @@ TH_API int th_tm_get_spectrogram_tile(th_tm *tm, size_t id, uint32_t ch, uint32_
     int rc = acquire_slot(tm, &lease.slot);
     if (rc != TH_OK) return rc;
     ReaderSlot &sl = *lease.slot;
+    // The raster kernel writes the pixels straight into the slot's pinned, device-visible host buffer (16 bytes per lane,
+    // 1 KB per wave-instruction over PCIe): no device staging tile, no copy-engine transfer queued behind other readers'.
     TH_HIP(launch_raster_tile(src, src_w, src_h, src_pitch, (uint32_t)g.origin_x, (uint32_t)g.origin_y, (uint32_t)g.width,
-                              (uint32_t)g.height, sl.d_tile, tm->d_colormap, (uint32_t)(tm->colormap_rgba.size() / 4),
+                              (uint32_t)g.height, sl.h_tile_dev, tm->d_colormap, (uint32_t)(tm->colormap_rgba.size() / 4),
                               sl.stream));
-    TH_HIP(hipMemcpyAsync(sl.h_tile, sl.d_tile, px_bytes, hipMemcpyDeviceToHost, sl.stream));
     TH_HIP(hipStreamSynchronize(sl.stream));
     std::memcpy(out + 40, sl.h_tile, px_bytes);
     return TH_OK;
