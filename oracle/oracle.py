@@ -33,6 +33,11 @@ _u16p = C.POINTER(C.c_uint16)
 _u8p = C.POINTER(C.c_uint8)
 
 
+class _TileGeom(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("origin_x", C.c_uint32), ("origin_y", C.c_uint32),
+                ("lod_w", C.c_size_t), ("lod_h", C.c_size_t)]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -80,6 +85,10 @@ def lib():
         L.orc_encode_spectrogram_tile.restype = C.c_size_t
         L.orc_encode_spectrogram_tile.argtypes = [_u16p, C.c_size_t, C.c_size_t, _u8p, C.c_size_t, C.c_uint64,
                                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _u8p]
+        L.orc_resize_whole_image.argtypes = [_u16p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, _u16p]
+        L.orc_spectrogram_tile_u16.restype = C.c_size_t
+        L.orc_spectrogram_tile_u16.argtypes = [_u16p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.c_uint32, C.c_int, _u16p, C.POINTER(_TileGeom)]
         L.orc_track_step.restype = C.c_size_t
         L.orc_track_step.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _u8p, C.c_size_t, C.c_float,
                                      C.POINTER(C.c_uint64)]
@@ -280,6 +289,32 @@ def encode_spectrogram_tile(img, colormap_rgba, revision: int, level_x: int, lev
     n = lib().orc_encode_spectrogram_tile(_p(img, _u16p), Hh, W, _p(cm, _u8p), cm.size, revision, level_x,
                                           level_y, tile_x, tile_y, _p(out, _u8p))
     return out[:n].tobytes()
+
+
+# LOD resize variants (sensitivity checks; see the C file): mode -1 = the tile encoder's own f64 Lanczos3,
+# 0 = f64 with pre-normalised taps, 1 = fixed point at the largest precision an i32 coefficient allows, 2 = 16-bit fixed point
+RESIZE_F64, RESIZE_F64_PRENORM, RESIZE_FIXED_MAX, RESIZE_FIXED_16 = -1, 0, 1, 2
+
+
+def resize_whole_image(img, level_x: int, level_y: int, mode: int = RESIZE_F64) -> np.ndarray:
+    """The whole image resampled to LOD (level_x, level_y): what a pre-built mip level holds (rows low -> high frequency)."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    Hh, W = img.shape
+    out = np.empty((-(-Hh // (1 << level_y)), -(-W // (1 << level_x))), np.uint16)
+    lib().orc_resize_whole_image(_p(img, _u16p), Hh, W, level_x, level_y, mode, _p(out, _u16p))
+    return out
+
+
+def spectrogram_tile_u16(img, level_x: int, level_y: int, tile_x: int, tile_y: int, mode: int = RESIZE_F64):
+    """LOD pixels of one tile before the row flip and the colour map (render_tiles.rs:330-338) + (origin_x, origin_y)."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    Hh, W = img.shape
+    out = np.empty(520 * 520, np.uint16)
+    g = _TileGeom()
+    n = lib().orc_spectrogram_tile_u16(_p(img, _u16p), Hh, W, level_x, level_y, tile_x, tile_y, mode, _p(out, _u16p),
+                                       C.byref(g))
+    assert n == g.width * g.height
+    return out[:n].reshape(g.height, g.width).copy(), (g.origin_x, g.origin_y)
 
 
 def track_step(x, win: int, hop: int, n_fft: int, colormap_rgba: bytes, dB_range: float = 100.0) -> int:

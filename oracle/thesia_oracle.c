@@ -747,6 +747,121 @@ static void resize_lanczos3_u16(const uint16_t *src, size_t sw, size_t sh, doubl
     free(tmp);
 }
 
+/* ------------------------------------------------------------------ */
+/* Sensitivity variants of the LOD resize (NOT parity: the crate source is absent, see the header).     */
+/* fast_image_resize resamples U16 images in fixed point (as Pillow does for 8-bit ones): per axis the   */
+/* f64 taps are normalised, scaled by 2^precision, rounded to i32, accumulated in i64 from 2^(p-1)       */
+/* (round half up) and shifted back.  mode 1 restates that with the "largest precision whose biggest     */
+/* coefficient still fits an i32" rule; mode 2 with a crude fixed precision of 16 bits.  They exist to   */
+/* bound how far ANY fixed-point Lanczos3 of this structure can sit from the f64 one on the colour-index */
+/* plane (tests/test_oracle_lod.py), which is what "parity unpinned" leaves open.                        */
+/* ------------------------------------------------------------------ */
+typedef struct { long *start, *count; double *w; size_t window; int precision; int64_t *wi; } orc_axis;
+
+static void axis_free(orc_axis *a) { free(a->start); free(a->count); free(a->w); free(a->wi); }
+
+/* per-axis coefficient table: in_size source pixels, crop [in0, in0 + extent), out_size outputs */
+static void axis_build(size_t in_size, double in0, double extent, size_t out_size, int fixed_bits, orc_axis *a) {
+    double scale = extent / (double)out_size;
+    double fscale = scale < 1.0 ? 1.0 : scale;
+    double radius = 3.0 * fscale;
+    size_t window = (size_t)ceil(radius) * 2 + 2;
+    a->window = window;
+    a->start = (long *)malloc(sizeof(long) * out_size);
+    a->count = (long *)malloc(sizeof(long) * out_size);
+    a->w = (double *)calloc(window * out_size, sizeof(double));
+    a->wi = NULL; a->precision = 0;
+    double wmax = 0.0;
+    for (size_t o = 0; o < out_size; o++) {
+        double center = in0 + ((double)o + 0.5) * scale;
+        long x0 = (long)floor(center - radius), x1 = (long)ceil(center + radius);
+        if (x0 < 0) x0 = 0; if (x1 > (long)in_size) x1 = (long)in_size;
+        if (x1 < x0) x1 = x0;
+        double ww = 0.0;
+        for (long x = x0; x < x1; x++) { double w = lanczos3(((double)x + 0.5 - center) / fscale); a->w[o * window + (size_t)(x - x0)] = w; ww += w; }
+        if (ww != 0.0) for (long x = x0; x < x1; x++) a->w[o * window + (size_t)(x - x0)] /= ww;
+        for (long x = x0; x < x1; x++) if (a->w[o * window + (size_t)(x - x0)] > wmax) wmax = a->w[o * window + (size_t)(x - x0)];
+        a->start[o] = x0; a->count[o] = x1 - x0;
+    }
+    if (fixed_bits != 0) {
+        int p = 0;
+        if (fixed_bits < 0) {  /* largest precision such that the biggest coefficient still fits an i32 */
+            for (int cur = 0; cur < 50; cur++) {
+                p = cur;
+                double next = floor(wmax * ldexp(1.0, cur + 1) + 0.5);
+                if (next >= 2147483647.0) break;
+            }
+        } else p = fixed_bits;
+        a->precision = p;
+        a->wi = (int64_t *)malloc(sizeof(int64_t) * window * out_size);
+        for (size_t i = 0; i < window * out_size; i++) {
+            double v = a->w[i] * ldexp(1.0, p);
+            a->wi[i] = (int64_t)(v < 0 ? -floor(-v + 0.5) : floor(v + 0.5));  /* f64::round: half away from zero */
+        }
+    }
+}
+
+static uint16_t axis_apply(const orc_axis *a, size_t o, const uint16_t *src, size_t stride, long base) {
+    const long x0 = a->start[o], n = a->count[o];
+    if (a->wi) {
+        int64_t ss = a->precision > 0 ? ((int64_t)1 << (a->precision - 1)) : 0;
+        for (long k = 0; k < n; k++) ss += (int64_t)src[(size_t)(x0 - base + k) * stride] * a->wi[o * a->window + (size_t)k];
+        ss >>= a->precision;
+        return (uint16_t)(ss < 0 ? 0 : ss > 65535 ? 65535 : ss);
+    }
+    double acc = 0.0;
+    for (long k = 0; k < n; k++) acc += a->w[o * a->window + (size_t)k] * (double)src[(size_t)(x0 - base + k) * stride];
+    double v = floor(acc + 0.5); if (v < 0) v = 0; if (v > 65535) v = 65535;
+    return (uint16_t)v;
+}
+
+/* mode 0: f64 taps normalised before the sum (one division per tap instead of one per pixel: differs from
+ * resize_lanczos3_u16 by f64 rounding only);  mode 1 / 2: fixed point, see above */
+ORC_API void orc_resize_crop_u16(const uint16_t *img, size_t Hh, size_t W, double left, double top, double cw, double ch,
+                                 size_t dw, size_t dh, int mode, uint16_t *dst) {
+    const int bits = mode == 0 ? 0 : mode == 1 ? -1 : 16;
+    orc_axis ax, ay;
+    axis_build(W, left, cw, dw, bits, &ax);
+    axis_build(Hh, top, ch, dh, bits, &ay);
+    long y_lo = dh ? ay.start[0] : 0, y_hi = dh ? ay.start[dh - 1] + ay.count[dh - 1] : 0;
+    for (size_t o = 0; o < dh; o++) { if (ay.start[o] < y_lo) y_lo = ay.start[o]; if (ay.start[o] + ay.count[o] > y_hi) y_hi = ay.start[o] + ay.count[o]; }
+    size_t nrows = (size_t)(y_hi - y_lo);
+    uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * (nrows ? nrows : 1) * (dw ? dw : 1));
+    for (size_t r = 0; r < nrows; r++)
+        for (size_t ox = 0; ox < dw; ox++) tmp[r * dw + ox] = axis_apply(&ax, ox, img + ((size_t)y_lo + r) * W, 1, 0);
+    for (size_t oy = 0; oy < dh; oy++)
+        for (size_t ox = 0; ox < dw; ox++) dst[oy * dw + ox] = axis_apply(&ay, oy, tmp + ox, dw, y_lo);
+    free(tmp); axis_free(&ax); axis_free(&ay);
+}
+
+/* The whole image as the crop box (what a pre-built mip level is): lod_h x lod_w, row 0 = lowest frequency.
+ * mode -1: the very function the tile encoder uses (resize_lanczos3_u16); 0/1/2 as orc_resize_crop_u16. */
+ORC_API void orc_resize_whole_image(const uint16_t *img, size_t Hh, size_t W, uint32_t level_x, uint32_t level_y,
+                                    int mode, uint16_t *dst) {
+    orc_tile_geom g;
+    orc_spectrogram_tile_geom(W, Hh, level_x, level_y, 0, 0, &g);
+    if (mode < 0) resize_lanczos3_u16(img, W, Hh, 0.0, 0.0, (double)W, (double)Hh, g.lod_w, g.lod_h, dst);
+    else orc_resize_crop_u16(img, Hh, W, 0.0, 0.0, (double)W, (double)Hh, g.lod_w, g.lod_h, mode, dst);
+}
+
+/* The LOD pixels of one tile before the row flip and the colour map (render_tiles.rs:330-338), resampled with
+ * the given mode (-1: resize_lanczos3_u16, as orc_encode_spectrogram_tile).  Returns width * height. */
+ORC_API size_t orc_spectrogram_tile_u16(const uint16_t *img, size_t Hh, size_t W, uint32_t level_x, uint32_t level_y,
+                                        uint32_t tile_x, uint32_t tile_y, int mode, uint16_t *dst, orc_tile_geom *geom) {
+    orc_tile_geom g;
+    orc_spectrogram_tile_geom(W, Hh, level_x, level_y, tile_x, tile_y, &g);
+    if (geom) *geom = g;
+    size_t w = g.width, h = g.height;
+    if (w == 0 || h == 0) return 0;
+    double left = (double)g.origin_x * (double)W / (double)g.lod_w;
+    double top = (double)g.origin_y * (double)Hh / (double)g.lod_h;
+    double right = (double)(g.origin_x + w) * (double)W / (double)g.lod_w;
+    double bottom = (double)(g.origin_y + h) * (double)Hh / (double)g.lod_h;
+    if (mode < 0) resize_lanczos3_u16(img, W, Hh, left, top, right - left, bottom - top, w, h, dst);
+    else orc_resize_crop_u16(img, Hh, W, left, top, right - left, bottom - top, w, h, mode, dst);
+    return w * h;
+}
+
 /* img: Hh x W u16 (row 0 = lowest frequency).  colormap: n_colors*4 RGBA bytes.
  * Returns bytes written (40 + w*h*4); out must hold 40 + 520*520*4. */
 ORC_API size_t orc_encode_spectrogram_tile(const uint16_t *img, size_t Hh, size_t W,

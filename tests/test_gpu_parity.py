@@ -561,8 +561,11 @@ def test_lod_mip_pyramid(ctx):
     """every channel's image gets a mip pyramid (the whole image resized per level with the separable
     Lanczos3 of render_tiles.rs:354-393) and LOD > 0 tiles are crops of it.  (a) Where a level is a single tile, crop box
     = whole image, so the pyramid level is byte-identical to the restated per-request resize.  (b) On a multi-tile image
-    the pyramid tiles equal the per-request tiles inside the 512-pixel core up to one u16 step in rare pixels (f64
-    rounding of the tap centres); the 4-pixel gutter differs by design (filter clipped at the image, not at the crop).
+    the pyramid tiles equal the per-request tiles — WHOLE tiles, core and 4-pixel gutters: the filter is clipped at the
+    image on both routes (render_tiles.rs:382-386 passes a crop box, not a sub-image), so a LOD pixel has one value
+    whichever tile asks for it (tests/test_oracle_lod.py) — up to one u16 step in rare pixels (f64 rounding of the tap
+    centres: origin + (o + 0.5)·scale against (o + 0.5)·scale).  (c) Every pyramid level is byte-identical to the oracle's
+    whole-image resize, and within the sensitivity bound of its fixed-point variant.
     PARITY UNPINNED against fast_image_resize 6.0.0 in both modes."""
     ident = _identity_colormap()
     tm = ta.TrackManager(ctx)
@@ -593,9 +596,13 @@ def test_lod_mip_pyramid(ctx):
         b, _ = _tile_u16(tm.get_spectrogram_tile(2, 0, lx, ly, tx, ty))
         assert b.tobytes() == _tile_u16(orc.encode_spectrogram_tile(img2, ident, s_rev, lx, ly, tx, ty))[0].tobytes()
         assert a.shape == b.shape and a.size > 0
-        core = (slice(4, a.shape[0] - 4), slice(4, a.shape[1] - 4))
-        d = np.abs(a[core] - b[core])
+        d = np.abs(a - b)  # whole tiles: core AND gutters
         worst, n_diff, n_px = max(worst, int(d.max())), n_diff + int((d > 0).sum()), n_px + d.size
+        # (c) the level itself == the oracle's whole-image resize, bit for bit (same taps, same order, same roundings)
+        assert np.array_equal(mip, orc.resize_whole_image(img2, lx, ly)), (lx, ly)
+        fx = orc.resize_whole_image(img2, lx, ly, orc.RESIZE_FIXED_MAX).astype(np.int64)
+        dfx = np.abs(mip.astype(np.int64) - fx)
+        assert dfx.max() <= 1 and (dfx > 0).mean() <= 2e-4, (lx, ly, dfx.max(), (dfx > 0).mean())
     assert worst <= 1 and n_diff <= 1e-3 * n_px, (worst, n_diff, n_px)
     tm.close()
 
