@@ -163,6 +163,40 @@ def test_multi_frame_wave_kernel(ctx, win, hop, n_fft, which):
     ref.close()
 
 
+@pytest.mark.parametrize("win,hop", [(512, 130), (512, 126), (504, 126), (440, 110), (512, 128), (320, 80)])
+def test_multi_frame_staged_loads_at_the_channel_end(ctx, win, hop):
+    """the staged loads of the four-frames-per-wave plan (n_fft 512, even hop) fetch 16-byte groups and clamp a
+    group's start to N - 4; with hop % 4 == 2 the last two samples of a frame can sit in a group of their own, which starts
+    at N - 2 or N - 3 when the frame's span ends at N or N - 1 — the clamped group then landed shifted in LDS and the frame
+    got s[N-4], s[N-3] where s[N-2], s[N-1] belong (the host now keeps such frames out of the interior set,
+    stft_wave_multi_tail_guard).  The window is ~1e-4 there, so the signal is ZERO except for its last eight samples: the
+    frames that see them consist of nothing else and a misplaced sample is an O(1) error of the frame.  Lengths put the end
+    of the last interior span at N, N - 1, N - 2, N - 3 for frames at every group offset of an iteration."""
+    n_fft = 512
+    lead = win // 2 + (n_fft - win) // 2
+    lens = [f * hop - lead + n_fft + d for f in (41, 42, 43, 44, 45, 46, 47, 48) for d in (0, 1, 2, 3)]
+    rng = np.random.default_rng(win * 1000 + hop)
+    wavs = []
+    for n in lens:
+        x = np.zeros(n, np.float32)
+        x[-8:] = rng.uniform(0.3, 1.0, 8) * rng.choice([-1.0, 1.0], 8)
+        wavs.append(x)
+    plan = ta.Plan(ctx, 8000, win, hop, n_fft, ta.LINEAR)
+    assert plan.kernel_name == "stft_wave_kernel"
+    a, mma = plan.calc_spec_batch(wavs)
+    for i, x in enumerate(wavs):
+        want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+        assert_spec_close(a[i], want, amp)
+        assert mma[i, 0] == a[i].min() and mma[i, 1] == a[i].max()
+    # the same framing on a dense signal (every frame non-trivial), lengths around the same ends
+    dense = [synth_track(300 + i, 8000, n) for i, n in enumerate(lens[:8])]
+    b, _ = plan.calc_spec_batch(dense)
+    for i, x in enumerate(dense):
+        want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+        assert_spec_close(b[i], want, amp)
+    plan.close()
+
+
 @pytest.mark.parametrize("n", [2, 3, 5, 100, 511, 1023, 1024, 1025, 2047])
 def test_calc_spec_short_inputs(ctx, n):
     """N < win (stft.rs:50-76): reflect padding cycles; frame count follows the same formula."""

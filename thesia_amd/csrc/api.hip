@@ -666,7 +666,10 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
                                ? th::stft_wave_phased_mode(g, p->wave_waves) : 0;
     const bool phased = phase_mode != 0;
     g.phased = (uint32_t)phase_mode;
-    auto interior = [&g, phased, phase_mode](const th_chan_desc &d, uint64_t T, uint64_t &fa, uint64_t &fb) {
+    // (multi-frame kernel with staged loads and hop % 4 == 2: see stft_wave_multi_tail_guard)
+    const uint64_t tail_guard = (wave && !phased && th::stft_wave_multi_applies(g, mel_mfma ? 1 : (mel_fused ? 2 : 0)) && g.log2_nc == 8)
+                                    ? th::stft_wave_multi_tail_guard(g) : 0;
+    auto interior = [&g, phased, phase_mode, tail_guard](const th_chan_desc &d, uint64_t T, uint64_t &fa, uint64_t &fb) {
         if (phased) {
             const int64_t N = (int64_t)d.n_samples, half = (int64_t)(g.win / 2);
             auto delta = [&](int64_t f) { return (((f * (int64_t)g.hop - half) % 128) + 128) % 128; };
@@ -678,7 +681,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
             fb = (uint64_t)b;
             return;
         }
-        const uint64_t lead = g.win / 2 + g.pad_left, N = d.n_samples;
+        const uint64_t lead = g.win / 2 + g.pad_left, N = d.n_samples > tail_guard ? d.n_samples - tail_guard : 0;
         fa = (lead + g.hop - 1) / g.hop;                                  // first f with e0 >= 0
         fb = N + lead >= g.n_fft ? (N + lead - g.n_fft) / g.hop + 1 : 0;  // one past the last f with e0 + n_fft <= N
         fa = std::min<uint64_t>(fa, T);

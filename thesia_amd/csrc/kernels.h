@@ -27,6 +27,7 @@ bool stft_wave_supported(const StftGeom &g);
 bool stft_is_block_plan(const StftGeom &g);
 // the multi-frame kernel (two / four frames per wave) takes this launch: n_fft 512 or 1024, dB output, no grid-aligned mode
 bool stft_wave_multi_applies(const StftGeom &g, int out_mode);
+uint32_t stft_wave_multi_tail_guard(const StftGeom &g);  // samples an interior span must stay clear of the channel's end
 int stft_wave_default_waves(const StftGeom &g);
 // d_minmax of launch_stft_wave is a per-CHUNK (min, max) array (2 floats per tile).  launch_wave_post follows every wave
 // launch: per channel it folds the chunk pairs of the channel's tiles [t0, t1) into the channel slot (store = the slot

@@ -1296,6 +1296,16 @@ bool stft_wave_multi_applies(const StftGeom &g, int out_mode) {
     return g.phased == 0 && ((out_mode == 0 && (g.log2_nc == 8 || g.log2_nc == 9)) || (out_mode == 1 && g.log2_nc == 8));
 }
 
+// Staged loads of the multi-frame kernel (launch_wave_multi_t: n_fft 512, even hop, span within 1280 samples) fetch 16-byte
+// groups from the iteration's first sample on and clamp a group's start to n_samples - 4.  A group that holds needed samples
+// must therefore start at or below n_samples - 4: with hop % 4 == 2 a frame's last two samples sit in a group of their own
+// (offset 510 of a frame that starts 2 mod 4 into the grid), so its span has to end 2 samples before the channel does.
+// The host keeps frames that end later out of the interior set (they run as boundary frames); 0 for every other plan.
+uint32_t stft_wave_multi_tail_guard(const StftGeom &g) {
+    const bool staged = g.log2_nc == 8 && g.hop % 2u == 0 && 3u * g.hop + g.n_fft <= 1280u;
+    return staged && g.hop % 4u != 0 ? 2u : 0u;
+}
+
 // Waves per workgroup (one persistent workgroup per CU).  Bounded by LDS (tables + one slab per
 // wave <= 160 KB) and by the VGPR file (64*WAVES threads => 512/(WAVES/4) VGPRs per lane).
 #if !defined(TH_RES12)
