@@ -414,12 +414,16 @@ TH_API int th_tm_tile_cache(th_tm *tm, th_tile_cache **out);
  * to ceil(W / 2^lx) x ceil(H / 2^ly) with the separable Lanczos3 — and a LOD tile is a crop of that level + colour
  * LUT, like a level-0 tile.  per_request = 1: the reference's own flow, the tile's crop box is
  * resampled from the level-0 image on every request (also used for levels the pyramid does not hold: images
- * smaller than 16 px at that level).  The two differ in the 4-pixel gutter (a per-request resize clips the filter at
- * the crop box, the pyramid at the image) and, rarely, by one u16 step elsewhere (f64 rounding of the tap centres).
- * PARITY UNPINNED against fast_image_resize in both modes. */
+ * smaller than 16 px at that level); the pyramids are then not kept at all (and come back with per_request = 0).  The
+ * two routes agree on whole tiles, core and gutter — both clip the filter at the image, never at the crop box — up to one
+ * u16 step in rare pixels (f64 rounding of the tap centres).  PARITY UNPINNED against fast_image_resize in both modes. */
 TH_API int th_tm_set_lod_source(th_tm *tm, int per_request);
 /* shape of (and, with out != NULL, a dense copy of) one resident mip level; (0, 0) is the image itself */
 TH_API int th_tm_mip_level(th_tm *tm, size_t id, uint32_t ch, uint32_t level_x, uint32_t level_y, uint16_t *out,
                            size_t capacity_px, size_t *width, size_t *height);
+/* device memory the manager holds besides audio, specs and images (accounting / leak checks): the Lanczos tap tables of
+ * the pyramid passes (one per (axis length, level) some resident image needs; dropped with the last such image) and the
+ * mip pyramids.  Any out pointer may be NULL. */
+TH_API int th_tm_lod_footprint(th_tm *tm, size_t *n_axis_tables, size_t *axis_table_bytes, size_t *mip_bytes);
 
 #endif /* THESIA_AMD_H */

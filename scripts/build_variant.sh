@@ -21,5 +21,5 @@ for f in api.hip track_manager.hip kernels_stft.hip kernels_mel.hip kernels_imag
     objs="$objs build/$f.o"
   fi
 done
-mkdir -p ../../scripts/variants && hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scripts/variants/libthesia_amd_$tag.so $objs
-echo built scripts/variants/libthesia_amd_$tag.so
+out=${VARIANT_DIR:-../../scripts/variants}; mkdir -p $out && hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libthesia_amd_$tag.so $objs
+echo built $out/libthesia_amd_$tag.so

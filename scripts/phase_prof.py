@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development tool: per-phase shader-clock breakdown of the wave STFT kernel's frame loop.
-Build the instrumented variant first:  scripts/build_variant.sh prof -DTH_PHASE_PROF
+Build the instrumented variant first:  patch -p1 < scripts/patches/instrumentation_phase_prof_wave_times.patch; scripts/build_variant.sh prof -DTH_PHASE_PROF; patch -R -p1 < (same)
 run:  THESIA_AMD_LIB=scripts/variants/libthesia_amd_prof.so python scripts/phase_prof.py [--nfft 2048]"""
 import argparse
 import ctypes

@@ -4,7 +4,7 @@ out=gpurun_out/r02_ablate.txt
 mkdir -p gpurun_out
 : > $out
 for v in "" nostore smallwav nomem noex1 noex2 nodft nolog nocomp nocompmem; do
-  lib=thesia_amd/libthesia_amd${v:+_$v}.so
+  lib=scripts/variants/libthesia_amd_$v.so; [ -z "$v" ] && lib=thesia_amd/libthesia_amd.so
   [ -f $lib ] || { echo "missing $lib" >> $out; continue; }
   echo "== variant '${v:-base}'" >> $out
   THESIA_AMD_LIB=$lib timeout 300 python scripts/bench_stft.py --reps 30 2>&1 | tail -1 >> $out

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development tool: when does every wave of the wave STFT kernel start its frame loop and when does it finish?
-Build the instrumented variant first:  scripts/build_variant.sh wt -DTH_WAVE_TIMES
+Build the instrumented variant first:  patch -p1 < scripts/patches/instrumentation_phase_prof_wave_times.patch; scripts/build_variant.sh wt -DTH_WAVE_TIMES; patch -R -p1 < (same)
 run:  THESIA_AMD_LIB=scripts/variants/libthesia_amd_wt.so python scripts/wave_times.py [--nfft 2048]"""
 import argparse
 import ctypes

@@ -641,6 +641,71 @@ def test_lod_mip_pyramid(ctx):
     tm.close()
 
 
+def test_lod_tables_follow_the_resident_images(ctx):
+    """(a) the Lanczos tap tables of the pyramid passes are keyed by (axis length, level) — the x axis length is a
+    track's frame count — and used to outlive their images: a session that adds and removes tracks grew device memory
+    without bound.  They are now dropped with the last image that needs them.  (b) With the per-request route selected
+    (set_lod_source(1)) no pyramid is kept; switching back rebuilds it, and the tiles are the same bytes as before."""
+    ident = _identity_colormap()
+    tm = ta.TrackManager(ctx)
+    tm.set_setting(40.0, 4, 1, ta.MEL)
+    tm.set_colormap(ident)
+    assert tm.lod_footprint() == {"axis_tables": 0, "axis_table_bytes": 0, "mip_bytes": 0}
+    seen = []
+    for k, n in enumerate([48000 * 9, 48000 * 7 + 123, 48000 * 11 + 77]):  # three different frame counts
+        tm.add_tracks([(k, 48000, synth_track(60 + k, 48000, n)[None])])
+        tm.apply_track_list_changes()
+        seen.append(tm.lod_footprint())
+        tm.remove_track(k)
+        tm.apply_track_list_changes()
+        assert tm.lod_footprint() == {"axis_tables": 0, "axis_table_bytes": 0, "mip_bytes": 0}, k
+    assert all(f["axis_tables"] > 0 and f["mip_bytes"] > 0 for f in seen)
+    # two tracks of one shape share their tables; removing one keeps them, removing both drops them
+    x = synth_track(70, 48000, 48000 * 8)
+    tm.add_tracks([(10, 48000, x[None]), (11, 48000, x[None] * 0.5)])
+    tm.apply_track_list_changes()
+    both = tm.lod_footprint()
+    tm.remove_track(10)
+    tm.apply_track_list_changes()
+    one = tm.lod_footprint()
+    assert one["axis_tables"] == both["axis_tables"] and one["mip_bytes"] * 2 == both["mip_bytes"]
+    # (b)
+    want = [tm.get_spectrogram_tile(11, 0, lx, ly, 0, 0) for lx, ly in [(1, 0), (2, 1)]]
+    tm.set_lod_source(per_request=True)
+    assert tm.lod_footprint() == {"axis_tables": 0, "axis_table_bytes": 0, "mip_bytes": 0}
+    per_req = [tm.get_spectrogram_tile(11, 0, lx, ly, 0, 0) for lx, ly in [(1, 0), (2, 1)]]
+    tm.set_dB_range(80.0)  # images re-made while the per-request route is selected: still no pyramid
+    assert tm.lod_footprint()["mip_bytes"] == 0
+    tm.set_dB_range(100.0)
+    tm.set_lod_source(per_request=False)
+    assert tm.lod_footprint() == one
+    assert [tm.get_spectrogram_tile(11, 0, lx, ly, 0, 0) for lx, ly in [(1, 0), (2, 1)]] == want
+    for a, b in zip(want, per_req):  # (one tile covers these levels: crop box = whole image, the two routes are byte-identical)
+        assert a == b
+    tm.close()
+
+
+def test_set_kernel_rejects_launch_shapes_that_do_not_exist(ctx):
+    """th_plan_set_kernel took waves-per-workgroup values the multi-frame kernel is not instantiated for and the
+    launch then failed with a bare HIP error; it now refuses them up front with TH_ERR_UNSUPPORTED and a message."""
+    plan = ta.Plan(ctx, 8000, 320, 80, 512, ta.LINEAR)
+    for wv in (4, 6, 7, 10, 14):
+        with pytest.raises(ta.ThError) as e:
+            plan.set_kernel(2 | (wv << 8))
+        assert e.value.code == -2 and "8, 12 or 16" in str(e.value)
+    x = synth_track(80, 8000, 8000 * 20)
+    want = orc.calc_spec(x, 320, 80, 512)
+    for wv in (0, 8, 12, 16):
+        plan.set_kernel(2 | (wv << 8))
+        assert_spec_close(plan.calc_spec(x)[0], want)
+    plan.close()
+    plan = ta.Plan(ctx, 48000, 1024, 256, 1024, ta.LINEAR)
+    plan.set_kernel(2 | (10 << 8))  # the one-frame plan of n_fft 1024 has this shape ...
+    with pytest.raises(ta.ThError):
+        plan.set_kernel(6 | (10 << 8))  # ... its two-frames-per-wave plan (selector 6) does not
+    plan.close()
+
+
 def test_lod_mip_pyramid_long_track(ctx):
     """The upper levels of a long track's pyramid (hundreds to thousands of Lanczos taps per output): the batched pass then
     runs with 4, 2 or 1 output rows per thread (what fits the LDS tap table) instead of 8 — same tiles as the per-request

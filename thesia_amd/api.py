@@ -586,6 +586,12 @@ class TrackManager:
                                   C.byref(h)))
         return out
 
+    def lod_footprint(self) -> dict:
+        """device memory of the LOD machinery: tap tables (count, bytes) and mip pyramids (bytes)"""
+        n, ab, mb = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        check(lib.th_tm_lod_footprint(self.handle, C.byref(n), C.byref(ab), C.byref(mb)))
+        return {"axis_tables": n.value, "axis_table_bytes": ab.value, "mip_bytes": mb.value}
+
     def render_metadata(self, track_id: int, ch: int, track_sec: float, is_clipped: bool) -> dict:
         """AudioRenderMetadata of get_audio_render_metadata (lib.rs:321-340)."""
         m = _ffi.RenderMetadata()

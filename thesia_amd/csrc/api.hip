@@ -615,6 +615,11 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     TH_REQUIRE(k >= 0 && k <= 6, "kernel selector must be 0 .. 6");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
+    // the multi-frame plans (n_fft 512; n_fft 1024 under selector 6) are instantiated for 8, 12 and 16 waves only
+    const bool multi = p->g.n_mel == 0 ? (p->g.log2_nc == 8 || (p->g.log2_nc == 9 && k == 6)) : p->g.log2_nc == 8;
+    if (multi && !(wv == 0 || wv == 8 || wv == 12 || wv == 16))
+        return fail(TH_ERR_UNSUPPORTED, "the multi-frame wave kernel of n_fft %u runs with 8, 12 or 16 waves per workgroup, not %d",
+                    p->g.n_fft, wv);
     p->kernel_choice = k;
     p->wave_waves = wv;
     p->wave_chunk = (which >> 16) & 0xff;  // tuning: frames per chunk of the wave kernel (0 = default)

@@ -32,7 +32,8 @@ int stft_wave_default_waves(const StftGeom &g);
 // d_minmax of launch_stft_wave is a per-CHUNK (min, max) array (2 floats per tile).  launch_wave_post follows every wave
 // launch: per channel it folds the chunk pairs of the channel's tiles [t0, t1) into the channel slot (store = the slot
 // needs no initialisation: every frame of the channel was in the wave launch) and rewinds the queue (d_queue_head[0],
-// zero before the first launch; the kernel counts from 0 behind its statically assigned first two rounds of chunks).
+// zero before the first launch; the kernel counts from 0 behind its statically assigned first round of chunks: a wave's
+// first chunk is its own index, TH_SCHED_ADVANCE adds the grid's wave count to what it pulls).
 struct WavePostJob {
     uint32_t t0, t1, mm_index, reserved;
 };
@@ -54,7 +55,7 @@ uint32_t stft_wave_mel_max_pieces(const StftGeom &g);
 bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words);
 // waves: waves per workgroup (4, 8, 12 or 16; <= 0 selects the default for this n_fft)
 // d_tile_start: HERE the per-chunk table, 2 words per chunk: (job, first frame) — not the jobs' first chunks as in
-// launch_stft_generic; chunks 0 .. 2 W - 1 are statically assigned (W = waves of the grid), the queue serves the rest
+// launch_stft_generic; chunks 0 .. W - 1 are statically assigned (W = waves of the grid), the queue serves the rest
 hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                             uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
                             uint32_t *d_queue_head, uint32_t n_cu, int waves, const WaveOut &out, hipStream_t s);

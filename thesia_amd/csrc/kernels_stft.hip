@@ -180,43 +180,8 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
 // ------------------------------------------------------------------------------------------
 #define TH_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 
-// Development instrumentation (variant builds with -DTH_PHASE_PROF only, scripts/phase_prof.py): per-phase
-// shader-clock totals of the wave kernel's frame loop, summed over all waves.
-#if defined(TH_PHASE_PROF)
-__device__ unsigned long long th_phase_prof_dev[16];
-#define TH_PROF_DECL()                                                                               \
-    unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; \
-    const unsigned long long prof_rt0 = wall_clock64(), prof_c0 = prof_t
-#define TH_PROF_MARK(i)                                              \
-    do {                                                             \
-        const unsigned long long t_ = __builtin_readcyclecounter();  \
-        prof_acc[i] += t_ - prof_t;                                  \
-        prof_t = t_;                                                 \
-    } while (0)
-#define TH_PROF_FLUSH(lane)                                                              \
-    do {                                                                                 \
-        if ((lane) == 0) {                                                               \
-            for (int i_ = 0; i_ < 9; i_++) atomicAdd(&th_phase_prof_dev[i_], prof_acc[i_]); \
-            atomicAdd(&th_phase_prof_dev[9], wall_clock64() - prof_rt0);   /* 100 MHz */   \
-            atomicAdd(&th_phase_prof_dev[10], __builtin_readcyclecounter() - prof_c0);      \
-        }                                                                                \
-    } while (0)
-#else
-#define TH_PROF_DECL() ((void)0)
-#define TH_PROF_MARK(i) ((void)0)
-#define TH_PROF_FLUSH(lane) ((void)0)
-#endif
-// Development instrumentation (variant builds with -DTH_WAVE_TIMES only, scripts/wave_times.py): per wave of the last
-// launch the 100 MHz wall clock at kernel entry, at the first frame and at exit, and the number of frames it took.
-#if defined(TH_WAVE_TIMES)
-__device__ unsigned long long th_wave_times_dev[6 * 256 * 16];
-#define TH_WT_STORE(slot, v)                                                                                 \
-    do {                                                                                                     \
-        if (lane == 0) th_wave_times_dev[6 * (blockIdx.x * WAVES + wave) + (slot)] = (v);                    \
-    } while (0)
-#else
-#define TH_WT_STORE(slot, v) ((void)0)
-#endif
+// (Development instrumentation — per-phase shader-clock totals, per-wave wall-clock stamps — is not part of this file: apply
+// scripts/patches/instrumentation_phase_prof_wave_times.patch and build a variant, see scripts/phase_prof.py / wave_times.py.)
 
 // Orders this wave's LDS writes before its later LDS reads (and vice versa) for the compiler; the
 // hardware already executes one wave's DS instructions in order, so no instruction is needed.
@@ -328,13 +293,6 @@ constexpr uint32_t MEL_PRF_1024 = 512;  // pieces of the per-wave (r, f) buffer 
 // registers.  All state is passed as separate by-reference scalars / arrays: the body is always inlined and
 // everything must stay in registers (a by-reference closure or struct here puts x[] into scratch memory).
 // Advances cur to the next frame and returns true when that frame continues the same chunk.
-#if defined(TH_PHASE_PROF)
-#define TH_PROF_PARAMS , unsigned long long &prof_t, unsigned long long (&prof_acc)[9]
-#define TH_PROF_ARGS , prof_t, prof_acc
-#else
-#define TH_PROF_PARAMS
-#define TH_PROF_ARGS
-#endif
 // RES: which per-lane constant tables the caller keeps resident in registers instead of re-reading them from
 // LDS every frame (bit 0 window, 1 pass-2 twiddles, 2 pass-3 twiddles, 3 split twiddles; 2 and 3 only on the
 // mirror-local path).  Worth it when fewer waves per SIMD leave the VGPRs: LDS is a co-bottleneck of this kernel.
@@ -351,11 +309,10 @@ __device__ __forceinline__ void wave_frame(
     const cf32 (&rwa)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::NT3],
     const cf32 (&rwb)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::NT3],
     const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], cf32 rw_mid, float &lmin, float &lmax,
-    const uint32_t *meltab, cf32 *mel_prf, const WaveOut &wo TH_PROF_PARAMS) {
+    const uint32_t *meltab, cf32 *mel_prf, const WaveOut &wo) {
     constexpr bool AMP = OUT == 1, MELF = OUT == 2;
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
-    TH_PROF_MARK(8);
     // Per-frame opaque copy of the lane id.  Everything below addresses LDS and the output row as
     // "f(lane) + immediate"; left loop-invariant, LICM hoists ~40 such addresses out of the frame loop
     // and the register allocator spills them.  Recomputing the handful of bases per frame is cheaper.
@@ -421,15 +378,12 @@ __device__ __forceinline__ void wave_frame(
         }
     }
     TH_SCHED_BARRIER();
-    TH_PROF_MARK(0);
     if constexpr (!(RES & 2)) W::load_t2(lane, w2, t2);  // lands during the pass-1 arithmetic
     W::pass1(lane, z, slab);
     wave_lds_sync();
     TH_SCHED_BARRIER();
-    TH_PROF_MARK(1);
     W::read1(lane, z, slab);
     wave_lds_sync();
-    TH_PROF_MARK(2);
 
     const gptr<float> row = spec + (size_t)f * spec_pitch;
     if constexpr (W::PAIRED) {
@@ -438,7 +392,6 @@ __device__ __forceinline__ void wave_frame(
         else W::pass2_w(lane, z, w2, slab);
         wave_lds_sync();
         TH_SCHED_BARRIER();
-        TH_PROF_MARK(3);
         cf32 wa[W::NQ][W::NT3], wb[W::NQ][W::NT3];
         const typename W::PairBase pbs = W::pair_base(lane);  // the lane's butterfly pairs as base + immediate (once per frame)
         if constexpr (!(RES & 4)) W::load_t3_paired(pbs, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
@@ -449,11 +402,9 @@ __device__ __forceinline__ void wave_frame(
         cf32 ws[W::NQ][W::R3];
         if constexpr (PRELOAD_STW && !(RES & 8)) W::load_stw_paired(lane, ws, stw);
         TH_SCHED_BARRIER();
-        TH_PROF_MARK(4);
         if constexpr (RES & 4) W::pass3_paired_w(za, zb, rwa, rwb);
         else W::pass3_paired_w(za, zb, wa, wb);
         TH_SCHED_BARRIER();
-        TH_PROF_MARK(5);
         if constexpr (!PRELOAD_STW && !(RES & 8)) W::load_stw_paired(lane, ws, stw);
         float *const slab_f = reinterpret_cast<float *>(slab);
         // bin kb + kc: per-lane base (opaque, split_base) + compile-time constant.  The global address is formed as
@@ -534,7 +485,6 @@ __device__ __forceinline__ void wave_frame(
         if (lane - 1u < ((pad < 32u && spec_pitch % 32u == 0) ? pad : 0u)) row[height - 1u + lane] = 0.0f;
     }
     TH_SCHED_BARRIER();
-    TH_PROF_MARK(6);
 }
 
 // SHIFT = hop/128 register slots reused between consecutive frames (0 = no reuse: hop not a
@@ -581,7 +531,6 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // wave index is wave-uniform: tell the compiler, so the frame cursor lives in SGPRs / SALU
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    TH_WT_STORE(0, wall_clock64());
     // The wave's first chunk is known from its index alone: look it up and request its first frame before anything else,
     // so that the samples travel while the workgroup fills its LDS tables (a single-track launch is one or two frames per
     // wave: its run time is this start-up).
@@ -598,14 +547,6 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         }                                                                                                                  \
     } while (0)
     TH_FETCH_FIRST();
-#if defined(TH_WAVE_TIMES)
-    {
-        uint32_t hw_id, xcc_id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-        TH_WT_STORE(4, ((unsigned long long)xcc_id << 32) | hw_id);
-    }
-#endif
     // n_fft 4096: the window pairs are stored in the order the lanes read them (lane l reads the pair of column
     // lane_col(l) = (l >> 3) + 8 (l & 7): consecutive lanes would be 64 bytes apart, a 2-way bank conflict on all 32 reads)
     constexpr bool WPERM = W::PLANES32 || (W::PLANES8 && !PHASED && !DYN);  // (n_fft 1024: the same column order)
@@ -628,7 +569,6 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         mel_prf = reinterpret_cast<cf32 *>(meltab + ((wo.mel_words + 1u) & ~1u)) + (size_t)wave * MEL_PRF_1024;
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
     const uint32_t lane_wave = lane;
-    TH_PROF_DECL();
     // Register rotation instead of register moves: with hop = SHIFT slots, frame f+1 is frame f moved down by
     // SHIFT slots.  Rather than moving P - SHIFT complex registers per frame, the frame body is instantiated
     // NROT = P/SHIFT times; instance ROT reads logical slot m from physical x[(m + ROT*SHIFT) % P] and loads
@@ -644,7 +584,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #define TH_FRAME(ROT)                                                                                                  \
     wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : DYN ? -2 : -1>(      \
         g, wtab + (PHASED ? WPAD - ((96 * (ROT)) & 127) / 2 : 0), stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
-        lmax, meltab, mel_prf, wo TH_PROF_ARGS)
+        lmax, meltab, mel_prf, wo)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
     cf32 rw[(RESK & 1) ? P : 1], rw2[(RESK & 2) ? W::NT2 : 1];
     cf32 rwa[(RESK & 4) ? W::NQ : 1][W::NT3], rwb[(RESK & 4) ? W::NQ : 1][W::NT3], rws[(RESK & 8) ? W::NQ : 1][W::R3];
@@ -663,22 +603,10 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         rw_mid = tw[NC / 2];
     }
     // chunk loop: one queue pull and one full fetch per chunk of up to frames_per_tile consecutive frames
-    TH_WT_STORE(1, wall_clock64());
-#if defined(TH_WAVE_TIMES)
-    unsigned long long wt_frames = 0, wt_start = 0, wt_chunks = 0;
-#endif
-#if defined(TH_WAVE_TIMES)
-    unsigned long long wt_pull0 = wall_clock64();
-#endif
     while (sch.cur.valid) {
         const FrameCursor &cur = sch.cur;
         lmin = __builtin_inff();
         lmax = -__builtin_inff();
-#if defined(TH_WAVE_TIMES)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (instrumented build only: chunk-start time up to the arrival of the first frame)
-        wt_start += wall_clock64() - wt_pull0;
-        wt_chunks++;
-#endif
         uint32_t f = cur.f;
         // frame loop (steady state: branch-free register flow, see wave_frame)
         // (The instruction arbiter serves the oldest wave of a SIMD first, and strictly: of the three waves of a SIMD the
@@ -722,24 +650,13 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
                 minmax[2 * (size_t)cur.t + 1] = b;
             }
         }
-#if defined(TH_WAVE_TIMES)
-        wt_frames += cur.f1 - cur.f;
-#endif
-#if defined(TH_WAVE_TIMES)
-        wt_pull0 = wall_clock64();
-#endif
         TH_SCHED_ADVANCE(sch, lane);
         TH_FETCH_FIRST();  // the next chunk's first frame
     }
 #undef TH_FETCH_FIRST
-    TH_WT_STORE(2, wall_clock64());
-#if defined(TH_WAVE_TIMES)
-    TH_WT_STORE(3, wt_frames | (wt_chunks << 16) | (wt_start << 32));
-#endif
 #undef TH_FRAME
 #undef TH_BODY_SHIFT
 #undef TH_BODY_OFF
-    TH_PROF_FLUSH(lane_wave);
 }
 
 
@@ -1140,25 +1057,6 @@ static hipError_t launch_block(const StftGeom &g, const ChanJob *d_jobs, const u
     return launch_block_t<LOG2_NC, AMP, false>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
 }
 
-#if defined(TH_WAVE_TIMES)
-}  // namespace th
-extern "C" __attribute__((visibility("default"))) int th_debug_wave_times(unsigned long long *out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(th::th_wave_times_dev), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-namespace th {
-#endif
-#if defined(TH_PHASE_PROF)
-}  // namespace th
-extern "C" __attribute__((visibility("default"))) int th_debug_phase_prof(unsigned long long *out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(th::th_phase_prof_dev), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(th::th_phase_prof_dev), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-namespace th {
-#endif
 
 // ------------------------------------------------------------------------------------------
 // launchers

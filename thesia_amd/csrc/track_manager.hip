@@ -71,6 +71,7 @@ struct AxisTable {
     void *d_blob = nullptr;
     uint32_t n_out = 0, max_taps = 0;
     uint32_t span[3] = {0, 0, 0};  // LodAxis::span
+    size_t bytes = 0;
 };
 
 struct Track {
@@ -296,6 +297,7 @@ int axis_table(th_tm *tm, uint32_t n_in, uint32_t level, AxisTable **out) {
         }
         t.n_out = (uint32_t)n_out;
         t.max_taps = ax.max_taps;
+        t.bytes = blob.size();
         for (int k = 0; k < 3; k++) {  // source rows under the tap windows of R = 8, 4, 2 consecutive outputs
             const size_t r = (size_t)8 >> k;
             int64_t span = 0;
@@ -325,12 +327,38 @@ LodAxis axis_view(const AxisTable &t) {
     return a;
 }
 
+// Tap tables are keyed by (axis length, level); the x-axis length is a track's frame count, i.e. different for practically
+// every track.  Drop the tables no resident image refers to (they survived remove_track / set_setting, ~48 W bytes
+// per level each, so a long session that adds and removes tracks grew device memory without bound).  hipFree waits for the
+// device, so a table still read by a launched pass is safe.
+void prune_axis_tabs(th_tm *tm) {
+    std::set<std::pair<uint32_t, uint32_t>> live;
+    for (auto &kv : tm->tracks)
+        for (Channel &ch : kv.second.ch)
+            for (auto &m : ch.mips) {
+                if (m.first.first) live.insert({(uint32_t)ch.img_w, m.first.first});
+                if (m.first.second) live.insert({(uint32_t)ch.img_h, m.first.second});
+            }
+    for (auto it = tm->axis_tabs.begin(); it != tm->axis_tabs.end();) {
+        if (live.count(it->first)) {
+            ++it;
+        } else {
+            (void)hipFree(it->second.d_blob);
+            it = tm->axis_tabs.erase(it);
+        }
+    }
+}
+
 // Build every (lx, ly) level of the images of `chans`: horizontal pass from level 0 for each lx, vertical pass from
 // (lx, 0) for each ly — the same order and the same one-rounding-per-pass as the per-request resize.  Images of one shape
 // go through every pass together (grid z = image): a launch per level, not per level and channel (32 tracks: ~1000 launches
 // of a few microseconds of work each took 27 ms of the 28 ms an apply_track_list_changes spent behind the STFT).
 int build_mips(th_tm *tm, const std::vector<Channel *> &chans) {
     hipStream_t s = tm->ctx->stream;
+    if (tm->lod_source == 1) {  // per-request route selected: no pyramid is kept (2.75x the image memory, and the passes)
+        for (Channel *ch : chans) free_mips(*ch);
+        return TH_OK;
+    }
     struct Shape {
         uint32_t w, h, pitch;
         bool operator<(const Shape &o) const { return std::tie(w, h, pitch) < std::tie(o.w, o.h, o.pitch); }
@@ -538,9 +566,17 @@ int update_spec_imgs(th_tm *tm, bool force_update_all, std::vector<size_t> *upda
         }
     }
     int rc = th_spec_to_img_batch_dev(tm->ctx, descs.data(), descs.size(), tm->min_dB, tm->max_dB, tm->colormap_length);
-    if (rc != TH_OK) return rc;
     // the LOD mip pyramid of every image that was just re-made (render_tiles.rs:290-313,354-393)
-    return build_mips(tm, made);
+    if (rc == TH_OK) rc = build_mips(tm, made);
+    if (rc != TH_OK) {
+        // Not failure-atomic otherwise: the images above are already re-quantised, so a pyramid that was only
+        // partly rebuilt would serve pixels of the old dB range under the new revision.  Without levels every LOD request
+        // falls back to the per-request resize of the (new) level-0 image.
+        (void)hipStreamSynchronize(tm->ctx->stream);
+        for (Channel *ch : made) free_mips(*ch);
+    }
+    prune_axis_tabs(tm);
+    return rc;
 }
 
 Channel *find_channel(th_tm *tm, size_t id, uint32_t ch) {
@@ -821,6 +857,7 @@ TH_API int th_tm_remove_track(th_tm *tm, size_t id) {
     TH_HIP(hipStreamSynchronize(tm->ctx->stream));
     for (Channel &ch : it->second.ch) free_channel(ch);
     tm->tracks.erase(it);
+    prune_axis_tabs(tm);
     retain_plans(tm);      // core/mod.rs:96-99
     tm->invalidate_all();  // lib.rs:221
     return TH_OK;
@@ -926,8 +963,21 @@ TH_API int th_tm_set_lod_source(th_tm *tm, int per_request) {
     TH_TRY
     TH_REQUIRE(tm, "tm is NULL");
     std::unique_lock<std::shared_mutex> wl(tm->rw);
-    tm->lod_source = per_request ? 1 : 0;
-    return TH_OK;
+    const int want = per_request ? 1 : 0;
+    if (want == tm->lod_source) return TH_OK;
+    TH_HIP(hipSetDevice(tm->ctx->device));
+    tm->lod_source = want;
+    std::vector<Channel *> have;
+    for (auto &kv : tm->tracks)
+        for (Channel &ch : kv.second.ch)
+            if (ch.d_img) have.push_back(&ch);
+    // 1: the pyramids go (build_mips frees them); 0: every resident image gets its levels back
+    TH_HIP(hipStreamSynchronize(tm->ctx->stream));
+    int rc = build_mips(tm, have);
+    if (rc != TH_OK)
+        for (Channel *ch : have) free_mips(*ch);
+    prune_axis_tabs(tm);
+    return writer_done(tm, rc);
     TH_CATCH
 }
 
@@ -1083,6 +1133,21 @@ TH_API int th_tm_tile_cache(th_tm *tm, th_tile_cache **out) {
 }
 
 // device pointer + shape of one level of a channel's LOD mip pyramid ((0, 0) = the image itself): parity tests
+TH_API int th_tm_lod_footprint(th_tm *tm, size_t *n_axis_tables, size_t *axis_table_bytes, size_t *mip_bytes) {
+    TH_TRY
+    TH_REQUIRE(tm, "tm is NULL");
+    std::shared_lock<std::shared_mutex> rl(tm->rw);
+    size_t ab = 0, mb = 0;
+    for (auto &kv : tm->axis_tabs) ab += kv.second.bytes;
+    for (auto &kv : tm->tracks)
+        for (Channel &ch : kv.second.ch) mb += ch.mips_elems * sizeof(uint16_t);
+    if (n_axis_tables) *n_axis_tables = tm->axis_tabs.size();
+    if (axis_table_bytes) *axis_table_bytes = ab;
+    if (mip_bytes) *mip_bytes = mb;
+    return TH_OK;
+    TH_CATCH
+}
+
 TH_API int th_tm_mip_level(th_tm *tm, size_t id, uint32_t ch, uint32_t level_x, uint32_t level_y, uint16_t *out, size_t cap,
                            size_t *width, size_t *height) {
     TH_TRY

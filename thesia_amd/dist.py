@@ -75,16 +75,21 @@ def gather_tensor_to_root(local, dist, root: int = 0, group=None):
     gets a list of world tensors (its own entry is `local` itself), the others get None.  Sizes go first (one 1-element
     all-gather), then one point-to-point transfer per peer, all posted at once (batch_isend_irecv): on xGMI the root's
     seven inbound links run concurrently instead of a ring that would be bound by one link (core/mod.rs:169-180 is the
-    path's only coupling; this gather is the viewer-side collection of the results, outside the timed step)."""
+    path's only coupling; this gather is the viewer-side collection of the results, outside the timed step).
+    `root` and the returned list are indexed by rank IN `group` (the default group: global ranks); P2POp takes global
+    ranks, so peers are translated (with a sub-group whose ranks are not 0..n-1 the untranslated peer hung)."""
     import torch
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def peer(r):  # group rank -> global rank
+        return r if group is None else dist.get_global_rank(group, r)
     flat = local.contiguous().view(-1)
     n_local = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)
     if rank != root:
         if flat.numel():
-            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, root, group)]):
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, peer(root), group)]):
                 req.wait()
         return None
     out, ops = [None] * world, []
@@ -95,7 +100,7 @@ def gather_tensor_to_root(local, dist, root: int = 0, group=None):
             continue
         out[r] = torch.empty(n, dtype=flat.dtype, device=flat.device)
         if n:
-            ops.append(dist.P2POp(dist.irecv, out[r], r, group))
+            ops.append(dist.P2POp(dist.irecv, out[r], peer(r), group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
