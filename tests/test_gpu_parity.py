@@ -183,12 +183,17 @@ def test_multi_frame_staged_loads_at_the_channel_end(ctx, win, hop):
         wavs.append(x)
     plan = ta.Plan(ctx, 8000, win, hop, n_fft, ta.LINEAR)
     assert plan.kernel_name == "stft_wave_kernel"
-    a, mma = plan.calc_spec_batch(wavs)
-    for i, x in enumerate(wavs):
-        want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
-        assert_spec_close(a[i], want, amp)
-        assert mma[i, 0] == a[i].min() and mma[i, 1] == a[i].max()
+    # A batch this small gets one-frame chunks (every frame is then the first of its iteration and the tail group is never
+    # the shifted one); chunks of 8 and 5 frames put the last interior frames at every group offset, as long batches do.
+    for chunk in (8, 5, 0):
+        plan.set_kernel(2 | (chunk << 16))
+        a, mma = plan.calc_spec_batch(wavs)
+        for i, x in enumerate(wavs):
+            want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+            assert_spec_close(a[i], want, amp)
+            assert mma[i, 0] == a[i].min() and mma[i, 1] == a[i].max()
     # the same framing on a dense signal (every frame non-trivial), lengths around the same ends
+    plan.set_kernel(2 | (8 << 16))
     dense = [synth_track(300 + i, 8000, n) for i, n in enumerate(lens[:8])]
     b, _ = plan.calc_spec_batch(dense)
     for i, x in enumerate(dense):
