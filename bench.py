@@ -35,6 +35,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32)
+
+
+def dist_of(ms):
+    """min / median / p90 / max of a series of launch durations (ms)"""
+    a = np.sort(np.asarray(ms, dtype=np.float64))
+    if a.size == 0:
+        return None
+    return {"n": int(a.size), "min": float(a[0]), "median": float(np.median(a)), "p90": float(a[min(a.size - 1, int(np.ceil(0.9 * a.size)) - 1)]),
+            "max": float(a[-1]), "mean": float(a.mean())}
+
+
+def memory_skeleton():
+    """The STFT kernel's memory skeleton, timed on this box in this run (scripts/ubench/stft_skeleton.hip, built by
+    __graft_entry__.build()): the same persistent waves, chunk queue, hop loads a frame ahead and row stores as
+    stft_wave_kernel on the same workload shape, with NO arithmetic — what the memory system gives this access structure —
+    and with the kernel's amount of stand-in VALU / LDS work.  A child process (its own 2.3 GB of buffers)."""
+    import subprocess
+    exe = os.path.join(ROOT, "scripts", "ubench", "stft_skeleton")
+    if not os.path.exists(exe):
+        return {"error": "scripts/ubench/stft_skeleton not built"}
+    out = {"source": "scripts/ubench/stft_skeleton.hip (mode 7), child process, HIP events, median of 20 launches"}
+    for key, gap in (("gaps_1ms", "1000"), ("back_to_back", "0")):
+        try:
+            r = subprocess.run([exe, gap, "7"], capture_output=True, text=True, timeout=120)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            out[key] = {"no_work_ms": j["runs"][0]["median_ms"], "no_work_min_ms": j["runs"][0]["min_ms"],
+                        "with_kernel_amount_of_work_ms": j["runs"][1]["median_ms"]}
+        except Exception as e:  # report, do not fail the bench line
+            out[key] = {"error": str(e)[:200]}
+    return out
 
 
 def parse_args():
@@ -44,7 +75,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tracks-per-gpu", type=int, default=128)
     ap.add_argument("--seconds", type=float, default=30.0)
+    ap.add_argument("--spin-up-steps", type=int, default=64, help="untimed steps before the warm-up steps (clock settling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-skeleton", action="store_true", help="skip the memory-skeleton child process (roofline.memory_skeleton)")
     ap.add_argument("--no-single-track", action="store_true", help="skip the extras (single track, other framings, tile latency, ...)")
     ap.add_argument("--no-full-cfg5", action="store_true", help="skip the strong-scaling anchor (all 1024 tracks of config 5 on one GPU)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 wave")
@@ -372,6 +405,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Spin-up (untimed, before the W warm-up steps, reported as `spin_up_steps`): a GPU that sat idle while the host built
+    # the descriptor tables needs ~30-40 ms of sustained load before its power management has settled the clocks — round 2's
+    # driver run (5 warm-up steps = 7 ms) timed exactly that transient: the STFT launch went 0.64 -> 0.48 ms monotonically
+    # over its 20 timed steps (`roofline.launch_ms_series` shows the series of THIS run).  The timed region is untouched:
+    # still exactly K steps between two barriers.
+    for _ in range(args.spin_up_steps):
+        wl.step(dist)
     for _ in range(args.warmup):
         wl.step(dist)
     barrier()
@@ -387,14 +427,18 @@ def main():
         dt = float(tt.item())
     # HIP events on the launch stream, inside the timed region: per-kernel average launch durations
     stft_stage_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in wl.ev]))  # init + STFT kernel + boundary-frame kernel
-    stft_ms = float(np.mean(wl.plan.kernel_ms_history()[-args.steps:]))         # the dominant kernel launch alone
+    stft_series = [float(v) for v in wl.plan.kernel_ms_history()[-args.steps:]]
+    stft_ms = float(np.mean(stft_series))                                        # the dominant kernel launch alone
     quant_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in wl.ev]))
     rast_ms = float(np.mean([e[3].elapsed_time(e[4]) for e in wl.ev]))
 
     # stage-only rates: STFT->dB stage and quantise+raster stage, HIP events
-    def time_stage(fn, reps=10):
-        fn()
-        torch.cuda.synchronize(dev)
+    def time_stage(fn, reps=10, spin_ms=40.0):
+        t_sp = time.perf_counter()  # (same settling as the headline: the case before this one left the GPU idle for a while)
+        while (time.perf_counter() - t_sp) * 1e3 < spin_ms:
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize(dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -407,9 +451,14 @@ def main():
     img_ms = time_stage(lambda: (ctx.spec_to_img_batch_ranged(wl.imgd, wl.range_db.data_ptr(), 258),
                                  ctx.raster_tiles(wl.rast, wl.cmap.data_ptr(), wl.n_colors)))
 
+    # The extras below (other configs and framings, latency, end to end ...) describe ONE GPU: they run at N = 1 only.  At
+    # N > 1 rank 0 reports the timed step and the tile gather and every rank leaves right behind them (round 2 ran the
+    # extras on rank 0 while the other ranks sat in the final barrier, stretching the N = 8 wall time by seconds).
+    extras = rank == 0 and world == 1 and not args.no_single_track
+
     # waveform side of the path: every decimation level of every channel, one pass over the audio
     wave = None
-    if rank == 0 and not args.no_single_track:
+    if extras:
         from thesia_amd import _ffi
         n_lv = 13
         tot = ta.api.pyramid_offset(n, n_lv)
@@ -424,23 +473,42 @@ def main():
                 "frac": (smp * 4 + wl.n_tracks * tot * 4) / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del pyr
 
-    # The other BASELINE configs' STFT stages on this GPU, same definition as `roofline` (algorithmic bytes of SURVEY 8(d) /
-    # HIP-event duration): config 3 (64 stereo 48 kHz tracks = 128 channels, n_fft 4096 / hop 1024) and config 4 (32 tracks
-    # 44.1 kHz, n_fft 2048 / hop 512, 128 mels, filterbank fused into the FFT kernel); plus the app's own default framing
-    # (40 ms window / 4 at 48 kHz = 1920 / 480 / 2048, linear: grid-aligned register reuse).
+    # The other BASELINE configs' STFT stages on this GPU AT THEIR BASELINE.md §3 SIZES, same definition as `roofline`
+    # (algorithmic bytes of SURVEY 8(d) / HIP-event duration of the dominant kernel inside the config's own whole step):
+    # config 3 (64 stereo 48 kHz tracks x 60 s = 128 channels, n_fft 4096 / hop 1024), config 4 (32 tracks 44.1 kHz x 60 s,
+    # n_fft 2048 / hop 512, 128 mels: fused epilogue, and the matrix-core path with its fp32-MFMA fraction) and config 1's
+    # shape (n_fft 1024 / hop 256: the single 2 113 529-sample track, and the 128-track batch for the roofline);
+    # `other_framings`: the framings the UI reaches at its 40 ms default (t_overlap 1 .. 32 -> tracks.ts:207) and the
+    # short / long transforms, 128 channels x 30 s each, 20 launches back to back.
     other, roof_cfg = None, []
-    if rank == 0 and not args.no_single_track:
+    if extras:
         other = []
-        wav44 = synth_on_gpu(torch, dev, list(range(2000, 2032)), 44100, int(round(args.seconds * 44100)))
-        cases = (("cfg3: 64 stereo 48 kHz tracks, n_fft 4096 / hop 1024, linear dB", wl.wav, 48000, (4096, 1024, 4096, ta.LINEAR, 0)),
-                 ("cfg4: 32 tracks 44.1 kHz, n_fft 2048 / hop 512, mel-128 dB", wav44, 44100, (2048, 512, 2048, ta.MEL, 128)),
-                 ("app default framing: 48 kHz, 1920 / 480 / 2048, linear dB", wl.wav, 48000, (1920, 480, 2048, ta.LINEAR, 0)),
-                 ("short transform: n_fft 512 / hop 128, linear dB (four frames per wave)", wl.wav, 48000, (512, 128, 512, ta.LINEAR, 0)),
-                 ("long transform: n_fft 8192 / hop 2048, linear dB (one workgroup per frame)", wl.wav, 48000, (8192, 2048, 8192, ta.LINEAR, 0)),
-                 ("long transform: n_fft 16384 / hop 4096, linear dB (one workgroup per frame)", wl.wav, 48000, (16384, 4096, 16384, ta.LINEAR, 0)))
-        for label, wav_, sr_, (w_, h_, nf_, scale, n_mel) in cases:
+        sec60 = 2.0 * args.seconds if args.seconds == 30.0 else 60.0
+        wav60 = synth_on_gpu(torch, dev, list(range(3000, 3000 + 128)), 48000, int(round(sec60 * 48000)))   # 64 stereo tracks: two seeds each
+        wav44 = synth_on_gpu(torch, dev, list(range(2000, 2032)), 44100, int(round(sec60 * 44100)))
+        wav_c1 = synth_on_gpu(torch, dev, [4000], 48000, 2113529)  # stand-in for samples/sample_48k.wav (audio.rs:506-508: shape [1, 2113529])
+        cases = (("cfg3: 64 stereo 48 kHz tracks x 60 s, n_fft 4096 / hop 1024, linear dB", wav60, 48000, (4096, 1024, 4096, ta.LINEAR, 0), 0),
+                 ("cfg4: 32 tracks 44.1 kHz x 60 s, n_fft 2048 / hop 512, mel-128 dB (filterbank fused into the FFT kernel)", wav44, 44100, (2048, 512, 2048, ta.MEL, 128), 0),
+                 ("cfg4 on the matrix cores: same, FFT kernel -> amplitude rows -> mel_mfma_kernel (v_mfma_f32_16x16x4_f32)", wav44, 44100, (2048, 512, 2048, ta.MEL, 128), 3),
+                 ("cfg1 shape, one track: 48 kHz mono 2113529 samples, n_fft 1024 / hop 256, linear dB", wav_c1, 48000, (1024, 256, 1024, ta.LINEAR, 0), 0),
+                 ("cfg1 shape, batch: n_fft 1024 / hop 256, linear dB", wl.wav, 48000, (1024, 256, 1024, ta.LINEAR, 0), 0),
+                 ("app default framing (40 ms, t_overlap 4): 48 kHz, 1920 / 480 / 2048, linear dB", wl.wav, 48000, (1920, 480, 2048, ta.LINEAR, 0), 0),
+                 ("app default, mel scale (the app's own default: 347 mels)", wl.wav, 48000, (1920, 480, 2048, ta.MEL, 0), 0),
+                 ("40 ms, t_overlap 2: 1920 / 960 / 2048, linear dB", wl.wav, 48000, (1920, 960, 2048, ta.LINEAR, 0), 0),
+                 ("40 ms, t_overlap 8: 1920 / 240 / 2048, linear dB", wl.wav, 48000, (1920, 240, 2048, ta.LINEAR, 0), 0),
+                 ("40 ms, t_overlap 16: 1920 / 120 / 2048, linear dB", wl.wav, 48000, (1920, 120, 2048, ta.LINEAR, 0), 0),
+                 ("44.1 kHz default: 1764 / 441 / 2048, linear dB", wav44, 44100, (1764, 441, 2048, ta.LINEAR, 0), 0),
+                 ("96 kHz default shape: 3840 / 960 / 4096, linear dB", wl.wav, 96000, (3840, 960, 4096, ta.LINEAR, 0), 0),
+                 ("short transform: n_fft 512 / hop 128, linear dB (four frames per wave)", wl.wav, 48000, (512, 128, 512, ta.LINEAR, 0), 0),
+                 ("8 kHz default shape: 320 / 80 / 512, linear dB", wl.wav, 8000, (320, 80, 512, ta.LINEAR, 0), 0),
+                 ("long transform: n_fft 8192 / hop 2048, linear dB (one workgroup per frame)", wl.wav, 48000, (8192, 2048, 8192, ta.LINEAR, 0), 0),
+                 ("long transform: n_fft 16384 / hop 4096, linear dB (one workgroup per frame)", wl.wav, 48000, (16384, 4096, 16384, ta.LINEAR, 0), 0),
+                 ("very long transform: n_fft 32768 / hop 8192, linear dB (400 ms window at 48 kHz)", wl.wav, 48000, (32768, 8192, 32768, ta.LINEAR, 0), 0))
+        for label, wav_, sr_, (w_, h_, nf_, scale, n_mel), sel in cases:
             try:
                 pl = ta.Plan(ctx, sr_, w_, h_, nf_, scale, n_mel)
+                if sel:
+                    pl.set_kernel(sel)
                 n_ = wav_.shape[1]
                 T_, H_ = pl.n_frames(n_), pl.height
                 sp_ = ta.pitch_f32(H_)
@@ -457,15 +525,31 @@ def main():
                      "stage_ms": ms_, "avg_launch_ms": k_ms, "frames_per_s": frames_ / (ms_ * 1e-3), "bound": "hbm",
                      "algorithmic_bytes_per_frame": bpf, "achieved": frames_ * bpf / (k_ms * 1e-3) / 1e9, "unit": "GB/s"}
                 e["frac"] = e["achieved"] / HBM_PEAK_GBS
-                if label.startswith("cfg"):
+                if sel == 3:
+                    # the whole two-kernel stage is what this path costs (the event pair only brackets the FFT kernel); the
+                    # contraction itself: algorithmic flops = 2 per non-zero filterbank weight per frame (the triangles hold
+                    # <= 2 non-zeros per frequency bin), against the dense fp32 MFMA peak
+                    fb = ta.calc_mel_fb(sr_, nf_, H_)
+                    nnz = int(np.count_nonzero(fb))
+                    mel_ms = max(ms_ - k_ms, 1e-6)
+                    e.update({"bound": "mfma", "mel_mfma_kernel_ms": mel_ms, "filterbank_nonzeros": nnz,
+                              "algorithmic_flops_per_frame": 2 * nnz, "dense_flops_per_frame": 2 * fb.size,
+                              "mfma_frac": frames_ * 2 * nnz / (mel_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                              "mfma_frac_dense_equivalent": frames_ * 2 * fb.size / (mel_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                              "peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
+                              "achieved": frames_ * bpf / (ms_ * 1e-3) / 1e9, "avg_launch_ms": ms_})
+                    e["frac"] = e["achieved"] / HBM_PEAK_GBS
+                elif label.startswith("cfg") and wav_.shape[0] > 1:
                     # the BASELINE configs also the way the headline is measured: the kernel's average launch inside this
                     # config's own whole step (STFT -> range -> u16 image -> level-0 RGBA), not 20 launches back to back
                     # (under the power cap what runs next to a kernel decides its clock: `back_to_back_*` keeps the other)
                     wcfg = Workload(torch, ta, ctx, dev, list(range(wav_.shape[0])), sr_, n_, w_, h_, nf_, 0, cmap_bytes,
                                     base=type("B", (), {"wav": wav_, "n_tracks": wav_.shape[0]})(), scale=scale, n_mel=n_mel)
-                    for _ in range(3):
-                        wcfg.step(None)
-                    torch.cuda.synchronize(dev)
+                    t_sp = time.perf_counter()
+                    while (time.perf_counter() - t_sp) * 1e3 < 40.0:
+                        for _ in range(3):
+                            wcfg.step(None)
+                        torch.cuda.synchronize(dev)
                     wcfg.plan.time_kernel(True)
                     t_ = time.perf_counter()
                     for _ in range(20):
@@ -475,18 +559,18 @@ def main():
                     k_in = float(np.mean(wcfg.plan.kernel_ms_history()[-20:]))
                     e.update({"back_to_back_avg_launch_ms": k_ms, "back_to_back_frac": e["frac"], "avg_launch_ms": k_in,
                               "achieved": frames_ * bpf / (k_in * 1e-3) / 1e9, "step_ms": step_ms,
-                              "step_frames_per_s": frames_ / (step_ms * 1e-3)})
+                              "step_frames_per_s": frames_ / (step_ms * 1e-3), "launch_ms": dist_of(wcfg.plan.kernel_ms_history()[-20:])})
                     e["frac"] = e["achieved"] / HBM_PEAK_GBS
                     del wcfg
                 (roof_cfg if label.startswith("cfg") else other).append(e)
                 pl.close()
                 del spec_
             except Exception as e:  # extras must not break the bench line
-                other.append({"workload": label, "error": str(e)[:200]})
-        del wav44
+                (roof_cfg if label.startswith("cfg") else other).append({"workload": label, "error": str(e)[:200]})
+        del wav44, wav60, wav_c1
 
     single = None
-    if rank == 0 and not args.no_single_track:
+    if extras:
         w1 = Workload(torch, ta, ctx, dev, [0], sr, 60 * sr, win, hop, n_fft, args.kernel, cmap_bytes)
         for _ in range(3):
             w1.step(None)
@@ -525,6 +609,9 @@ def main():
     gather = None
     if dist is not None:
         from thesia_amd import dist as tdist
+        # (one untimed gather first: the first point-to-point transfer between two ranks sets up their RCCL connection)
+        got = tdist.gather_tensor_to_root(wl.rgba.view(-1)[: 1 << 20], dist, root=0)
+        del got
         barrier()
         t0 = time.perf_counter()
         got = tdist.gather_tensor_to_root(wl.rgba.view(-1), dist, root=0)
@@ -540,7 +627,7 @@ def main():
     # ---- PCIe-inclusive end to end + the tile-request latency path, through the TrackManager (th_tm_*): host buffers in,
     # tiles out.  Never `value` (inputs start in host memory here).
     e2e = latency = None
-    if rank == 0 and not args.no_single_track:
+    if extras:
         try:
             e2e, latency = tm_end_to_end_and_latency(torch, ta, ctx, wl, sr, cmap_bytes)
         except Exception as e:  # extras must not break the bench line
@@ -548,11 +635,12 @@ def main():
 
     # ---- strong-scaling anchor: ALL of BASELINE config 5 (1024 tracks x 30 s) resident on this one GPU, same step
     full5 = None
-    if rank == 0 and world == 1 and not args.no_single_track and not args.no_full_cfg5 and args.tracks_per_gpu == 128:
+    if extras and not args.no_full_cfg5 and args.tracks_per_gpu == 128:
         try:
             t_s = time.perf_counter()
             del wl.rgba  # (rebuilt below at the larger size; the 128-track line above is complete)
-            w5 = Workload(torch, ta, ctx, dev, list(range(1024)), sr, n, win, hop, n_fft, args.kernel, cmap_bytes, base=wl)
+            # (1024 DISTINCT tracks, seeds 0x7E51A + 0 .. 1023 as BASELINE.md prescribes: all 5.9 GB of input are read)
+            w5 = Workload(torch, ta, ctx, dev, list(range(1024)), sr, n, win, hop, n_fft, args.kernel, cmap_bytes)
             for _ in range(2):
                 w5.step(None)
             torch.cuda.synchronize(dev)
@@ -562,10 +650,9 @@ def main():
                 w5.step(None)
             torch.cuda.synchronize(dev)
             d5 = (time.perf_counter() - t1) / reps5
-            full5 = {"workload": "cfg5 complete on ONE GPU: 1024 tracks x 30 s 48 kHz mono, n_fft=2048 hop=512, same step "
-                                 "(tracks 128.. reuse the audio of tracks 0..127: eight spec / image / tile sets per waveform)",
+            full5 = {"workload": "cfg5 complete on ONE GPU: 1024 distinct tracks x 30 s 48 kHz mono, n_fft=2048 hop=512, same step",
                      "frames": w5.frames, "ms_per_step": d5 * 1e3, "frames_per_s": w5.frames / d5,
-                     "resident_GB": (w5.spec.numel() * 4 + w5.img.numel() * 2 + w5.rgba.numel() + wl.wav.numel() * 4) / 1e9,
+                     "resident_GB": (w5.spec.numel() * 4 + w5.img.numel() * 2 + w5.rgba.numel() + w5.wav.numel() * 4) / 1e9,
                      "setup_s": time.perf_counter() - t_s}
             del w5
         except Exception as e:
@@ -608,10 +695,21 @@ def main():
             del a_, b_
         except Exception:
             copy_gbs = None
+        # the kernel's memory skeleton on this box, in this run (N = 1 only: a child process with its own buffers)
+        skeleton = None
+        if world == 1 and not args.no_skeleton:
+            skeleton = memory_skeleton()
+            try:
+                sk = skeleton["gaps_1ms"]["no_work_ms"]
+                skeleton["kernel_over_skeleton"] = stft_ms / sk
+                skeleton["kernel_median_over_skeleton"] = float(np.median(stft_series)) / sk
+                skeleton["frac_if_kernel_ran_at_skeleton"] = interior * bytes_per_frame / (sk * 1e-3) / 1e9 / HBM_PEAK_GBS
+            except Exception:
+                pass
         out = {
             "metric": "STFT frames/sec (whole step: STFT->dB->min/max->u16 image->level-0 RGBA raster), n_fft=2048",
             "value": total_frames * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "spin_up_steps": args.spin_up_steps, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg5 shard: {args.tracks_per_gpu} tracks/GPU x {args.seconds:g} s 48 kHz mono, "
                                    f"n_fft={n_fft} hop={hop} Hann, linear dB + u16 image + level-0 RGBA tiles",
@@ -622,7 +720,12 @@ def main():
             "stft_kernel": wl.plan.kernel_name,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": wl.plan.kernel_name, "avg_launch_ms": stft_ms, "stage_ms_incl_init_and_boundary_frames": stft_stage_ms,
+                         "kernel": wl.plan.kernel_name, "avg_launch_ms": stft_ms, "launch_ms": dist_of(stft_series),
+                         "launch_ms_series": [round(v, 4) for v in stft_series],
+                         "frac_at_median_launch": interior * bytes_per_frame / (float(np.median(stft_series)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_at_min_launch": interior * bytes_per_frame / (min(stft_series) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "memory_skeleton": skeleton,
+                         "stage_ms_incl_init_and_boundary_frames": stft_stage_ms,
                          "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": interior,
                          "read_only_frac": interior * 4 * hop / (stft_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "measured_copy_GBs": copy_gbs, "measured_copy_kernel": "th_dev_copy (16 B per lane, 1 GiB -> 1 GiB)",

@@ -264,6 +264,7 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_,
     }
 }
 
+static int g_json = 0;       // > 0: JSON output (mode 7), counts the entries printed
 static uint32_t g_grid = 0;  // 0: one workgroup per CU (persistent); else this many workgroups (argv[3])
 template <int LOADM, int STOREM, int FMA, int LDSR, int WAVES, int LDSM = 0>
 static void run(const char *name, const float *wav, float *spec, uint32_t n_chan, uint32_t n_samples, uint32_t T, uint32_t *q,
@@ -295,6 +296,11 @@ static void run(const char *name, const float *wav, float *spec, uint32_t n_chan
     const double med = ts[ts.size() / 2];
     const double frames = (double)n_chan * (T - 4);
     const double bytes = frames * ((LOADM ? 2048.0 : 0.0) + (STOREM ? 4100.0 : 0.0));
+    if (g_json) {
+        printf("%s{\"load\": %d, \"store\": %d, \"fma_per_frame\": %d, \"lds_rounds\": %d, \"waves\": %d, \"median_ms\": %.4f, \"min_ms\": %.4f, \"p90_ms\": %.4f}",
+               g_json++ > 1 ? ", " : "", LOADM, STOREM, FMA * 16, LDSR, WAVES, med, ts[0], ts[ts.size() * 9 / 10]);
+        return;
+    }
     printf("%-4s ldsm %d load %d store %d fma %4d ldsr %d waves %2d: median %.3f ms min %.3f  %.0f GB/s\n", name, LDSM, LOADM, STOREM, FMA * 16,
            LDSR, WAVES, med, ts[0], bytes / med / 1e6);
     fflush(stdout);
@@ -318,8 +324,18 @@ int main(int argc, char **argv) {
         }
         for (uint32_t c = 0; c < n_chan; c++) hipMemcpy(wav + (size_t)c * n_samples, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     }
-    printf("# gap between launches: %d us\n", gap_us);
 #define R(L, S, F, D, W, M) run<L, S, F, D, W, M>("", wav, spec, n_chan, n_samples, T, q, gap_us)
+    if (argc > 2 && atoi(argv[2]) == 7) {
+        // bench.py's `roofline.memory_skeleton`: one JSON line — the kernel's own access structure (load shape 3, store
+        // shape 1, 12 waves per CU) with no arithmetic, and with the kernel's amount of stand-in work
+        g_json = 1;
+        printf("{\"gap_us\": %d, \"workload\": \"128 channels x 1440000 samples, n_fft 2048 / hop 512, rows at pitch 1056\", \"runs\": [", gap_us);
+        R(3, 1, 0, 0, 12, 2);
+        R(3, 1, 42, 2, 12, 2);
+        printf("]}\n");
+        return 0;
+    }
+    printf("# gap between launches: %d us\n", gap_us);
     if (argc > 2 && atoi(argv[2]) == 1) {
         // store shapes next to the kernel's amount of VALU / LDS work: the kernel's pattern (1), 16 aligned dword stores
         // (2), four 16-byte stores (3; with a third LDS round standing for the transposition that would feed them),
