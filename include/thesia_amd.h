@@ -65,6 +65,8 @@ typedef enum {
 } th_status;
 
 /* FreqScale (src-common/src/lib.rs:105-109) */
+/* largest transform a plan takes (powers of two from 2 up to this): 2^20 samples = 5.5 s at 192 kHz */
+#define TH_MAX_N_FFT (1u << 20)
 #define TH_FREQ_LINEAR 0
 #define TH_FREQ_MEL 1
 
@@ -359,8 +361,9 @@ TH_API int th_tm_destroy(th_tm *tm);
 TH_API int th_tm_set_colormap(th_tm *tm, const uint8_t *rgba, size_t bytes);
 /* TrackManager::set_setting — core/mod.rs:107-115 (recomputes every resident track).  Transactional: when the new
  * setting cannot be planned (this library needs n_fft = next_pow2(win) * f_overlap to be a power of two in
- * [8, 16384]; the reference's realfft takes any even length, so e.g. f_overlap = 3 or 192 kHz with f_overlap = 4 are
- * valid there and TH_ERR_UNSUPPORTED here) or memory runs out, the call fails and the manager — settings, plans,
+ * [2, TH_MAX_N_FFT], which covers every window length the UI accepts; the reference's realfft takes any length, so
+ * f_overlap = 3, which no control offers, is valid there and TH_ERR_UNSUPPORTED here) or memory runs out, the call
+ * fails and the manager — settings, plans,
  * specs, images, revisions — is exactly as before.  th_tm_add_tracks gives the same guarantee. */
 TH_API int th_tm_set_setting(th_tm *tm, double win_ms, uint32_t t_overlap, uint32_t f_overlap, int freq_scale);
 /* TrackManager::set_dB_range — core/mod.rs:123-126 */

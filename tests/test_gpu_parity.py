@@ -54,9 +54,86 @@ def assert_spec_close(got_db, want_db, want_amp=None):
 
 
 # ---------------------------------------------------------------- STFT -> dB
+def test_stft_impulse_known_answer_verbatim(ctx):
+    """stft.rs:173-196 verbatim through calc_spec: impulse(4, @2), win = 4, hop = 2, n_fft = 4 -> 3 frames x 3 bins with
+    |X| = [[0,0,0],[1/4,1/4,1/4],[1/4,1/4,1/4]] (n_fft 4 is a real setting: 1 ms at 4 kHz; round 2 refused it)."""
+    x = np.zeros(4, np.float32)
+    x[2] = 1.0
+    plan = ta.Plan(ctx, 4000, 4, 2, 4, ta.LINEAR)
+    spec, mn, mx = plan.calc_spec(x)
+    assert spec.shape == (3, 3)
+    amp = np.where(np.isneginf(spec), 0.0, 10.0 ** (spec.astype(np.float64) / 20))
+    assert np.allclose(amp, [[0, 0, 0], [0.25, 0.25, 0.25], [0.25, 0.25, 0.25]], atol=1e-7)
+    assert np.all(np.isneginf(spec[0])) and mn == -np.inf and abs(mx - 20 * np.log10(0.25)) < 1e-4
+    assert_spec_close(spec, orc.calc_spec(x, 4, 2, 4))
+    plan.close()
+
+
+@pytest.mark.parametrize("win,hop,n_fft,n", [(2, 1, 2, 9), (2, 1, 2, 1000), (4, 1, 4, 1000), (3, 1, 4, 777), (4, 2, 4, 5),
+                                             (4, 4, 4, 4001), (2, 2, 4, 100)])
+def test_tiny_transforms(ctx, win, hop, n_fft, n):
+    """n_fft 2 and 4 (the smallest windows the UI's lower bound allows at low sample rates) on the generic kernel."""
+    x = synth_track(500 + n_fft + hop, 4000, n)
+    plan = ta.Plan(ctx, 4000, win, hop, n_fft, ta.LINEAR)
+    assert plan.kernel_name == "stft_generic_kernel"
+    spec, mn, mx = plan.calc_spec(x)
+    want = orc.calc_spec(x, win, hop, n_fft)
+    assert_spec_close(spec, want)
+    assert mn == spec.min() and mx == spec.max()
+    plan.close()
+
+
+@pytest.mark.parametrize("sr,win,hop,n_fft,scale,n_mel", [(48000, 19200, 4800, 32768, 0, 0), (48000, 32768, 8192, 32768, 0, 0),
+                                                          (192000, 19200, 9600, 32768, 0, 0), (96000, 38400, 9600, 65536, 0, 0),
+                                                          (48000, 32768, 8192, 32768, 1, 128), (48000, 19200, 4800, 32768, 1, 0)])
+def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
+    """n_fft 32768 / 65536 (400 ms at 48 kHz, 100 ms at 192 kHz: winMillisec has no upper bound, Control.tsx:96-107): the
+    generic kernel with its frame buffers in global scratch.  Ragged batch incl. a channel shorter than the window, oracle
+    on every channel, min / max = extrema of the stored rows.  (scale 1: mel, n_mel 0 = the reference's default count:
+    5571 mels at n_fft 32768 / 48 kHz.)"""
+    lens = [n_fft * 3 + 17, n_fft + hop * 2 + 1, n_fft // 3 + 5, 5 * hop]
+    wavs = [synth_track(600 + i, sr, n) for i, n in enumerate(lens)]
+    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, n_mel)
+    assert plan.kernel_name == "stft_generic_kernel"
+    fb = None
+    if scale:
+        fb = orc.calc_mel_fb(sr, n_fft, n_mel) if n_mel else orc.calc_mel_fb_default(sr, n_fft)
+        assert plan.height == fb.shape[1]
+    a, mma = plan.calc_spec_batch(wavs)
+    for i, x in enumerate(wavs):
+        want, amp = orc.calc_spec(x, win, hop, n_fft, mel_fb=fb, return_amp=True)
+        if fb is None:
+            assert_spec_close(a[i], want, amp)
+        else:
+            assert_spec_close(a[i], want)
+        assert mma[i, 0] == a[i].min() and mma[i, 1] == a[i].max()
+    plan.close()
+
+
+def test_transform_size_limits(ctx):
+    """powers of two from 2 to TH_MAX_N_FFT (2^20) are planned; everything else is TH_ERR_UNSUPPORTED, as is a mel plan whose
+    dense filterbank would not fit 1 GiB"""
+    for bad in (3, 6, 6144, 1 << 21):
+        with pytest.raises(ta.ThError) as e:
+            ta.Plan(ctx, 48000, min(bad, 2048), 512, bad, ta.LINEAR)
+        assert e.value.code == -2
+    with pytest.raises(ta.ThError) as e:
+        ta.Plan(ctx, 48000, 1 << 17, 1 << 15, 1 << 17, ta.MEL, 0)
+    assert e.value.code == -2 and "1 GiB" in str(e.value)
+    plan = ta.Plan(ctx, 48000, 1 << 20, 1 << 18, 1 << 20, ta.LINEAR)  # the largest: one frame of white noise, Parseval
+    x = np.random.default_rng(3).uniform(-1, 1, (1 << 20) + 5).astype(np.float32)
+    spec, _, _ = plan.calc_spec(x)
+    assert spec.shape == (5, (1 << 19) + 1)
+    w = ta.calc_normalized_win(1 << 20, 1 << 20).astype(np.float64)
+    frame = x[: 1 << 20].astype(np.float64) * w  # frame 2 starts at 2 hop - win / 2 = 0
+    p = 10.0 ** (spec[2].astype(np.float64) / 10)
+    parseval = (p[0] + p[-1] + 2 * p[1:-1].sum()) / (1 << 20)
+    assert abs(parseval / (frame ** 2).sum() - 1) < 1e-4
+    plan.close()
+
+
 def test_stft_impulse_known_answer(ctx):
-    """stft.rs:173-196 restated through calc_spec: |X| = [[0,0,0],[1/4,1/4,1/4],[1/4,1/4,1/4]].
-    n_fft=4 is below the library's minimum (8), so the same impulse is run at win=hop*2=8."""
+    """the same impulse at win = hop * 2 = 8"""
     x = np.zeros(8, np.float32)
     x[4] = 1.0
     plan = ta.Plan(ctx, 48000, 8, 4, 8, ta.LINEAR)
@@ -754,7 +831,7 @@ def test_track_manager_failed_setting_changes_nothing(ctx, golden_dir):
     tm.apply_track_list_changes()
     before = (tm.spec(7, 0).copy(), tm.img(7, 0).copy(), tm.db_state(), tm.revisions(), tm.get_spectrogram_tile(7, 0, 0, 0, 0, 0),
               tm.get_waveform_tile(7, 0, 3, 0))
-    for bad in [(40.0, 4, 3, ta.LINEAR), (40.0, 4, 16, ta.MEL)]:  # n_fft 6144; 32768 (> 16384)
+    for bad in [(40.0, 4, 3, ta.LINEAR), (40.0, 4, 5, ta.MEL)]:  # n_fft 6144, 10240: not powers of two
         with pytest.raises(ta.ThError) as e:
             tm.set_setting(*bad)
         assert e.value.code == -2, e.value

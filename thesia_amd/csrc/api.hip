@@ -410,6 +410,7 @@ static void plan_free(th_plan *p) {
     if (p->d_mel_lo) (void)hipFree(p->d_mel_lo);
     if (p->d_mel_hi) (void)hipFree(p->d_mel_hi);
     p->jobs.release();
+    p->gen_scratch.release();
     p->tile_start.release();
     p->edge_jobs.release();
     p->edge_tile_start.release();
@@ -425,8 +426,12 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
     TH_REQUIRE(win > 1 && hop >= 1 && win <= n_fft, "need 1 < win <= n_fft and hop >= 1 (win=%zu hop=%zu n_fft=%zu)",
                win, hop, n_fft);
     TH_REQUIRE(sr > 0, "sr must be > 0");
-    if (!is_pow2(n_fft) || n_fft < 8 || n_fft > 16384)
-        return fail(TH_ERR_UNSUPPORTED, "n_fft=%zu: only powers of two in [8, 16384] are supported", n_fft);
+    // Any power of two from 2 to 2^20: what SpecSetting::calc_framing_params (spectrogram.rs:56-98) yields for every window
+    // the UI accepts with f_overlap a power of two — winMillisec has a lower bound only (tracks.ts:205, Control.tsx:96-107),
+    // so e.g. 400 ms at 48 kHz is n_fft 32768 and 1 ms at 4 kHz is n_fft 4.  (The reference's realfft takes any length: a
+    // non-power-of-two n_fft needs f_overlap = 3, 5, ..., which no control offers.)
+    if (!is_pow2(n_fft) || n_fft < 2 || n_fft > TH_MAX_N_FFT)
+        return fail(TH_ERR_UNSUPPORTED, "n_fft=%zu: only powers of two in [2, %u] are supported", n_fft, (unsigned)TH_MAX_N_FFT);
     TH_HIP(hipSetDevice(c->device));
 
     th_plan *p = new th_plan();
@@ -496,6 +501,12 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
         if (n_mel == 0 || n_mel > 65535) {
             plan_free(p);
             return fail(TH_ERR_INVALID_ARG, "n_mel=%zu out of range", n_mel);
+        }
+        // the dense (F x n_mel) filterbank of calc_mel_fb (src-common/src/lib.rs:46-89) is what the generic kernel reads: at the
+        // default mel counts of very long windows it no longer fits anything (n_fft 131072 at 48 kHz: 65537 x ~22000 floats)
+        if ((double)(n_fft / 2 + 1) * (double)n_mel * sizeof(float) > (double)((size_t)1 << 30)) {
+            plan_free(p);
+            return fail(TH_ERR_UNSUPPORTED, "mel filterbank of %zu bins x %zu mels exceeds 1 GiB", n_fft / 2 + 1, n_mel);
         }
         g.n_mel = (uint32_t)n_mel;
         g.height = (uint32_t)n_mel;
@@ -855,6 +866,14 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         if (rc == TH_OK) rc = p->edge_tile_start.upload(c->stream, edge_start.data(), edge_start.size() * sizeof(uint32_t));
     }
     if (rc != TH_OK) return rc;
+    if (!wave) {  // n_fft >= 32768: the generic kernel's frame buffers live in global scratch
+        const size_t need = th::stft_generic_scratch_bytes(g, (uint32_t)tiles, c->n_cu);
+        if (need) {
+            if (need > p->gen_scratch.cap) TH_HIP(hipStreamSynchronize(c->stream));  // (a launch may still use the old buffer)
+            rc = p->gen_scratch.ensure(need);
+            if (rc != TH_OK) return rc;
+        }
+    }
     // (min, max) slots: when every frame of every channel is in the wave launch, its last workgroup initialises and fills
     // them (no init launch); otherwise initialise here and let every kernel add with atomics
     const bool all_in_wave = wave && !mel_mfma && edge.empty() && tiles > 0;
@@ -920,7 +939,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     } else {
         TH_HIP(launch_stft_generic(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                    (uint32_t)jobs.size(), (uint32_t)tiles, p->d_window, p->d_tw, p->d_mel_fb,
-                                   p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream));
+                                   p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream, p->gen_scratch.dptr, c->n_cu));
         if (timed) TH_HIP(hipEventRecord(p->ev_k1[slot], c->stream));
     }
     if (timed) p->timed_launches++;

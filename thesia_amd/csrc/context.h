@@ -87,6 +87,7 @@ struct th_plan {
     th::DeviceTable amp_buf, mel_jobs, mel_tile_start;  // amplitude scratch + job tables of mel_mfma_kernel
     size_t amp_zeroed = 0;                               // bytes of amp_buf known to be zero-initialised
     th::DeviceTable chunk_mm;                            // (min, max) per chunk of the wave kernel's last launch
+    th::DeviceTable gen_scratch;                         // n_fft >= 32768: frame buffers of the generic kernel (global scratch)
     th::DeviceTable post_jobs;                           // per-channel tile ranges for wave_post_kernel
     bool use_mel_mfma() const;   // mel plan: amplitude rows + mel_mfma_kernel
     bool use_mel_fused() const;  // mel plan: filterbank fused into the wave kernel's epilogue (mel_fuse.h)

@@ -16,10 +16,13 @@ hipError_t launch_minmax_init(float *d_minmax, uint32_t n_chan, hipStream_t s);
 // d_out = [min, -max] and / or d_range = [min_dB, max_dB] (core/mod.rs:179-180); either may be NULL
 hipError_t launch_minmax_reduce(const float *d_minmax, uint32_t n_chan, float *d_out, float dB_range, float *d_range, hipStream_t s);
 size_t stft_generic_lds_bytes(const StftGeom &g);
+// n_fft >= 32768: the generic kernel keeps its two frame buffers in global scratch (d_scratch, at least
+// stft_generic_scratch_bytes) instead of LDS and runs as a persistent grid; 0 bytes = the LDS variant, no scratch needed
+size_t stft_generic_scratch_bytes(const StftGeom &g, uint32_t n_tiles, uint32_t n_cu);
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                uint32_t n_chan, uint32_t n_tiles, const float *d_window, const cf32 *d_tw,
                                const float *d_mel_fb, const uint32_t *d_mel_lo, const uint32_t *d_mel_hi,
-                               float *d_minmax, hipStream_t s);
+                               float *d_minmax, hipStream_t s, void *d_scratch = nullptr, uint32_t n_cu = 256);
 
 bool stft_wave_supported(const StftGeom &g);
 // n_fft 8192 / 16384: launch_stft_wave runs the workgroup-per-frame kernel (stft_block.h): interior frames only, the

@@ -7,6 +7,7 @@
 // the windowed frames, the complex spectrum and the linear magnitudes never leave the CU.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "kernels.h"
@@ -68,26 +69,33 @@ __device__ __forceinline__ uint32_t find_chan(const uint32_t *__restrict__ tile_
 }
 
 // ------------------------------------------------------------------------------------------
-// Generic workgroup kernel: any power-of-two n_fft in [8, 16384].  256 threads work on one frame
-// at a time: LDS ping-pong Stockham radix-4 (+ one radix-2 pass when log2(Nc) is odd), split
-// pass, optional banded mel reduction, dB, coalesced row store.  Correctness-first fallback for
-// sizes the wave kernel does not cover.
+// Generic workgroup kernel: any power-of-two n_fft >= 2.  256 threads work on one frame at a time:
+// ping-pong Stockham radix-4 (+ one radix-2 pass when log2(Nc) is odd), split pass, optional banded
+// mel reduction, dB, coalesced row store.  Correctness-first fallback for sizes the wave kernel does
+// not cover.  SCRATCH = false (n_fft <= 16384): the two frame buffers live in LDS, one workgroup per
+// tile of frames.  SCRATCH = true (n_fft >= 32768: a 400 ms window at 48 kHz, 100 ms at 192 kHz —
+// winMillisec has no upper bound in the UI, Control.tsx:96-107 / tracks.ts:205): the buffers are two
+// n_fft/2-point regions of a global scratch area per workgroup (L2-resident: 256 KB at 32768) and a
+// persistent grid walks the tiles; __syncthreads orders the workgroup's global writes and reads.
 // ------------------------------------------------------------------------------------------
 constexpr int GEN_THREADS = 256;
 
+template <bool SCRATCH>
 __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
-    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan,
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan, uint32_t n_tiles,
     const float *__restrict__ window, const cf32 *__restrict__ tw, const float *__restrict__ mel_fb,
-    const uint32_t *__restrict__ mel_lo, const uint32_t *__restrict__ mel_hi, float *__restrict__ minmax) {
+    const uint32_t *__restrict__ mel_lo, const uint32_t *__restrict__ mel_hi, float *__restrict__ minmax,
+    cf32 *__restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf32 *bufA = reinterpret_cast<cf32 *>(smem_raw);
+    cf32 *bufA = SCRATCH ? scratch + (size_t)blockIdx.x * 2u * g.nc : reinterpret_cast<cf32 *>(smem_raw);
     cf32 *bufB = bufA + g.nc;
     __shared__ float red[2 * (GEN_THREADS / 64)];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t chan = find_chan(tile_start, n_chan, blockIdx.x);
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // (LDS variant: the grid is n_tiles, one trip)
+    const uint32_t chan = find_chan(tile_start, n_chan, tile);
     const ChanJob job = jobs[chan];
-    const uint32_t f0 = job.f_begin + (blockIdx.x - tile_start[chan]) * g.frames_per_tile;
+    const uint32_t f0 = job.f_begin + (tile - tile_start[chan]) * g.frames_per_tile;
     const uint32_t f1 = min(f0 + g.frames_per_tile, job.f_end);
 
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
@@ -153,7 +161,9 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
             atomic_min_f32(&minmax[2 * job.mm_index], a);
             atomic_max_f32(&minmax[2 * job.mm_index + 1], b);
         }
+        __syncthreads();  // (red[] is reused by the next tile of a persistent workgroup)
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1163,20 +1173,38 @@ hipError_t launch_wave_post(const WavePostJob *d_pj, uint32_t n_pj, const float 
 }
 
 size_t stft_generic_lds_bytes(const StftGeom &g) { return 2 * (size_t)g.nc * sizeof(cf32); }
+// n_fft > 16384: the frame buffers do not fit LDS; workgroups and bytes of global scratch the launch needs (0: LDS variant)
+uint32_t stft_generic_scratch_grid(const StftGeom &g, uint32_t n_tiles, uint32_t n_cu) {
+    if (stft_generic_lds_bytes(g) <= 128 * 1024) return 0;
+    const size_t per_wg = stft_generic_lds_bytes(g);
+    const size_t cap = ((size_t)1 << 30) / per_wg;  // at most 1 GiB of scratch
+    const size_t want = (size_t)n_cu * 4;           // 4 workgroups of 256 threads per CU
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>({(size_t)n_tiles, want, cap}));
+}
+size_t stft_generic_scratch_bytes(const StftGeom &g, uint32_t n_tiles, uint32_t n_cu) {
+    return (size_t)stft_generic_scratch_grid(g, n_tiles, n_cu) * stft_generic_lds_bytes(g);
+}
 
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                uint32_t n_chan, uint32_t n_tiles, const float *d_window, const cf32 *d_tw,
                                const float *d_mel_fb, const uint32_t *d_mel_lo, const uint32_t *d_mel_hi,
-                               float *d_minmax, hipStream_t s) {
+                               float *d_minmax, hipStream_t s, void *d_scratch, uint32_t n_cu) {
     if (!n_tiles) return hipSuccess;
+    const uint32_t sgrid = stft_generic_scratch_grid(g, n_tiles, n_cu);
+    if (sgrid) {
+        if (d_scratch == nullptr) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(stft_generic_kernel<true>, dim3(sgrid), dim3(GEN_THREADS), 0, s, g, d_jobs, d_tile_start, n_chan, n_tiles,
+                           d_window, d_tw, d_mel_fb, d_mel_lo, d_mel_hi, d_minmax, static_cast<cf32 *>(d_scratch));
+        return hipGetLastError();
+    }
     const size_t lds = stft_generic_lds_bytes(g);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_generic_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_generic_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(stft_generic_kernel, dim3(n_tiles), dim3(GEN_THREADS), lds, s, g, d_jobs, d_tile_start,
-                       n_chan, d_window, d_tw, d_mel_fb, d_mel_lo, d_mel_hi, d_minmax);
+    hipLaunchKernelGGL(stft_generic_kernel<false>, dim3(n_tiles), dim3(GEN_THREADS), lds, s, g, d_jobs, d_tile_start,
+                       n_chan, n_tiles, d_window, d_tw, d_mel_fb, d_mel_lo, d_mel_hi, d_minmax, (cf32 *)nullptr);
     return hipGetLastError();
 }
 }  // namespace th
