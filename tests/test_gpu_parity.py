@@ -560,7 +560,11 @@ def test_track_manager_flow(ctx, golden_dir):
     glo, ghi, gsr = tm.db_state()
     assert (glo, ghi, gsr) == (lo, hi, 48000)
     mism = tot = idx_mism = 0
-    idx_worst = 0
+    idx_worst = dd_worst = 0
+    dd_gt2 = 0.0
+    # end-to-end u16 bound = 3 x what this flow shows on hardware (round 3: worst step 5, 6.2e-4 of the pixels beyond +-2
+    # steps; 1 step = 0.0015 dB): round 2's 655 steps / 1 % would not have caught a 0.5 dB regression
+    U16_WORST, U16_GT2_RATE = 15, 2e-3
 
     def colour_index(v):  # render_tiles.rs:342-346 with C = 258
         return (v.astype(np.int64) * 257 + 32767) // 65535
@@ -576,7 +580,8 @@ def test_track_manager_flow(ctx, golden_dir):
         # end to end the u16 values inherit the f32-FFT noise of weak bins (1 u16 step = 0.0015 dB):
         # reported, and bounded at 1 dB / 1 % of pixels beyond +-2 steps
         dd = np.abs(img.astype(np.int32) - ref_img.astype(np.int32))
-        assert dd.max() <= 655 and np.count_nonzero(dd > 2) <= 0.01 * dd.size, (dd.max(), np.count_nonzero(dd > 2))
+        dd_worst, dd_gt2 = max(dd_worst, int(dd.max())), max(dd_gt2, np.count_nonzero(dd > 2) / dd.size)
+        assert dd.max() <= U16_WORST and np.count_nonzero(dd > 2) <= U16_GT2_RATE * dd.size, (dd.max(), np.count_nonzero(dd > 2) / dd.size)
         # what the viewer sees: colour indices (north star: bit-exact colormap indices GIVEN the same image; end to end the
         # f32-FFT noise of weak bins can move a pixel across one of the 257 index boundaries)
         di = np.abs(colour_index(img) - colour_index(ref_img))
@@ -584,9 +589,10 @@ def test_track_manager_flow(ctx, golden_dir):
         idx_worst = max(idx_worst, int(di.max()))
         b = tm.get_spectrogram_tile(tid, ch, 0, 0, 0, 0)
         assert b == orc.encode_spectrogram_tile(img, cmap, s1, 0, 0, 0, 0)
-    print(f"end-to-end mismatch rate vs the oracle's own spec: u16 {mism / tot:.3e}, colour index {idx_mism / tot:.3e} (worst {idx_worst})")
+    print(f"end-to-end mismatch rate vs the oracle's own spec: u16 {mism / tot:.3e} (worst step {dd_worst}, beyond +-2 steps: {dd_gt2:.3e} "
+          f"of an image at most), colour index {idx_mism / tot:.3e} (worst {idx_worst})")
     assert mism / tot < 0.10
-    assert idx_mism / tot < 2e-3 and idx_worst <= 1, (idx_mism / tot, idx_worst)
+    assert idx_mism / tot < 1e-3 and idx_worst <= 1, (idx_mism / tot, idx_worst)  # (observed 2.8e-4)
     wt = tm.get_waveform_tile(2, 1, 3, 1)
     assert wt == orc.encode_waveform_tile(tracks[2][2][1], w1, 3, 1)
     # nothing new: no ids
@@ -877,6 +883,52 @@ def test_waveform_pyramid_matches_tiles(ctx, n):
                 assert np.array_equal(got[:, 2], want[:, 2]), (level, t)
             else:
                 assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-6 * peak, (level, t)
+
+
+def test_waveform_pyramid_at_config3_batch_shape(ctx):
+    """the pyramid kernel at BASELINE config 3's full batch shape — 128 channels x 2 880 000 samples (64 stereo
+    48 kHz tracks x 60 s), levels 0..12 in one launch, what bench.py times — against the oracle's tile bins on sampled
+    channels (first, last, two in the middle) and sampled tiles of every level; every channel's level-12 bins against
+    numpy min / max (exact in any order), so that a channel mix-up anywhere in the batch shows."""
+    import torch
+
+    from bench import synth_on_gpu
+    from thesia_amd import _ffi
+    n_ch, n, n_lv = 128, 2_880_000, 13
+    dev = torch.device("cuda", 0)
+    wav = synth_on_gpu(torch, dev, list(range(3000, 3000 + n_ch)), 48000, n)
+    tot = ta.api.pyramid_offset(n, n_lv)
+    pyr = torch.zeros((n_ch, tot), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    desc = (_ffi.PyramidDesc * n_ch)(*[_ffi.PyramidDesc(wav[i].data_ptr(), pyr[i].data_ptr(), n, n_lv, 0) for i in range(n_ch)])
+    ctx.waveform_pyramid_dev(desc)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    top = ta.api.pyramid_offset(n, 12)
+    bins12 = ta.api.pyramid_bins(n, 12)
+    lv12 = pyr[:, top:top + 3 * bins12].cpu().numpy().reshape(n_ch, bins12, 3)
+    host = wav.cpu().numpy()
+    padded = np.full((n_ch, bins12 * 4096), np.nan, np.float32)
+    padded[:, :n] = host
+    blocks = padded.reshape(n_ch, bins12, 4096)
+    assert np.array_equal(lv12[:, :, 0], np.nanmin(blocks, axis=2)) and np.array_equal(lv12[:, :, 1], np.nanmax(blocks, axis=2))
+    for c in (0, 41, 86, n_ch - 1):
+        x = host[c]
+        flat = pyr[c].cpu().numpy()
+        peak = float(np.abs(x).max())
+        for level in range(n_lv):
+            a, bins = ta.api.pyramid_offset(n, level), ta.api.pyramid_bins(n, level)
+            got_l = flat[a:a + 3 * bins].reshape(-1, 3)
+            n_tiles = -(-bins // 1024)
+            for t in sorted({0, n_tiles // 3, n_tiles - 1}):
+                want = np.frombuffer(orc.encode_waveform_tile(x, 1, level, t)[24:], np.float32).reshape(-1, 3)
+                got = got_l[1024 * t: 1024 * (t + 1)]
+                assert got.shape == want.shape, (c, level, t)
+                assert np.array_equal(got[:, :2], want[:, :2]), (c, level, t)
+                if level <= 4:
+                    assert np.array_equal(got[:, 2], want[:, 2]), (c, level, t)
+                else:
+                    assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-6 * peak, (c, level, t)
 
 
 def test_waveform_pyramid_batch_ragged_and_partial_levels(ctx):
