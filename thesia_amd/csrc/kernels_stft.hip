@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     constexpr int DYN_K = DYN ? -SHIFT - 16 : 0;
     static_assert(PHASED || DYN || (SHIFT >= 0 && SHIFT < P), "shift must leave something to reuse");
     static_assert(!PHASED || (P == 16 && OUT != 1), "phased mode: n_fft = 2048, dB output");
-    static_assert(!DYN || (DYN_K >= 1 && DYN_K + 1 < P && OUT != 1), "dynamic mode: something to reuse, dB output");
+    static_assert(!DYN || (DYN_K >= 0 && DYN_K + 1 < P && OUT != 1), "dynamic mode: something to reuse, dB output");
     // zero pairs in front of the window table(s): room to read them up to 96 (127) samples lower; DYN: even + odd table
     constexpr int WPAD = PHASED ? 48 : DYN ? 64 + NC + 64 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1338,7 +1338,10 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
                                                               d_minmax, d_queue_head, n_cu, out, s);
             TH_DYN_CASE(10, 3)  // 44.1 kHz: 1764 / 441
             TH_DYN_CASE(10, 2)  // 32 kHz: 1280 / 320
+            TH_DYN_CASE(10, 1)  // 48 kHz, t_overlap 8: 1920 / 240
+            TH_DYN_CASE(10, 0)  // 48 kHz, t_overlap 16 / 32: 1920 / 120, 1920 / 60
             TH_DYN_CASE(9, 1)   // 16 kHz: 640 / 160, 22.05 kHz: 884 / 221
+            TH_DYN_CASE(9, 0)   // 16 kHz, t_overlap 8 .. 32: 640 / 80
 #undef TH_DYN_CASE
         }
         return hipErrorInvalidValue;
@@ -1397,10 +1400,12 @@ int stft_wave_phased_mode(const StftGeom &g, int waves) {
     const uint32_t k = g.hop / 128;
     if (g.log2_nc == 10 && (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES)) {
         if (g.hop == 3 * 128 + 96 && g.n_fft - g.win >= 96) return 1;     // phased: rotation
-        if ((k == 2 || k == 3) && g.n_fft - g.win >= 127) return 2;         // dynamic: moves
+        // dynamic: moves.  k = 2, 3: the 44.1 / 32 kHz defaults; k = 1, 0: t_overlap 8, 16, 32 at the 40 ms default (hop 240,
+        // 120, 60 — tracks.ts:207), where a frame brings in two, one or no new 128-sample slot
+        if (k <= 3 && g.n_fft - g.win >= 127) return 2;
     }
-    if (g.log2_nc == 9 && (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) && k == 1 && g.n_fft - g.win >= 127)
-        return 2;
+    if (g.log2_nc == 9 && (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) && k <= 1 && g.n_fft - g.win >= 127)
+        return 2;  // (k = 0: 16 kHz with t_overlap 8 .. 32, 640 / 80 / 1024)
     return 0;
 }
 
