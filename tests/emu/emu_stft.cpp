@@ -246,6 +246,7 @@ extern "C" __attribute__((visibility("default"))) int emu_stft_wave(const float 
             case 4096: emu_frame<11>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
             case 8192: emu_frame_block<12>(wav, f, g, wtab.data(), tw.data(), row); break;
             case 16384: emu_frame_block<13>(wav, f, g, wtab.data(), tw.data(), row); break;
+            case 32768: emu_frame_block<14>(wav, f, g, wtab.data(), tw.data(), row); break;
             default: return -1;
         }
     }

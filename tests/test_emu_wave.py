@@ -30,7 +30,7 @@ def emu():
                                              (2047, 2047, 2048, 9000),
                                              # the workgroup-per-frame plan (stft_block.h)
                                              (8192, 2048, 8192, 30000), (7680, 1920, 8192, 30000), (16384, 4096, 16384, 60000),
-                                             (15001, 5000, 16384, 70000)])
+                                             (15001, 5000, 16384, 70000), (32768, 8192, 32768, 100000), (19200, 4800, 32768, 80000)])
 def test_emulated_wave_kernel_matches_oracle(emu, win, hop, n_fft, n):
     x = synth_track(n_fft + win, 48000, n)
     w = orc.calc_normalized_win(win, n_fft)
@@ -45,7 +45,7 @@ def test_emulated_wave_kernel_matches_oracle(emu, win, hop, n_fft, n):
     e0 = np.arange(T) * hop - win // 2 - (n_fft - win) // 2     # start of the frame's n_fft-sample span
     assert np.array_equal(interior, (e0 >= 0) & (e0 + n_fft <= n))
     if n >= 2 * win:
-        assert interior.sum() >= T - 6
+        assert interior.sum() >= T - 8  # (win < n_fft at hop = win / 4: up to four boundary frames on either side)
     got_amp = np.power(10.0, out[interior].astype(np.float64) / 20.0)
     rel = (np.abs(got_amp - amp[interior]) / amp[interior].max(axis=1, keepdims=True)).max() if interior.any() else 0
     assert rel <= 2e-6, rel

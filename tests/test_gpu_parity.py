@@ -94,12 +94,22 @@ def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
     lens = [n_fft * 3 + 17, n_fft + hop * 2 + 1, n_fft // 3 + 5, 5 * hop]
     wavs = [synth_track(600 + i, sr, n) for i, n in enumerate(lens)]
     plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, n_mel)
-    assert plan.kernel_name == "stft_generic_kernel"
+    # n_fft 32768 is the largest frame that fits the CU's LDS: workgroup-per-frame kernel (1024 threads, stft_block.h), with the
+    # matrix-core filterbank for mel plans of up to 512 mels; beyond that (and for the default mel counts) the generic kernel
+    want_kernel = ("stft_generic_kernel" if n_fft > 32768 or (scale and n_mel == 0) else
+                   "stft_block_kernel+mel_mfma_kernel" if scale else "stft_block_kernel")
+    assert plan.kernel_name == want_kernel
     fb = None
     if scale:
         fb = orc.calc_mel_fb(sr, n_fft, n_mel) if n_mel else orc.calc_mel_fb_default(sr, n_fft)
         assert plan.height == fb.shape[1]
     a, mma = plan.calc_spec_batch(wavs)
+    ref = None
+    if want_kernel != "stft_generic_kernel":  # the generic kernel (global-scratch variant) on the same batch: shares no FFT code
+        ref = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, n_mel)
+        ref.set_kernel(1)
+        assert ref.kernel_name == "stft_generic_kernel"
+        b, _ = ref.calc_spec_batch(wavs)
     for i, x in enumerate(wavs):
         want, amp = orc.calc_spec(x, win, hop, n_fft, mel_fb=fb, return_amp=True)
         if fb is None:
@@ -107,6 +117,10 @@ def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
         else:
             assert_spec_close(a[i], want)
         assert mma[i, 0] == a[i].min() and mma[i, 1] == a[i].max()
+        if ref is not None:
+            assert_spec_close(b[i], want, amp if fb is None else None)
+    if ref is not None:
+        ref.close()
     plan.close()
 
 

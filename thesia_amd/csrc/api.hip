@@ -866,8 +866,10 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         if (rc == TH_OK) rc = p->edge_tile_start.upload(c->stream, edge_start.data(), edge_start.size() * sizeof(uint32_t));
     }
     if (rc != TH_OK) return rc;
-    if (!wave) {  // n_fft >= 32768: the generic kernel's frame buffers live in global scratch
-        const size_t need = th::stft_generic_scratch_bytes(g, (uint32_t)tiles, c->n_cu);
+    {   // n_fft >= 32768: the generic kernel's frame buffers live in global scratch (all frames of a plan without a fast
+        // kernel, or the boundary frames of the n_fft 32768 block plan)
+        const size_t need = !wave ? th::stft_generic_scratch_bytes(g, (uint32_t)tiles, c->n_cu)
+                                  : (edge.empty() ? 0 : th::stft_generic_scratch_bytes(ge, (uint32_t)edge_tiles, c->n_cu));
         if (need) {
             if (need > p->gen_scratch.cap) TH_HIP(hipStreamSynchronize(c->stream));  // (a launch may still use the old buffer)
             rc = p->gen_scratch.ensure(need);
@@ -935,7 +937,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         if (!edge.empty())  // boundary frames the wave kernel did not take: generic kernel (reflect padding; mel included)
             TH_HIP(launch_stft_generic(ge, (const ChanJob *)p->edge_jobs.dptr, (const uint32_t *)p->edge_tile_start.dptr,
                                        (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, p->d_mel_fb,
-                                       p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream));
+                                       p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream, p->gen_scratch.dptr, c->n_cu));
     } else {
         TH_HIP(launch_stft_generic(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                    (uint32_t)jobs.size(), (uint32_t)tiles, p->d_window, p->d_tw, p->d_mel_fb,

@@ -939,10 +939,15 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     const uint32_t t = threadIdx.x;
     const FrameCursor cur = cursor_at(g, jobs, chunk_tab, n_tiles, blockIdx.x);
     if (!cur.valid) return;
+    // pass constants: in registers for the whole launch — except at n_fft 32768, whose 1024 threads have 128 VGPRs each:
+    // there every pass loads its ten constants (L2-resident table) when it starts
+    constexpr bool TW_RES = LOG2_NC <= 13;
     cf32 wA[B::NTW], wB[B::NTW], wC[B::NTW];
-    if constexpr (B::R2_FIRST) B::template load_tw<B::NS_A>(t, wA, tw);
-    B::template load_tw<B::NS_B>(t, wB, tw);
-    B::template load_tw<B::NS_C>(t, wC, tw);
+    if constexpr (TW_RES) {
+        if constexpr (B::R2_FIRST) B::template load_tw<B::NS_A>(t, wA, tw);
+        B::template load_tw<B::NS_B>(t, wB, tw);
+        B::template load_tw<B::NS_C>(t, wC, tw);
+    }
     const cf32 stw_t = tw[t];
     cf32 rw[WIN_REGS ? 16 : 1];
     if constexpr (WIN_REGS) {
@@ -991,17 +996,20 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
         B::template read_in<B::FIRST_LAYOUT>(t, z, wr);
         TH_BLOCK_SWAP();
         if constexpr (B::R2_FIRST) {
+            if constexpr (!TW_RES) B::template load_tw<B::NS_A>(t, wA, tw);
             B::template pass_mid_compute<B::NS_A>(z, wA);
             B::template pass_mid_store<B::NS_A>(t, z, wr);
             __syncthreads();
             B::template read_in<B::NS_A>(t, z, wr);
             TH_BLOCK_SWAP();
         }
+        if constexpr (!TW_RES) B::template load_tw<B::NS_B>(t, wB, tw);
         B::template pass_mid_compute<B::NS_B>(z, wB);
         B::template pass_mid_store<B::NS_B>(t, z, wr);
         __syncthreads();
         B::template read_in<B::NS_B>(t, z, wr);
         TH_BLOCK_SWAP();
+        if constexpr (!TW_RES) B::template load_tw<B::NS_C>(t, wC, tw);
         B::pass_last(z, wC);
         B::write_z(t, z, wr);
         __syncthreads();
@@ -1062,8 +1070,9 @@ static hipError_t launch_block_t(const StftGeom &g, const ChanJob *d_jobs, const
 template <int LOG2_NC, bool AMP>
 static hipError_t launch_block(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
                                const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
-    // (every frame of a chunk then sits exactly four slots behind its predecessor)
-    if (g.hop * 4 == g.n_fft) return launch_block_t<LOG2_NC, AMP, true>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
+    // (every frame of a chunk then sits exactly four slots behind its predecessor; not at n_fft 32768: 128 VGPRs per thread)
+    if constexpr (LOG2_NC <= 13)
+        if (g.hop * 4 == g.n_fft) return launch_block_t<LOG2_NC, AMP, true>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
     return launch_block_t<LOG2_NC, AMP, false>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
 }
 
@@ -1213,9 +1222,9 @@ namespace th {
 
 // n_fft 512 (multi-frame kernel): linear dB only
 bool stft_wave_supported(const StftGeom &g) {
-    // n_fft 512 (multi-frame kernel) ... 4096 (one frame per wave), 8192 / 16384 (block kernel); mel plans up to 512
+    // n_fft 512 (multi-frame kernel) ... 4096 (one frame per wave), 8192 / 16384 / 32768 (block kernel); mel plans up to 512
     // mels (fused epilogue at n_fft 1024 / 2048 where the tables fit, else amplitude rows + the matrix-core kernel)
-    return g.log2_nc >= 8 && g.log2_nc <= 13 && g.n_mel <= 512;
+    return g.log2_nc >= 8 && g.log2_nc <= 14 && g.n_mel <= 512;
 }
 bool stft_is_block_plan(const StftGeom &g) { return g.log2_nc >= 12; }
 bool stft_wave_multi_applies(const StftGeom &g, int out_mode) {
@@ -1435,7 +1444,7 @@ int stft_wave_default_waves(const StftGeom &g) {
         // n_fft 512 (four frames per wave, staged loads): measured 12 / 2 x 8 / 16 waves per CU — 512/128: 0.77 / 0.70-0.74 /
         // 0.68-0.72 ms, 320/80 (8 kHz default): 1.16-1.18 / 1.21-1.26 / 1.24 ms
         case 8: return g.hop >= 128 ? 16 : 12;
-        case 12: case 13: return 12;  // (block kernel: only sizes the chunks, 12 x CUs of them per round)
+        case 12: case 13: case 14: return 12;  // (block kernel: only sizes the chunks, 12 x CUs of them per round)
         default: return WaveLaunchCfg<9>::DEFAULT_WAVES;
     }
 }
@@ -1458,10 +1467,12 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
         if (out.mode == 1) {  // amplitude rows, no (min, max)
             if (g.log2_nc == 12) return launch_block<12, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
             if (g.log2_nc == 13) return launch_block<13, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
+            if (g.log2_nc == 14) return launch_block<14, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
             return hipErrorInvalidValue;
         }
         if (g.log2_nc == 12) return launch_block<12, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
         if (g.log2_nc == 13) return launch_block<13, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+        if (g.log2_nc == 14) return launch_block<14, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
         return hipErrorInvalidValue;
     }
     switch (g.log2_nc) {

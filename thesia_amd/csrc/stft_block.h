@@ -1,16 +1,18 @@
-// stft_block.h — one WORKGROUP per frame: the packed real FFT of the long transforms, n_fft = 8192 (Nc = 4096) and
-// 16384 (Nc = 8192), which do not fit one wave's registers (stft_wave.h stops at n_fft = 4096).
+// stft_block.h — one WORKGROUP per frame: the packed real FFT of the long transforms, n_fft = 8192 (Nc = 4096),
+// 16384 (Nc = 8192) and 32768 (Nc = 16384: round 3, the largest whose frame fits the CU's LDS), which do not fit one
+// wave's registers (stft_wave.h stops at n_fft = 4096).
 //
-// T = Nc / 16 threads (256 or 512) work on one frame, 16 complex points per thread.  Stockham autosort, decimation in
-// time, radix-16 passes in registers with an LDS exchange (and a workgroup barrier) between passes:
+// T = Nc / 16 threads (256, 512 or 1024) work on one frame, 16 complex points per thread.  Stockham autosort, decimation
+// in time, radix-16 passes in registers with an LDS exchange (and a workgroup barrier) between passes:
 //
 //     Nc = 4096:          16 (Ns = 1)  x 16 (Ns = 16)  x 16 (Ns = 256)
 //     Nc = 8192:  2 (Ns = 1) x 16 (Ns = 2)  x 16 (Ns = 32)  x 16 (Ns = 512)
+//     Nc = 16384: 4 (Ns = 1) x 16 (Ns = 4)  x 16 (Ns = 64)  x 16 (Ns = 1024)
 //
 // A pass with sub-transform size Ns: thread t owns butterfly j = t, k = t mod Ns,
 //     v_r = in[t + T r] * W_{16 Ns}^{r k}   (r = 0..15),     out[(t - k) 16 + k + Ns c] = DFT16(v)_c
 // (the radix-2 first pass of Nc = 8192: butterflies j = t + T m', m' < 8, on the points the thread loaded itself,
-// out[2 j + r]).  The twiddled passes run as the fused-multiply-add butterflies of stft_wave.h (bfly4_tw): 10 per-thread
+// out[2 j + r]; the radix-4 first pass of Nc = 16384 likewise: j = t + T m', m' < 4, slots m', m' + 4, m' + 8, m' + 12).  The twiddled passes run as the fused-multiply-add butterflies of stft_wave.h (bfly4_tw): 10 per-thread
 // constants per pass, held in registers for the whole launch.  After the last pass thread t holds Z[t + T c], c = 0..15;
 // Z goes through LDS once more so that every thread can read the mirror partners Z[Nc - k] of its bins k = t + T c, c < 8,
 // and emit X[k] and X[Nc - k] of the real-FFT split pass together.
@@ -27,11 +29,12 @@ namespace th {
 
 template <int LOG2_NC>
 struct BlockFft {
-    static_assert(LOG2_NC == 12 || LOG2_NC == 13, "n_fft = 8192 or 16384");
+    static_assert(LOG2_NC == 12 || LOG2_NC == 13 || LOG2_NC == 14, "n_fft = 8192, 16384 or 32768");
     static constexpr int NC = 1 << LOG2_NC;
     static constexpr int T = NC / 16;           // threads per frame
-    static constexpr bool R2_FIRST = (LOG2_NC == 13);
-    static constexpr int NS_A = R2_FIRST ? 2 : 1;      // sub-transform sizes of the three radix-16 passes
+    static constexpr int FIRST_R = LOG2_NC == 12 ? 16 : LOG2_NC == 13 ? 2 : 4;  // radix of the untwiddled first pass
+    static constexpr bool R2_FIRST = FIRST_R != 16;  // (a small first pass, then THREE twiddled radix-16 passes)
+    static constexpr int NS_A = R2_FIRST ? FIRST_R : 1;  // sub-transform sizes of the three radix-16 passes
     static constexpr int NS_B = 16 * NS_A, NS_C = 16 * NS_B;
     static_assert(16 * NS_C == NC, "last pass completes the transform");
     static constexpr int NTW = 10;                       // FMA-plan constants per twiddled pass (WaveFft::FMA_TW)
@@ -79,13 +82,23 @@ struct BlockFft {
 
     // ---- first pass(es): z[m] = windowed point t + T m of the frame -> LDS (exchange 1)
     static TH_HD void pass_first(uint32_t t, cf32 (&z)[16], cf32 *buf) {
-        if constexpr (R2_FIRST) {
+        if constexpr (FIRST_R == 2) {
             // radix 2, Ns = 1: butterfly j = t + T m' pairs the points j and j + Nc/2 = slots m', m' + 8; out[2 j + r]
             TH_UNROLL for (int m = 0; m < 8; m++) {
                 fft2(z[m], z[m + 8]);
                 const uint32_t o = 2u * (t + (uint32_t)T * m);
                 buf[o] = z[m];
                 buf[o + 1] = z[m + 8];
+            }
+        } else if constexpr (FIRST_R == 4) {
+            // radix 4, Ns = 1: butterfly j = t + T m' on the points j + r Nc/4 = slots m' + 4 r; out[4 j + r]
+            TH_UNROLL for (int m = 0; m < 4; m++) {
+                fft4(z[m], z[m + 4], z[m + 8], z[m + 12]);
+                const uint32_t o = 4u * (t + (uint32_t)T * m);
+                buf[o] = z[m];
+                buf[o + 1] = z[m + 4];
+                buf[o + 2] = z[m + 8];
+                buf[o + 3] = z[m + 12];
             }
         } else {
             // radix 16, Ns = 1: butterfly j = t on the thread's own 16 points; out[16 t + c]
