@@ -954,6 +954,13 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
 #pragma unroll
         for (int m = 0; m < 16; m++) rw[m] = wtab_g[t + (uint32_t)T * m];
     }
+    // (!TW_RES: an opaque copy of the thread index per use, or the loads — loop-invariant — are hoisted out of the frame loop
+    // and 60 registers stay live across it: 71 spilled VGPRs at n_fft 32768)
+    auto tw_lane = [&]() {
+        uint32_t v = t;
+        asm volatile("" : "+v"(v));
+        return v;
+    };
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
     cf32 x[16];  // raw samples of the frame
     auto fetch = [&](uint32_t f) {
@@ -969,11 +976,12 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     for (uint32_t f = cur.f; f < cur.f1; f++) {
         if constexpr (!REUSE) fetch(f);
         cf32 z[16];
+        const uint32_t tl = TW_RES ? t : tw_lane();  // (!TW_RES: keeps the 16 window pairs from being hoisted out of the loop too)
 #pragma unroll
         for (int m = 0; m < 16; m++) {
             cf32 w;
             if constexpr (WIN_REGS) w = rw[m];
-            else w = wtab_g[t + (uint32_t)T * m];
+            else w = wtab_g[tl + (uint32_t)T * m];
             z[m] = {x[m].re * w.re, x[m].im * w.im};
         }
         if constexpr (REUSE) {  // the next frame: four slots down, the new hop requested now
@@ -996,20 +1004,20 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
         B::template read_in<B::FIRST_LAYOUT>(t, z, wr);
         TH_BLOCK_SWAP();
         if constexpr (B::R2_FIRST) {
-            if constexpr (!TW_RES) B::template load_tw<B::NS_A>(t, wA, tw);
+            if constexpr (!TW_RES) B::template load_tw<B::NS_A>(tw_lane(), wA, tw);
             B::template pass_mid_compute<B::NS_A>(z, wA);
             B::template pass_mid_store<B::NS_A>(t, z, wr);
             __syncthreads();
             B::template read_in<B::NS_A>(t, z, wr);
             TH_BLOCK_SWAP();
         }
-        if constexpr (!TW_RES) B::template load_tw<B::NS_B>(t, wB, tw);
+        if constexpr (!TW_RES) B::template load_tw<B::NS_B>(tw_lane(), wB, tw);
         B::template pass_mid_compute<B::NS_B>(z, wB);
         B::template pass_mid_store<B::NS_B>(t, z, wr);
         __syncthreads();
         B::template read_in<B::NS_B>(t, z, wr);
         TH_BLOCK_SWAP();
-        if constexpr (!TW_RES) B::template load_tw<B::NS_C>(t, wC, tw);
+        if constexpr (!TW_RES) B::template load_tw<B::NS_C>(tw_lane(), wC, tw);
         B::pass_last(z, wC);
         B::write_z(t, z, wr);
         __syncthreads();
