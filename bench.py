@@ -273,8 +273,34 @@ def tm_end_to_end_and_latency(torch, ta, ctx, wl, sr, cmap_bytes, n_tracks=32):
             _ffi.check(lib.th_tm_get_spectrogram_tile(tm.handle, i, 0, 0, 0, tx, ty, bp, buf.size, C.byref(ln)))
             nbytes += ln.value
     t4 = time.perf_counter()
+    # the same tiles through th_tm_get_spectrogram_tiles: one launch, one transfer — into pinned memory the kernel writes
+    # directly (th_host_alloc), and into a pageable buffer (pinned staging + host copy)
+    batch = {}
+    try:
+        reqs_all = [(i, 0, 0, 0, tx, ty) for i in range(n_tracks) for tx, ty in tiles_xy]
+        arr = (_ffi.TileRequest * len(reqs_all))(*[_ffi.TileRequest(*r, 0) for r in reqs_all])
+        offs = (C.c_size_t * (len(reqs_all) + 1))()
+        need = C.c_size_t()
+        lib.th_tm_get_spectrogram_tiles(tm.handle, arr, len(reqs_all), None, 0, offs, C.byref(need))
+        pin = C.c_void_p()
+        _ffi.check(lib.th_host_alloc(ctx.handle, need.value, C.byref(pin)))
+        page = np.empty(need.value, np.uint8)
+        for key, ptr in (("pinned", pin), ("pageable", page.ctypes.data_as(C.c_void_p))):
+            best = 1e9
+            for _ in range(3):
+                tb = time.perf_counter()
+                _ffi.check(lib.th_tm_get_spectrogram_tiles(tm.handle, arr, len(reqs_all), ptr, need.value, offs, C.byref(need)))
+                best = min(best, time.perf_counter() - tb)
+            batch[key + "_ms"] = best * 1e3
+            batch[key + "_GBs"] = need.value / best / 1e9
+        batch["bytes"] = need.value
+        batch["tiles"] = len(reqs_all)
+        _ffi.check(lib.th_host_free(ctx.handle, pin))
+    except Exception as e:  # extras must not break the bench line
+        batch = {"error": str(e)[:200]}
     # the interactive case: the dB-range slider (lib.rs:257-266 -> core/mod.rs:123-126) re-quantises every image and
     # rebuilds every mip pyramid from the resident specs, no STFT
+    t4b = time.perf_counter()
     tm.set_dB_range(80.0)
     t5 = time.perf_counter()
     tm.set_dB_range(100.0)
@@ -283,7 +309,8 @@ def tm_end_to_end_and_latency(torch, ta, ctx, wl, sr, cmap_bytes, n_tracks=32):
     e2e = {"workload": f"{n_tracks} tracks x {n / sr:.0f} s 48 kHz mono from pageable host memory, n_fft=2048 hop=512: th_tm_add_tracks "
                        "-> th_tm_apply_track_list_changes -> every level-0 tile to host memory",
            "frames": frames, "upload_pyramid_stft_ms": (t1 - t0) * 1e3, "range_quantise_mips_ms": (t2 - t1) * 1e3,
-           "all_level0_tiles_ms": (t4 - t3) * 1e3, "tile_bytes": nbytes, "set_dB_range_ms": min(t5 - t4, t6 - t5) * 1e3,
+           "all_level0_tiles_ms": (t4 - t3) * 1e3, "tile_bytes": nbytes, "all_level0_tiles_one_batch": batch,
+           "set_dB_range_ms": min(t5 - t4b, t6 - t5) * 1e3,
            "frames_per_s_compute_only": frames / (t2 - t0), "frames_per_s_with_tile_fetch": frames / ((t2 - t0) + (t4 - t3)),
            "host_input_GBs": host.nbytes / (t1 - t0) / 1e9}
 

@@ -394,6 +394,25 @@ TH_API int th_tm_get_spectrogram_tile(th_tm *tm, size_t id, uint32_t ch, uint32_
                                       size_t *out_len);
 TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t level, uint32_t tile_index,
                                    uint8_t *out, size_t out_capacity, size_t *out_len);
+/* Many spectrogram tiles in one call (the initial paint of a view, a zoom that invalidates every visible tile): ONE raster
+ * launch and one transfer for all of them instead of a launch + synchronisation per tile.  Tile i is written at
+ * out + offsets[i] as the very bytes th_tm_get_spectrogram_tile returns for it (40-byte header + RGBA); records start on
+ * 64-byte boundaries, offsets[n] = bytes used, *out_len = bytes needed (TH_ERR_BUFFER_TOO_SMALL when out_capacity is
+ * less; out may then be NULL to query the size).  When `out` is pinned host memory (th_host_alloc, or memory the caller
+ * registered with HIP) the kernel writes it directly over PCIe; otherwise the tiles pass through a pinned staging buffer
+ * of the manager and are copied.  The reference's consumer asks tile by tile (lib.rs:369-389); a host that wants the
+ * batch sends its visible-tile list once instead. */
+typedef struct {
+    size_t id;
+    uint32_t ch, level_x, level_y, tile_x, tile_y;
+    uint32_t reserved; /* 0 */
+} th_tile_request;
+TH_API int th_tm_get_spectrogram_tiles(th_tm *tm, const th_tile_request *reqs, size_t n, uint8_t *out, size_t out_capacity,
+                                       size_t *offsets /* n + 1 */, size_t *out_len);
+/* pinned, device-visible host memory for tile batches (and for audio handed to th_tm_add_tracks: uploads from pinned
+ * memory run at PCIe speed) */
+TH_API int th_host_alloc(th_ctx *ctx, size_t bytes, void **ptr);
+TH_API int th_host_free(th_ctx *ctx, void *ptr);
 /* AudioRenderMetadata — render_tiles.rs:36-49, filled as RenderTileCache::metadata (:101-122) does for
  * get_audio_render_metadata (lib.rs:321-340).  track_sec and is_clipped come from the reference's TrackList
  * (decode / clip guard, upstream of this path) and are passed through unchanged; an absent spectrogram gives

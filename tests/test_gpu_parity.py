@@ -743,6 +743,42 @@ def test_lod_mip_pyramid(ctx):
     tm.close()
 
 
+def test_batched_tile_fetch_equals_single_requests(ctx, golden_dir):
+    """th_tm_get_spectrogram_tiles (round 3): N tiles in one launch — every record byte-identical to what
+    th_tm_get_spectrogram_tile returns for the same request: level 0 and LOD levels (crops of the mip pyramid), two tracks of
+    different shapes, empty tiles (past the image: header only), a level the pyramid does not hold (per-request resize),
+    into pageable memory (staged) and into pinned memory (written by the kernel directly).  Unknown track: NOT_FOUND."""
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    tm = ta.TrackManager(ctx)
+    tm.set_setting(40.0, 4, 1, ta.MEL)
+    tm.set_colormap(cmap)
+    tm.add_tracks([(1, 48000, synth_track(90, 48000, 48000 * 12)[None]),
+                   (2, 44100, np.stack([synth_track(91, 44100, 44100 * 5), synth_track(92, 44100, 44100 * 5)]))])
+    tm.apply_track_list_changes()
+    reqs = []
+    for tid, ch in [(1, 0), (2, 0), (2, 1)]:
+        ih, iw = tm.img(tid, ch).shape
+        for lx, ly in [(0, 0), (1, 0), (0, 1), (2, 1), (13, 0)]:
+            for tx in range(-(-(-(-iw // (1 << lx))) // 512) + 1):  # (+ 1: one empty tile past the end)
+                reqs.append((tid, ch, lx, ly, tx, 0))
+    want = [tm.get_spectrogram_tile(*r) for r in reqs]
+    assert any(len(w) == 40 for w in want) and any(len(w) > 500000 for w in want)
+    for pinned in (False, True, False):
+        got = tm.get_spectrogram_tiles(reqs, pinned=pinned)
+        assert len(got) == len(want)
+        for r, g, w in zip(reqs, got, want):
+            assert g == w, (pinned, r, len(g), len(w))
+    assert tm.get_spectrogram_tiles([]) == []
+    with pytest.raises(ta.ThError) as e:
+        tm.get_spectrogram_tiles([(1, 0, 0, 0, 0, 0), (99, 0, 0, 0, 0, 0)])
+    assert e.value.code == -7
+    # the dB-range slider re-makes the images: the next batch shows the new pixels and the new revision
+    tm.set_dB_range(60.0)
+    got = tm.get_spectrogram_tiles(reqs[:6], pinned=True)
+    assert got == [tm.get_spectrogram_tile(*r) for r in reqs[:6]] and got[0] != want[0]
+    tm.close()
+
+
 def test_lod_tables_follow_the_resident_images(ctx):
     """(a) the Lanczos tap tables of the pyramid passes are keyed by (axis length, level) — the x axis length is a
     track's frame count — and used to outlive their images: a session that adds and removes tracks grew device memory

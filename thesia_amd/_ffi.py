@@ -60,6 +60,11 @@ OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_OOM, ERR_BUFFE
     ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 
+class TileRequest(C.Structure):
+    _fields_ = [("id", C.c_size_t), ("ch", C.c_uint32), ("level_x", C.c_uint32), ("level_y", C.c_uint32),
+                ("tile_x", C.c_uint32), ("tile_y", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class StatsDesc(C.Structure):
     _fields_ = [("wav", C.c_void_p), ("n_samples", C.c_uint64)]
 
@@ -171,6 +176,9 @@ _SIGS = {
     "th_tm_get_spectrogram_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    c_u8p, C.c_size_t, c_szp],
     "th_tm_get_waveform_tile": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
+    "th_tm_get_spectrogram_tiles": [vp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, c_szp, c_szp],
+    "th_host_alloc": [vp, C.c_size_t, C.POINTER(C.c_void_p)],
+    "th_host_free": [vp, C.c_void_p],
     "th_minmax_reduce_dev": [vp, C.c_void_p, C.c_size_t, C.c_void_p],
     "th_global_db_range_dev": [vp, C.c_void_p, C.c_float, C.c_void_p],
     "th_minmax_reduce_range_dev": [vp, vp, C.c_size_t, C.c_float, vp, vp],

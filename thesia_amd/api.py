@@ -9,6 +9,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Iterable, Optional, Sequence
 
+import struct
+
 import numpy as np
 
 from . import _ffi
@@ -572,6 +574,39 @@ class TrackManager:
         check(lib.th_tm_get_spectrogram_tile(self.handle, track_id, ch, level_x, level_y, tile_x, tile_y,
                                              _ptr(out, c_u8p), out.size, C.byref(n)))
         return out[: n.value].tobytes()
+
+    def get_spectrogram_tiles(self, requests, pinned: bool = False):
+        """th_tm_get_spectrogram_tiles: requests = iterable of (track_id, ch, level_x, level_y, tile_x, tile_y); returns the
+        list of tile byte strings (each equal to get_spectrogram_tile's).  pinned: the output buffer is pinned host memory
+        (th_host_alloc), which the raster kernel writes directly; else a pageable numpy buffer (staged + copied)."""
+        reqs = list(requests)
+        n = len(reqs)
+        arr = (_ffi.TileRequest * max(n, 1))(*[_ffi.TileRequest(*r, 0) for r in reqs])
+        offs = (C.c_size_t * (n + 1))()
+        need = C.c_size_t()
+        rc = lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, None, 0, offs, C.byref(need))
+        if rc not in (_ffi.OK, _ffi.ERR_BUFFER_TOO_SMALL):
+            check(rc)
+        if n == 0 or need.value == 0:
+            return []
+        if pinned:
+            p = C.c_void_p()
+            check(lib.th_host_alloc(self.ctx.handle, need.value, C.byref(p)))
+            try:
+                check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, p, need.value, offs, C.byref(need)))
+                buf = (C.c_uint8 * need.value).from_address(p.value)
+                out = bytes(buf)
+            finally:
+                check(lib.th_host_free(self.ctx.handle, p))
+        else:
+            b = np.empty(need.value, np.uint8)
+            check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, b.ctypes.data_as(C.c_void_p), b.size, offs, C.byref(need)))
+            out = b.tobytes()
+        tiles = []
+        for i in range(n):
+            w, h = struct.unpack_from("<II", out, offs[i] + 8)
+            tiles.append(out[offs[i]: offs[i] + 40 + 4 * w * h])
+        return tiles
 
     def set_lod_source(self, per_request: bool) -> None:
         """LOD > 0 tiles from the resident mip pyramid (False, default) or resampled per request (True)."""

@@ -114,6 +114,10 @@ struct th_tm {
     th::DeviceTable mip_jobs;                                       // job table of the batched mip-pyramid passes
     th::DeviceTable mip_scratch;                                    // transposed images of one chunk of the batch
     uint64_t stat_tiles_served = 0;
+    // th_tm_get_spectrogram_tiles: pinned staging for callers whose buffer the GPU cannot write directly (one batch at a time)
+    std::mutex batch_mu;
+    void *batch_stage = nullptr, *batch_stage_dev = nullptr;
+    size_t batch_stage_cap = 0;
 
     void invalidate_waveform() { cache.invalidate_waveform(); }
     void invalidate_spectrogram() { cache.invalidate_spectrogram(); }
@@ -666,6 +670,7 @@ TH_API int th_tm_destroy(th_tm *tm) {
         for (Channel &ch : kv.second.ch) free_channel(ch);
     for (auto &kv : tm->plans) th_plan_destroy(kv.second);
     for (auto &kv : tm->axis_tabs) (void)hipFree(kv.second.d_blob);
+    if (tm->batch_stage) (void)hipHostFree(tm->batch_stage);
     tm->mip_jobs.release();
     tm->mip_scratch.release();
     if (tm->d_colormap) (void)hipFree(tm->d_colormap);
@@ -1055,6 +1060,166 @@ TH_API int th_tm_get_spectrogram_tile(th_tm *tm, size_t id, uint32_t ch, uint32_
 
 // get_waveform_tile — lib.rs:342-367: cache lookup (:350-355); on a miss the tile's bins are a contiguous piece of the
 // channel's resident pyramid level (built once at add_tracks from one pass over the audio): one copy, no kernel.
+TH_API int th_host_alloc(th_ctx *c, size_t bytes, void **ptr) {
+    TH_TRY
+    TH_REQUIRE(c && ptr, "NULL argument");
+    TH_HIP(hipSetDevice(c->device));
+    TH_HIP(hipHostMalloc(ptr, std::max<size_t>(bytes, 1), hipHostMallocMapped | hipHostMallocPortable));
+    return TH_OK;
+    TH_CATCH
+}
+TH_API int th_host_free(th_ctx *c, void *ptr) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    if (!ptr) return TH_OK;
+    TH_HIP(hipSetDevice(c->device));
+    TH_HIP(hipHostFree(ptr));
+    return TH_OK;
+    TH_CATCH
+}
+
+// N tiles, one raster launch (th_raster_tiles_dev on the context stream), one wait.  Level (0, 0) tiles are crops of the
+// u16 image, LOD > 0 tiles crops of their mip level; requests for levels the pyramid does not hold (or with the per-request
+// route selected) go through the single-tile path one by one.
+TH_API int th_tm_get_spectrogram_tiles(th_tm *tm, const th_tile_request *reqs, size_t n, uint8_t *out, size_t cap,
+                                       size_t *offsets, size_t *out_len) {
+    TH_TRY
+    TH_REQUIRE(tm && out_len && (n == 0 || (reqs && offsets)), "NULL argument");
+    *out_len = 0;
+    if (n == 0) {
+        if (offsets) offsets[0] = 0;
+        return TH_OK;
+    }
+    std::shared_lock<std::shared_mutex> rl(tm->rw);
+    if (!tm->d_colormap) {  // no th_tm_set_colormap yet: upload the default map (as the single-tile path does)
+        rl.unlock();
+        {
+            std::unique_lock<std::shared_mutex> wl(tm->rw);
+            TH_HIP(hipSetDevice(tm->ctx->device));
+            if (!tm->d_colormap) {
+                int rc = upload_colormap(tm);
+                if (rc != TH_OK) return rc;
+            }
+        }
+        rl.lock();
+    }
+    const uint64_t revision = tm->spectrogram_revision();
+    struct Item {
+        TileGeom g;
+        const uint16_t *src;
+        uint32_t src_w, src_h, src_pitch;
+        bool single;  // served by th_tm_get_spectrogram_tile
+    };
+    std::vector<Item> items(n);
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        const th_tile_request &r = reqs[i];
+        Channel *c = find_channel(tm, r.id, r.ch);
+        if (!c || !c->d_img) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", r.id, r.ch);
+        Item &it = items[i];
+        it.g = spectrogram_tile_geometry(c->img_w, c->img_h, r.level_x, r.level_y, r.tile_x, r.tile_y);
+        it.src = c->d_img;
+        it.src_w = (uint32_t)c->img_w;
+        it.src_h = (uint32_t)c->img_h;
+        it.src_pitch = (uint32_t)c->img_pitch;
+        it.single = false;
+        if (r.level_x != 0 || r.level_y != 0) {
+            auto im = c->mips.find({r.level_x, r.level_y});
+            if (tm->lod_source != 0 || im == c->mips.end()) {
+                it.single = true;
+            } else {
+                it.src = im->second.d;
+                it.src_w = im->second.w;
+                it.src_h = im->second.h;
+                it.src_pitch = im->second.pitch;
+                if (it.g.width && it.g.height && (it.g.lod_w != it.src_w || it.g.lod_h != it.src_h))
+                    return fail(TH_ERR_INTERNAL, "mip level (%u, %u) has the wrong shape", r.level_x, r.level_y);
+            }
+        }
+        offsets[i] = total;
+        total += (40 + it.g.width * it.g.height * 4 + 63) / 64 * 64;
+    }
+    offsets[n] = total;
+    *out_len = total;
+    if (cap < total || !out) return fail(TH_ERR_BUFFER_TOO_SMALL, "need %zu bytes", total);
+    TH_HIP(hipSetDevice(tm->ctx->device));
+    // where the kernel writes: the caller's buffer when the GPU can reach it, else the manager's pinned staging buffer
+    uint8_t *dev_base = nullptr;
+    {
+        hipPointerAttribute_t at{};
+        void *dp = nullptr;
+        if (hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeHost &&
+            hipHostGetDevicePointer(&dp, out, 0) == hipSuccess && dp)
+            dev_base = static_cast<uint8_t *>(dp);
+        else
+            (void)hipGetLastError();  // (pageable memory: the query fails, that is the answer)
+    }
+    std::unique_lock<std::mutex> bl(tm->batch_mu, std::defer_lock);
+    const bool staged = dev_base == nullptr;
+    if (staged) {
+        bl.lock();
+        if (tm->batch_stage_cap < total) {
+            if (tm->batch_stage) (void)hipHostFree(tm->batch_stage);
+            tm->batch_stage = tm->batch_stage_dev = nullptr;
+            tm->batch_stage_cap = 0;
+            TH_HIP(hipHostMalloc(&tm->batch_stage, total, hipHostMallocMapped));
+            TH_HIP(hipHostGetDevicePointer(&tm->batch_stage_dev, tm->batch_stage, 0));
+            tm->batch_stage_cap = total;
+        }
+        dev_base = static_cast<uint8_t *>(tm->batch_stage_dev);
+    }
+    std::vector<th_raster_desc> descs;
+    descs.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        const Item &it = items[i];
+        if (it.single || !it.g.width || !it.g.height) continue;
+        th_raster_desc d{};
+        d.img = it.src;
+        d.rgba = dev_base + offsets[i] + 40;
+        d.img_width = it.src_w;
+        d.img_height = it.src_h;
+        d.origin_x = (uint32_t)it.g.origin_x;
+        d.origin_y = (uint32_t)it.g.origin_y;
+        d.width = (uint32_t)it.g.width;
+        d.height = (uint32_t)it.g.height;
+        d.img_pitch = it.src_pitch;
+        descs.push_back(d);
+    }
+    if (!descs.empty()) {
+        std::lock_guard<std::recursive_mutex> lk(tm->ctx->mu);  // the context stream: one user at a time
+        int rc = th_raster_tiles_dev(tm->ctx, descs.data(), descs.size(), tm->d_colormap, (uint32_t)(tm->colormap_rgba.size() / 4));
+        if (rc != TH_OK) return rc;
+        TH_HIP(hipStreamSynchronize(tm->ctx->stream));
+    }
+    for (size_t i = 0; i < n; i++) {
+        const th_tile_request &r = reqs[i];
+        const Item &it = items[i];
+        uint8_t *rec = out + offsets[i];
+        if (it.single) {
+            size_t len = 0;
+            int rc = th_encode_spectrogram_tile_dev(tm->ctx, find_channel(tm, r.id, r.ch)->d_img, find_channel(tm, r.id, r.ch)->img_h,
+                                                    find_channel(tm, r.id, r.ch)->img_w, find_channel(tm, r.id, r.ch)->img_pitch,
+                                                    tm->colormap_rgba.data(), tm->colormap_rgba.size(), revision, r.level_x, r.level_y,
+                                                    r.tile_x, r.tile_y, rec, offsets[i + 1] - offsets[i], &len);
+            if (rc != TH_OK) return rc;
+            continue;
+        }
+        const size_t px = it.g.width * it.g.height * 4;
+        if (staged && px) std::memcpy(rec + 40, static_cast<uint8_t *>(tm->batch_stage) + offsets[i] + 40, px);
+        put_u64(rec, revision);
+        put_u32(rec + 8, (uint32_t)it.g.width);
+        put_u32(rec + 12, (uint32_t)it.g.height);
+        put_u32(rec + 16, r.level_x);
+        put_u32(rec + 20, r.level_y);
+        put_u32(rec + 24, r.tile_x);
+        put_u32(rec + 28, r.tile_y);
+        put_u32(rec + 32, (uint32_t)it.g.origin_x);
+        put_u32(rec + 36, (uint32_t)it.g.origin_y);
+    }
+    return TH_OK;
+    TH_CATCH
+}
+
 TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t level, uint32_t tile_index,
                                    uint8_t *out, size_t cap, size_t *out_len) {
     TH_TRY
