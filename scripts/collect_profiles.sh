@@ -6,13 +6,15 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final
 rm -rf "$out"; mkdir -p "$out"
-echo "bench" >> "$out/progress.txt"; python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-single-track > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
+echo "bench" >> "$out/progress.txt"; python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single-track --no-skeleton > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 find "$out/trace" -type f ! -name "*kernel_stats.csv" -delete
 scripts/pmc_stft.sh "$out/pmc_stft" > "$out/pmc_stft.log" 2>&1
 TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pmc_img.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stft1024" --nfft 1024 > "$out/pmc_stft1024.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stft512_multi" --nfft 512 > "$out/pmc_stft512_multi.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_stft4096" --nfft 4096 --seconds 60 > "$out/pmc_stft4096.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_stftmel" --sr 44100 --tracks 32 --seconds 60 --mel 128 > "$out/pmc_stftmel.log" 2>&1
 {
   python3 scripts/bench_stft.py --reps 30 --kernel 0 1
   python3 scripts/bench_stft.py --reps 30 --nfft 1024
@@ -35,6 +37,11 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 4096
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 8192
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 16384
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 32768
+  python3 scripts/bench_stft.py --reps 10 --gap-ms 1 --nfft 65536
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --win 1920 --hop 240 --kernel 0 4
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --win 1920 --hop 120 --kernel 0 4
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 4096 --seconds 60
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 8192 --win 3840 --hop 960 --sr 96000
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 --kernel 0 1
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 192000 --nfft 8192 --win 7680 --hop 1920 --mel 0 --seconds 8 --kernel 0 1
@@ -54,7 +61,7 @@ TH_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-
 if [ -f scripts/variants/libthesia_amd_wt.so ]; then
   THESIA_AMD_LIB=scripts/variants/libthesia_amd_wt.so python3 scripts/wave_times.py > "$out/wave_times.txt" 2>&1
 fi
-for u in lds_rate valu_rate valu_bank copy_rate row_stores; do
+for u in lds_rate valu_rate valu_bank copy_rate row_stores stream_shapes; do
   [ -x scripts/ubench/$u ] && timeout 120 scripts/ubench/$u > "$out/ubench_$u.txt" 2>&1
 done
 if [ -f scripts/variants/libthesia_amd_prof.so ]; then

@@ -36,7 +36,7 @@ for f in sorted(glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True), 
             seen.add(r["Name"])
             rows.append(r)
 with open(f"{dst}/{tag}_bench_kernel_stats.csv", "w") as fo:
-    fo.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 "
+    fo.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 "
              "--no-cpu-baseline --no-single-track\n# MI355X.  Library kernels only (torch kernels of the synthetic-signal "
              "generator omitted); durations in ns.\n")
     if rows:
@@ -51,7 +51,9 @@ hdr = ("# rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python3
        "# gfx950: FETCH_SIZE reports exactly 1/2 of streamed bytes for 4/8/16-byte-per-lane reads "
        "(profiles/r01_fetch_calibration.txt); WRITE_SIZE is exact.\n")
 for name, script in (("stft", "scripts/bench_stft.py"), ("img", "scripts/bench_img.py"),
-                     ("stft1024", "scripts/bench_stft.py --nfft 1024"), ("stft512_multi", "scripts/bench_stft.py --nfft 512")):
+                     ("stft1024", "scripts/bench_stft.py --nfft 1024"), ("stft512_multi", "scripts/bench_stft.py --nfft 512"),
+                     ("stft4096", "scripts/bench_stft.py --nfft 4096 --seconds 60"),
+                     ("stftmel", "scripts/bench_stft.py --sr 44100 --tracks 32 --seconds 60 --mel 128")):
     p = f"{src}/pmc_{name}/summary.txt"
     if os.path.exists(p):
         open(f"{dst}/{tag}_{name}_pmc_summary.txt", "w").write(hdr.format(script=script) + open(p).read())
@@ -85,7 +87,7 @@ if os.path.exists(p):
 
 # 5. plain-text measurement logs
 for f in ("bench_stft.txt", "bench_img.txt", "bench_cfg3.txt", "bench_cfg4.txt", "phase_prof.txt", "ubench_lds_rate.txt",
-          "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt", "wave_times.txt", "power.txt",
+          "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt", "ubench_stream_shapes.txt", "wave_times.txt", "power.txt",
           "bench_line_force_dist.json", "gputest.txt"):
     if os.path.exists(f"{src}/{f}"):
         txt = "\n".join(l for l in open(f"{src}/{f}").read().splitlines() if "amdgpu.ids" not in l) + "\n"
