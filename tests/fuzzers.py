@@ -128,8 +128,10 @@ def fuzz_track_manager(ctx, seed=1, max_cases=10 ** 9, max_seconds=30.0):
                 del tracks[tid]
                 tm.apply_track_list_changes()
             elif op == "setting":
-                setting = (float(rng.choice([20.0, 40.0, 2048 / 48])), int(rng.choice([2, 4, 8])), int(rng.choice([1, 2])),
+                setting = (float(rng.choice([20.0, 40.0, 2048 / 48])), int(rng.choice([2, 4, 8, 16, 32])), int(rng.choice([1, 2])),
                            int(rng.choice([ta.MEL, ta.LINEAR])))
+                if rng.random() < 0.25:  # the ends of what the UI accepts (winMillisec has a lower bound only): n_fft 4 .. 65536
+                    setting = (float(rng.choice([1.0, 2.5, 170.0, 400.0])), int(rng.choice([1, 2, 4])), int(rng.choice([1, 2])), ta.LINEAR)
                 tm.set_setting(*setting)
             else:
                 dB_range = float(rng.choice([40.0, 60.0, 100.0, 120.0]))
@@ -162,6 +164,11 @@ def fuzz_track_manager(ctx, seed=1, max_cases=10 ** 9, max_seconds=30.0):
                 assert np.array_equal(img, orc.convert_spectrogram_to_img(got, r, (lo, hi), 258)), (setting, sr, r)
                 _, srev = tm.revisions()
                 assert tm.get_spectrogram_tile(tid, ch, 0, 0, 0, 0) == orc.encode_spectrogram_tile(img, cmap, srev, 0, 0, 0, 0)
+            # the batched fetch answers a random mix of requests (level 0, LOD, past-the-end tiles) like the single-tile call
+            keys = list(specs)
+            reqs = [(*keys[int(rng.integers(0, len(keys)))], int(rng.integers(0, 3)), int(rng.integers(0, 2)), int(rng.integers(0, 3)), 0)
+                    for _ in range(5)]
+            assert tm.get_spectrogram_tiles(reqs, pinned=bool(rng.integers(0, 2))) == [tm.get_spectrogram_tile(*r) for r in reqs]
         tm.close()
         n_runs += 1
     return {"sessions": n_runs, "operations": n_ops}
@@ -176,11 +183,12 @@ def fuzz_stft(ctx, seed=1, max_cases=10 ** 9, max_seconds=60.0, big=False):
     n_cases = 0
     worst = 0.0
     while time.time() < t_end and n_cases < max_cases:
-        n_fft = int(rng.choice([512, 1024, 2048, 2048, 4096, 8192, 16384]))  # multi-frame, one-frame and block kernels
+        n_fft = int(rng.choice([512, 1024, 2048, 2048, 4096, 8192, 16384, 32768]))  # multi-frame, one-frame and block kernels
         win = int(rng.integers(n_fft // 2 + 1, n_fft + 1))
         if rng.random() < 0.5:
             win = n_fft if rng.random() < 0.5 else win // 2 * 2
-        hop = int(rng.choice([win // 4, win // 2, win // 8, int(rng.integers(1, win + 1)), 480, 441, 160, 221, 320]))
+        hop = int(rng.choice([win // 4, win // 2, win // 8, win // 16, win // 32, int(rng.integers(1, win + 1)), int(rng.integers(1, 300)),
+                              480, 441, 160, 221, 320, 240, 120, 80, 60]))
         hop = max(1, min(hop, win))
         mel = rng.random() < 0.35
         n_mel = int(rng.choice([0, 40, 128, 200])) if mel else 0
@@ -197,6 +205,8 @@ def fuzz_stft(ctx, seed=1, max_cases=10 ** 9, max_seconds=60.0, big=False):
             hop = max(hop, 64)
         if hop < 8:
             lens = [min(v, 3 * n_fft) for v in lens]
+        elif hop < 64:
+            lens = [min(v, 20 * n_fft) for v in lens]
         wavs = [(rng.standard_normal(v) * 0.1 + 0.3 * np.sin(np.arange(v) * rng.uniform(0.001, 1.0))).astype(np.float32) for v in lens]
         a, mma = plan.calc_spec_batch(wavs)
         b, mmb = ref.calc_spec_batch(wavs)
