@@ -1270,6 +1270,11 @@ struct WaveLaunchCfg {
     }
 };
 
+// (selector 6 runs the two-frames-per-wave plan of n_fft 1024 at the one-frame plan's default shape: it must be one the
+// multi-frame kernel is instantiated for, launch_wave_multi)
+static_assert(WaveLaunchCfg<9>::DEFAULT_WAVES == 8 || WaveLaunchCfg<9>::DEFAULT_WAVES == 12 || WaveLaunchCfg<9>::DEFAULT_WAVES == 16,
+              "stft_wave_multi_kernel<9> exists for 8, 12 and 16 waves per workgroup");
+
 template <int LOG2_NC, int WAVES>
 static size_t wave_lds_bytes() {
     using W = WaveFft<LOG2_NC>;
