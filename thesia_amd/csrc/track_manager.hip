@@ -1148,8 +1148,10 @@ TH_API int th_tm_get_spectrogram_tiles(th_tm *tm, const th_tile_request *reqs, s
     {
         hipPointerAttribute_t at{};
         void *dp = nullptr;
-        if (hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeHost &&
-            hipHostGetDevicePointer(&dp, out, 0) == hipSuccess && dp)
+        const hipError_t qe = hipPointerGetAttributes(&at, out);
+        if (qe == hipSuccess && at.type == hipMemoryTypeDevice)
+            return fail(TH_ERR_INVALID_ARG, "out is device memory: th_tm_get_spectrogram_tiles writes tile headers from the host");
+        if (qe == hipSuccess && at.type == hipMemoryTypeHost && hipHostGetDevicePointer(&dp, out, 0) == hipSuccess && dp)
             dev_base = static_cast<uint8_t *>(dp);
         else
             (void)hipGetLastError();  // (pageable memory: the query fails, that is the answer)
