@@ -1343,7 +1343,7 @@ def test_hip_graph_replay_of_a_single_track_step(ctx, golden_dir):
                                            (1700, 400, 2048), (1900, 500, 2048), (1920, 479, 2048), (1280, 320, 2048),
                                            (1200, 300, 2048), (640, 160, 1024), (884, 221, 1024), (800, 255, 1024),
                                            (1920, 240, 2048), (1920, 120, 2048), (1920, 60, 2048), (1764, 147, 2048),
-                                           (1905, 127, 2048), (1600, 200, 2048), (1000, 25, 2048), (640, 80, 1024), (882, 63, 1024)])
+                                           (1905, 127, 2048), (1600, 200, 2048), (1000, 25, 2048), (640, 80, 1024), (882, 63, 1024), (1920, 960, 2048), (1764, 882, 2048), (1900, 801, 2048)])
 def test_phased_register_reuse_for_hop_480(ctx, win, hop, n_fft):
     """hop = 480 (the app's 40 ms / 4 at 48 kHz) with n_fft = 2048: the wave kernel loads every frame from the 128-sample grid
     below its first window sample (|X| does not change when the windowed frame moves inside its zero padding) and reuses

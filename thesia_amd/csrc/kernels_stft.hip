@@ -1360,6 +1360,8 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
                                                               d_minmax, d_queue_head, n_cu, out, s);
             TH_DYN_CASE(10, 3)  // 44.1 kHz: 1764 / 441
             TH_DYN_CASE(10, 2)  // 32 kHz: 1280 / 320
+            TH_DYN_CASE(10, 7)  // 48 kHz, t_overlap 2: 1920 / 960
+            TH_DYN_CASE(10, 6)  // 44.1 kHz, t_overlap 2: 1764 / 882
             TH_DYN_CASE(10, 1)  // 48 kHz, t_overlap 8: 1920 / 240
             TH_DYN_CASE(10, 0)  // 48 kHz, t_overlap 16 / 32: 1920 / 120, 1920 / 60
             TH_DYN_CASE(9, 1)   // 16 kHz: 640 / 160, 22.05 kHz: 884 / 221
@@ -1424,7 +1426,8 @@ int stft_wave_phased_mode(const StftGeom &g, int waves) {
         if (g.hop == 3 * 128 + 96 && g.n_fft - g.win >= 96) return 1;     // phased: rotation
         // dynamic: moves.  k = 2, 3: the 44.1 / 32 kHz defaults; k = 1, 0: t_overlap 8, 16, 32 at the 40 ms default (hop 240,
         // 120, 60 — tracks.ts:207), where a frame brings in two, one or no new 128-sample slot
-        if (k <= 3 && g.n_fft - g.win >= 127) return 2;
+        // k = 6, 7: t_overlap 2 at the 40 ms default (44.1 kHz: 1764 / 882, 48 kHz: 1920 / 960): half of the slots are new
+        if ((k <= 3 || k == 6 || k == 7) && g.n_fft - g.win >= 127) return 2;
     }
     if (g.log2_nc == 9 && (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) && k <= 1 && g.n_fft - g.win >= 127)
         return 2;  // (k = 0: 16 kHz with t_overlap 8 .. 32, 640 / 80 / 1024)
