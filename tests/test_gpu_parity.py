@@ -935,6 +935,59 @@ def test_waveform_pyramid_matches_tiles(ctx, n):
                 assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-6 * peak, (level, t)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 4097, 70_001, 1_000_003])
+def test_waveform_pyramid_without_level_0(ctx, n):
+    """th_pyramid_desc.first_level = 1 (what the TrackManager builds since round 3): levels 1 .. n_levels - 1 bit for bit the
+    levels of the full pyramid, laid out from offset 0; level 0 — (x, x, x) per sample, half of all the bytes — is not
+    written (the buffer has no room for it)."""
+    from thesia_amd import _ffi
+    x = synth_track(n + 7, 44100, n)
+    n_levels = 15
+    full = ctx.waveform_pyramid(x, n_levels)
+    off1 = ta.api.pyramid_offset(n, 1)
+    tot = ta.api.pyramid_offset(n, n_levels) - off1
+    dw, do = ctx.to_device(x), ctx.alloc(max(tot, 1) * 4 + 256)
+    guard = np.full(max(tot, 1) + 64, np.float32(-12345.0), np.float32)
+    do.upload(guard)
+    ctx.waveform_pyramid_dev([_ffi.PyramidDesc(dw.ptr, do.ptr, n, n_levels, 1)])
+    flat = do.download((max(tot, 1) + 64,), np.float32)
+    assert np.all(flat[tot:] == np.float32(-12345.0))  # nothing behind the last level
+    for level in range(1, n_levels):
+        a = ta.api.pyramid_offset(n, level) - off1
+        got = flat[a:a + 3 * ta.api.pyramid_bins(n, level)].reshape(-1, 3)
+        assert np.array_equal(got, full[level]), (n, level)
+
+
+def test_track_manager_waveform_tiles_every_level(ctx):
+    """th_tm_get_waveform_tile against the oracle's encode_waveform_tile (render_tiles.rs:232-279) for every kind of level:
+    level 0 (served from the resident samples: one-sample bins are (x, x, x)), the in-block levels, the tree levels, the
+    levels built by the follow-up kernel, a level above the last (one bin over everything), first / middle / partial last /
+    past-the-end tiles; a one-sample channel."""
+    tm = ta.TrackManager(ctx)
+    tm.set_setting(40.0, 4, 1, ta.LINEAR)
+    n = 48000 * 3 + 777
+    x = np.stack([synth_track(95, 48000, n), synth_track(96, 48000, n)])
+    tm.add_tracks([(5, 48000, x), (6, 48000, np.array([[0.25]], np.float32))])
+    w_rev, _ = tm.revisions()
+    peak = float(np.abs(x).max())
+    for ch in (0, 1):
+        for level in (0, 1, 2, 4, 5, 9, 11, 12, 13, 16, 18, 25):
+            n_tiles = -(-(-(-n // (1 << level))) // 1024)
+            for t in sorted({0, n_tiles // 2, n_tiles - 1, n_tiles}):
+                got = tm.get_waveform_tile(5, ch, level, t)
+                want = orc.encode_waveform_tile(x[ch], w_rev, level, t)
+                assert got[:24] == want[:24], (ch, level, t)
+                g, w = np.frombuffer(got[24:], np.float32).reshape(-1, 3), np.frombuffer(want[24:], np.float32).reshape(-1, 3)
+                assert g.shape == w.shape and np.array_equal(g[:, :2], w[:, :2]), (ch, level, t)
+                if level <= 4:
+                    assert np.array_equal(g[:, 2], w[:, 2]), (ch, level, t)
+                elif g.size:
+                    assert np.abs(g[:, 2] - w[:, 2]).max() <= 1e-6 * peak, (ch, level, t)
+    for level in (0, 1, 7):
+        assert tm.get_waveform_tile(6, 0, level, 0) == orc.encode_waveform_tile(np.array([0.25], np.float32), w_rev, level, 0)
+    tm.close()
+
+
 def test_waveform_pyramid_at_config3_batch_shape(ctx):
     """the pyramid kernel at BASELINE config 3's full batch shape — 128 channels x 2 880 000 samples (64 stereo
     48 kHz tracks x 60 s), levels 0..12 in one launch, what bench.py times — against the oracle's tile bins on sampled

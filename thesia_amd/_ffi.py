@@ -71,7 +71,7 @@ class StatsDesc(C.Structure):
 
 class PyramidDesc(C.Structure):
     _fields_ = [("wav", C.c_void_p), ("out", C.c_void_p), ("n_samples", C.c_uint64), ("n_levels", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("first_level", C.c_uint32)]
 
 
 class RenderMetadata(C.Structure):

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const PyrJob *__restr
     const uint64_t base = wave_base + (uint64_t)lane * PYR_SPT;
     const uint32_t valid = base >= n ? 0u : (uint32_t)min((uint64_t)PYR_SPT, n - base);
     float x[PYR_SPT];
-    if (valid == PYR_SPT && job.aligned16) {
+    if (valid == PYR_SPT && (job.aligned16 & 1u)) {
 #pragma unroll
         for (uint32_t q = 0; q < PYR_SPT / 4; q++) {
             const float4 t = *reinterpret_cast<gptr<const float4>>(wav + base + 4 * q);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const PyrJob *__restr
     // level 0: one-sample bins (min = max = mean = x), half of all the bytes this kernel writes.  Output dword d
     // of the wave is sample d/3, so a lane builds whole 16-byte groups from two neighbouring samples read back
     // from LDS (samples staged with one pad dword per lane) and stores them as float4: 1 KiB per wave-instruction.
-    if (job.n_levels > 0) {
+    if (job.n_levels > 0 && !(job.aligned16 & 2u)) {
         const uint64_t first = wave_base;  // bin index of the wave's first bin at level 0
         const uint64_t nb = pyramid_dev_bins(n, 0);
         const uint64_t vd = first >= nb ? 0 : 3 * min((uint64_t)64 * PYR_SPT, nb - first);  // valid dwords

@@ -812,7 +812,10 @@ TH_API int th_tm_add_tracks(th_tm *tm, size_t n_tracks, const size_t *ids, const
             uint32_t lv = 1;
             while (lv < PYR_MAX_LEVELS && ((uint64_t)1 << (lv - 1)) < ch.n) lv++;
             ch.pyr_levels = lv;
-            if (e == hipSuccess) e = hipMalloc((void **)&ch.d_pyr, th_waveform_pyramid_offset(ch.n, lv) * sizeof(float));
+            // (levels 1 .. lv - 1: level 0 would be (x, x, x) per sample — half of the pyramid's bytes — and is served from the
+            // resident samples instead, th_pyramid_desc.first_level = 1)
+            if (e == hipSuccess)
+                e = hipMalloc((void **)&ch.d_pyr, std::max<size_t>(1, th_waveform_pyramid_offset(ch.n, lv) - th_waveform_pyramid_offset(ch.n, 1)) * sizeof(float));
         }
         added.push_back(ids[t]);
     }
@@ -825,7 +828,7 @@ TH_API int th_tm_add_tracks(th_tm *tm, size_t n_tracks, const size_t *ids, const
     for (auto &kv : staged)
         for (Channel &ch : kv.second.ch) {
             chans.push_back({kv.second.sr, &ch});
-            pdescs.push_back(th_pyramid_desc{ch.d_wav, ch.d_pyr, ch.n, ch.pyr_levels, 0});
+            pdescs.push_back(th_pyramid_desc{ch.d_wav, ch.d_pyr, ch.n, ch.pyr_levels, 1});
         }
     rc = th_waveform_pyramid_dev(c, pdescs.data(), pdescs.size());
     if (rc == TH_OK) rc = compute_specs(tm, setting_of(tm), chans, created, &fresh);
@@ -1248,19 +1251,32 @@ TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t l
     put_u32(out + 16, tile_index);
     put_u32(out + 20, 0);
     if (bins) {
-        if (!c->d_pyr || !c->pyr_levels) return fail(TH_ERR_INTERNAL, "channel %zu_%u has no waveform pyramid", id, ch);
+        if (!c->d_wav || !c->pyr_levels) return fail(TH_ERR_INTERNAL, "channel %zu_%u has no waveform pyramid", id, ch);
         // a level above the pyramid's last one still has exactly one bin, over the same samples
         const uint32_t lv = level < c->pyr_levels ? level : c->pyr_levels - 1;
         const size_t first_bin = lv == level ? (size_t)tile_index * 1024 : 0;
-        const float *d_src = c->d_pyr + th_waveform_pyramid_offset(c->n, lv) + 3 * first_bin;
         TH_HIP(hipSetDevice(tm->ctx->device));
         SlotLease lease{tm, nullptr};
         int rc = acquire_slot(tm, &lease.slot);
         if (rc != TH_OK) return rc;
         ReaderSlot &sl = *lease.slot;
-        TH_HIP(hipMemcpyAsync(sl.h_tile, d_src, bins * 12, hipMemcpyDeviceToHost, sl.stream));
-        TH_HIP(hipStreamSynchronize(sl.stream));
-        std::memcpy(out + 24, sl.h_tile, bins * 12);
+        if (lv == 0) {
+            // level 0 is not materialised: a one-sample bin is (x, x, x) (render_tiles.rs:261-279 on a slice of one sample:
+            // min = max = x, mean = x / 1) — copy the samples (a third of the bytes) and expand them here
+            TH_HIP(hipMemcpyAsync(sl.h_tile, c->d_wav + start, bins * 4, hipMemcpyDeviceToHost, sl.stream));
+            TH_HIP(hipStreamSynchronize(sl.stream));
+            const float *x = reinterpret_cast<const float *>(sl.h_tile);
+            for (size_t b = 0; b < bins; b++) {
+                std::memcpy(out + 24 + 12 * b, &x[b], 4);
+                std::memcpy(out + 28 + 12 * b, &x[b], 4);
+                std::memcpy(out + 32 + 12 * b, &x[b], 4);
+            }
+        } else {
+            const float *d_src = c->d_pyr + (th_waveform_pyramid_offset(c->n, lv) - th_waveform_pyramid_offset(c->n, 1)) + 3 * first_bin;
+            TH_HIP(hipMemcpyAsync(sl.h_tile, d_src, bins * 12, hipMemcpyDeviceToHost, sl.stream));
+            TH_HIP(hipStreamSynchronize(sl.stream));
+            std::memcpy(out + 24, sl.h_tile, bins * 12);
+        }
     }
     tm->cache.store(id, ch, revision, level, tile_index, out, need);
     return TH_OK;
