@@ -499,14 +499,14 @@ def main():
                 "algorithmic_bytes_per_sample": 4 + 4.0 * tot / n,
                 "frac": (smp * 4 + wl.n_tracks * tot * 4) / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del pyr
-        # what th_tm_add_tracks builds since round 3: levels 1 .. 12 only (th_pyramid_desc.first_level = 1) — level 0 is
-        # (x, x, x) per sample, half of the pyramid's bytes, and is served from the resident samples instead
-        tot1 = tot - ta.api.pyramid_offset(n, 1)
+        # what th_tm_add_tracks builds since round 3: levels 2 .. 12 only (th_pyramid_desc.first_level = 2) — level 0 is
+        # (x, x, x) per sample, half of the pyramid's bytes, level 1 a quarter; tiles of both are served from the resident samples
+        tot1 = tot - ta.api.pyramid_offset(n, 2)
         pyr1 = torch.empty((wl.n_tracks, tot1), dtype=torch.float32, device=dev)
-        pdesc1 = (_ffi.PyramidDesc * wl.n_tracks)(*[_ffi.PyramidDesc(wl.wav[i].data_ptr(), pyr1[i].data_ptr(), n, n_lv, 1)
+        pdesc1 = (_ffi.PyramidDesc * wl.n_tracks)(*[_ffi.PyramidDesc(wl.wav[i].data_ptr(), pyr1[i].data_ptr(), n, n_lv, 2)
                                                     for i in range(wl.n_tracks)])
         pyr1_ms = time_stage(lambda: ctx.waveform_pyramid_dev(pdesc1))
-        wave["levels_1_up"] = {"workload": f"levels 1..{n_lv - 1} (first_level = 1: level 0 is served from the samples)", "ms": pyr1_ms,
+        wave["levels_2_up"] = {"workload": f"levels 2..{n_lv - 1} (first_level = 2: levels 0 and 1 are served from the samples)", "ms": pyr1_ms,
                                "msamples_per_s": smp / 1e6 / (pyr1_ms * 1e-3), "algorithmic_bytes_per_sample": 4 + 4.0 * tot1 / n,
                                "frac": (smp * 4 + wl.n_tracks * tot1 * 4) / (pyr1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del pyr1

@@ -316,16 +316,17 @@ TH_API int th_channel_stats_dev(th_ctx *ctx, const th_stats_desc *descs, size_t 
  * th_waveform_pyramid_offset(n, L) of `out` (every level starts on a 128-byte boundary: the offsets are multiples of 32
  * floats, with up to 31 unused floats behind a level); tile t of level L is bins [1024 t, 1024 (t + 1)) of that level.
  * `out` must hold th_waveform_pyramid_offset(n, n_levels) floats.
- * first_level = 1: level 0 is NOT materialised — its bins are (x, x, x) per sample, half of all the pyramid's bytes and
- * pure redundancy next to the resident audio (the TrackManager serves level-0 tiles from the samples) — and the layout
- * starts at level 1: level L >= 1 at float offset th_waveform_pyramid_offset(n, L) - th_waveform_pyramid_offset(n, 1),
- * `out` holds th_waveform_pyramid_offset(n, n_levels) - th_waveform_pyramid_offset(n, 1) floats. */
+ * first_level = F in {1, 2}: levels below F are NOT materialised — level 0 is (x, x, x) per sample, half of all the
+ * pyramid's bytes, level 1 a quarter, and a tile of either is no larger as samples (4 / 8 KB) than as bins (12 KB): the
+ * TrackManager serves them from the resident audio — and the layout starts at level F: level L >= F at float offset
+ * th_waveform_pyramid_offset(n, L) - th_waveform_pyramid_offset(n, F); `out` holds
+ * th_waveform_pyramid_offset(n, n_levels) - th_waveform_pyramid_offset(n, F) floats. */
 typedef struct {
     const float *wav; /* DEVICE */
     float *out;       /* DEVICE */
     uint64_t n_samples;
     uint32_t n_levels; /* levels 0 .. n_levels-1, at most 40 */
-    uint32_t first_level; /* 0 (all levels) or 1 (levels 1 .. n_levels-1) */
+    uint32_t first_level; /* 0 (all levels), 1 or 2 (levels first_level .. n_levels-1) */
 } th_pyramid_desc;
 TH_API size_t th_waveform_pyramid_bins(uint64_t n_samples, uint32_t level);
 TH_API size_t th_waveform_pyramid_offset(uint64_t n_samples, uint32_t level);

@@ -935,24 +935,25 @@ def test_waveform_pyramid_matches_tiles(ctx, n):
                 assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-6 * peak, (level, t)
 
 
+@pytest.mark.parametrize("first", [1, 2])
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 4097, 70_001, 1_000_003])
-def test_waveform_pyramid_without_level_0(ctx, n):
-    """th_pyramid_desc.first_level = 1 (what the TrackManager builds since round 3): levels 1 .. n_levels - 1 bit for bit the
-    levels of the full pyramid, laid out from offset 0; level 0 — (x, x, x) per sample, half of all the bytes — is not
-    written (the buffer has no room for it)."""
+def test_waveform_pyramid_without_level_0(ctx, n, first):
+    """th_pyramid_desc.first_level = 1 / 2 (2 is what the TrackManager builds since round 3): levels first .. n_levels - 1 bit
+    for bit the levels of the full pyramid, laid out from offset 0; level 0 — (x, x, x) per sample, half of all the bytes —
+    and level 1 are not written (the buffer has no room for them)."""
     from thesia_amd import _ffi
     x = synth_track(n + 7, 44100, n)
     n_levels = 15
     full = ctx.waveform_pyramid(x, n_levels)
-    off1 = ta.api.pyramid_offset(n, 1)
+    off1 = ta.api.pyramid_offset(n, first)
     tot = ta.api.pyramid_offset(n, n_levels) - off1
     dw, do = ctx.to_device(x), ctx.alloc(max(tot, 1) * 4 + 256)
     guard = np.full(max(tot, 1) + 64, np.float32(-12345.0), np.float32)
     do.upload(guard)
-    ctx.waveform_pyramid_dev([_ffi.PyramidDesc(dw.ptr, do.ptr, n, n_levels, 1)])
+    ctx.waveform_pyramid_dev([_ffi.PyramidDesc(dw.ptr, do.ptr, n, n_levels, first)])
     flat = do.download((max(tot, 1) + 64,), np.float32)
     assert np.all(flat[tot:] == np.float32(-12345.0))  # nothing behind the last level
-    for level in range(1, n_levels):
+    for level in range(first, n_levels):
         a = ta.api.pyramid_offset(n, level) - off1
         got = flat[a:a + 3 * ta.api.pyramid_bins(n, level)].reshape(-1, 3)
         assert np.array_equal(got, full[level]), (n, level)
@@ -985,6 +986,13 @@ def test_track_manager_waveform_tiles_every_level(ctx):
                     assert np.abs(g[:, 2] - w[:, 2]).max() <= 1e-6 * peak, (ch, level, t)
     for level in (0, 1, 7):
         assert tm.get_waveform_tile(6, 0, level, 0) == orc.encode_waveform_tile(np.array([0.25], np.float32), w_rev, level, 0)
+    tiny = [np.array([0.5, -0.25], np.float32), np.array([0.1, 0.2, -0.3, 0.4, 0.05], np.float32)]
+    tm.add_tracks([(7, 8000, tiny[0][None]), (8, 8000, tiny[1][None])])
+    w_rev, _ = tm.revisions()
+    for tid, xs in ((7, tiny[0]), (8, tiny[1])):
+        for level in (0, 1, 2, 3, 5):
+            for t in (0, 1):
+                assert tm.get_waveform_tile(tid, 0, level, t) == orc.encode_waveform_tile(xs, w_rev, level, t), (tid, level, t)
     tm.close()
 
 

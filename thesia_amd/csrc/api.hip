@@ -1423,14 +1423,14 @@ TH_API int th_waveform_pyramid_dev(th_ctx *c, const th_pyramid_desc *descs, size
         TH_REQUIRE(d.n_samples < (1ull << 40), "desc %zu: too many samples", i);
         PyrJob &j = jobs[i];
         j = PyrJob{};
-        TH_REQUIRE(d.first_level <= 1, "desc %zu: first_level must be 0 or 1", i);
+        TH_REQUIRE(d.first_level <= 2, "desc %zu: first_level must be 0, 1 or 2", i);
         j.wav = d.wav;
-        // first_level = 1: the kernels keep addressing level L at out + level_off[L]; shifting `out` back by level 0's extent
-        // (a multiple of 128 bytes) puts level 1 at the start of the caller's buffer, and level 0 is never touched
-        j.out = d.first_level ? reinterpret_cast<float *>(reinterpret_cast<uintptr_t>(d.out) - pyramid_offset(d.n_samples, 1) * sizeof(float)) : d.out;
+        // first_level = 1: the kernels keep addressing level L at out + level_off[L]; shifting `out` back by the extent of the skipped levels
+        // (a multiple of 128 bytes) puts level first_level at the start of the caller's buffer; the levels below are never touched
+        j.out = d.first_level ? reinterpret_cast<float *>(reinterpret_cast<uintptr_t>(d.out) - pyramid_offset(d.n_samples, d.first_level) * sizeof(float)) : d.out;
         j.n_samples = (d.n_levels > d.first_level) ? d.n_samples : 0;
         j.n_levels = d.n_levels;
-        j.aligned16 = ((reinterpret_cast<uintptr_t>(d.wav) & 15u) == 0 ? 1u : 0u) | (d.first_level ? 2u : 0u);
+        j.aligned16 = ((reinterpret_cast<uintptr_t>(d.wav) & 15u) == 0 ? 1u : 0u) | (d.first_level << 1);
         for (uint32_t l = 0; l < PYR_MAX_LEVELS; l++) j.level_off[l] = pyramid_offset(d.n_samples, l);
         j.sums_half = pyramid_bins(d.n_samples, 12);
         sums_total += 2 * j.sums_half;

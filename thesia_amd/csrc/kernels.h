@@ -170,7 +170,7 @@ struct PyrJob {
     uint64_t sums_half;
     uint64_t level_off[PYR_MAX_LEVELS];
     uint32_t n_levels;
-    uint32_t aligned16;  // bit 0: wav is 16-byte aligned (float4 loads); bit 1: level 0 is not written (th_pyramid_desc.first_level = 1)
+    uint32_t aligned16;  // bit 0: wav is 16-byte aligned (float4 loads); bits 1-2: th_pyramid_desc.first_level (levels below it are not written)
 };
 struct StatsJob {
     const float *wav;

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const PyrJob *__restr
     // level 0: one-sample bins (min = max = mean = x), half of all the bytes this kernel writes.  Output dword d
     // of the wave is sample d/3, so a lane builds whole 16-byte groups from two neighbouring samples read back
     // from LDS (samples staged with one pad dword per lane) and stores them as float4: 1 KiB per wave-instruction.
-    if (job.n_levels > 0 && !(job.aligned16 & 2u)) {
+    const uint32_t first_level = job.aligned16 >> 1;  // levels below it are not materialised (th_pyramid_desc.first_level)
+    if (job.n_levels > 0 && first_level == 0) {
         const uint64_t first = wave_base;  // bin index of the wave's first bin at level 0
         const uint64_t nb = pyramid_dev_bins(n, 0);
         const uint64_t vd = first >= nb ? 0 : 3 * min((uint64_t)64 * PYR_SPT, nb - first);  // valid dwords
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void pyramid_base_kernel(const PyrJob *__restr
                 mx16 = mx;                                                                                     \
             }                                                                                                  \
         }                                                                                                      \
-        if (job.n_levels > (L)) {                                                                              \
+        if (job.n_levels > (L) && first_level <= (L)) {                                                        \
             const uint64_t first = wave_base >> (L);                                                           \
             const uint64_t nb = pyramid_dev_bins(n, (L));                                                      \
             const uint64_t vd = first >= nb ? 0 : 3 * min((uint64_t)64 * NB, nb - first);                      \

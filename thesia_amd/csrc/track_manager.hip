@@ -280,6 +280,7 @@ void commit_specs(std::vector<NewSpec> &v) {
 // (levels beyond these are resampled per request: the frontend's level = floor(log2(source pixels per screen pixel)),
 // AudioTrackViewport.tsx:91,406,439 — rows are hundreds of pixels high, so level_y rarely exceeds 2)
 constexpr uint32_t MIP_MAX_LX = 12, MIP_MAX_LY = 3, MIP_MIN_DIM = 16;
+constexpr uint32_t PYR_FIRST = 2;  // first materialised level of the resident waveform pyramids (levels 0, 1: from the samples)
 
 int axis_table(th_tm *tm, uint32_t n_in, uint32_t level, AxisTable **out) {
     const auto key = std::make_pair(n_in, level);
@@ -812,10 +813,11 @@ TH_API int th_tm_add_tracks(th_tm *tm, size_t n_tracks, const size_t *ids, const
             uint32_t lv = 1;
             while (lv < PYR_MAX_LEVELS && ((uint64_t)1 << (lv - 1)) < ch.n) lv++;
             ch.pyr_levels = lv;
-            // (levels 1 .. lv - 1: level 0 would be (x, x, x) per sample — half of the pyramid's bytes — and is served from the
-            // resident samples instead, th_pyramid_desc.first_level = 1)
+            // (levels PYR_FIRST .. lv - 1: level 0 would be (x, x, x) per sample — half of the pyramid's bytes — and level 1 a
+            // quarter; tiles of both are served from the resident samples instead, th_pyramid_desc.first_level)
             if (e == hipSuccess)
-                e = hipMalloc((void **)&ch.d_pyr, std::max<size_t>(1, th_waveform_pyramid_offset(ch.n, lv) - th_waveform_pyramid_offset(ch.n, 1)) * sizeof(float));
+                e = hipMalloc((void **)&ch.d_pyr,
+                              std::max<size_t>(1, th_waveform_pyramid_offset(ch.n, std::max(lv, PYR_FIRST)) - th_waveform_pyramid_offset(ch.n, PYR_FIRST)) * sizeof(float));
         }
         added.push_back(ids[t]);
     }
@@ -828,7 +830,7 @@ TH_API int th_tm_add_tracks(th_tm *tm, size_t n_tracks, const size_t *ids, const
     for (auto &kv : staged)
         for (Channel &ch : kv.second.ch) {
             chans.push_back({kv.second.sr, &ch});
-            pdescs.push_back(th_pyramid_desc{ch.d_wav, ch.d_pyr, ch.n, ch.pyr_levels, 1});
+            pdescs.push_back(th_pyramid_desc{ch.d_wav, ch.d_pyr, ch.n, ch.pyr_levels, PYR_FIRST});
         }
     rc = th_waveform_pyramid_dev(c, pdescs.data(), pdescs.size());
     if (rc == TH_OK) rc = compute_specs(tm, setting_of(tm), chans, created, &fresh);
@@ -1260,19 +1262,30 @@ TH_API int th_tm_get_waveform_tile(th_tm *tm, size_t id, uint32_t ch, uint32_t l
         int rc = acquire_slot(tm, &lease.slot);
         if (rc != TH_OK) return rc;
         ReaderSlot &sl = *lease.slot;
-        if (lv == 0) {
-            // level 0 is not materialised: a one-sample bin is (x, x, x) (render_tiles.rs:261-279 on a slice of one sample:
-            // min = max = x, mean = x / 1) — copy the samples (a third of the bytes) and expand them here
-            TH_HIP(hipMemcpyAsync(sl.h_tile, c->d_wav + start, bins * 4, hipMemcpyDeviceToHost, sl.stream));
+        if (lv < PYR_FIRST) {
+            // levels 0 and 1 are not materialised: copy the tile's samples (4 / 8 KB against 12 KB of bins) and form the bins
+            // here exactly as waveform_bin_stats does for short slices (render_tiles.rs:261-279: f32::min / f32::max folds,
+            // sequential sum / len — one or two samples per bin)
+            const size_t spb_lv = (size_t)1 << lv;
+            const size_t s0 = lv == level ? start : 0, s1 = std::min<size_t>(c->n, s0 + bins * spb_lv);
+            TH_HIP(hipMemcpyAsync(sl.h_tile, c->d_wav + s0, (s1 - s0) * 4, hipMemcpyDeviceToHost, sl.stream));
             TH_HIP(hipStreamSynchronize(sl.stream));
             const float *x = reinterpret_cast<const float *>(sl.h_tile);
             for (size_t b = 0; b < bins; b++) {
-                std::memcpy(out + 24 + 12 * b, &x[b], 4);
-                std::memcpy(out + 28 + 12 * b, &x[b], 4);
-                std::memcpy(out + 32 + 12 * b, &x[b], 4);
+                const size_t a = b * spb_lv, e = std::min(s1 - s0, a + spb_lv);
+                float mn = INFINITY, mx = -INFINITY, sum = 0.0f;
+                for (size_t i = a; i < e; i++) {
+                    mn = std::fmin(mn, x[i]);
+                    mx = std::fmax(mx, x[i]);
+                    sum = sum + x[i];
+                }
+                const float mean = sum / (float)(e - a);
+                std::memcpy(out + 24 + 12 * b, &mn, 4);
+                std::memcpy(out + 28 + 12 * b, &mx, 4);
+                std::memcpy(out + 32 + 12 * b, &mean, 4);
             }
         } else {
-            const float *d_src = c->d_pyr + (th_waveform_pyramid_offset(c->n, lv) - th_waveform_pyramid_offset(c->n, 1)) + 3 * first_bin;
+            const float *d_src = c->d_pyr + (th_waveform_pyramid_offset(c->n, lv) - th_waveform_pyramid_offset(c->n, PYR_FIRST)) + 3 * first_bin;
             TH_HIP(hipMemcpyAsync(sl.h_tile, d_src, bins * 12, hipMemcpyDeviceToHost, sl.stream));
             TH_HIP(hipStreamSynchronize(sl.stream));
             std::memcpy(out + 24, sl.h_tile, bins * 12);
