@@ -1194,7 +1194,7 @@ size_t stft_generic_lds_bytes(const StftGeom &g) { return 2 * (size_t)g.nc * siz
 uint32_t stft_generic_scratch_grid(const StftGeom &g, uint32_t n_tiles, uint32_t n_cu) {
     if (stft_generic_lds_bytes(g) <= 128 * 1024) return 0;
     const size_t per_wg = stft_generic_lds_bytes(g);
-    const size_t cap = ((size_t)1 << 30) / per_wg;  // at most 1 GiB of scratch
+    const size_t cap = ((size_t)1 << 28) / per_wg;  // at most 256 MiB of scratch per plan (1024 workgroups at n_fft 32768)
     const size_t want = (size_t)n_cu * 4;           // 4 workgroups of 256 threads per CU
     return (uint32_t)std::max<size_t>(1, std::min<size_t>({(size_t)n_tiles, want, cap}));
 }
