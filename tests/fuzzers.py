@@ -164,6 +164,23 @@ def fuzz_track_manager(ctx, seed=1, max_cases=10 ** 9, max_seconds=30.0):
                 assert np.array_equal(img, orc.convert_spectrogram_to_img(got, r, (lo, hi), 258)), (setting, sr, r)
                 _, srev = tm.revisions()
                 assert tm.get_spectrogram_tile(tid, ch, 0, 0, 0, 0) == orc.encode_spectrogram_tile(img, cmap, srev, 0, 0, 0, 0)
+            # waveform tiles of random levels (0 and 1 come from the samples, 2 .. from the resident pyramid, levels above the
+            # last one are a single bin) against the oracle's encode_waveform_tile
+            wrev, _ = tm.revisions()
+            for _ in range(3):
+                tid = int(rng.choice(list(tracks)))
+                sr_, wav_ = tracks[tid]
+                ch_ = int(rng.integers(0, wav_.shape[0]))
+                level = int(rng.integers(0, 17))
+                n_t = -(-(-(-wav_.shape[1] // (1 << level))) // 1024)
+                t_ = int(rng.integers(0, n_t + 1))
+                got_t, want_t = tm.get_waveform_tile(tid, ch_, level, t_), orc.encode_waveform_tile(wav_[ch_], wrev, level, t_)
+                assert got_t[:24] == want_t[:24], (tid, ch_, level, t_)
+                gb, wb = np.frombuffer(got_t[24:], np.float32).reshape(-1, 3), np.frombuffer(want_t[24:], np.float32).reshape(-1, 3)
+                assert gb.shape == wb.shape and np.array_equal(gb[:, :2], wb[:, :2]), (tid, ch_, level, t_)
+                if gb.size:
+                    tol = 0.0 if level <= 4 else 1e-6 * float(np.abs(wav_[ch_]).max())
+                    assert np.abs(gb[:, 2] - wb[:, 2]).max() <= tol, (tid, ch_, level, t_)
             # the batched fetch answers a random mix of requests (level 0, LOD, past-the-end tiles) like the single-tile call
             keys = list(specs)
             reqs = [(*keys[int(rng.integers(0, len(keys)))], int(rng.integers(0, 3)), int(rng.integers(0, 2)), int(rng.integers(0, 3)), 0)
