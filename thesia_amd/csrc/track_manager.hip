@@ -1204,10 +1204,10 @@ TH_API int th_tm_get_spectrogram_tiles(th_tm *tm, const th_tile_request *reqs, s
         uint8_t *rec = out + offsets[i];
         if (it.single) {
             size_t len = 0;
-            int rc = th_encode_spectrogram_tile_dev(tm->ctx, find_channel(tm, r.id, r.ch)->d_img, find_channel(tm, r.id, r.ch)->img_h,
-                                                    find_channel(tm, r.id, r.ch)->img_w, find_channel(tm, r.id, r.ch)->img_pitch,
-                                                    tm->colormap_rgba.data(), tm->colormap_rgba.size(), revision, r.level_x, r.level_y,
-                                                    r.tile_x, r.tile_y, rec, offsets[i + 1] - offsets[i], &len);
+            const Channel *c = find_channel(tm, r.id, r.ch);  // (checked in the first pass; the shared lock is still held)
+            int rc = th_encode_spectrogram_tile_dev(tm->ctx, c->d_img, c->img_h, c->img_w, c->img_pitch, tm->colormap_rgba.data(),
+                                                    tm->colormap_rgba.size(), revision, r.level_x, r.level_y, r.tile_x, r.tile_y,
+                                                    rec, offsets[i + 1] - offsets[i], &len);
             if (rc != TH_OK) return rc;
             continue;
         }
