@@ -19,7 +19,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "stft" not in k and "spec_to_img" not in k and "raster" not in k and "waveform" not in k:
+        if not any(t in k for t in ("stft", "spec_to_img", "raster", "waveform", "mel_")):
             continue
         agg[k.split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:

@@ -335,6 +335,8 @@ def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
                                                     (44100, 2048, 512, 2048, 17), (16000, 640, 160, 1024, 0),
                                                     (22050, 884, 221, 1024, 0), (48000, 1024, 256, 1024, 128),
                                                     (8000, 320, 80, 512, 0), (16000, 512, 128, 512, 64),
+                                                    (11025, 441, 110, 512, 0), (8000, 512, 128, 512, 512),
+                                                    (16000, 400, 50, 512, 5), (12000, 512, 256, 512, 33),
                                                     (192000, 7680, 1920, 8192, 0), (48000, 16384, 4096, 16384, 200)])
 def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     """The three mel paths against the oracle on a ragged batch: the filterbank fused into the wave kernel's epilogue
@@ -346,12 +348,20 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     wavs = [synth_track(31 + i, sr, n) for i, n in enumerate(lens)]
     want = [orc.calc_spec(w, win, hop, n_fft, mel_fb=fb) for w in wavs]
     fft_kernel = "stft_wave_kernel" if n_fft <= 4096 else "stft_block_kernel"  # (n_fft 512: the multi-frame wave kernel)
-    mfma = fft_kernel + "+mel_mfma_kernel" if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
+    # (n_fft 512 under filters of at most 8 bins — the default mel counts of 8-12 kHz audio: banded sums by mel_rows_kernel
+    # instead of the matrix cores; selector 7 keeps mel_mfma_kernel)
+    nz = fb != 0
+    widest = int((nz.shape[0] - np.argmax(nz[::-1], axis=0) - np.argmax(nz, axis=0))[nz.any(axis=0)].max())
+    rows = n_fft == 512 and widest <= 8
+    assert rows == ((sr, n_mel) in ((8000, 0), (11025, 0), (8000, 512)))
+    mfma = fft_kernel + ("+mel_rows_kernel" if rows else "+mel_mfma_kernel") if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
     # auto: the fused epilogue for n_fft 2048 and (when the piece table fits: <= 512 pieces) 1024, else the matrix-core path
     fused = "stft_wave_kernel(fused mel)"
-    for which, name in ((1, "stft_generic_kernel"), (3, mfma), (0, None)):
-        if which == 3 and name == "stft_generic_kernel":
+    for which, name in ((1, "stft_generic_kernel"), (3, mfma), (7, fft_kernel + "+mel_mfma_kernel"), (0, None)):
+        if which in (3, 7) and mfma == "stft_generic_kernel":
             continue  # more than 512 mels: there is no matrix-core path to force
+        if which == 7 and not rows:
+            continue
         plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
         if which:
             plan.set_kernel(which)

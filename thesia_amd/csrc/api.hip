@@ -383,7 +383,7 @@ bool th_plan::use_wave() const {
 // mel plans on the wave kernel: the filterbank fused into the FFT kernel's epilogue where its table fits (n_fft 1024 /
 // 2048 at the default launch shape), else amplitude out of the FFT kernel and the filterbank on the matrix cores
 bool th_plan::use_mel_fused() const {
-    return g.n_mel != 0 && use_wave() && kernel_choice != 3 && d_mel_fuse != nullptr &&
+    return g.n_mel != 0 && use_wave() && kernel_choice != 3 && kernel_choice != 7 && d_mel_fuse != nullptr &&
            th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words);
 }
 bool th_plan::use_mel_mfma() const { return g.n_mel != 0 && use_wave() && !use_mel_fused(); }
@@ -398,6 +398,7 @@ static void plan_free(th_plan *p) {
     if (p->d_mel_bt) (void)hipFree(p->d_mel_bt);
     if (p->d_mel_band) (void)hipFree(p->d_mel_band);
     if (p->d_mel_slice) (void)hipFree(p->d_mel_slice);
+    if (p->d_mel_rows) (void)hipFree(p->d_mel_rows);
     if (p->d_mel_fuse) (void)hipFree(p->d_mel_fuse);
     p->amp_buf.release();
     p->chunk_mm.release();
@@ -571,7 +572,25 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
                 slice.push_back(nt);
             }
             p->mel_slices = (uint32_t)slice.size() - 1;
-            rc = up((void **)&p->d_mel_bt, bt.data(), bt.size() * sizeof(float));
+            {   // short rows under narrow filters (n_fft 512 at the default mel counts): the per-mel table of mel_rows_kernel
+                uint32_t widest = 0;
+                for (size_t m = 0; m < n_mel; m++) widest = std::max(widest, hi[m] - lo[m]);
+                const uint32_t ng = (uint32_t)((n_mel + 63) / 64);
+                if (kb_n <= (uint32_t)th::MEL_ROWS_NKB && g.n_freq - 1 + th::MEL_ROWS_W <= 16 * th::MEL_ROWS_NKB + 4 &&  // (reads stay in the LDS row)
+                    widest <= (uint32_t)th::MEL_ROWS_W && ng <= (uint32_t)th::MEL_ROWS_MAX_GROUPS) {
+                    constexpr uint32_t W = th::MEL_ROWS_W;
+                    std::vector<uint32_t> tab((size_t)ng * (W + 1) * 64, 0u);
+                    for (size_t m = 0; m < n_mel; m++) {
+                        const size_t at = (m / 64) * (W + 1) * 64 + m % 64;
+                        tab[at] = lo[m];
+                        for (uint32_t t = 0; t < W && lo[m] + t < hi[m]; t++)
+                            std::memcpy(&tab[at + (1 + t) * 64], &p->h_mel_fb[(size_t)(lo[m] + t) * n_mel + m], 4);
+                    }
+                    p->mel_rows_groups = ng;
+                    rc = up((void **)&p->d_mel_rows, tab.data(), tab.size() * sizeof(uint32_t));
+                }
+            }
+            if (rc == TH_OK) rc = up((void **)&p->d_mel_bt, bt.data(), bt.size() * sizeof(float));
             if (rc == TH_OK) rc = up((void **)&p->d_mel_band, band.data(), band.size() * sizeof(uint32_t));
             if (rc == TH_OK) rc = up((void **)&p->d_mel_slice, slice.data(), slice.size() * sizeof(uint32_t));
         }
@@ -621,9 +640,10 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     TH_TRY
     TH_REQUIRE(p, "plan is NULL");
     // bits 0-7: 0 auto, 1 generic, 2 wave, 3 wave + matrix-core mel, 4 wave without the phased mode, 5 phased mode also with the
-    // fused mel epilogue, 6 wave with the two-frames-per-wave plan at n_fft 1024;  bits 8-15 (tuning): waves per workgroup
+    // fused mel epilogue, 6 wave with the two-frames-per-wave plan at n_fft 1024, 7 as 3 with the matrix-core kernel also where
+    // the banded-sum kernel for short rows under narrow filters is the default (n_fft 512);  bits 8-15 (tuning): waves per workgroup
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 6, "kernel selector must be 0 .. 6");
+    TH_REQUIRE(k >= 0 && k <= 7, "kernel selector must be 0 .. 7");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     // the multi-frame plans (n_fft 512; n_fft 1024 under selector 6) are instantiated for 8, 12 and 16 waves only
@@ -641,6 +661,7 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
 TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (!p) return "";
     if (p->use_mel_fused()) return "stft_wave_kernel(fused mel)";
+    if (p->use_mel_mfma() && p->d_mel_rows != nullptr && p->kernel_choice != 7) return "stft_wave_kernel+mel_rows_kernel";
     if (p->use_mel_mfma()) return th::stft_is_block_plan(p->g) ? "stft_block_kernel+mel_mfma_kernel" : "stft_wave_kernel+mel_mfma_kernel";
     if (p->use_wave() && th::stft_is_block_plan(p->g)) return "stft_block_kernel";
     return p->use_wave() ? "stft_wave_kernel" : "stft_generic_kernel";
@@ -664,7 +685,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     const bool wave = p->use_wave();
     const bool mel_mfma = p->use_mel_mfma(), mel_fused = p->use_mel_fused();
     if (p->kernel_choice >= 2 && !wave)
-        return fail(TH_ERR_UNSUPPORTED, "the wave kernels cover n_fft in {512 (linear only), 1024, 2048, 4096} (mel: n_mel <= 512) and 8192 / 16384 (linear only)");
+        return fail(TH_ERR_UNSUPPORTED, "the wave kernels cover n_fft 512 .. 32768 (mel: n_mel <= 512)");
     StftGeom g = p->g;       // main launch
     StftGeom ge = p->g;      // edge launch (generic kernel)
     const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);
@@ -930,7 +951,11 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         TH_HIP(launch_wave_post((const th::WavePostJob *)p->post_jobs.dptr, n_post, chunk_mm, d_minmax, all_in_wave,
                                 p->d_queue_head, dB_range, range_done ? d_range : nullptr, c->stream));
         p->queue_dirty = false;
-        if (mel_mfma)
+        if (mel_mfma && p->d_mel_rows != nullptr && p->kernel_choice != 7)
+            TH_HIP(launch_mel_rows((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
+                                   (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_rows, p->mel_rows_groups,
+                                   g.n_mel, d_minmax, c->n_cu, c->stream));
+        else if (mel_mfma)
             TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
                                    (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_bt, p->d_mel_band,
                                    p->d_mel_slice, p->mel_slices, p->mel_zero_block, g.n_mel, d_minmax, c->stream));

@@ -84,6 +84,8 @@ struct th_plan {
     float *d_mel_bt = nullptr;
     uint32_t *d_mel_band = nullptr, *d_mel_slice = nullptr;  // + slices of the tile range with ~equal K-group counts
     uint32_t mel_kblocks = 0, mel_ntiles = 0, mel_zero_block = 0, mel_slices = 0;
+    uint32_t *d_mel_rows = nullptr;  // short rows under narrow filters: the per-mel table of mel_rows_kernel (kernels.h)
+    uint32_t mel_rows_groups = 0;
     th::DeviceTable amp_buf, mel_jobs, mel_tile_start;  // amplitude scratch + job tables of mel_mfma_kernel
     size_t amp_zeroed = 0;                               // bytes of amp_buf known to be zero-initialised
     th::DeviceTable chunk_mm;                            // (min, max) per chunk of the wave kernel's last launch

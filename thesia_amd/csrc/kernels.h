@@ -77,6 +77,13 @@ constexpr uint32_t MEL_TILE_FRAMES = 64 * MEL_MT;         // 4 waves x MEL_MT x 
 hipError_t launch_mel_mfma(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
                            uint32_t amp_pitch, const float *d_bt, const uint32_t *d_tile_band, const uint32_t *d_slice_start,
                            uint32_t n_slices, uint32_t zero_block, uint32_t n_mel, float *d_minmax, hipStream_t s);
+// short rows (at most MEL_ROWS_NKB * 16 bins: n_fft 512) under narrow filters (at most MEL_ROWS_W bins each, at most
+// 64 * MEL_ROWS_MAX_GROUPS mels): banded sums, lane = mel.  d_tab: [n_groups][1 + MEL_ROWS_W][64] words — the first bin of
+// mel 64 g + lane, then its weights (float bits, zero past the filter's end and for mels >= n_mel)
+constexpr int MEL_ROWS_NKB = 17, MEL_ROWS_W = 8, MEL_ROWS_MAX_GROUPS = 8;
+hipError_t launch_mel_rows(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
+                           uint32_t amp_pitch, const uint32_t *d_tab, uint32_t n_groups, uint32_t n_mel, float *d_minmax,
+                           uint32_t n_cu, hipStream_t s);
 
 // ---- kernels_image.hip
 struct ImgJob {  // device-visible copy of th_img_desc

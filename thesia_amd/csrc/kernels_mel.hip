@@ -185,6 +185,143 @@ __global__ __launch_bounds__(256) void mel_mfma_kernel(const MelJob *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Short rows (n_fft 512: 257 bins) with mel counts near the bin count (the app's defaults at 8-12 kHz: 245-257 mels):
+// mel_rows_kernel.  A filter is then 1-6 bins wide, a 16 x 16 block of the filterbank holds ~40 non-zeros, and the matrix
+// cores spend 240 dependent 32-cycle MFMAs per 16 frames on them (measured: mel_mfma_kernel 2.2 ms for the 2.3 M frames of
+// the 8 kHz default = 2.1 TB/s; a whole-row MFMA variant 1.39 ms, its loads of B ordered behind the row prefetch in vmcnt).
+// Here the product is what it is, a banded sum: lane = mel (64 g + lane, g < n_groups <= 8), its W <= 8 weights and its
+// first bin live in registers for the life of the (persistent) wave, and per frame a mel costs W LDS reads + W FMAs.
+// A wave stages 16 whole amplitude rows in LDS (17 coalesced 16-byte loads per lane, the next 16 rows requested before
+// this unit's sums start: nothing else of the unit loads from memory, so the prefetch really runs ahead) and stores every
+// output row as 256-byte spans.  Sum order: ascending bins, one FMA each, from 0 (the generic kernel's order).
+// tab: [n_groups][1 + W][64] words: first bin, then W weights (float bits; zero past the filter's last bin).
+// ------------------------------------------------------------------------------------------
+constexpr int MEL_ROWS_COLS = 16 * MEL_ROWS_NKB;      // columns staged per row
+constexpr int MEL_ROWS_C4 = MEL_ROWS_COLS / 4;        // 16-byte columns per row
+constexpr int MEL_ROWS_AP = MEL_ROWS_COLS + 4;        // LDS row pitch (floats)
+constexpr int MEL_ROWS_NLD = (16 * MEL_ROWS_C4 + 63) / 64;
+static_assert(16 * MEL_ROWS_C4 == 64 * MEL_ROWS_NLD, "the 16-row tile is a whole number of wave loads");
+// (a filter's W reads start below n_freq and must end inside the row: the host checks n_freq - 1 + W <= MEL_ROWS_AP)
+template <int W>
+__global__ __launch_bounds__(256) void mel_rows_kernel(const MelJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start,
+                                                       uint32_t n_jobs, uint32_t n_tiles, uint32_t amp_pitch,
+                                                       const uint32_t *__restrict__ tab, uint32_t n_groups, uint32_t n_mel,
+                                                       float *__restrict__ minmax) {
+    constexpr int MAXG = MEL_ROWS_MAX_GROUPS;
+    __shared__ __attribute__((aligned(16))) float lds_a[4][16][MEL_ROWS_AP];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *const tile = &lds_a[wave][0][0];
+    // Persistent waves: a "unit" is one 16-frame tile of a workgroup tile of the host's table (MEL_TILE_FRAMES frames =
+    // 4 MEL_MT units); every wave takes a contiguous range of units, so it stays within a channel for long stretches
+    // (one (min, max) atomic pair per channel it touches) and always has the next unit's rows in flight.
+    constexpr uint32_t UPT = 4 * MEL_MT;
+    const uint32_t n_units = n_tiles * UPT, n_w = gridDim.x * 4u, per = (n_units + n_w - 1) / n_w;
+    const uint32_t q_end = min(n_units, (blockIdx.x * 4u + wave + 1u) * per);
+    uint32_t q = (blockIdx.x * 4u + wave) * per;
+    if (q >= q_end) return;
+    uint32_t ji = mel_find_job(tile_start, n_jobs, q / UPT);
+    // the next unit with frames at or after q: (job index, first frame); false past the wave's range
+    auto locate = [&](uint32_t &qq, uint32_t &jj, uint32_t &frame0) {
+        for (; qq < q_end; qq++) {
+            const uint32_t t = qq / UPT;
+            while (t >= tile_start[jj + 1]) jj++;
+            frame0 = jobs[jj].f_begin + (t - tile_start[jj]) * MEL_TILE_FRAMES + 16u * (qq % UPT);
+            if (frame0 < jobs[jj].f_end) return true;
+        }
+        return false;
+    };
+    f32x4 raw[MEL_ROWS_NLD];
+    auto fetch = [&](const MelJob &jb, uint32_t frame0) {  // rows past the end of the range are clamped here and never stored
+        const gptr<const float> amp = as_global(jb.amp);
+#pragma unroll
+        for (int c = 0; c < MEL_ROWS_NLD; c++) {
+            const uint32_t idx = 64u * c + lane, r = idx / MEL_ROWS_C4, c4 = idx - r * MEL_ROWS_C4;
+            raw[c] = *reinterpret_cast<gptr<const f32x4>>(amp + (size_t)min(frame0 + r, jb.f_end - 1) * amp_pitch + 4u * c4);
+        }
+    };
+    float lmin = __builtin_inff(), lmax = -__builtin_inff();
+    auto flush = [&](uint32_t mm_index) {
+        if (minmax == nullptr) return;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lmin = fminf(lmin, __shfl_xor(lmin, o, 64));
+            lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+        }
+        if (lane == 0) {
+            mel_atomic_min(&minmax[2 * mm_index], lmin);
+            mel_atomic_max(&minmax[2 * mm_index + 1], lmax);
+        }
+        lmin = __builtin_inff();
+        lmax = -__builtin_inff();
+    };
+    uint32_t frame0 = 0;
+    bool have = locate(q, ji, frame0);
+    if (have) fetch(jobs[ji], frame0);
+    // the lane's filters: first bin (as an LDS float offset) and weights
+    uint32_t lo[MAXG];
+    float w[MAXG][W];
+#pragma unroll
+    for (int g = 0; g < MAXG; g++) {
+        const uint32_t gg = (uint32_t)g < n_groups ? g : n_groups - 1u;
+        lo[g] = tab[(gg * (W + 1)) * 64u + lane];
+#pragma unroll
+        for (int t = 0; t < W; t++) w[g][t] = __uint_as_float(tab[(gg * (W + 1) + 1 + t) * 64u + lane]);
+    }
+    while (have) {
+        const MelJob job = jobs[ji];
+        mel_wave_sync();  // the previous unit's reads are done
+#pragma unroll
+        for (int c = 0; c < MEL_ROWS_NLD; c++) {
+            const uint32_t idx = 64u * c + lane, r = idx / MEL_ROWS_C4, c4 = idx - r * MEL_ROWS_C4;
+            *reinterpret_cast<f32x4 *>(tile + r * MEL_ROWS_AP + 4u * c4) = raw[c];
+        }
+        mel_wave_sync();
+        uint32_t qn = q + 1, jn = ji, fn = 0;
+        const bool have_next = locate(qn, jn, fn);
+        if (have_next) fetch(jobs[jn], fn);
+        const uint32_t rows = min(16u, job.f_end - frame0);
+        gptr<float> orow = as_global(job.spec) + (size_t)frame0 * job.spec_pitch + lane;
+        const float *row = tile;
+        for (uint32_t r = 0; r < rows; r++, row += MEL_ROWS_AP, orow += job.spec_pitch) {
+#pragma unroll
+            for (int g = 0; g < MAXG; g++) {
+                if ((uint32_t)g < n_groups) {  // wave-uniform
+                    float a[W];
+#pragma unroll
+                    for (int t = 0; t < W; t++) a[t] = row[lo[g] + t];
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < W; t++) acc = __builtin_fmaf(a[t], w[g][t], acc);
+                    if (64u * g + lane < n_mel) {
+                        const float d = 6.02059991327962390f * __builtin_amdgcn_logf(acc);  // dB_from_amp (decibel.rs:179-202)
+                        orow[64 * g] = d;
+                        lmin = fminf(lmin, d);
+                        lmax = fmaxf(lmax, d);
+                    }
+                }
+            }
+        }
+        if (!have_next || jn != ji) flush(job.mm_index);
+        have = have_next;
+        q = qn;
+        ji = jn;
+        frame0 = fn;
+    }
+}
+
+hipError_t launch_mel_rows(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
+                           uint32_t amp_pitch, const uint32_t *d_tab, uint32_t n_groups, uint32_t n_mel, float *d_minmax,
+                           uint32_t n_cu, hipStream_t s) {
+    if (!n_tiles) return hipSuccess;
+    if (n_groups == 0 || n_groups > (uint32_t)MEL_ROWS_MAX_GROUPS || amp_pitch < (uint32_t)MEL_ROWS_COLS) return hipErrorInvalidValue;
+    const uint32_t grid = n_tiles < 2u * n_cu ? n_tiles : 2u * n_cu;  // two workgroups per CU (LDS)
+    hipLaunchKernelGGL(mel_rows_kernel<MEL_ROWS_W>, dim3(grid), dim3(256), 0, s, d_jobs, d_tile_start, n_jobs, n_tiles,
+                       amp_pitch, d_tab, n_groups, n_mel, d_minmax);
+    return hipGetLastError();
+}
+
 hipError_t launch_mel_mfma(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
                            uint32_t amp_pitch, const float *d_bt, const uint32_t *d_tile_band, const uint32_t *d_slice_start,
                            uint32_t n_slices, uint32_t zero_block, uint32_t n_mel, float *d_minmax, hipStream_t s) {
