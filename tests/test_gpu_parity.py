@@ -336,6 +336,7 @@ def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
                                                     (22050, 884, 221, 1024, 0), (48000, 1024, 256, 1024, 128),
                                                     (8000, 320, 80, 512, 0), (16000, 512, 128, 512, 64),
                                                     (11025, 441, 110, 512, 0), (8000, 512, 128, 512, 512),
+                                                    (96000, 3840, 960, 4096, 0), (88200, 3528, 882, 4096, 100),
                                                     (16000, 400, 50, 512, 5), (12000, 512, 256, 512, 33),
                                                     (192000, 7680, 1920, 8192, 0), (48000, 16384, 4096, 16384, 200)])
 def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
@@ -1414,7 +1415,9 @@ def test_hip_graph_replay_of_a_single_track_step(ctx, golden_dir):
                                            (1700, 400, 2048), (1900, 500, 2048), (1920, 479, 2048), (1280, 320, 2048),
                                            (1200, 300, 2048), (640, 160, 1024), (884, 221, 1024), (800, 255, 1024),
                                            (1920, 240, 2048), (1920, 120, 2048), (1920, 60, 2048), (1764, 147, 2048),
-                                           (1905, 127, 2048), (1600, 200, 2048), (1000, 25, 2048), (640, 80, 1024), (882, 63, 1024), (1920, 960, 2048), (1764, 882, 2048), (1900, 801, 2048)])
+                                           (1905, 127, 2048), (1600, 200, 2048), (1000, 25, 2048), (640, 80, 1024), (882, 63, 1024), (1920, 960, 2048), (1764, 882, 2048), (1900, 801, 2048),
+                                           (3840, 960, 4096), (3528, 882, 4096), (3840, 480, 4096), (3528, 441, 4096), (3900, 961, 4096), (3969, 799, 4096),
+                                           (3840, 240, 4096), (3528, 110, 4096), (3840, 1920, 4096), (3528, 1764, 4096)])
 def test_phased_register_reuse_for_hop_480(ctx, win, hop, n_fft):
     """hop = 480 (the app's 40 ms / 4 at 48 kHz) with n_fft = 2048: the wave kernel loads every frame from the 128-sample grid
     below its first window sample (|X| does not change when the windowed frame moves inside its zero padding) and reuses
@@ -1422,7 +1425,8 @@ def test_phased_register_reuse_for_hop_480(ctx, win, hop, n_fft):
     the unphased wave kernel to f32-FFT accuracy, and a ragged batch must equal single launches bit for bit."""
     # (hop 480: "phased" — offsets cycle 0, 96, 64, 32, slot rotation; other hops in (384, 512), e.g. 441 at 44.1 kHz:
     # "dynamic" — offset and reuse decided per frame, odd offsets through the one-sample-shifted window table)
-    # (also n_fft = 2048 with hops in (256, 384), 32 kHz: 1280 / 320, and n_fft = 1024 with hops in (128, 256), 16 kHz: 640 / 160)
+    # (also n_fft = 2048 with hops in (256, 384), 32 kHz: 1280 / 320, and n_fft = 1024 with hops in (128, 256), 16 kHz: 640 / 160;
+    # n_fft = 4096 — the 40 ms default at 88.2 / 96 kHz, 3528 / 882 and 3840 / 960 — with 7 waves per workgroup)
     sr = 48000
     wavs = [synth_track(900 + i, sr, n) for i, n in enumerate((131072, 40000, 2048, 2049, 3000, 97531))]
     plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)

@@ -688,7 +688,6 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         return fail(TH_ERR_UNSUPPORTED, "the wave kernels cover n_fft 512 .. 32768 (mel: n_mel <= 512)");
     StftGeom g = p->g;       // main launch
     StftGeom ge = p->g;      // edge launch (generic kernel)
-    const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);
     // wave kernel: chunk of consecutive frames one wave walks (the first frame of a chunk loads
     // n_fft samples, the rest only hop new ones).  32 amortises that well on large batches; small
     // batches (one track) get shorter chunks so that every wave of the chip has work.
@@ -699,10 +698,12 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     // (not with the fused mel epilogue unless selector 5 asks for it: measured no gain there, with or without idle gaps —
     // 48 kHz / 347 mels 0.522 vs 0.521 ms, 44.1 kHz / 370 mels 0.513 vs 0.541 — the window then comes from LDS instead of
     // registers and the mel kernel is not bound by its loads)
-    const int phase_mode = (wave && !mel_mfma && (!mel_fused || p->kernel_choice == 5) && p->kernel_choice != 4 && p->d_wtab_phased != nullptr)
+    // (n_fft 4096 — the 40 ms default at 88.2 / 96 kHz — also with amplitude output for the matrix-core mel kernel)
+    const int phase_mode = (wave && (!mel_mfma || g.log2_nc == 11) && (!mel_fused || p->kernel_choice == 5) && p->kernel_choice != 4 && p->d_wtab_phased != nullptr)
                                ? th::stft_wave_phased_mode(g, p->wave_waves) : 0;
     const bool phased = phase_mode != 0;
     g.phased = (uint32_t)phase_mode;
+    const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);
     // (multi-frame kernel with staged loads and hop % 4 == 2: see stft_wave_multi_tail_guard)
     const uint64_t tail_guard = (wave && !phased && th::stft_wave_multi_applies(g, mel_mfma ? 1 : (mel_fused ? 2 : 0)) && g.log2_nc == 8)
                                     ? th::stft_wave_multi_tail_guard(g) : 0;

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     constexpr int DYN_K = DYN ? -SHIFT - 16 : 0;
     static_assert(PHASED || DYN || (SHIFT >= 0 && SHIFT < P), "shift must leave something to reuse");
     static_assert(!PHASED || (P == 16 && OUT != 1), "phased mode: n_fft = 2048, dB output");
-    static_assert(!DYN || (DYN_K >= 0 && DYN_K + 1 < P && OUT != 1), "dynamic mode: something to reuse, dB output");
+    static_assert(!DYN || (DYN_K >= 0 && DYN_K + 1 < P && (OUT != 1 || LOG2_NC == 11)), "dynamic mode: something to reuse; amplitude output at n_fft 4096 only");
     // zero pairs in front of the window table(s): room to read them up to 96 (127) samples lower; DYN: even + odd table
     constexpr int WPAD = PHASED ? 48 : DYN ? 64 + NC + 64 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -559,7 +559,9 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     TH_FETCH_FIRST();
     // n_fft 4096: the window pairs are stored in the order the lanes read them (lane l reads the pair of column
     // lane_col(l) = (l >> 3) + 8 (l & 7): consecutive lanes would be 64 bytes apart, a 2-way bank conflict on all 32 reads)
-    constexpr bool WPERM = W::PLANES32 || (W::PLANES8 && !PHASED && !DYN);  // (n_fft 1024: the same column order)
+    // (the grid-aligned modes read their shifted tables by column: at n_fft 4096 that is the 2-way conflict again, on 32 of
+    // the frame's ~250 LDS instructions, against 22 of 30 global loads saved)
+    constexpr bool WPERM = (W::PLANES32 || W::PLANES8) && !PHASED && !DYN;  // (n_fft 1024: the same column order)
     static_assert(!WPERM || (!PHASED && !DYN), "the shifted window tables are read by column");
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
         const uint32_t col = i & 63u, li = WPERM ? (i & ~63u) + 8u * (col & 7u) + (col >> 3) : i;
@@ -1260,11 +1262,14 @@ uint32_t stft_wave_multi_tail_guard(const StftGeom &g) {
 template <int LOG2_NC>
 struct WaveLaunchCfg {
     static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? TH_WAVES_4096 : 12;  // n_fft = 4096: LDS-bound (17 KB slab per wave): 8 waves = 160 KB exactly
+    // launch shape of the grid-aligned (phased / dynamic) modes: n_fft 4096 gives one wave's slab to the second window table
+    static constexpr int GRID_WAVES = LOG2_NC == 11 ? 7 : DEFAULT_WAVES;
     // register-resident tables by VGPR budget (512 / waves per SIMD); mirror-local path only for bits 2, 3
     static constexpr int resident(int waves) {
         // n_fft 4096: split twiddles in registers (32 VGPRs) free their 16 KB table; with the pass-2 constants too (20
         // more) the eighth wave's slab fits exactly (160 KB)
-        if (LOG2_NC == 11) return waves <= 7 ? 8 : waves == 8 ? 10 : 0;
+        // (7 waves: the same, which leaves exactly the 17 KB the second window table of the dynamic mode needs)
+        if (LOG2_NC == 11) return waves <= 6 ? 8 : waves <= 8 ? 10 : 0;
         if (LOG2_NC != 10) return 0;
         return waves <= 8 ? 15 : waves <= 12 ? TH_RES12 : 0;
     }
@@ -1314,8 +1319,8 @@ template <int LOG2_NC, int WAVES, int SHIFT>
 static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
-    if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
-        if constexpr (SHIFT >= 0) {
+    if constexpr (WAVES == (SHIFT < 0 ? WaveLaunchCfg<LOG2_NC>::GRID_WAVES : WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES)) {
+        if constexpr (SHIFT >= 0 || (SHIFT <= -16 && LOG2_NC == 11)) {
             if (out.mode == 1)
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                                                                         d_tw, nullptr, d_queue_head, n_cu, out, s);
@@ -1347,7 +1352,7 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     constexpr int P = WaveFft<LOG2_NC>::P;
     if (g.phased) {  // grid-aligned loads (see stft_wave_kernel): only the default launch shapes are instantiated
-        if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
+        if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::GRID_WAVES) {
             const uint32_t k = g.hop / 128;
 #define TH_DYN_CASE(L2, K)                                                                                            \
     if constexpr (LOG2_NC == (L2))                                                                                    \
@@ -1366,6 +1371,13 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
             TH_DYN_CASE(10, 0)  // 48 kHz, t_overlap 16 / 32: 1920 / 120, 1920 / 60
             TH_DYN_CASE(9, 1)   // 16 kHz: 640 / 160, 22.05 kHz: 884 / 221
             TH_DYN_CASE(9, 0)   // 16 kHz, t_overlap 8 .. 32: 640 / 80
+            TH_DYN_CASE(11, 7)  // 96 kHz: 3840 / 960
+            TH_DYN_CASE(11, 6)  // 88.2 kHz: 3528 / 882
+            TH_DYN_CASE(11, 3)  // 96 / 88.2 kHz, t_overlap 8: 3840 / 480, 3528 / 441
+            TH_DYN_CASE(11, 1)  // t_overlap 16: 3840 / 240, 3528 / 220
+            TH_DYN_CASE(11, 0)  // t_overlap 32: 3840 / 120, 3528 / 110
+            TH_DYN_CASE(11, 15) // 96 kHz, t_overlap 2: 3840 / 1920
+            TH_DYN_CASE(11, 13) // 88.2 kHz, t_overlap 2: 3528 / 1764
 #undef TH_DYN_CASE
         }
         return hipErrorInvalidValue;
@@ -1431,6 +1443,9 @@ int stft_wave_phased_mode(const StftGeom &g, int waves) {
     }
     if (g.log2_nc == 9 && (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) && k <= 1 && g.n_fft - g.win >= 127)
         return 2;  // (k = 0: 16 kHz with t_overlap 8 .. 32, 640 / 80 / 1024)
+    // n_fft 4096 (the 40 ms default at 88.2 / 96 kHz): 7 waves per workgroup, the eighth's LDS holds the second window table
+    if (g.log2_nc == 11 && (waves <= 0 || waves == WaveLaunchCfg<11>::GRID_WAVES) && (k == 7 || k == 6 || k == 3 || k <= 1 || k == 15 || k == 13) && g.n_fft - g.win >= 127)
+        return 2;
     return 0;
 }
 
@@ -1455,7 +1470,7 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words) {
 
 int stft_wave_default_waves(const StftGeom &g) {
     switch (g.log2_nc) {
-        case 11: return WaveLaunchCfg<11>::DEFAULT_WAVES;
+        case 11: return g.phased ? WaveLaunchCfg<11>::GRID_WAVES : WaveLaunchCfg<11>::DEFAULT_WAVES;
         case 10: return WaveLaunchCfg<10>::DEFAULT_WAVES;
         // n_fft 512 (four frames per wave, staged loads): measured 12 / 2 x 8 / 16 waves per CU — 512/128: 0.77 / 0.70-0.74 /
         // 0.68-0.72 ms, 320/80 (8 kHz default): 1.16-1.18 / 1.21-1.26 / 1.24 ms
