@@ -1376,8 +1376,7 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
             TH_DYN_CASE(11, 3)  // 96 / 88.2 kHz, t_overlap 8: 3840 / 480, 3528 / 441
             TH_DYN_CASE(11, 1)  // t_overlap 16: 3840 / 240, 3528 / 220
             TH_DYN_CASE(11, 0)  // t_overlap 32: 3840 / 120, 3528 / 110
-            TH_DYN_CASE(11, 15) // 96 kHz, t_overlap 2: 3840 / 1920
-            TH_DYN_CASE(11, 13) // 88.2 kHz, t_overlap 2: 3528 / 1764
+            TH_DYN_CASE(11, 13) // 88.2 kHz, t_overlap 2: 3528 / 1764 (96 kHz, 3840 / 1920, k = 15: measured no gain at 7 waves, not instantiated)
 #undef TH_DYN_CASE
         }
         return hipErrorInvalidValue;
@@ -1444,7 +1443,7 @@ int stft_wave_phased_mode(const StftGeom &g, int waves) {
     if (g.log2_nc == 9 && (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) && k <= 1 && g.n_fft - g.win >= 127)
         return 2;  // (k = 0: 16 kHz with t_overlap 8 .. 32, 640 / 80 / 1024)
     // n_fft 4096 (the 40 ms default at 88.2 / 96 kHz): 7 waves per workgroup, the eighth's LDS holds the second window table
-    if (g.log2_nc == 11 && (waves <= 0 || waves == WaveLaunchCfg<11>::GRID_WAVES) && (k == 7 || k == 6 || k == 3 || k <= 1 || k == 15 || k == 13) && g.n_fft - g.win >= 127)
+    if (g.log2_nc == 11 && (waves <= 0 || waves == WaveLaunchCfg<11>::GRID_WAVES) && (k == 7 || k == 6 || k == 3 || k <= 1 || k == 13) && g.n_fft - g.win >= 127)
         return 2;
     return 0;
 }
