@@ -6,6 +6,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final
 rm -rf "$out"; mkdir -p "$out"
+python3 -m pytest tests -x -q -m gpu 2>&1 | tail -4 > "$out/gputest.txt"
 echo "bench" >> "$out/progress.txt"; python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single-track --no-skeleton > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 find "$out/trace" -type f ! -name "*kernel_stats.csv" -delete
@@ -15,6 +16,8 @@ scripts/pmc_stft.sh "$out/pmc_stft1024" --nfft 1024 > "$out/pmc_stft1024.log" 2>
 scripts/pmc_stft.sh "$out/pmc_stft512_multi" --nfft 512 > "$out/pmc_stft512_multi.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stft4096" --nfft 4096 --seconds 60 > "$out/pmc_stft4096.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stftmel" --sr 44100 --tracks 32 --seconds 60 --mel 128 > "$out/pmc_stftmel.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_stft4096dyn" --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 > "$out/pmc_stft4096dyn.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_melrows" --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 > "$out/pmc_melrows.log" 2>&1
 {
   python3 scripts/bench_stft.py --reps 30 --kernel 0 1
   python3 scripts/bench_stft.py --reps 30 --nfft 1024
@@ -46,6 +49,13 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 --kernel 0 1
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 192000 --nfft 8192 --win 7680 --hop 1920 --mel 0 --seconds 8 --kernel 0 1
   python3 scripts/bench_stft.py --reps 30 --tracks 1 --seconds 60
+  # round 3: grid-aligned reuse at n_fft 4096 (selector 4 = without), the banded-sum mel kernel (selector 7 = matrix cores)
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 --kernel 0 4
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 88200 --nfft 4096 --win 3528 --hop 882 --seconds 30 --kernel 0 4
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 96000 --nfft 4096 --win 3840 --hop 480 --seconds 30 --kernel 0 4
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 --mel 0 --kernel 0 4
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 --kernel 0 7
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 11025 --nfft 512 --win 441 --hop 110 --mel 0 --seconds 120 --kernel 0 7
 } >> "$out/bench_stft.txt" 2>&1
 # the RCCL path on one GPU (world size 1): the line bench.py prints with the process group up
 TH_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-single-track --no-full-cfg5 > "$out/force_dist.out" 2> "$out/force_dist.err"; grep "^{" "$out/force_dist.out" | tail -1 > "$out/bench_line_force_dist.json"

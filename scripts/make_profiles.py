@@ -53,7 +53,9 @@ hdr = ("# rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python3
 for name, script in (("stft", "scripts/bench_stft.py"), ("img", "scripts/bench_img.py"),
                      ("stft1024", "scripts/bench_stft.py --nfft 1024"), ("stft512_multi", "scripts/bench_stft.py --nfft 512"),
                      ("stft4096", "scripts/bench_stft.py --nfft 4096 --seconds 60"),
-                     ("stftmel", "scripts/bench_stft.py --sr 44100 --tracks 32 --seconds 60 --mel 128")):
+                     ("stftmel", "scripts/bench_stft.py --sr 44100 --tracks 32 --seconds 60 --mel 128"),
+                     ("stft4096dyn", "scripts/bench_stft.py --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30"),
+                     ("melrows", "scripts/bench_stft.py --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180")):
     p = f"{src}/pmc_{name}/summary.txt"
     if os.path.exists(p):
         open(f"{dst}/{tag}_{name}_pmc_summary.txt", "w").write(hdr.format(script=script) + open(p).read())
