@@ -316,6 +316,7 @@ hipError_t launch_mel_rows(const MelJob *d_jobs, const uint32_t *d_tile_start, u
                            uint32_t n_cu, hipStream_t s) {
     if (!n_tiles) return hipSuccess;
     if (n_groups == 0 || n_groups > (uint32_t)MEL_ROWS_MAX_GROUPS || amp_pitch < (uint32_t)MEL_ROWS_COLS) return hipErrorInvalidValue;
+    if (n_tiles > 0xffffffffu / (4u * MEL_MT)) return hipErrorInvalidValue;  // (the kernel counts 16-frame units in 32 bits)
     const uint32_t grid = n_tiles < 2u * n_cu ? n_tiles : 2u * n_cu;  // two workgroups per CU (LDS)
     hipLaunchKernelGGL(mel_rows_kernel<MEL_ROWS_W>, dim3(grid), dim3(256), 0, s, d_jobs, d_tile_start, n_jobs, n_tiles,
                        amp_pitch, d_tab, n_groups, n_mel, d_minmax);
