@@ -560,7 +560,7 @@ def main():
                  ("96 kHz default, mel scale (404 mels: FFT kernel -> amplitude rows -> matrix cores)", wl.wav, 96000, (3840, 960, 4096, ta.MEL, 0), 0),
                  ("short transform: n_fft 512 / hop 128, linear dB (four frames per wave)", wl.wav, 48000, (512, 128, 512, ta.LINEAR, 0), 0),
                  ("8 kHz default shape: 320 / 80 / 512, linear dB", wl.wav, 8000, (320, 80, 512, ta.LINEAR, 0), 0),
-                 ("8 kHz default, mel scale (257 mels: FFT kernel -> amplitude rows -> banded sums)", wl.wav, 8000, (320, 80, 512, ta.MEL, 0), 0),
+                 ("8 kHz default, mel scale (257 mels: banded sums, lane = mel, in the epilogue of the four-frames-per-wave kernel)", wl.wav, 8000, (320, 80, 512, ta.MEL, 0), 0),
                  ("long transform: n_fft 8192 / hop 2048, linear dB (one workgroup per frame)", wl.wav, 48000, (8192, 2048, 8192, ta.LINEAR, 0), 0),
                  ("long transform: n_fft 16384 / hop 4096, linear dB (one workgroup per frame)", wl.wav, 48000, (16384, 4096, 16384, ta.LINEAR, 0), 0),
                  ("very long transform: n_fft 32768 / hop 8192, linear dB (400 ms window at 48 kHz)", wl.wav, 48000, (32768, 8192, 32768, ta.LINEAR, 0), 0))

@@ -349,8 +349,9 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     wavs = [synth_track(31 + i, sr, n) for i, n in enumerate(lens)]
     want = [orc.calc_spec(w, win, hop, n_fft, mel_fb=fb) for w in wavs]
     fft_kernel = "stft_wave_kernel" if n_fft <= 4096 else "stft_block_kernel"  # (n_fft 512: the multi-frame wave kernel)
-    # (n_fft 512 under filters of at most 8 bins — the default mel counts of 8-12 kHz audio: banded sums by mel_rows_kernel
-    # instead of the matrix cores; selector 7 keeps mel_mfma_kernel)
+    # (n_fft 512 under filters of at most 8 bins — the default mel counts of 8-12 kHz audio: banded sums, lane = mel, as the
+    # epilogue of the four-frames-per-wave FFT kernel (auto), or as mel_rows_kernel over amplitude rows (selector 3); selector 7
+    # keeps mel_mfma_kernel)
     nz = fb != 0
     widest = int((nz.shape[0] - np.argmax(nz[::-1], axis=0) - np.argmax(nz, axis=0))[nz.any(axis=0)].max())
     rows = n_fft == 512 and widest <= 8
@@ -367,7 +368,7 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
         if which:
             plan.set_kernel(which)
         if name is None:
-            assert plan.kernel_name == fused if n_fft == 2048 else plan.kernel_name in (fused, mfma)
+            assert plan.kernel_name == fused if (n_fft == 2048 or rows) else plan.kernel_name in (fused, mfma)
             if (n_fft, want_n_mel) in ((1024, 128), (1024, 385), (1024, 308)):
                 assert plan.kernel_name == fused  # incl. the default mel counts of 16 and 22.05 kHz audio
         else:

@@ -383,8 +383,10 @@ bool th_plan::use_wave() const {
 // mel plans on the wave kernel: the filterbank fused into the FFT kernel's epilogue where its table fits (n_fft 1024 /
 // 2048 at the default launch shape), else amplitude out of the FFT kernel and the filterbank on the matrix cores
 bool th_plan::use_mel_fused() const {
-    return g.n_mel != 0 && use_wave() && kernel_choice != 3 && kernel_choice != 7 && d_mel_fuse != nullptr &&
-           th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words);
+    if (g.n_mel == 0 || !use_wave() || kernel_choice == 3 || kernel_choice == 7) return false;
+    // n_fft 512 under narrow filters: the banded sums of mel_rows_kernel as the epilogue of the four-frames-per-wave kernel
+    if (g.log2_nc == 8) return d_mel_rows != nullptr;
+    return d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words);
 }
 bool th_plan::use_mel_mfma() const { return g.n_mel != 0 && use_wave() && !use_mel_fused(); }
 
@@ -913,7 +915,12 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         // n_fft 1024 (selector 6) but measures 0.72 ms against 0.64 for the one-frame plan on the bench tracks (it reloads
         // every frame in full: 16 loads per iteration against 4), so 1024 keeps the one-frame kernel by default.
         wo.multi = (th::stft_wave_multi_applies(g, wo.mode) && (g.log2_nc == 8 || p->kernel_choice == 6)) ? 1 : 0;
-        if (mel_fused) {
+        if (mel_fused && g.log2_nc == 8) {  // (the per-mel table of the banded sums, kernels.h)
+            wo.mel_tab = p->d_mel_rows;
+            wo.mel_groups = p->mel_rows_groups;
+            wo.mel_words = p->mel_rows_groups * (uint32_t)(th::MEL_ROWS_W + 1) * 64u;
+            wo.n_mel = g.n_mel;
+        } else if (mel_fused) {
             wo.mel_tab = p->d_mel_fuse;
             wo.mel_words = p->mel_fuse_words;
             wo.mel_slots = p->mel_fuse_slots;

@@ -686,19 +686,28 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 // NLD * 4 registers instead of 32 — and at the start of the next iteration passes them through its (free) exchange slab:
 // ds_write_b128, then each lane reads the 16 sample pairs of its own frame.
 // ------------------------------------------------------------------------------------------
-template <int LOG2_NC, int WAVES, bool AMP, int NLD>
+// OUT: 0 dB rows, 1 amplitude rows (first half of the two-kernel mel paths), 2 mel rows (n_fft 512 under narrow filters: the
+// banded sums of mel_rows_kernel as an epilogue — the four frames' amplitudes go to the wave's slab instead of memory, then
+// lane = mel: per group of 64 mels the lane's first bin and 8 weights come from the table in LDS once, and each of the four
+// frames costs 8 LDS reads + 8 FMAs + one 256-byte row store; table layout as launch_mel_rows, kernels.h)
+constexpr int MELR_AP = 272;  // floats per amplitude row in the slab (257 bins + the 8-bin reach of the last filters, 16-bank skew between the groups)
+template <int LOG2_NC, int WAVES, int OUT, int NLD>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
-    uint32_t *__restrict__ queue_head) {
+    uint32_t *__restrict__ queue_head, WaveOut wo) {
     using W = WaveFftM<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC, G = W::G, L = W::L;
+    constexpr bool AMP = OUT == 1, MELR = OUT == 2;
+    static_assert(!MELR || (LOG2_NC == 8 && 4 * MELR_AP * (int)sizeof(float) <= (int)(sizeof(cf32) * W::SLAB_LEN) &&
+                            NC + MEL_ROWS_W <= MELR_AP), "mel rows: four amplitude rows in the wave's slab");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *wtab = reinterpret_cast<cf32 *>(smem_raw);
     cf32 *stw = wtab + NC;
     cf32 *t2 = stw + NC;
     cf32 *t3 = t2 + W::T2_LEN;
     cf32 *slabs = t3 + W::T3_LEN;
+    uint32_t *meltab = reinterpret_cast<uint32_t *>(slabs + (size_t)WAVES * W::SLAB_LEN);  // OUT == 2 only
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
@@ -706,6 +715,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
         stw[i] = tw[i];
     }
     W::fill_tables(tid, 64 * WAVES, tw, t2, t3);
+    if constexpr (MELR)
+        for (uint32_t i = tid; i < wo.mel_words; i += 64 * WAVES) meltab[i] = wo.mel_tab[i];
     __syncthreads();
     cf32 *slab = slabs + (size_t)wave * W::SLAB_LEN;
     const uint32_t lane_wave = tid & 63u;
@@ -822,9 +833,12 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
             TH_SCHED_BARRIER();
             const uint32_t grp = W::grp(lane), last = cur.f1 - 1u - f, dg = grp < last ? grp : last;
             const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch + (size_t)dg * cur.spec_pitch;
+            float *const amp_row = reinterpret_cast<float *>(slab) + grp * (uint32_t)MELR_AP;  // OUT == 2: the group's amplitude row
             W::split_paired_w(lane, za, zb, ws, w_mid, [&](uint32_t kb, int kc, float p) {
                 const gptr<float> dst = (gptr<float>)((gptr<char>)row + (uint64_t)(kb << 2) + (int64_t)(4 * kc));  // base + immediate (split_base)
-                if constexpr (AMP) {  // amplitude rows for the matrix-core mel path (spectrogram.rs:200-207)
+                if constexpr (MELR) {  // (pre-scaled by 2^32 like the fused epilogue of the one-frame kernels: amp_to_dB_fast)
+                    amp_row[kb + (uint32_t)kc] = power_to_amp_scaled(p);
+                } else if constexpr (AMP) {  // amplitude rows for the matrix-core mel path (spectrogram.rs:200-207)
                     *dst = power_to_amp(p);
                 } else {
                     const float d = power_to_dB(p);
@@ -833,7 +847,46 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
                     lmax = nmax(lmax, d);
                 }
             });
-            {   // complete the row's last 128-byte line (see wave_frame)
+            if constexpr (MELR) {
+                // the filters' reach past the last bin: zero (weights there are zero, whatever the slab held must not be NaN)
+                if (W::lig(lane) < (uint32_t)(MELR_AP - NC - 1)) amp_row[NC + 1 + W::lig(lane)] = 0.0f;
+                wave_lds_sync();
+                const float *const ampf = reinterpret_cast<const float *>(slab);
+                constexpr int MW = MEL_ROWS_W;
+                const uint32_t height = wo.n_mel, pad = cur.spec_pitch - height;
+                const uint32_t npad = (pad < 32u && cur.spec_pitch % 32u == 0) ? pad : 0u;
+#pragma unroll
+                for (int gq = 0; gq < MEL_ROWS_MAX_GROUPS; gq++) {
+                    if ((uint32_t)gq < wo.mel_groups) {  // wave-uniform
+                        const uint32_t *const tg = meltab + (uint32_t)gq * (MW + 1) * 64u + lane;
+                        const uint32_t lo = tg[0];
+                        float wq[MW];
+#pragma unroll
+                        for (int t = 0; t < MW; t++) wq[t] = __uint_as_float(tg[(1 + t) * 64]);
+                        const uint32_t m = 64u * gq + lane;
+#pragma unroll
+                        for (int fr = 0; fr < G; fr++) {
+                            float a[MW];
+#pragma unroll
+                            for (int t = 0; t < MW; t++) a[t] = ampf[fr * MELR_AP + lo + t];
+                            float acc = 0.0f;
+#pragma unroll
+                            for (int t = 0; t < MW; t++) acc = __builtin_fmaf(a[t], wq[t], acc);
+                            const uint32_t dgf = (uint32_t)fr < last ? (uint32_t)fr : last;  // (groups past the chunk's end repeat its last frame)
+                            const gptr<float> orow = cur.spec + (size_t)f * cur.spec_pitch + (size_t)dgf * cur.spec_pitch;
+                            if (m < height) {
+                                const float d = amp_to_dB_fast(acc);
+                                orow[m] = d;
+                                lmin = nmin(lmin, d);
+                                lmax = nmax(lmax, d);
+                            } else if (m - height < npad) {
+                                orow[m] = 0.0f;  // complete the row's last 128-byte line (see wave_frame)
+                            }
+                        }
+                    }
+                }
+                wave_lds_sync();  // the next iteration stages its samples in the slab
+            } else {   // complete the row's last 128-byte line (see wave_frame)
                 const uint32_t height = (uint32_t)(NC + 1), pad = cur.spec_pitch - height, l = W::lig(lane);
                 if (l - 1u < ((pad < 32u && cur.spec_pitch % 32u == 0) ? pad : 0u)) row[height - 1u + l] = 0.0f;
             }
@@ -850,14 +903,18 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
     }
 }
 
-template <int LOG2_NC, int WAVES, bool AMP, int NLD>
+template <int LOG2_NC, int WAVES, int OUT, int NLD>
 static hipError_t launch_wave_multi_n(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                                       uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
-                                      uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
+                                      uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     using W = WaveFftM<LOG2_NC>;
-    auto kern = stft_wave_multi_kernel<LOG2_NC, WAVES, AMP, NLD>;
+    auto kern = stft_wave_multi_kernel<LOG2_NC, WAVES, OUT, NLD>;
     static_assert(NLD * 1024 <= (int)(sizeof(cf32) * W::SLAB_LEN), "the staged samples fit the wave's slab");
-    const size_t lds = sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
+    if (OUT == 2 && (out.mel_tab == nullptr || out.mel_groups == 0 || out.mel_groups > (uint32_t)MEL_ROWS_MAX_GROUPS ||
+                     out.mel_words != out.mel_groups * (MEL_ROWS_W + 1) * 64u))
+        return hipErrorInvalidValue;
+    const size_t lds = sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN) +
+                       (OUT == 2 ? (size_t)out.mel_words * 4 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -865,31 +922,31 @@ static hipError_t launch_wave_multi_n(const StftGeom &g, const ChanJob *d_jobs, 
     const uint32_t per_cu = 2 * lds <= 160 * 1024 ? 2u : 1u;  // (8 waves: two independent workgroups per CU)
     const uint32_t grid = wg_needed < n_cu * per_cu ? wg_needed : n_cu * per_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, s, g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw,
-                       d_minmax, d_queue_head);
+                       d_minmax, d_queue_head, out);
     return hipGetLastError();
 }
 // staged loads (see the kernel): n_fft 512, even hop (8-byte LDS reads), span (G - 1) hop + n_fft within NLD KB of samples
-template <int LOG2_NC, int WAVES, bool AMP>
+template <int LOG2_NC, int WAVES, int OUT>
 static hipError_t launch_wave_multi_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                                       uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
-                                      uint32_t *d_queue_head, uint32_t n_cu, hipStream_t s) {
+                                      uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     if constexpr (LOG2_NC == 8) {
         const uint32_t span = 3u * g.hop + g.n_fft;
         if (g.hop % 2u == 0 && span <= 1024u)
-            return launch_wave_multi_n<LOG2_NC, WAVES, AMP, 4>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+            return launch_wave_multi_n<LOG2_NC, WAVES, OUT, 4>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
         if (g.hop % 2u == 0 && span <= 1280u)
-            return launch_wave_multi_n<LOG2_NC, WAVES, AMP, 5>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+            return launch_wave_multi_n<LOG2_NC, WAVES, OUT, 5>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
     }
-    return launch_wave_multi_n<LOG2_NC, WAVES, AMP, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+    return launch_wave_multi_n<LOG2_NC, WAVES, OUT, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
 }
-template <int LOG2_NC, bool AMP>
+template <int LOG2_NC, int OUT>
 static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan,
                                     uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax,
-                                    uint32_t *d_queue_head, uint32_t n_cu, int waves, hipStream_t s) {
+                                    uint32_t *d_queue_head, uint32_t n_cu, int waves, const WaveOut &out, hipStream_t s) {
     switch (waves <= 0 ? 12 : waves) {
-        case 8: return launch_wave_multi_t<LOG2_NC, 8, AMP>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
-        case 12: return launch_wave_multi_t<LOG2_NC, 12, AMP>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
-        case 16: return launch_wave_multi_t<LOG2_NC, 16, AMP>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, s);
+        case 8: return launch_wave_multi_t<LOG2_NC, 8, OUT>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
+        case 12: return launch_wave_multi_t<LOG2_NC, 12, OUT>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
+        case 16: return launch_wave_multi_t<LOG2_NC, 16, OUT>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1238,7 +1295,7 @@ bool stft_wave_supported(const StftGeom &g) {
 }
 bool stft_is_block_plan(const StftGeom &g) { return g.log2_nc >= 12; }
 bool stft_wave_multi_applies(const StftGeom &g, int out_mode) {
-    return g.phased == 0 && ((out_mode == 0 && (g.log2_nc == 8 || g.log2_nc == 9)) || (out_mode == 1 && g.log2_nc == 8));
+    return g.phased == 0 && ((out_mode == 0 && (g.log2_nc == 8 || g.log2_nc == 9)) || ((out_mode == 1 || out_mode == 2) && g.log2_nc == 8));
 }
 
 // Staged loads of the multi-frame kernel (launch_wave_multi_t: n_fft 512, even hop, span within 1280 samples) fetch 16-byte
@@ -1487,10 +1544,13 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
     if (out.multi) {  // several short frames per wave (stft_wave_multi.h)
         if (!stft_wave_multi_applies(g, out.mode)) return hipErrorInvalidValue;
         if (out.mode == 1)  // amplitude rows (mel on the matrix cores): n_fft 512 only, 1024 has the one-frame kernel for that
-            return g.log2_nc == 8 ? launch_wave_multi<8, true>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, nullptr, d_queue_head, n_cu, waves, s)
+            return g.log2_nc == 8 ? launch_wave_multi<8, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, nullptr, d_queue_head, n_cu, waves, out, s)
                                   : hipErrorInvalidValue;
-        if (g.log2_nc == 8) return launch_wave_multi<8, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
-        return launch_wave_multi<9, false>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, s);
+        if (out.mode == 2)  // mel rows by banded sums in the epilogue (n_fft 512 under narrow filters)
+            return g.log2_nc == 8 ? launch_wave_multi<8, 2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s)
+                                  : hipErrorInvalidValue;
+        if (g.log2_nc == 8) return launch_wave_multi<8, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
+        return launch_wave_multi<9, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
     }
     if (g.log2_nc >= 12) {  // one workgroup per frame (stft_block.h): dB output, linear scale
         if (out.mode > 1 || g.phased) return hipErrorInvalidValue;
