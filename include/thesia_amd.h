@@ -168,7 +168,8 @@ TH_API int th_plan_dims(const th_plan *plan, size_t *n_freq, size_t *height);
  * the matrix-core mel kernel instead of the fused mel epilogue (mel plans; same as 2 for linear ones), 4 = wave kernel
  * without the grid-aligned register reuse of hop = 480 / 441-style framings, 5 = that reuse also with the fused mel
  * epilogue (both for A/B measurements: it does not pay there), 7 = as 3 with the matrix-core kernel also where 3 runs the
- * banded-sum kernel over the amplitude rows (n_fft 512 under filters of at most 8 bins: the default mel counts of 8-12 kHz audio);
+ * banded-sum kernel over the amplitude rows (n_fft 512 under filters of at most 8 bins: the default mel counts of 8-12 kHz audio),
+ * 8 = the fused mel epilogue in its pieces / gather form where banded sums are the default (A/B);
  * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
  * frames per queue pull */
 TH_API int th_plan_set_kernel(th_plan *plan, int which);

@@ -290,3 +290,23 @@ extern "C" __attribute__((visibility("default"))) int emu_mel_fuse(const float *
         });
     return 0;
 }
+
+// The same product as banded sums, lane = mel (build_mel_band + mel_banded): out[m] = the filter outputs (linear).
+// info[0..2] = table words, groups, widest group's taps.  amp must be followed by 128 readable zeros (the kernel zeroes them).
+extern "C" __attribute__((visibility("default"))) int emu_mel_band(const float *amp, const float *fb, uint32_t n_freq,
+                                                                    uint32_t n_mel, uint32_t max_words, float *out,
+                                                                    uint32_t *info) {
+    const MelBandHost h = build_mel_band(fb, n_freq, n_mel, max_words);
+    if (!h.ok) return 1;
+    info[0] = (uint32_t)h.words.size();
+    info[1] = h.n_groups;
+    info[2] = h.max_taps;
+    std::vector<float> a(n_freq + MEL_BAND_MAX_TAPS, 0.0f);
+    std::memcpy(a.data(), amp, n_freq * sizeof(float));
+    for (uint32_t m = 0; m < n_mel; m++) out[m] = NAN;
+    for (uint32_t l = 0; l < 64; l++)
+        mel_banded(l, a.data(), h.words.data(), h.n_groups, [&](uint32_t m, float v) {
+            if (m < n_mel) out[m] = v;
+        });
+    return 0;
+}

@@ -359,10 +359,14 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     mfma = fft_kernel + ("+mel_rows_kernel" if rows else "+mel_mfma_kernel") if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
     # auto: the fused epilogue for n_fft 2048 and (when the piece table fits: <= 512 pieces) 1024, else the matrix-core path
     fused = "stft_wave_kernel(fused mel)"
-    for which, name in ((1, "stft_generic_kernel"), (3, mfma), (7, fft_kernel + "+mel_mfma_kernel"), (0, None)):
+    # (n_fft 1024 / 2048: the fused epilogue has two forms — banded sums, lane = mel, where the filters are narrow (the default mel
+    # counts), pieces / gather otherwise; selector 8 keeps the second form everywhere)
+    for which, name in ((1, "stft_generic_kernel"), (3, mfma), (7, fft_kernel + "+mel_mfma_kernel"), (8, None), (0, None)):
         if which in (3, 7) and mfma == "stft_generic_kernel":
             continue  # more than 512 mels: there is no matrix-core path to force
         if which == 7 and not rows:
+            continue
+        if which == 8 and n_fft not in (1024, 2048):
             continue
         plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
         if which:

@@ -386,7 +386,10 @@ bool th_plan::use_mel_fused() const {
     if (g.n_mel == 0 || !use_wave() || kernel_choice == 3 || kernel_choice == 7) return false;
     // n_fft 512 under narrow filters: the banded sums of mel_rows_kernel as the epilogue of the four-frames-per-wave kernel
     if (g.log2_nc == 8) return d_mel_rows != nullptr;
-    return d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words);
+    return mel_bsum_fits() || (d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words));
+}
+bool th_plan::mel_bsum_fits() const {
+    return kernel_choice != 8 && d_mel_bsum != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_bsum_words);
 }
 bool th_plan::use_mel_mfma() const { return g.n_mel != 0 && use_wave() && !use_mel_fused(); }
 
@@ -402,6 +405,7 @@ static void plan_free(th_plan *p) {
     if (p->d_mel_slice) (void)hipFree(p->d_mel_slice);
     if (p->d_mel_rows) (void)hipFree(p->d_mel_rows);
     if (p->d_mel_fuse) (void)hipFree(p->d_mel_fuse);
+    if (p->d_mel_bsum) (void)hipFree(p->d_mel_bsum);
     p->amp_buf.release();
     p->chunk_mm.release();
     p->post_jobs.release();
@@ -599,7 +603,21 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
         if (rc == TH_OK && th::stft_wave_supported(g)) {
             // fused mel epilogue of the wave kernel: piece / gather tables, when the filterbank has the expected structure
             const th::MelFuseHost mf = th::build_mel_fuse(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, th::stft_wave_mel_max_pieces(g));
-            if (mf.ok) {
+            if (rc == TH_OK && (g.log2_nc == 9 || g.log2_nc == 10)) {
+                const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16);
+                // Measured against the pieces / gather form (same box, alternating; taps = the sum over the groups of their
+                // widest filter): n_fft 2048 — 60 / 64 taps (44.1 / 48 kHz defaults) 3 / 7 % faster, 72 (config 4: 128 mels)
+                // 3.5 % slower, 96 (200 mels) 8 % slower, 124 (64 mels) 40 % slower; n_fft 1024 — 32 / 44 taps (22.05 / 16 kHz
+                // defaults) 22 / 12 % faster, 76 (48 kHz, 80 mels) 3 % faster
+                uint32_t taps = 0;
+                for (uint32_t gq = 0; mb.ok && gq < mb.n_groups; gq++) taps += mb.words[2 * gq + 1];
+                if (mb.ok && taps <= (g.log2_nc == 9 ? 80u : 64u)) {
+                    p->mel_bsum_words = (uint32_t)mb.words.size();
+                    p->mel_bsum_groups = mb.n_groups;
+                    rc = up((void **)&p->d_mel_bsum, mb.words.data(), mb.words.size() * sizeof(uint32_t));
+                }
+            }
+            if (mf.ok && rc == TH_OK) {
                 p->mel_fuse_words = (uint32_t)mf.words.size();
                 p->mel_fuse_slots = mf.n_slots;
                 p->mel_fuse_groups = mf.n_groups;
@@ -643,9 +661,10 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     TH_REQUIRE(p, "plan is NULL");
     // bits 0-7: 0 auto, 1 generic, 2 wave, 3 wave + matrix-core mel, 4 wave without the phased mode, 5 phased mode also with the
     // fused mel epilogue, 6 wave with the two-frames-per-wave plan at n_fft 1024, 7 as 3 with the matrix-core kernel also where
-    // the banded-sum kernel for short rows under narrow filters is the default (n_fft 512);  bits 8-15 (tuning): waves per workgroup
+    // the banded-sum kernel for short rows under narrow filters is the default (n_fft 512), 8 fused mel epilogue in its pieces / gather
+    // form where the banded sums are the default;  bits 8-15 (tuning): waves per workgroup
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 7, "kernel selector must be 0 .. 7");
+    TH_REQUIRE(k >= 0 && k <= 8, "kernel selector must be 0 .. 8");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     // the multi-frame plans (n_fft 512; n_fft 1024 under selector 6) are instantiated for 8, 12 and 16 waves only
@@ -919,6 +938,12 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
             wo.mel_tab = p->d_mel_rows;
             wo.mel_groups = p->mel_rows_groups;
             wo.mel_words = p->mel_rows_groups * (uint32_t)(th::MEL_ROWS_W + 1) * 64u;
+            wo.n_mel = g.n_mel;
+        } else if (mel_fused && p->mel_bsum_fits()) {  // banded sums (mel_slots = 0 tells the kernel)
+            wo.mel_tab = p->d_mel_bsum;
+            wo.mel_words = p->mel_bsum_words;
+            wo.mel_slots = 0;
+            wo.mel_groups = p->mel_bsum_groups;
             wo.n_mel = g.n_mel;
         } else if (mel_fused) {
             wo.mel_tab = p->d_mel_fuse;

@@ -471,19 +471,29 @@ __device__ __forceinline__ void wave_frame(
         float *const slab_f = reinterpret_cast<float *>(slab);
         // the (r, f) buffer: behind the amplitude row in the slab (n_fft 2048: room for 512 pieces), or the wave's own
         // region behind the mel table (n_fft 1024: the slab would only hold 256 pieces, the default mel counts need ~400)
-        cf32 *const prf = mel_prf != nullptr ? mel_prf : slab + (NC + 2) / 2;
-        const MelFuseTab mt = mel_fuse_view(meltab, wo.mel_slots, wo.mel_groups);
-        wave_lds_sync();
-        mel_pieces(lane, slab_f, prf, mt);
-        wave_lds_sync();
-        mel_gather(lane, prf, mt, [&](uint32_t m, float v) {
+        auto emit_mel = [&](uint32_t m, float v) {
             if (m < wo.n_mel) {
                 const float d = amp_to_dB_fast(v);
                 row[m] = d;
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }
-        });
+        };
+        if (wo.mel_slots == 0) {  // wave-uniform: banded sums, lane = mel (mel_banded, stft_wave.h; table: build_mel_band)
+            // the filters of a group reach up to its widest one's width past their own end: zeros behind the row
+            static_assert(2 * (int)W::SLAB_LEN >= NC + 1 + 128, "room for the zeros behind the amplitude row");
+            slab_f[NC + 1 + lane] = 0.0f;
+            slab_f[NC + 65 + lane] = 0.0f;
+            wave_lds_sync();
+            mel_banded(lane, slab_f, meltab, wo.mel_groups, emit_mel);
+        } else {
+            cf32 *const prf = mel_prf != nullptr ? mel_prf : slab + (NC + 2) / 2;
+            const MelFuseTab mt = mel_fuse_view(meltab, wo.mel_slots, wo.mel_groups);
+            wave_lds_sync();
+            mel_pieces(lane, slab_f, prf, mt);
+            wave_lds_sync();
+            mel_gather(lane, prf, mt, emit_mel);
+        }
         wave_lds_sync();  // the next frame's pass 1 rewrites the slab
     }
     // Rows at the library's padded pitch (th_pitch_f32): bin Nc would be the only dword written in its 128-byte line, and

@@ -142,4 +142,66 @@ inline MelFuseHost build_mel_fuse(const float *fb, uint32_t n_freq, uint32_t n_m
     return out;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Banded-sum form of the same product (round 3): lane = mel.  Mel m = 64 g + lane adds amp[lo_m + t] * w_m[t] for
+// t < n_g, n_g = the widest filter of its group of 64 mels rounded up to 4 (zero weights past a filter's own width; the
+// caller keeps n_g finite floats readable behind the amplitude row).  The mels of a group are neighbours on the scale, so their
+// widths are close (1-3 bins at the bottom, 14-25 in the last group of the 48 kHz default): the loop runs to the group's
+// maximum and wastes little, and there is no second phase — no partial sums through LDS, no gather.  Works for any
+// filterbank whose filters are narrow; no triangle structure is assumed.
+// Words: [2 g] = offset of group g's block, [2 g + 1] = n_g (g < 8); block = 64 first bins, then n_g x 64 weights (float bits).
+// ---------------------------------------------------------------------------------------------
+struct MelBandHost {
+    std::vector<uint32_t> words;
+    uint32_t n_groups = 0, max_taps = 0;
+    bool ok = false;
+};
+constexpr uint32_t MEL_BAND_MAX_GROUPS = 8, MEL_BAND_HDR = 2 * MEL_BAND_MAX_GROUPS, MEL_BAND_MAX_TAPS = 128;
+inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_mel, uint32_t max_words) {
+    MelBandHost out;
+    if (n_mel == 0 || n_freq == 0) return out;
+    const uint32_t G = (n_mel + 63) / 64;
+    if (G > MEL_BAND_MAX_GROUPS) return out;
+    std::vector<uint32_t> lo(n_mel, 0), hi(n_mel, 0);
+    for (uint32_t m = 0; m < n_mel; m++) {
+        uint32_t a = n_freq, b = 0;
+        for (uint32_t k = 0; k < n_freq; k++)
+            if (fb[(size_t)k * n_mel + m] != 0.f) {
+                a = std::min(a, k);
+                b = k + 1;
+            }
+        lo[m] = b ? a : 0;
+        hi[m] = b;
+    }
+    std::vector<uint32_t> &t = out.words;
+    t.assign(MEL_BAND_HDR, 0);
+    for (uint32_t g = 0; g < G; g++) {
+        uint32_t n = 0;
+        for (uint32_t m = 64 * g; m < std::min(n_mel, 64 * g + 64); m++) n = std::max(n, hi[m] - lo[m]);
+        n = (n + 3) / 4 * 4;
+        if (n > MEL_BAND_MAX_TAPS) {
+            t.clear();
+            return out;
+        }
+        out.max_taps = std::max(out.max_taps, n);
+        const size_t off = t.size();
+        t[2 * g] = (uint32_t)off;
+        t[2 * g + 1] = n;
+        t.resize(off + 64 * (size_t)(1 + n), 0);
+        for (uint32_t lane = 0; lane < 64; lane++) {
+            const uint32_t m = 64 * g + lane;
+            if (m >= n_mel) continue;  // (first bin 0, zero weights)
+            t[off + lane] = lo[m];
+            for (uint32_t k = lo[m]; k < hi[m]; k++) std::memcpy(&t[off + 64 * (size_t)(1 + k - lo[m]) + lane], &fb[(size_t)k * n_mel + m], 4);
+        }
+    }
+    if (t.size() > max_words) {
+        t.clear();
+        return out;
+    }
+    out.n_groups = G;
+    out.ok = true;
+    return out;
+}
+
 }  // namespace th

@@ -1136,4 +1136,33 @@ TH_HD void mel_gather(uint32_t lane, const cf32 *prf, const MelFuseTab &t, Emit 
     }
 }
 
+// Banded-sum mel epilogue (tables: build_mel_band, mel_fuse.h): lane = mel.  amp[0 .. n_freq) holds the frame's amplitudes and
+// at least MEL_BAND_MAX_TAPS finite floats behind them.  Four taps per step: the reads of a step are issued together.
+template <class Emit>
+TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint32_t n_groups, Emit emit) {
+    TH_UNROLL for (uint32_t g = 0; g < 8; g++) {
+        if (g < n_groups) {  // wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t off = __builtin_amdgcn_readfirstlane(tab[2 * g]), n = __builtin_amdgcn_readfirstlane(tab[2 * g + 1]);
+#else
+            const uint32_t off = tab[2 * g], n = tab[2 * g + 1];
+#endif
+            const uint32_t lo = tab[off + lane];
+            const float *const ap = amp + lo;
+            const float *const wp = reinterpret_cast<const float *>(tab) + off + 64u + lane;
+            // four partial sums (taps t = u mod 4): a wide group's 64 taps are then four chains of 16 dependent FMAs, not one of 64
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t t = 0; t < n; t += 4) {
+                float a[4], w[4];
+                TH_UNROLL for (uint32_t u = 0; u < 4; u++) {
+                    a[u] = ap[t + u];
+                    w[u] = wp[64u * (t + u)];
+                }
+                TH_UNROLL for (uint32_t u = 0; u < 4; u++) acc[u] = fma_rn(a[u], w[u], acc[u]);
+            }
+            emit(64u * g + lane, (acc[0] + acc[1]) + (acc[2] + acc[3]));
+        }
+    }
+}
+
 }  // namespace th
