@@ -12,6 +12,10 @@
 #include "host_math.h"
 #include "kernels.h"
 #include "mel_fuse.h"
+#if !defined(TH_MEL_BAND_TAPS_2048)
+#define TH_MEL_BAND_TAPS_2048 64u  // (measured thresholds: th_plan_create)
+#define TH_MEL_BAND_TAPS_1024 80u
+#endif
 
 // ------------------------------------------------------------------------------------------ errors
 namespace th {
@@ -606,12 +610,14 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
             if (rc == TH_OK && (g.log2_nc == 9 || g.log2_nc == 10)) {
                 const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16);
                 // Measured against the pieces / gather form (same box, alternating; taps = the sum over the groups of their
-                // widest filter): n_fft 2048 — 60 / 64 taps (44.1 / 48 kHz defaults) 3 / 7 % faster, 72 (config 4: 128 mels)
-                // 3.5 % slower, 96 (200 mels) 8 % slower, 124 (64 mels) 40 % slower; n_fft 1024 — 32 / 44 taps (22.05 / 16 kHz
-                // defaults) 22 / 12 % faster, 76 (48 kHz, 80 mels) 3 % faster
+                // widest filter): n_fft 2048 — 56 / 60 / 64 taps (256 mels, the 44.1 / 48 kHz defaults) 6 / 8 / 10 % faster; 72 taps
+                // (128 mels) 4 % faster in the register-reuse kernel (hop a multiple of 128: config 4), 6 % slower in the full-reload
+                // one (hop 480); 96 (200 mels) 5 % slower, 124 (64 mels) 40 % slower; n_fft 1024 — 32 / 36 / 44 taps (22.05 kHz
+                // default, 128 mels, 16 kHz default) 22 / 13 / 12 % faster, 76 (48 kHz, 80 mels) 1 % faster
                 uint32_t taps = 0;
                 for (uint32_t gq = 0; mb.ok && gq < mb.n_groups; gq++) taps += mb.words[2 * gq + 1];
-                if (mb.ok && taps <= (g.log2_nc == 9 ? 80u : 64u)) {
+                const uint32_t max_taps = g.log2_nc == 9 ? TH_MEL_BAND_TAPS_1024 : (g.hop % 128 == 0 ? TH_MEL_BAND_TAPS_2048 + 8u : TH_MEL_BAND_TAPS_2048);
+                if (mb.ok && taps <= max_taps) {
                     p->mel_bsum_words = (uint32_t)mb.words.size();
                     p->mel_bsum_groups = mb.n_groups;
                     rc = up((void **)&p->d_mel_bsum, mb.words.data(), mb.words.size() * sizeof(uint32_t));

@@ -1138,6 +1138,16 @@ TH_HD void mel_gather(uint32_t lane, const cf32 *prf, const MelFuseTab &t, Emit 
 
 // Banded-sum mel epilogue (tables: build_mel_band, mel_fuse.h): lane = mel.  amp[0 .. n_freq) holds the frame's amplitudes and
 // at least MEL_BAND_MAX_TAPS finite floats behind them.  Four taps per step: the reads of a step are issued together.
+// (LDS pointers carry their address space explicitly here: the reads then are `ds_read … offset:imm` from one running base per
+// array — written as amp[lo + t + u] the compiler formed every address with its own add, 8 of the 12 vector instructions per
+// four taps — and eight taps are read before the first of their FMAs, so a step exposes one LDS latency, not two)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TH_LDS_F32 const __attribute__((address_space(3))) float
+#define TH_LDS_F32_PTR(p) ((TH_LDS_F32 *)(p))
+#else
+#define TH_LDS_F32 const float
+#define TH_LDS_F32_PTR(p) (p)
+#endif
 template <class Emit>
 TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint32_t n_groups, Emit emit) {
     TH_UNROLL for (uint32_t g = 0; g < 8; g++) {
@@ -1148,15 +1158,24 @@ TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint
             const uint32_t off = tab[2 * g], n = tab[2 * g + 1];
 #endif
             const uint32_t lo = tab[off + lane];
-            const float *const ap = amp + lo;
-            const float *const wp = reinterpret_cast<const float *>(tab) + off + 64u + lane;
+            TH_LDS_F32 *ap = TH_LDS_F32_PTR(amp + lo);
+            TH_LDS_F32 *wp = TH_LDS_F32_PTR(reinterpret_cast<const float *>(tab) + off + 64u + lane);
             // four partial sums (taps t = u mod 4): a wide group's 64 taps are then four chains of 16 dependent FMAs, not one of 64
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (uint32_t t = 0; t < n; t += 4) {
+            uint32_t t = 0;
+            for (; t + 8 <= n; t += 8, ap += 8, wp += 8 * 64) {
+                float a[8], w[8];
+                TH_UNROLL for (uint32_t u = 0; u < 8; u++) {
+                    a[u] = ap[u];
+                    w[u] = wp[64u * u];
+                }
+                TH_UNROLL for (uint32_t u = 0; u < 8; u++) acc[u & 3u] = fma_rn(a[u], w[u], acc[u & 3u]);
+            }
+            if (t < n) {  // (n is a multiple of 4)
                 float a[4], w[4];
                 TH_UNROLL for (uint32_t u = 0; u < 4; u++) {
-                    a[u] = ap[t + u];
-                    w[u] = wp[64u * (t + u)];
+                    a[u] = ap[u];
+                    w[u] = wp[64u * u];
                 }
                 TH_UNROLL for (uint32_t u = 0; u < 4; u++) acc[u] = fma_rn(a[u], w[u], acc[u]);
             }
