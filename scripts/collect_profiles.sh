@@ -18,6 +18,7 @@ scripts/pmc_stft.sh "$out/pmc_stft4096" --nfft 4096 --seconds 60 > "$out/pmc_stf
 scripts/pmc_stft.sh "$out/pmc_stftmel" --sr 44100 --tracks 32 --seconds 60 --mel 128 > "$out/pmc_stftmel.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stft4096dyn" --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 > "$out/pmc_stft4096dyn.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_melrows" --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 > "$out/pmc_melrows.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_stftmel48" --sr 48000 --win 1920 --hop 480 --mel 0 > "$out/pmc_stftmel48.log" 2>&1
 {
   python3 scripts/bench_stft.py --reps 30 --kernel 0 1
   python3 scripts/bench_stft.py --reps 30 --nfft 1024
@@ -54,8 +55,14 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 88200 --nfft 4096 --win 3528 --hop 882 --seconds 30 --kernel 0 4
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 96000 --nfft 4096 --win 3840 --hop 480 --seconds 30 --kernel 0 4
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 --mel 0 --kernel 0 4
-  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 --kernel 0 7
-  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 11025 --nfft 512 --win 441 --hop 110 --mel 0 --seconds 120 --kernel 0 7
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 --kernel 0 3 7
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 11025 --nfft 512 --win 441 --hop 110 --mel 0 --seconds 120 --kernel 0 3 7
+  # the fused mel epilogue: banded sums (0) against pieces / gather (8)
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 48000 --win 1920 --hop 480 --mel 0 --kernel 0 8
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 44100 --win 1764 --hop 441 --mel 0 --tracks 32 --seconds 60 --kernel 0 8
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 44100 --tracks 32 --seconds 60 --mel 128 --kernel 0 8
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 16000 --nfft 1024 --win 640 --hop 160 --mel 0 --seconds 90 --kernel 0 8
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 22050 --nfft 1024 --win 882 --hop 220 --mel 0 --seconds 60 --kernel 0 8
 } >> "$out/bench_stft.txt" 2>&1
 # the RCCL path on one GPU (world size 1): the line bench.py prints with the process group up
 TH_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-single-track --no-full-cfg5 > "$out/force_dist.out" 2> "$out/force_dist.err"; grep "^{" "$out/force_dist.out" | tail -1 > "$out/bench_line_force_dist.json"
