@@ -304,8 +304,13 @@ extern "C" __attribute__((visibility("default"))) int emu_mel_band(const float *
     std::vector<float> a(n_freq + MEL_BAND_MAX_TAPS, 0.0f);
     std::memcpy(a.data(), amp, n_freq * sizeof(float));
     for (uint32_t m = 0; m < n_mel; m++) out[m] = NAN;
+    uint32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t g = 0; g < h.n_groups; g++) {
+        off[g] = h.words[2 * g];
+        nt[g] = h.words[2 * g + 1];
+    }
     for (uint32_t l = 0; l < 64; l++)
-        mel_banded(l, a.data(), h.words.data(), h.n_groups, [&](uint32_t m, float v) {
+        mel_banded(l, a.data(), h.words.data(), h.n_groups, off, nt, [&](uint32_t m, float v) {
             if (m < n_mel) out[m] = v;
         });
     return 0;

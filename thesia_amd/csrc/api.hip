@@ -619,6 +619,7 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
                 const uint32_t max_taps = g.log2_nc == 9 ? TH_MEL_BAND_TAPS_1024 : (g.hop % 128 == 0 ? TH_MEL_BAND_TAPS_2048 + 8u : TH_MEL_BAND_TAPS_2048);
                 if (mb.ok && taps <= max_taps) {
                     p->mel_bsum_words = (uint32_t)mb.words.size();
+                    std::copy(mb.words.begin(), mb.words.begin() + 16, p->mel_bsum_hdr);
                     p->mel_bsum_groups = mb.n_groups;
                     rc = up((void **)&p->d_mel_bsum, mb.words.data(), mb.words.size() * sizeof(uint32_t));
                 }
@@ -950,6 +951,10 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
             wo.mel_words = p->mel_bsum_words;
             wo.mel_slots = 0;
             wo.mel_groups = p->mel_bsum_groups;
+            for (uint32_t gq = 0; gq < 8; gq++) {
+                wo.band_off[gq] = p->mel_bsum_hdr[2 * gq];
+                wo.band_n[gq] = p->mel_bsum_hdr[2 * gq + 1];
+            }
             wo.n_mel = g.n_mel;
         } else if (mel_fused) {
             wo.mel_tab = p->d_mel_fuse;

@@ -50,6 +50,9 @@ struct WaveOut {
     int multi = 0;                    // 1: the multi-frame kernel (n_fft 512 / 1024, stft_wave_multi.h; mode 0 only)
     const uint32_t *mel_tab = nullptr;  // DEVICE: mel_fuse.h word table
     uint32_t mel_words = 0, mel_slots = 0, mel_groups = 0, n_mel = 0;
+    // banded sums (mel_slots == 0, build_mel_band): the table's header again, as kernel arguments (scalar registers instead
+    // of two LDS reads + v_readfirstlane per group and frame): block offset and taps of group g
+    uint32_t band_off[8] = {0, 0, 0, 0, 0, 0, 0, 0}, band_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 // pieces the per-wave (r, f) buffer of the fused mel epilogue can hold for this n_fft (0: not supported), and whether
 // the launch shape leaves room in LDS for a table of `words`

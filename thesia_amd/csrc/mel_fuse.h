@@ -178,7 +178,7 @@ inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_m
     for (uint32_t g = 0; g < G; g++) {
         uint32_t n = 0;
         for (uint32_t m = 64 * g; m < std::min(n_mel, 64 * g + 64); m++) n = std::max(n, hi[m] - lo[m]);
-        n = (n + 3) / 4 * 4;
+        n = std::max<uint32_t>(4, (n + 3) / 4 * 4);  // (mel_banded starts its sums with four taps)
         if (n > MEL_BAND_MAX_TAPS) {
             t.clear();
             return out;

@@ -1148,22 +1148,31 @@ TH_HD void mel_gather(uint32_t lane, const cf32 *prf, const MelFuseTab &t, Emit 
 #define TH_LDS_F32 const float
 #define TH_LDS_F32_PTR(p) (p)
 #endif
+// off[g], n[g]: block offset and taps of group g (the table's header; the kernel gets them as scalar arguments)
 template <class Emit>
-TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint32_t n_groups, Emit emit) {
+TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint32_t n_groups, const uint32_t (&off)[8],
+                      const uint32_t (&n)[8], Emit emit) {
+    uint32_t lo[8];  // every group's first bin up front: one LDS round trip for all of them
+    TH_UNROLL for (uint32_t g = 0; g < 8; g++) lo[g] = tab[off[g < n_groups ? g : 0] + lane];
     TH_UNROLL for (uint32_t g = 0; g < 8; g++) {
         if (g < n_groups) {  // wave-uniform
-#if defined(__HIP_DEVICE_COMPILE__)
-            const uint32_t off = __builtin_amdgcn_readfirstlane(tab[2 * g]), n = __builtin_amdgcn_readfirstlane(tab[2 * g + 1]);
-#else
-            const uint32_t off = tab[2 * g], n = tab[2 * g + 1];
-#endif
-            const uint32_t lo = tab[off + lane];
-            TH_LDS_F32 *ap = TH_LDS_F32_PTR(amp + lo);
-            TH_LDS_F32 *wp = TH_LDS_F32_PTR(reinterpret_cast<const float *>(tab) + off + 64u + lane);
-            // four partial sums (taps t = u mod 4): a wide group's 64 taps are then four chains of 16 dependent FMAs, not one of 64
-            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            uint32_t t = 0;
-            for (; t + 8 <= n; t += 8, ap += 8, wp += 8 * 64) {
+            TH_LDS_F32 *ap = TH_LDS_F32_PTR(amp + lo[g]);
+            TH_LDS_F32 *wp = TH_LDS_F32_PTR(reinterpret_cast<const float *>(tab) + off[g] + 64u + lane);
+            // four partial sums (taps t = u mod 4): a wide group's 64 taps are then four chains of 16 dependent FMAs, not one of 64;
+            // the first four taps start them (n >= 4)
+            float acc[4];
+            {
+                float a[4], w[4];
+                TH_UNROLL for (uint32_t u = 0; u < 4; u++) {
+                    a[u] = ap[u];
+                    w[u] = wp[64u * u];
+                }
+                TH_UNROLL for (uint32_t u = 0; u < 4; u++) acc[u] = a[u] * w[u];
+            }
+            ap += 4;
+            wp += 4 * 64;
+            uint32_t t = 4;
+            for (; t + 8 <= n[g]; t += 8, ap += 8, wp += 8 * 64) {
                 float a[8], w[8];
                 TH_UNROLL for (uint32_t u = 0; u < 8; u++) {
                     a[u] = ap[u];
@@ -1171,7 +1180,7 @@ TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint
                 }
                 TH_UNROLL for (uint32_t u = 0; u < 8; u++) acc[u & 3u] = fma_rn(a[u], w[u], acc[u & 3u]);
             }
-            if (t < n) {  // (n is a multiple of 4)
+            if (t < n[g]) {  // (n is a multiple of 4)
                 float a[4], w[4];
                 TH_UNROLL for (uint32_t u = 0; u < 4; u++) {
                     a[u] = ap[u];
