@@ -870,18 +870,21 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
                     if ((uint32_t)gq < wo.mel_groups) {  // wave-uniform
                         const uint32_t *const tg = meltab + (uint32_t)gq * (MW + 1) * 64u + lane;
                         const uint32_t lo = tg[0];
+                        // (explicit LDS pointers: every read below is one running base + an immediate offset, see mel_banded)
+                        TH_LDS_F32 *const wp = TH_LDS_F32_PTR(reinterpret_cast<const float *>(tg));
+                        TH_LDS_F32 *const ap = TH_LDS_F32_PTR(ampf + lo);
                         float wq[MW];
 #pragma unroll
-                        for (int t = 0; t < MW; t++) wq[t] = __uint_as_float(tg[(1 + t) * 64]);
+                        for (int t = 0; t < MW; t++) wq[t] = wp[(1 + t) * 64];
                         const uint32_t m = 64u * gq + lane;
 #pragma unroll
                         for (int fr = 0; fr < G; fr++) {
                             float a[MW];
 #pragma unroll
-                            for (int t = 0; t < MW; t++) a[t] = ampf[fr * MELR_AP + lo + t];
-                            float acc = 0.0f;
+                            for (int t = 0; t < MW; t++) a[t] = ap[fr * MELR_AP + t];
+                            float acc = a[0] * wq[0];
 #pragma unroll
-                            for (int t = 0; t < MW; t++) acc = __builtin_fmaf(a[t], wq[t], acc);
+                            for (int t = 1; t < MW; t++) acc = __builtin_fmaf(a[t], wq[t], acc);
                             const uint32_t dgf = (uint32_t)fr < last ? (uint32_t)fr : last;  // (groups past the chunk's end repeat its last frame)
                             const gptr<float> orow = cur.spec + (size_t)f * cur.spec_pitch + (size_t)dgf * cur.spec_pitch;
                             if (m < height) {
