@@ -557,7 +557,7 @@ def main():
                  ("40 ms, t_overlap 16: 1920 / 120 / 2048, linear dB", wl.wav, 48000, (1920, 120, 2048, ta.LINEAR, 0), 0),
                  ("44.1 kHz default: 1764 / 441 / 2048, linear dB", wav44, 44100, (1764, 441, 2048, ta.LINEAR, 0), 0),
                  ("96 kHz default shape: 3840 / 960 / 4096, linear dB", wl.wav, 96000, (3840, 960, 4096, ta.LINEAR, 0), 0),
-                 ("96 kHz default, mel scale (404 mels: FFT kernel -> amplitude rows -> matrix cores)", wl.wav, 96000, (3840, 960, 4096, ta.MEL, 0), 0),
+                 ("96 kHz default, mel scale (404 mels: FFT kernel -> amplitude rows -> banded sums, lane = mel)", wl.wav, 96000, (3840, 960, 4096, ta.MEL, 0), 0),
                  ("short transform: n_fft 512 / hop 128, linear dB (four frames per wave)", wl.wav, 48000, (512, 128, 512, ta.LINEAR, 0), 0),
                  ("8 kHz default shape: 320 / 80 / 512, linear dB", wl.wav, 8000, (320, 80, 512, ta.LINEAR, 0), 0),
                  ("8 kHz default, mel scale (257 mels: banded sums, lane = mel, in the epilogue of the four-frames-per-wave kernel)", wl.wav, 8000, (320, 80, 512, ta.MEL, 0), 0),

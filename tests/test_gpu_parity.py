@@ -336,7 +336,7 @@ def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
                                                     (22050, 884, 221, 1024, 0), (48000, 1024, 256, 1024, 128),
                                                     (8000, 320, 80, 512, 0), (16000, 512, 128, 512, 64),
                                                     (11025, 441, 110, 512, 0), (8000, 512, 128, 512, 512),
-                                                    (96000, 3840, 960, 4096, 0), (88200, 3528, 882, 4096, 100),
+                                                    (96000, 3840, 960, 4096, 0), (88200, 3528, 882, 4096, 100), (88200, 3528, 882, 4096, 0),
                                                     (16000, 400, 50, 512, 5), (12000, 512, 256, 512, 33),
                                                     (192000, 7680, 1920, 8192, 0), (48000, 16384, 4096, 16384, 200)])
 def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
@@ -356,7 +356,14 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     widest = int((nz.shape[0] - np.argmax(nz[::-1], axis=0) - np.argmax(nz, axis=0))[nz.any(axis=0)].max())
     rows = n_fft == 512 and widest <= 8
     assert rows == ((sr, n_mel) in ((8000, 0), (11025, 0), (8000, 512)))
-    mfma = fft_kernel + ("+mel_rows_kernel" if rows else "+mel_mfma_kernel") if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
+    # (n_fft 4096 under the default mel counts: banded sums over the amplitude rows, mel_band_rows_kernel, instead of the
+    # matrix cores — where every group of 64 mels has filters of at most 128 bins and the table fits LDS beside four rows)
+    grp_taps = [int((nz.shape[0] - np.argmax(nz[::-1, g:g + 64], axis=0) - np.argmax(nz[:, g:g + 64], axis=0))[nz[:, g:g + 64].any(axis=0)].max(initial=0))
+                for g in range(0, want_n_mel, 64)]
+    band_rows = n_fft == 4096 and want_n_mel <= 512 and max(grp_taps) <= 128
+    assert band_rows == ((sr, n_fft, n_mel) in ((96000, 4096, 0), (88200, 4096, 0)))
+    second = "+mel_rows_kernel" if rows else "+mel_band_rows_kernel" if band_rows else "+mel_mfma_kernel"
+    mfma = fft_kernel + second if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
     # auto: the fused epilogue for n_fft 2048 and (when the piece table fits: <= 512 pieces) 1024, else the matrix-core path
     fused = "stft_wave_kernel(fused mel)"
     # (n_fft 1024 / 2048: the fused epilogue has two forms — banded sums, lane = mel, where the filters are narrow (the default mel
@@ -364,7 +371,7 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     for which, name in ((1, "stft_generic_kernel"), (3, mfma), (7, fft_kernel + "+mel_mfma_kernel"), (8, None), (0, None)):
         if which in (3, 7) and mfma == "stft_generic_kernel":
             continue  # more than 512 mels: there is no matrix-core path to force
-        if which == 7 and not rows:
+        if which == 7 and not (rows or band_rows):
             continue
         if which == 8 and n_fft not in (1024, 2048):
             continue

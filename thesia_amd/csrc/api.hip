@@ -607,6 +607,16 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
         if (rc == TH_OK && th::stft_wave_supported(g)) {
             // fused mel epilogue of the wave kernel: piece / gather tables, when the filterbank has the expected structure
             const th::MelFuseHost mf = th::build_mel_fuse(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, th::stft_wave_mel_max_pieces(g));
+            if (rc == TH_OK && g.log2_nc == 11) {
+                // n_fft 4096 (two kernels): the same banded table for mel_band_rows_kernel, where it fits LDS beside four rows
+                const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16);
+                if (mb.ok && th::mel_band_rows_fits(g.n_freq, (uint32_t)mb.words.size())) {
+                    p->mel_bsum_words = (uint32_t)mb.words.size();
+                    std::copy(mb.words.begin(), mb.words.begin() + 16, p->mel_bsum_hdr);
+                    p->mel_bsum_groups = mb.n_groups;
+                    rc = up((void **)&p->d_mel_bsum, mb.words.data(), mb.words.size() * sizeof(uint32_t));
+                }
+            }
             if (rc == TH_OK && (g.log2_nc == 9 || g.log2_nc == 10)) {
                 const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16);
                 // Measured against the pieces / gather form (same box, alternating; taps = the sum over the groups of their
@@ -690,6 +700,8 @@ TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (!p) return "";
     if (p->use_mel_fused()) return "stft_wave_kernel(fused mel)";
     if (p->use_mel_mfma() && p->d_mel_rows != nullptr && p->kernel_choice != 7) return "stft_wave_kernel+mel_rows_kernel";
+    if (p->use_mel_mfma() && p->g.log2_nc >= 11 && p->d_mel_bsum != nullptr && p->kernel_choice != 7)
+        return th::stft_is_block_plan(p->g) ? "stft_block_kernel+mel_band_rows_kernel" : "stft_wave_kernel+mel_band_rows_kernel";
     if (p->use_mel_mfma()) return th::stft_is_block_plan(p->g) ? "stft_block_kernel+mel_mfma_kernel" : "stft_wave_kernel+mel_mfma_kernel";
     if (p->use_wave() && th::stft_is_block_plan(p->g)) return "stft_block_kernel";
     return p->use_wave() ? "stft_wave_kernel" : "stft_generic_kernel";
@@ -999,6 +1011,11 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
             TH_HIP(launch_mel_rows((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
                                    (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_rows, p->mel_rows_groups,
                                    g.n_mel, d_minmax, c->n_cu, c->stream));
+        else if (mel_mfma && g.log2_nc >= 11 && p->d_mel_bsum != nullptr && p->kernel_choice != 7)
+            TH_HIP(launch_mel_band_rows((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
+                                        (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, g.n_freq, p->d_mel_bsum,
+                                        p->mel_bsum_words, p->mel_bsum_groups, p->mel_bsum_hdr, g.n_mel, d_minmax, c->n_cu,
+                                        c->stream));
         else if (mel_mfma)
             TH_HIP(launch_mel_mfma((const MelJob *)p->mel_jobs.dptr, (const uint32_t *)p->mel_tile_start.dptr,
                                    (uint32_t)mel_jobs.size(), (uint32_t)mel_tiles, amp_pitch, p->d_mel_bt, p->d_mel_band,

@@ -88,6 +88,13 @@ hipError_t launch_mel_rows(const MelJob *d_jobs, const uint32_t *d_tile_start, u
                            uint32_t amp_pitch, const uint32_t *d_tab, uint32_t n_groups, uint32_t n_mel, float *d_minmax,
                            uint32_t n_cu, hipStream_t s);
 
+// long rows (n_fft 4096) under narrow filters: the banded sums of build_mel_band (mel_fuse.h) over the amplitude rows,
+// one row per wave at a time through LDS.  hdr: the table's 16 header words (offset and taps per group).
+bool mel_band_rows_fits(uint32_t n_freq, uint32_t words);
+hipError_t launch_mel_band_rows(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
+                                uint32_t amp_pitch, uint32_t n_freq, const uint32_t *d_tab, uint32_t words, uint32_t groups,
+                                const uint32_t *hdr, uint32_t n_mel, float *d_minmax, uint32_t n_cu, hipStream_t s);
+
 // ---- kernels_image.hip
 struct ImgJob {  // device-visible copy of th_img_desc
     const float *spec;

@@ -23,12 +23,15 @@
 // is the price of not yet fusing this into the FFT kernel).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 #include "stft_core.h"
+#include "stft_wave.h"  // mel_banded
 
 namespace th {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
+using vf32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ uint32_t mel_find_job(const uint32_t *__restrict__ start, uint32_t n, uint32_t b) {
     uint32_t lo = 0, hi = n;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void mel_mfma_kernel(const MelJob *__restrict_
 #pragma unroll
         for (int c = 0; c < 4; c++)
             ldrow[t][c] = as_global(job.amp) + (size_t)min(frame0 + 16 * t + 4 * c + lr, job.f_end - 1) * amp_pitch;
-    const gptr<const f32x4> bl = reinterpret_cast<gptr<const f32x4>>(as_global(bt)) + lane;
+    const gptr<const vf32x4> bl = reinterpret_cast<gptr<const vf32x4>>(as_global(bt)) + lane;
     const gptr<float> spec = as_global(job.spec);
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
 
@@ -105,18 +108,18 @@ __global__ __launch_bounds__(256) void mel_mfma_kernel(const MelJob *__restrict_
         const uint32_t j0 = slice_start[blockIdx.y], j1 = slice_start[blockIdx.y + 1];
         for (uint32_t j = j0; j < j1; j++) {
             const uint32_t klo = tile_band[3 * j], khi = tile_band[3 * j + 1], off = tile_band[3 * j + 2];  // scalar loads
-            f32x4 acc[MEL_MT];
+            vf32x4 acc[MEL_MT];
 #pragma unroll
-            for (int t = 0; t < MEL_MT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < MEL_MT; t++) acc[t] = vf32x4{0.f, 0.f, 0.f, 0.f};
             for (uint32_t kb = klo; kb < khi; kb += MEL_UNROLL) {
-                f32x4 raw[MEL_MT][4], b[MEL_UNROLL];
+                vf32x4 raw[MEL_MT][4], b[MEL_UNROLL];
                 // 64 floats of every row starting at K block kb; a ragged last group runs into the next K blocks (or, at
                 // the end of the row, is clamped): whatever it reads there meets the all-zero B block
                 const uint32_t col = min(16 * kb + 4 * lq, amp_pitch - 4);
 #pragma unroll
                 for (int t = 0; t < MEL_MT; t++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) raw[t][c] = *reinterpret_cast<gptr<const f32x4>>(ldrow[t][c] + col);
+                    for (int c = 0; c < 4; c++) raw[t][c] = *reinterpret_cast<gptr<const vf32x4>>(ldrow[t][c] + col);
 #pragma unroll
                 for (int u = 0; u < MEL_UNROLL; u++) {
                     const uint32_t kbi = kb + u < khi ? off + (kb + u - klo) : zero_block;  // wave-uniform
@@ -126,13 +129,13 @@ __global__ __launch_bounds__(256) void mel_mfma_kernel(const MelJob *__restrict_
 #pragma unroll
                 for (int t = 0; t < MEL_MT; t++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) *reinterpret_cast<f32x4 *>(&lds_a[wave][t][4 * c + lr][4 * lq]) = raw[t][c];
+                    for (int c = 0; c < 4; c++) *reinterpret_cast<vf32x4 *>(&lds_a[wave][t][4 * c + lr][4 * lq]) = raw[t][c];
                 mel_wave_sync();
-                f32x4 a[MEL_MT][MEL_UNROLL];
+                vf32x4 a[MEL_MT][MEL_UNROLL];
 #pragma unroll
                 for (int t = 0; t < MEL_MT; t++)
 #pragma unroll
-                    for (int u = 0; u < MEL_UNROLL; u++) a[t][u] = *reinterpret_cast<const f32x4 *>(&lds_a[wave][t][li][16 * u + 4 * kq]);
+                    for (int u = 0; u < MEL_UNROLL; u++) a[t][u] = *reinterpret_cast<const vf32x4 *>(&lds_a[wave][t][li][16 * u + 4 * kq]);
 #pragma unroll
                 for (int u = 0; u < MEL_UNROLL; u++) {
 #pragma unroll
@@ -232,13 +235,13 @@ __global__ __launch_bounds__(256) void mel_rows_kernel(const MelJob *__restrict_
         }
         return false;
     };
-    f32x4 raw[MEL_ROWS_NLD];
+    vf32x4 raw[MEL_ROWS_NLD];
     auto fetch = [&](const MelJob &jb, uint32_t frame0) {  // rows past the end of the range are clamped here and never stored
         const gptr<const float> amp = as_global(jb.amp);
 #pragma unroll
         for (int c = 0; c < MEL_ROWS_NLD; c++) {
             const uint32_t idx = 64u * c + lane, r = idx / MEL_ROWS_C4, c4 = idx - r * MEL_ROWS_C4;
-            raw[c] = *reinterpret_cast<gptr<const f32x4>>(amp + (size_t)min(frame0 + r, jb.f_end - 1) * amp_pitch + 4u * c4);
+            raw[c] = *reinterpret_cast<gptr<const vf32x4>>(amp + (size_t)min(frame0 + r, jb.f_end - 1) * amp_pitch + 4u * c4);
         }
     };
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void mel_rows_kernel(const MelJob *__restrict_
 #pragma unroll
         for (int c = 0; c < MEL_ROWS_NLD; c++) {
             const uint32_t idx = 64u * c + lane, r = idx / MEL_ROWS_C4, c4 = idx - r * MEL_ROWS_C4;
-            *reinterpret_cast<f32x4 *>(tile + r * MEL_ROWS_AP + 4u * c4) = raw[c];
+            *reinterpret_cast<vf32x4 *>(tile + r * MEL_ROWS_AP + 4u * c4) = raw[c];
         }
         mel_wave_sync();
         uint32_t qn = q + 1, jn = ji, fn = 0;
@@ -321,6 +324,140 @@ hipError_t launch_mel_rows(const MelJob *d_jobs, const uint32_t *d_tile_start, u
     hipLaunchKernelGGL(mel_rows_kernel<MEL_ROWS_W>, dim3(grid), dim3(256), 0, s, d_jobs, d_tile_start, n_jobs, n_tiles,
                        amp_pitch, d_tab, n_groups, n_mel, d_minmax);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Long rows (n_fft 4096: the 40 ms default at 88.2 / 96 kHz) under the default mel counts: mel_band_rows_kernel —
+// the banded sums of the fused epilogues (mel_banded, stft_wave.h; table: build_mel_band, shared by the workgroup in LDS)
+// over the amplitude rows the FFT kernel wrote.  A wave stages ONE row at a time in LDS (NLD coalesced 16-byte loads per
+// lane, the next row requested before this row's sums start) and lane = mel: 136 taps per frame at the 96 kHz default
+// against the matrix-core kernel's 16 x 16 x 4 products over blocks that are mostly zeros.  Persistent waves over
+// contiguous frame ranges as in mel_rows_kernel.
+// ------------------------------------------------------------------------------------------
+struct MelBandArgs {
+    uint32_t groups, words;
+    uint32_t off[8], n[8];
+};
+template <int NLD>
+__global__ __launch_bounds__(256) void mel_band_rows_kernel(const MelJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start,
+                                                            uint32_t n_jobs, uint32_t n_tiles, uint32_t amp_pitch,
+                                                            const uint32_t *__restrict__ tab_g, MelBandArgs hb, uint32_t n_mel,
+                                                            float *__restrict__ minmax) {
+    constexpr uint32_t ROWP = 256u * NLD + 128u;  // staged floats + the zeros the widest group's taps may reach into
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *const tab = reinterpret_cast<uint32_t *>(smem_raw);
+    float *const rows = reinterpret_cast<float *>(smem_raw) + ((hb.words + 3u) & ~3u);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t i = tid; i < hb.words; i += 256) tab[i] = tab_g[i];
+    float *const row = rows + wave * ROWP;
+    row[256u * NLD + lane] = 0.0f;
+    row[256u * NLD + 64u + lane] = 0.0f;
+    __syncthreads();
+    // a "unit" is one frame of the host's 128-frame tiles; every wave takes a contiguous range of units
+    constexpr uint32_t UPT = MEL_TILE_FRAMES;
+    const uint32_t n_units = n_tiles * UPT, n_w = gridDim.x * 4u, per = (n_units + n_w - 1) / n_w;
+    const uint32_t q_end = min(n_units, (blockIdx.x * 4u + wave + 1u) * per);
+    uint32_t q = (blockIdx.x * 4u + wave) * per;
+    if (q >= q_end) return;
+    uint32_t ji = mel_find_job(tile_start, n_jobs, q / UPT);
+    auto locate = [&](uint32_t &qq, uint32_t &jj, uint32_t &frame) {
+        while (qq < q_end) {
+            const uint32_t t = qq / UPT;
+            while (t >= tile_start[jj + 1]) jj++;
+            frame = jobs[jj].f_begin + (t - tile_start[jj]) * UPT + qq % UPT;
+            if (frame < jobs[jj].f_end) return true;
+            qq = (t + 1u) * UPT;  // the rest of this tile is past the channel's last frame
+        }
+        return false;
+    };
+    vf32x4 raw[NLD];
+    auto fetch = [&](const MelJob &jb, uint32_t frame) {
+        const gptr<const float> a = as_global(jb.amp) + (size_t)frame * amp_pitch;
+#pragma unroll
+        for (int c = 0; c < NLD; c++) raw[c] = *reinterpret_cast<gptr<const vf32x4>>(a + min(256u * c + 4u * lane, amp_pitch - 4u));
+    };
+    float lmin = __builtin_inff(), lmax = -__builtin_inff();
+    auto flush = [&](uint32_t mm_index) {
+        if (minmax == nullptr) return;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lmin = fminf(lmin, __shfl_xor(lmin, o, 64));
+            lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+        }
+        if (lane == 0) {
+            mel_atomic_min(&minmax[2 * mm_index], lmin);
+            mel_atomic_max(&minmax[2 * mm_index + 1], lmax);
+        }
+        lmin = __builtin_inff();
+        lmax = -__builtin_inff();
+    };
+    uint32_t frame = 0;
+    bool have = locate(q, ji, frame);
+    if (have) fetch(jobs[ji], frame);
+    while (have) {
+        const MelJob job = jobs[ji];
+        mel_wave_sync();  // the previous row's reads are done
+#pragma unroll
+        for (int c = 0; c < NLD; c++) *reinterpret_cast<vf32x4 *>(row + 256u * c + 4u * lane) = raw[c];
+        mel_wave_sync();
+        uint32_t qn = q + 1, jn = ji, fn = 0;
+        const bool have_next = locate(qn, jn, fn);
+        if (have_next) fetch(jobs[jn], fn);
+        const gptr<float> orow = as_global(job.spec) + (size_t)frame * job.spec_pitch;
+        mel_banded(lane, row, tab, hb.groups, hb.off, hb.n, [&](uint32_t m, float v) {
+            if (m < n_mel) {
+                const float d = 6.02059991327962390f * __builtin_amdgcn_logf(v);  // dB_from_amp (decibel.rs:179-202)
+                orow[m] = d;
+                lmin = fminf(lmin, d);
+                lmax = fmaxf(lmax, d);
+            }
+        });
+        if (!have_next || jn != ji) flush(job.mm_index);
+        have = have_next;
+        q = qn;
+        ji = jn;
+        frame = fn;
+    }
+}
+
+template <int NLD>
+static hipError_t launch_mel_band_rows_n(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
+                                         uint32_t amp_pitch, const uint32_t *d_tab, const MelBandArgs &hb, uint32_t n_mel,
+                                         float *d_minmax, uint32_t n_cu, hipStream_t s) {
+    auto kern = mel_band_rows_kernel<NLD>;
+    const size_t lds = 4 * ((size_t)((hb.words + 3u) & ~3u) + 4 * (256 * (size_t)NLD + 128));
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, 160 * 1024 / lds));
+    const uint32_t grid = n_tiles < per_cu * n_cu ? n_tiles : per_cu * n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, d_jobs, d_tile_start, n_jobs, n_tiles, amp_pitch, d_tab, hb, n_mel,
+                       d_minmax);
+    return hipGetLastError();
+}
+bool mel_band_rows_fits(uint32_t n_freq, uint32_t words) {
+    const uint32_t nld = (n_freq + 255) / 256;
+    // n_fft 4096.  (n_fft 8192, 17 loads per row: measured 7 % SLOWER than the matrix cores at the 192 kHz default — 18 KB rows
+    // leave room for one workgroup of four waves per CU —, so those plans keep mel_mfma_kernel)
+    if (nld != 9) return false;
+    return 4 * ((size_t)((words + 3u) & ~3u) + 4 * (256 * (size_t)nld + 128)) <= 160 * 1024;
+}
+hipError_t launch_mel_band_rows(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
+                                uint32_t amp_pitch, uint32_t n_freq, const uint32_t *d_tab, uint32_t words, uint32_t groups,
+                                const uint32_t *hdr, uint32_t n_mel, float *d_minmax, uint32_t n_cu, hipStream_t s) {
+    if (!n_tiles) return hipSuccess;
+    if (n_tiles > 0xffffffffu / MEL_TILE_FRAMES || groups == 0 || groups > 8 || amp_pitch < 4) return hipErrorInvalidValue;
+    MelBandArgs hb;
+    hb.groups = groups;
+    hb.words = words;
+    for (int g = 0; g < 8; g++) {
+        hb.off[g] = hdr[2 * g];
+        hb.n[g] = hdr[2 * g + 1];
+    }
+    const uint32_t nld = (n_freq + 255) / 256;
+    if (nld == 9) return launch_mel_band_rows_n<9>(d_jobs, d_tile_start, n_jobs, n_tiles, amp_pitch, d_tab, hb, n_mel, d_minmax, n_cu, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_mel_mfma(const MelJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_jobs, uint32_t n_tiles,
