@@ -14,8 +14,8 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 n_seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 with ta.Context(0) as ctx:
     for seed in range(seed0, seed0 + n_seeds):
-        print(seed, "stft", fuzzers.fuzz_stft(ctx, seed=seed, max_seconds=budget), flush=True)
-        print(seed, "stft big", fuzzers.fuzz_stft(ctx, seed=seed + 1000, max_seconds=budget, big=True), flush=True)
+        print(seed, "stft", fuzzers.fuzz_stft(ctx, seed=seed, max_seconds=budget, cap_bytes=1 << 30), flush=True)
+        print(seed, "stft big", fuzzers.fuzz_stft(ctx, seed=seed + 1000, max_seconds=budget, big=True, cap_bytes=1 << 30), flush=True)
         print(seed, "track manager", fuzzers.fuzz_track_manager(ctx, seed=seed, max_seconds=budget), flush=True)
         print(seed, "img", fuzzers.fuzz_img(ctx, seed=seed, max_seconds=budget / 2), flush=True)
         print(seed, "waveform", fuzzers.fuzz_waveform(ctx, seed=seed, max_seconds=budget / 2), flush=True)

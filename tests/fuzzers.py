@@ -191,7 +191,7 @@ def fuzz_track_manager(ctx, seed=1, max_cases=10 ** 9, max_seconds=30.0):
     return {"sessions": n_runs, "operations": n_ops}
 
 
-def fuzz_stft(ctx, seed=1, max_cases=10 ** 9, max_seconds=60.0, big=False):
+def fuzz_stft(ctx, seed=1, max_cases=10 ** 9, max_seconds=60.0, big=False, cap_bytes=None):
     """Random framings / lengths / batch shapes through the auto-selected kernel (the wave kernels with all their modes —
     register reuse, phased, dynamic, boundary frames, fused mel, several frames per wave — the block kernel of n_fft 8192 /
     16384, the matrix-core mel path) against the generic kernel, which shares none of that code."""
@@ -230,6 +230,12 @@ def fuzz_stft(ctx, seed=1, max_cases=10 ** 9, max_seconds=60.0, big=False):
             lens = [min(v, 3 * n_fft) for v in lens]
         elif hop < 64:
             lens = [min(v, 20 * n_fft) for v in lens]
+        if cap_bytes is not None:
+            # soak runs (scripts/fuzz_soak.py, open-ended seeds): bound one case's spectrograms — a long channel at a small hop and
+            # n_fft 32768 is 3-4 GB of f32 per plan, and the checker below holds two plans' worth plus float64 temporaries on the host
+            h = plan.height
+            while sum(v // hop + 1 for v in lens) * h * 4 > cap_bytes and max(lens) > 2 * n_fft:
+                lens[int(np.argmax(lens))] //= 2
         wavs = [(rng.standard_normal(v) * 0.1 + 0.3 * np.sin(np.arange(v) * rng.uniform(0.001, 1.0))).astype(np.float32) for v in lens]
         a, mma = plan.calc_spec_batch(wavs)
         b, mmb = ref.calc_spec_batch(wavs)
