@@ -1156,8 +1156,9 @@ TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint
     TH_UNROLL for (uint32_t g = 0; g < 8; g++) lo[g] = tab[off[g < n_groups ? g : 0] + lane];
     TH_UNROLL for (uint32_t g = 0; g < 8; g++) {
         if (g < n_groups) {  // wave-uniform
-            TH_LDS_F32 *ap = TH_LDS_F32_PTR(amp + lo[g]);
-            TH_LDS_F32 *wp = TH_LDS_F32_PTR(reinterpret_cast<const float *>(tab) + off[g] + 64u + lane);
+            // (cast first, then index: 32-bit LDS address arithmetic instead of a 64-bit generic pointer that is truncated afterwards)
+            TH_LDS_F32 *ap = TH_LDS_F32_PTR(amp) + lo[g];
+            TH_LDS_F32 *wp = TH_LDS_F32_PTR(reinterpret_cast<const float *>(tab)) + (off[g] + 64u + lane);
             // four partial sums (taps t = u mod 4): a wide group's 64 taps are then four chains of 16 dependent FMAs, not one of 64;
             // the first four taps start them (n >= 4)
             float acc[4];
