@@ -158,7 +158,8 @@ TH_API int th_timer_stop_ms(th_ctx *ctx, float *ms);
 /* ---------------------------------------------------------------- SpectrogramAnalyzer plan */
 /* Device-resident window / twiddles / mel filterbank for one (sr, win, hop, n_fft, scale, n_mel)
  * key; mirrors prepare()/retain() (spectrogram.rs:116-185).  n_mel = 0 with TH_FREQ_MEL selects
- * calc_mel_fb_default's count.  n_fft must be a power of two in [8, 32768] and win <= n_fft. */
+ * calc_mel_fb_default's count.  n_fft must be a power of two in [2, TH_MAX_N_FFT] and win <= n_fft (else
+ * TH_ERR_UNSUPPORTED; mel plans whose dense filterbank would exceed 1 GiB are refused the same way). */
 TH_API int th_plan_create(th_ctx *ctx, uint32_t sr, size_t win, size_t hop, size_t n_fft, int freq_scale,
                           size_t n_mel, th_plan **out);
 TH_API int th_plan_destroy(th_plan *plan);
