@@ -65,8 +65,6 @@ typedef enum {
 } th_status;
 
 /* FreqScale (src-common/src/lib.rs:105-109) */
-/* largest transform a plan takes (powers of two from 2 up to this): 2^20 samples = 5.5 s at 192 kHz */
-#define TH_MAX_N_FFT (1u << 20)
 #define TH_FREQ_LINEAR 0
 #define TH_FREQ_MEL 1
 
@@ -156,6 +154,8 @@ TH_API int th_timer_start(th_ctx *ctx);
 TH_API int th_timer_stop_ms(th_ctx *ctx, float *ms);
 
 /* ---------------------------------------------------------------- SpectrogramAnalyzer plan */
+/* largest transform a plan takes (powers of two from 2 up to this): 2^20 samples = 5.5 s at 192 kHz */
+#define TH_MAX_N_FFT (1u << 20)
 /* Device-resident window / twiddles / mel filterbank for one (sr, win, hop, n_fft, scale, n_mel)
  * key; mirrors prepare()/retain() (spectrogram.rs:116-185).  n_mel = 0 with TH_FREQ_MEL selects
  * calc_mel_fb_default's count.  n_fft must be a power of two in [2, TH_MAX_N_FFT] and win <= n_fft (else
@@ -168,7 +168,9 @@ TH_API int th_plan_dims(const th_plan *plan, size_t *n_freq, size_t *height);
 /* kernel selection: 0 = auto, 1 = force the generic workgroup kernel, 2 = force the wave kernel, 3 = wave kernel with
  * the matrix-core mel kernel instead of the fused mel epilogue (mel plans; same as 2 for linear ones), 4 = wave kernel
  * without the grid-aligned register reuse of hop = 480 / 441-style framings, 5 = that reuse also with the fused mel
- * epilogue (both for A/B measurements: it does not pay there), 7 = as 3 with the matrix-core kernel also where 3 runs the
+ * epilogue (both for A/B measurements: it does not pay there), 6 = n_fft 1024 on the two-frames-per-wave plan instead of the
+ * one-frame plan (A/B; other sizes: as 2; a wave count in the tuning form below is validated against that plan's launch
+ * shapes: 8, 12 or 16), 7 = as 3 with the matrix-core kernel also where 3 runs the
  * banded-sum kernel over the amplitude rows (n_fft 512 under filters of at most 8 bins: the default mel counts of 8-12 kHz audio),
  * 8 = the fused mel epilogue in its pieces / gather form where banded sums are the default (A/B);
  * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
@@ -329,7 +331,8 @@ typedef struct {
     float *out;       /* DEVICE */
     uint64_t n_samples;
     uint32_t n_levels; /* levels 0 .. n_levels-1, at most 40 */
-    uint32_t first_level; /* 0 (all levels), 1 or 2 (levels first_level .. n_levels-1) */
+    uint32_t first_level; /* 0 (all levels), 1 or 2 (levels first_level .. n_levels-1); > 2: TH_ERR_INVALID_ARG.  ABI note:
+                           * this field was `reserved` (unvalidated) before round 3 — callers must zero it */
 } th_pyramid_desc;
 TH_API size_t th_waveform_pyramid_bins(uint64_t n_samples, uint32_t level);
 TH_API size_t th_waveform_pyramid_offset(uint64_t n_samples, uint32_t level);
@@ -451,6 +454,11 @@ TH_API int th_tm_set_lod_source(th_tm *tm, int per_request);
 /* shape of (and, with out != NULL, a dense copy of) one resident mip level; (0, 0) is the image itself */
 TH_API int th_tm_mip_level(th_tm *tm, size_t id, uint32_t ch, uint32_t level_x, uint32_t level_y, uint16_t *out,
                            size_t capacity_px, size_t *width, size_t *height);
+/* Replaces the pixels of one resident u16 image (same shape: H x W dense u16, row 0 = lowest frequency) and rebuilds its mip
+ * pyramid, as update_spec_imgs does after a re-quantise (core/mod.rs:181-229).  For hosts that quantise elsewhere and for
+ * the parity tests, which pin the pyramid to third-party known answers on given images (tests/golden/lod_pillow_cases.npz);
+ * the next update_spec_imgs of that channel overwrites it.  Bumps the spectrogram revision. */
+TH_API int th_tm_put_img(th_tm *tm, size_t id, uint32_t ch, const uint16_t *img, size_t height, size_t width);
 /* device memory the manager holds besides audio, specs and images (accounting / leak checks): the Lanczos tap tables of
  * the pyramid passes (one per (axis length, level) some resident image needs; dropped with the last such image) and the
  * mip pyramids.  Any out pointer may be NULL. */

@@ -701,50 +701,93 @@ static double lanczos3(double x) {
     return 3.0 * sin(px) * sin(px / 3.0) / (px * px);
 }
 
-/* Textbook separable Lanczos3 resample of the crop box [left, left+cw) x [top, top+ch)
- * of a u16 image into dw x dh (PARITY UNPINNED vs fast_image_resize 6.0.0, see header).
- * Horizontal pass first (f64 accumulate → u16 round/clamp), then vertical. */
+/* Separable Lanczos3 resample of the crop box [left, left+cw) x [top, top+ch) of a u16 image into dw x dh.
+ * PARITY UNPINNED vs fast_image_resize 6.0.0 (crate absent, see header) — but since round 4 restated in the exact
+ * arithmetic of the convolution that crate documents itself as following, Pillow's ImagingResample (src/libImaging/
+ * Resample.c: precompute_coeffs + the 16-bit horizontal / vertical passes), and pinned to Pillow 12.2's own output
+ * (tests/golden/lod_pillow_cases.npz, scripts/make_golden_lod.py):
+ *   scale = extent / out_size, filterscale = max(scale, 1), support = 3 * filterscale, ss = 1 / filterscale;
+ *   center = in0 + (o + 0.5) * scale;  window [ (int)(center - support + 0.5), (int)(center + support + 0.5) ) clipped at
+ *   the IMAGE (never at the crop box);  tap k = lanczos(((k + xmin) - center + 0.5) * ss) with lanczos(t) =
+ *   sinc(t) * sinc(t / 3) on -3 <= t < 3, sinc(t) = sin(pi t) / (pi t);  taps divided by their sum BEFORE the pass;
+ *   a pixel = sum of pixel * tap in ascending order from 0.0 (multiply, then add), + 0.5, truncated; horizontal pass over
+ *   the rows the vertical pass needs, rounded to u16, then the vertical pass.
+ * One deliberate difference: a sum above 65535 is clamped to 65535 (u16 saturation, as a u16 resizer must); Pillow's
+ * 16-bit path writes CLIP8(v >> 8) and CLIP8(v % 256) separately there, i.e. 0xFF00 | (v & 0xFF) — the fixtures' tests
+ * treat exactly those pixels (and what the second pass derives from them) as Pillow's overflow artefact. */
+static double pil_sinc(double x) {
+    if (x == 0.0) return 1.0;
+    x = x * M_PI;
+    return sin(x) / x;
+}
+static double pil_lanczos(double x) {
+    if (-3.0 <= x && x < 3.0) return pil_sinc(x) * pil_sinc(x / 3);
+    return 0.0;
+}
+typedef struct { int *xmin, *n; double *k; int ksize; } pil_axis;
+static void pil_axis_build(int in_size, double in0, double in1, int out_size, pil_axis *a) {
+    double scale = (in1 - in0) / out_size, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 3.0 * filterscale;
+    a->ksize = (int)ceil(support) * 2 + 1;
+    a->xmin = (int *)malloc(sizeof(int) * (size_t)(out_size ? out_size : 1));
+    a->n = (int *)malloc(sizeof(int) * (size_t)(out_size ? out_size : 1));
+    a->k = (double *)calloc((size_t)a->ksize * (size_t)(out_size ? out_size : 1), sizeof(double));
+    for (int xx = 0; xx < out_size; xx++) {
+        const double center = in0 + (xx + 0.5) * scale, ss = 1.0 / filterscale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        if (xmax < 0) xmax = 0;
+        double *k = a->k + (size_t)xx * (size_t)a->ksize;
+        for (int x = 0; x < xmax; x++) {
+            const double w = pil_lanczos((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; x++)
+            if (ww != 0.0) k[x] /= ww;
+        a->xmin[xx] = xmin;
+        a->n[xx] = xmax;
+    }
+}
+static uint16_t pil_round_u16(double ss) {
+    const long v = (long)(ss >= 0.0 ? ss + 0.5 : ss - 0.5);  /* ROUND_UP */
+    return (uint16_t)(v < 0 ? 0 : v > 65535 ? 65535 : v);
+}
 static void resize_lanczos3_u16(const uint16_t *src, size_t sw, size_t sh, double left, double top,
                                 double cw, double ch, size_t dw, size_t dh, uint16_t *dst) {
-    double scx = cw / (double)dw, scy = ch / (double)dh;
-    double fx = scx < 1.0 ? 1.0 : scx, fy = scy < 1.0 ? 1.0 : scy;
-    double supx = 3.0 * fx, supy = 3.0 * fy;
-    /* rows needed by the vertical pass */
-    long y_lo = (long)floor(top - supy) - 1, y_hi = (long)ceil(top + ch + supy) + 1;
-    if (y_lo < 0) y_lo = 0; if (y_hi > (long)sh) y_hi = (long)sh;
-    size_t nrows = (size_t)(y_hi - y_lo);
-    uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * nrows * dw);
-    for (size_t ox = 0; ox < dw; ox++) {
-        double center = left + ((double)ox + 0.5) * scx;
-        long x0 = (long)floor(center - supx), x1 = (long)ceil(center + supx);
-        if (x0 < 0) x0 = 0; if (x1 > (long)sw) x1 = (long)sw;
-        double wsum = 0.0;
-        for (long x = x0; x < x1; x++) wsum += lanczos3(((double)x + 0.5 - center) / fx);
-        for (size_t r = 0; r < nrows; r++) {
-            const uint16_t *row = src + ((size_t)y_lo + r) * sw;
-            double acc = 0.0;
-            for (long x = x0; x < x1; x++) acc += lanczos3(((double)x + 0.5 - center) / fx) * (double)row[x];
-            double v = wsum != 0.0 ? acc / wsum : 0.0;
-            v = floor(v + 0.5); if (v < 0) v = 0; if (v > 65535) v = 65535;
-            tmp[r * dw + ox] = (uint16_t)v;
+    pil_axis ax, ay;
+    pil_axis_build((int)sw, left, left + cw, (int)dw, &ax);
+    pil_axis_build((int)sh, top, top + ch, (int)dh, &ay);
+    /* rows needed by the vertical pass: first window's start .. last window's end (Resample.c: ybox_first / ybox_last) */
+    long y_lo = dh ? ay.xmin[0] : 0, y_hi = dh ? ay.xmin[dh - 1] + ay.n[dh - 1] : 0;
+    if (y_hi < y_lo) y_hi = y_lo;
+    const size_t nrows = (size_t)(y_hi - y_lo);
+    uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * (nrows ? nrows : 1) * (dw ? dw : 1));
+    for (size_t r = 0; r < nrows; r++) {
+        const uint16_t *row = src + ((size_t)y_lo + r) * sw;
+        for (size_t ox = 0; ox < dw; ox++) {
+            const double *k = ax.k + ox * (size_t)ax.ksize;
+            double ss = 0.0;
+            for (int x = 0; x < ax.n[ox]; x++) ss += (double)row[ax.xmin[ox] + x] * k[x];
+            tmp[r * dw + ox] = pil_round_u16(ss);
         }
     }
     for (size_t oy = 0; oy < dh; oy++) {
-        double center = top + ((double)oy + 0.5) * scy;
-        long y0 = (long)floor(center - supy), y1 = (long)ceil(center + supy);
-        if (y0 < y_lo) y0 = y_lo; if (y1 > y_hi) y1 = y_hi;
-        double wsum = 0.0;
-        for (long y = y0; y < y1; y++) wsum += lanczos3(((double)y + 0.5 - center) / fy);
+        const double *k = ay.k + oy * (size_t)ay.ksize;
         for (size_t ox = 0; ox < dw; ox++) {
-            double acc = 0.0;
-            for (long y = y0; y < y1; y++)
-                acc += lanczos3(((double)y + 0.5 - center) / fy) * (double)tmp[(size_t)(y - y_lo) * dw + ox];
-            double v = wsum != 0.0 ? acc / wsum : 0.0;
-            v = floor(v + 0.5); if (v < 0) v = 0; if (v > 65535) v = 65535;
-            dst[oy * dw + ox] = (uint16_t)v;
+            double ss = 0.0;
+            for (int y = 0; y < ay.n[oy]; y++) ss += (double)tmp[(size_t)(ay.xmin[oy] + y - y_lo) * dw + ox] * k[y];
+            dst[oy * dw + ox] = pil_round_u16(ss);
         }
     }
     free(tmp);
+    free(ax.xmin); free(ax.n); free(ax.k);
+    free(ay.xmin); free(ay.n); free(ay.k);
 }
 
 /* ------------------------------------------------------------------ */

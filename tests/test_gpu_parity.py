@@ -427,6 +427,29 @@ def test_calc_spec_cfg2_full_size(ctx):
     plan.close()
 
 
+def test_calc_spec_cfg1_full_length(ctx, golden_dir):
+    """BASELINE config 1 at its real length: one 48 kHz mono track of 2 113 529 samples (the shape of the missing
+    samples/sample_48k.wav, audio.rs:506-508), Hann 1024 / hop 256 -> 8256 x 513, through the whole step the config names:
+    linear dB spectrogram vs the oracle, min / max, global range, u16 image and one level-0 tile bit for bit."""
+    sr, win, hop, n_fft = 48000, 1024, 256, 1024
+    n = 2113529
+    x = synth_track(4000, sr, n)
+    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    spec, mn, mx = plan.calc_spec(x)
+    assert spec.shape == (n // hop + 1, 513) == (8256, 513)
+    want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+    rel = assert_spec_close(spec, want, amp)
+    assert mn == spec.min() and mx == spec.max()
+    lo, hi = orc.global_db_range([mn], [mx], 100.0)
+    img = ctx.spec_to_img(spec, (0, spec.shape[1]), (lo, hi), 258)
+    assert np.array_equal(img, orc.convert_spectrogram_to_img(spec, (0, spec.shape[1]), (lo, hi), 258))
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    for tx, ty in ((0, 0), (16, 1), (7, 0)):  # first, last (partial: 8256 = 16 * 512 + 64 columns, 513 = 512 + 1 rows), middle
+        assert ctx.encode_spectrogram_tile(img, cmap, 2, 0, 0, tx, ty) == orc.encode_spectrogram_tile(img, cmap, 2, 0, 0, tx, ty)
+    print(f"cfg1 max magnitude error {rel:.2e} of frame max")
+    plan.close()
+
+
 def test_calc_spec_golden_f64_fixtures(ctx, golden_dir):
     """Committed float64 numpy.fft.rfft ground truth (scripts/make_golden.py)."""
     z = np.load(f"{golden_dir}/stft_f64_cases.npz")
@@ -763,6 +786,90 @@ def test_lod_mip_pyramid(ctx):
         dfx = np.abs(mip.astype(np.int64) - fx)
         assert dfx.max() <= 1 and (dfx > 0).mean() <= 2e-4, (lx, ly, dfx.max(), (dfx > 0).mean())
     assert worst <= 1 and n_diff <= 1e-3 * n_px, (worst, n_diff, n_px)
+    tm.close()
+
+
+def _pillow_cases(golden_dir):
+    return np.load(f"{golden_dir}/lod_pillow_cases.npz")
+
+
+def test_lod_per_request_tiles_equal_pillow(ctx, golden_dir):
+    """the per-request LOD resize (the reference's own flow, render_tiles.rs:354-393) against a THIRD
+    PARTY — Pillow 12.2's 16-bit Lanczos resize with the tile's crop box (tests/golden/lod_pillow_cases.npz, generated in the
+    build container by scripts/make_golden_lod.py).  Every 512 + 4 px tile of the 1300 x 2600 image at five level pairs, and
+    every whole-image case whose level fits one tile (odd sizes, 1-pixel axes, the reference's 2 x 2 case, the tie image's
+    neighbours).  Bit-identical; still formally unpinned against fast_image_resize itself."""
+    import hashlib
+
+    from tests import lod_images as li
+    cases = _pillow_cases(golden_dir)
+    ident = _identity_colormap()
+    img = li.lod_image(li.TILE_IMAGE)
+    Hh, W = img.shape
+    d = ctx.to_device(img)
+    n_tiles = 0
+    for lx, ly in li.TILE_LEVELS:
+        lod_w, lod_h = -(-W // (1 << lx)), -(-Hh // (1 << ly))
+        for ty in range(-(-lod_h // 512)):
+            for tx in range(-(-lod_w // 512)):
+                t, (ox, oy) = _tile_u16(ctx.encode_spectrogram_tile_dev(d.ptr, Hh, W, ident, 1, lx, ly, tx, ty))
+                g = li.tile_geometry(W, Hh, lx, ly, tx, ty)
+                assert (int(ox), int(oy), t.shape) == (g["origin_x"], g["origin_y"], (g["height"], g["width"]))
+                px = np.ascontiguousarray(t[::-1]).astype(np.uint16)  # (tile rows: highest frequency first)
+                key = f"tile/{lx}_{ly}/{tx}_{ty}"
+                assert np.array_equal(px[::7, ::7], cases[key + "/sample"]), key
+                assert hashlib.sha256(px.tobytes()).digest() == cases[key + "/sha256"].tobytes(), key
+                if (lx, ly, tx, ty) in li.FULL_TILES:
+                    assert np.array_equal(px, cases[key + "/full"]), key
+                n_tiles += 1
+    d.free()
+    assert n_tiles >= 30
+    n_whole = 0
+    for name in li.IMAGES:
+        im = li.lod_image(name)
+        for lx, ly in li.LEVELS[name]:
+            want = cases[f"whole/{name}/{lx}_{ly}"]
+            if want.shape[0] > 512 or want.shape[1] > 512:
+                continue  # more than one tile: the mip-pyramid test takes the whole-image resizes
+            t, _ = _tile_u16(ctx.encode_spectrogram_tile(im, ident, 1, lx, ly, 0, 0))
+            got = t[::-1].astype(np.uint16)
+            m = got != want
+            if name in li.SATURATING:  # Pillow's 16-bit overflow artefact (0xFF00 | low byte where a u16 resizer saturates)
+                assert (got[m] == 65535).all() and (want[m] >= 0xFF00).all(), (name, lx, ly)
+            else:
+                assert not m.any(), (name, lx, ly, int(m.sum()))
+            n_whole += 1
+    assert n_whole >= 20
+
+
+def test_lod_mip_pyramid_equals_pillow(ctx, golden_dir):
+    """The resident mip pyramid against the same third-party fixtures: th_tm_put_img replaces a channel's image with a
+    fixture image (513 x 513 noise on a linear n_fft-1024 track, the 347 x 1601 spectrogram-like image on the app's default
+    mel setting) and rebuilds its levels through the batched transpose / vertical-pass kernels; every level == Pillow's
+    whole-image resize, and a LOD tile served from the pyramid == the crop of it."""
+    from tests import lod_images as li
+    cases = _pillow_cases(golden_dir)
+    ident = _identity_colormap()
+    tm = ta.TrackManager(ctx)
+    tm.set_colormap(ident)
+    for name, setting, n in (("noise513", (1024 / 48, 4, 1, ta.LINEAR), 512 * 256), ("speclike", (40.0, 4, 1, ta.MEL), 1600 * 480)):
+        tm.set_setting(*setting)
+        tm.add_tracks([(7, 48000, synth_track(3, 48000, n)[None])])
+        tm.apply_track_list_changes()
+        img = li.lod_image(name)
+        assert tm.img(7, 0).shape == img.shape, (name, tm.img(7, 0).shape)
+        tm.put_img(7, 0, img)
+        assert np.array_equal(tm.img(7, 0), img)
+        for lx, ly in li.LEVELS[name]:
+            want = cases[f"whole/{name}/{lx}_{ly}"]
+            assert np.array_equal(tm.mip_level(7, 0, lx, ly), want), (name, lx, ly)
+            # tiles served from the pyramid: crops of the level (core + gutters), rows highest frequency first
+            for tx in range(-(-want.shape[1] // 512)):
+                t, (ox, oy) = _tile_u16(tm.get_spectrogram_tile(7, 0, lx, ly, tx, 0))
+                hh = want.shape[0]
+                assert np.array_equal(t[::-1].astype(np.uint16), want[oy: oy + t.shape[0], ox: ox + t.shape[1]]), (name, lx, ly, tx, hh)
+        tm.remove_track(7)
+        tm.apply_track_list_changes()
     tm.close()
 
 

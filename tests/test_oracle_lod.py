@@ -1,6 +1,12 @@
 """LOD > 0 tiles (render_tiles.rs:290-313,354-393) — what can be established WITHOUT the fast_image_resize source.
 
-PARITY UNPINNED against fast_image_resize 6.0.0 (crate not vendored).  Two things are pinned down here instead:
+PARITY UNPINNED against fast_image_resize 6.0.0 (crate not vendored).  Three things are pinned down here instead:
+
+0. *A third-party anchor (round 4).*  The oracle's resize is bit-identical to Pillow 12.2's 16-bit Lanczos resize
+   (`Image.resize(size, LANCZOS, box=...)`, mode I;16 — the convolution fast_image_resize documents itself as following) on
+   every fixture of tests/golden/lod_pillow_cases.npz: whole-image resizes of eight closed-form images (odd sizes, 1-pixel
+   axes, 513 x 513 noise, a two-valued image whose exact results sit on .5 ties, the reference's own 2 x 2 case) and every
+   512 + 4 px tile of a 1300 x 2600 image with the crop box of render_tiles.rs:382-386 (scripts/make_golden_lod.py).
 
 1. *Position purity.*  The reference resamples the crop box of one tile, with the filter clipped at the IMAGE
    (fast_image_resize / Pillow semantics: taps outside the crop box are read, taps outside the image are dropped).  A pixel
@@ -121,3 +127,68 @@ def test_fixed_point_tiles_equal_fixed_point_whole_image(images):
             t, (ox, oy) = orc.spectrogram_tile_u16(img, lx, ly, tx, 0, orc.RESIZE_FIXED_MAX)
             d = np.abs(t.astype(np.int64) - whole[oy:oy + t.shape[0], ox:ox + t.shape[1]].astype(np.int64))
             assert d.max() <= 1 and (d > 0).mean() <= 1e-3
+
+
+# ---- round 4: the third-party pin (Pillow 12.2, mode I;16, LANCZOS) -------------------------------------------------
+import hashlib
+import os
+
+from tests import lod_images as li
+
+
+@pytest.fixture(scope="module")
+def pillow_cases():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "lod_pillow_cases.npz"))
+
+
+def assert_equals_pillow(got, want, saturating, what):
+    """bit-identical, except where Pillow's 16-bit path overflows: above 65535 it stores CLIP8(v >> 8) and CLIP8(v % 256)
+    separately, i.e. 0xFF00 | (v & 0xFF); a u16 resizer saturates.  Only images listed as SATURATING may use the rule."""
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    m = got != want
+    if saturating:
+        assert (got[m] == 65535).all() and (want[m] >= 0xFF00).all(), what
+    else:
+        assert not m.any(), (what, int(m.sum()), int(np.abs(got.astype(np.int64) - want.astype(np.int64)).max()))
+
+
+@pytest.mark.parametrize("name", li.IMAGES)
+def test_oracle_whole_image_resize_equals_pillow(pillow_cases, name):
+    img = li.lod_image(name)
+    n_sat = 0
+    for lx, ly in li.LEVELS[name]:
+        want = pillow_cases[f"whole/{name}/{lx}_{ly}"]
+        got = orc.resize_whole_image(img, lx, ly)
+        assert_equals_pillow(got, want, name in li.SATURATING, (name, lx, ly))
+        n_sat += int((got != want).sum())
+    if name in li.SATURATING:
+        assert n_sat > 0  # the overflow rule was exercised
+
+
+def test_oracle_reference_2x2_case_via_pillow(pillow_cases):
+    """render_tiles.rs:435-443: [[0, MAX], [MAX, MAX]] at level (1, 1) is one pixel that maps to colour 1 of 2"""
+    v = int(pillow_cases["whole/ref2x2/1_1"][0, 0])
+    assert (v * 1 + 32767) // 65535 == 1 and v == int(orc.resize_whole_image(li.lod_image("ref2x2"), 1, 1)[0, 0])
+
+
+@pytest.mark.parametrize("lx,ly", li.TILE_LEVELS)
+def test_oracle_tiles_equal_pillow_box_crops(pillow_cases, lx, ly):
+    """every 512 + 4 px tile of the 1300 x 2600 image: the oracle's per-request resize of the tile's crop box
+    (render_tiles.rs:382-386) == Pillow's resize(..., box=...) — SHA-256 of the u16 pixels, the strided sample for a
+    readable failure, full pixels for the tiles the fixture stores"""
+    img = li.lod_image(li.TILE_IMAGE)
+    Hh, W = img.shape
+    lod_w, lod_h = -(-W // (1 << lx)), -(-Hh // (1 << ly))
+    n = 0
+    for ty in range(-(-lod_h // 512)):
+        for tx in range(-(-lod_w // 512)):
+            t, (ox, oy) = orc.spectrogram_tile_u16(img, lx, ly, tx, ty)
+            g = li.tile_geometry(W, Hh, lx, ly, tx, ty)
+            assert (ox, oy, t.shape) == (g["origin_x"], g["origin_y"], (g["height"], g["width"]))
+            key = f"tile/{lx}_{ly}/{tx}_{ty}"
+            assert np.array_equal(t[::7, ::7], pillow_cases[key + "/sample"]), key
+            assert hashlib.sha256(t.tobytes()).digest() == pillow_cases[key + "/sha256"].tobytes(), key
+            if (lx, ly, tx, ty) in li.FULL_TILES:
+                assert np.array_equal(t, pillow_cases[key + "/full"]), key
+            n += 1
+    assert n >= 1

@@ -193,6 +193,7 @@ _SIGS = {
     "th_tm_tile_cache": [vp, C.POINTER(vp)],
     "th_tm_set_lod_source": [vp, C.c_int],
     "th_tm_mip_level": [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, c_u16p, C.c_size_t, c_szp, c_szp],
+    "th_tm_put_img": [vp, C.c_size_t, C.c_uint32, c_u16p, C.c_size_t, C.c_size_t],
     "th_tm_lod_footprint": [vp, c_szp, c_szp, c_szp],
     "th_tm_get_audio_render_metadata": [vp, C.c_size_t, C.c_uint32, C.c_double, C.c_int, C.POINTER(RenderMetadata)],
     "th_tile_cache_create": [C.c_size_t, C.POINTER(vp)],

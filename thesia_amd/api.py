@@ -505,9 +505,16 @@ class TrackManager:
         h = vp()
         check(lib.th_tm_create(ctx.handle, C.byref(h)))
         self.handle, self.ctx = h, ctx
+        self._pin, self._pin_cap = None, 0  # pinned output buffer of get_spectrogram_tiles(pinned=True), grow-only
+
+    def _free_pinned(self):
+        if self._pin is not None:
+            check(lib.th_host_free(self.ctx.handle, self._pin))
+        self._pin, self._pin_cap = None, 0
 
     def close(self):
         if self.handle:
+            self._free_pinned()
             check(lib.th_tm_destroy(self.handle))
             self.handle = None
 
@@ -590,14 +597,15 @@ class TrackManager:
         if n == 0 or need.value == 0:
             return []
         if pinned:
-            p = C.c_void_p()
-            check(lib.th_host_alloc(self.ctx.handle, need.value, C.byref(p)))
-            try:
-                check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, p, need.value, offs, C.byref(need)))
-                buf = (C.c_uint8 * need.value).from_address(p.value)
-                out = bytes(buf)
-            finally:
-                check(lib.th_host_free(self.ctx.handle, p))
+            # one grow-only pinned buffer per manager (a hipHostMalloc / hipHostFree pair per call costs
+            # milliseconds, most of what the direct write saves); freed in close()
+            if getattr(self, "_pin_cap", 0) < need.value:
+                self._free_pinned()
+                p = C.c_void_p()
+                check(lib.th_host_alloc(self.ctx.handle, need.value, C.byref(p)))
+                self._pin, self._pin_cap = p, need.value
+            check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, self._pin, self._pin_cap, offs, C.byref(need)))
+            out = bytes((C.c_uint8 * need.value).from_address(self._pin.value))
         else:
             b = np.empty(need.value, np.uint8)
             check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, b.ctypes.data_as(C.c_void_p), b.size, offs, C.byref(need)))
@@ -620,6 +628,11 @@ class TrackManager:
         check(lib.th_tm_mip_level(self.handle, track_id, ch, level_x, level_y, _ptr(out, c_u16p), out.size, C.byref(w),
                                   C.byref(h)))
         return out
+
+    def put_img(self, track_id: int, ch: int, img: np.ndarray) -> None:
+        """Replace the pixels of a resident u16 image (same shape) and rebuild its mip pyramid (th_tm_put_img)."""
+        img = np.ascontiguousarray(img, dtype=np.uint16)
+        check(lib.th_tm_put_img(self.handle, track_id, ch, _ptr(img, c_u16p), img.shape[0], img.shape[1]))
 
     def lod_footprint(self) -> dict:
         """device memory of the LOD machinery: tap tables (count, bytes) and mip pyramids (bytes)"""

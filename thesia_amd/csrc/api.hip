@@ -389,11 +389,11 @@ bool th_plan::use_wave() const {
 bool th_plan::use_mel_fused() const {
     if (g.n_mel == 0 || !use_wave() || kernel_choice == 3 || kernel_choice == 7) return false;
     // n_fft 512 under narrow filters: the banded sums of mel_rows_kernel as the epilogue of the four-frames-per-wave kernel
-    if (g.log2_nc == 8) return d_mel_rows != nullptr;
+    if (g.log2_nc == 8) return d_mel_rows != nullptr && th::stft_wave_multi_mel_fits(g, wave_waves, mel_rows_groups * (uint32_t)(th::MEL_ROWS_W + 1) * 64u);
     return mel_bsum_fits() || (d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words));
 }
 bool th_plan::mel_bsum_fits() const {
-    return kernel_choice != 8 && d_mel_bsum != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_bsum_words);
+    return kernel_choice != 8 && d_mel_bsum != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_bsum_words, true);
 }
 bool th_plan::use_mel_mfma() const { return g.n_mel != 0 && use_wave() && !use_mel_fused(); }
 
@@ -586,7 +586,8 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
                 uint32_t widest = 0;
                 for (size_t m = 0; m < n_mel; m++) widest = std::max(widest, hi[m] - lo[m]);
                 const uint32_t ng = (uint32_t)((n_mel + 63) / 64);
-                if (kb_n <= (uint32_t)th::MEL_ROWS_NKB && g.n_freq - 1 + th::MEL_ROWS_W <= 16 * th::MEL_ROWS_NKB + 4 &&  // (reads stay in the LDS row)
+                // (only n_fft 512 plans on the wave kernel ever read it — ADVICE r3: n_fft 128 / 256 used to pay the upload too)
+                if (g.log2_nc == 8 && th::stft_wave_supported(g) && kb_n <= (uint32_t)th::MEL_ROWS_NKB && g.n_freq - 1 + th::MEL_ROWS_W <= 16 * th::MEL_ROWS_NKB + 4 &&  // (reads stay in the LDS row)
                     widest <= (uint32_t)th::MEL_ROWS_W && ng <= (uint32_t)th::MEL_ROWS_MAX_GROUPS) {
                     constexpr uint32_t W = th::MEL_ROWS_W;
                     std::vector<uint32_t> tab((size_t)ng * (W + 1) * 64, 0u);

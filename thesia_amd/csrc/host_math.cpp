@@ -210,22 +210,32 @@ void waveform_tile_geometry(size_t n, uint32_t level, uint32_t tile, size_t *sta
     *bins = st >= en ? 0 : div_ceil(en - st, s);
 }
 
-static double lanczos3(double x) {
+// Lanczos3 taps in the arithmetic of the convolution fast_image_resize documents itself as following (Pillow's
+// ImagingResample, precompute_coeffs): lanczos(t) = sinc(t) sinc(t / 3) on -3 <= t < 3, sinc(t) = sin(pi t) / (pi t).
+static double pil_sinc(double x) {
     if (x == 0.0) return 1.0;
-    if (x <= -3.0 || x >= 3.0) return 0.0;
-    const double px = M_PI * x;
-    return 3.0 * std::sin(px) * std::sin(px / 3.0) / (px * px);
+    x = x * M_PI;
+    return std::sin(x) / x;
+}
+static double pil_lanczos(double x) {
+    if (-3.0 <= x && x < 3.0) return pil_sinc(x) * pil_sinc(x / 3);
+    return 0.0;
 }
 
+// Window [ (int)(center - support + 0.5), (int)(center + support + 0.5) ) clipped at [lo, hi) = the IMAGE, tap k =
+// lanczos(((k + xmin) - center + 0.5) * (1 / filterscale)), taps divided by their sum HERE (one division per tap, not per
+// pixel): the kernels then add pixel * tap in ascending order from 0.0 and round half up, which makes a level bit-identical
+// to Pillow 12.2's 16-bit Lanczos resize (tests/golden/lod_pillow_cases.npz) wherever that does not overflow 65535.
+// wsum stays in the table's layout as 1.0 (x / 1.0 == x exactly).
 void build_lod_axis(double origin, double extent, size_t n_out, long lo, long hi, LodAxisHost &ax) {
-    const double sc = extent / (double)n_out, f = sc < 1.0 ? 1.0 : sc, sup = 3.0 * f;
+    const double sc = extent / (double)n_out, f = sc < 1.0 ? 1.0 : sc, sup = 3.0 * f, ss = 1.0 / f;
     ax.start.resize(n_out);
     ax.count.resize(n_out);
-    ax.wsum.resize(n_out);
+    ax.wsum.assign(n_out, 1.0);
     ax.max_taps = 0;
     for (size_t o = 0; o < n_out; o++) {
         const double center = origin + ((double)o + 0.5) * sc;
-        long i0 = (long)std::floor(center - sup), i1 = (long)std::ceil(center + sup);
+        long i0 = (long)(center - sup + 0.5), i1 = (long)(center + sup + 0.5);  // (truncation, as the C casts of Pillow)
         if (i0 < lo) i0 = lo;
         if (i1 > hi) i1 = hi;
         if (i1 < i0) i1 = i0;
@@ -237,13 +247,15 @@ void build_lod_axis(double origin, double extent, size_t n_out, long lo, long hi
     ax.w.assign(n_out * (size_t)ax.max_taps, 0.0);
     for (size_t o = 0; o < n_out; o++) {
         const double center = origin + ((double)o + 0.5) * sc;
-        double ws = 0.0;
+        double *const k = &ax.w[o * (size_t)ax.max_taps];
+        double ww = 0.0;
         for (int32_t t = 0; t < ax.count[o]; t++) {
-            const double wv = lanczos3(((double)(ax.start[o] + t) + 0.5 - center) / f);
-            ax.w[o * (size_t)ax.max_taps + t] = wv;
-            ws += wv;
+            const double wv = pil_lanczos(((double)(t + ax.start[o]) - center + 0.5) * ss);
+            k[t] = wv;
+            ww += wv;
         }
-        ax.wsum[o] = ws;
+        if (ww != 0.0)
+            for (int32_t t = 0; t < ax.count[o]; t++) k[t] /= ww;
     }
 }
 

@@ -58,7 +58,10 @@ struct WaveOut {
 // the launch shape leaves room in LDS for a table of `words`
 int stft_wave_phased_mode(const StftGeom &g, int waves);  // 0 no, 1 phased (hop 480), 2 dynamic (e.g. 441)
 uint32_t stft_wave_mel_max_pieces(const StftGeom &g);
-bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words);
+// banded: the banded-sum table (no per-wave (r, f) buffer at n_fft 1024, which only the pieces / gather form uses)
+bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool banded = false);
+// n_fft 512 (four frames per wave): does the mel_rows table fit the launch's LDS beside the slabs at this wave count?
+bool stft_wave_multi_mel_fits(const StftGeom &g, int waves, uint32_t words);
 // waves: waves per workgroup (4, 8, 12 or 16; <= 0 selects the default for this n_fft)
 // d_tile_start: HERE the per-chunk table, 2 words per chunk: (job, first frame) — not the jobs' first chunks as in
 // launch_stft_generic; chunks 0 .. W - 1 are statically assigned (W = waves of the grid), the queue serves the rest

@@ -588,7 +588,8 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // fused mel at n_fft 1024: a (r, f) buffer of MEL_PRF_1024 pieces per wave behind the mel table (see wave_frame)
     cf32 *mel_prf = nullptr;
     if constexpr (OUT == 2 && LOG2_NC == 9)
-        mel_prf = reinterpret_cast<cf32 *>(meltab + ((wo.mel_words + 1u) & ~1u)) + (size_t)wave * MEL_PRF_1024;
+        if (wo.mel_slots != 0)  // (the banded sums have no partial-sum buffer: the launch does not allocate it)
+            mel_prf = reinterpret_cast<cf32 *>(meltab + ((wo.mel_words + 1u) & ~1u)) + (size_t)wave * MEL_PRF_1024;
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
     const uint32_t lane_wave = lane;
     // Register rotation instead of register moves: with hop = SHIFT slots, frame f+1 is frame f moved down by
@@ -1364,7 +1365,7 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
     const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>() + (OUT == 2 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
-                       (OUT == 2 && LOG2_NC == 9 ? (size_t)WAVES * MEL_PRF_1024 * sizeof(cf32) : 0) +
+                       (OUT == 2 && LOG2_NC == 9 && out.mel_slots != 0 ? (size_t)WAVES * MEL_PRF_1024 * sizeof(cf32) : 0) +  // (pieces / gather only)
                        (SHIFT == -1 ? 48 * sizeof(cf32) : 0) +  // phased: zero pairs in front of the window table
                        (SHIFT <= -16 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -1525,7 +1526,7 @@ uint32_t stft_wave_mel_max_pieces(const StftGeom &g) {
     const uint32_t cap = (slab_cf32 - prf0) / 64 * 64;                    // whole slots of 64 pieces
     return cap;
 }
-bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words) {
+bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool banded) {
     const size_t extra = (size_t)words * 4;
     if (g.log2_nc == 10)
         return (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES) &&
@@ -1533,8 +1534,16 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words) {
     if (g.log2_nc == 9)
         return (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) &&
                wave_lds_bytes<9, WaveLaunchCfg<9>::DEFAULT_WAVES>() + extra + (512 + 128) * sizeof(cf32) +
-                       (size_t)WaveLaunchCfg<9>::DEFAULT_WAVES * MEL_PRF_1024 * sizeof(cf32) <= 160 * 1024;
+                       (banded ? 0 : (size_t)WaveLaunchCfg<9>::DEFAULT_WAVES * MEL_PRF_1024 * sizeof(cf32)) <= 160 * 1024;
     return false;
+}
+// (the same sum as launch_wave_multi_n; ADVICE r3: without this check a small growth of SLAB_LEN or MEL_ROWS_W would turn the
+// default path into hipErrorInvalidValue at launch instead of the two-kernel fallback)
+bool stft_wave_multi_mel_fits(const StftGeom &g, int waves, uint32_t words) {
+    if (g.log2_nc != 8) return false;
+    using W = WaveFftM<8>;
+    const int wv = waves > 0 ? waves : stft_wave_default_waves(g);
+    return sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)wv * W::SLAB_LEN) + (size_t)words * 4 <= 160 * 1024;
 }
 
 int stft_wave_default_waves(const StftGeom &g) {

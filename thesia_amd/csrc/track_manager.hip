@@ -960,6 +960,27 @@ TH_API int th_tm_copy_img(th_tm *tm, size_t id, uint32_t ch, uint16_t *out, size
     TH_CATCH
 }
 
+TH_API int th_tm_put_img(th_tm *tm, size_t id, uint32_t ch, const uint16_t *img, size_t height, size_t width) {
+    TH_TRY
+    TH_REQUIRE(tm && img, "NULL argument");
+    std::unique_lock<std::shared_mutex> wl(tm->rw);
+    TH_HIP(hipSetDevice(tm->ctx->device));
+    Channel *c = find_channel(tm, id, ch);
+    if (!c || !c->d_img) return fail(TH_ERR_NOT_FOUND, "Spectrogram %zu_%u does not exist", id, ch);
+    if (height != c->img_h || width != c->img_w)
+        return fail(TH_ERR_INVALID_ARG, "image is %zu x %zu, the resident one %zu x %zu", height, width, c->img_h, c->img_w);
+    if (height && width)
+        TH_HIP(hipMemcpy2DAsync(c->d_img, c->img_pitch * sizeof(uint16_t), img, width * sizeof(uint16_t), width * sizeof(uint16_t),
+                                height, hipMemcpyHostToDevice, tm->ctx->stream));
+    TH_HIP(hipStreamSynchronize(tm->ctx->stream));  // img is the caller's
+    std::vector<Channel *> one{c};
+    int rc = build_mips(tm, one);
+    if (rc != TH_OK) free_mips(*c);
+    tm->invalidate_spectrogram();
+    return writer_done(tm, rc);
+    TH_CATCH
+}
+
 TH_API int th_tm_revisions(const th_tm *tm, uint64_t *waveform_revision, uint64_t *spectrogram_revision) {
     TH_TRY
     TH_REQUIRE(tm, "tm is NULL");
@@ -976,16 +997,21 @@ TH_API int th_tm_set_lod_source(th_tm *tm, int per_request) {
     const int want = per_request ? 1 : 0;
     if (want == tm->lod_source) return TH_OK;
     TH_HIP(hipSetDevice(tm->ctx->device));
-    tm->lod_source = want;
     std::vector<Channel *> have;
     for (auto &kv : tm->tracks)
         for (Channel &ch : kv.second.ch)
             if (ch.d_img) have.push_back(&ch);
     // 1: the pyramids go (build_mips frees them); 0: every resident image gets its levels back
-    TH_HIP(hipStreamSynchronize(tm->ctx->stream));
+    TH_HIP(hipStreamSynchronize(tm->ctx->stream));  // (may fail: the route has not changed yet)
+    const int old_source = tm->lod_source;
+    tm->lod_source = want;  // build_mips reads it
     int rc = build_mips(tm, have);
-    if (rc != TH_OK)
+    if (rc != TH_OK) {
+        // failure-atomic like the other writers: the route stays what it was.  The channels are left without
+        // levels — never with stale ones — and are served through the per-request fallback, which is correct on either route.
         for (Channel *ch : have) free_mips(*ch);
+        tm->lod_source = old_source;
+    }
     prune_axis_tabs(tm);
     return writer_done(tm, rc);
     TH_CATCH
@@ -1198,6 +1224,16 @@ TH_API int th_tm_get_spectrogram_tiles(th_tm *tm, const th_tile_request *reqs, s
         if (rc != TH_OK) return rc;
         TH_HIP(hipStreamSynchronize(tm->ctx->stream));
     }
+    if (staged) {
+        // the staging buffer is held only until its pixels are copied out: the per-request fallbacks and the
+        // headers below no longer keep other pageable-buffer callers waiting
+        for (size_t i = 0; i < n; i++) {
+            const Item &it = items[i];
+            const size_t px = it.g.width * it.g.height * 4;
+            if (!it.single && px) std::memcpy(out + offsets[i] + 40, static_cast<uint8_t *>(tm->batch_stage) + offsets[i] + 40, px);
+        }
+        bl.unlock();
+    }
     for (size_t i = 0; i < n; i++) {
         const th_tile_request &r = reqs[i];
         const Item &it = items[i];
@@ -1211,8 +1247,6 @@ TH_API int th_tm_get_spectrogram_tiles(th_tm *tm, const th_tile_request *reqs, s
             if (rc != TH_OK) return rc;
             continue;
         }
-        const size_t px = it.g.width * it.g.height * 4;
-        if (staged && px) std::memcpy(rec + 40, static_cast<uint8_t *>(tm->batch_stage) + offsets[i] + 40, px);
         put_u64(rec, revision);
         put_u32(rec + 8, (uint32_t)it.g.width);
         put_u32(rec + 12, (uint32_t)it.g.height);
