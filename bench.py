@@ -512,6 +512,27 @@ def main():
             if len(h):
                 cold_series.append(float(h[-1]))
 
+    # The packed-f32 pipeline of the same kernel (th_plan_set_kernel(plan, 9): v_pk_fma_f32 butterflies on register pairs, 417
+    # instead of 681 VALU instructions per frame — the lever VERDICT r3 named), inside the same step, right after the
+    # default: reported so that the driver's record shows why it is not the default.
+    pk_ms = None
+    if rank == 0 and world == 1:
+        try:
+            wl.plan.set_kernel(9)
+            for _ in range(args.spin_up_steps // 2):
+                wl.step(dist)
+            torch.cuda.synchronize(dev)
+            wl.plan.time_kernel(True)
+            for _ in range(args.steps):
+                wl.step(dist)
+            torch.cuda.synchronize(dev)
+            pk_ms = float(np.mean(wl.plan.kernel_ms_history()[-args.steps:]))
+        except Exception:
+            pk_ms = None
+        finally:
+            wl.plan.set_kernel(args.kernel)
+            wl.plan.time_kernel(True)
+
     # The extras below (other configs and framings, latency, end to end ...) describe ONE GPU: they run at N = 1 only.  At
     # N > 1 rank 0 reports the timed step and the tile gather and every rank leaves right behind them (round 2 ran the
     # extras on rank 0 while the other ranks sat in the final barrier, stretching the N = 8 wall time by seconds).
@@ -828,6 +849,9 @@ def main():
             cm = float(np.median(cold_series))
             rf.update({"cold_first_launch_ms": cm, "cold_first_launch_max_ms": max(cold_series),
                        "cold_first_launch_frac": interior * bytes_per_frame / (cm * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        if pk_ms is not None:
+            rf["packed_f32_variant_ms"] = pk_ms
+            rf["packed_f32_variant_frac"] = interior * bytes_per_frame / (pk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if skeleton is not None:
             for k_src, k_dst in (("gaps_1ms", "skeleton_no_work_ms"), ("back_to_back", "skeleton_no_work_back_to_back_ms")):
                 try:

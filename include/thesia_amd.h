@@ -172,7 +172,9 @@ TH_API int th_plan_dims(const th_plan *plan, size_t *n_freq, size_t *height);
  * one-frame plan (A/B; other sizes: as 2; a wave count in the tuning form below is validated against that plan's launch
  * shapes: 8, 12 or 16), 7 = as 3 with the matrix-core kernel also where 3 runs the
  * banded-sum kernel over the amplitude rows (n_fft 512 under filters of at most 8 bins: the default mel counts of 8-12 kHz audio),
- * 8 = the fused mel epilogue in its pieces / gather form where banded sums are the default (A/B);
+ * 8 = the fused mel epilogue in its pieces / gather form where banded sums are the default (A/B),
+ * 9 = the wave kernel's packed-f32 pipeline (v_pk_fma_f32 butterflies on register pairs) where it is instantiated: n_fft 2048,
+ * hop = n_fft / 4, linear dB, default waves (A/B: it measures the same as the scalar pipeline; elsewhere as 2);
  * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
  * frames per queue pull */
 TH_API int th_plan_set_kernel(th_plan *plan, int which);

@@ -7,6 +7,7 @@ set -e
 tag=$1; shift
 cd "$(dirname "$0")/../thesia_amd/csrc"
 srcs=${VARIANT_SOURCES:-kernels_stft.hip}
+obj=../../build/obj   # __graft_entry__.build()'s object cache
 objs=""
 for f in api.hip track_manager.hip kernels_stft.hip kernels_mel.hip kernels_image.hip kernels_waveform.hip host_math.cpp tile_cache.cpp; do
   if [[ " $srcs " == *" $f "* ]]; then
@@ -15,10 +16,10 @@ for f in api.hip track_manager.hip kernels_stft.hip kernels_mel.hip kernels_imag
       kernels_stft.hip) extra="-fno-slp-vectorize";;
       kernels_image.hip|kernels_waveform.hip) extra="-ffp-contract=off";;
     esac
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden $extra "$@" -c $f -o build/${f}_$tag.o
-    objs="$objs build/${f}_$tag.o"
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden $extra "$@" -c $f -o $obj/${f}_$tag.o
+    objs="$objs $obj/${f}_$tag.o"
   else
-    objs="$objs build/$f.o"
+    objs="$objs $obj/$f.o"
   fi
 done
 out=${VARIANT_DIR:-../../scripts/variants}; mkdir -p $out && hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libthesia_amd_$tag.so $objs

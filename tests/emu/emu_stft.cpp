@@ -70,6 +70,54 @@ static void emu_frame(const float *wav, uint32_t n_samples, uint32_t frame, cons
     }
 }
 
+// The packed-f32 pipeline of the n_fft 2048 plan (WaveFft<10>::*_pk, stft_pk.h): the same phases on register pairs, with
+// the pair-ordered split-twiddle table.  On the CPU the pair helpers are plain structs: this checks the pair bookkeeping
+// (which point sits in which half of which pair after every level), the lane-0 selects and the table layout.
+static void emu_frame_pk(const float *wav, uint32_t n_samples, uint32_t frame, const StftGeom &g, const cf32 *wtab,
+                         const cf32 *tw, float *row) {
+    using W = WaveFft<10>;
+    constexpr int P = W::P, NC = W::NC;
+    static_assert(W::PK, "packed pipeline");
+    std::vector<cf32> slab(W::SLAB_LEN), t2(W::T2_LEN), t3(W::T3_LEN), stwp(W::STWP_LEN);
+    static cf32 x[64][P], z[64][P];
+    static v2f zp[64][16], zr[64][8], zi[64][8];
+    const int64_t e0 = (int64_t)frame * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+    for (uint32_t t = 0; t < 256; t++) {
+        W::fill_tables(t, 256, tw, t2.data(), t3.data());
+        W::fill_stwp(t, 256, tw, stwp.data());
+    }
+    for (uint32_t l = 0; l < 64; l++) wave_fetch<P, 0>(W::lane_col(l), x[l], wav, e0);
+    for (uint32_t l = 0; l < 64; l++) wave_window<P>(W::lane_col(l), z[l], x[l], wtab);
+    for (uint32_t l = 0; l < 64; l++)
+        for (int m = 0; m < P; m++) zp[l][m] = mk2(z[l][m].re, z[l][m].im);
+    for (uint32_t l = 0; l < 64; l++) W::pass1_pk(l, zp[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++) W::read1_pk(l, zr[l], zi[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++) {
+        v2f w2[W::NT2];
+        W::load_t2_pk(l, w2, t2.data());
+        W::pass2_pk(l, zr[l], zi[l], w2, slab.data());
+    }
+    static typename W::PkPairs za[64][W::NQ], zb[64][W::NQ];
+    for (uint32_t l = 0; l < 64; l++) W::read2_paired_pk(W::pair_base(l), za[l], zb[l], slab.data());
+    for (uint32_t l = 0; l < 64; l++) {
+        v2f wa[W::NQ][W::NT3], wb[W::NQ][W::NT3];
+        W::load_t3_paired_pk(W::pair_base(l), wa, wb, t3.data());
+        W::pass3_paired_pk(za[l], zb[l], wa, wb);
+    }
+    std::vector<int> hits(NC + 1, 0);
+    for (uint32_t l = 0; l < 64; l++) {
+        v2f wsr[W::NQ][2], wsi[W::NQ][2];
+        W::load_stw_paired_pk(l, wsr, wsi, stwp.data());
+        W::split_paired_pk(l, za[l], zb[l], wsr, wsi, tw[NC / 2], [&](uint32_t kb, int kc, float p) {
+            const uint32_t k = kb + (uint32_t)kc;
+            row[k] = power_to_dB(p);
+            hits[k]++;
+        });
+    }
+    for (int k = 0; k <= NC; k++)
+        if (hits[k] != 1) row[k] = NAN;  // every bin must be emitted exactly once
+}
+
 // One frame of the workgroup-per-frame plan (stft_block.h): the T threads run every phase one after the other, a phase
 // boundary stands for the workgroup barrier.
 template <int LOG2_NC>
@@ -213,10 +261,24 @@ extern "C" __attribute__((visibility("default"))) int emu_stft_wave_multi(const 
 }
 
 // out: n_frames x (n_fft/2+1).  window: normalised window (len win).  Returns 0 on success.
+static int emu_stft_wave_impl(const float *wav, uint32_t n_samples, uint32_t win, uint32_t hop, uint32_t n_fft,
+                              const float *window, uint32_t n_frames, float *out, bool packed);
 extern "C" __attribute__((visibility("default"))) int emu_stft_wave(const float *wav, uint32_t n_samples,
                                                                      uint32_t win, uint32_t hop, uint32_t n_fft,
                                                                      const float *window, uint32_t n_frames,
                                                                      float *out) {
+    return emu_stft_wave_impl(wav, n_samples, win, hop, n_fft, window, n_frames, out, false);
+}
+// the packed-f32 pipeline (n_fft 2048 only)
+extern "C" __attribute__((visibility("default"))) int emu_stft_wave_pk(const float *wav, uint32_t n_samples,
+                                                                        uint32_t win, uint32_t hop, uint32_t n_fft,
+                                                                        const float *window, uint32_t n_frames,
+                                                                        float *out) {
+    if (n_fft != 2048) return -1;
+    return emu_stft_wave_impl(wav, n_samples, win, hop, n_fft, window, n_frames, out, true);
+}
+static int emu_stft_wave_impl(const float *wav, uint32_t n_samples, uint32_t win, uint32_t hop, uint32_t n_fft,
+                              const float *window, uint32_t n_frames, float *out, bool packed) {
     StftGeom g{};
     g.hop = hop;
     g.win = win;
@@ -242,7 +304,10 @@ extern "C" __attribute__((visibility("default"))) int emu_stft_wave(const float 
         }
         switch (n_fft) {
             case 1024: emu_frame<9>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
-            case 2048: emu_frame<10>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
+            case 2048:
+                if (packed) emu_frame_pk(wav, n_samples, f, g, wtab.data(), tw.data(), row);
+                else emu_frame<10>(wav, n_samples, f, g, wtab.data(), tw.data(), row);
+                break;
             case 4096: emu_frame<11>(wav, n_samples, f, g, wtab.data(), tw.data(), row); break;
             case 8192: emu_frame_block<12>(wav, f, g, wtab.data(), tw.data(), row); break;
             case 16384: emu_frame_block<13>(wav, f, g, wtab.data(), tw.data(), row); break;

@@ -21,6 +21,7 @@ def emu():
     f32p = C.POINTER(C.c_float)
     lib.emu_stft_wave.argtypes = [f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p, C.c_uint32, f32p]
     lib.emu_stft_wave_multi.argtypes = lib.emu_stft_wave.argtypes
+    lib.emu_stft_wave_pk.argtypes = lib.emu_stft_wave.argtypes
     return lib
 
 
@@ -49,6 +50,31 @@ def test_emulated_wave_kernel_matches_oracle(emu, win, hop, n_fft, n):
     got_amp = np.power(10.0, out[interior].astype(np.float64) / 20.0)
     rel = (np.abs(got_amp - amp[interior]) / amp[interior].max(axis=1, keepdims=True)).max() if interior.any() else 0
     assert rel <= 2e-6, rel
+
+
+@pytest.mark.parametrize("win,hop,n", [(2048, 512, 9000), (1920, 480, 9000), (1764, 441, 7000), (2047, 2047, 9000)])
+def test_emulated_packed_pipeline_matches_oracle_and_scalar_plan(emu, win, hop, n):
+    """stft_pk.h / WaveFft<10>::*_pk (round 4): the n_fft 2048 plan on register pairs (v_pk_*_f32 on the GPU).  The lane
+    functions run on the CPU with the pair helpers as plain structs: every bin emitted exactly once, the oracle's
+    magnitudes, and the scalar plan's to rounding (the butterfly algebra is the same; only d = a - t b of the cross levels
+    is formed directly instead of as 2 a - s)."""
+    n_fft = 2048
+    x = synth_track(n_fft + win + 3, 48000, n)
+    w = orc.calc_normalized_win(win, n_fft)
+    T = orc.stft_n_frames(n, win, hop)
+    f32p = C.POINTER(C.c_float)
+    out, ref = np.empty((T, n_fft // 2 + 1), np.float32), np.empty((T, n_fft // 2 + 1), np.float32)
+    assert emu.emu_stft_wave_pk(x.ctypes.data_as(f32p), n, win, hop, n_fft, w.ctypes.data_as(f32p), T, out.ctypes.data_as(f32p)) == 0
+    assert emu.emu_stft_wave(x.ctypes.data_as(f32p), n, win, hop, n_fft, w.ctypes.data_as(f32p), T, ref.ctypes.data_as(f32p)) == 0
+    want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+    interior = ~np.isnan(ref[:, 0])
+    assert interior.any() and np.array_equal(interior, ~np.isnan(out[:, 0]))
+    assert not np.isnan(out[interior]).any()   # every bin of every interior frame emitted exactly once
+    got_amp = np.power(10.0, out[interior].astype(np.float64) / 20.0)
+    ref_amp = np.power(10.0, ref[interior].astype(np.float64) / 20.0)
+    scale = amp[interior].max(axis=1, keepdims=True)
+    assert (np.abs(got_amp - amp[interior]) / scale).max() <= 2e-6
+    assert (np.abs(got_amp - ref_amp) / scale).max() <= 3e-6  # (two f32 FFTs with different roundings: each within 2e-6 of the f64 truth)
 
 
 @pytest.mark.parametrize("win,hop,n_fft,n", [(1024, 256, 1024, 5000), (1000, 250, 1024, 5003), (512, 128, 512, 3000),

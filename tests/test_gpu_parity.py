@@ -392,6 +392,33 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
         plan.close()
 
 
+def test_packed_f32_pipeline_matches_oracle_and_scalar_pipeline(ctx):
+    """th_plan_set_kernel(plan, 9): the n_fft 2048 wave kernel on register pairs (v_pk_fma_f32 butterflies, stft_pk.h; built
+    in round 4 as the lever VERDICT r3 named — it measures the same as the scalar pipeline, which stays the default).  Same
+    bar as every STFT path: the oracle per frame, the scalar pipeline to f32 rounding, batched == single launches bit for
+    bit, true min / max, silence exactly -inf."""
+    sr, win, hop, n_fft = 48000, 2048, 512, 2048
+    plan, ref = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR), ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    plan.set_kernel(9)
+    assert plan.kernel_name == "stft_wave_kernel"
+    xs = [synth_track(70 + i, sr, n) for i, n in enumerate((48000 * 4, 30011, 2048, 5000))] + [np.zeros(9000, np.float32)]
+    specs, mm = plan.calc_spec_batch(xs)
+    for i, (x, s) in enumerate(zip(xs, specs)):
+        want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+        if i == 4:
+            assert np.all(np.isneginf(s))
+            continue
+        assert_spec_close(s, want, amp)
+        assert mm[i, 0] == s.min() and mm[i, 1] == s.max()
+        one, _, _ = plan.calc_spec(x)
+        assert np.array_equal(one, s)
+        r, _, _ = ref.calc_spec(x)
+        a, b = np.power(10.0, s.astype(np.float64) / 20), np.power(10.0, r.astype(np.float64) / 20)
+        assert (np.abs(a - b).max(axis=1) / amp.max(axis=1)).max() <= 3e-6
+    plan.close()
+    ref.close()
+
+
 def test_calc_spec_batch_ragged(ctx):
     """Ragged batch: different lengths incl. N < win, one silent channel, per-channel min/max."""
     win, hop, n_fft = 2048, 512, 2048

@@ -680,9 +680,10 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     // bits 0-7: 0 auto, 1 generic, 2 wave, 3 wave + matrix-core mel, 4 wave without the phased mode, 5 phased mode also with the
     // fused mel epilogue, 6 wave with the two-frames-per-wave plan at n_fft 1024, 7 as 3 with the matrix-core kernel also where
     // the banded-sum kernel for short rows under narrow filters is the default (n_fft 512), 8 fused mel epilogue in its pieces / gather
-    // form where the banded sums are the default;  bits 8-15 (tuning): waves per workgroup
+    // form where the banded sums are the default, 9 wave kernel with the packed-f32 pipeline (stft_pk.h) on the launch shape it is
+    // instantiated for (n_fft 2048, hop = n_fft / 4, linear dB, default waves; elsewhere as 2);  bits 8-15 (tuning): waves per workgroup
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 8, "kernel selector must be 0 .. 8");
+    TH_REQUIRE(k >= 0 && k <= 9, "kernel selector must be 0 .. 9");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     // the multi-frame plans (n_fft 512; n_fft 1024 under selector 6) are instantiated for 8, 12 and 16 waves only
@@ -954,6 +955,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         // n_fft 1024 (selector 6) but measures 0.72 ms against 0.64 for the one-frame plan on the bench tracks (it reloads
         // every frame in full: 16 loads per iteration against 4), so 1024 keeps the one-frame kernel by default.
         wo.multi = (th::stft_wave_multi_applies(g, wo.mode) && (g.log2_nc == 8 || p->kernel_choice == 6)) ? 1 : 0;
+        wo.packed = p->kernel_choice == 9 ? 1 : 0;
         if (mel_fused && g.log2_nc == 8) {  // (the per-mel table of the banded sums, kernels.h)
             wo.mel_tab = p->d_mel_rows;
             wo.mel_groups = p->mel_rows_groups;

@@ -48,6 +48,7 @@ hipError_t launch_wave_post(const WavePostJob *d_pj, uint32_t n_pj, const float 
 struct WaveOut {
     int mode = 0;                     // 0 dB linear, 1 amplitude, 2 fused mel
     int multi = 0;                    // 1: the multi-frame kernel (n_fft 512 / 1024, stft_wave_multi.h; mode 0 only)
+    int packed = 0;                   // 1: the packed-f32 pipeline (stft_pk.h) where it is instantiated (selector 9), else ignored
     const uint32_t *mel_tab = nullptr;  // DEVICE: mel_fuse.h word table
     uint32_t mel_words = 0, mel_slots = 0, mel_groups = 0, n_mel = 0;
     // banded sums (mel_slots == 0, build_mel_band): the table's header again, as kernel arguments (scalar registers instead

@@ -189,6 +189,16 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
 // 4*n_freq B written.
 // ------------------------------------------------------------------------------------------
 #define TH_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// n_fft 2048: the packed-f32 pipeline (stft_pk.h, WaveFft<10>::*_pk) is template parameter PKV of wave_frame /
+// stft_wave_kernel.  Round 4 built it as VERDICT r3 asked (v_pk_fma_f32 butterflies on pairs: 417 VALU instructions per frame
+// instead of 681, 301 of them packed) and measured it against the scalar pipeline on one box, alternating, inside bench.py's
+// step: 0.491 / 0.494 / 0.496 ms against 0.490 / 0.487 / 0.493 ms (profiles/r04_ab_packed.txt) — no gain: the launch does not
+// follow its VALU instruction count.  The scalar pipeline stays the default; th_plan_set_kernel(plan, 9) runs the packed one
+// on the headline shape (12 waves, hop = n_fft / 4, dB rows), parity-tested and reported next to the default by bench.py.
+// -DTH_USE_PK=1 makes it the default of every n_fft 2048 launch shape (A/B builds).
+#if !defined(TH_USE_PK)
+#define TH_USE_PK 0
+#endif
 
 // (Development instrumentation — per-phase shader-clock totals, per-wave wall-clock stamps — is not part of this file: apply
 // scripts/patches/instrumentation_phase_prof_wave_times.patch and build a variant, see scripts/phase_prof.py / wave_times.py.)
@@ -311,7 +321,7 @@ constexpr uint32_t MEL_PRF_1024 = 512;  // pieces of the per-wave (r, f) buffer 
 // PH == -2: "dynamic" mode — any hop in (128 SHIFT, 128 (SHIFT + 1)): the offset and the number of reused slots (SHIFT or
 // SHIFT + 1) are computed per frame (wave-uniform), registers are moved instead of rotated, wtab = even table, the odd
 // one (pairs shifted by one sample) NC + 64 entries behind it, each with 64 zero pairs in front.
-template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH = -1>
+template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH = -1, bool PKV = false>
 __device__ __forceinline__ void wave_frame(
     const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
     uint32_t f, uint32_t f1, gptr<const float> wav, uint32_t n_samples, gptr<float> spec, uint32_t spec_pitch, cf32 (&x)[WaveFft<LOG2_NC>::P],
@@ -337,10 +347,18 @@ __device__ __forceinline__ void wave_frame(
     // pass-1 arithmetic, pass-3 and split twiddles together with the reads of exchange 2.
     cf32 z[P];
     cf32 w2[W::NT2];
+    constexpr bool PKP = W::PK && PKV;
+    v2f zp[PKP ? P : 1];  // the windowed frame as (re, im) pairs (packed pipeline)
     constexpr bool DYN = PH == -2;
     if constexpr (DYN) {
         const uint32_t d = (uint32_t)((int64_t)f * g.hop - (int64_t)(g.win / 2)) & 127u;  // first window sample above the grid
         wave_window_rot<P, 0>(col, z, x, wtab + 64 + ((d & 1u) ? NC + 64 : 0) - ((d + 1u) >> 1));
+    } else if constexpr ((RES & 1) != 0 && PKP) {
+#pragma unroll
+        for (int m = 0; m < P; m++) {
+            const cf32 v = x[(m + OFF) % P];
+            zp[m] = mk2(v.re, v.im) * mk2(rw[m].re, rw[m].im);  // one v_pk_mul_f32: (x[2n] w[2n], x[2n+1] w[2n+1])
+        }
     } else if constexpr (RES & 1) {
 #pragma unroll
         for (int m = 0; m < P; m++) {
@@ -349,6 +367,10 @@ __device__ __forceinline__ void wave_frame(
         }
     } else {
         wave_window_rot<P, OFF>((W::PLANES32 || (W::PLANES8 && PH == -1)) ? lane : col, z, x, wtab);  // (4096, 1024: table stored in lane order, see the kernel)
+    }
+    if constexpr (PKP && (DYN || !(RES & 1))) {
+#pragma unroll
+        for (int m = 0; m < P; m++) zp[m % (PKP ? P : 1)] = mk2(z[m].re, z[m].im);
     }
     // Request the next frame of the chunk now: its samples land while this frame is transformed.  The fetch
     // is unconditional (branch-free register flow: no copies of x[]); on the last frame of a chunk it simply
@@ -388,6 +410,74 @@ __device__ __forceinline__ void wave_frame(
         }
     }
     TH_SCHED_BARRIER();
+    const gptr<float> row = spec + (size_t)f * spec_pitch;
+    if constexpr (PKP) {
+        // packed-f32 pipeline (stft_pk.h; WaveFft::pass1_pk .. split_paired_pk): the same phases, exchanges and waits
+        v2f w2p[W::NT2];
+        if constexpr (!(RES & 2)) {
+            W::load_t2_pk(lane, w2p, t2);  // lands during the pass-1 arithmetic
+        } else {
+#pragma unroll
+            for (int r = 0; r < W::NT2; r++) w2p[r] = mk2(rw2[r].re, rw2[r].im);
+        }
+        W::pass1_pk(lane, zp, slab);
+        wave_lds_sync();
+        TH_SCHED_BARRIER();
+        v2f zr[8], zi[8];
+        W::read1_pk(lane, zr, zi, slab);
+        wave_lds_sync();
+        W::pass2_pk(lane, zr, zi, w2p, slab);
+        wave_lds_sync();
+        TH_SCHED_BARRIER();
+        v2f wa[W::NQ][W::NT3], wb[W::NQ][W::NT3];
+        const typename W::PairBase pbs = W::pair_base(lane);
+        if constexpr (!(RES & 4)) {
+            W::load_t3_paired_pk(pbs, wa, wb, t3);  // queued behind the exchange writes, ahead of the exchange reads
+        } else {
+#pragma unroll
+            for (int q = 0; q < W::NQ; q++)
+#pragma unroll
+                for (int r = 0; r < W::NT3; r++) {
+                    wa[q][r] = mk2(rwa[q][r].re, rwa[q][r].im);
+                    wb[q][r] = mk2(rwb[q][r].re, rwb[q][r].im);
+                }
+        }
+        typename W::PkPairs za[W::NQ], zb[W::NQ];
+        W::read2_paired_pk(pbs, za, zb, slab);
+        wave_lds_sync();  // slab is free again: the next frame's pass 1 may overwrite it
+        v2f wsr[W::NQ][2], wsi[W::NQ][2];
+        if constexpr (!(RES & 8)) {
+            W::load_stw_paired_pk(lane, wsr, wsi, stw);  // (stw = the pair-ordered table, WaveFft::fill_stwp)
+        } else {
+#pragma unroll
+            for (int q = 0; q < W::NQ; q++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    wsr[q][h] = mk2(rws[q][h].re, rws[q][h + 2].re);
+                    wsi[q][h] = mk2(rws[q][h].im, rws[q][h + 2].im);
+                }
+        }
+        TH_SCHED_BARRIER();
+        W::pass3_paired_pk(za, zb, wa, wb);
+        TH_SCHED_BARRIER();
+        float *const slab_f = reinterpret_cast<float *>(slab);
+        auto row_at = [&](uint32_t kb, int kc) -> gptr<float> {
+            return (gptr<float>)((gptr<char>)row + (uint64_t)(kb << 2) + (int64_t)(4 * kc));
+        };
+        auto emit = [&](uint32_t kb, int kc, float p) {
+            if constexpr (MELF) {
+                slab_f[kb + (uint32_t)kc] = power_to_amp_scaled(p);
+            } else if constexpr (AMP) {
+                *row_at(kb, kc) = power_to_amp(p);
+            } else {
+                const float d = power_to_dB(p);
+                *row_at(kb, kc) = d;
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            }
+        };
+        W::split_paired_pk(lane, za, zb, wsr, wsi, rw_mid, emit);
+    } else {
     if constexpr (!(RES & 2)) W::load_t2(lane, w2, t2);  // lands during the pass-1 arithmetic
     W::pass1(lane, z, slab);
     wave_lds_sync();
@@ -395,7 +485,6 @@ __device__ __forceinline__ void wave_frame(
     W::read1(lane, z, slab);
     wave_lds_sync();
 
-    const gptr<float> row = spec + (size_t)f * spec_pitch;
     if constexpr (W::PAIRED) {
         // mirror-local last pass: every Z[k] / Z[Nc-k] pair ends up in one lane's registers
         if constexpr (RES & 2) W::pass2_w(lane, z, rw2, slab);
@@ -465,6 +554,7 @@ __device__ __forceinline__ void wave_frame(
         };
         W::split_sw(sl, z, z256, stw, emit);
     }
+    }  // (scalar pipeline)
     if constexpr (MELF) {
         // fused mel filterbank (stft_wave.h / mel_fuse.h): the frame's amplitudes sit in the wave's slab; pieces of 4 bins
         // -> (r, f) partial sums -> one mel per lane and group; the (r, f) buffer sits behind the amplitude row
@@ -511,7 +601,7 @@ __device__ __forceinline__ void wave_frame(
 // multiple of 128 samples or hop >= n_fft)
 // AMP: store the linear amplitude |X| instead of dB and skip min/max (first half of the mel path;
 // mel_mfma_kernel then applies the filterbank).
-template <int LOG2_NC, int WAVES, int SHIFT, int OUT, int RES>
+template <int LOG2_NC, int WAVES, int SHIFT, int OUT, int RES, bool PKV = false>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
@@ -543,7 +633,10 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // (the pass-2 constants leave LDS too when the lanes hold them in registers, RES bit 1: at n_fft 4096 those 1280 bytes
     // are what an eighth wave per CU needs)
     constexpr bool T2_IN_LDS = !(RES & 2);
-    cf32 *t2 = stw + (STW_IN_LDS ? NC : 0);
+    // (packed pipeline: the split twiddles sit in LDS in pair order, WaveFft::fill_stwp)
+    constexpr bool PKP = W::PK && PKV;
+    constexpr int STW_LEN = PKP ? W::STWP_LEN : NC;
+    cf32 *t2 = stw + (STW_IN_LDS ? STW_LEN : 0);
     cf32 *t3 = t2 + (T2_IN_LDS ? W::T2_LEN : 0);
     cf32 *slabs = t3 + W::T3_LEN;
     uint32_t *meltab = reinterpret_cast<uint32_t *>(slabs + (size_t)WAVES * W::SLAB_LEN);  // OUT == 2 only
@@ -576,8 +669,9 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
         const uint32_t col = i & 63u, li = WPERM ? (i & ~63u) + 8u * (col & 7u) + (col >> 3) : i;
         wtab[WPAD + li] = wtab_g[WPAD + i];
-        if constexpr (STW_IN_LDS) stw[i] = tw[i];
+        if constexpr (STW_IN_LDS && !PKP) stw[i] = tw[i];
     }
+    if constexpr (STW_IN_LDS && PKP) W::fill_stwp(tid, 64 * WAVES, tw, stw);
     for (uint32_t i = tid; i < WPAD; i += 64 * WAVES) wtab[i] = wtab_g[i];
     W::fill_tables(tid, 64 * WAVES, tw, T2_IN_LDS ? t2 : nullptr, t3);
     if constexpr (OUT == 2)
@@ -605,7 +699,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #define TH_BODY_SHIFT(ROT) (PHASED ? ((ROT) == 0 ? 3 : 4) : DYN ? DYN_K : SHIFT)
 #define TH_BODY_OFF(ROT) (PHASED ? ((ROT) == 0 ? 0 : 4 * (ROT) - 1) : (ROTATE ? (ROT) * SHIFT : 0))
 #define TH_FRAME(ROT)                                                                                                  \
-    wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : DYN ? -2 : -1>(      \
+    wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : DYN ? -2 : -1, PKV>( \
         g, wtab + (PHASED ? WPAD - ((96 * (ROT)) & 127) / 2 : 0), stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
         lmax, meltab, mel_prf, wo)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
@@ -625,6 +719,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
             for (int s = 0; s < W::R3; s++) rws[q][s] = tw[W::split_k(lane, q, s)];
         rw_mid = tw[NC / 2];
     }
+    if constexpr (PKP) rw_mid = tw[NC / 2];  // (the pair-ordered LDS table has no entry for the self-mirrored bin)
     // chunk loop: one queue pull and one full fetch per chunk of up to frames_per_tile consecutive frames
     while (sch.cur.valid) {
         const FrameCursor &cur = sch.cur;
@@ -1351,20 +1446,26 @@ struct WaveLaunchCfg {
 static_assert(WaveLaunchCfg<9>::DEFAULT_WAVES == 8 || WaveLaunchCfg<9>::DEFAULT_WAVES == 12 || WaveLaunchCfg<9>::DEFAULT_WAVES == 16,
               "stft_wave_multi_kernel<9> exists for 8, 12 and 16 waves per workgroup");
 
-template <int LOG2_NC, int WAVES>
+template <int LOG2_NC, int WAVES, bool PKV = (TH_USE_PK != 0)>
 static size_t wave_lds_bytes() {
     using W = WaveFft<LOG2_NC>;
     const bool stw_in_lds = !((WaveLaunchCfg<LOG2_NC>::resident(WAVES) & 8) && W::PAIRED);
     const bool t2_in_lds = !(WaveLaunchCfg<LOG2_NC>::resident(WAVES) & 2);
-    return sizeof(cf32) * ((size_t)(stw_in_lds ? 2 : 1) * W::NC + (t2_in_lds ? W::T2_LEN : 0) + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
+    const size_t stw_len = (W::PK && PKV) ? (size_t)W::STWP_LEN : (size_t)W::NC;
+    return sizeof(cf32) * ((size_t)W::NC + (stw_in_lds ? stw_len : 0) + (t2_in_lds ? W::T2_LEN : 0) + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
 }
 
 template <int LOG2_NC, int WAVES, int SHIFT, int OUT>
 static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
-    auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
-    const size_t lds = wave_lds_bytes<LOG2_NC, WAVES>() + (OUT == 2 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
+    // the packed-f32 pipeline (selector 9): instantiated for the headline shape only (n_fft 2048, 12 waves, hop = n_fft / 4, dB rows)
+    constexpr bool PK_SHAPE = LOG2_NC == 10 && WAVES == 12 && SHIFT == 4 && OUT == 0;
+    const bool pkv = (TH_USE_PK != 0) || (PK_SHAPE && out.packed != 0);
+    auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES), (TH_USE_PK != 0)>;
+    if constexpr (PK_SHAPE && TH_USE_PK == 0)
+        if (pkv) kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES), true>;
+    const size_t lds = (pkv ? wave_lds_bytes<LOG2_NC, WAVES, true>() : wave_lds_bytes<LOG2_NC, WAVES, false>()) + (OUT == 2 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
                        (OUT == 2 && LOG2_NC == 9 && out.mel_slots != 0 ? (size_t)WAVES * MEL_PRF_1024 * sizeof(cf32) : 0) +  // (pieces / gather only)
                        (SHIFT == -1 ? 48 * sizeof(cf32) : 0) +  // phased: zero pairs in front of the window table
                        (SHIFT <= -16 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes

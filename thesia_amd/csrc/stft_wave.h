@@ -17,6 +17,7 @@
 // tests/emu (g++), which runs the phases lane by lane to check the index arithmetic.
 #pragma once
 #include "stft_core.h"
+#include "stft_pk.h"
 
 namespace th {
 
@@ -65,6 +66,29 @@ TH_HD f32x4 lds_ld4(const float *p) {
 #endif
 }
 
+// 16-byte LDS read as two packed pairs (sub-registers of the loaded quad: no moves), for the packed-f32 plan (stft_pk.h)
+struct v2x2 {
+    v2f lo, hi;
+};
+TH_HD v2x2 lds_ld4_pk(const float *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const f32x4v v = *(const volatile __attribute__((address_space(3))) f32x4v *)(p);
+    return {v.xy, v.zw};
+#else
+    return {{p[0], p[1]}, {p[2], p[3]}};
+#endif
+}
+// 8-byte LDS read as one packed pair, in program order (see lds_ld)
+TH_HD v2f lds_ld_pk(const void *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const volatile __attribute__((address_space(3))) v2f *)(p);
+#else
+    const float *f = static_cast<const float *>(p);
+    return {f[0], f[1]};
+#endif
+}
+
 // "Plane" stores: ds_write_addtid_b32 writes one dword per lane at LDS address M0 + offset + 4 * lane — no address
 // VGPR, so the store moves one source dword per lane instead of three (ds_write_b64) or five (ds_write_b128): 2
 // cycles per 256 bytes against 6 per 512 / 13 per 1024, and 64 consecutive dwords can never bank-conflict.  Four
@@ -101,6 +125,12 @@ TH_HD void lds_st_planes4(float *slab, uint32_t lane, cf32 v0, cf32 v1, cf32 v2,
         slab[(IM0 + i * STEP) / 4 + lane] = v[i].im;
     }
 #endif
+}
+
+// the same from eight scalars (the packed plan stores sub-registers of its pairs)
+template <int RE0, int IM0, int STEP>
+TH_HD void lds_st_planes4f(float *slab, uint32_t lane, float r0, float i0, float r1, float i1, float r2, float i2, float r3, float i3) {
+    lds_st_planes4<RE0, IM0, STEP>(slab, lane, cf32{r0, i0}, cf32{r1, i1}, cf32{r2, i2}, cf32{r3, i3});
 }
 
 // full unrolling is required everywhere below: register arrays must never be indexed dynamically
@@ -934,6 +964,198 @@ struct WaveFft {
         cf32 ws[NQ][R3];
         load_stw_paired(lane, ws, stw);
         split_paired_w(lane, za, zb, ws, stw[NC / 2], emit);
+    }
+
+    // -----------------------------------------------------------------------------------------
+    // Packed-f32 pipeline of the n_fft 2048 plane plan (round 4; arithmetic: stft_pk.h).  Same LDS layouts, same lane ->
+    // butterfly maps and the same butterfly algebra as pass1 / read1 / pass2_w / read2_paired / pass3_paired_w /
+    // split_paired_w above — the instruction stream is re-expressed on register PAIRS:
+    //   pass 1   AoS (re, im): the windowed points as loaded (8-byte loads), un-twiddled 4 x 4 DFT-16  ->  planes
+    //   pass 2   SoA: a ds_read_b128 returns one component of the points 4 t .. 4 t + 3 of the lane's butterfly = the pairs
+    //            (4 t, 4 t + 1), (4 t + 2, 4 t + 3).  Inner butterflies (over a, one per b): b = 0, 1 and b = 2, 3 run as pairs
+    //            (clean); outer butterfly m' takes y_b[m'], b = 0..3, = two pairs: first level clean, second level cross.
+    //   pass 3   SoA: one ds_read_b128 = the four inputs of one radix-4 butterfly = two pairs: clean level, cross level;
+    //            outputs as the pairs (X0, X2), (X1, X3).
+    //   split    pairs of (Z[k], conj Z[Nc - k]) combinations: bins (s, s + 2) of butterfly pair q together; the split
+    //            twiddles come from a table laid out for that (stwp: (w[k].re, w[k + 512].re), (w[k].im, w[k + 512].im)).
+    // -----------------------------------------------------------------------------------------
+    static constexpr bool PK = PLANES;
+    // table of the split twiddles for the packed plan: entry e < 512: re2[e] = (w[e].re, w[e + 512].re), im2[e] likewise;
+    // entries 512, 513: lane 0's two self-mirrored butterflies 0 and Ns3 / 2 = 128: (w[0], w[128]) and (w[256], w[384])
+    static constexpr int STWP_N = 514;           // v2f entries per component
+    static constexpr int STWP_LEN = 2 * STWP_N;  // in cf32-sized (8-byte) units: re2[514] then im2[514]
+    static TH_HD void fill_stwp(uint32_t tid, uint32_t nthr, const cf32 *tw, cf32 *stwp) {
+        for (uint32_t e = tid; e < (uint32_t)STWP_N; e += nthr) {
+            const uint32_t k0 = e < 512u ? e : (e == 512u ? 0u : 256u), k1 = e < 512u ? e + 512u : (e == 512u ? 128u : 384u);
+            stwp[e] = {tw[k0].re, tw[k1].re};
+            stwp[STWP_N + e] = {tw[k0].im, tw[k1].im};
+        }
+    }
+    template <int PITCH, int G>
+    static TH_HD void st_group4_pk(float *sf, uint32_t lane, v2f v0, v2f v1, v2f v2, v2f v3) {  // AoS points -> planes G, G + 4, ..
+        lds_st_planes4f<G * PITCH * 4, (NPL + G) * PITCH * 4, 16 * PITCH>(sf, lane, v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y);
+    }
+    static TH_HD void pass1_pk(uint32_t lane, v2f (&v)[16], cf32 *slab) {
+        float *const sf = reinterpret_cast<float *>(slab);
+        pk_dft16_head(v);
+        pk_dft16_tail<0>(v);
+        st_group4_pk<PITCH1, 0>(sf, lane, v[0], v[1], v[2], v[3]);
+        pk_dft16_tail<1>(v);
+        st_group4_pk<PITCH1, 1>(sf, lane, v[4], v[5], v[6], v[7]);
+        pk_dft16_tail<2>(v);
+        st_group4_pk<PITCH1, 2>(sf, lane, v[8], v[9], v[10], v[11]);
+        pk_dft16_tail<3>(v);
+        st_group4_pk<PITCH1, 3>(sf, lane, v[12], v[13], v[14], v[15]);
+    }
+    // zr[j], zi[j]: components of the points (2 j, 2 j + 1) of the lane's pass-2 butterfly
+    static TH_HD void read1_pk(uint32_t lane, v2f (&zr)[8], v2f (&zi)[8], const cf32 *slab) {
+        const float *const sf = reinterpret_cast<const float *>(slab) + (lane >> 2) * PITCH1 + 16u * (lane & 3u);
+        v2x2 re[4], im[4];
+        TH_UNROLL for (int t = 0; t < 4; t++) {
+            re[t] = lds_ld4_pk(sf + 4 * t);
+            im[t] = lds_ld4_pk(sf + 16 * PITCH1 + 4 * t);
+        }
+        TH_UNROLL for (int t = 0; t < 4; t++) {
+            zr[2 * t] = re[t].lo;
+            zr[2 * t + 1] = re[t].hi;
+            zi[2 * t] = im[t].lo;
+            zi[2 * t + 1] = im[t].hi;
+        }
+    }
+    static TH_HD void load_t2_pk(uint32_t lane, v2f (&w2)[NT2], const cf32 *t2) {
+        const uint32_t k = t2_k(lane);
+        TH_UNROLL for (int r = 0; r < NT2; r++) w2[r] = lds_ld_pk(&t2[r * NS2 + k]);
+    }
+    // twiddled radix-16 butterfly of pass 2 (dft16_tw_to_planes) on pairs, into the planes of exchange 2
+    static TH_HD void pass2_pk(uint32_t lane, v2f (&zr)[8], v2f (&zi)[8], const v2f (&w)[NT2], cf32 *slab) {
+        float *const sf = reinterpret_cast<float *>(slab);
+        // inner butterflies over a (inputs v[b + 4 a]), t = w^4: pairs b = (0, 1) -> j = 0, (2, 3) -> j = 1; v[b + 4 a] = pair 2 a + j.
+        // y_b[m'] ends up in v[b + 4 pi(m')], pi = (0, 2, 1, 3)
+        TH_UNROLL for (int j = 0; j < 2; j++)
+            s_bfly4(zr[j], zi[j], zr[2 + j], zi[2 + j], zr[4 + j], zi[4 + j], zr[6 + j], zi[6 + j], w[0], w[1 % NT2]);
+        // outer butterfly m' over b (inputs y_b[m'] = v[4 PI + b], PI = pi(m')): pairs p = 2 PI, q = 2 PI + 1; t = w W16^m'.
+        // out p = (X[m'], X[m' + 8]), q = (X[m' + 4], X[m' + 12]) -> planes m' + 4 m''
+#define TH_OUTER_PK(MP, PI)                                                                                               \
+    x_bfly4(zr[2 * (PI)], zi[2 * (PI)], zr[2 * (PI) + 1], zi[2 * (PI) + 1], w[(2 + 2 * (MP)) % NT2], w[(3 + 2 * (MP)) % NT2]); \
+    lds_st_planes4f<(MP) * PITCH2 * 4, (NPL + (MP)) * PITCH2 * 4, 16 * PITCH2>(                                           \
+        sf, lane, zr[2 * (PI)].x, zi[2 * (PI)].x, zr[2 * (PI) + 1].x, zi[2 * (PI) + 1].x, zr[2 * (PI)].y, zi[2 * (PI)].y, \
+        zr[2 * (PI) + 1].y, zi[2 * (PI) + 1].y)
+        TH_OUTER_PK(0, 0);
+        TH_OUTER_PK(1, 2);
+        TH_OUTER_PK(2, 1);
+        TH_OUTER_PK(3, 3);
+#undef TH_OUTER_PK
+    }
+    // exchange-2 read, paired layout: butterfly A_q / B_q inputs (0, 1) -> p, (2, 3) -> q
+    struct PkPairs {
+        v2f pr, pi, qr, qi;
+    };
+    static TH_HD void read2_paired_pk(const PairBase &pbs, PkPairs (&za)[NQ], PkPairs (&zb)[NQ], const cf32 *slab) {
+        static_assert(!PLANES || (R3 == 4 && PITCH2 == 64), "one 16-byte load per butterfly and component");
+        const float *const sf = reinterpret_cast<const float *>(slab);
+        v2x2 ar[NQ], ai[NQ], br[NQ], bi[NQ];
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
+            const float *const pa = sf + (pbs.a * 4u + 256u * (uint32_t)q), *const pb = sf + pb_b(pbs, q, 4u, 0u);
+            ar[q] = lds_ld4_pk(pa);
+            ai[q] = lds_ld4_pk(pa + 16 * PITCH2);
+            br[q] = lds_ld4_pk(pb);
+            bi[q] = lds_ld4_pk(pb + 16 * PITCH2);
+        }
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
+            za[q] = {ar[q].lo, ai[q].lo, ar[q].hi, ai[q].hi};
+            zb[q] = {br[q].lo, bi[q].lo, br[q].hi, bi[q].hi};
+        }
+    }
+    static TH_HD void load_t3_paired_pk(const PairBase &pbs, v2f (&wa)[NQ][NT3], v2f (&wb)[NQ][NT3], const cf32 *t3) {
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
+            TH_UNROLL for (int r = 1; r <= NT3; r++) {
+                wa[q][r - 1] = lds_ld_pk(&t3[pbs.a + (uint32_t)((r - 1) * NS3 + 64 * q)]);
+                wb[q][r - 1] = lds_ld_pk(&t3[pb_b(pbs, q, 1u, (uint32_t)((r - 1) * NS3))]);
+            }
+        }
+    }
+    // last pass: za[q] -> p = (Z[A_q], Z[A_q + 2 Ns3]), q = (Z[A_q + Ns3], Z[A_q + 3 Ns3]); zb likewise
+    static TH_HD void pass3_paired_pk(PkPairs (&za)[NQ], PkPairs (&zb)[NQ], const v2f (&wa)[NQ][NT3], const v2f (&wb)[NQ][NT3]) {
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
+            x_bfly4(za[q].pr, za[q].pi, za[q].qr, za[q].qi, wa[q][0], wa[q][1 % NT3]);
+            x_bfly4(zb[q].pr, zb[q].pi, zb[q].qr, zb[q].qi, wb[q][0], wb[q][1 % NT3]);
+        }
+    }
+    // split twiddle pairs of the lane: wr[q][h], wi[q][h] = (w[k(q, h)], w[k(q, h + 2)]) components, h = 0, 1
+    static TH_HD void load_stw_paired_pk(uint32_t lane, v2f (&wr)[NQ][2], v2f (&wi)[NQ][2], const cf32 *stwp) {
+        const uint32_t l6 = lane & 63u;
+        uint32_t e00 = l6 == 0 ? 512u : l6, e01 = l6 == 0 ? 513u : l6 + (uint32_t)NS3;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(e00), "+v"(e01));  // opaque (see split_base)
+#endif
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
+            TH_UNROLL for (int h = 0; h < 2; h++) {
+                const cf32 *const e = q == 0 ? stwp + (h == 0 ? e00 : e01) : stwp + (l6 + (uint32_t)(64 * q + h * NS3));
+                wr[q][h] = lds_ld_pk(e);
+                wi[q][h] = lds_ld_pk(e + STWP_N);
+            }
+        }
+    }
+    // Split pass on pairs (split_paired_w: the same bins, the same emit order of bases and constants).
+    // Generic lane: pair h of butterfly pair q = bins s = h and s = h + 2:  zk = (za X_h, za X_{h+2}), zm = (zb X_{3-h}, zb X_{1-h}).
+    // With za = (p, q) = ((X0, X2), (X1, X3)):  h = 0: zk = za.p, zm = swap(zb.q);  h = 1: zk = za.q, zm = swap(zb.p).
+    // Lane 0, q = 0 pairs inside its two self-mirrored butterflies:  h = 0: zk = (A.X0, B.X0), zm = (A.X0, B.X3);
+    //                                                               h = 1: zk = (A.X1, B.X1), zm = (A.X3, B.X2).
+    template <class Emit>
+    static TH_HD void split_paired_pk(uint32_t lane, const PkPairs (&za)[NQ], const PkPairs (&zb)[NQ], const v2f (&wr)[NQ][2],
+                                      const v2f (&wi)[NQ][2], cf32 w_mid, Emit emit) {
+        static_assert(R3 == 4, "pairs (s, s + 2)");
+        const bool l0 = (lane & 63u) == 0;
+        const SplitBase sb = split_base(lane);
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
+            TH_UNROLL for (int h = 0; h < 2; h++) {
+                const v2f zkr_g = h == 0 ? za[q].pr : za[q].qr, zki_g = h == 0 ? za[q].pi : za[q].qi;
+                const v2f zmr_g = h == 0 ? zb[q].qr : zb[q].pr, zmi_g = h == 0 ? zb[q].qi : zb[q].pi;  // to be read swapped
+                v2f er, ei, dr, di;
+                if (q == 0) {
+                    // lane 0: its own pairs (selects build the pairs in order, no operand swap)
+                    const v2f ak = h == 0 ? za[0].pr : za[0].qr, aki = h == 0 ? za[0].pi : za[0].qi;   // (A.X_h, A.X_{h+2})
+                    const v2f bk = h == 0 ? zb[0].pr : zb[0].qr, bki = h == 0 ? zb[0].pi : zb[0].qi;   // (B.X_h, B.X_{h+2})
+                    const v2f bo = h == 0 ? zb[0].qr : zb[0].pr, boi = h == 0 ? zb[0].qi : zb[0].pi;   // (B.X_{1-h}', ..): (B.X1, B.X3) / (B.X0, B.X2)
+                    // h = 0: zk = (A.X0, l0 ? B.X0 : A.X2), zm = (l0 ? A.X0 : B.X3, l0 ? B.X3 : B.X1)
+                    // h = 1: zk = (A.X1, l0 ? B.X1 : A.X3), zm = (l0 ? A.X3 : B.X2, l0 ? B.X2 : B.X0)
+                    const v2f zkr = mk2(ak.x, l0 ? bk.x : ak.y), zki = mk2(aki.x, l0 ? bki.x : aki.y);
+                    const v2f zmr = h == 0 ? mk2(l0 ? ak.x : bo.y, l0 ? bo.y : bo.x) : mk2(l0 ? ak.y : bo.y, l0 ? bo.y : bo.x);
+                    const v2f zmi = h == 0 ? mk2(l0 ? aki.x : boi.y, l0 ? boi.y : boi.x) : mk2(l0 ? aki.y : boi.y, l0 ? boi.y : boi.x);
+                    er = zkr + zmr;
+                    ei = zki - zmi;
+                    dr = zkr - zmr;
+                    di = zki + zmi;
+                } else {
+                    er = pk_add_sw(zkr_g, zmr_g);
+                    ei = pk_sub_sw(zki_g, zmi_g);
+                    dr = pk_sub_sw(zkr_g, zmr_g);
+                    di = pk_add_sw(zki_g, zmi_g);
+                }
+                // e = Z[k] + conj Z[Nc-k];  d = Z[k] - conj Z[Nc-k];  t = W^k (-i d);  X[k] = e + t,  X[Nc-k] = conj(e - t)
+                const v2f xr = pk_fma(di, wr[q][h], pk_fma(dr, wi[q][h], er));
+                const v2f xi = pk_fma(di, wi[q][h], pk_fma(-dr, wr[q][h], ei));
+                const v2f yr = pk_2x_minus(er, xr), yi = pk_2x_minus(ei, xi);
+                const v2f px = pk_fma(xr, xr, xi * xi), py = pk_fma(yr, yr, yi * yi);
+                TH_UNROLL for (int u = 0; u < 2; u++) {
+                    const int s = h + 2 * u;
+                    const float pxs = u == 0 ? px.x : px.y, pys = u == 0 ? py.x : py.y;
+                    if (q == 0 && s >= R3 / 2) {
+                        emit(sb.hi, (s - R3 / 2) * NS3, pxs);
+                        emit(sb.mhi, (R3 - 1 - s) * NS3, pys);
+                    } else {
+                        emit(sb.lo, 64 * q + s * NS3, pxs);
+                        emit(sb.mlo, CMAX - (64 * q + s * NS3), pys);
+                    }
+                }
+            }
+        }
+        if (l0) {  // the self-mirrored bin Nc/2 = output R3/2 = X2 of butterfly 0
+            const float zre = za[0].pr.y, zim = za[0].pi.y;
+            const float er = 2.0f * zre, di = 2.0f * zim;
+            const float xr = er + di * w_mid.re, xi = di * w_mid.im;
+            emit((uint32_t)NC / 2, 0, xr * xr + xi * xi);
+        }
     }
 };
 
