@@ -598,7 +598,10 @@ def main():
                  ("sr8k_default_mel", "8 kHz default, mel scale (257 mels: banded sums, lane = mel, in the epilogue of the four-frames-per-wave kernel)", wl.wav, 8000, (320, 80, 512, ta.MEL, 0), 0),
                  ("nfft8192", "long transform: n_fft 8192 / hop 2048, linear dB (one workgroup per frame)", wl.wav, 48000, (8192, 2048, 8192, ta.LINEAR, 0), 0),
                  ("nfft16384", "long transform: n_fft 16384 / hop 4096, linear dB (one workgroup per frame)", wl.wav, 48000, (16384, 4096, 16384, ta.LINEAR, 0), 0),
-                 ("nfft32768", "very long transform: n_fft 32768 / hop 8192, linear dB (400 ms window at 48 kHz)", wl.wav, 48000, (32768, 8192, 32768, ta.LINEAR, 0), 0))
+                 ("nfft32768", "very long transform: n_fft 32768 / hop 8192, linear dB (400 ms window at 48 kHz)", wl.wav, 48000, (32768, 8192, 32768, ta.LINEAR, 0), 0),
+                 # the Mel default of long windows has more than 512 mels (src-common/src/lib.rs:91-103): two kernels since round 4
+                 ("nfft4096_mel_default", "48 kHz, n_fft 4096 / hop 1024, mel scale at the default count (695 mels)", wl.wav, 48000, (4096, 1024, 4096, ta.MEL, 0), 0),
+                 ("nfft16384_mel_default", "48 kHz, n_fft 16384 / hop 4096, mel scale at the default count (2785 mels)", wl.wav, 48000, (16384, 4096, 16384, ta.MEL, 0), 0))
         for key, label, wav_, sr_, (w_, h_, nf_, scale, n_mel), sel in cases:
             try:
                 pl = ta.Plan(ctx, sr_, w_, h_, nf_, scale, n_mel)

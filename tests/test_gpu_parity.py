@@ -95,8 +95,9 @@ def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
     wavs = [synth_track(600 + i, sr, n) for i, n in enumerate(lens)]
     plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, n_mel)
     # n_fft 32768 is the largest frame that fits the CU's LDS: workgroup-per-frame kernel (1024 threads, stft_block.h), with the
-    # matrix-core filterbank for mel plans of up to 512 mels; beyond that (and for the default mel counts) the generic kernel
-    want_kernel = ("stft_generic_kernel" if n_fft > 32768 or (scale and n_mel == 0) else
+    # matrix-core filterbank for mel plans of ANY mel count (round 4: the default counts — 5571 mels here — used to drop to
+    # the generic kernel); beyond 32768 the generic kernel
+    want_kernel = ("stft_generic_kernel" if n_fft > 32768 else
                    "stft_block_kernel+mel_mfma_kernel" if scale else "stft_block_kernel")
     assert plan.kernel_name == want_kernel
     fb = None
@@ -338,7 +339,10 @@ def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
                                                     (11025, 441, 110, 512, 0), (8000, 512, 128, 512, 512),
                                                     (96000, 3840, 960, 4096, 0), (88200, 3528, 882, 4096, 100), (88200, 3528, 882, 4096, 0),
                                                     (16000, 400, 50, 512, 5), (12000, 512, 256, 512, 33),
-                                                    (192000, 7680, 1920, 8192, 0), (48000, 16384, 4096, 16384, 200)])
+                                                    (192000, 7680, 1920, 8192, 0), (48000, 16384, 4096, 16384, 200),
+                                                    # more than 512 mels (round 4: the two-kernel path takes any mel count) — the
+                                                    # Mel defaults of long windows at 44.1 / 48 kHz: 1392, 2970 and (n_fft 4096) 695 mels
+                                                    (48000, 8192, 2048, 8192, 0), (44100, 16384, 4096, 16384, 0), (48000, 2048, 512, 2048, 700)])
 def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     """The three mel paths against the oracle on a ragged batch: the filterbank fused into the wave kernel's epilogue
     (n_fft = 2048), the matrix-core path (wave FFT kernel -> amplitudes -> v_mfma_f32_16x16x4_f32 filterbank) and the
@@ -363,14 +367,12 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     band_rows = n_fft == 4096 and want_n_mel <= 512 and max(grp_taps) <= 128
     assert band_rows == ((sr, n_fft, n_mel) in ((96000, 4096, 0), (88200, 4096, 0)))
     second = "+mel_rows_kernel" if rows else "+mel_band_rows_kernel" if band_rows else "+mel_mfma_kernel"
-    mfma = fft_kernel + second if want_n_mel <= 512 else "stft_generic_kernel"  # 32 N tiles max
+    mfma = fft_kernel + second  # (any mel count since round 4; beyond 512 mels there is no fused form)
     # auto: the fused epilogue for n_fft 2048 and (when the piece table fits: <= 512 pieces) 1024, else the matrix-core path
     fused = "stft_wave_kernel(fused mel)"
     # (n_fft 1024 / 2048: the fused epilogue has two forms — banded sums, lane = mel, where the filters are narrow (the default mel
     # counts), pieces / gather otherwise; selector 8 keeps the second form everywhere)
     for which, name in ((1, "stft_generic_kernel"), (3, mfma), (7, fft_kernel + "+mel_mfma_kernel"), (8, None), (0, None)):
-        if which in (3, 7) and mfma == "stft_generic_kernel":
-            continue  # more than 512 mels: there is no matrix-core path to force
         if which == 7 and not (rows or band_rows):
             continue
         if which == 8 and n_fft not in (1024, 2048):
@@ -379,7 +381,9 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
         if which:
             plan.set_kernel(which)
         if name is None:
-            assert plan.kernel_name == fused if (n_fft == 2048 or rows) else plan.kernel_name in (fused, mfma)
+            assert plan.kernel_name == fused if ((n_fft == 2048 and want_n_mel <= 512) or rows) else plan.kernel_name in (fused, mfma)
+            if want_n_mel > 512:
+                assert plan.kernel_name == mfma
             if (n_fft, want_n_mel) in ((1024, 128), (1024, 385), (1024, 308)):
                 assert plan.kernel_name == fused  # incl. the default mel counts of 16 and 22.05 kHz audio
         else:

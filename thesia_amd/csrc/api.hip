@@ -533,8 +533,9 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
             lo[m] = b ? a : 0;
             hi[m] = b;
         }
-        if (n_mel <= 512) {
-            // MFMA mel path tables (kernels_mel.hip): for every N tile j of 16 mels the band of K blocks (16 bins each)
+        {
+            // MFMA mel path tables (kernels_mel.hip; any mel count since round 4 — the Mel default of long windows, e.g. 5571 mels
+            // at n_fft 32768 / 48 kHz, used to fall back to the generic kernel: 12 ms where the linear plan takes 2): for every N tile j of 16 mels the band of K blocks (16 bins each)
             // that hold non-zeros, and the filterbank of those blocks in operand order: lane (kq = lane / 16,
             // li = lane % 16), step s -> fb[16 kb + 4 kq + s][16 j + li]
             const uint32_t nt = (uint32_t)((n_mel + 15) / 16);
@@ -605,7 +606,7 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
             if (rc == TH_OK) rc = up((void **)&p->d_mel_band, band.data(), band.size() * sizeof(uint32_t));
             if (rc == TH_OK) rc = up((void **)&p->d_mel_slice, slice.data(), slice.size() * sizeof(uint32_t));
         }
-        if (rc == TH_OK && th::stft_wave_supported(g)) {
+        if (rc == TH_OK && th::stft_wave_supported(g) && n_mel <= 512) {  // (the fused forms: lane = mel in at most 8 groups of 64)
             // fused mel epilogue of the wave kernel: piece / gather tables, when the filterbank has the expected structure
             const th::MelFuseHost mf = th::build_mel_fuse(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, th::stft_wave_mel_max_pieces(g));
             if (rc == TH_OK && g.log2_nc == 11) {
@@ -727,7 +728,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     const bool wave = p->use_wave();
     const bool mel_mfma = p->use_mel_mfma(), mel_fused = p->use_mel_fused();
     if (p->kernel_choice >= 2 && !wave)
-        return fail(TH_ERR_UNSUPPORTED, "the wave kernels cover n_fft 512 .. 32768 (mel: n_mel <= 512)");
+        return fail(TH_ERR_UNSUPPORTED, "the wave kernels cover n_fft 512 .. 32768");
     StftGeom g = p->g;       // main launch
     StftGeom ge = p->g;      // edge launch (generic kernel)
     // wave kernel: chunk of consecutive frames one wave walks (the first frame of a chunk loads

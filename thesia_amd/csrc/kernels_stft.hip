@@ -1398,9 +1398,10 @@ namespace th {
 
 // n_fft 512 (multi-frame kernel): linear dB only
 bool stft_wave_supported(const StftGeom &g) {
-    // n_fft 512 (multi-frame kernel) ... 4096 (one frame per wave), 8192 / 16384 / 32768 (block kernel); mel plans up to 512
-    // mels (fused epilogue at n_fft 1024 / 2048 where the tables fit, else amplitude rows + the matrix-core kernel)
-    return g.log2_nc >= 8 && g.log2_nc <= 14 && g.n_mel <= 512;
+    // n_fft 512 (multi-frame kernel) ... 4096 (one frame per wave), 8192 / 16384 / 32768 (block kernel); mel plans: fused
+    // epilogue at n_fft 512 / 1024 / 2048 where the tables fit (at most 512 mels), else amplitude rows + a second kernel
+    // (banded sums or the matrix cores: any mel count)
+    return g.log2_nc >= 8 && g.log2_nc <= 14;
 }
 bool stft_is_block_plan(const StftGeom &g) { return g.log2_nc >= 12; }
 bool stft_wave_multi_applies(const StftGeom &g, int out_mode) {
