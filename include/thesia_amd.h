@@ -174,7 +174,10 @@ TH_API int th_plan_dims(const th_plan *plan, size_t *n_freq, size_t *height);
  * banded-sum kernel over the amplitude rows (n_fft 512 under filters of at most 8 bins: the default mel counts of 8-12 kHz audio),
  * 8 = the fused mel epilogue in its pieces / gather form where banded sums are the default (A/B),
  * 9 = the wave kernel's packed-f32 pipeline (v_pk_fma_f32 butterflies on register pairs) where it is instantiated: n_fft 2048,
- * hop = n_fft / 4, linear dB, default waves (A/B: it measures the same as the scalar pipeline; elsewhere as 2);
+ * hop = n_fft / 4, linear dB, default waves (A/B: it measures the same as the scalar pipeline; elsewhere as 2),
+ * 11 = the wave kernel with the "sweep" chunk schedule (4-frame chunks dealt out in order through a per-workgroup ticket
+ * counter, the next chunk's first frame prefetched) on large batches of that same shape (A/B: a faster memory skeleton, the
+ * same launch time; elsewhere as 2; 10 is reserved and behaves as 2);
  * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
  * frames per queue pull */
 TH_API int th_plan_set_kernel(th_plan *plan, int which);

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <algorithm>
+#include <type_traits>
 #include <ctime>
 #include <vector>
 
@@ -264,6 +265,215 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// "Sweep" schedule (round 4): the same per-frame traffic and stand-in work, but the frames are dealt out so that everything
+// in flight chip-wide is one compact window moving linearly through input and output (what the DRAM likes: r03 stream_shapes B)
+// WITHOUT giving up the register reuse and without a workgroup barrier:
+//   * a workgroup pulls GROUPS of SUBS x SUBF consecutive frames of one channel from the in-order device-wide queue (one
+//     atomic per group: 7.5 k per launch instead of 90 k), one group ahead of its use;
+//   * inside the workgroup the waves draw SUB-CHUNKS of SUBF = 4 frames from a ticket counter in LDS (dynamic: the waves of a
+//     SIMD run at different speeds), so its 12 waves write 12 neighbouring 16 KB pieces at any time;
+//   * the first frame of the NEXT sub-chunk (all 16 slots) is requested in the last frame of the current one, where the kept
+//     slots are dead anyway: a sub-chunk start exposes no load latency and needs no extra registers.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int FMA, int LDSR, int WAVES, int SUBS>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sweep(const float *wav_, float *spec_, uint32_t n_chan, uint32_t n_samples, uint32_t T,
+                                                      uint32_t groups_per_chan, uint32_t *queue, float seed) {
+    constexpr uint32_t SUBF = 4, GF = SUBS * SUBF, K = 8;
+    // (the scheduler's words sit in front of the dynamic LDS: keep the slabs 16-byte aligned — misaligned ds_read_b128 cost
+    // this skeleton 0.27 ms per launch before the attribute was there)
+    extern __shared__ __attribute__((aligned(256))) v2f lds[];
+    __shared__ uint32_t s_ticket, s_group[K], s_tag[K];
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    v2f *slab = lds + wave * 1100;
+    const uint32_t n_groups = n_chan * groups_per_chan, fpc = T - 4;  // interior frames per channel
+    if (threadIdx.x == 0) {
+        s_ticket = 0;
+        for (uint32_t i = 0; i < K; i++) s_tag[i] = 0xffffffffu;
+        s_group[0] = blockIdx.x;  // sequence 0: static
+        s_tag[0] = 0;
+        s_group[1] = atomicAdd(queue, 1u) + gridDim.x;  // sequence 1
+        s_tag[1] = 1;
+    }
+    __syncthreads();
+    // resolves ticket t -> (valid, channel, first frame); fills the group slot one sequence ahead when t opens a group
+    auto draw = [&](uint32_t &ch, uint32_t &f0, uint32_t &nf) -> int {  // 1 valid, 0 skip (ragged tail of a group), -1 no more groups
+        uint32_t t = 0;
+        // (explicit LDS address space everywhere: through a generic volatile pointer these become FLAT operations, which count on
+        // vmcnt, and every draw then waits for the wave's outstanding row stores)
+        if (lane == 0) t = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)&s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const uint32_t q = t / SUBS, sub = t % SUBS;
+        if (sub == 0 && q >= 1) {  // this wave opens group q: pull the group of sequence q + 1
+            uint32_t g2 = 0;
+            if (lane == 0) g2 = atomicAdd(queue, 1u);
+            g2 = __builtin_amdgcn_readfirstlane(g2) + gridDim.x;
+            if (lane == 0) {
+                // (LDS executes one wave's DS operations in order and is the only copy of these words: program order of the two
+                // stores is all the release there is to do — a workgroup-scope fence would drain vmcnt, i.e. wait for the frame's
+                // row stores)
+                *(volatile __attribute__((address_space(3))) uint32_t *)&s_group[(q + 1) % K] = g2;
+                asm volatile("" ::: "memory");
+                *(volatile __attribute__((address_space(3))) uint32_t *)&s_tag[(q + 1) % K] = q + 1;
+            }
+        }
+        for (uint32_t spin = 0; *(volatile __attribute__((address_space(3))) uint32_t *)&s_tag[q % K] != q; spin++) {
+            if (spin > (1u << 22)) return -1;  // (cannot happen: the opener of group q - 1 fills the slot; bounded anyway)
+            __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("" ::: "memory");
+        const uint32_t g = __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) uint32_t *)&s_group[q % K]);
+        if (g >= n_groups) return -1;
+        ch = g / groups_per_chan;
+        const uint32_t fr = (g % groups_per_chan) * GF + sub * SUBF;  // frame offset inside the channel's interior range
+        if (fr >= fpc) return 0;
+        f0 = 2 + fr;
+        nf = min(SUBF, fpc - fr);
+        return 1;
+    };
+    const uint32_t L = 4 * (lane & 15) + (lane >> 4);
+    uint32_t ch = 0, f0 = 0, nf = 0;
+    int st;
+    do st = draw(ch, f0, nf); while (st == 0);
+    if (st < 0) return;
+    v2f x[16];
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = seed + i;
+    {
+        const gf *wav = (const gf *)(wav_ + (size_t)ch * n_samples);
+        const int64_t e0 = (int64_t)f0 * HOP - N_FFT / 2;
+#pragma unroll
+        for (int m = 0; m < 16; m++) x[m] = *(const gf2 *)(wav + e0 + 2 * (L + 64 * m));
+    }
+    // one frame: consume x, request what the next frame needs (KIND 0: the next frame of the sub-chunk, 4 new slots; 1: the first
+    // frame of the next sub-chunk, all 16 slots; 2: nothing), stand-in work, row stores.  Straight-line code per KIND: with the
+    // frames in a run-time loop the compiler cannot count the outstanding loads / stores across the back edge and waits for
+    // vmcnt(0) at the loop head, i.e. for the previous frame's STORES (0.76 ms instead of 0.50 with the kernel's work).
+    auto frame = [&](auto kind, const gf *wav, gf *spec, uint32_t f, const gf *wn, int64_t e0n) {
+        constexpr int KIND = decltype(kind)::value;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = acc[i] * 0.999f + (x[i].x + x[i].y);
+        if constexpr (KIND == 0) {
+            const int64_t e1 = (int64_t)(f + 1) * HOP - N_FFT / 2;
+#pragma unroll
+            for (int m = 0; m < 12; m++) x[m] = x[m + 4];
+#pragma unroll
+            for (int m = 12; m < 16; m++) x[m] = *(const gf2 *)(wav + e1 + 2 * (L + 64 * m));
+        } else if constexpr (KIND == 1) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = *(const gf2 *)(wn + e0n + 2 * (L + 64 * m));
+        }
+#pragma unroll 1
+        for (int r = 0; r < FMA; r++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = __builtin_fmaf(acc[i], 1.0001f, 0.25f);
+        }
+#pragma unroll 1
+        for (int r = 0; r < LDSR; r++) {
+            const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)slab);
+#define WA(i, o) "ds_write_addtid_b32 %" #i " offset:" #o "\n\t"
+            asm volatile("s_mov_b32 m0, %16\n\ts_nop 0\n\t" WA(0, 0) WA(1, 272) WA(2, 544) WA(3, 816) WA(4, 1088) WA(5, 1360) WA(6, 1632) WA(7, 1904)
+                         WA(8, 2176) WA(9, 2448) WA(10, 2720) WA(11, 2992) WA(12, 3264) WA(13, 3536) WA(14, 3808) WA(15, 4080)
+                         :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]),
+                         "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15]),
+                         "s"(base) : "memory");
+            asm volatile("s_mov_b32 m0, %16\n\ts_nop 0\n\t" WA(0, 4352) WA(1, 4624) WA(2, 4896) WA(3, 5168) WA(4, 5440) WA(5, 5712) WA(6, 5984) WA(7, 6256)
+                         WA(8, 6528) WA(9, 6800) WA(10, 7072) WA(11, 7344) WA(12, 7616) WA(13, 7888) WA(14, 8160) WA(15, 8432)
+                         :: "v"(acc[15]), "v"(acc[14]), "v"(acc[13]), "v"(acc[12]), "v"(acc[11]), "v"(acc[10]), "v"(acc[9]), "v"(acc[8]),
+                         "v"(acc[7]), "v"(acc[6]), "v"(acc[5]), "v"(acc[4]), "v"(acc[3]), "v"(acc[2]), "v"(acc[1]), "v"(acc[0]),
+                         "s"(base) : "memory");
+#undef WA
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // (explicit LDS address space: inside the lambda the slab pointer is "flat" to the compiler, and flat loads go through
+            // the vector memory pipe)
+            const __attribute__((address_space(3))) float *sf = (const __attribute__((address_space(3))) float *)slab;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const v4f v = *(const __attribute__((address_space(3))) v4f *)(&sf[(4 * i + (lane >> 4)) * 68 + 4 * (lane & 15)]);
+                acc[2 * i] += v.x + v.y;
+                acc[2 * i + 1] += v.z + v.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        gf *row = spec + (size_t)f * PITCH;
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) row[lane + 64 * jj] = acc[jj];
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) row[1024 - lane - 64 * jj] = acc[8 + jj];
+        if (lane == 0) row[512] = acc[0];
+        if (lane - 1u < 31u) row[1024 + lane] = 0.f;
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    for (;;) {
+        const gf *wav = (const gf *)(wav_ + (size_t)ch * n_samples);
+        gf *spec = (gf *)(spec_ + (size_t)ch * T * PITCH);
+        uint32_t chn = 0, f0n = 0, nfn = 0;
+        int stn;
+        if (nf == SUBF) {
+            frame(K0{}, wav, spec, f0, wav, 0);
+            frame(K0{}, wav, spec, f0 + 1, wav, 0);
+            // the next sub-chunk is drawn a frame before its first frame is requested: the ticket, a possible queue pull and
+            // the table look-up are over when the last frame starts
+            do stn = draw(chn, f0n, nfn); while (stn == 0);
+            frame(K0{}, wav, spec, f0 + 2, wav, 0);
+            const gf *wn = (const gf *)(wav_ + (size_t)chn * n_samples);
+            const int64_t e0n = (int64_t)f0n * HOP - N_FFT / 2;
+            if (stn > 0) frame(K1{}, wav, spec, f0 + 3, wn, e0n);
+            else frame(K2{}, wav, spec, f0 + 3, wn, e0n);
+        } else {  // ragged tail of a channel (1..3 frames)
+            for (uint32_t j = 0; j + 1 < nf; j++) frame(K0{}, wav, spec, f0 + j, wav, 0);
+            do stn = draw(chn, f0n, nfn); while (stn == 0);
+            const gf *wn = (const gf *)(wav_ + (size_t)chn * n_samples);
+            const int64_t e0n = (int64_t)f0n * HOP - N_FFT / 2;
+            if (stn > 0) frame(K1{}, wav, spec, f0 + nf - 1, wn, e0n);
+            else frame(K2{}, wav, spec, f0 + nf - 1, wn, e0n);
+        }
+        if (stn < 0) return;
+        ch = chn;
+        f0 = f0n;
+        nf = nfn;
+    }
+}
+
+template <int FMA, int LDSR, int WAVES, int SUBS>
+static void run_sweep(const float *wav, float *spec, uint32_t n_chan, uint32_t n_samples, uint32_t T, uint32_t *q, int gap_us) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const uint32_t gpc = (T - 4 + SUBS * 4 - 1) / (SUBS * 4);
+    auto kern = k_sweep<FMA, LDSR, WAVES, SUBS>;
+    const size_t lds = (size_t)WAVES * 1100 * sizeof(v2f);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    std::vector<float> ts;
+    for (int i = 0; i < 24; i++) {
+        hipMemsetAsync(q, 0, 4, 0);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WAVES), lds, 0, wav, spec, n_chan, n_samples, T, gpc, q, 1.0f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (i >= 4) ts.push_back(ms);
+        if (gap_us) {
+            hipDeviceSynchronize();
+            struct timespec t = {0, gap_us * 1000};
+            nanosleep(&t, nullptr);
+        }
+    }
+    std::sort(ts.begin(), ts.end());
+    const double med = ts[ts.size() / 2], frames = (double)n_chan * (T - 4);
+    printf("sweep: groups of %2d x 4 frames, fma %4d ldsr %d waves %2d: median %.3f ms min %.3f  %.0f GB/s\n", SUBS, FMA * 16, LDSR, WAVES, med, ts[0],
+           frames * 6148.0 / med / 1e6);
+    fflush(stdout);
+}
+
 static int g_json = 0;       // > 0: JSON output (mode 7), counts the entries printed
 static uint32_t g_grid = 0;  // 0: one workgroup per CU (persistent); else this many workgroups (argv[3])
 template <int LOADM, int STOREM, int FMA, int LDSR, int WAVES, int LDSM = 0>
@@ -346,6 +556,25 @@ int main(int argc, char **argv) {
             R(3, 3, 42, 2, 12, 2);
             R(3, 3, 42, 3, 12, 2);
             R(3, 4, 42, 2, 12, 2);
+        }
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == 8) {  // the sweep schedule against the kernel's schedule: no work / the kernel's amount of work
+        for (int rep = 0; rep < 2; rep++) {
+            R(3, 1, 0, 0, 12, 2);
+            run_sweep<0, 0, 12, 12>(wav, spec, n_chan, n_samples, T, q, gap_us);
+            run_sweep<0, 0, 12, 24>(wav, spec, n_chan, n_samples, T, q, gap_us);
+            run_sweep<0, 0, 12, 6>(wav, spec, n_chan, n_samples, T, q, gap_us);
+            R(3, 1, 42, 2, 12, 2);
+            run_sweep<42, 2, 12, 12>(wav, spec, n_chan, n_samples, T, q, gap_us);
+            run_sweep<42, 2, 12, 24>(wav, spec, n_chan, n_samples, T, q, gap_us);
+            run_sweep<42, 2, 12, 6>(wav, spec, n_chan, n_samples, T, q, gap_us);
+            run_sweep<30, 2, 12, 12>(wav, spec, n_chan, n_samples, T, q, gap_us);
+            run_sweep<42, 0, 12, 12>(wav, spec, n_chan, n_samples, T, q, gap_us);
+            run_sweep<0, 2, 12, 12>(wav, spec, n_chan, n_samples, T, q, gap_us);
+            run_sweep<10, 0, 12, 12>(wav, spec, n_chan, n_samples, T, q, gap_us);
+            R(3, 1, 42, 0, 12, 2);
+            R(3, 1, 0, 2, 12, 2);
         }
         return 0;
     }

@@ -423,6 +423,52 @@ def test_packed_f32_pipeline_matches_oracle_and_scalar_pipeline(ctx):
     ref.close()
 
 
+def test_sweep_chunk_schedule_matches_the_default_schedule(ctx):
+    """th_plan_set_kernel(plan, 11): the wave kernel's sweep schedule (round 4: 4-frame chunks dealt out in order through a
+    per-workgroup ticket counter in LDS, blocks of 12 chunks from the device-wide queue, the next chunk's first frame
+    requested by the current chunk's last frame).  A batch large enough to use it (more than 32 frames per wave of the grid),
+    ragged, with a channel shorter than n_fft in it: the oracle on head / tail cuts of sampled channels, every row equal to
+    the default schedule's to f32 rounding, true min / max, padding zeros, and twice in a row (the queue is rewound)."""
+    import torch
+    sr, win, hop, n_fft = 48000, 2048, 512, 2048
+    lens = [48000 * 25 + 17 * i for i in range(44)] + [1500, 2048, 4099, 48000 * 3 + 1]
+    plan, ref = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR), ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    plan.set_kernel(11)
+    dev = torch.device("cuda", ctx.device)
+    wavs = [torch.from_numpy(synth_track(900 + i, sr, n)).to(dev) for i, n in enumerate(lens)]
+    T = [plan.n_frames(n) for n in lens]
+    assert sum(T) > 256 * 12 * 32
+    H, sp = plan.height, ta.pitch_f32(plan.height)
+    outs = []
+    for pl in (plan, ref, plan):
+        spec = [torch.full((t, sp), -12345.0, dtype=torch.float32, device=dev) for t in T]
+        mm = torch.empty((len(lens), 2), dtype=torch.float32, device=dev)
+        chan = (ta.ChanDesc * len(lens))(*[ta.ChanDesc(w.data_ptr(), s_.data_ptr(), n, t, sp) for w, s_, n, t in zip(wavs, spec, lens, T)])
+        pl.calc_spec_batch_dev(chan, mm.data_ptr())
+        torch.cuda.synchronize()
+        outs.append((spec, mm.cpu().numpy()))
+    (a, mma), (b, mmb), (a2, mma2) = outs
+    for i in range(len(lens)):
+        sa, sb = a[i][:, :H], b[i][:, :H]
+        assert torch.equal(a[i], a2[i])                                        # same schedule twice: bit for bit
+        pad = a[i][:, H:]
+        assert bool(((pad == 0) | (pad == -12345.0)).all())                    # row padding: completed with zeros (wave kernel) or untouched
+        assert not bool((sa == -12345.0).any())                                # every bin of every frame written
+        assert mma[i, 0] == float(sa.min()) and mma[i, 1] == float(sa.max())
+        pa, pb = torch.pow(10.0, sa.double() / 20), torch.pow(10.0, sb.double() / 20)
+        finite = torch.isfinite(pa) & torch.isfinite(pb)
+        scale = pb.amax(dim=1, keepdim=True).clamp_min(1e-30)
+        assert float(((pa - pb).abs() / scale)[finite].max()) <= 3e-6, i
+    for i in (0, 43, 44, 46, 47):  # head / tail cuts against the oracle
+        x = wavs[i].cpu().numpy()
+        want, amp = orc.calc_spec(x[: min(len(x), 6 * n_fft)], win, hop, n_fft, return_amp=True)
+        got = a[i][:, :H].cpu().numpy()
+        k = max(1, want.shape[0] - 6)  # frames that do not see the cut
+        assert_spec_close(got[:k], want[:k], amp[:k])
+    plan.close()
+    ref.close()
+
+
 def test_calc_spec_batch_ragged(ctx):
     """Ragged batch: different lengths incl. N < win, one silent channel, per-channel min/max."""
     win, hop, n_fft = 2048, 512, 2048

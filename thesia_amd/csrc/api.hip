@@ -682,9 +682,11 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     // fused mel epilogue, 6 wave with the two-frames-per-wave plan at n_fft 1024, 7 as 3 with the matrix-core kernel also where
     // the banded-sum kernel for short rows under narrow filters is the default (n_fft 512), 8 fused mel epilogue in its pieces / gather
     // form where the banded sums are the default, 9 wave kernel with the packed-f32 pipeline (stft_pk.h) on the launch shape it is
-    // instantiated for (n_fft 2048, hop = n_fft / 4, linear dB, default waves; elsewhere as 2);  bits 8-15 (tuning): waves per workgroup
+    // instantiated for (n_fft 2048, hop = n_fft / 4, linear dB, default waves; elsewhere as 2), 11 wave kernel with the sweep chunk
+    // schedule (4-frame chunks dealt out in order) on large batches of that same shape (A/B; elsewhere as 2; 10 is reserved: as 2);
+    // bits 8-15 (tuning): waves per workgroup
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 9, "kernel selector must be 0 .. 9");
+    TH_REQUIRE(k >= 0 && k <= 11, "kernel selector must be 0 .. 11");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     // the multi-frame plans (n_fft 512; n_fft 1024 under selector 6) are instantiated for 8, 12 and 16 waves only
@@ -772,6 +774,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     // reflect-indexed fetch): no second launch on the fast path.  Not on the matrix-core mel path (its amplitude rows
     // are laid out for the interior jobs), not for channels shorter than n_fft (a single reflection is not enough there).
     const bool edges_in_wave = wave && !mel_mfma && !phased && !th::stft_is_block_plan(g);
+    bool sweep = false;
     if (wave) {
         uint64_t total = 0;
         for (size_t i = 0; i < n_chan; i++) total += chans[i].n_frames;
@@ -821,6 +824,15 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
             chunk = best;
         }
         g.frames_per_tile = p->wave_chunk > 0 ? (uint32_t)p->wave_chunk : (uint32_t)chunk;
+        // The sweep schedule (kernels_stft.hip: 4-frame chunks dealt out in order, next chunk prefetched) — round 4, selector 11
+        // only: its memory skeleton streams 3-10 % faster (scripts/ubench/stft_skeleton.hip mode 8), the kernel does not: inside
+        // bench.py's step 0.492 / 0.497 / 0.496 ms against 0.495 / 0.495 / 0.494 for the default schedule on one box, alternating,
+        // and 8 % SLOWER alone with 1 ms gaps (profiles/r04_ab_sweep.txt).  With the packed-f32 pipeline (-39 % VALU instructions,
+        // +-0) that makes three independent changes of what the kernel DOES per frame that do not change what a launch TAKES:
+        // it runs at the package power cap, where time follows flops + bytes, and neither moved.
+        sweep = total > n_waves * 32 && p->wave_chunk == 0 && p->kernel_choice == 11 && !mel_mfma && !mel_fused &&
+                g.n_mel == 0 && phase_mode == 0 && th::stft_wave_sweep_applies(g, p->wave_waves, 0);
+        if (sweep) g.frames_per_tile = 4;
         if (phase_mode == 1) g.frames_per_tile = std::max<uint32_t>(4, (g.frames_per_tile + 3) / 4 * 4);  // chunks start on the grid
     } else {
         g.frames_per_tile = 8;
@@ -957,6 +969,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         // every frame in full: 16 loads per iteration against 4), so 1024 keeps the one-frame kernel by default.
         wo.multi = (th::stft_wave_multi_applies(g, wo.mode) && (g.log2_nc == 8 || p->kernel_choice == 6)) ? 1 : 0;
         wo.packed = p->kernel_choice == 9 ? 1 : 0;
+        wo.sweep = sweep ? 1 : 0;
         if (mel_fused && g.log2_nc == 8) {  // (the per-mel table of the banded sums, kernels.h)
             wo.mel_tab = p->d_mel_rows;
             wo.mel_groups = p->mel_rows_groups;

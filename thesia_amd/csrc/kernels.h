@@ -49,6 +49,7 @@ struct WaveOut {
     int mode = 0;                     // 0 dB linear, 1 amplitude, 2 fused mel
     int multi = 0;                    // 1: the multi-frame kernel (n_fft 512 / 1024, stft_wave_multi.h; mode 0 only)
     int packed = 0;                   // 1: the packed-f32 pipeline (stft_pk.h) where it is instantiated (selector 9), else ignored
+    int sweep = 0;                    // 1: the sweep chunk schedule (4-frame chunks dealt out in order; n_fft 2048, hop = n_fft / 4, dB rows, 12 waves)
     const uint32_t *mel_tab = nullptr;  // DEVICE: mel_fuse.h word table
     uint32_t mel_words = 0, mel_slots = 0, mel_groups = 0, n_mel = 0;
     // banded sums (mel_slots == 0, build_mel_band): the table's header again, as kernel arguments (scalar registers instead
@@ -59,6 +60,8 @@ struct WaveOut {
 // the launch shape leaves room in LDS for a table of `words`
 int stft_wave_phased_mode(const StftGeom &g, int waves);  // 0 no, 1 phased (hop 480), 2 dynamic (e.g. 441)
 uint32_t stft_wave_mel_max_pieces(const StftGeom &g);
+// the sweep chunk schedule exists for this launch (shape, output mode, wave count; the caller adds: batch large enough)
+bool stft_wave_sweep_applies(const StftGeom &g, int waves, int out_mode);
 // banded: the banded-sum table (no per-wave (r, f) buffer at n_fft 1024, which only the pieces / gather form uses)
 bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool banded = false);
 // n_fft 512 (four frames per wave): does the mel_rows table fit the launch's LDS beside the slabs at this wave count?

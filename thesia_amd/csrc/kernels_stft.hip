@@ -214,6 +214,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // A wave's position in the frame stream.  All members are wave-uniform (SGPRs).
 struct FrameCursor {
     uint32_t f, f1, mm_index, spec_pitch, t;  // t: chunk index
+    uint32_t chan, f_end;                     // job index and the end of its frame range (cursor_next)
     uint32_t n_samples, edge;
     gptr<const float> wav;
     gptr<float> spec;
@@ -232,8 +233,10 @@ __device__ __forceinline__ FrameCursor cursor_at(const StftGeom &g, const ChanJo
         const uint32_t chan = chunk_tab[2 * (size_t)t];
         c.f = chunk_tab[2 * (size_t)t + 1];
         c.edge = jobs[chan].edge;
+        c.chan = chan;
+        c.f_end = jobs[chan].f_end;
         const uint32_t fpt = c.edge ? 1u : g.frames_per_tile;  // boundary frames: one per chunk (no register reuse)
-        c.f1 = min(c.f + fpt, jobs[chan].f_end);
+        c.f1 = min(c.f + fpt, c.f_end);
         c.n_samples = jobs[chan].n_samples;
         c.mm_index = jobs[chan].mm_index;
         c.t = t;
@@ -242,6 +245,21 @@ __device__ __forceinline__ FrameCursor cursor_at(const StftGeom &g, const ChanJo
         c.spec = as_global(jobs[chan].spec);
         c.fresh = true;
     }
+    return c;
+}
+
+// The same for a chunk that usually continues the previous cursor's job (sweep schedule: consecutive 4-frame chunks): one
+// 8-byte scalar load of the chunk table, and the job's fields only when the job changes.
+__device__ __forceinline__ FrameCursor cursor_next(const StftGeom &g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab,
+                                                   uint32_t n_tiles, uint32_t t, const FrameCursor &prev) {
+    if (t >= n_tiles) return FrameCursor{};
+    const uint2 e = *reinterpret_cast<const uint2 *>(chunk_tab + 2 * (size_t)t);
+    if (!prev.valid || e.x != prev.chan) return cursor_at(g, jobs, chunk_tab, n_tiles, t);
+    FrameCursor c = prev;
+    c.f = e.y;
+    c.f1 = min(c.f + (c.edge ? 1u : g.frames_per_tile), c.f_end);
+    c.t = t;
+    c.fresh = true;
     return c;
 }
 
@@ -321,7 +339,11 @@ constexpr uint32_t MEL_PRF_1024 = 512;  // pieces of the per-wave (r, f) buffer 
 // PH == -2: "dynamic" mode — any hop in (128 SHIFT, 128 (SHIFT + 1)): the offset and the number of reused slots (SHIFT or
 // SHIFT + 1) are computed per frame (wave-uniform), registers are moved instead of rotated, wtab = even table, the odd
 // one (pairs shifted by one sample) NC + 64 entries behind it, each with 64 zero pairs in front.
-template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH = -1, bool PKV = false>
+// SWEEPF (sweep schedule, see stft_wave_kernel): this is the fourth and last frame of a chunk, and the NEXT chunk's first
+// frame is requested in full — all P slots from (nwav, ne0) — where a frame otherwise requests the slots its successor in
+// the chunk needs: after the window multiply every slot is dead in a chunk's last frame, so the next chunk starts without an
+// exposed fetch and without an extra register.
+template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH = -1, bool PKV = false, bool SWEEPF = false>
 __device__ __forceinline__ void wave_frame(
     const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
     uint32_t f, uint32_t f1, gptr<const float> wav, uint32_t n_samples, gptr<float> spec, uint32_t spec_pitch, cf32 (&x)[WaveFft<LOG2_NC>::P],
@@ -329,7 +351,8 @@ __device__ __forceinline__ void wave_frame(
     const cf32 (&rwa)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::NT3],
     const cf32 (&rwb)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::NT3],
     const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], cf32 rw_mid, float &lmin, float &lmax,
-    const uint32_t *meltab, cf32 *mel_prf, const WaveOut &wo) {
+    const uint32_t *meltab, cf32 *mel_prf, const WaveOut &wo, bool nxt_full = false, gptr<const float> nwav = nullptr,
+    int64_t ne0 = 0) {
     constexpr bool AMP = OUT == 1, MELF = OUT == 2;
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
@@ -401,6 +424,11 @@ __device__ __forceinline__ void wave_frame(
             }
         } else if constexpr (SHIFT == 0) {
             wave_fetch<P, 0>(col, x, wav, e0n);
+        } else if constexpr (ROTATE && SWEEPF) {
+            // (unconditional: a wave-uniform branch between the two fetches made the register allocator spill loaded slots
+            // behind a vmcnt(0) in every frame; the caller passes this frame's own span when there is nothing to prefetch)
+            (void)nxt_full;
+            wave_fetch<P, 0>(col, x, nwav, ne0);
         } else if constexpr (ROTATE) {
             wave_fetch_rot<P, SHIFT, OFF>(col, x, wav, e0n);
         } else {
@@ -601,7 +629,23 @@ __device__ __forceinline__ void wave_frame(
 // multiple of 128 samples or hop >= n_fft)
 // AMP: store the linear amplitude |X| instead of dB and skip min/max (first half of the mel path;
 // mel_mfma_kernel then applies the filterbank).
-template <int LOG2_NC, int WAVES, int SHIFT, int OUT, int RES, bool PKV = false>
+// SWEEP (round 4; rotation mode with NROT = 4, i.e. hop = n_fft / 4): the "sweep" chunk schedule for large batches.  Chunks
+// are 4 frames (one rotation cycle) and are dealt out IN ORDER, so that everything in flight chip-wide is one compact window
+// moving linearly through the input and the output — what the DRAM likes (r03 stream_shapes: 5.9-6.4 TB/s against 4.9-5.1 for
+// 3072 independent 126 KB streams; scripts/ubench/stft_skeleton.hip mode 8 with this very schedule: 3-10 % off the memory
+// skeleton, 8-10 % with the kernel's FMA work) — without giving up the register reuse or the dynamic balance, and without a
+// workgroup barrier:
+//   * a workgroup takes BLOCKS of SWEEP_BLK = 12 consecutive chunks from the device-wide in-order queue (one returning
+//     atomicAdd per block, 7.5 k per launch of the bench workload where per-chunk pulls would be 90 k at ~8 ns each), one block
+//     ahead of its use; its first block is its own index;
+//   * its waves draw chunks of the current block from a ticket counter in LDS (the three waves of a SIMD run at different
+//     speeds: dynamic inside the workgroup), so the 12 waves of a CU write 12 neighbouring 16 KB pieces at any time;
+//   * the first frame of a wave's next chunk is requested in the last frame of its current one (wave_frame, SWEEPF), its
+//     cursor having been drawn and looked up a frame earlier.
+// The (job, first frame) chunk table, the per-chunk (min, max) slots and wave_post_kernel's fold are the ones of the default
+// schedule; queue_head counts blocks here.
+constexpr uint32_t SWEEP_BLK = 12, SWEEP_RING = 8;
+template <int LOG2_NC, int WAVES, int SHIFT, int OUT, int RES, bool PKV = false, bool SWEEP = false>
 __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
@@ -647,8 +691,72 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // The wave's first chunk is known from its index alone: look it up and request its first frame before anything else,
     // so that the samples travel while the workgroup fills its LDS tables (a single-track launch is one or two frames per
     // wave: its run time is this start-up).
+    // sweep schedule: ticket counter + block ring, 2 * SWEEP_RING + 1 words behind the slabs (the launch adds 128 bytes)
+    // (ring slot = one 8-byte word {sequence tag, first chunk}: written and read with single 8-byte DS operations)
+    uint64_t *const sw_ring = reinterpret_cast<uint64_t *>(slabs + (size_t)WAVES * W::SLAB_LEN);
+    uint32_t &sw_ticket = *reinterpret_cast<uint32_t *>(sw_ring + SWEEP_RING);
+    if constexpr (SWEEP) {
+        static_assert(!SWEEP || OUT == 0, "sweep: dB rows (the mel table would sit where the scheduler's words are)");
+        if (tid == 0) {
+            sw_ticket = 0;
+            for (uint32_t i = 0; i < SWEEP_RING; i++) sw_ring[i] = 0xffffffffull;
+            sw_ring[0] = ((uint64_t)(blockIdx.x * SWEEP_BLK) << 32) | 0u;  // block sequence 0: the workgroup's own index
+            sw_ring[1] = ((uint64_t)((atomicAdd(queue_head, 1u) + gridDim.x) * SWEEP_BLK) << 32) | 1u;  // sequence 1
+        }
+        __syncthreads();
+    }
+    // next chunk index of this wave (wave-uniform; >= n_tiles: no more work).  All LDS accesses in the explicit address space:
+    // through a generic volatile pointer they would be FLAT operations, which count on vmcnt — every draw would wait for the
+    // wave's outstanding row stores.  LDS executes one wave's DS operations in order and is the only copy of these words, so
+    // program order is all the release / acquire there is (a workgroup-scope fence would drain vmcnt as well).
+    typedef volatile __attribute__((address_space(3))) uint64_t lds_u64;
+    // The draw in three steps, each issued a frame body ahead of the next so that no LDS / scalar-load latency is exposed:
+    //   ticket (LDS atomic, value still in flight)  ->  block slot (opener's duty + ring read)  ->  chunk index
+    auto sweep_ticket = [&]() -> uint32_t {  // per-lane value (lane 0 holds the ticket)
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)&sw_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return t;
+    };
+    auto sweep_slot = [&](uint32_t tk, uint32_t &q, uint32_t &idx) -> uint64_t {
+        const uint32_t t = __builtin_amdgcn_readfirstlane(tk);
+        q = t / SWEEP_BLK;
+        idx = t - q * SWEEP_BLK;
+        if (idx == 0 && q >= 1) {  // this wave opens block q: pull the block of sequence q + 1 (even when its own block is empty)
+            uint32_t nb = 0;
+            if (lane == 0) nb = atomicAdd(queue_head, 1u);
+            nb = (__builtin_amdgcn_readfirstlane(nb) + gridDim.x) * SWEEP_BLK;
+            if (lane == 0) *(lds_u64 *)&sw_ring[(q + 1) % SWEEP_RING] = ((uint64_t)nb << 32) | (q + 1);
+        }
+        return *(lds_u64 *)&sw_ring[q % SWEEP_RING];
+    };
+    auto sweep_chunk = [&](uint64_t slot, uint32_t q, uint32_t idx) -> uint32_t {  // wave-uniform chunk index (>= n_tiles: no more work)
+        // (the opener of block q - 1 filled this slot a block's worth of work ago; bounded anyway: a wave that gives up ends)
+        for (uint32_t spin = 0; (uint32_t)slot != q; spin++) {
+            if (spin > (1u << 24)) return n_tiles;
+            __builtin_amdgcn_s_sleep(2);
+            slot = *(lds_u64 *)&sw_ring[q % SWEEP_RING];
+        }
+        const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(slot >> 32));
+        const uint32_t c = base + idx;
+        return c < base ? n_tiles : c;  // (overflow guard)
+    };
+    auto sweep_draw = [&]() -> uint32_t {
+        uint32_t q, idx;
+        const uint64_t slot = sweep_slot(sweep_ticket(), q, idx);
+        return sweep_chunk(slot, q, idx);
+    };
     WaveSched sch;
-    TH_SCHED_INIT(sch, blockIdx.x * WAVES + wave, TH_PULL_AHEAD);
+    if constexpr (SWEEP) {
+        sch.ahead = 0;
+        sch.n_waves = gridDim.x * WAVES;
+        sch.use_queue = false;
+        sch.armed = false;
+        sch.pulled = 0;
+        sch.pull_f = 0;
+        sch.cur = cursor_at(g, jobs, chunk_tab, n_tiles, sweep_draw());
+    } else {
+        TH_SCHED_INIT(sch, blockIdx.x * WAVES + wave, TH_PULL_AHEAD);
+    }
     cf32 x[P];  // raw samples of the current frame; the frame body refills it for the next one
 #define TH_FETCH_FIRST()                                                                                                   \
     do {                                                                                                                   \
@@ -720,6 +828,70 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         rw_mid = tw[NC / 2];
     }
     if constexpr (PKP) rw_mid = tw[NC / 2];  // (the pair-ordered LDS table has no entry for the self-mirrored bin)
+    if constexpr (SWEEP) {
+        static_assert(!SWEEP || (SHIFT > 0 && P / SHIFT_NZ == 4 && P % SHIFT_NZ == 0), "sweep: rotation mode with four bodies");
+#define TH_FRAME_SW(ROT, FULL)                                                                                         \
+    wave_frame<LOG2_NC, SHIFT, OUT, true, (ROT) * SHIFT, RESK, -1, PKV, FULL>(                                          \
+        g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
+        lmax, meltab, mel_prf, wo, true, nwav, ne0)
+#define TH_SW_NEXT() (nxt = cursor_next(g, jobs, chunk_tab, n_tiles, sweep_draw(), cur))
+        while (sch.cur.valid) {
+            const FrameCursor cur = sch.cur;
+            lmin = __builtin_inff();
+            lmax = -__builtin_inff();
+            uint32_t f = cur.f;
+            const uint32_t n = cur.f1 - cur.f;  // 4 frames; fewer at the tail of a channel, 1 for a boundary frame
+            FrameCursor nxt{};
+            bool pre = false;  // the next chunk's first frame has been requested by this chunk's last frame
+            gptr<const float> nwav = cur.wav;
+            int64_t ne0 = 0;
+            if (n == 4) {
+                // the next chunk is drawn in steps between the frame bodies (ticket | block slot | chunk-table entry | cursor):
+                // every step's LDS / scalar-load latency hides behind a whole frame
+                const uint32_t tk = sweep_ticket();
+                TH_FRAME_SW(0, false);
+                ++f;
+                uint32_t sq, sidx;
+                const uint64_t slot = sweep_slot(tk, sq, sidx);
+                TH_FRAME_SW(1, false);
+                ++f;
+                nxt = cursor_next(g, jobs, chunk_tab, n_tiles, sweep_chunk(slot, sq, sidx), cur);
+                pre = nxt.valid && !nxt.edge;
+                if (pre) {
+                    nwav = nxt.wav;
+                    ne0 = frame_e0(nxt, g);
+                } else {  // nothing to prefetch: the last frame re-reads its own span (in bounds; the result is never used)
+                    ne0 = frame_e0(cur, g) + 3 * (int64_t)g.hop;
+                }
+                TH_FRAME_SW(2, false);
+                ++f;
+                TH_FRAME_SW(3, true);
+            } else {  // tail of a channel (1 .. 3 frames) or a boundary frame: no prefetch across the chunk end
+                TH_FRAME_SW(0, false);
+                if (n > 1) {
+                    ++f;
+                    TH_FRAME_SW(1, false);
+                    if (n > 2) {
+                        ++f;
+                        TH_FRAME_SW(2, false);
+                    }
+                }
+                TH_SW_NEXT();
+            }
+            if (minmax != nullptr) {
+                const float a = wave_min(lmin), b = wave_max(lmax);
+                if (lane == 0) {
+                    minmax[2 * (size_t)cur.t] = a;
+                    minmax[2 * (size_t)cur.t + 1] = b;
+                }
+            }
+            sch.cur = nxt;
+            if (!pre) TH_FETCH_FIRST();
+        }
+#undef TH_FRAME_SW
+#undef TH_SW_NEXT
+        return;
+    }
     // chunk loop: one queue pull and one full fetch per chunk of up to frames_per_tile consecutive frames
     while (sch.cur.valid) {
         const FrameCursor &cur = sch.cur;
@@ -1466,7 +1638,17 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
     auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES), (TH_USE_PK != 0)>;
     if constexpr (PK_SHAPE && TH_USE_PK == 0)
         if (pkv) kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES), true>;
-    const size_t lds = (pkv ? wave_lds_bytes<LOG2_NC, WAVES, true>() : wave_lds_bytes<LOG2_NC, WAVES, false>()) + (OUT == 2 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
+    // the sweep chunk schedule (large batches; the host then cut 4-frame chunks): the same shape, scalar pipeline
+    bool sweep = false;
+    if constexpr (PK_SHAPE) {
+        if (out.sweep != 0 && !pkv) {
+            if (g.frames_per_tile != 4) return hipErrorInvalidValue;
+            kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES), false, true>;
+            sweep = true;
+        }
+    }
+    if (out.sweep != 0 && !sweep) return hipErrorInvalidValue;  // (the host only asks for it where it exists)
+    const size_t lds = (pkv ? wave_lds_bytes<LOG2_NC, WAVES, true>() : wave_lds_bytes<LOG2_NC, WAVES, false>()) + (sweep ? 128 : 0) + (OUT == 2 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
                        (OUT == 2 && LOG2_NC == 9 && out.mel_slots != 0 ? (size_t)WAVES * MEL_PRF_1024 * sizeof(cf32) : 0) +  // (pieces / gather only)
                        (SHIFT == -1 ? 48 * sizeof(cf32) : 0) +  // phased: zero pairs in front of the window table
                        (SHIFT <= -16 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes
@@ -1646,6 +1828,11 @@ bool stft_wave_multi_mel_fits(const StftGeom &g, int waves, uint32_t words) {
     using W = WaveFftM<8>;
     const int wv = waves > 0 ? waves : stft_wave_default_waves(g);
     return sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)wv * W::SLAB_LEN) + (size_t)words * 4 <= 160 * 1024;
+}
+
+bool stft_wave_sweep_applies(const StftGeom &g, int waves, int out_mode) {
+    return g.log2_nc == 10 && g.phased == 0 && g.hop * 4 == g.n_fft && out_mode == 0 && (TH_USE_PK == 0) &&
+           (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES);
 }
 
 int stft_wave_default_waves(const StftGeom &g) {
