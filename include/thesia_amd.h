@@ -272,7 +272,8 @@ TH_API int th_spec_to_img_batch_dev_ranged(th_ctx *ctx, const th_img_desc *descs
 /* encode_spectrogram_tile — render_tiles.rs:281-352.  d_img: img_height x img_width u16 (DEVICE).
  * colormap: HOST RGBA8 bytes.  Writes the 40-byte LE header + RGBA (top row = highest frequency)
  * to the HOST buffer `out`.  Level (0,0) is an exact crop copy; level > 0 uses a separable
- * Lanczos3 resample (parity unpinned vs fast_image_resize). */
+ * Lanczos3 resample in the arithmetic of Pillow's ImagingResample: bit-identical to Pillow 12.2's 16-bit resize on the
+ * committed fixtures, formally unpinned vs fast_image_resize itself. */
 TH_API int th_encode_spectrogram_tile_dev(th_ctx *ctx, const uint16_t *d_img, size_t img_height, size_t img_width,
                                           size_t img_pitch /* u16 per row, 0 = dense */,
                                           const uint8_t *colormap_rgba, size_t colormap_bytes, uint64_t revision,

@@ -1372,8 +1372,9 @@ TH_API int th_encode_spectrogram_tile_dev(th_ctx *c, const uint16_t *d_img, size
         if (rc != TH_OK) return rc;
     } else {
         // LOD > 0: separable Lanczos3 of the crop box (render_tiles.rs:354-393), then the same raster.
-        // Tap tables are built here in f64 exactly as the CPU restatement does (PARITY UNPINNED against
-        // fast_image_resize).
+        // Tap tables are built here in f64 exactly as the CPU restatement does, in the arithmetic of Pillow's
+        // ImagingResample (bit-identical to Pillow on the committed fixtures; formally unpinned against
+        // fast_image_resize itself).
         const size_t dw = g.width, dh = g.height;
         const double W = (double)img_width, Hh = (double)img_height;
         const double left = (double)g.origin_x * W / (double)g.lod_w, top = (double)g.origin_y * Hh / (double)g.lod_h;
