@@ -2,16 +2,40 @@
 # Run on the GPU box (gpurun): collects every measurement that profiles/ and the docs quote into gpurun_out/final/.
 # (build the instrumented variant first if the phase profile is wanted: scripts/build_variant.sh prof -DTH_PHASE_PROF)
 # usage: scripts/collect_profiles.sh        then locally: python scripts/make_profiles.py gpurun_out/final r01
+# Since round 4 in parts (a gpurun call is at most 20 minutes): `collect_profiles.sh 1` = tests, bench lines, rocprofv3 trace, the
+# PMC passes of the headline kernel (default / packed-f32 / sweep variants) and of the image kernels, power; `2` = the PMC
+# passes of the other plans; `3` = the bench_stft / cfg tables and the micro-benchmarks.  No argument: everything.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/final
-rm -rf "$out"; mkdir -p "$out"
+part=${1:-all}
+want() { [ "$part" = all ] || [ "$part" = "$1" ]; }
+[ "$part" = all ] || [ "$part" = 1 ] && rm -rf "$out"
+mkdir -p "$out"
+if want 1; then
 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -4 > "$out/gputest.txt"
 echo "bench" >> "$out/progress.txt"; python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
+cp gpurun_out/bench_extras.json "$out/bench_extras.json" 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single-track --no-skeleton > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 find "$out/trace" -type f ! -name "*kernel_stats.csv" -delete
 scripts/pmc_stft.sh "$out/pmc_stft" > "$out/pmc_stft.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_stftpk" --kernel 9 > "$out/pmc_stftpk.log" 2>&1      # round 4: the packed-f32 pipeline
+scripts/pmc_stft.sh "$out/pmc_stftsweep" --kernel 11 > "$out/pmc_stftsweep.log" 2>&1  # round 4: the sweep chunk schedule
 TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pmc_img.log" 2>&1
+# the RCCL path on one GPU (world size 1): the line bench.py prints with the process group up
+TH_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-single-track --no-full-cfg5 > "$out/force_dist.out" 2> "$out/force_dist.err"; grep "^{" "$out/force_dist.out" | tail -1 > "$out/bench_line_force_dist.json"
+# package power / clocks next to the kernel loop and next to plain memory streams (scripts/power_probe.sh)
+{
+  for k in stft stftpk copy store; do
+    if [ $k = stft ]; then bash scripts/power_probe.sh "$out/pw_$k" python3 scripts/bench_stft.py --reps 20000
+    elif [ $k = stftpk ]; then bash scripts/power_probe.sh "$out/pw_$k" python3 scripts/bench_stft.py --reps 20000 --kernel 9
+    else bash scripts/power_probe.sh "$out/pw_$k" python3 scripts/power_loops.py $k 12; fi
+    echo "== $k loop: $(tail -1 $out/pw_$k.cmd)"; grep -E "Power|sclk" "$out/pw_$k" | tail -4
+  done
+  echo "== idle"; grep -E "Max Graphics|Package Power" "$out/pw_stft.idle"
+} > "$out/power.txt" 2>&1
+fi
+if want 2; then
 scripts/pmc_stft.sh "$out/pmc_stft1024" --nfft 1024 > "$out/pmc_stft1024.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stft512_multi" --nfft 512 > "$out/pmc_stft512_multi.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stft4096" --nfft 4096 --seconds 60 > "$out/pmc_stft4096.log" 2>&1
@@ -19,8 +43,11 @@ scripts/pmc_stft.sh "$out/pmc_stftmel" --sr 44100 --tracks 32 --seconds 60 --mel
 scripts/pmc_stft.sh "$out/pmc_stft4096dyn" --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 > "$out/pmc_stft4096dyn.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_melrows" --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 > "$out/pmc_melrows.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stftmel48" --sr 48000 --win 1920 --hop 480 --mel 0 > "$out/pmc_stftmel48.log" 2>&1
+fi
+if want 3; then
 {
   python3 scripts/bench_stft.py --reps 30 --kernel 0 1
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --kernel 0 9 11 0 9 11   # round 4: default | packed-f32 | sweep schedule
   python3 scripts/bench_stft.py --reps 30 --nfft 1024
   python3 scripts/bench_stft.py --reps 30 --nfft 4096
   python3 scripts/bench_stft.py --reps 30 --win 1920 --hop 480 --kernel 0 4   # phased mode vs plain wave kernel
@@ -63,25 +90,21 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 44100 --tracks 32 --seconds 60 --mel 128 --kernel 0 8
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 16000 --nfft 1024 --win 640 --hop 160 --mel 0 --seconds 90 --kernel 0 8
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 22050 --nfft 1024 --win 882 --hop 220 --mel 0 --seconds 60 --kernel 0 8
+  # round 4: the Mel default of long windows (more than 512 mels) on the two-kernel path against the generic kernel
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 4096 --mel 0 --kernel 0 1
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 8192 --mel 0 --kernel 0 1
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 16384 --mel 0 --kernel 0 1
+  python3 scripts/bench_stft.py --reps 10 --gap-ms 1 --sr 48000 --nfft 32768 --mel 0 --kernel 0 1
 } >> "$out/bench_stft.txt" 2>&1
-# the RCCL path on one GPU (world size 1): the line bench.py prints with the process group up
-TH_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-single-track --no-full-cfg5 > "$out/force_dist.out" 2> "$out/force_dist.err"; grep "^{" "$out/force_dist.out" | tail -1 > "$out/bench_line_force_dist.json"
-# package power / clocks next to the kernel loop and next to plain memory streams (scripts/power_probe.sh)
-{
-  for k in stft copy store; do
-    if [ $k = stft ]; then bash scripts/power_probe.sh "$out/pw_$k" python3 scripts/bench_stft.py --reps 20000
-    else bash scripts/power_probe.sh "$out/pw_$k" python3 scripts/power_loops.py $k 12; fi
-    echo "== $k loop: $(tail -1 $out/pw_$k.cmd)"; grep -E "Power|sclk" "$out/pw_$k" | tail -4
-  done
-  echo "== idle"; grep -E "Max Graphics|Package Power" "$out/pw_stft.idle"
-} > "$out/power.txt" 2>&1
 if [ -f scripts/variants/libthesia_amd_wt.so ]; then
   THESIA_AMD_LIB=scripts/variants/libthesia_amd_wt.so python3 scripts/wave_times.py > "$out/wave_times.txt" 2>&1
 fi
-for u in lds_rate valu_rate valu_bank copy_rate row_stores stream_shapes; do
+for u in lds_rate valu_rate valu_bank copy_rate row_stores stream_shapes fused_img_shapes; do
   [ -x scripts/ubench/$u ] && timeout 120 scripts/ubench/$u > "$out/ubench_$u.txt" 2>&1
 done
+[ -x scripts/ubench/stft_skeleton ] && timeout 120 scripts/ubench/stft_skeleton 1000 8 > "$out/ubench_stft_skeleton_sweep.txt" 2>&1
 if [ -f scripts/variants/libthesia_amd_prof.so ]; then
   THESIA_AMD_LIB=scripts/variants/libthesia_amd_prof.so python3 scripts/phase_prof.py > "$out/phase_prof.txt" 2>&1
+fi
 fi
 ls -la "$out"

@@ -28,6 +28,9 @@ def last_json_line(path):
 json.dump(last_json_line(f"{src}/bench.json"), open(f"{dst}/{tag}_bench_line.json", "w"), indent=1)
 json.dump(last_json_line(f"{src}/bench_under_rocprof.json"), open(f"{dst}/{tag}_bench_line_under_rocprof.json", "w"), indent=1)
 
+if os.path.exists(f"{src}/bench_extras.json"):
+    shutil.copy(f"{src}/bench_extras.json", f"{dst}/{tag}_bench_extras.json")
+
 # 2. kernel stats of the bench run (library kernels only)
 rows, seen = [], set()
 for f in sorted(glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime, reverse=True)[:1]:  # newest run only
@@ -50,7 +53,8 @@ hdr = ("# rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python3
        "# per-dispatch medians over the launches of each kernel; SQ_* in quad-cycles summed over waves, FETCH_SIZE/WRITE_SIZE in KB.\n"
        "# gfx950: FETCH_SIZE reports exactly 1/2 of streamed bytes for 4/8/16-byte-per-lane reads "
        "(profiles/r01_fetch_calibration.txt); WRITE_SIZE is exact.\n")
-for name, script in (("stft", "scripts/bench_stft.py"), ("img", "scripts/bench_img.py"),
+for name, script in (("stft", "scripts/bench_stft.py"), ("stftpk", "scripts/bench_stft.py --kernel 9"),
+                     ("stftsweep", "scripts/bench_stft.py --kernel 11"), ("img", "scripts/bench_img.py"),
                      ("stft1024", "scripts/bench_stft.py --nfft 1024"), ("stft512_multi", "scripts/bench_stft.py --nfft 512"),
                      ("stft4096", "scripts/bench_stft.py --nfft 4096 --seconds 60"),
                      ("stftmel", "scripts/bench_stft.py --sr 44100 --tracks 32 --seconds 60 --mel 128"),
@@ -90,7 +94,8 @@ if os.path.exists(p):
 
 # 5. plain-text measurement logs
 for f in ("bench_stft.txt", "bench_img.txt", "bench_cfg3.txt", "bench_cfg4.txt", "phase_prof.txt", "ubench_lds_rate.txt",
-          "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt", "ubench_stream_shapes.txt", "wave_times.txt", "power.txt",
+          "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt", "ubench_stream_shapes.txt", "ubench_fused_img_shapes.txt",
+          "ubench_stft_skeleton_sweep.txt", "wave_times.txt", "power.txt",
           "bench_line_force_dist.json", "gputest.txt"):
     if os.path.exists(f"{src}/{f}"):
         txt = "\n".join(l for l in open(f"{src}/{f}").read().splitlines() if "amdgpu.ids" not in l) + "\n"
