@@ -81,6 +81,7 @@ def parse_args():
     ap.add_argument("--no-single-track", action="store_true", help="skip the extras (single track, other framings, tile latency, ...)")
     ap.add_argument("--no-full-cfg5", action="store_true", help="skip the strong-scaling anchor (all 1024 tracks of config 5 on one GPU)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 wave")
+    ap.add_argument("--no-fused-image", action="store_true", help="quantise and raster as two kernels (A/B; the default fuses them)")
     return ap.parse_args()
 
 
@@ -158,6 +159,17 @@ class Workload:
                                                self.H, g.origin_x, g.origin_y, g.width, g.height, self.ip, 0))
                 off += -(-(g.width * g.height) // 64) * 64
         self.rast = (ta.RasterDesc * len(rast))(*rast)
+        # the same outputs through ONE pass over the spec (th_spec_to_img_raster_batch_dev, round 4): per image the level-0
+        # tile grid's device pointers, tile (tx, ty) at tx * n_ty + ty — the order `geoms` was built in
+        fused_items = []
+        for i in range(n_tracks):
+            ptrs, off = [], 0
+            for g in geoms:
+                ptrs.append(self.rgba[i].data_ptr() + off * 4)
+                off += -(-(g.width * g.height) // 64) * 64
+            fused_items.append((self.imgd[i], ptrs))
+        self.fused = ctx.make_img_tiles_descs(fused_items)
+        self.use_fused = True
         self.frames = n_tracks * self.T
         self.pixels = n_tracks * self.H * self.T
         self.range2 = torch.empty(2, dtype=torch.float32, device=dev)    # [min, -max]
@@ -185,10 +197,15 @@ class Workload:
 
         if record:
             ev[2].record()
-        self.ctx.spec_to_img_batch_ranged(self.imgd, self.range_db.data_ptr(), 258)
-        if record:
-            ev[3].record()
-        self.ctx.raster_tiles(self.rast, self.cmap.data_ptr(), self.n_colors)
+        if self.use_fused:  # quantise + level-0 raster of every tile in one kernel (10 B per pixel)
+            self.ctx.spec_to_img_raster_batch(self.fused, self.cmap.data_ptr(), self.n_colors, d_range=self.range_db.data_ptr())
+            if record:
+                ev[3].record()
+        else:               # the two kernels (6 + 6 B per pixel)
+            self.ctx.spec_to_img_batch_ranged(self.imgd, self.range_db.data_ptr(), 258)
+            if record:
+                ev[3].record()
+            self.ctx.raster_tiles(self.rast, self.cmap.data_ptr(), self.n_colors)
         if record:
             ev[4].record()
             self.ev.append(ev)
@@ -446,6 +463,7 @@ def main():
     owner = ta.shard_assign([ta.stft_n_frames(n, win, hop)] * total_tracks, world)
     mine = [i for i in range(total_tracks) if owner[i] == rank]
     wl = Workload(torch, ta, ctx, dev, mine, sr, n, win, hop, n_fft, args.kernel, cmap_bytes)
+    wl.use_fused = not args.no_fused_image
 
     def barrier():
         if dist is not None:
@@ -476,6 +494,8 @@ def main():
     stft_stage_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in wl.ev]))  # init + STFT kernel + boundary-frame kernel
     stft_series = [float(v) for v in wl.plan.kernel_ms_history()[-args.steps:]]
     stft_ms = float(np.mean(stft_series))                                        # the dominant kernel launch alone
+    # image stage inside the timed step: one fused kernel (default) or the two kernels
+    image_ms = float(np.mean([e[2].elapsed_time(e[4]) for e in wl.ev]))
     quant_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in wl.ev]))
     rast_ms = float(np.mean([e[3].elapsed_time(e[4]) for e in wl.ev]))
 
@@ -495,8 +515,14 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     wl.step(dist)
-    img_ms = time_stage(lambda: (ctx.spec_to_img_batch_ranged(wl.imgd, wl.range_db.data_ptr(), 258),
-                                 ctx.raster_tiles(wl.rast, wl.cmap.data_ptr(), wl.n_colors)))
+    if wl.use_fused:
+        img_ms = time_stage(lambda: ctx.spec_to_img_raster_batch(wl.fused, wl.cmap.data_ptr(), wl.n_colors, d_range=wl.range_db.data_ptr()))
+        # the two separate kernels on the same data, for the record (they are what a host that wants only SOME tiles runs)
+        quant_ms = time_stage(lambda: ctx.spec_to_img_batch_ranged(wl.imgd, wl.range_db.data_ptr(), 258))
+        rast_ms = time_stage(lambda: ctx.raster_tiles(wl.rast, wl.cmap.data_ptr(), wl.n_colors))
+    else:
+        img_ms = time_stage(lambda: (ctx.spec_to_img_batch_ranged(wl.imgd, wl.range_db.data_ptr(), 258),
+                                     ctx.raster_tiles(wl.rast, wl.cmap.data_ptr(), wl.n_colors)))
 
     # Cold launch: a desktop viewer's add_tracks is always the first launch after an idle gap.  The dominant kernel alone,
     # once after each of five 0.25 s idle gaps (the clocks have fallen back by then), HIP events on the launch stream.
@@ -868,7 +894,10 @@ def main():
             for k in ("kernel_over_skeleton", "kernel_median_over_skeleton", "frac_if_kernel_ran_at_skeleton"):
                 if k in skeleton:
                     rf[k] = skeleton[k]
-        rf.update({"quantise_ms": quant_ms, "quantise_frac": out["roofline_other"][0]["frac"],
+        rf.update({"image_stage_in_step_ms": image_ms, "image_stage_fused": bool(wl.use_fused),
+                   "image_stage_bytes_per_pixel": 10 if wl.use_fused else 12,
+                   "image_stage_frac": wl.pixels * (10 if wl.use_fused else 12) / (image_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "quantise_ms": quant_ms, "quantise_frac": out["roofline_other"][0]["frac"],
                    "raster_ms": rast_ms, "raster_frac": out["roofline_other"][1]["frac"],
                    "stft_frames_per_s": out["stft_frames_per_s"], "raster_mpixels_per_s": out["raster_mpixels_per_s"]})
         for e in roof_cfg + (other or []):

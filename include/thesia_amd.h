@@ -268,6 +268,22 @@ TH_API int th_spec_to_img_batch_dev(th_ctx *ctx, const th_img_desc *descs, size_
 TH_API int th_spec_to_img_batch_dev_ranged(th_ctx *ctx, const th_img_desc *descs, size_t n, const float *d_range,
                                            uint32_t colormap_len);
 
+/* Quantise + level-0 raster in one pass over the f32 spec (round 4): what th_spec_to_img_batch_dev[_ranged] followed by
+ * th_raster_tiles_dev over EVERY level-0 tile of every image produces — the same u16 images, the same RGBA tiles, bit for
+ * bit — moving 10 bytes per pixel instead of 6 + 6 (drawing.rs:4-33 + render_tiles.rs:290-351).
+ * tiles: HOST array of n_tiles_x * n_tiles_y DEVICE pointers, tile (tx, ty) of the level-0 grid of the (i_end - i_start) x
+ * n_frames image (th_spectrogram_tile_geometry with levels 0) at [tx * n_tiles_y + ty]: a dense width x height RGBA8 array,
+ * top row = highest frequency, 4-byte aligned (16-byte aligned bases are faster); NULL entries are skipped.
+ * d_range != NULL: [min_dB, max_dB] on the DEVICE (th_global_db_range_dev), else the host values.  d_colormap: DEVICE RGBA8
+ * LUT of n_colors entries (1 .. 65536); the quantiser's colormap_len is n_colors. */
+typedef struct {
+    th_img_desc img;
+    uint8_t *const *tiles; /* HOST array of DEVICE pointers */
+    uint32_t n_tiles_x, n_tiles_y; /* ceil(n_frames / 512), ceil((i_end - i_start) / 512) */
+} th_img_tiles_desc;
+TH_API int th_spec_to_img_raster_batch_dev(th_ctx *ctx, const th_img_tiles_desc *descs, size_t n, float min_dB, float max_dB,
+                                           const float *d_range, const uint8_t *d_colormap, uint32_t n_colors);
+
 /* ---------------------------------------------------------------- tiles */
 /* encode_spectrogram_tile — render_tiles.rs:281-352.  d_img: img_height x img_width u16 (DEVICE).
  * colormap: HOST RGBA8 bytes.  Writes the 40-byte LE header + RGBA (top row = highest frequency)

@@ -72,3 +72,18 @@ print(f"spec_to_img: {ms:.3f} ms  {px * 6 / ms / 1e6:.0f} GB/s ({px * 6 / ms / 1
 ms = timeit(lambda: ctx.raster_tiles(rast, d_cmap.data_ptr(), 258))
 rpx = n * tile_px
 print(f"raster_level0: {ms:.3f} ms  {rpx * 6 / ms / 1e6:.0f} GB/s ({rpx * 6 / ms / 1e6 / 80:.1f}% of 8 TB/s)  {rpx / ms / 1e3:.0f} Mpx/s")
+
+# round 4: the fused pass (th_spec_to_img_raster_batch_dev): same outputs, 10 B per pixel
+items = []
+for i in range(n):
+    ptrs, off = [], 0
+    for g in geoms:
+        ptrs.append(rgba[i].data_ptr() + off * 4)
+        off += -(-(g.width * g.height) // 64) * 64
+    items.append((imgd[i], ptrs))
+fused = ctx.make_img_tiles_descs(items)
+for _ in range(2):
+    ms = timeit(lambda: ctx.spec_to_img_raster_batch(fused, d_cmap.data_ptr(), 258, min_dB=-100.0, max_dB=0.0))
+    print(f"fused quantise + raster: {ms:.3f} ms  {px * 10 / ms / 1e6:.0f} GB/s ({px * 10 / ms / 1e6 / 80:.1f}% of 8 TB/s)  {px / ms / 1e3:.0f} Mpx/s")
+    ms2 = timeit(lambda: (ctx.spec_to_img_batch(imgd, -100.0, 0.0, 258), ctx.raster_tiles(rast, d_cmap.data_ptr(), 258)))
+    print(f"the two kernels: {ms2:.3f} ms")

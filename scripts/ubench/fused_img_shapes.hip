@@ -123,6 +123,81 @@ __global__ __launch_bounds__(1024) void fused_cols(const float *__restrict__ spe
     }
 }
 
+// ---- mode 3: as mode 2 with 128 freq rows, engineered for bytes in flight: every lane requests its whole share of the block's
+// 520 x 512 B of spec (16-byte loads: 32 lanes per row piece, 2 frames per wave-instruction, 17 requests per lane) before it
+// converts any of it; the u16 rows leave as one 1 KB row per wave-instruction (16 B per lane), the RGBA rows as 1 KB pieces
+// (16 B = 4 px per lane), both from 16- / 8-byte LDS reads.  One block per CU (133 KB of LDS), 1024 threads.
+template <int FB, int THREADS>
+__global__ __launch_bounds__(THREADS) void fused_cols_deep(const float *__restrict__ spec, uint16_t *__restrict__ img, uint8_t *__restrict__ rgba,
+                                                           const uint32_t *__restrict__ cmap) {
+    constexpr int PITCH = 536, WAVES = THREADS / 64;  // u16 per LDS row (1072 B: 16-byte aligned rows)
+    constexpr int LPR = FB / 4;                       // lanes per 16-byte-per-lane row piece
+    constexpr int FPI = 64 / LPR;                     // frames per wave-instruction
+    constexpr int NLD = (520 + FPI * WAVES - 1) / (FPI * WAVES);
+    extern __shared__ __attribute__((aligned(16))) uint16_t tile[];
+    __shared__ uint32_t lut[256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 256) lut[tid] = cmap[tid];
+    constexpr int BANDS = (H + FB - 1) / FB;
+    const int b = blockIdx.x, n = b / (BANDS * NTX), l = b % (BANDS * NTX);
+    const int band = l % BANDS, tx = l / BANDS;
+    const int f0 = band * FB, x0 = G.ox[tx], w = G.w[tx];
+    const float *sp = spec + (size_t)n * T * HP;
+    const int fl = 4 * (lane % LPR), fr = lane / LPR;
+    float4 v[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+        const int tt = FPI * (wv + WAVES * i) + fr;
+        const bool ok = tt < w && f0 + fl + 3 < HP;
+        v[i] = ok ? *reinterpret_cast<const float4 *>(sp + (size_t)(x0 + tt) * HP + f0 + fl) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+        const int tt = FPI * (wv + WAVES * i) + fr;
+        if (tt < w) {
+            tile[(fl + 0) * PITCH + tt] = (uint16_t)(int)v[i].x;
+            tile[(fl + 1) * PITCH + tt] = (uint16_t)(int)v[i].y;
+            tile[(fl + 2) * PITCH + tt] = (uint16_t)(int)v[i].z;
+            tile[(fl + 3) * PITCH + tt] = (uint16_t)(int)v[i].w;
+        }
+    }
+    __syncthreads();
+    uint16_t *im = img + (size_t)n * H * TP;
+    const int cs = tx * 512 - x0, core = (T - tx * 512 < 512 ? T - tx * 512 : 512);
+#pragma unroll
+    for (int i = 0; i < (FB + WAVES - 1) / WAVES; i++) {
+        const int r = wv + WAVES * i, c = 8 * lane;
+        if (r < FB && f0 + r < H && c < core) {
+            const uint2 a = *reinterpret_cast<const uint2 *>(&tile[r * PITCH + cs + c]);
+            const uint2 bq = *reinterpret_cast<const uint2 *>(&tile[r * PITCH + cs + c + 4]);
+            *reinterpret_cast<uint4 *>(im + (size_t)(f0 + r) * TP + tx * 512 + c) = make_uint4(a.x, a.y, bq.x, bq.y);
+        }
+    }
+    uint8_t *rg = rgba + (size_t)n * G.total;
+#pragma unroll 1
+    for (int i = 0; i < (FB + WAVES - 1) / WAVES; i++) {
+        const int r = wv + WAVES * i, f = f0 + r;
+        if (r >= FB || f >= H) continue;
+#pragma unroll
+        for (int ty = 0; ty < NTY; ty++) {
+            if (f < G.oy[ty] || f >= G.oy[ty] + G.h[ty]) continue;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(rg + G.base[tx][ty]) + (size_t)(G.oy[ty] + G.h[ty] - 1 - f) * w;
+            const int mis = (int)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int c = 4 * (lane + 64 * k) - mis;
+                if (c >= w) continue;
+                if (c >= 0 && c + 4 <= w) {
+                    const uint16_t *s4 = &tile[r * PITCH + c];
+                    *reinterpret_cast<uint4 *>(dst + c) = make_uint4(lutc(lut, s4[0]), lutc(lut, s4[1]), lutc(lut, s4[2]), lutc(lut, s4[3]));
+                } else {
+                    for (int q = (c < 0 ? 0 : c); q < c + 4 && q < w; q++) dst[q] = lutc(lut, tile[r * PITCH + q]);
+                }
+            }
+        }
+    }
+}
+
 // ---- mode 1: block = 128 freq x 64 frames, RGBA pieces straight from the block
 __global__ __launch_bounds__(256) void fused_small(const float *__restrict__ spec, uint16_t *__restrict__ img, uint8_t *__restrict__ rgba,
                                                    const uint32_t *__restrict__ cmap, int write_rgba) {
@@ -255,6 +330,20 @@ int main() {
         const float f = time_ms([&] { hipLaunchKernelGGL(fused_cols<FB>, dim3(blocks), dim3(1024), lds, 0, a, b, c, cm); });
         printf("mode 2  fused, %d freq x tile column in LDS (%.0f KB), whole rows: %.3f ms   (%.0f GB/s of 10 B/px)\n", FB, lds / 1024.0, f, px * 10 / f / 1e6);
     }
+#define RUN_DEEP(FB, TH)                                                                                                    \
+    {                                                                                                                        \
+        const size_t lds = (size_t)(FB) * 536 * 2;                                                                           \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fused_cols_deep<FB, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        const int blocks = ((H + (FB) - 1) / (FB)) * NTX * N;                                                                \
+        const float f = time_ms([&] { hipLaunchKernelGGL((fused_cols_deep<FB, TH>), dim3(blocks), dim3(TH), lds, 0, a, b, c, cm); }); \
+        printf("mode 3  fused, %3d freq x tile column in LDS (%.0f KB), %4d threads, all loads of a lane in flight, whole rows out: %.3f ms   (%.0f GB/s of 10 B/px)\n", \
+               FB, lds / 1024.0, TH, f, px * 10 / f / 1e6);                                                                   \
+    }
+    RUN_DEEP(128, 1024)
+    RUN_DEEP(64, 1024)
+    RUN_DEEP(64, 512)
+    RUN_DEEP(32, 512)
+    RUN_DEEP(32, 256)
     {
         const Geom ga = make_geom(true);
         hipMemcpyToSymbol(HIP_SYMBOL(G), &ga, sizeof ga);

@@ -1388,6 +1388,86 @@ def test_raster_tiles_batch_any_alignment(ctx, golden_dir, W, H):
     d_img.free(); d_cmap.free()
 
 
+@pytest.mark.parametrize("T,H,i0,i1,hh,cm,dense", [(2813, 1025, 0, 1025, 1025, 258, False), (700, 347, 0, 347, 347, 258, False),
+                                                  (1030, 600, 5, 521, 300, 2, False), (513, 70, 0, 70, 70, 1025, True),
+                                                  (37, 9, 0, 9, 9, 258, True), (516, 1029, 0, 1029, 1029, 17, False),
+                                                  (2049, 513, 3, 513, 513, 258, True), (1, 1, 0, 1, 1, 258, True)])
+def test_fused_quantise_and_raster_equals_the_two_kernels(ctx, golden_dir, T, H, i0, i1, hh, cm, dense):
+    """th_spec_to_img_raster_batch_dev (round 4: quantise + every level-0 tile in ONE pass over the f32 spec, 10 instead of
+    12 bytes per pixel): the u16 image equals convert_spectrogram_to_img (drawing.rs:4-33) and every tile equals the RGBA
+    payload of encode_spectrogram_tile (render_tiles.rs:281-352) bit for bit — NaN, +-inf, exact .5 values, rows >= H
+    (mixed sample rates: zero rows), row ranges, dense and padded pitches, widths with and without 16-byte aligned tile
+    rows, colour maps in LDS and (1025 entries) in global memory, device-resident and host range, a NULL tile, a two-image
+    batch — and equals what the two separate kernels write."""
+    from thesia_amd import _ffi
+    rng = np.random.default_rng(T * 7 + H)
+    spec = (rng.random((T, hh), dtype=np.float32) * 130.0 - 120.0).astype(np.float32)
+    spec.reshape(-1)[rng.integers(0, spec.size, max(1, spec.size // 50))] = np.float32("-inf")
+    spec.reshape(-1)[rng.integers(0, spec.size, max(1, spec.size // 200))] = np.float32("nan")
+    spec.reshape(-1)[rng.integers(0, spec.size, max(1, spec.size // 200))] = np.float32("inf")
+    lo, hi = -100.0, -3.5
+    cmap = bytes(rng.integers(0, 256, cm * 4, dtype=np.uint8))
+    want_img = orc.convert_spectrogram_to_img(spec, (i0, i1), (lo, hi), cm)
+    out_h = i1 - i0
+    sp = hh if dense else ta.pitch_f32(hh)
+    ip = T if dense else ta.pitch_u16(T)
+    host_spec = np.full((T, sp), 7.0, np.float32)
+    host_spec[:, :hh] = spec
+    d_spec, d_cmap = ctx.to_device(host_spec), ctx.to_device(np.frombuffer(cmap, np.uint8))
+    d_range = ctx.to_device(np.array([lo, hi], np.float32))
+    geoms = [(tx, ty, ta.spectrogram_tile_geometry(T, out_h, 0, 0, tx, ty)) for tx in range(-(-T // 512)) for ty in range(-(-out_h // 512))]
+    for variant in ("device range", "host range, packed tiles, one NULL"):
+        lead = 0 if variant == "device range" else 3
+        sizes = [g.width * g.height if lead else -(-(g.width * g.height) // 64) * 64 for _, _, g in geoms]
+        d_img = [ctx.alloc(out_h * ip * 2 + 64) for _ in range(2)]
+        d_out = [ctx.alloc((lead + sum(sizes)) * 4 + 64) for _ in range(2)]
+        for b_ in d_img + d_out:
+            b_.upload(np.full(b_.nbytes, 0xAB, np.uint8)) if hasattr(b_, "upload") else None
+        items = []
+        for k in range(2):
+            ptrs, off = [], lead
+            for j, sz in enumerate(sizes):
+                ptrs.append(0 if (lead and k == 1 and j == 0) else d_out[k].ptr + off * 4)
+                off += sz
+            items.append((_ffi.ImgDesc(d_spec.ptr, d_img[k].ptr, T, hh, i0, i1, sp, ip), ptrs))
+        descs = ctx.make_img_tiles_descs(items)
+        if lead:
+            ctx.spec_to_img_raster_batch(descs, d_cmap.ptr, cm, min_dB=lo, max_dB=hi)
+        else:
+            ctx.spec_to_img_raster_batch(descs, d_cmap.ptr, cm, d_range=d_range.ptr)
+        for k in range(2):
+            got_img = d_img[k].download((out_h, ip), np.uint16)
+            assert np.array_equal(got_img[:, :T], want_img), (variant, k)
+            flat = d_out[k].download(((lead + sum(sizes)) * 4,), np.uint8)
+            off = lead
+            for j, ((tx, ty, g), sz) in enumerate(zip(geoms, sizes)):
+                if not (lead and k == 1 and j == 0):
+                    want = orc.encode_spectrogram_tile(want_img, cmap, 1, 0, 0, tx, ty)[40:]
+                    assert flat[off * 4:(off + g.width * g.height) * 4].tobytes() == want, (variant, k, tx, ty)
+                off += sz
+        # the two separate kernels write the same image (incl. the zero-completed row padding at the library's pitch)
+        d_ref = ctx.alloc(out_h * ip * 2 + 64)
+        ctx.spec_to_img_batch([_ffi.ImgDesc(d_spec.ptr, d_ref.ptr, T, hh, i0, i1, sp, ip)], lo, hi, cm)
+        ref = d_ref.download((out_h, ip), np.uint16)
+        if not dense:
+            assert np.array_equal(d_img[0].download((out_h, ip), np.uint16), ref), variant
+        for b_ in d_img + d_out + [d_ref]:
+            b_.free()
+    # all -inf range: zero image, every tile the colour of index 0 (drawing.rs:16-18)
+    d_img0, d_out0 = ctx.alloc(out_h * ip * 2 + 64), ctx.alloc(sum(g.width * g.height for _, _, g in geoms) * 4 + 64)
+    ptrs, off = [], 0
+    for _, _, g in geoms:
+        ptrs.append(d_out0.ptr + off * 4)
+        off += g.width * g.height
+    descs = ctx.make_img_tiles_descs([(_ffi.ImgDesc(d_spec.ptr, d_img0.ptr, T, hh, i0, i1, sp, ip), ptrs)])
+    ctx.spec_to_img_raster_batch(descs, d_cmap.ptr, cm, min_dB=float("-inf"), max_dB=float("-inf"))
+    assert not d_img0.download((out_h, ip), np.uint16)[:, :T].any()
+    px = d_out0.download((off * 4,), np.uint8).reshape(-1, 4)
+    assert (px == np.frombuffer(cmap[:4], np.uint8)).all()
+    for b_ in (d_img0, d_out0, d_spec, d_cmap, d_range):
+        b_.free()
+
+
 # ---------------------------------------------------------------- BASELINE sizes, size-independent properties
 def _batch_on_gpu(ctx, plan, n_tr, n, seed):
     """n_tr synthetic tracks resident on the GPU -> (wav tensor, spec tensor incl. row padding, minmax tensor)"""
@@ -1516,6 +1596,23 @@ def test_baseline_size_image_stage(ctx, golden_dir):
             want = orc.encode_spectrogram_tile(want_img, cmap, 1, 0, 0, tx, ty)[40:]
             assert flat[off * 4:(off + g.width * g.height) * 4].tobytes() == want, (i, tx, ty)
             off += s
+    # round 4: the same stage in ONE pass over the spec (th_spec_to_img_raster_batch_dev): every image and every tile of all 128
+    # tracks identical to what the two kernels wrote (compared on the device)
+    img2, rgba2 = torch.full_like(img, 0x5A5A), torch.zeros_like(rgba)
+    items = []
+    for i in range(n_tr):
+        ptrs, off = [], 0
+        for s_ in slots:
+            ptrs.append(rgba2[i].data_ptr() + off * 4)
+            off += s_
+        items.append((_ffi.ImgDesc(spec[i].data_ptr(), img2[i].data_ptr(), T, H, 0, H, sp, ip), ptrs))
+    ctx.spec_to_img_raster_batch(ctx.make_img_tiles_descs(items), d_cmap.data_ptr(), len(cmap) // 4, d_range=rng_db.data_ptr())
+    ctx.synchronize()
+    assert torch.equal(img2, img)
+    off = 0
+    for (tx, ty, g), s_ in zip(geoms, slots):  # (the slots' padding behind a tile is nobody's: compare the tiles)
+        assert torch.equal(rgba2[:, off:off + g.width * g.height], rgba[:, off:off + g.width * g.height]), (tx, ty)
+        off += s_
     plan.close()
 
 

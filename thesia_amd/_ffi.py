@@ -102,6 +102,10 @@ class RasterDesc(C.Structure):
                 ("img_pitch", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class ImgTilesDesc(C.Structure):  # th_img_tiles_desc
+    _fields_ = [("img", ImgDesc), ("tiles", C.POINTER(vp)), ("n_tiles_x", C.c_uint32), ("n_tiles_y", C.c_uint32)]
+
+
 class WaveDesc(C.Structure):
     _fields_ = [("wav", vp), ("bins", vp), ("n_samples", C.c_uint64), ("start", C.c_uint64),
                 ("level", C.c_uint32), ("bin_count", C.c_uint32)]
@@ -154,6 +158,7 @@ _SIGS = {
     "th_encode_spectrogram_tile_dev": [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, c_u8p, C.c_size_t, C.c_uint64, C.c_uint32,
                                        C.c_uint32, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t, c_szp],
     "th_raster_tiles_dev": [vp, C.POINTER(RasterDesc), C.c_size_t, vp, C.c_uint32],
+    "th_spec_to_img_raster_batch_dev": [vp, C.POINTER(ImgTilesDesc), C.c_size_t, C.c_float, C.c_float, C.c_void_p, vp, C.c_uint32],
     "th_encode_waveform_tile_dev": [vp, vp, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, c_u8p, C.c_size_t,
                                     c_szp],
     "th_waveform_tiles_dev": [vp, C.POINTER(WaveDesc), C.c_size_t],

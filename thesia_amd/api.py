@@ -285,6 +285,29 @@ class Context:
         arr = descs if isinstance(descs, C.Array) else (RasterDesc * len(descs))(*descs)
         check(lib.th_raster_tiles_dev(self.handle, arr, len(arr), d_colormap, n_colors))
 
+    def make_img_tiles_descs(self, items):
+        """items: iterable of (ImgDesc, [device pointer of tile (tx, ty) at tx * n_ty + ty, 0 = skip]) -> ctypes array of
+        th_img_tiles_desc (keeps the pointer arrays alive)."""
+        items = list(items)
+        arr = (_ffi.ImgTilesDesc * len(items))()
+        keep = []
+        for i, (d, ptrs) in enumerate(items):
+            out_h, w = int(d.i_end - d.i_start), int(d.n_frames)
+            n_tx, n_ty = (-(-w // 512), -(-out_h // 512)) if out_h and w else (0, 0)
+            assert len(ptrs) == n_tx * n_ty, (len(ptrs), n_tx, n_ty)
+            pa = (C.c_void_p * max(len(ptrs), 1))(*[C.c_void_p(p or None) for p in ptrs])
+            keep.append(pa)
+            arr[i].img = d
+            arr[i].tiles = C.cast(pa, C.POINTER(C.c_void_p))
+            arr[i].n_tiles_x, arr[i].n_tiles_y = n_tx, n_ty
+        arr._keep = keep
+        return arr
+
+    def spec_to_img_raster_batch(self, descs, d_colormap: int, n_colors: int, min_dB: float = 0.0, max_dB: float = 0.0,
+                                 d_range: int = 0):
+        """th_spec_to_img_raster_batch_dev: quantise + every level-0 tile in one pass.  descs: make_img_tiles_descs(...)."""
+        check(lib.th_spec_to_img_raster_batch_dev(self.handle, descs, len(descs), min_dB, max_dB, d_range or None, d_colormap, n_colors))
+
     # ---- encode_waveform_tile (render_tiles.rs:232-279)
     def encode_waveform_tile(self, wav: np.ndarray, revision: int, level: int, tile_index: int) -> bytes:
         wav = _f32(wav)

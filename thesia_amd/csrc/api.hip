@@ -1257,6 +1257,77 @@ TH_API int th_spec_to_img_batch_dev_ranged(th_ctx *c, const th_img_desc *descs, 
     return spec_to_img_impl(c, descs, n, 0.0f, 0.0f, d_range, colormap_len);
 }
 
+// Quantise + level-0 raster of every tile in one pass (kernels_image.hip: spec_to_img_raster_kernel)
+TH_API int th_spec_to_img_raster_batch_dev(th_ctx *c, const th_img_tiles_desc *descs, size_t n, float min_dB, float max_dB,
+                                           const float *d_range, const uint8_t *d_colormap, uint32_t n_colors) {
+    TH_TRY
+    TH_REQUIRE(c, "ctx is NULL");
+    if (n == 0) return TH_OK;
+    TH_REQUIRE(descs && d_colormap && n_colors >= 1, "NULL descs / colormap or empty colormap");
+    TH_REQUIRE(n_colors <= 65536, "colormaps of more than 65536 entries are not supported");
+    const bool all_neg_inf = !d_range && (min_dB == max_dB) && std::isinf(max_dB) && max_dB < 0;  // drawing.rs:16-18
+    if (!all_neg_inf && !d_range) TH_REQUIRE(std::isfinite(min_dB), "min_dB must be finite (drawing.rs:19)");
+    // key of the batch: the descriptors and every tile pointer (identical batch -> the device tables are reused as they are)
+    std::vector<unsigned char> key;
+    size_t n_ptrs = 0;
+    for (size_t i = 0; i < n; i++) n_ptrs += (size_t)descs[i].n_tiles_x * descs[i].n_tiles_y;
+    key.reserve(n * sizeof(th_img_tiles_desc) + n_ptrs * sizeof(void *));
+    for (size_t i = 0; i < n; i++) {
+        const th_img_tiles_desc &d = descs[i];
+        TH_REQUIRE(d.tiles || (size_t)d.n_tiles_x * d.n_tiles_y == 0, "desc %zu: tiles is NULL", i);
+        const unsigned char *p = reinterpret_cast<const unsigned char *>(&d);
+        key.insert(key.end(), p, p + sizeof(th_img_tiles_desc));
+        const unsigned char *q = reinterpret_cast<const unsigned char *>(d.tiles);
+        key.insert(key.end(), q, q + (size_t)d.n_tiles_x * d.n_tiles_y * sizeof(void *));
+    }
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    TH_HIP(hipSetDevice(c->device));
+    if (!(c->fused_key == key && c->fused_jobs.dptr && c->fused_start.dptr && c->fused_ptrs.dptr)) {
+        std::vector<FusedJob> jobs(n);
+        std::vector<uint32_t> start;
+        std::vector<uint8_t *> ptrs;
+        ptrs.reserve(n_ptrs);
+        uint64_t blocks = 0;
+        for (size_t i = 0; i < n; i++) {
+            const th_img_desc &d = descs[i].img;
+            TH_REQUIRE(d.i_end >= d.i_start, "desc %zu: i_end < i_start", i);
+            const uint64_t out_h = d.i_end - d.i_start;
+            TH_REQUIRE(d.n_frames < (1ull << 31) && d.height < (1ull << 31) && d.i_end < (1ull << 31), "desc %zu: too large", i);
+            TH_REQUIRE((d.spec && d.img && d.height >= 1) || out_h * d.n_frames == 0, "desc %zu: NULL device pointer or empty spec", i);
+            TH_REQUIRE(d.spec_pitch == 0 || (d.spec_pitch >= d.height && d.spec_pitch < (1ull << 31)), "desc %zu: bad spec_pitch", i);
+            TH_REQUIRE(d.img_pitch == 0 || (d.img_pitch >= d.n_frames && d.img_pitch < (1ull << 31)), "desc %zu: bad img_pitch", i);
+            const uint64_t n_tx = out_h && d.n_frames ? (d.n_frames + 511) / 512 : 0, n_ty = out_h && d.n_frames ? (out_h + 511) / 512 : 0;
+            TH_REQUIRE(descs[i].n_tiles_x == n_tx && descs[i].n_tiles_y == n_ty, "desc %zu: the image has %llu x %llu level-0 tiles, not %u x %u",
+                       i, (unsigned long long)n_tx, (unsigned long long)n_ty, descs[i].n_tiles_x, descs[i].n_tiles_y);
+            const uint64_t n_bands = (out_h + FUSED_FB - 1) / FUSED_FB, nb = n_tx * n_bands;
+            TH_REQUIRE(blocks + nb < (1ull << 27) && ptrs.size() + n_tx * n_ty < (1ull << 31), "batch too large for one launch");
+            for (uint64_t t = 0; t < n_tx * n_ty; t++) {
+                uint8_t *tp = descs[i].tiles[t];
+                TH_REQUIRE((reinterpret_cast<uintptr_t>(tp) & 3u) == 0, "desc %zu: tile %llu must be 4-byte aligned", i, (unsigned long long)t);
+                ptrs.push_back(tp);
+            }
+            jobs[i] = FusedJob{d.spec, d.img, (uint32_t)d.n_frames, (uint32_t)d.height, (uint32_t)d.i_start, (uint32_t)d.i_end,
+                               (uint32_t)(d.spec_pitch ? d.spec_pitch : d.height), (uint32_t)(d.img_pitch ? d.img_pitch : d.n_frames),
+                               (uint32_t)blocks, (uint32_t)std::max<uint64_t>(n_bands, 1), (uint32_t)n_tx, (uint32_t)n_ty,
+                               (uint32_t)(ptrs.size() - n_tx * n_ty), 0u};
+            blocks += nb;
+            start.insert(start.end(), (size_t)nb, (uint32_t)i);
+        }
+        if (ptrs.empty()) ptrs.push_back(nullptr);
+        int rc = c->fused_jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(FusedJob));
+        if (rc == TH_OK && !start.empty()) rc = c->fused_start.upload(c->stream, start.data(), start.size() * sizeof(uint32_t));
+        if (rc == TH_OK) rc = c->fused_ptrs.upload(c->stream, ptrs.data(), ptrs.size() * sizeof(uint8_t *));
+        if (rc != TH_OK) return rc;
+        c->fused_key.swap(key);
+        c->fused_blocks_key = (uint32_t)blocks;
+    }
+    TH_HIP(launch_spec_to_img_raster((const FusedJob *)c->fused_jobs.dptr, (const uint32_t *)c->fused_start.dptr, c->fused_blocks_key,
+                                     (uint8_t *const *)c->fused_ptrs.dptr, min_dB, max_dB, d_range, all_neg_inf ? 1 : 0, d_colormap,
+                                     n_colors, c->stream));
+    return TH_OK;
+    TH_CATCH
+}
+
 TH_API int th_global_db_range_dev(th_ctx *c, const float *d_min_negmax, float dB_range, float *d_range) {
     TH_TRY
     TH_REQUIRE(c && d_min_negmax && d_range, "NULL argument");

@@ -34,13 +34,17 @@ struct th_ctx {
     // (tile encoders → batched launchers) can hold it across the whole request.
     std::recursive_mutex mu;
     th::DeviceTable img_jobs, img_start, raster_jobs, raster_start, wave_jobs, wave_start, colormap, tile_out, lod_tabs, lod_tmp,
-        pyr_jobs, pyr_sums;
+        pyr_jobs, pyr_sums, fused_jobs, fused_start, fused_ptrs;
     // the descriptor batches the img / raster tables were built from (identical batch -> tables reused as they are)
-    std::vector<unsigned char> img_descs_key, raster_descs_key;
-    uint32_t img_tiles_key = 0, raster_blocks_key = 0;
+    std::vector<unsigned char> img_descs_key, raster_descs_key, fused_key;
+    uint32_t img_tiles_key = 0, raster_blocks_key = 0, fused_blocks_key = 0;
     void release_scratch() {
         img_descs_key.clear();
         raster_descs_key.clear();
+        fused_key.clear();
+        fused_jobs.release();
+        fused_start.release();
+        fused_ptrs.release();
         img_jobs.release();
         img_start.release();
         raster_jobs.release();

@@ -115,6 +115,30 @@ hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_job, 
                               hipStream_t s);
 hipError_t launch_db_range(const float *d_in, float dB_range, float *d_out, hipStream_t s);
 
+// Quantise + level-0 raster in one pass (round 4): one job per image; block b of a job = (tile column tx = local / n_bands,
+// band of FUSED_FB image rows = local % n_bands); tiles[tile0 + tx * n_ty + ty] = RGBA array of level-0 tile (tx, ty) or NULL
+struct FusedJob {
+    const float *spec;
+    uint16_t *img;
+    uint32_t n_frames, height, i_start, i_end;
+    uint32_t spec_pitch, img_pitch;
+    uint32_t first_block, n_bands;
+    uint32_t n_tx, n_ty;
+    uint32_t tile0, reserved;
+};
+static_assert(sizeof(FusedJob) == 64, "FusedJob must have no implicit padding");
+#if !defined(TH_FUSED_FB)
+#define TH_FUSED_FB 32
+#endif
+#if !defined(TH_FUSED_THREADS)
+#define TH_FUSED_THREADS 256
+#endif
+constexpr uint32_t FUSED_FB = TH_FUSED_FB;        // image rows (frequency bins) per block
+constexpr uint32_t FUSED_THREADS = TH_FUSED_THREADS;
+hipError_t launch_spec_to_img_raster(const FusedJob *d_jobs, const uint32_t *d_block_job, uint32_t n_blocks, uint8_t *const *d_tiles,
+                                     float min_dB, float max_dB, const float *d_range, int all_zero, const uint8_t *d_colormap,
+                                     uint32_t n_colors, hipStream_t s);
+
 struct RasterJob {  // device-visible copy of th_raster_desc (+ derived fields)
     const uint16_t *img;
     uint8_t *rgba;

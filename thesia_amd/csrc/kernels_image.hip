@@ -398,6 +398,201 @@ hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block
 }
 
 // ------------------------------------------------------------------------------------------
+// Quantise + level-0 raster in ONE pass over the f32 spec (round 4; drawing.rs:4-33 + render_tiles.rs:290-351): 10 bytes per
+// pixel (4 read, 2 + 4 written) where spec_to_img_kernel + raster_level0_kernel move 6 + 6.
+// Round 3's fused attempt (128 freq x 64 frames per block, 256-byte pieces of 128 RGBA rows) ran at 2.7 TB/s: tile rows are
+// width * 4 = 2064 / 2080 / 1028 bytes, so no piece starts on a 128-byte line, and the pieces of one row come from blocks far
+// apart in time.  Shape by measurement (scripts/ubench/fused_img_shapes.hip: 0.696 ms for the bench's 369 M pixels = 5.3 TB/s,
+// against 0.78-0.82 ms for the two kernels; 128 rows per block — one block per CU — 1.0 ms; pieces of 64 frames 1.1-1.2 ms):
+//   block = (image, level-0 tile column tx, band of FUSED_FB = 32 image rows): the <= 520 frames of the tile column INCLUDING
+//   its 4-frame gutters x 32 bins are staged as u16 in LDS (34 KB: four blocks of 256 threads per CU overlap each other's
+//   phases; the real kernel, quantiser included: 32 rows x 256 threads 0.72-0.74 ms, 32 x 512 0.73-0.74, 64 x 1024 0.77-0.79,
+//   64 x 512 0.80-0.81, 128 x 1024 0.96-0.97 against 0.81 for the two kernels, same box: profiles/r04_ab_fused_image.txt);
+//   read   16-byte loads, 8 lanes per 128-byte row piece, 8 frames per wave-instruction, ALL of a lane's 17 requests in flight
+//          before the first is consumed (a block's read phase is one HBM latency, not seventeen);
+//   write  the u16 image rows of the column's core frames whole (16 B per lane: 512 frames = one wave-instruction) and every
+//          RGBA tile row the band touches — its own tile and, within 4 rows of a tile boundary, the neighbour's gutter — whole,
+//          on the destination's 16-byte grid.
+// The quantiser and the colour index are the very functions the two kernels use: the results are bit-identical to theirs.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t FUSED_PITCH = 536;  // u16 per LDS row: 520 frames + the row padding the last column completes; 1072 B = 8-byte aligned rows
+template <bool LUT_IN_LDS>
+__global__ __launch_bounds__(FUSED_THREADS) void spec_to_img_raster_kernel(
+    const FusedJob *__restrict__ jobs, const uint32_t *__restrict__ block_job, uint8_t *const *__restrict__ tiles, float min_dB,
+    float span, float u16_span, float min_value, const float *__restrict__ d_range, int all_zero_in,
+    const uint32_t *__restrict__ colormap, uint32_t n_colors) {
+    constexpr uint32_t FB = FUSED_FB, WAVES = FUSED_THREADS / 64, LPR = FB / 4, FPI = 64 / LPR;
+    constexpr uint32_t NLD = (FUSED_PITCH + FPI * WAVES - 1) / (FPI * WAVES);
+    extern __shared__ __attribute__((aligned(16))) uint16_t ftile[];  // [FB][FUSED_PITCH]
+    __shared__ uint32_t lut[LUT_IN_LDS ? 1024 : 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (LUT_IN_LDS)
+        for (uint32_t i = tid; i < n_colors; i += FUSED_THREADS) lut[i] = colormap[i];
+    bool all_zero = all_zero_in != 0;
+    float rinv = quantise_rinv(span);
+    if (d_range != nullptr) {
+        const float lo = d_range[0], hi = d_range[1];
+        min_dB = lo;
+        span = hi - lo;
+        rinv = quantise_rinv(span);
+        all_zero = lo == hi && __builtin_isinf(hi) && hi < 0.0f;  // every value -inf: zero image (drawing.rs:16-18)
+    }
+    const FusedJob job = jobs[block_job[blockIdx.x]];
+    const gptr<const float> spec = as_global(job.spec);
+    const uint32_t out_h = job.i_end - job.i_start, W = job.n_frames;
+    const uint32_t local = blockIdx.x - job.first_block;
+    const uint32_t band = local % job.n_bands, tx = local / job.n_bands;  // bands of one column are neighbours in the launch
+    const uint32_t r0 = band * FB;                                       // first image row of the band (relative to i_start)
+    // level-0 tile column tx (render_tiles.rs:290-313): core 512 frames + 4-frame gutters, clipped at the image
+    const uint32_t sx = tx * 512u, core = min(W - sx, 512u), ox = sx > 4u ? sx - 4u : 0u, wt = min(W, sx + core + 4u) - ox;
+    // ---- read + quantise: lane -> bins fl .. fl + 3 of frame ox + FPI (wv + WAVES i) + fr
+    const uint32_t fl = 4u * (lane % LPR), fr = lane / LPR;
+    const uint32_t bin0 = job.i_start + r0 + fl;
+    bool okb[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) okb[k] = bin0 + k < job.height && r0 + fl + k < out_h;
+    // 16-byte loads: aligned base / pitch / first bin (block-uniform).  A lane whose four bins lie past the row's allocation
+    // reads the row's last quad instead — with these alignments its bins are all >= spec_pitch >= height, so they are discarded
+    // anyway — which keeps the loads free of per-lane branches (a branch around a load makes the compiler wait for the previous one)
+    const bool al16 = (reinterpret_cast<uintptr_t>(job.spec) & 15u) == 0 && job.spec_pitch % 4u == 0 && (job.i_start + r0) % 4u == 0 &&
+                      job.spec_pitch >= 4u;
+    const uint32_t b16 = min(bin0, job.spec_pitch - 4u);
+    float v[NLD][4];
+    const float qnan = __builtin_nanf("");
+#pragma unroll
+    for (uint32_t i = 0; i < NLD; i++) {
+        const uint32_t tt = FPI * (wv + WAVES * i) + fr;
+        const gptr<const float> rowp = spec + (size_t)min(ox + tt, W - 1u) * job.spec_pitch;
+        if (al16) {
+            const float4 x = *reinterpret_cast<gptr<const float4>>(rowp + b16);
+            v[i][0] = x.x;
+            v[i][1] = x.y;
+            v[i][2] = x.z;
+            v[i][3] = x.w;
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) v[i][k] = rowp[min(bin0 + k, max(job.height, 1u) - 1u)];
+        }
+    }
+    // the three cases are launch-uniform: one specialised loop each instead of a branch per element (as spec_to_img_kernel)
+    // (NaN -> 0: rows >= H and columns past the image are zero; columns >= wt are the row padding the last tile column writes)
+#define TH_FUSED_QUANT(EXPR)                                                                             \
+    _Pragma("unroll") for (uint32_t i = 0; i < NLD; i++) {                                               \
+        const uint32_t tt = FPI * (wv + WAVES * i) + fr;                                                 \
+        if (tt < FUSED_PITCH) {                                                                          \
+            const bool okt = tt < wt;                                                                    \
+            _Pragma("unroll") for (uint32_t k = 0; k < 4; k++) {                                         \
+                const float x = (okt && okb[k]) ? v[i][k] : qnan;                                        \
+                (void)x;                                                                                 \
+                ftile[(fl + k) * FUSED_PITCH + tt] = (uint16_t)(EXPR);                                   \
+            }                                                                                            \
+        }                                                                                                \
+    }
+    if (all_zero) {
+        TH_FUSED_QUANT(0u)
+    } else if (rinv != 0.0f) {
+        TH_FUSED_QUANT(quantise<true>(x, min_dB, span, rinv, u16_span, min_value))
+    } else {
+        TH_FUSED_QUANT(quantise<false>(x, min_dB, span, rinv, u16_span, min_value))
+    }
+#undef TH_FUSED_QUANT
+    __syncthreads();
+    // ---- u16 image rows: the column's core frames [sx, sx + core) (+ the row padding in the last column), 8 px per lane
+    const gptr<uint16_t> img = as_global(job.img);
+    const uint32_t cs = sx - ox;  // 0 or 4
+    // rows at the library's padded pitch own their padding (see spec_to_img_kernel): complete the last 128-byte line
+    const uint32_t t_lim = (job.img_pitch % IMG_TILE_T == 0 && job.img_pitch - W < IMG_TILE_T) ? job.img_pitch : W;
+    const uint32_t c_lim = min(t_lim - sx, 512u);  // columns of this tile column to write (the last column: up to the pitch)
+    const bool img_al = (reinterpret_cast<uintptr_t>(job.img) & 15u) == 0 && job.img_pitch % 8u == 0;
+#pragma unroll
+    for (uint32_t i = 0; i < (FB + WAVES - 1) / WAVES; i++) {
+        const uint32_t r = wv + WAVES * i, c = 8u * lane;
+        if (r < FB && r0 + r < out_h && c < c_lim) {
+            const uint16_t *src = &ftile[r * FUSED_PITCH + cs + c];
+            const gptr<uint16_t> dst = img + (size_t)(r0 + r) * job.img_pitch + sx + c;
+            if (img_al && c + 8u <= c_lim) {
+                const uint2 a = *reinterpret_cast<const uint2 *>(src), b = *reinterpret_cast<const uint2 *>(src + 4);
+                *reinterpret_cast<gptr<uint4>>(dst) = make_uint4(a.x, a.y, b.x, b.y);
+            } else {
+                for (uint32_t k = 0; k < 8u && c + k < c_lim; k++) dst[k] = src[k];
+            }
+        }
+    }
+    // ---- RGBA rows: image row r_img -> row (oy + h - 1 - r_img) of every tile (tx, ty) that holds it
+    auto look = [&](uint32_t val) -> uint32_t {
+        const uint32_t ci = colour_index(val, n_colors);
+        if constexpr (LUT_IN_LDS) return lut[ci];
+        else return as_global(colormap)[ci];
+    };
+#pragma unroll 1
+    for (uint32_t i = 0; i < (FB + WAVES - 1) / WAVES; i++) {
+        const uint32_t r = wv + WAVES * i, r_img = r0 + r;
+        if (r >= FB || r_img >= out_h) continue;  // wave-uniform
+        const uint32_t ty0 = r_img / 512u;
+#pragma unroll
+        for (int dty = -1; dty <= 1; dty++) {
+            const int tyi = (int)ty0 + dty;
+            if (tyi < 0 || (uint32_t)tyi >= job.n_ty) continue;
+            const uint32_t ty = (uint32_t)tyi, sy = ty * 512u, coreh = min(out_h - sy, 512u);
+            const uint32_t oy = sy > 4u ? sy - 4u : 0u, ht = min(out_h, sy + coreh + 4u) - oy;
+            if (r_img < oy || r_img >= oy + ht) continue;
+            uint8_t *const tbase = tiles[job.tile0 + tx * job.n_ty + ty];  // scalar load
+            if (tbase == nullptr) continue;
+            const gptr<uint32_t> dst = as_global(reinterpret_cast<uint32_t *>(tbase)) + (size_t)(oy + ht - 1u - r_img) * wt;
+            const uint16_t *const srow = &ftile[r * FUSED_PITCH];
+            // 16-byte stores on the destination's 16-byte grid (rows of odd widths start 4 / 8 / 12 bytes off it)
+            const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(tbase) / 4u + (size_t)(oy + ht - 1u - r_img) * wt) & 3u;
+#pragma unroll
+            for (uint32_t k = 0; k < 3; k++) {  // wt <= 520: at most 131 quads (+ 1 for a shifted grid)
+                const int32_t c = (int32_t)(4u * (lane + 64u * k)) - (int32_t)mis;
+                if (c >= (int32_t)wt) continue;
+                if (c >= 0 && (uint32_t)c + 4u <= wt) {
+                    uint32_t p0, p1, p2, p3;
+                    if (mis == 0u) {  // (wave-uniform) the source quad is 8-byte aligned: one LDS read
+                        const uint2 q = *reinterpret_cast<const uint2 *>(srow + c);
+                        p0 = q.x & 0xffffu;
+                        p1 = q.x >> 16;
+                        p2 = q.y & 0xffffu;
+                        p3 = q.y >> 16;
+                    } else {
+                        p0 = srow[c];
+                        p1 = srow[c + 1];
+                        p2 = srow[c + 2];
+                        p3 = srow[c + 3];
+                    }
+                    *reinterpret_cast<gptr<uint4>>(dst + c) = make_uint4(look(p0), look(p1), look(p2), look(p3));
+                } else {
+                    for (int32_t q = c < 0 ? 0 : c; q < c + 4 && q < (int32_t)wt; q++) dst[q] = look(srow[q]);
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_spec_to_img_raster(const FusedJob *d_jobs, const uint32_t *d_block_job, uint32_t n_blocks, uint8_t *const *d_tiles,
+                                     float min_dB, float max_dB, const float *d_range, int all_zero, const uint8_t *d_colormap,
+                                     uint32_t n_colors, hipStream_t s) {
+    if (!n_blocks) return hipSuccess;
+    uint32_t min_value = 1;  // drawing.rs:20-22, as launch_spec_to_img
+    if (n_colors) {
+        const double r = __builtin_round(65535.0 / (double)n_colors);
+        const uint32_t v = r >= 65535.0 ? 65535u : (uint32_t)r;
+        min_value = v > 1 ? v : 1;
+    }
+    const float span = max_dB - min_dB;
+    const size_t lds = (size_t)FUSED_FB * FUSED_PITCH * sizeof(uint16_t);
+    const bool lut_lds = n_colors <= 1024;
+    auto kern = lut_lds ? spec_to_img_raster_kernel<true> : spec_to_img_raster_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(FUSED_THREADS), lds, s, d_jobs, d_block_job, d_tiles, min_dB, span,
+                       (float)(65535u - min_value), (float)min_value, d_range, all_zero,
+                       reinterpret_cast<const uint32_t *>(d_colormap), n_colors);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // LOD > 0 tiles: separable Lanczos3 in f64 with host-tabulated taps (see LodAxis).  The reference
 // delegates this to fast_image_resize 6.0.0, whose source is not vendored: parity is pinned only at
 // level (0,0) (exact copy) and by three coarse tests; this is the textbook filter, bit-identical to
