@@ -16,6 +16,9 @@
 #define TH_MEL_BAND_TAPS_2048 64u  // (measured thresholds: th_plan_create)
 #define TH_MEL_BAND_TAPS_1024 80u
 #endif
+#if !defined(TH_MEL_BAND_SPREAD)
+#define TH_MEL_BAND_SPREAD 1  // the banded tables' first bins on distinct LDS banks (mel_fuse.h; 0: as the filters start, for A/B runs)
+#endif
 
 // ------------------------------------------------------------------------------------------ errors
 namespace th {
@@ -611,7 +614,9 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
             const th::MelFuseHost mf = th::build_mel_fuse(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, th::stft_wave_mel_max_pieces(g));
             if (rc == TH_OK && g.log2_nc == 11) {
                 // n_fft 4096 (two kernels): the same banded table for mel_band_rows_kernel, where it fits LDS beside four rows
-                const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16);
+                // (first bins as the filters start: mel_band_rows_kernel measured 3 % slower on the bank-spread table, 2.08 -> 2.15 ms
+                // at the 96 kHz default, profiles/r04_ab_mel_bank_spread.txt)
+                const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16, false);
                 if (mb.ok && th::mel_band_rows_fits(g.n_freq, (uint32_t)mb.words.size())) {
                     p->mel_bsum_words = (uint32_t)mb.words.size();
                     std::copy(mb.words.begin(), mb.words.begin() + 16, p->mel_bsum_hdr);
@@ -620,14 +625,15 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
                 }
             }
             if (rc == TH_OK && (g.log2_nc == 9 || g.log2_nc == 10)) {
-                const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16);
+                const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16, TH_MEL_BAND_SPREAD != 0);
                 // Measured against the pieces / gather form (same box, alternating; taps = the sum over the groups of their
                 // widest filter): n_fft 2048 — 56 / 60 / 64 taps (256 mels, the 44.1 / 48 kHz defaults) 6 / 8 / 10 % faster; 72 taps
                 // (128 mels) 4 % faster in the register-reuse kernel (hop a multiple of 128: config 4), 6 % slower in the full-reload
                 // one (hop 480); 96 (200 mels) 5 % slower, 124 (64 mels) 40 % slower; n_fft 1024 — 32 / 36 / 44 taps (22.05 kHz
                 // default, 128 mels, 16 kHz default) 22 / 13 / 12 % faster, 76 (48 kHz, 80 mels) 1 % faster
-                uint32_t taps = 0;
-                for (uint32_t gq = 0; mb.ok && gq < mb.n_groups; gq++) taps += mb.words[2 * gq + 1];
+                // (round 4: the table's first bins are spread over the LDS banks, which may add 4 taps to a group; the limits
+                // were measured on, and still apply to, the tap count before that)
+                const uint32_t taps = mb.taps_unshifted;
                 const uint32_t max_taps = g.log2_nc == 9 ? TH_MEL_BAND_TAPS_1024 : (g.hop % 128 == 0 ? TH_MEL_BAND_TAPS_2048 + 8u : TH_MEL_BAND_TAPS_2048);
                 if (mb.ok && taps <= max_taps) {
                     p->mel_bsum_words = (uint32_t)mb.words.size();

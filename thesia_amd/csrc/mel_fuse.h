@@ -154,10 +154,65 @@ inline MelFuseHost build_mel_fuse(const float *fb, uint32_t n_freq, uint32_t n_m
 struct MelBandHost {
     std::vector<uint32_t> words;
     uint32_t n_groups = 0, max_taps = 0;
+    uint32_t taps_unshifted = 0;  // sum over the groups of their widest filter (rounded to 4), before the bank spreading below
     bool ok = false;
 };
 constexpr uint32_t MEL_BAND_MAX_GROUPS = 8, MEL_BAND_HDR = 2 * MEL_BAND_MAX_GROUPS, MEL_BAND_MAX_TAPS = 128;
-inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_mel, uint32_t max_words) {
+
+// Bank spreading (round 4).  The amplitude reads of a tap are `ds_read_b32 amp[first_m + t]`, lane = mel: the LDS serves a
+// wave's read as two halves of 32 lanes, bank = dword address mod 32, one more cycle for every further address on a busy bank
+// (MI355X_MICROARCH.md, LDS).  The first bins of 32 neighbouring filters are spread quasi-randomly over the banks (3-4 on the
+// busiest one for the wide filters: SQ_LDS_BANK_CONFLICT 27 % of SQ_LDS_IDX_ACTIVE at the 48 kHz default), and since every tap
+// moves all lanes by the same amount the collisions are the same for every tap.  A filter narrower than its group's tap count
+// has slack: it may start `s` bins early against `s` leading zero weights.  mel_band_spread picks the shifts of one half so
+// that at most `cap` first bins fall on any bank (bipartite matching filter -> bank, smallest shifts tried first), within
+// `taps`; returns false when no such assignment exists.
+inline bool mel_band_spread(const uint32_t *lo, const uint32_t *width, uint32_t n, uint32_t taps, uint32_t cap, uint32_t *shift) {
+    // Kuhn's augmenting paths, filter -> (bank, one of its `cap` places); 32 x 32 cap, trivial sizes
+    struct Rec {
+        const uint32_t *lo, *width;
+        uint32_t taps, cap;
+        int owner[32][4];  // (bank, place) -> filter
+        uint32_t pick[32];
+        bool visit(uint32_t m, bool (&seen)[32]) {
+            const uint32_t smax = std::min(lo[m], taps - width[m]);
+            for (uint32_t s = 0; s <= smax; s++) {
+                const uint32_t b = (lo[m] - s) & 31u;
+                if (seen[b]) continue;
+                seen[b] = true;
+                for (uint32_t c = 0; c < cap; c++)
+                    if (owner[b][c] < 0 || visit((uint32_t)owner[b][c], seen)) {
+                        owner[b][c] = (int)m;
+                        pick[m] = s;
+                        return true;
+                    }
+            }
+            return false;
+        }
+    } rec{lo, width, taps, cap, {}, {}};
+    if (n > 32 || cap < 1 || cap > 4) return false;
+    for (auto &o : rec.owner) std::fill(o, o + 4, -1);
+    for (uint32_t m = 0; m < n; m++) {
+        bool seen[32] = {};
+        if (width[m] > taps || !rec.visit(m, seen)) return false;
+    }
+    std::copy(rec.pick, rec.pick + n, shift);
+    return true;
+}
+// LDS cycles of one tap's amplitude read for a half whose first bins are lo[0 .. n): the largest number of different
+// addresses on one bank
+inline uint32_t mel_band_half_cycles(const uint32_t *lo, uint32_t n) {
+    uint32_t worst = n ? 1u : 0u;
+    for (uint32_t b = 0; b < 32; b++) {
+        std::vector<uint32_t> a;
+        for (uint32_t m = 0; m < n; m++)
+            if ((lo[m] & 31u) == b && std::find(a.begin(), a.end(), lo[m]) == a.end()) a.push_back(lo[m]);
+        worst = std::max<uint32_t>(worst, (uint32_t)a.size());
+    }
+    return worst;
+}
+
+inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_mel, uint32_t max_words, bool spread = true) {
     MelBandHost out;
     if (n_mel == 0 || n_freq == 0) return out;
     const uint32_t G = (n_mel + 63) / 64;
@@ -176,12 +231,40 @@ inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_m
     std::vector<uint32_t> &t = out.words;
     t.assign(MEL_BAND_HDR, 0);
     for (uint32_t g = 0; g < G; g++) {
+        const uint32_t m0 = 64 * g, m1 = std::min(n_mel, 64 * g + 64);
         uint32_t n = 0;
-        for (uint32_t m = 64 * g; m < std::min(n_mel, 64 * g + 64); m++) n = std::max(n, hi[m] - lo[m]);
+        for (uint32_t m = m0; m < m1; m++) n = std::max(n, hi[m] - lo[m]);
         n = std::max<uint32_t>(4, (n + 3) / 4 * 4);  // (mel_banded starts its sums with four taps)
         if (n > MEL_BAND_MAX_TAPS) {
             t.clear();
             return out;
+        }
+        out.taps_unshifted += n;
+        // first bins: as they are, or moved down onto distinct banks where that costs fewer LDS cycles.  A tap costs the two
+        // halves' weight reads (one cycle each, lane-contiguous) plus their amplitude reads (mel_band_half_cycles each).
+        uint32_t shift[64] = {}, width[64] = {};
+        for (uint32_t m = m0; m < m1; m++) width[m - m0] = hi[m] - lo[m];
+        if (spread) {
+            const uint32_t h0 = std::min(32u, m1 - m0), h1 = m1 - m0 - h0;
+            uint32_t best_cost = n * (2u + mel_band_half_cycles(&lo[m0], h0) + mel_band_half_cycles(&lo[m0] + h0, h1)), best_n = n;
+            for (uint32_t nn = n; nn <= std::min(n + 8u, MEL_BAND_MAX_TAPS); nn += 4) {
+                uint32_t sh[64] = {}, cycles = 0;
+                bool found = true;
+                for (uint32_t h = 0; h < 2 && found; h++) {  // each half: the fewest addresses per bank that can be had within nn taps
+                    const uint32_t hn = h ? h1 : h0, hb = h ? h0 : 0;
+                    if (!hn) continue;
+                    uint32_t cap = 1;
+                    while (cap <= 4 && !mel_band_spread(&lo[m0] + hb, width + hb, hn, nn, cap, sh + hb)) cap++;
+                    found = cap <= 4;
+                    cycles += cap;
+                }
+                if (found && nn * (2u + cycles) < best_cost) {
+                    best_cost = nn * (2u + cycles);
+                    best_n = nn;
+                    std::copy(sh, sh + 64, shift);
+                }
+            }
+            n = best_n;
         }
         out.max_taps = std::max(out.max_taps, n);
         const size_t off = t.size();
@@ -190,9 +273,13 @@ inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_m
         t.resize(off + 64 * (size_t)(1 + n), 0);
         for (uint32_t lane = 0; lane < 64; lane++) {
             const uint32_t m = 64 * g + lane;
-            if (m >= n_mel) continue;  // (first bin 0, zero weights)
-            t[off + lane] = lo[m];
-            for (uint32_t k = lo[m]; k < hi[m]; k++) std::memcpy(&t[off + 64 * (size_t)(1 + k - lo[m]) + lane], &fb[(size_t)k * n_mel + m], 4);
+            if (m >= n_mel) {  // zero weights; the address of the half's first lane, so that it is served by the same broadcast
+                t[off + lane] = t[off + (lane & 32u)];
+                continue;
+            }
+            const uint32_t first = lo[m] - shift[lane];
+            t[off + lane] = first;
+            for (uint32_t k = lo[m]; k < hi[m]; k++) std::memcpy(&t[off + 64 * (size_t)(1 + k - first) + lane], &fb[(size_t)k * n_mel + m], 4);
         }
     }
     if (t.size() > max_words) {
