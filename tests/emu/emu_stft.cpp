@@ -357,15 +357,18 @@ extern "C" __attribute__((visibility("default"))) int emu_mel_fuse(const float *
 }
 
 // The same product as banded sums, lane = mel (build_mel_band + mel_banded): out[m] = the filter outputs (linear).
-// info[0..2] = table words, groups, widest group's taps.  amp must be followed by 128 readable zeros (the kernel zeroes them).
+// layout: 0 = first bins as the filters start, 1 = spread over the LDS banks, 2 = the paired layout (even first bins, weights
+// in quads).  info[0..4] = table words, groups, widest group's taps, all groups' taps, LDS cycles of one frame's amplitude reads
+// by the bank rule (mel_fuse.h).  amp must be followed by 128 readable zeros (the kernel zeroes them).
 extern "C" __attribute__((visibility("default"))) int emu_mel_band(const float *amp, const float *fb, uint32_t n_freq,
-                                                                    uint32_t n_mel, uint32_t max_words, float *out,
+                                                                    uint32_t n_mel, uint32_t max_words, uint32_t layout, float *out,
                                                                     uint32_t *info) {
-    const MelBandHost h = build_mel_band(fb, n_freq, n_mel, max_words);
+    const MelBandHost h = build_mel_band(fb, n_freq, n_mel, max_words, layout >= 1, layout == 2);
     if (!h.ok) return 1;
     info[0] = (uint32_t)h.words.size();
     info[1] = h.n_groups;
     info[2] = h.max_taps;
+    info[3] = info[4] = 0;
     std::vector<float> a(n_freq + MEL_BAND_MAX_TAPS, 0.0f);
     std::memcpy(a.data(), amp, n_freq * sizeof(float));
     for (uint32_t m = 0; m < n_mel; m++) out[m] = NAN;
@@ -373,10 +376,24 @@ extern "C" __attribute__((visibility("default"))) int emu_mel_band(const float *
     for (uint32_t g = 0; g < h.n_groups; g++) {
         off[g] = h.words[2 * g];
         nt[g] = h.words[2 * g + 1];
+        info[3] += nt[g];
+        uint32_t first[64];
+        for (uint32_t l = 0; l < 64; l++) {
+            first[l] = h.words[off[g] + l];
+            if (layout == 2) {
+                if (first[l] & 1u) return 2;  // 8-byte reads need even first bins
+                first[l] /= 2;
+            }
+        }
+        const uint32_t cyc = mel_band_half_cycles(first, 32) + mel_band_half_cycles(first + 32, 32);
+        info[4] += layout == 2 ? nt[g] / 2 * cyc : nt[g] * cyc;
     }
-    for (uint32_t l = 0; l < 64; l++)
-        mel_banded(l, a.data(), h.words.data(), h.n_groups, off, nt, [&](uint32_t m, float v) {
+    for (uint32_t l = 0; l < 64; l++) {
+        auto emit = [&](uint32_t m, float v) {
             if (m < n_mel) out[m] = v;
-        });
+        };
+        if (layout == 2) mel_banded<true>(l, a.data(), h.words.data(), h.n_groups, off, nt, emit);
+        else mel_banded<false>(l, a.data(), h.words.data(), h.n_groups, off, nt, emit);
+    }
     return 0;
 }

@@ -149,28 +149,36 @@ def test_fused_mel_epilogue_tables(emu, sr, n_fft, n_mel):
 @pytest.mark.parametrize("sr,n_fft,n_mel", [(44100, 2048, 128), (48000, 2048, 0), (44100, 2048, 0), (16000, 1024, 0),
                                             (22050, 1024, 0), (48000, 1024, 80), (32000, 2048, 0), (48000, 2048, 512)])
 def test_banded_mel_epilogue_matches_the_dense_product(emu, sr, n_fft, n_mel):
-    """build_mel_band + mel_banded (lane = mel, taps to the widest filter of each group of 64 mels) against amp @ fb in f64."""
+    """build_mel_band + mel_banded (lane = mel, taps to the widest filter of each group of 64 mels) against amp @ fb in f64, in the
+    table's three layouts: first bins as the filters start, spread over the LDS banks, paired (8-byte amplitude reads)."""
     M = n_mel or orc.mel_default_n_mel(sr, n_fft)
     fb = np.ascontiguousarray(orc.calc_mel_fb(sr, n_fft, M), np.float32)
     F = n_fft // 2 + 1
     rng = np.random.default_rng(5)
     f32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
-    emu.emu_mel_band.argtypes = [f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p]
-    info = np.zeros(3, np.uint32)
-    for trial in range(3):
-        amp = (rng.uniform(0, 1, F) * 10.0 ** rng.uniform(-6, 0, F)).astype(np.float32)
-        out = np.empty(M, np.float32)
-        rc = emu.emu_mel_band(amp.ctypes.data_as(f32p), fb.ctypes.data_as(f32p), F, M, 1 << 16, out.ctypes.data_as(f32p),
-                              info.ctypes.data_as(u32p))
-        assert rc == 0
-        want = amp.astype(np.float64) @ fb.astype(np.float64)
-        assert np.all(np.abs(out - want) <= 4e-6 * want + 1e-30), np.abs(out / np.maximum(want, 1e-300) - 1).max()
-    assert info[1] == (M + 63) // 64 and info[2] % 4 == 0
+    emu.emu_mel_band.argtypes = [f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p]
+    infos = []
+    for layout in (0, 1, 2):
+        info = np.zeros(5, np.uint32)
+        for trial in range(3):
+            amp = (rng.uniform(0, 1, F) * 10.0 ** rng.uniform(-6, 0, F)).astype(np.float32)
+            out = np.empty(M, np.float32)
+            rc = emu.emu_mel_band(amp.ctypes.data_as(f32p), fb.ctypes.data_as(f32p), F, M, 1 << 16, layout, out.ctypes.data_as(f32p),
+                                  info.ctypes.data_as(u32p))
+            assert rc == 0, (layout, rc)
+            want = amp.astype(np.float64) @ fb.astype(np.float64)
+            assert np.all(np.abs(out - want) <= 4e-6 * want + 1e-30), np.abs(out / np.maximum(want, 1e-300) - 1).max()
+        assert info[1] == (M + 63) // 64 and info[2] % 4 == 0
+        infos.append(info)
+    # the bank spreading never costs LDS cycles, and the paired layout (half the cycles per conflict-free tap, a few more taps)
+    # stays below the plain one as well; neither adds more than 8 taps to a group
+    assert infos[1][4] <= infos[0][4] and infos[1][3] <= infos[0][3] + 8 * infos[0][1]
+    assert infos[2][4] <= infos[0][4] and infos[2][3] <= infos[0][3] + 8 * infos[0][1], (infos[0], infos[2])
     # a filterbank with a filter wider than 128 bins has no table (the plan keeps the pieces or the matrix cores)
     wide = np.zeros((F, 4), np.float32)
     wide[: F // 2, 0] = 1.0
     wide[F // 2:, 1] = 1.0
-    assert emu.emu_mel_band(amp.ctypes.data_as(f32p), wide.ctypes.data_as(f32p), F, 4, 1 << 16, out.ctypes.data_as(f32p),
+    assert emu.emu_mel_band(amp.ctypes.data_as(f32p), wide.ctypes.data_as(f32p), F, 4, 1 << 16, 1, out.ctypes.data_as(f32p),
                             info.ctypes.data_as(u32p)) == 1
 
 

@@ -625,7 +625,8 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
                 }
             }
             if (rc == TH_OK && (g.log2_nc == 9 || g.log2_nc == 10)) {
-                const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16, TH_MEL_BAND_SPREAD != 0);
+                // (the wave kernels of n_fft 1024 / 2048 read the table's paired layout, mel_banded<true>)
+                const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16, TH_MEL_BAND_SPREAD != 0, TH_MEL_BAND_PAIRED != 0);
                 // Measured against the pieces / gather form (same box, alternating; taps = the sum over the groups of their
                 // widest filter): n_fft 2048 — 56 / 60 / 64 taps (256 mels, the 44.1 / 48 kHz defaults) 6 / 8 / 10 % faster; 72 taps
                 // (128 mels) 4 % faster in the register-reuse kernel (hop a multiple of 128: config 4), 6 % slower in the full-reload

@@ -9,6 +9,12 @@
 #include "../../include/thesia_amd.h"
 #include "stft_core.h"
 
+// The banded mel table of the n_fft 1024 / 2048 wave kernels in its paired layout (mel_fuse.h build_mel_band, stft_wave.h
+// mel_banded<true>): host table and device code must agree, so the switch lives here (0: plain layout, for A/B builds).
+#if !defined(TH_MEL_BAND_PAIRED)
+#define TH_MEL_BAND_PAIRED 1
+#endif
+
 namespace th {
 
 // ---- kernels_stft.hip

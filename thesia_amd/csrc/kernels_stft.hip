@@ -603,7 +603,7 @@ __device__ __forceinline__ void wave_frame(
             slab_f[NC + 1 + lane] = 0.0f;
             slab_f[NC + 65 + lane] = 0.0f;
             wave_lds_sync();
-            mel_banded(lane, slab_f, meltab, wo.mel_groups, wo.band_off, wo.band_n, emit_mel);
+            mel_banded<TH_MEL_BAND_PAIRED != 0>(lane, slab_f, meltab, wo.mel_groups, wo.band_off, wo.band_n, emit_mel);
         } else {
             cf32 *const prf = mel_prf != nullptr ? mel_prf : slab + (NC + 2) / 2;
             const MelFuseTab mt = mel_fuse_view(meltab, wo.mel_slots, wo.mel_groups);

@@ -167,17 +167,19 @@ constexpr uint32_t MEL_BAND_MAX_GROUPS = 8, MEL_BAND_HDR = 2 * MEL_BAND_MAX_GROU
 // has slack: it may start `s` bins early against `s` leading zero weights.  mel_band_spread picks the shifts of one half so
 // that at most `cap` first bins fall on any bank (bipartite matching filter -> bank, smallest shifts tried first), within
 // `taps`; returns false when no such assignment exists.
-inline bool mel_band_spread(const uint32_t *lo, const uint32_t *width, uint32_t n, uint32_t taps, uint32_t cap, uint32_t *shift) {
+// step = 2 (paired layout, below): first bins must be even and a lane's 8-byte read covers the bank pair (first / 2) mod 32.
+inline bool mel_band_spread(const uint32_t *lo, const uint32_t *width, uint32_t n, uint32_t taps, uint32_t cap, uint32_t *shift,
+                            uint32_t step = 1) {
     // Kuhn's augmenting paths, filter -> (bank, one of its `cap` places); 32 x 32 cap, trivial sizes
     struct Rec {
         const uint32_t *lo, *width;
-        uint32_t taps, cap;
+        uint32_t taps, cap, step;
         int owner[32][4];  // (bank, place) -> filter
         uint32_t pick[32];
         bool visit(uint32_t m, bool (&seen)[32]) {
             const uint32_t smax = std::min(lo[m], taps - width[m]);
-            for (uint32_t s = 0; s <= smax; s++) {
-                const uint32_t b = (lo[m] - s) & 31u;
+            for (uint32_t s = (lo[m] % step); s <= smax; s += step) {
+                const uint32_t b = ((lo[m] - s) / step) & 31u;
                 if (seen[b]) continue;
                 seen[b] = true;
                 for (uint32_t c = 0; c < cap; c++)
@@ -189,7 +191,7 @@ inline bool mel_band_spread(const uint32_t *lo, const uint32_t *width, uint32_t 
             }
             return false;
         }
-    } rec{lo, width, taps, cap, {}, {}};
+    } rec{lo, width, taps, cap, step, {}, {}};
     if (n > 32 || cap < 1 || cap > 4) return false;
     for (auto &o : rec.owner) std::fill(o, o + 4, -1);
     for (uint32_t m = 0; m < n; m++) {
@@ -212,7 +214,14 @@ inline uint32_t mel_band_half_cycles(const uint32_t *lo, uint32_t n) {
     return worst;
 }
 
-inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_mel, uint32_t max_words, bool spread = true) {
+// Paired layout (round 4, `paired`): four taps are one 16-byte weight read (ds_read_b128, weights stored [tap / 4][lane][4])
+// and two 8-byte amplitude reads (ds_read_b64 of amp[first + 2 j], first bins EVEN) instead of four + four dword reads: both
+// wider reads move 256 B per LDS clock where ds_read_b32 / ds_read2_b32 move 128 (MI355X_MICROARCH.md, LDS), so a tap costs
+// half the LDS cycles when the 32 lanes of a half sit on different bank pairs.  Making the first bins even and distinct
+// mod 64 needs more slack than the dword spreading: a group's tap count may grow by 4 or 8.  `ok` stays false when no
+// assignment with at most 4 addresses per bank exists (the caller then builds the plain layout).
+inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_mel, uint32_t max_words, bool spread = true,
+                                  bool paired = false) {
     MelBandHost out;
     if (n_mel == 0 || n_freq == 0) return out;
     const uint32_t G = (n_mel + 63) / 64;
@@ -240,29 +249,51 @@ inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_m
             return out;
         }
         out.taps_unshifted += n;
-        // first bins: as they are, or moved down onto distinct banks where that costs fewer LDS cycles.  A tap costs the two
-        // halves' weight reads (one cycle each, lane-contiguous) plus their amplitude reads (mel_band_half_cycles each).
+        // first bins: as they are, or moved down onto distinct banks where that costs fewer LDS cycles.  Four taps cost the
+        // two halves' weight reads plus their amplitude reads — plain layout: 4 x (1 + 1) cycles + 4 x (the halves' busiest
+        // banks, mel_band_half_cycles); paired: 4 + 2 x (the halves' busiest bank pairs).
         uint32_t shift[64] = {}, width[64] = {};
         for (uint32_t m = m0; m < m1; m++) width[m - m0] = hi[m] - lo[m];
-        if (spread) {
+        if (spread || paired) {
             const uint32_t h0 = std::min(32u, m1 - m0), h1 = m1 - m0 - h0;
-            uint32_t best_cost = n * (2u + mel_band_half_cycles(&lo[m0], h0) + mel_band_half_cycles(&lo[m0] + h0, h1)), best_n = n;
-            for (uint32_t nn = n; nn <= std::min(n + 8u, MEL_BAND_MAX_TAPS); nn += 4) {
-                uint32_t sh[64] = {}, cycles = 0;
-                bool found = true;
-                for (uint32_t h = 0; h < 2 && found; h++) {  // each half: the fewest addresses per bank that can be had within nn taps
-                    const uint32_t hn = h ? h1 : h0, hb = h ? h0 : 0;
-                    if (!hn) continue;
-                    uint32_t cap = 1;
-                    while (cap <= 4 && !mel_band_spread(&lo[m0] + hb, width + hb, hn, nn, cap, sh + hb)) cap++;
-                    found = cap <= 4;
-                    cycles += cap;
-                }
-                if (found && nn * (2u + cycles) < best_cost) {
-                    best_cost = nn * (2u + cycles);
+            uint32_t best_cost = ~0u, best_n = n;
+            if (!paired) best_cost = n * (2u + mel_band_half_cycles(&lo[m0], h0) + mel_band_half_cycles(&lo[m0] + h0, h1)) + n;
+            const uint32_t step = paired ? 2u : 1u;
+            auto try_shifts = [&](uint32_t nn, const uint32_t *sh) {  // the cost of an assignment by the bank rule; keeps the best
+                uint32_t first[64] = {};
+                for (uint32_t l = 0; l < h0 + h1; l++) first[l] = (lo[m0 + l] - sh[l]) / step;
+                const uint32_t cycles = mel_band_half_cycles(first, h0) + mel_band_half_cycles(first + h0, h1);
+                // (+ nn: a tap is also a multiply-add and its share of the loop, about one more cycle of the CU's time)
+                const uint32_t cost = (paired ? nn / 4 * (4u + 2u * cycles) : nn * (2u + cycles)) + nn;
+                if (cost < best_cost) {
+                    best_cost = cost;
                     best_n = nn;
                     std::copy(sh, sh + 64, shift);
                 }
+            };
+            for (uint32_t nn = n; nn <= std::min(n + 8u, MEL_BAND_MAX_TAPS); nn += 4) {
+                uint32_t sh[64] = {};
+                if (paired) {  // only made even: filters that start on the same bin (dense filterbanks) stay one broadcast address
+                    bool fits = true;
+                    for (uint32_t l = 0; l < h0 + h1; l++) {
+                        sh[l] = lo[m0 + l] & 1u;
+                        fits = fits && width[l] + sh[l] <= nn;
+                    }
+                    if (fits) try_shifts(nn, sh);
+                }
+                bool found = true;
+                for (uint32_t h = 0; h < 2 && found; h++) {  // each half: the fewest filters per bank that can be had within nn taps
+                    const uint32_t hn = h ? h1 : h0, hb = h ? h0 : 0;
+                    if (!hn) continue;
+                    uint32_t cap = 1;
+                    while (cap <= 4 && !mel_band_spread(&lo[m0] + hb, width + hb, hn, nn, cap, sh + hb, step)) cap++;
+                    found = cap <= 4;
+                }
+                if (found) try_shifts(nn, sh);
+            }
+            if (best_cost == ~0u) {  // (paired only)
+                t.clear();
+                return out;
             }
             n = best_n;
         }
@@ -279,7 +310,11 @@ inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_m
             }
             const uint32_t first = lo[m] - shift[lane];
             t[off + lane] = first;
-            for (uint32_t k = lo[m]; k < hi[m]; k++) std::memcpy(&t[off + 64 * (size_t)(1 + k - first) + lane], &fb[(size_t)k * n_mel + m], 4);
+            for (uint32_t k = lo[m]; k < hi[m]; k++) {
+                const uint32_t tap = k - first;
+                const size_t at = paired ? off + 64 + ((size_t)(tap / 4) * 64 + lane) * 4 + tap % 4 : off + 64 * (size_t)(1 + tap) + lane;
+                std::memcpy(&t[at], &fb[(size_t)k * n_mel + m], 4);
+            }
         }
     }
     if (t.size() > max_words) {

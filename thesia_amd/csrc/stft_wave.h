@@ -1371,13 +1371,60 @@ TH_HD void mel_gather(uint32_t lane, const cf32 *prf, const MelFuseTab &t, Emit 
 #define TH_LDS_F32_PTR(p) (p)
 #endif
 // off[g], n[g]: block offset and taps of group g (the table's header; the kernel gets them as scalar arguments)
-template <class Emit>
+// PAIRED: the table's paired layout (build_mel_band): even first bins, weights [tap / 4][lane][4] — four taps are one
+// ds_read_b128 of weights and two ds_read_b64 of amplitudes (amp and the table 16-byte aligned in LDS).
+template <bool PAIRED = false, class Emit>
 TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint32_t n_groups, const uint32_t (&off)[8],
                       const uint32_t (&n)[8], Emit emit) {
     uint32_t lo[8];  // every group's first bin up front: one LDS round trip for all of them
     TH_UNROLL for (uint32_t g = 0; g < 8; g++) lo[g] = tab[off[g < n_groups ? g : 0] + lane];
     TH_UNROLL for (uint32_t g = 0; g < 8; g++) {
         if (g < n_groups) {  // wave-uniform
+            if constexpr (PAIRED) {
+                auto ld2 = [](const float *q) -> cf32 {  // two amplitudes, one ds_read_b64
+#if defined(__HIP_DEVICE_COMPILE__)
+                    return lds_ld(reinterpret_cast<const cf32 *>(q));
+#else
+                    return {q[0], q[1]};
+#endif
+                };
+                const float *ap = amp + lo[g];
+                const float *wp = reinterpret_cast<const float *>(tab) + (off[g] + 64u + 4u * lane);
+                float acc[4];
+                {
+                    const f32x4 w = lds_ld4(wp);
+                    const cf32 a01 = ld2(ap), a23 = ld2(ap + 2);
+                    acc[0] = a01.re * w.a;
+                    acc[1] = a01.im * w.b;
+                    acc[2] = a23.re * w.c;
+                    acc[3] = a23.im * w.d;
+                }
+                ap += 4;
+                wp += 256;
+                uint32_t t = 4;
+                for (; t + 8 <= n[g]; t += 8, ap += 8, wp += 512) {
+                    const f32x4 w0 = lds_ld4(wp), w1 = lds_ld4(wp + 256);
+                    cf32 a[4];
+                    TH_UNROLL for (uint32_t u = 0; u < 4; u++) a[u] = ld2(ap + 2u * u);
+                    acc[0] = fma_rn(a[0].re, w0.a, acc[0]);
+                    acc[1] = fma_rn(a[0].im, w0.b, acc[1]);
+                    acc[2] = fma_rn(a[1].re, w0.c, acc[2]);
+                    acc[3] = fma_rn(a[1].im, w0.d, acc[3]);
+                    acc[0] = fma_rn(a[2].re, w1.a, acc[0]);
+                    acc[1] = fma_rn(a[2].im, w1.b, acc[1]);
+                    acc[2] = fma_rn(a[3].re, w1.c, acc[2]);
+                    acc[3] = fma_rn(a[3].im, w1.d, acc[3]);
+                }
+                if (t < n[g]) {  // (n is a multiple of 4)
+                    const f32x4 w = lds_ld4(wp);
+                    const cf32 a01 = ld2(ap), a23 = ld2(ap + 2);
+                    acc[0] = fma_rn(a01.re, w.a, acc[0]);
+                    acc[1] = fma_rn(a01.im, w.b, acc[1]);
+                    acc[2] = fma_rn(a23.re, w.c, acc[2]);
+                    acc[3] = fma_rn(a23.im, w.d, acc[3]);
+                }
+                emit(64u * g + lane, (acc[0] + acc[1]) + (acc[2] + acc[3]));
+            } else {
             // (cast first, then index: 32-bit LDS address arithmetic instead of a 64-bit generic pointer that is truncated afterwards)
             TH_LDS_F32 *ap = TH_LDS_F32_PTR(amp) + lo[g];
             TH_LDS_F32 *wp = TH_LDS_F32_PTR(reinterpret_cast<const float *>(tab)) + (off[g] + 64u + lane);
@@ -1412,6 +1459,7 @@ TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint
                 TH_UNROLL for (uint32_t u = 0; u < 4; u++) acc[u] = fma_rn(a[u], w[u], acc[u]);
             }
             emit(64u * g + lane, (acc[0] + acc[1]) + (acc[2] + acc[3]));
+            }
         }
     }
 }
