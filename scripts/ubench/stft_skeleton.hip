@@ -283,7 +283,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3
     // (the scheduler's words sit in front of the dynamic LDS: keep the slabs 16-byte aligned — misaligned ds_read_b128 cost
     // this skeleton 0.27 ms per launch before the attribute was there)
     extern __shared__ __attribute__((aligned(256))) v2f lds[];
-    __shared__ uint32_t s_ticket, s_group[K], s_tag[K];
+    // (BEHIND the slabs: static __shared__ words are placed in front of the dynamic segment, which then starts at byte 72 whatever
+    // alignment the extern array asks for — every ds_read_b128 of the stand-in exchange was misaligned by 8 bytes, 0.28 ms per
+    // launch; the "ldsr 2" lines of profiles/r04_ubench_stft_skeleton_sweep.txt before this fix measure that, not the schedule)
+    uint32_t *const sched = reinterpret_cast<uint32_t *>(lds + WAVES * 1100);
+    uint32_t &s_ticket = sched[0];
+    uint32_t *const s_group = sched + 1, *const s_tag = sched + 1 + K;
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     v2f *slab = lds + wave * 1100;
     const uint32_t n_groups = n_chan * groups_per_chan, fpc = T - 4;  // interior frames per channel
@@ -449,7 +454,7 @@ static void run_sweep(const float *wav, float *spec, uint32_t n_chan, uint32_t n
     hipEventCreate(&e1);
     const uint32_t gpc = (T - 4 + SUBS * 4 - 1) / (SUBS * 4);
     auto kern = k_sweep<FMA, LDSR, WAVES, SUBS>;
-    const size_t lds = (size_t)WAVES * 1100 * sizeof(v2f);
+    const size_t lds = (size_t)WAVES * 1100 * sizeof(v2f) + 128;  // + the scheduler's words
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<float> ts;
     for (int i = 0; i < 24; i++) {
@@ -484,7 +489,7 @@ static void run(const char *name, const float *wav, float *spec, uint32_t n_chan
     hipEventCreate(&e1);
     const uint32_t cpc = (T - 4 + CHUNK - 1) / CHUNK;
     auto kern = k<LOADM, STOREM, FMA, LDSR, WAVES, LDSM>;
-    const size_t lds = (size_t)WAVES * 1100 * sizeof(v2f);
+    const size_t lds = (size_t)WAVES * 1100 * sizeof(v2f) + 128;  // + the scheduler's words
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<float> ts;
     for (int i = 0; i < 24; i++) {
