@@ -834,9 +834,11 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         // The sweep schedule (kernels_stft.hip: 4-frame chunks dealt out in order, next chunk prefetched) — round 4, selector 11
         // only: its memory skeleton streams 3-10 % faster (scripts/ubench/stft_skeleton.hip mode 8), the kernel does not: inside
         // bench.py's step 0.492 / 0.497 / 0.496 ms against 0.495 / 0.495 / 0.494 for the default schedule on one box, alternating,
-        // and 8 % SLOWER alone with 1 ms gaps (profiles/r04_ab_sweep.txt).  With the packed-f32 pipeline (-39 % VALU instructions,
-        // +-0) that makes three independent changes of what the kernel DOES per frame that do not change what a launch TAKES:
-        // it runs at the package power cap, where time follows flops + bytes, and neither moved.
+        // and 8 % slower alone with 1 ms gaps (profiles/r04_ab_sweep.txt) — of which the kernel itself is 1 % (rocprofv3 trace:
+        // 480 us against 475, profiles/r04_ab_sweep_kernel_level.txt); the rest is this function building and uploading a
+        // seven times longer chunk table per call, which a pipelined step hides and a lone call does not.  With the packed-f32
+        // pipeline (-39 % VALU instructions, +-0) that makes three independent changes of what the kernel DOES per frame that do
+        // not change what a launch TAKES: it runs at the package power cap, where time follows flops + bytes, and neither moved.
         sweep = total > n_waves * 32 && p->wave_chunk == 0 && p->kernel_choice == 11 && !mel_mfma && !mel_fused &&
                 g.n_mel == 0 && phase_mode == 0 && th::stft_wave_sweep_applies(g, p->wave_waves, 0);
         if (sweep) g.frames_per_tile = 4;

@@ -802,7 +802,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     constexpr int SHIFT_NZ = SHIFT > 0 ? SHIFT : 1;  // (keeps the constant expression below free of a % 0)
     constexpr bool ROTATE = PHASED || (SHIFT > 0 && P % SHIFT_NZ == 0 && P / SHIFT_NZ <= 4);
     constexpr int NROT = PHASED ? 4 : (ROTATE ? P / SHIFT : 1);
-    constexpr int RESK = (PHASED || DYN) ? (RES & ~1) : RES;  // phased: the window changes every frame, it stays in LDS
+    constexpr int RESK = (PHASED || DYN || SWEEP) ? (RES & ~1) : RES;  // phased: the window changes every frame, it stays in LDS; sweep: 148 VGPRs instead of 168 + scratch
     // slots reused / rotation offset / window table of body ROT
 #define TH_BODY_SHIFT(ROT) (PHASED ? ((ROT) == 0 ? 3 : 4) : DYN ? DYN_K : SHIFT)
 #define TH_BODY_OFF(ROT) (PHASED ? ((ROT) == 0 ? 0 : 4 * (ROT) - 1) : (ROTATE ? (ROT) * SHIFT : 0))
@@ -866,15 +866,16 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
                 TH_FRAME_SW(2, false);
                 ++f;
                 TH_FRAME_SW(3, true);
-            } else {  // tail of a channel (1 .. 3 frames) or a boundary frame: no prefetch across the chunk end
-                TH_FRAME_SW(0, false);
-                if (n > 1) {
-                    ++f;
-                    TH_FRAME_SW(1, false);
-                    if (n > 2) {
-                        ++f;
-                        TH_FRAME_SW(2, false);
-                    }
+            }
+            else {  // tail of a channel (1 .. 3 frames) or a boundary frame: ONE more body (every frame loaded in full) instead of
+                // three rotation bodies — 53 -> 41 KB of code, and with the window read from LDS (RESK) no register spills: the
+                // first version kept two per-lane words in scratch and reloaded them in every frame body, each reload behind
+                // the previous frame's row stores (one in-order vmcnt)
+                for (;;) {
+                    wave_frame<LOG2_NC, 0, OUT, false, 0, RESK, -1, PKV>(
+                        g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin,
+                        lmax, meltab, mel_prf, wo);
+                    if (++f >= cur.f1) break;
                 }
                 TH_SW_NEXT();
             }
