@@ -276,6 +276,7 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_,
 //   * the first frame of the NEXT sub-chunk (all 16 slots) is requested in the last frame of the current one, where the kept
 //     slots are dead anyway: a sub-chunk start exposes no load latency and needs no extra registers.
 // ---------------------------------------------------------------------------------------------------------------------
+static int g_iters = 24;  // launches per measurement (mode 9: long loops for the power probe)
 template <int FMA, int LDSR, int WAVES, int SUBS>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sweep(const float *wav_, float *spec_, uint32_t n_chan, uint32_t n_samples, uint32_t T,
                                                       uint32_t groups_per_chan, uint32_t *queue, float seed) {
@@ -457,7 +458,7 @@ static void run_sweep(const float *wav, float *spec, uint32_t n_chan, uint32_t n
     const size_t lds = (size_t)WAVES * 1100 * sizeof(v2f) + 128;  // + the scheduler's words
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<float> ts;
-    for (int i = 0; i < 24; i++) {
+    for (int i = 0; i < g_iters; i++) {
         hipMemsetAsync(q, 0, 4, 0);
         hipEventRecord(e0);
         hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WAVES), lds, 0, wav, spec, n_chan, n_samples, T, gpc, q, 1.0f);
@@ -492,7 +493,7 @@ static void run(const char *name, const float *wav, float *spec, uint32_t n_chan
     const size_t lds = (size_t)WAVES * 1100 * sizeof(v2f) + 128;  // + the scheduler's words
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<float> ts;
-    for (int i = 0; i < 24; i++) {
+    for (int i = 0; i < g_iters; i++) {
         hipMemsetAsync(q, 0, 4, 0);
         hipEventRecord(e0);
         hipLaunchKernelGGL(kern, dim3(g_grid ? g_grid : 256), dim3(64 * WAVES), lds, 0, wav, spec, n_chan, n_samples, T, cpc, q, 1.0f);
@@ -523,7 +524,7 @@ static void run(const char *name, const float *wav, float *spec, uint32_t n_chan
 
 int main(int argc, char **argv) {
     const int gap_us = argc > 1 ? atoi(argv[1]) : 0;
-    if (argc > 3) g_grid = (uint32_t)atoi(argv[3]);
+    if (argc > 3 && (argc < 3 || atoi(argv[2]) != 9)) g_grid = (uint32_t)atoi(argv[3]);
     const uint32_t n_chan = 128, n_samples = 1440000, T = n_samples / HOP + 1;
     float *wav, *spec;
     uint32_t *q;
@@ -551,6 +552,16 @@ int main(int argc, char **argv) {
         return 0;
     }
     printf("# gap between launches: %d us\n", gap_us);
+    if (argc > 2 && atoi(argv[2]) == 9) {
+        // power probe (scripts/power_probe.sh): argv[3] = 0: the kernel's own schedule, 1: the sweep schedule, both with the kernel's
+        // amount of stand-in work, back to back for about ten seconds
+        g_iters = 20000;
+        const int which = argc > 3 ? atoi(argv[3]) : 0;
+        g_grid = 0;
+        if (which == 0) R(3, 1, 42, 2, 12, 2);
+        else run_sweep<42, 2, 12, 6>(wav, spec, n_chan, n_samples, T, q, gap_us);
+        return 0;
+    }
     if (argc > 2 && atoi(argv[2]) == 1) {
         // store shapes next to the kernel's amount of VALU / LDS work: the kernel's pattern (1), 16 aligned dword stores
         // (2), four 16-byte stores (3; with a third LDS round standing for the transposition that would feed them),
