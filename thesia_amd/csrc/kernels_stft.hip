@@ -684,6 +684,10 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     cf32 *t3 = t2 + (T2_IN_LDS ? W::T2_LEN : 0);
     cf32 *slabs = t3 + W::T3_LEN;
     uint32_t *meltab = reinterpret_cast<uint32_t *>(slabs + (size_t)WAVES * W::SLAB_LEN);  // OUT == 2 only
+    // (the banded mel table's paired layout is read with ds_read_b128, the amplitude row in the slab with ds_read_b64: the
+    // table and every slab start on 16 bytes — all lengths in front of them are even numbers of 8-byte entries)
+    static_assert(OUT != 2 || ((NC + WPAD + (STW_IN_LDS ? STW_LEN : 0) + (T2_IN_LDS ? W::T2_LEN : 0) + W::T3_LEN) % 2 == 0 && W::SLAB_LEN % 2 == 0),
+                  "mel table and slabs 16-byte aligned");
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // wave index is wave-uniform: tell the compiler, so the frame cursor lives in SGPRs / SALU
