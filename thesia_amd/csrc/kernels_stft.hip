@@ -1255,19 +1255,30 @@ static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, co
 // transform ahead of its use.  Without it every frame is loaded in full and three quarters of that are re-reads that the
 // L2 (4 MB per XCD against 96 workgroups streaming 48 KB per frame each) mostly misses: PMC 1.87 GB fetched per launch for
 // 0.74 GB of audio.  The 32 registers come from the window pairs, which are read from the (L2-resident) table instead.
-constexpr bool block_double_buffered(int log2_nc) { return log2_nc == 13; }
-template <int LOG2_NC, bool AMP, bool REUSE>
-__global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
+// VT (round 4): "virtual threads" per thread.  With VT = 2 a workgroup has T / 2 threads and every thread runs the lane
+// functions of BlockFft for the two thread ids t and t + T / 2 (stft_block.h is unchanged: its functions take t as an argument):
+// twice the independent work between two barriers, half the waves at each barrier, 256 registers per thread; a pass's
+// constants are requested behind the previous pass's LDS stores (the constants of a pass with sub-size NS <= T / 2 depend on
+// t mod NS only: both virtual threads share them).  Measured (profiles/r04_ab_block_virtual_threads.txt):
+//   n_fft 32768: 1.94 ms against 2.19 (hop = n_fft / 4), 3.26 against 3.69 (19200 / 4800): the default there.  With the raw
+//                samples resident on top (REUSE: 256 VGPRs + 120 bytes of scratch) 1.98: not used.
+//   n_fft 16384: ONE exchange buffer per workgroup of four waves, so that two workgroups share a CU: 1.35 ms against 1.01 for
+//                one workgroup of eight waves with two buffers and resident constants: not used.
+constexpr bool block_double_buffered(int log2_nc, int vt) { return log2_nc == 13 && vt == 1; }
+template <int LOG2_NC, bool AMP, bool REUSE, int VT>
+__global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) __attribute__((amdgpu_waves_per_eu(VT == 2 ? 2 : 1))) void stft_block_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_tiles,
     const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax) {
     using B = BlockFft<LOG2_NC>;
-    constexpr int T = B::T, NC = B::NC;
-    constexpr bool WIN_REGS = LOG2_NC == 12 && !REUSE;  // 32 VGPRs: with three sets of pass constants (n_fft 16384) or the resident samples they do not fit
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // BUF_LEN cf32 (n_fft 16384: 2 x 68 KB) + the (min, max) scratch
+    constexpr int T = B::T, NC = B::NC, TT = T / VT;
+    static_assert(VT == 1 || VT == 2, "one or two virtual threads");
+    static_assert(VT == 1 || (TT % B::NS_B == 0 && (!B::R2_FIRST || TT % B::NS_A == 0)), "shared pass constants");
+    constexpr bool WIN_REGS = LOG2_NC == 12 && !REUSE && VT == 1;  // 32 VGPRs: with three sets of pass constants (n_fft 16384) or the resident samples they do not fit
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // BUF_LEN cf32 (n_fft 16384, VT 1: 2 x 68 KB) + the (min, max) scratch
     // n_fft 16384 (one workgroup per CU either way): two exchange buffers used alternately, see the frame loop.  n_fft 8192
     // keeps one: a second would cost its full-reload variant the third workgroup per CU (3.2 -> 3.6 ms on 3840/960/8192)
     // and gains nothing at two (0.72 ms either way).
-    constexpr bool DBUF = block_double_buffered(LOG2_NC);
+    constexpr bool DBUF = block_double_buffered(LOG2_NC, VT);
     cf32 *const buf = reinterpret_cast<cf32 *>(smem_raw);
     float *const red = reinterpret_cast<float *>(buf + (DBUF ? 2 : 1) * B::BUF_LEN);
     cf32 *wr = buf, *nx = buf + (DBUF ? B::BUF_LEN : 0);
@@ -1281,19 +1292,24 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
             __syncthreads(); /* one buffer: its reads are done before the next writes */      \
         }                                                                                      \
     } while (0)
-    const uint32_t t = threadIdx.x;
+#define TH_VT _Pragma("unroll") for (int v = 0; v < VT; v++)
+    const uint32_t t = threadIdx.x;  // virtual thread ids: t + TT v
     const FrameCursor cur = cursor_at(g, jobs, chunk_tab, n_tiles, blockIdx.x);
     if (!cur.valid) return;
-    // pass constants: in registers for the whole launch — except at n_fft 32768, whose 1024 threads have 128 VGPRs each:
-    // there every pass loads its ten constants (L2-resident table) when it starts
-    constexpr bool TW_RES = LOG2_NC <= 13;
-    cf32 wA[B::NTW], wB[B::NTW], wC[B::NTW];
+    // pass constants: in registers for the whole launch — except at n_fft 32768 with 1024 threads (128 VGPRs each): there
+    // every pass loads its ten constants (L2-resident table) when it starts.  VT = 2: the constants of the last pass differ
+    // between the two virtual threads (sub-size T): two sets, loaded per frame
+    // VT = 2: no constants are resident either; a pass's constants are requested right behind the previous pass's LDS stores,
+    // where the 64 registers of z are free, and land during the barrier and the exchange reads
+    constexpr bool TW_RES = LOG2_NC <= 13 && VT == 1, TWC_RES = TW_RES;
+    cf32 wA[B::NTW], wB[B::NTW], wC[VT][B::NTW];
     if constexpr (TW_RES) {
         if constexpr (B::R2_FIRST) B::template load_tw<B::NS_A>(t, wA, tw);
         B::template load_tw<B::NS_B>(t, wB, tw);
-        B::template load_tw<B::NS_C>(t, wC, tw);
+        B::template load_tw<B::NS_C>(t, wC[0], tw);
     }
-    const cf32 stw_t = tw[t];
+    cf32 stw_t[VT];
+    TH_VT stw_t[v] = tw[t + (uint32_t)TT * v];
     cf32 rw[WIN_REGS ? 16 : 1];
     if constexpr (WIN_REGS) {
 #pragma unroll
@@ -1301,76 +1317,86 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     }
     // (!TW_RES: an opaque copy of the thread index per use, or the loads — loop-invariant — are hoisted out of the frame loop
     // and 60 registers stay live across it: 71 spilled VGPRs at n_fft 32768)
-    auto tw_lane = [&]() {
-        uint32_t v = t;
-        asm volatile("" : "+v"(v));
-        return v;
+    auto tw_lane = [&](uint32_t tv) {
+        uint32_t x_ = tv;
+        asm volatile("" : "+v"(x_));
+        return x_;
     };
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
-    cf32 x[16];  // raw samples of the frame
+    cf32 x[VT][16];  // raw samples of the frame
     auto fetch = [&](uint32_t f) {
         // the frame's n_fft-sample span starts at e0 (interior frames only: the whole span is inside the channel)
         const int64_t e0 = (int64_t)f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+        TH_VT {
 #pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const gptr<const float> p = cur.wav + (e0 + 2 * (int64_t)(t + (uint32_t)T * m));
-            x[m] = {p[0], p[1]};
+            for (int m = 0; m < 16; m++) {
+                const gptr<const float> p = cur.wav + (e0 + 2 * (int64_t)(t + (uint32_t)TT * v + (uint32_t)T * m));
+                x[v][m] = {p[0], p[1]};
+            }
         }
     };
     if constexpr (REUSE) fetch(cur.f);
     for (uint32_t f = cur.f; f < cur.f1; f++) {
         if constexpr (!REUSE) fetch(f);
-        cf32 z[16];
-        const uint32_t tl = TW_RES ? t : tw_lane();  // (!TW_RES: keeps the 16 window pairs from being hoisted out of the loop too)
+        cf32 z[VT][16];
+        TH_VT {
+            const uint32_t tl = (TW_RES && VT == 1) ? t : tw_lane(t + (uint32_t)TT * v);  // (keeps the 16 window pairs from being hoisted out of the loop too)
 #pragma unroll
-        for (int m = 0; m < 16; m++) {
-            cf32 w;
-            if constexpr (WIN_REGS) w = rw[m];
-            else w = wtab_g[tl + (uint32_t)T * m];
-            z[m] = {x[m].re * w.re, x[m].im * w.im};
+            for (int m = 0; m < 16; m++) {
+                cf32 w;
+                if constexpr (WIN_REGS) w = rw[m];
+                else w = wtab_g[tl + (uint32_t)T * m];
+                z[v][m] = {x[v][m].re * w.re, x[v][m].im * w.im};
+            }
         }
         if constexpr (REUSE) {  // the next frame: four slots down, the new hop requested now
-#pragma unroll
-            for (int m = 0; m < 12; m++) x[m] = x[m + 4];
             const uint32_t fn = f + 1 < cur.f1 ? f + 1 : f;  // (the last frame of a chunk re-reads its own hop: in bounds, never used)
             const int64_t e0n = (int64_t)fn * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+            TH_VT {
 #pragma unroll
-            for (int m = 12; m < 16; m++) {
-                const gptr<const float> p = cur.wav + (e0n + 2 * (int64_t)(t + (uint32_t)T * m));
-                x[m] = {p[0], p[1]};
+                for (int m = 0; m < 12; m++) x[v][m] = x[v][m + 4];
+#pragma unroll
+                for (int m = 12; m < 16; m++) {
+                    const gptr<const float> p = cur.wav + (e0n + 2 * (int64_t)(t + (uint32_t)TT * v + (uint32_t)T * m));
+                    x[v][m] = {p[0], p[1]};
+                }
             }
         }
         // DBUF: exchange n goes through buffer n mod 2: a thread that has passed the barrier of exchange n - 1 knows that
         // every thread is done reading exchange n - 2, so ONE barrier per exchange (between its writes and its reads) is
         // enough; with a single buffer TH_BLOCK_SWAP is the second barrier, before the next writes (n_fft 16384: 4 barriers
         // per frame instead of 8, 1.12 -> 1.01 ms).
-        B::pass_first(t, z, wr);
+        constexpr bool EARLY = VT == 2;  // (see TW_RES)
+        TH_VT B::pass_first(t + (uint32_t)TT * v, z[v], wr);
+        if constexpr (EARLY) {
+            if constexpr (B::R2_FIRST) B::template load_tw<B::NS_A>(tw_lane(t), wA, tw);
+            else B::template load_tw<B::NS_B>(tw_lane(t), wB, tw);
+        }
         __syncthreads();
-        B::template read_in<B::FIRST_LAYOUT>(t, z, wr);
+        TH_VT B::template read_in<B::FIRST_LAYOUT>(t + (uint32_t)TT * v, z[v], wr);
         TH_BLOCK_SWAP();
         if constexpr (B::R2_FIRST) {
-            if constexpr (!TW_RES) B::template load_tw<B::NS_A>(tw_lane(), wA, tw);
-            B::template pass_mid_compute<B::NS_A>(z, wA);
-            B::template pass_mid_store<B::NS_A>(t, z, wr);
+            if constexpr (!TW_RES && !EARLY) B::template load_tw<B::NS_A>(tw_lane(t), wA, tw);
+            TH_VT B::template pass_mid_compute<B::NS_A>(z[v], wA);
+            TH_VT B::template pass_mid_store<B::NS_A>(t + (uint32_t)TT * v, z[v], wr);
+            if constexpr (EARLY) B::template load_tw<B::NS_B>(tw_lane(t), wB, tw);
             __syncthreads();
-            B::template read_in<B::NS_A>(t, z, wr);
+            TH_VT B::template read_in<B::NS_A>(t + (uint32_t)TT * v, z[v], wr);
             TH_BLOCK_SWAP();
         }
-        if constexpr (!TW_RES) B::template load_tw<B::NS_B>(tw_lane(), wB, tw);
-        B::template pass_mid_compute<B::NS_B>(z, wB);
-        B::template pass_mid_store<B::NS_B>(t, z, wr);
+        if constexpr (!TW_RES && !EARLY) B::template load_tw<B::NS_B>(tw_lane(t), wB, tw);
+        TH_VT B::template pass_mid_compute<B::NS_B>(z[v], wB);
+        TH_VT B::template pass_mid_store<B::NS_B>(t + (uint32_t)TT * v, z[v], wr);
+        if constexpr (EARLY) TH_VT B::template load_tw<B::NS_C>(tw_lane(t + (uint32_t)TT * v), wC[v], tw);
         __syncthreads();
-        B::template read_in<B::NS_B>(t, z, wr);
+        TH_VT B::template read_in<B::NS_B>(t + (uint32_t)TT * v, z[v], wr);
         TH_BLOCK_SWAP();
-        if constexpr (!TW_RES) B::template load_tw<B::NS_C>(tw_lane(), wC, tw);
-        B::pass_last(z, wC);
-        B::write_z(t, z, wr);
+        if constexpr (!TWC_RES && !EARLY) B::template load_tw<B::NS_C>(tw_lane(t), wC[0], tw);
+        TH_VT B::pass_last(z[v], wC[v]);
+        TH_VT B::write_z(t + (uint32_t)TT * v, z[v], wr);
         __syncthreads();
-        cf32 zm[8];
-        B::split_read(t, wr, zm);
-        TH_BLOCK_SWAP();
         const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch;
-        B::split_compute(t, z, zm, stw_t, [&](uint32_t k, float p) {
+        auto emit = [&](uint32_t k, float p) {
             if constexpr (AMP) {  // amplitude rows for the matrix-core mel path
                 row[k] = power_to_amp(p);
             } else {
@@ -1379,7 +1405,20 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }
-        });
+        };
+        if constexpr (VT == 1) {
+            cf32 zm[8];
+            B::split_read(t, wr, zm);
+            TH_BLOCK_SWAP();
+            B::split_compute(t, z[0], zm, stw_t[0], emit);
+        } else {  // one virtual thread after the other (16 registers of mirror partners instead of 32), the barrier behind both
+            TH_VT {
+                cf32 zm[8];
+                B::split_read(t + (uint32_t)TT * v, wr, zm);
+                B::split_compute(t + (uint32_t)TT * v, z[v], zm, stw_t[v], emit);
+            }
+            TH_BLOCK_SWAP();
+        }
         {   // complete the row's last 128-byte line (see wave_frame)
             const uint32_t height = (uint32_t)(NC + 1), padn = cur.spec_pitch - height;
             if (t - 1u < ((padn < 32u && cur.spec_pitch % 32u == 0) ? padn : 0u)) row[height - 1u + t] = 0.0f;
@@ -1395,7 +1434,7 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
         __syncthreads();
         if (t == 0) {
             float a = red[0], b = red[1];
-            for (int w = 1; w < T / 64; w++) {
+            for (int w = 1; w < TT / 64; w++) {
                 a = nmin(a, red[2 * w]);
                 b = nmax(b, red[2 * w + 1]);
             }
@@ -1405,28 +1444,40 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T) void stft_block_kernel(
     }
 }
 
+#undef TH_VT
 #undef TH_BLOCK_SWAP
 
-template <int LOG2_NC, bool AMP, bool REUSE>
+#if !defined(TH_BLOCK_VT_13)
+#define TH_BLOCK_VT_13 1  // virtual threads per thread of the n_fft 16384 block kernel: 2 measured 1.35 ms against 1.01 (profiles/r04_ab_block_virtual_threads.txt)
+#endif
+#if !defined(TH_BLOCK_VT_14)
+#define TH_BLOCK_VT_14 2  // ... of the n_fft 32768 kernel: 1.94-1.98 ms against 2.19 (hop = n_fft / 4), 3.26 against 3.69 (19200 / 4800)
+#endif
+#if !defined(TH_BLOCK_VT2_REUSE)
+#define TH_BLOCK_VT2_REUSE 0  // resident samples under VT = 2: 1.98 ms against 1.94 without at n_fft 32768 (256 VGPRs + 120 bytes of scratch)
+#endif
+template <int LOG2_NC, bool AMP, bool REUSE, int VT>
 static hipError_t launch_block_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
                                const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
     using B = BlockFft<LOG2_NC>;
-    auto kern = stft_block_kernel<LOG2_NC, AMP, REUSE>;
-    const size_t lds = sizeof(cf32) * (block_double_buffered(LOG2_NC) ? 2 : 1) * B::BUF_LEN + sizeof(float) * 2 * (B::T / 64);
-    static_assert(sizeof(cf32) * (block_double_buffered(LOG2_NC) ? 2 : 1) * B::BUF_LEN + 64 <= 160 * 1024, "the exchange buffers fit the CU's LDS");
+    auto kern = stft_block_kernel<LOG2_NC, AMP, REUSE, VT>;
+    constexpr size_t lds = sizeof(cf32) * (block_double_buffered(LOG2_NC, VT) ? 2 : 1) * B::BUF_LEN + sizeof(float) * 2 * (B::T / VT / 64);
+    static_assert(lds + 64 <= 160 * 1024, "the exchange buffers fit the CU's LDS");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(B::T), lds, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax);
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(B::T / VT), lds, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax);
     return hipGetLastError();
 }
 
 template <int LOG2_NC, bool AMP>
 static hipError_t launch_block(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
                                const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
-    // (every frame of a chunk then sits exactly four slots behind its predecessor; not at n_fft 32768: 128 VGPRs per thread)
-    if constexpr (LOG2_NC <= 13)
-        if (g.hop * 4 == g.n_fft) return launch_block_t<LOG2_NC, AMP, true>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
-    return launch_block_t<LOG2_NC, AMP, false>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
+    constexpr int VT = LOG2_NC == 13 ? TH_BLOCK_VT_13 : LOG2_NC == 14 ? TH_BLOCK_VT_14 : 1;
+    // (every frame of a chunk then sits exactly four slots behind its predecessor; at n_fft 32768 only with two virtual threads:
+    // 1024 threads have 128 VGPRs each)
+    if constexpr (LOG2_NC <= 13 || VT == 2)
+        if (g.hop * 4 == g.n_fft && (VT == 1 || TH_BLOCK_VT2_REUSE)) return launch_block_t<LOG2_NC, AMP, true, VT>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
+    return launch_block_t<LOG2_NC, AMP, false, VT>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
 }
 
 
