@@ -614,9 +614,9 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
             const th::MelFuseHost mf = th::build_mel_fuse(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, th::stft_wave_mel_max_pieces(g));
             if (rc == TH_OK && g.log2_nc == 11) {
                 // n_fft 4096 (two kernels): the same banded table for mel_band_rows_kernel, where it fits LDS beside four rows
-                // (first bins as the filters start: mel_band_rows_kernel measured 3 % slower on the bank-spread table, 2.08 -> 2.15 ms
-                // at the 96 kHz default, profiles/r04_ab_mel_bank_spread.txt)
-                const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16, false);
+                // (the paired layout as in the wave kernels; with dword reads the bank-spread table had measured 3 % SLOWER here, 2.08 ->
+                // 2.15 ms at the 96 kHz default, profiles/r04_ab_mel_bank_spread.txt — the paired one is 1 % faster than the plain table)
+                const th::MelBandHost mb = th::build_mel_band(p->h_mel_fb.data(), g.n_freq, (uint32_t)n_mel, 1u << 16, false, TH_MEL_ROWS_PAIRED != 0);
                 if (mb.ok && th::mel_band_rows_fits(g.n_freq, (uint32_t)mb.words.size())) {
                     p->mel_bsum_words = (uint32_t)mb.words.size();
                     std::copy(mb.words.begin(), mb.words.begin() + 16, p->mel_bsum_hdr);

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void mel_band_rows_kernel(const MelJob *__rest
         const bool have_next = locate(qn, jn, fn);
         if (have_next) fetch(jobs[jn], fn);
         const gptr<float> orow = as_global(job.spec) + (size_t)frame * job.spec_pitch;
-        mel_banded(lane, row, tab, hb.groups, hb.off, hb.n, [&](uint32_t m, float v) {
+        mel_banded<TH_MEL_ROWS_PAIRED != 0>(lane, row, tab, hb.groups, hb.off, hb.n, [&](uint32_t m, float v) {
             if (m < n_mel) {
                 const float d = 6.02059991327962390f * __builtin_amdgcn_logf(v);  // dB_from_amp (decibel.rs:179-202)
                 orow[m] = d;
