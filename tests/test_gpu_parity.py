@@ -1719,7 +1719,8 @@ def test_phased_register_reuse_for_hop_480(ctx, win, hop, n_fft):
     # (hop 480: "phased" — offsets cycle 0, 96, 64, 32, slot rotation; other hops in (384, 512), e.g. 441 at 44.1 kHz:
     # "dynamic" — offset and reuse decided per frame, odd offsets through the one-sample-shifted window table)
     # (also n_fft = 2048 with hops in (256, 384), 32 kHz: 1280 / 320, and n_fft = 1024 with hops in (128, 256), 16 kHz: 640 / 160;
-    # n_fft = 4096 — the 40 ms default at 88.2 / 96 kHz, 3528 / 882 and 3840 / 960 — with 7 waves per workgroup)
+    # n_fft = 4096 — the 40 ms default at 88.2 / 96 kHz, 3528 / 882 and 3840 / 960 — with 7 waves per workgroup; round 4: those two
+    # have even hops and even win / 2, so every offset is even, the odd table is never read and the kernel runs 8 waves with one table)
     sr = 48000
     wavs = [synth_track(900 + i, sr, n) for i, n in enumerate((131072, 40000, 2048, 2049, 3000, 97531))]
     plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)

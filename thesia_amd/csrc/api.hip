@@ -494,7 +494,7 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
             std::vector<float> w4(96 + n_fft, 0.f);
             for (size_t i = 0; i < win; i++) w4[96 + i] = half * w[i];
             rc = up((void **)&p->d_wtab_phased, w4.data(), w4.size() * sizeof(float));
-        } else if (rc == TH_OK && pm == 2) {
+        } else if (rc == TH_OK && (pm == 2 || pm == 3)) {  // (3 reads the even table only: the same buffer)
             std::vector<float> t0(n_fft + 2, 0.f), w2(2 * (128 + n_fft), 0.f);
             for (size_t i = 0; i < win; i++) t0[i] = half * w[i];
             for (size_t i = 0; i < n_fft; i++) {

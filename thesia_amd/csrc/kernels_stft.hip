@@ -372,8 +372,22 @@ __device__ __forceinline__ void wave_frame(
     cf32 w2[W::NT2];
     constexpr bool PKP = W::PK && PKV;
     v2f zp[PKP ? P : 1];  // the windowed frame as (re, im) pairs (packed pipeline)
-    constexpr bool DYN = PH == -2;
-    if constexpr (DYN) {
+    // PH == -3: dynamic mode with even offsets only and NO zero pairs in front of the (single) table — the table's own tail is
+    // zeros (n_fft - win >= 128 samples), so the one read that would fall below the table wraps around into it
+    constexpr bool DYN = PH == -2 || PH == -3, DYNW = PH == -3;
+    if constexpr (DYNW) {
+        const uint32_t h = ((uint32_t)((int64_t)f * g.hop - (int64_t)(g.win / 2)) & 127u) >> 1;  // (the offset is even) pairs above the grid
+        {
+            const cf32 w = lds_ld(&wtab[(col - h) & (uint32_t)(NC - 1)]);
+            z[0] = {x[0].re * w.re, x[0].im * w.im};
+        }
+        const cf32 *const wb = wtab + col - h;  // (slots m >= 1 start at pair 64 m + col - h >= 1)
+#pragma unroll
+        for (int m = 1; m < P; m++) {
+            const cf32 w = lds_ld(&wb[64u * m]);
+            z[m] = {x[m].re * w.re, x[m].im * w.im};
+        }
+    } else if constexpr (DYN) {
         const uint32_t d = (uint32_t)((int64_t)f * g.hop - (int64_t)(g.win / 2)) & 127u;  // first window sample above the grid
         wave_window_rot<P, 0>(col, z, x, wtab + 64 + ((d & 1u) ? NC + 64 : 0) - ((d + 1u) >> 1));
     } else if constexpr ((RES & 1) != 0 && PKP) {
@@ -662,13 +676,15 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // idea with the offset (any value in [0, 128), odd ones served by a second table whose pairs are shifted by one sample)
     // and the reuse (3 or 4 slots) decided per frame; registers are moved, not rotated (the offsets have no short cycle).
     // (SHIFT = -16 - K encodes the dynamic mode for hops in (128 K, 128 (K + 1)): K or K + 1 slots are reused)
-    constexpr bool PHASED = SHIFT == -1, DYN = SHIFT <= -16;
-    constexpr int DYN_K = DYN ? -SHIFT - 16 : 0;
+    // (SHIFT = -48 - K: the same when hop and win / 2 are both even — the offset is then always even and the odd table is never read:
+    // no second table, which at n_fft 4096 is the eighth wave's LDS)
+    constexpr bool PHASED = SHIFT == -1, DYN = SHIFT <= -16, DYN_EVEN = SHIFT <= -48;
+    constexpr int DYN_K = DYN_EVEN ? -SHIFT - 48 : DYN ? -SHIFT - 16 : 0;
     static_assert(PHASED || DYN || (SHIFT >= 0 && SHIFT < P), "shift must leave something to reuse");
     static_assert(!PHASED || (P == 16 && OUT != 1), "phased mode: n_fft = 2048, dB output");
     static_assert(!DYN || (DYN_K >= 0 && DYN_K + 1 < P && (OUT != 1 || LOG2_NC == 11)), "dynamic mode: something to reuse; amplitude output at n_fft 4096 only");
     // zero pairs in front of the window table(s): room to read them up to 96 (127) samples lower; DYN: even + odd table
-    constexpr int WPAD = PHASED ? 48 : DYN ? 64 + NC + 64 : 0;
+    constexpr int WPAD = PHASED ? 48 : DYN_EVEN ? 0 : DYN ? 64 + NC + 64 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *wtab = reinterpret_cast<cf32 *>(smem_raw);
     // the split-twiddle table is not kept in LDS when the lanes hold their entries in registers (RES bit 3)
@@ -780,7 +796,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     static_assert(!WPERM || (!PHASED && !DYN), "the shifted window tables are read by column");
     for (uint32_t i = tid; i < NC; i += 64 * WAVES) {
         const uint32_t col = i & 63u, li = WPERM ? (i & ~63u) + 8u * (col & 7u) + (col >> 3) : i;
-        wtab[WPAD + li] = wtab_g[WPAD + i];
+        wtab[WPAD + li] = wtab_g[(DYN_EVEN ? 64 : WPAD) + i];  // (even-only dynamic mode: the even table behind the global buffer's 64 zero pairs)
         if constexpr (STW_IN_LDS && !PKP) stw[i] = tw[i];
     }
     if constexpr (STW_IN_LDS && PKP) W::fill_stwp(tid, 64 * WAVES, tw, stw);
@@ -811,7 +827,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #define TH_BODY_SHIFT(ROT) (PHASED ? ((ROT) == 0 ? 3 : 4) : DYN ? DYN_K : SHIFT)
 #define TH_BODY_OFF(ROT) (PHASED ? ((ROT) == 0 ? 0 : 4 * (ROT) - 1) : (ROTATE ? (ROT) * SHIFT : 0))
 #define TH_FRAME(ROT)                                                                                                  \
-    wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : DYN ? -2 : -1, PKV>( \
+    wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : DYN_EVEN ? -3 : DYN ? -2 : -1, PKV>( \
         g, wtab + (PHASED ? WPAD - ((96 * (ROT)) & 127) / 2 : 0), stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
         lmax, meltab, mel_prf, wo)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
@@ -1654,6 +1670,9 @@ uint32_t stft_wave_multi_tail_guard(const StftGeom &g) {
 #if !defined(TH_WAVES_4096)
 #define TH_WAVES_4096 8
 #endif
+#if !defined(TH_DYN_EVEN_4096)
+#define TH_DYN_EVEN_4096 1  // grid-aligned mode without the odd window table where the offsets are always even (0: A/B builds)
+#endif
 template <int LOG2_NC>
 struct WaveLaunchCfg {
     static constexpr int DEFAULT_WAVES = LOG2_NC == 11 ? TH_WAVES_4096 : 12;  // n_fft = 4096: LDS-bound (17 KB slab per wave): 8 waves = 160 KB exactly
@@ -1707,7 +1726,7 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
     const size_t lds = (pkv ? wave_lds_bytes<LOG2_NC, WAVES, true>() : wave_lds_bytes<LOG2_NC, WAVES, false>()) + (sweep ? 128 : 0) + (OUT == 2 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
                        (OUT == 2 && LOG2_NC == 9 && out.mel_slots != 0 ? (size_t)WAVES * MEL_PRF_1024 * sizeof(cf32) : 0) +  // (pieces / gather only)
                        (SHIFT == -1 ? 48 * sizeof(cf32) : 0) +  // phased: zero pairs in front of the window table
-                       (SHIFT <= -16 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes
+                       (SHIFT <= -48 ? 0 : SHIFT <= -16 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes (even offsets only: neither)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -1730,7 +1749,7 @@ template <int LOG2_NC, int WAVES, int SHIFT>
 static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
-    if constexpr (WAVES == (SHIFT < 0 ? WaveLaunchCfg<LOG2_NC>::GRID_WAVES : WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES)) {
+    if constexpr (WAVES == ((SHIFT < 0 && SHIFT > -48) ? WaveLaunchCfg<LOG2_NC>::GRID_WAVES : WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES)) {
         if constexpr (SHIFT >= 0 || (SHIFT <= -16 && LOG2_NC == 11)) {
             if (out.mode == 1)
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
@@ -1762,6 +1781,14 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     constexpr int P = WaveFft<LOG2_NC>::P;
+    if (g.phased == 3) {  // dynamic mode, even offsets only (n_fft 4096: the 96 / 88.2 kHz defaults at eight waves)
+        if constexpr (LOG2_NC == 11 && WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
+            const uint32_t k = g.hop / 128;
+            if (k == 7) return launch_wave_t4<LOG2_NC, WAVES, -48 - 7>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
+            if (k == 6) return launch_wave_t4<LOG2_NC, WAVES, -48 - 6>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
+        }
+        return hipErrorInvalidValue;
+    }
     if (g.phased) {  // grid-aligned loads (see stft_wave_kernel): only the default launch shapes are instantiated
         if constexpr (WAVES == WaveLaunchCfg<LOG2_NC>::GRID_WAVES) {
             const uint32_t k = g.hop / 128;
@@ -1854,6 +1881,11 @@ int stft_wave_phased_mode(const StftGeom &g, int waves) {
     if (g.log2_nc == 9 && (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) && k <= 1 && g.n_fft - g.win >= 127)
         return 2;  // (k = 0: 16 kHz with t_overlap 8 .. 32, 640 / 80 / 1024)
     // n_fft 4096 (the 40 ms default at 88.2 / 96 kHz): 7 waves per workgroup, the eighth's LDS holds the second window table
+    // (3: hop and win / 2 both even — the frame's offset above the grid is then always even, the odd window table is never
+    // read and its 17 KB hold the eighth wave: the 96 kHz (3840 / 960) and 88.2 kHz (3528 / 882) defaults)
+    if (TH_DYN_EVEN_4096 && g.log2_nc == 11 && (waves <= 0 || waves == WaveLaunchCfg<11>::DEFAULT_WAVES) && (k == 7 || k == 6) && g.hop % 2 == 0 &&
+        (g.win / 2) % 2 == 0 && g.n_fft - g.win >= 127)
+        return 3;
     if (g.log2_nc == 11 && (waves <= 0 || waves == WaveLaunchCfg<11>::GRID_WAVES) && (k == 7 || k == 6 || k == 3 || k <= 1 || k == 13) && g.n_fft - g.win >= 127)
         return 2;
     return 0;
@@ -1893,7 +1925,7 @@ bool stft_wave_sweep_applies(const StftGeom &g, int waves, int out_mode) {
 
 int stft_wave_default_waves(const StftGeom &g) {
     switch (g.log2_nc) {
-        case 11: return g.phased ? WaveLaunchCfg<11>::GRID_WAVES : WaveLaunchCfg<11>::DEFAULT_WAVES;
+        case 11: return (g.phased && g.phased != 3) ? WaveLaunchCfg<11>::GRID_WAVES : WaveLaunchCfg<11>::DEFAULT_WAVES;
         case 10: return WaveLaunchCfg<10>::DEFAULT_WAVES;
         // n_fft 512 (four frames per wave, staged loads): measured 12 / 2 x 8 / 16 waves per CU — 512/128: 0.77 / 0.70-0.74 /
         // 0.68-0.72 ms, 320/80 (8 kHz default): 1.16-1.18 / 1.21-1.26 / 1.24 ms
