@@ -1784,8 +1784,17 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
     if (g.phased == 3) {  // dynamic mode, even offsets only (n_fft 4096: the 96 / 88.2 kHz defaults at eight waves)
         if constexpr (LOG2_NC == 11 && WAVES == WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES) {
             const uint32_t k = g.hop / 128;
-            if (k == 7) return launch_wave_t4<LOG2_NC, WAVES, -48 - 7>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
-            if (k == 6) return launch_wave_t4<LOG2_NC, WAVES, -48 - 6>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
+#define TH_DYN_EVEN_CASE(K)                                                                                            \
+    if (k == (K))                                                                                                     \
+        return launch_wave_t4<LOG2_NC, WAVES, -48 - (K)>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, \
+                                                          d_queue_head, n_cu, out, s);
+            TH_DYN_EVEN_CASE(7)   // 96 kHz: 3840 / 960
+            TH_DYN_EVEN_CASE(6)   // 88.2 kHz: 3528 / 882
+            TH_DYN_EVEN_CASE(3)   // 96 kHz, t_overlap 8: 3840 / 480 (3528 / 441 has an odd hop: two tables, seven waves)
+            TH_DYN_EVEN_CASE(1)   // t_overlap 16: 3840 / 240, 3528 / 220
+            TH_DYN_EVEN_CASE(0)   // t_overlap 32: 3840 / 120, 3528 / 110
+            TH_DYN_EVEN_CASE(13)  // 88.2 kHz, t_overlap 2: 3528 / 1764
+#undef TH_DYN_EVEN_CASE
         }
         return hipErrorInvalidValue;
     }
@@ -1882,8 +1891,8 @@ int stft_wave_phased_mode(const StftGeom &g, int waves) {
         return 2;  // (k = 0: 16 kHz with t_overlap 8 .. 32, 640 / 80 / 1024)
     // n_fft 4096 (the 40 ms default at 88.2 / 96 kHz): 7 waves per workgroup, the eighth's LDS holds the second window table
     // (3: hop and win / 2 both even — the frame's offset above the grid is then always even, the odd window table is never
-    // read and its 17 KB hold the eighth wave: the 96 kHz (3840 / 960) and 88.2 kHz (3528 / 882) defaults)
-    if (TH_DYN_EVEN_4096 && g.log2_nc == 11 && (waves <= 0 || waves == WaveLaunchCfg<11>::DEFAULT_WAVES) && (k == 7 || k == 6) && g.hop % 2 == 0 &&
+    // read and its 17 KB hold the eighth wave: the 96 kHz (3840 / 960) and 88.2 kHz (3528 / 882) defaults and every even hop below)
+    if (TH_DYN_EVEN_4096 && g.log2_nc == 11 && (waves <= 0 || waves == WaveLaunchCfg<11>::DEFAULT_WAVES) && (k == 7 || k == 6 || k == 3 || k <= 1 || k == 13) && g.hop % 2 == 0 &&
         (g.win / 2) % 2 == 0 && g.n_fft - g.win >= 127)
         return 3;
     if (g.log2_nc == 11 && (waves <= 0 || waves == WaveLaunchCfg<11>::GRID_WAVES) && (k == 7 || k == 6 || k == 3 || k <= 1 || k == 13) && g.n_fft - g.win >= 127)
