@@ -212,7 +212,7 @@ def fuzz_stft(ctx, seed=1, max_cases=10 ** 9, max_seconds=60.0, big=False, cap_b
         sr = int(rng.choice([16000, 22050, 44100, 48000])) if n_fft <= 4096 else int(rng.choice([48000, 96000, 192000]))
         if n_fft == 512 and mel:  # the banded-sum mel kernel: default mel counts of 8-12 kHz audio, and 512 mels
             sr, n_mel = int(rng.choice([8000, 11025, 12000, sr])), int(rng.choice([0, 0, 512, n_mel]))
-        if n_fft == 4096 and rng.random() < 0.5:  # the 88.2 / 96 kHz framings (grid-aligned reuse with 7 waves)
+        if n_fft == 4096 and rng.random() < 0.5:  # the 88.2 / 96 kHz framings (grid-aligned reuse: 8 waves and one window table for even hops, 7 and two for 3528 / 441)
             sr = int(rng.choice([88200, 96000]))
             win = sr // 25
             hop = win // int(rng.choice([2, 4, 4, 8, 16, 32]))
