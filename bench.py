@@ -2,8 +2,13 @@
 """bench.py — headline benchmark of the spectrogram hot path (BASELINE.json metric:
 "STFT frames/sec + spectrogram Mpixels/sec at n_fft=2048, 1/2/4/8 MI355X").
 
-  python bench.py --gpus N --steps K --warmup W            (N = 1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form for N > 1)
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this process a LAUNCHER: before anything touches the GPU
+(no torch import, no HIP call) it checks that N devices are visible — fewer is an error, never a silent one-rank run —
+and starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a CHILD process
+(never an exec), relays its stdout and exits with its code.  Under torchrun, WORLD_SIZE must equal --gpus.
 
 Workload (per GPU, fixed as N grows -> weak scaling): BASELINE config "1024 synthetic 48 kHz mono
 tracks, n_fft=2048, sharded across 8 GPUs" = 128 tracks x 30 s per GPU (track index = rank*128+i),
@@ -68,7 +73,83 @@ def memory_skeleton():
     return out
 
 
-def parse_args():
+def visible_gpu_count(env=None) -> int:
+    """GPUs a rank could open, found WITHOUT initialising HIP in this process: the KFD topology (nodes with SIMDs are
+    GPUs), cut down by HIP_/ROCR_/CUDA_VISIBLE_DEVICES.  Where the topology cannot be read, a CHILD process asks torch
+    (torch.cuda.device_count() does not create a HIP context on this image; a child keeps even that out of the launcher).
+    TH_BENCH_ASSUME_GPUS overrides (tests)."""
+    env = os.environ if env is None else env
+    if env.get("TH_BENCH_ASSUME_GPUS", "") != "":
+        return int(env["TH_BENCH_ASSUME_GPUS"])
+    n = None
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, node, "properties")) if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        n = None
+    if n is None:
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                               text=True, timeout=600, env=dict(env))
+            return int(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
+def launcher_plan(gpus: int, argv, env, n_visible: int):
+    """What `bench.py --gpus N` (N > 1, no WORLD_SIZE) starts: (command, environment) of ONE child process — torchrun with
+    N ranks on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve), this script and its own
+    arguments unchanged.  Fewer than N visible devices: SystemExit with a message, never a smaller job."""
+    if n_visible < gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} needs {gpus} visible GPUs, this node shows {n_visible}; refusing to run a smaller "
+                         "job under the same name (set HIP_VISIBLE_DEVICES / pick --gpus to match)")
+    port = env.get("MASTER_PORT")
+    if not port:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+        s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    child_env = dict(env)
+    child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    child_env.setdefault("OMP_NUM_THREADS", "4")
+    return cmd, child_env
+
+
+def launch_ranks(args, argv) -> int:
+    """The launcher side of `--gpus N`: start the ranks as a child, pass its stdout through line by line (the JSON record
+    stays the last line), return its exit code.  Nothing here imports torch or touches the GPU."""
+    import subprocess
+    cmd, child_env = launcher_plan(args.gpus, argv, os.environ, visible_gpu_count())
+    print("bench.py launcher: " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=child_env, stdout=subprocess.PIPE, text=True, bufsize=1, cwd=ROOT)
+    try:
+        for line in proc.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        return proc.wait()
+    except BaseException:
+        proc.terminate()   # the exact child we started (and through torchrun its ranks), nothing matched by pattern
+        try:
+            proc.wait(timeout=30)
+        except Exception:
+            proc.kill()
+        raise
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -82,7 +163,7 @@ def parse_args():
     ap.add_argument("--no-full-cfg5", action="store_true", help="skip the strong-scaling anchor (all 1024 tracks of config 5 on one GPU)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 wave")
     ap.add_argument("--no-fused-image", action="store_true", help="quantise and raster as two kernels (A/B; the default fuses them)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def synth_on_gpu(torch, dev, track_ids, sr: int, n: int):
@@ -426,6 +507,16 @@ def tm_end_to_end_and_latency(torch, ta, ctx, wl, sr, cmap_bytes, n_tracks=32):
 
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        # launcher: N ranks as a child process, before anything here touches the GPU (TH_BENCH_FORCE_LAUNCHER=1 takes the
+        # same route with N = 1: launcher -> torchrun -> rank -> RCCL process group, end to end on a one-GPU box)
+        if args.gpus > 1 or os.environ.get("TH_BENCH_FORCE_LAUNCHER") == "1":
+            sys.exit(launch_ranks(args, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's rank count and "
+                         "--gpus must agree (n_gpus in the record is the number of ranks that ran)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -440,10 +531,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants device {local_rank}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("TH_BENCH_FORCE_DIST") == "1":  # (the env switch exercises the RCCL path on one GPU)
+    # under torchrun (WORLD_SIZE set) the process group always comes up, also at one rank; the env switch does the same
+    # for a plain `python bench.py`: both exercise the RCCL path on one GPU
+    if world > 1 or "WORLD_SIZE" in os.environ or os.environ.get("TH_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -496,6 +591,9 @@ def main():
     stft_ms = float(np.mean(stft_series))                                        # the dominant kernel launch alone
     # image stage inside the timed step: one fused kernel (default) or the two kernels
     image_ms = float(np.mean([e[2].elapsed_time(e[4]) for e in wl.ev]))
+    # the path's only exchange step, as it sits between the two kernels of the timed step (N > 1 or TH_BENCH_FORCE_DIST):
+    # fold of the per-track (min, max) -> 2-float all-reduce (RCCL) -> clamp kernel; HIP events on the launch stream
+    range_exchange_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in wl.ev])) if dist is not None else None
     quant_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in wl.ev]))
     rast_ms = float(np.mean([e[3].elapsed_time(e[4]) for e in wl.ev]))
 
@@ -936,6 +1034,10 @@ def main():
         if gather is not None:
             rf["tile_gather_ms"] = gather["ms"]
             rf["tile_gather_inbound_GBs"] = gather["inbound_GBs"]
+            rf["tile_gather_ranks"] = gather["ranks"]
+        if range_exchange_ms is not None:
+            rf["range_allreduce_in_step_ms"] = range_exchange_ms
+            rf["range_allreduce_ranks"] = world
         for k, v in list(rf.items()):  # 5 significant digits are plenty and keep the line short
             if isinstance(v, float):
                 rf[k] = float(f"{v:.5g}")
@@ -949,6 +1051,9 @@ def main():
                 extras_out[k] = v
         if gather is not None:
             out["tile_gather"] = {"ms": gather["ms"], "inbound_GBs": gather["inbound_GBs"], "ranks": gather["ranks"]}
+        if range_exchange_ms is not None:
+            out["range_allreduce"] = {"in_step_ms": range_exchange_ms, "ranks": world, "backend": "nccl (RCCL)",
+                                      "what": "minmax fold kernel + 2-float all_reduce(MIN) + clamp kernel, HIP events inside the timed step"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft)
         try:  # RCCL prints a version banner through C stdio; push it out first so that the JSON is the last stdout line

@@ -1855,3 +1855,41 @@ def test_concurrent_tile_readers(ctx, golden_dir):
         t.join()
     assert not errors, errors[:5]
     tm.close()
+
+
+@pytest.mark.gpu
+def test_concurrent_pinned_batch_fetches_do_not_share_a_buffer(ctx, golden_dir):
+    """get_spectrogram_tiles(pinned=True) from several threads at once — each thread owns its pinned buffer, so
+    every batch (different sizes per thread: the buffers grow at different times) is byte-identical to the single
+    requests, and close() frees every thread's buffer."""
+    import threading
+    cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
+    tm = ta.TrackManager(ctx)
+    tm.set_colormap(cmap)
+    tm.add_tracks([(0, 48000, synth_track(80, 48000, 48000 * 8)[None]), (1, 48000, synth_track(81, 48000, 48000 * 6)[None])])
+    tm.apply_track_list_changes()
+    reqs = [(tid, 0, lx, 0, tx, ty) for tid in (0, 1) for lx in (0, 1) for tx in range(2) for ty in range(3)]
+    want = {r: tm.get_spectrogram_tile(*r) for r in reqs}
+    errors = []
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for it in range(12):
+                k = int(rng.integers(1, len(reqs) + 1)) if it else 1 + seed   # growing batches: re-allocation mid-run
+                pick = [reqs[int(i)] for i in rng.integers(0, len(reqs), k)]
+                got = tm.get_spectrogram_tiles(pick, pinned=True)
+                if got != [want[r] for r in pick]:
+                    errors.append((seed, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    assert len(tm._pin_all) == 6
+    tm.close()
+    assert len(tm._pin_all) == 0

@@ -10,6 +10,7 @@ import ctypes as C
 from typing import Iterable, Optional, Sequence
 
 import struct
+import threading
 
 import numpy as np
 
@@ -528,12 +529,37 @@ class TrackManager:
         h = vp()
         check(lib.th_tm_create(ctx.handle, C.byref(h)))
         self.handle, self.ctx = h, ctx
-        self._pin, self._pin_cap = None, 0  # pinned output buffer of get_spectrogram_tiles(pinned=True), grow-only
+        # pinned output buffers of get_spectrogram_tiles(pinned=True): ONE PER CALLING THREAD (tile getters run
+        # concurrently from IPC threads and ctypes drops the GIL during the C call — ADVICE r4: a buffer shared by all
+        # callers let one caller read another's pixels and freed memory a kernel was still writing).  A thread's buffer is
+        # grow-only and only that thread ever replaces it, between its own calls; close() frees them all.
+        self._pin_tls = threading.local()
+        self._pin_all = {}   # id -> c_void_p of every live pinned buffer (for close()), under _pin_lock
+        self._pin_lock = threading.Lock()
+
+    def _pinned_for_this_thread(self, nbytes: int):
+        tls = self._pin_tls
+        if getattr(tls, "cap", 0) < nbytes:
+            old = getattr(tls, "ptr", None)
+            if old is not None:   # this thread's previous buffer: no call of this thread is in flight now
+                with self._pin_lock:
+                    self._pin_all.pop(old.value, None)
+                tls.ptr, tls.cap = None, 0
+                check(lib.th_host_free(self.ctx.handle, old))
+            p = C.c_void_p()
+            check(lib.th_host_alloc(self.ctx.handle, nbytes, C.byref(p)))
+            with self._pin_lock:
+                self._pin_all[p.value] = p
+            tls.ptr, tls.cap = p, nbytes
+        return tls.ptr, tls.cap
 
     def _free_pinned(self):
-        if self._pin is not None:
-            check(lib.th_host_free(self.ctx.handle, self._pin))
-        self._pin, self._pin_cap = None, 0
+        """close(): every thread's buffer (the caller guarantees no tile call is in flight, as for the handle itself)"""
+        with self._pin_lock:
+            bufs, self._pin_all = list(self._pin_all.values()), {}
+        self._pin_tls = threading.local()
+        for p in bufs:
+            check(lib.th_host_free(self.ctx.handle, p))
 
     def close(self):
         if self.handle:
@@ -620,15 +646,11 @@ class TrackManager:
         if n == 0 or need.value == 0:
             return []
         if pinned:
-            # one grow-only pinned buffer per manager (a hipHostMalloc / hipHostFree pair per call costs
-            # milliseconds, most of what the direct write saves); freed in close()
-            if getattr(self, "_pin_cap", 0) < need.value:
-                self._free_pinned()
-                p = C.c_void_p()
-                check(lib.th_host_alloc(self.ctx.handle, need.value, C.byref(p)))
-                self._pin, self._pin_cap = p, need.value
-            check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, self._pin, self._pin_cap, offs, C.byref(need)))
-            out = bytes((C.c_uint8 * need.value).from_address(self._pin.value))
+            # one grow-only pinned buffer per calling thread (a hipHostMalloc / hipHostFree pair per call costs
+            # milliseconds, most of what the direct write saves; ADVICE r4: never shared between threads); freed in close()
+            pin, cap = self._pinned_for_this_thread(need.value)
+            check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, pin, cap, offs, C.byref(need)))
+            out = bytes((C.c_uint8 * need.value).from_address(pin.value))
         else:
             b = np.empty(need.value, np.uint8)
             check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, b.ctypes.data_as(C.c_void_p), b.size, offs, C.byref(need)))
