@@ -536,7 +536,7 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
             lo[m] = b ? a : 0;
             hi[m] = b;
         }
-        {
+        if (th::stft_wave_supported(g)) {   // (no wave / block kernel for this geometry: the generic kernel reads none of these)
             // MFMA mel path tables (kernels_mel.hip; any mel count since round 4 — the Mel default of long windows, e.g. 5571 mels
             // at n_fft 32768 / 48 kHz, used to fall back to the generic kernel: 12 ms where the linear plan takes 2): for every N tile j of 16 mels the band of K blocks (16 bins each)
             // that hold non-zeros, and the filterbank of those blocks in operand order: lane (kq = lane / 16,
@@ -547,16 +547,14 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
             std::vector<float> bt;
             auto fbv = [&](uint32_t f, size_t m) { return (f < g.n_freq && m < n_mel) ? p->h_mel_fb[(size_t)f * n_mel + m] : 0.f; };
             for (uint32_t j = 0; j < nt; j++) {
+                // the tile's K band from the per-mel non-zero ranges [lo, hi) found above (the dense scan over
+                // every (bin, mel) of every tile was ~90 M filterbank reads at the 5571-mel default of n_fft 32768)
                 uint32_t klo = kb_n, khi = 0;
-                for (uint32_t kb = 0; kb < kb_n; kb++) {
-                    bool nz = false;
-                    for (uint32_t f = 16 * kb; f < 16 * kb + 16 && !nz; f++)
-                        for (size_t m = 16 * (size_t)j; m < 16 * (size_t)j + 16 && !nz; m++) nz = fbv(f, m) != 0.f;
-                    if (nz) {
-                        klo = std::min(klo, kb);
-                        khi = kb + 1;
+                for (size_t m = 16 * (size_t)j; m < std::min<size_t>(16 * (size_t)j + 16, n_mel); m++)
+                    if (hi[m]) {
+                        klo = std::min(klo, lo[m] / 16);
+                        khi = std::max(khi, (hi[m] + 15) / 16);
                     }
-                }
                 if (!khi) klo = 0;
                 band[3 * j] = klo;
                 band[3 * j + 1] = khi;
@@ -725,6 +723,17 @@ TH_API size_t th_pitch_u16(size_t n) { return (n + 63) / 64 * 64; }
 // ------------------------------------------------------------------------------------------ calc_spec
 // d_range != NULL: also leave the global dB range [min_dB, max_dB] of these channels (core/mod.rs:169-180) in d_range —
 // folded into the wave kernel's follow-up launch when the batch is one channel, else one more small launch
+// Selector 11 (the in-order "sweep" chunk schedule, measurement apparatus): a wave whose ring slot never arrives gives its chunk
+// up and raises word 1 of the queue block.  Read it back (4 bytes; blocks until the stream is idle) and fail the call that
+// finds it: rows of that launch were left unwritten.
+static int sweep_check(th_plan *p) {
+    uint32_t flag = 0;
+    TH_HIP(hipMemcpy(&flag, p->d_queue_head + 1, sizeof flag, hipMemcpyDeviceToHost));
+    if (!flag) return TH_OK;
+    TH_HIP(hipMemset(p->d_queue_head + 1, 0, sizeof flag));
+    return fail(TH_ERR_INTERNAL, "sweep schedule (kernel selector 11): a wave gave up waiting for its chunk block; rows of the last launch are unwritten");
+}
+
 static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_chan, float *d_minmax, float dB_range,
                                 float *d_range) {
     TH_TRY
@@ -842,6 +851,12 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         sweep = total > n_waves * 32 && p->wave_chunk == 0 && p->kernel_choice == 11 && !mel_mfma && !mel_fused &&
                 g.n_mel == 0 && phase_mode == 0 && th::stft_wave_sweep_applies(g, p->wave_waves, 0);
         if (sweep) g.frames_per_tile = 4;
+        // (an earlier launch of this plan that dropped a chunk: found here when the stream has gone idle — no stall otherwise —
+        // and in th_calc_spec_host behind its synchronisation)
+        if (sweep && hipStreamQuery(c->stream) == hipSuccess) {
+            const int src = sweep_check(p);
+            if (src != TH_OK) return src;
+        }
         if (phase_mode == 1) g.frames_per_tile = std::max<uint32_t>(4, (g.frames_per_tile + 3) / 4 * 4);  // chunks start on the grid
     } else {
         g.frames_per_tile = 8;
@@ -1176,7 +1191,7 @@ TH_API int th_calc_spec_host(th_plan *p, const float *wav, size_t n_samples, flo
         rc = th_calc_spec_batch_dev(p, &d, 1, d_mm);
         if (rc == TH_OK) {
             float mm[2];
-            if (hipok(hipStreamSynchronize(c->stream), "sync") &&
+            if (hipok(hipStreamSynchronize(c->stream), "sync") && (p->kernel_choice != 11 || (rc = sweep_check(p)) == TH_OK) &&
                 hipok(hipMemcpy(out_spec, d_spec, T * g.height * sizeof(float), hipMemcpyDeviceToHost), "download") &&
                 hipok(hipMemcpy(mm, d_mm, sizeof mm, hipMemcpyDeviceToHost), "download minmax")) {
                 if (out_min) *out_min = mm[0];
@@ -1241,6 +1256,7 @@ static int spec_to_img_impl(th_ctx *c, const th_img_desc *descs, size_t n, float
         }
         return TH_OK;
     }
+    c->img_descs_key.clear();   // the tables are about to be overwritten: the key names them only once BOTH uploads succeeded
     int rc = c->img_jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(ImgJob));
     if (rc != TH_OK) return rc;
     rc = c->img_start.upload(c->stream, start.data(), start.size() * sizeof(uint32_t));
@@ -1323,6 +1339,7 @@ TH_API int th_spec_to_img_raster_batch_dev(th_ctx *c, const th_img_tiles_desc *d
             start.insert(start.end(), (size_t)nb, (uint32_t)i);
         }
         if (ptrs.empty()) ptrs.push_back(nullptr);
+        c->fused_key.clear();   // the previous batch's key must not survive a partly failed re-upload of the three tables
         int rc = c->fused_jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(FusedJob));
         if (rc == TH_OK && !start.empty()) rc = c->fused_start.upload(c->stream, start.data(), start.size() * sizeof(uint32_t));
         if (rc == TH_OK) rc = c->fused_ptrs.upload(c->stream, ptrs.data(), ptrs.size() * sizeof(uint8_t *));
@@ -1397,6 +1414,7 @@ TH_API int th_raster_tiles_dev(th_ctx *c, const th_raster_desc *descs, size_t n,
     }
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     TH_HIP(hipSetDevice(c->device));
+    c->raster_descs_key.clear();   // (as above: a failed second upload must not leave the old key on mixed tables)
     int rc = c->raster_jobs.upload(c->stream, jobs.data(), jobs.size() * sizeof(RasterJob));
     if (rc != TH_OK) return rc;
     rc = c->raster_start.upload(c->stream, start.data(), start.size() * sizeof(uint32_t));

@@ -752,7 +752,12 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     auto sweep_chunk = [&](uint64_t slot, uint32_t q, uint32_t idx) -> uint32_t {  // wave-uniform chunk index (>= n_tiles: no more work)
         // (the opener of block q - 1 filled this slot a block's worth of work ago; bounded anyway: a wave that gives up ends)
         for (uint32_t spin = 0; (uint32_t)slot != q; spin++) {
-            if (spin > (1u << 24)) return n_tiles;
+            if (spin > (1u << 24)) {
+                // give up LOUDLY: this chunk stays undone, so the launch must not read as a success — word 1 of the
+                // queue block is the plan's "sweep dropped a chunk" flag, which the host turns into an error (api.hip: sweep_check)
+                if (lane == 0) atomicOr(queue_head + 1, 1u);
+                return n_tiles;
+            }
             __builtin_amdgcn_s_sleep(2);
             slot = *(lds_u64 *)&sw_ring[q % SWEEP_RING];
         }
