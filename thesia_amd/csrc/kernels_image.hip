@@ -5,6 +5,8 @@
 // Both kernels are pure HBM streaming (read 4 B + write 2 B per pixel; read 2 B + write 4 B).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "stft_core.h"
 
@@ -217,9 +219,12 @@ hipError_t launch_spec_to_img(const ImgJob *d_jobs, const uint32_t *d_tile_job, 
 // x / 65535 == (x + 1 + (x >> 16)) >> 16 for every x < 2^32 - 65536 (checked exhaustively), i.e. for every
 // v <= 65535 and n_colors <= 65536 (the host entry points require that): three full-rate operations instead of a
 // quarter-rate 32-bit multiply-high.
+// v <= 65535 and n_colors - 1 <= 65535 fit v_mul_u32_u24 / v_mad_u32_u24 (full rate; the 32-bit v_mul_lo_u32 the plain
+// product compiles to is a quarter-rate instruction).  One colour (or none): n_colors - 1 = 0 gives x = 32767 -> index 0, the
+// reference's `C <= 1 -> 0` (render_tiles.rs:342-343), without a branch in front of every pixel.
 __device__ __forceinline__ uint32_t colour_index(uint32_t v, uint32_t n_colors) {
-    if (n_colors <= 1) return 0u;
-    const uint32_t x = v * (n_colors - 1) + 32767u;
+    const uint32_t cm1 = n_colors > 1u ? n_colors - 1u : 0u;  // launch-uniform: a scalar
+    const uint32_t x = __umul24(v, cm1) + 32767u;
     return (x + 1u + (x >> 16)) >> 16;
 }
 
@@ -415,14 +420,45 @@ hipError_t launch_raster_level0(const RasterJob *d_jobs, const uint32_t *d_block
 //          on the destination's 16-byte grid.
 // The quantiser and the colour index are the very functions the two kernels use: the results are bit-identical to theirs.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t FUSED_PITCH = 536;  // u16 per LDS row: 520 frames + the row padding the last column completes; 1072 B = 8-byte aligned rows
+constexpr uint32_t FUSED_PITCH = 536;  // u16 per LDS row: 1072 B = 268 dwords, 268 mod 32 = 12: the eight rows a wave's ds_write_b64 touches land on eight different bank quads
+constexpr uint32_t FUSED_COL0 = 8;     // LDS column of the tile column's first CORE frame (16-byte aligned); its left gutter sits in columns 4..7
+#if !defined(TH_FUSED_MIN_WAVES)
+#define TH_FUSED_MIN_WAVES (FUSED_THREADS / 64)  // four blocks of 256 threads (two of 512) per CU: at most 128 VGPRs
+#endif
+
+// The quantiser of a REGULAR block (round 5): the function of quantise<true> in 10 instead of 16 operations per pixel.
+//   a   = med3(dB - min_dB, a_lo, a_hi)  clamps the dividend into the range whose ends already quantise to 0 and 65535
+//         (a_hi = 2 span; a_lo = -(min_value / u16_span) span: u(a_lo) = 0 up to rounding, far below the 0.5 that rounds up),
+//         which also takes +-inf and NaN out (v_med3_f32 returns min3 when an operand is NaN: a_lo -> 0, Rust's `NaN as u16`)
+//   z   = a / span                       correctly rounded (reciprocal + one FMA correction, as quantise<true>)
+//   u2  = z * (2 u16_span) + 2 min_value = exactly twice the reference's u (scaling by two commutes with both roundings)
+//   r   = (trunc(u2) + 1) >> 1           = floor(u + 0.5) = round-half-away(u) for u >= 0; u2 > -1 after the clamp, so the
+//                                          conversion needs no saturation; values above 65535 are cut by v_cvt_pk_u16_u32
+// Needs u16_span > 0 (two or more colours) and the reciprocal's verified range: the launch-uniform `fastq` says so.
+__device__ __forceinline__ uint32_t quantise_regular(float dB, float min_dB, float a_lo, float a_hi, float span, float rinv,
+                                                     float u16_span2, float min_value2) {
+    const float a = __builtin_amdgcn_fmed3f(dB - min_dB, a_lo, a_hi);
+    const float q0 = a * rinv;
+    const float e = __builtin_fmaf(-q0, span, a);
+    const float z = __builtin_fmaf(e, rinv, q0);
+    const float u2 = z * u16_span2 + min_value2;  // two roundings, as the reference (contraction is off in this file)
+    return ((uint32_t)u2 + 1u) >> 1;
+}
+__device__ __forceinline__ uint32_t pack_u16_sat(uint32_t lo, uint32_t hi) {  // v_cvt_pk_u16_u32: both halves saturate at 65535
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 p = __builtin_amdgcn_cvt_pk_u16(lo, hi);
+    return __builtin_bit_cast(uint32_t, p);
+}
+
 template <bool LUT_IN_LDS>
-__global__ __launch_bounds__(FUSED_THREADS) void spec_to_img_raster_kernel(
+__global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img_raster_kernel(
     const FusedJob *__restrict__ jobs, const uint32_t *__restrict__ block_job, uint8_t *const *__restrict__ tiles, float min_dB,
     float span, float u16_span, float min_value, const float *__restrict__ d_range, int all_zero_in,
     const uint32_t *__restrict__ colormap, uint32_t n_colors) {
-    constexpr uint32_t FB = FUSED_FB, WAVES = FUSED_THREADS / 64, LPR = FB / 4, FPI = 64 / LPR;
-    constexpr uint32_t NLD = (FUSED_PITCH + FPI * WAVES - 1) / (FPI * WAVES);
+    constexpr uint32_t FB = FUSED_FB, WAVES = FUSED_THREADS / 64, LPR = FB / 4, GPW = 64 / LPR;
+    constexpr uint32_t NIT = 128 / (GPW * WAVES);  // a group = 4 consecutive frames of 4 bins in one lane; 128 groups = the 512 core frames
+    static_assert(128 % (GPW * WAVES) == 0 && 512 % FB == 0 && 64 % LPR == 0, "block shape");
+    constexpr uint32_t PB = FUSED_PITCH * 2;  // LDS row pitch in bytes
     extern __shared__ __attribute__((aligned(16))) uint16_t ftile[];  // [FB][FUSED_PITCH]
     __shared__ uint32_t lut[LUT_IN_LDS ? 1024 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -444,63 +480,158 @@ __global__ __launch_bounds__(FUSED_THREADS) void spec_to_img_raster_kernel(
     const uint32_t local = blockIdx.x - job.first_block;
     const uint32_t band = local % job.n_bands, tx = local / job.n_bands;  // bands of one column are neighbours in the launch
     const uint32_t r0 = band * FB;                                       // first image row of the band (relative to i_start)
+    const uint32_t nrows = min(FB, out_h - r0);                          // image rows of this band (0 for an empty image)
     // level-0 tile column tx (render_tiles.rs:290-313): core 512 frames + 4-frame gutters, clipped at the image
     const uint32_t sx = tx * 512u, core = min(W - sx, 512u), ox = sx > 4u ? sx - 4u : 0u, wt = min(W, sx + core + 4u) - ox;
-    // ---- read + quantise: lane -> bins fl .. fl + 3 of frame ox + FPI (wv + WAVES i) + fr
-    const uint32_t fl = 4u * (lane % LPR), fr = lane / LPR;
-    const uint32_t bin0 = job.i_start + r0 + fl;
-    bool okb[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) okb[k] = bin0 + k < job.height && r0 + fl + k < out_h;
-    // 16-byte loads: aligned base / pitch / first bin (block-uniform).  A lane whose four bins lie past the row's allocation
-    // reads the row's last quad instead — with these alignments its bins are all >= spec_pitch >= height, so they are discarded
-    // anyway — which keeps the loads free of per-lane branches (a branch around a load makes the compiler wait for the previous one)
+    const uint32_t cs = sx - ox;           // 0 or 4: frames of left gutter
+    const uint32_t ct = FUSED_COL0 - cs;   // LDS column of the tile column's first frame `ox`
+    // the band lies inside ONE tile row (512 % FB == 0); its rows within 4 of a core boundary are also a neighbour's gutter
+    const uint32_t ty0 = r0 / 512u, sy = ty0 * 512u, coreh = min(out_h - sy, 512u);
+    const uint32_t oy = sy > 4u ? sy - 4u : 0u, ht = min(out_h, sy + coreh + 4u) - oy;
+    uint8_t *const tb0 = (nrows && job.n_ty) ? tiles[job.tile0 + tx * job.n_ty + ty0] : nullptr;  // scalar load, long before its use
+
+    // ---- read + quantise.  lane -> bins 4 bq .. 4 bq + 3 of the four frames of group g = GPW (wv + WAVES i) + fg
+    const uint32_t bq = lane % LPR, fg = lane / LPR;
     const bool al16 = (reinterpret_cast<uintptr_t>(job.spec) & 15u) == 0 && job.spec_pitch % 4u == 0 && (job.i_start + r0) % 4u == 0 &&
                       job.spec_pitch >= 4u;
-    const uint32_t b16 = min(bin0, job.spec_pitch - 4u);
-    float v[NLD][4];
-    const float qnan = __builtin_nanf("");
+    const bool fastq = !all_zero && rinv != 0.0f && u16_span > 0.0f;
+    // Packed path (block-uniform): 16-byte loads, the reciprocal quantiser, four frames of a bin as one ds_write_b64.
+    // REGULAR block: every core frame and every bin of the band exists — no clamps, no selects.  EDGE block (the last tile
+    // column, the last band, an image shorter than the band): frames clamped into the image, results outside it zeroed.
+    const bool packed = fastq && al16 && job.spec_pitch <= (1u << 24) && nrows > 0;
+    const bool regular = core == 512u && nrows == FB && job.i_start + r0 + FB <= job.height;
+    auto read_packed = [&](auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const float a_hi = span + span, a_lo = -((min_value / u16_span) * span);
+        const float us2 = u16_span + u16_span, mv2 = min_value + min_value;
+        const uint32_t bin0 = job.i_start + r0 + 4u * bq;
+        bool okb[4];
 #pragma unroll
-    for (uint32_t i = 0; i < NLD; i++) {
-        const uint32_t tt = FPI * (wv + WAVES * i) + fr;
-        const gptr<const float> rowp = spec + (size_t)min(ox + tt, W - 1u) * job.spec_pitch;
-        if (al16) {
-            const float4 x = *reinterpret_cast<gptr<const float4>>(rowp + b16);
-            v[i][0] = x.x;
-            v[i][1] = x.y;
-            v[i][2] = x.z;
-            v[i][3] = x.w;
-        } else {
+        for (uint32_t k = 0; k < 4; k++) okb[k] = !EDGE || (bin0 + k < job.height && 4u * bq + k < nrows);
+        // (EDGE: a lane whose bins lie past the row's allocation reads the row's last quad; its bins are all invalid then)
+        const uint32_t b16 = EDGE ? min(bin0, job.spec_pitch - 4u) : bin0;
+        const uint32_t voff = (4u * fg) * job.spec_pitch + (b16 - (job.i_start + r0));  // elements; 28 * pitch * 4 B < 2^31
+        const gptr<const float> b0 = spec + (size_t)sx * job.spec_pitch + (job.i_start + r0);
+        float4 v[NIT][4];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) v[i][k] = rowp[min(bin0 + k, max(job.height, 1u) - 1u)];
+        for (uint32_t i = 0; i < NIT; i++)
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t f = 4u * GPW * (wv + WAVES * i) + q;  // frame - sx - 4 fg (wave-uniform)
+                if constexpr (!EDGE) {
+                    const gptr<const float> rowp = b0 + (size_t)f * job.spec_pitch;  // scalar
+                    v[i][q] = *reinterpret_cast<gptr<const float4>>(rowp + voff);
+                } else {
+                    const uint32_t fc = min(sx + f + 4u * fg, W - 1u);
+                    v[i][q] = *reinterpret_cast<gptr<const float4>>(spec + ((size_t)fc * job.spec_pitch + b16));
+                }
+            }
+        // the eight gutter frames x FB bins: one 4-byte load per thread (a gutter the tile column does not have is never read
+        // back: its address is clamped into the image and whatever it quantises to stays in LDS unused)
+        constexpr uint32_t NGV = (8 * FB + FUSED_THREADS - 1) / FUSED_THREADS;
+        float gv[NGV];
+#pragma unroll
+        for (uint32_t e = 0; e < NGV; e++) {
+            const uint32_t id = tid + FUSED_THREADS * e, g = id / FB, bin = id % FB;
+            const uint32_t fr = g < 4u ? (sx >= 4u ? sx - 4u + g : 0u) : min(sx + 508u + g, W - 1u);
+            const uint32_t bn = EDGE ? min(job.i_start + r0 + bin, job.height - 1u) : job.i_start + r0 + bin;
+            gv[e] = (8 * FB % FUSED_THREADS == 0 || id < 8 * FB) ? spec[(size_t)fr * job.spec_pitch + bn] : 0.0f;
         }
-    }
-    // the three cases are launch-uniform: one specialised loop each instead of a branch per element (as spec_to_img_kernel)
-    // (NaN -> 0: rows >= H and columns past the image are zero; columns >= wt are the row padding the last tile column writes)
+        const uint32_t wbase = (4u * bq) * PB + 2u * (FUSED_COL0 + 4u * (GPW * wv + fg));  // LDS byte address of (row 4 bq, group of i = 0)
+#pragma unroll
+        for (uint32_t i = 0; i < NIT; i++) {
+            uint32_t u[4][4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                u[q][0] = quantise_regular(v[i][q].x, min_dB, a_lo, a_hi, span, rinv, us2, mv2);
+                u[q][1] = quantise_regular(v[i][q].y, min_dB, a_lo, a_hi, span, rinv, us2, mv2);
+                u[q][2] = quantise_regular(v[i][q].z, min_dB, a_lo, a_hi, span, rinv, us2, mv2);
+                u[q][3] = quantise_regular(v[i][q].w, min_dB, a_lo, a_hi, span, rinv, us2, mv2);
+                if constexpr (EDGE) {  // frames past the image and bins past the spec are zero (drawing.rs:24-31, the row padding)
+                    const bool okf = sx + 4u * GPW * (wv + WAVES * i) + q + 4u * fg < W;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) u[q][k] = (okf && okb[k]) ? u[q][k] : 0u;
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++)
+                *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(ftile) + wbase + k * PB + 8u * GPW * WAVES * i) =
+                    make_uint2(pack_u16_sat(u[0][k], u[1][k]), pack_u16_sat(u[2][k], u[3][k]));
+        }
+#pragma unroll
+        for (uint32_t e = 0; e < NGV; e++) {
+            const uint32_t id = tid + FUSED_THREADS * e, g = id / FB, bin = id % FB;
+            if (8 * FB % FUSED_THREADS == 0 || id < 8 * FB) {
+                uint32_t uq = min(quantise_regular(gv[e], min_dB, a_lo, a_hi, span, rinv, us2, mv2), 65535u);
+                if (EDGE && job.i_start + r0 + bin >= job.height) uq = 0u;
+                ftile[bin * FUSED_PITCH + (g < 4u ? 4u + g : FUSED_COL0 + 508u + g)] = (uint16_t)uq;
+            }
+        }
+    };
+    if (packed && regular) {
+        read_packed(std::false_type{});
+    } else if (packed) {
+        read_packed(std::true_type{});
+    } else {
+        // ---- anything else (odd pitches / bases, slow division, one colour, the zero image): element-wise — frame
+        // ox + tt -> LDS column ct + tt, lane -> bins fl .. fl + 3 of frame ox + FPI (wv + WAVES i) + fr, element-wise ds_write_b16
+        constexpr uint32_t FPI = GPW, NLD = (FUSED_PITCH + FPI * WAVES - 1) / (FPI * WAVES);
+        const uint32_t fl = 4u * bq, fr = fg;
+        const uint32_t bin0 = job.i_start + r0 + fl;
+        bool okb[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) okb[k] = bin0 + k < job.height && r0 + fl + k < out_h;
+        // 16-byte loads: aligned base / pitch / first bin (block-uniform).  A lane whose four bins lie past the row's allocation
+        // reads the row's last quad instead — with these alignments its bins are all >= spec_pitch >= height, so they are discarded
+        // anyway — which keeps the loads free of per-lane branches (a branch around a load makes the compiler wait for the previous one)
+        const uint32_t b16 = min(bin0, job.spec_pitch - 4u);
+        const float qnan = __builtin_nanf("");
+        // (in rounds of four loads: this path is rare, keep its registers below the regular path's)
+#pragma unroll 1
+        for (uint32_t i0 = 0; i0 < NLD; i0 += 4) {
+            float v[4][4];
+#pragma unroll
+            for (uint32_t ii = 0; ii < 4; ii++) {
+                const uint32_t tt = FPI * (wv + WAVES * (i0 + ii)) + fr;
+                const gptr<const float> rowp = spec + (size_t)min(ox + tt, W - 1u) * job.spec_pitch;
+                if (al16) {
+                    const float4 x = *reinterpret_cast<gptr<const float4>>(rowp + b16);
+                    v[ii][0] = x.x;
+                    v[ii][1] = x.y;
+                    v[ii][2] = x.z;
+                    v[ii][3] = x.w;
+                } else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) v[ii][k] = rowp[min(bin0 + k, max(job.height, 1u) - 1u)];
+                }
+            }
+            // the three cases are launch-uniform: one specialised loop each instead of a branch per element (as spec_to_img_kernel)
+            // (NaN -> 0: rows >= H and columns past the image are zero; columns >= wt are the row padding the last tile column writes)
 #define TH_FUSED_QUANT(EXPR)                                                                             \
-    _Pragma("unroll") for (uint32_t i = 0; i < NLD; i++) {                                               \
-        const uint32_t tt = FPI * (wv + WAVES * i) + fr;                                                 \
-        if (tt < FUSED_PITCH) {                                                                          \
+    _Pragma("unroll") for (uint32_t ii = 0; ii < 4; ii++) {                                              \
+        const uint32_t tt = FPI * (wv + WAVES * (i0 + ii)) + fr;                                         \
+        if (ct + tt < FUSED_PITCH) {                                                                     \
             const bool okt = tt < wt;                                                                    \
             _Pragma("unroll") for (uint32_t k = 0; k < 4; k++) {                                         \
-                const float x = (okt && okb[k]) ? v[i][k] : qnan;                                        \
+                const float x = (okt && okb[k]) ? v[ii][k] : qnan;                                       \
                 (void)x;                                                                                 \
-                ftile[(fl + k) * FUSED_PITCH + tt] = (uint16_t)(EXPR);                                   \
+                ftile[(fl + k) * FUSED_PITCH + ct + tt] = (uint16_t)(EXPR);                              \
             }                                                                                            \
         }                                                                                                \
     }
-    if (all_zero) {
-        TH_FUSED_QUANT(0u)
-    } else if (rinv != 0.0f) {
-        TH_FUSED_QUANT(quantise<true>(x, min_dB, span, rinv, u16_span, min_value))
-    } else {
-        TH_FUSED_QUANT(quantise<false>(x, min_dB, span, rinv, u16_span, min_value))
-    }
+            if (all_zero) {
+                TH_FUSED_QUANT(0u)
+            } else if (rinv != 0.0f) {
+                TH_FUSED_QUANT(quantise<true>(x, min_dB, span, rinv, u16_span, min_value))
+            } else {
+                TH_FUSED_QUANT(quantise<false>(x, min_dB, span, rinv, u16_span, min_value))
+            }
 #undef TH_FUSED_QUANT
+        }
+    }
     __syncthreads();
     // ---- u16 image rows: the column's core frames [sx, sx + core) (+ the row padding in the last column), 8 px per lane
     const gptr<uint16_t> img = as_global(job.img);
-    const uint32_t cs = sx - ox;  // 0 or 4
     // rows at the library's padded pitch own their padding (see spec_to_img_kernel): complete the last 128-byte line
     const uint32_t t_lim = (job.img_pitch % IMG_TILE_T == 0 && job.img_pitch - W < IMG_TILE_T) ? job.img_pitch : W;
     const uint32_t c_lim = min(t_lim - sx, 512u);  // columns of this tile column to write (the last column: up to the pitch)
@@ -508,12 +639,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void spec_to_img_raster_kernel(
 #pragma unroll
     for (uint32_t i = 0; i < (FB + WAVES - 1) / WAVES; i++) {
         const uint32_t r = wv + WAVES * i, c = 8u * lane;
-        if (r < FB && r0 + r < out_h && c < c_lim) {
-            const uint16_t *src = &ftile[r * FUSED_PITCH + cs + c];
+        if (r < nrows && c < c_lim) {
+            const uint16_t *src = &ftile[r * FUSED_PITCH + FUSED_COL0 + c];  // 16-byte aligned
             const gptr<uint16_t> dst = img + (size_t)(r0 + r) * job.img_pitch + sx + c;
             if (img_al && c + 8u <= c_lim) {
-                const uint2 a = *reinterpret_cast<const uint2 *>(src), b = *reinterpret_cast<const uint2 *>(src + 4);
-                *reinterpret_cast<gptr<uint4>>(dst) = make_uint4(a.x, a.y, b.x, b.y);
+                *reinterpret_cast<gptr<uint4>>(dst) = *reinterpret_cast<const uint4 *>(src);
             } else {
                 for (uint32_t k = 0; k < 8u && c + k < c_lim; k++) dst[k] = src[k];
             }
@@ -525,24 +655,71 @@ __global__ __launch_bounds__(FUSED_THREADS) void spec_to_img_raster_kernel(
         if constexpr (LUT_IN_LDS) return lut[ci];
         else return as_global(colormap)[ci];
     };
+    // The band's rows in its OWN tile are one contiguous piece of that tile (rows oy + ht - 1 - r_img, descending with r_img):
+    // when the rows are whole quads (wt % 4 == 0, 16-byte aligned tile) the piece is written front to back, 16 bytes per lane,
+    // a wave-instruction = 1 KiB of consecutive addresses whatever the row length (round 4 went row by row: three
+    // wave-instructions per 2080-byte row, the third with two lanes)
+    const bool flat = tb0 != nullptr && wt % 4u == 0 && (reinterpret_cast<uintptr_t>(tb0) & 15u) == 0 && nrows > 0;
+    if (flat) {
+        const uint32_t qpr = wt >> 2, nq = nrows * qpr;
+        const uint32_t r_top = oy + ht - 1u - (r0 + nrows - 1u);  // tile row of the band's LAST image row = the piece's first row
+        const gptr<uint4> dst = reinterpret_cast<gptr<uint4>>(as_global(reinterpret_cast<uint32_t *>(tb0)) + (size_t)r_top * wt);
+        const uint32_t dj = FUSED_THREADS / qpr, dc = FUSED_THREADS % qpr;  // block-uniform
+        uint32_t j = tid / qpr, c = tid - j * qpr;                          // quad q = tid + THREADS m -> (piece row j, quad c of the row)
+        // LDS byte address of the quad: image row (nrows - 1 - j), column ct + 4 c
+        uint32_t la = (nrows - 1u - j) * PB + 2u * ct + 8u * c;
+        const uint32_t dla = 8u * dc - dj * PB;  // (mod 2^32)
+        // rounds of four quads per lane: the four u16 quads are requested together, then the sixteen LUT entries, then the four
+        // 16-byte stores — two LDS latencies per round instead of eight
+        constexpr uint32_t NQI = (FB * 130u + FUSED_THREADS - 1u) / FUSED_THREADS;
+#pragma unroll 1
+        for (uint32_t m0 = 0; m0 < NQI; m0 += 4) {
+            if (m0 * FUSED_THREADS >= nq) break;  // block-uniform
+            uint2 w[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const bool ok = tid + (m0 + u) * FUSED_THREADS < nq;
+                w[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(ftile) + (ok ? la : 0u));
+                c += dc;
+                la += dla;
+                if (c >= qpr) {
+                    c -= qpr;
+                    la -= 8u * qpr + PB;
+                }
+            }
+            uint4 o[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                o[u] = make_uint4(look(w[u].x & 0xffffu), look(w[u].x >> 16), look(w[u].y & 0xffffu), look(w[u].y >> 16));
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t q = tid + (m0 + u) * FUSED_THREADS;
+                if (q < nq) dst[q] = o[u];
+            }
+        }
+    }
+    // rows that are ALSO a neighbour's gutter (the first / last 4 rows of a tile row's core), and the own tile where the flat
+    // form does not apply (odd widths: the last tile column): row by row
+    const bool lo_nb = ty0 > 0u && r0 - sy < 4u, hi_nb = ty0 + 1u < job.n_ty && r0 + FB + 4u > sy + 512u;
+    if ((flat && !lo_nb && !hi_nb) || nrows == 0) return;
 #pragma unroll 1
     for (uint32_t i = 0; i < (FB + WAVES - 1) / WAVES; i++) {
         const uint32_t r = wv + WAVES * i, r_img = r0 + r;
-        if (r >= FB || r_img >= out_h) continue;  // wave-uniform
-        const uint32_t ty0 = r_img / 512u;
-#pragma unroll
+        if (r >= nrows) continue;  // wave-uniform
+#pragma unroll 1
         for (int dty = -1; dty <= 1; dty++) {
+            if (dty == 0 && flat) continue;
             const int tyi = (int)ty0 + dty;
             if (tyi < 0 || (uint32_t)tyi >= job.n_ty) continue;
-            const uint32_t ty = (uint32_t)tyi, sy = ty * 512u, coreh = min(out_h - sy, 512u);
-            const uint32_t oy = sy > 4u ? sy - 4u : 0u, ht = min(out_h, sy + coreh + 4u) - oy;
-            if (r_img < oy || r_img >= oy + ht) continue;
+            const uint32_t ty = (uint32_t)tyi, sy2 = ty * 512u, coreh2 = min(out_h - sy2, 512u);
+            const uint32_t oy2 = sy2 > 4u ? sy2 - 4u : 0u, ht2 = min(out_h, sy2 + coreh2 + 4u) - oy2;
+            if (r_img < oy2 || r_img >= oy2 + ht2) continue;
             uint8_t *const tbase = tiles[job.tile0 + tx * job.n_ty + ty];  // scalar load
             if (tbase == nullptr) continue;
-            const gptr<uint32_t> dst = as_global(reinterpret_cast<uint32_t *>(tbase)) + (size_t)(oy + ht - 1u - r_img) * wt;
-            const uint16_t *const srow = &ftile[r * FUSED_PITCH];
+            const gptr<uint32_t> dst = as_global(reinterpret_cast<uint32_t *>(tbase)) + (size_t)(oy2 + ht2 - 1u - r_img) * wt;
+            const uint16_t *const srow = &ftile[r * FUSED_PITCH + ct];
             // 16-byte stores on the destination's 16-byte grid (rows of odd widths start 4 / 8 / 12 bytes off it)
-            const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(tbase) / 4u + (size_t)(oy + ht - 1u - r_img) * wt) & 3u;
+            const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(tbase) / 4u + (size_t)(oy2 + ht2 - 1u - r_img) * wt) & 3u;
 #pragma unroll
             for (uint32_t k = 0; k < 3; k++) {  // wt <= 520: at most 131 quads (+ 1 for a shifted grid)
                 const int32_t c = (int32_t)(4u * (lane + 64u * k)) - (int32_t)mis;
