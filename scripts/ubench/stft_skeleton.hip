@@ -24,7 +24,14 @@ using gf4 = __attribute__((address_space(1))) v4f;
 #if !defined(CHUNK_FRAMES)
 #define CHUNK_FRAMES 32
 #endif
+// -DNYQ_PLANE (round 5, VERDICT r4 #5a): rows of exactly 4096 bytes (bins 0 .. 1023, no padding, no partial line) and the
+// Nyquist bins of a channel in a plane of their own behind the rows — a wave keeps the bin of each frame of its chunk in one
+// lane and stores them together at the end of the chunk
+#if defined(NYQ_PLANE)
+constexpr uint32_t N_FFT = 2048, HOP = 512, H = 1025, PITCH = 1024, CHUNK = CHUNK_FRAMES;
+#else
 constexpr uint32_t N_FFT = 2048, HOP = 512, H = 1025, PITCH = 1056, CHUNK = CHUNK_FRAMES;
+#endif
 
 template <int LOADM, int STOREM, int FMA, int LDSR, int WAVES, int LDSM = 0>
 __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_, uint32_t n_chan, uint32_t n_samples,
@@ -55,6 +62,10 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_,
         const uint32_t f1 = min(f0 + CHUNK, T - 2);
         const gf *wav = (const gf *)(wav_ + (size_t)ch * n_samples);
         gf *spec = (gf *)(spec_ + (size_t)ch * T * PITCH);
+#if defined(NYQ_PLANE)
+        gf *plane = (gf *)(spec_ + (size_t)n_chan * T * PITCH + (size_t)ch * T);
+        float nyq = 0.f;
+#endif
         v2f x[16];
         float acc[16];
 #pragma unroll
@@ -223,10 +234,18 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_,
             if (STOREM == 1) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) row[lane + 64 * j] = acc[j];
+#if defined(NYQ_PLANE)
+                if (lane) row[1024 - lane] = acc[8];
+#pragma unroll
+                for (int j = 1; j < 8; j++) row[1024 - lane - 64 * j] = acc[8 + j];
+                if (lane == 0) row[512] = acc[0];
+                nyq = lane == f - f0 ? __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[8])) * 1.0f : nyq;
+#else
 #pragma unroll
                 for (int j = 0; j < 8; j++) row[1024 - lane - 64 * j] = acc[8 + j];
                 if (lane == 0) row[512] = acc[0];
                 if (lane - 1u < 31u) row[1024 + lane] = 0.f;
+#endif
             } else if (STOREM == 4 || STOREM == 5) {
                 // adjacent-bin pairs: A side 4 aligned 8-byte stores (bins 2 l + 256 s, + 1); B side the mirrored pairs
                 // (bins 1023 - 2 l - 256 s, + 1): 4 misaligned 8-byte stores (mode 4) or 8 dword stores (mode 5)
@@ -262,6 +281,9 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float *wav_, float *spec_,
                 if (s == 12345.678f) row[lane] = s;
             }
         }
+#if defined(NYQ_PLANE)
+        if (STOREM == 1 && lane < f1 - f0) plane[f0 + lane] = nyq;
+#endif
     }
 }
 
@@ -529,7 +551,7 @@ int main(int argc, char **argv) {
     float *wav, *spec;
     uint32_t *q;
     hipMalloc(&wav, (size_t)n_chan * n_samples * 4);
-    hipMalloc(&spec, (size_t)n_chan * T * PITCH * 4);
+    hipMalloc(&spec, (size_t)n_chan * T * (PITCH + 1) * 4);  // (+ 1: the Nyquist plane of the NYQ_PLANE build)
     hipMalloc(&q, 4);
     {   // pseudo-random input (bit toggling matters on a power-limited part)
         std::vector<float> h((size_t)n_samples);
@@ -552,6 +574,15 @@ int main(int argc, char **argv) {
         return 0;
     }
     printf("# gap between launches: %d us\n", gap_us);
+    if (argc > 2 && atoi(argv[2]) == 10) {  // row layout A/B (build with and without -DNYQ_PLANE): stores alone, skeleton, with the kernel's work
+        printf("# rows at pitch %u floats%s\n", PITCH, PITCH == 1024 ? " + Nyquist plane" : "");
+        for (int rep = 0; rep < 3; rep++) {
+            R(0, 1, 0, 0, 12, 2);
+            R(3, 1, 0, 0, 12, 2);
+            R(3, 1, 42, 2, 12, 2);
+        }
+        return 0;
+    }
     if (argc > 2 && atoi(argv[2]) == 9) {
         // power probe (scripts/power_probe.sh): argv[3] = 0: the kernel's own schedule, 1: the sweep schedule, both with the kernel's
         // amount of stand-in work, back to back for about ten seconds

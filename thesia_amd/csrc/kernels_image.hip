@@ -426,23 +426,27 @@ constexpr uint32_t FUSED_COL0 = 8;     // LDS column of the tile column's first 
 #define TH_FUSED_MIN_WAVES (FUSED_THREADS / 64)  // four blocks of 256 threads (two of 512) per CU: at most 128 VGPRs
 #endif
 
-// The quantiser of a REGULAR block (round 5): the function of quantise<true> in 10 instead of 16 operations per pixel.
-//   a   = med3(dB - min_dB, a_lo, a_hi)  clamps the dividend into the range whose ends already quantise to 0 and 65535
-//         (a_hi = 2 span; a_lo = -(min_value / u16_span) span: u(a_lo) = 0 up to rounding, far below the 0.5 that rounds up),
-//         which also takes +-inf and NaN out (v_med3_f32 returns min3 when an operand is NaN: a_lo -> 0, Rust's `NaN as u16`)
-//   z   = a / span                       correctly rounded (reciprocal + one FMA correction, as quantise<true>)
-//   u2  = z * (2 u16_span) + 2 min_value = exactly twice the reference's u (scaling by two commutes with both roundings)
-//   r   = (trunc(u2) + 1) >> 1           = floor(u + 0.5) = round-half-away(u) for u >= 0; u2 > -1 after the clamp, so the
-//                                          conversion needs no saturation; values above 65535 are cut by v_cvt_pk_u16_u32
+// The quantiser of the packed path (round 5): the function of quantise<true> in 8 instead of 16 operations per pixel.
+//   a = med3(dB - min_dB, a_lo, a_hi)  clamps the dividend into the range whose ends already quantise to 0 and 65535
+//       (a_hi = 2 span; a_lo = -(min_value / u16_span) span: u(a_lo) = 0 up to rounding, far below the 0.5 that rounds up),
+//       which also takes +-inf and NaN out (v_med3_f32 returns min3 when an operand is NaN: a_lo -> 0, Rust's `NaN as u16`)
+//   z = a / span                       correctly rounded (reciprocal + one FMA correction, as quantise<true>)
+//   u = z * u16_span + min_value       two roundings, as the reference (contraction is off in this file)
+//   r = v_cvt_rpi_i32_f32(u)           floor(u + 0.5) evaluated exactly = f32::round for u >= 0 — checked against
+//                                      trunc + (frac >= 0.5) for every f32 in [0, 2^18) on gfx950 (scripts/ubench/rpi_probe.hip:
+//                                      0 mismatches, 0.5 - 2^-25 included, where an f32 `u + 0.5` would round up to 1);
+//                                      u > -0.5 after the clamp (-> 0); values above 65535 are cut by v_cvt_pk_u16_u32
 // Needs u16_span > 0 (two or more colours) and the reciprocal's verified range: the launch-uniform `fastq` says so.
 __device__ __forceinline__ uint32_t quantise_regular(float dB, float min_dB, float a_lo, float a_hi, float span, float rinv,
-                                                     float u16_span2, float min_value2) {
+                                                     float u16_span, float min_value) {
     const float a = __builtin_amdgcn_fmed3f(dB - min_dB, a_lo, a_hi);
     const float q0 = a * rinv;
     const float e = __builtin_fmaf(-q0, span, a);
     const float z = __builtin_fmaf(e, rinv, q0);
-    const float u2 = z * u16_span2 + min_value2;  // two roundings, as the reference (contraction is off in this file)
-    return ((uint32_t)u2 + 1u) >> 1;
+    const float u = z * u16_span + min_value;
+    uint32_t r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(u));
+    return r;
 }
 __device__ __forceinline__ uint32_t pack_u16_sat(uint32_t lo, uint32_t hi) {  // v_cvt_pk_u16_u32: both halves saturate at 65535
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -463,8 +467,25 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
     __shared__ uint32_t lut[LUT_IN_LDS ? 1024 : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if constexpr (LUT_IN_LDS)
-        for (uint32_t i = tid; i < n_colors; i += FUSED_THREADS) lut[i] = colormap[i];
+    // (the block's first memory request is its job — two dependent scalar loads; the colour table is requested BEHIND the spec
+    // loads and stored to LDS in front of the barrier: filled first, as in round 4, every block began with a memory round trip
+    // of its own before it asked for anything else)
+    const FusedJob job = jobs[block_job[blockIdx.x]];
+    constexpr uint32_t NLUT = LUT_IN_LDS ? 1024 / FUSED_THREADS : 1;
+    uint32_t lutv[NLUT];
+    auto lut_request = [&]() {
+        if constexpr (LUT_IN_LDS) {
+#pragma unroll
+            for (uint32_t i = 0; i < NLUT; i++) lutv[i] = as_global(colormap)[min(tid + FUSED_THREADS * i, n_colors - 1u)];
+        }
+    };
+    auto lut_store = [&]() {
+        if constexpr (LUT_IN_LDS) {
+#pragma unroll
+            for (uint32_t i = 0; i < NLUT; i++)
+                if (tid + FUSED_THREADS * i < n_colors) lut[tid + FUSED_THREADS * i] = lutv[i];
+        }
+    };
     bool all_zero = all_zero_in != 0;
     float rinv = quantise_rinv(span);
     if (d_range != nullptr) {
@@ -474,7 +495,6 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
         rinv = quantise_rinv(span);
         all_zero = lo == hi && __builtin_isinf(hi) && hi < 0.0f;  // every value -inf: zero image (drawing.rs:16-18)
     }
-    const FusedJob job = jobs[block_job[blockIdx.x]];
     const gptr<const float> spec = as_global(job.spec);
     const uint32_t out_h = job.i_end - job.i_start, W = job.n_frames;
     const uint32_t local = blockIdx.x - job.first_block;
@@ -503,7 +523,7 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
     auto read_packed = [&](auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         const float a_hi = span + span, a_lo = -((min_value / u16_span) * span);
-        const float us2 = u16_span + u16_span, mv2 = min_value + min_value;
+        const float us2 = u16_span, mv2 = min_value;
         const uint32_t bin0 = job.i_start + r0 + 4u * bq;
         bool okb[4];
 #pragma unroll
@@ -520,6 +540,10 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
                 const uint32_t f = 4u * GPW * (wv + WAVES * i) + q;  // frame - sx - 4 fg (wave-uniform)
                 if constexpr (!EDGE) {
                     const gptr<const float> rowp = b0 + (size_t)f * job.spec_pitch;  // scalar
+#if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 1)  // ablation build: no spec reads
+                    v[i][q] = make_float4(-1.0f * (float)lane, -2.0f * f, -3.0f, -4.0f * fg);
+                    if (min_dB == 12345.0f)
+#endif
                     v[i][q] = *reinterpret_cast<gptr<const float4>>(rowp + voff);
                 } else {
                     const uint32_t fc = min(sx + f + 4u * fg, W - 1u);
@@ -537,6 +561,7 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
             const uint32_t bn = EDGE ? min(job.i_start + r0 + bin, job.height - 1u) : job.i_start + r0 + bin;
             gv[e] = (8 * FB % FUSED_THREADS == 0 || id < 8 * FB) ? spec[(size_t)fr * job.spec_pitch + bn] : 0.0f;
         }
+        lut_request();
         const uint32_t wbase = (4u * bq) * PB + 2u * (FUSED_COL0 + 4u * (GPW * wv + fg));  // LDS byte address of (row 4 bq, group of i = 0)
 #pragma unroll
         for (uint32_t i = 0; i < NIT; i++) {
@@ -567,6 +592,7 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
                 ftile[bin * FUSED_PITCH + (g < 4u ? 4u + g : FUSED_COL0 + 508u + g)] = (uint16_t)uq;
             }
         }
+        lut_store();
     };
     if (packed && regular) {
         read_packed(std::false_type{});
@@ -586,6 +612,8 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
         // anyway — which keeps the loads free of per-lane branches (a branch around a load makes the compiler wait for the previous one)
         const uint32_t b16 = min(bin0, job.spec_pitch - 4u);
         const float qnan = __builtin_nanf("");
+        lut_request();
+        lut_store();
         // (in rounds of four loads: this path is rare, keep its registers below the regular path's)
 #pragma unroll 1
         for (uint32_t i0 = 0; i0 < NLD; i0 += 4) {
@@ -643,6 +671,9 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
             const uint16_t *src = &ftile[r * FUSED_PITCH + FUSED_COL0 + c];  // 16-byte aligned
             const gptr<uint16_t> dst = img + (size_t)(r0 + r) * job.img_pitch + sx + c;
             if (img_al && c + 8u <= c_lim) {
+#if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 2)  // ablation build: no u16 image stores
+                if (reinterpret_cast<const uint4 *>(src)->x == 0x12345678u)
+#endif
                 *reinterpret_cast<gptr<uint4>>(dst) = *reinterpret_cast<const uint4 *>(src);
             } else {
                 for (uint32_t k = 0; k < 8u && c + k < c_lim; k++) dst[k] = src[k];
@@ -659,27 +690,35 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
     // when the rows are whole quads (wt % 4 == 0, 16-byte aligned tile) the piece is written front to back, 16 bytes per lane,
     // a wave-instruction = 1 KiB of consecutive addresses whatever the row length (round 4 went row by row: three
     // wave-instructions per 2080-byte row, the third with two lanes)
-    const bool flat = tb0 != nullptr && wt % 4u == 0 && (reinterpret_cast<uintptr_t>(tb0) & 15u) == 0 && nrows > 0;
+    // (wt >= 32: at least eight quads per row, so that a lane's "quad before the piece" lies in the one row before it)
+    const bool flat = tb0 != nullptr && wt % 4u == 0 && wt >= 32u && (reinterpret_cast<uintptr_t>(tb0) & 15u) == 0 && nrows > 0;
     if (flat) {
         const uint32_t qpr = wt >> 2, nq = nrows * qpr;
         const uint32_t r_top = oy + ht - 1u - (r0 + nrows - 1u);  // tile row of the band's LAST image row = the piece's first row
         const gptr<uint4> dst = reinterpret_cast<gptr<uint4>>(as_global(reinterpret_cast<uint32_t *>(tb0)) + (size_t)r_top * wt);
         const uint32_t dj = FUSED_THREADS / qpr, dc = FUSED_THREADS % qpr;  // block-uniform
-        uint32_t j = tid / qpr, c = tid - j * qpr;                          // quad q = tid + THREADS m -> (piece row j, quad c of the row)
+        // The piece starts wherever its first row starts: at a multiple of 16 bytes, k quads into a 128-byte line.  Quads are
+        // dealt to the lanes in LINE-ALIGNED order — lane t of round m takes quad qa - k of the piece, qa = t + THREADS m —
+        // so that a wave-instruction writes eight whole lines (round 5: dealt from the piece's first quad, every 1 KiB store
+        // straddled nine lines and every line boundary was written by two different waves)
+        const uint32_t k = (uint32_t)(reinterpret_cast<uintptr_t>(tb0) / 16u + (size_t)r_top * qpr) & 7u;
+        const int32_t q0 = (int32_t)tid - (int32_t)k;                       // first quad of this lane (negative: none in round 0)
+        uint32_t j = q0 >= 0 ? (uint32_t)q0 / qpr : 0xffffffffu;            // piece row; -1 = "the row before the piece" (mod 2^32)
+        uint32_t c = q0 >= 0 ? (uint32_t)q0 - j * qpr : (uint32_t)(q0 + (int32_t)qpr);  // quad of the row
         // LDS byte address of the quad: image row (nrows - 1 - j), column ct + 4 c
         uint32_t la = (nrows - 1u - j) * PB + 2u * ct + 8u * c;
         const uint32_t dla = 8u * dc - dj * PB;  // (mod 2^32)
         // rounds of four quads per lane: the four u16 quads are requested together, then the sixteen LUT entries, then the four
         // 16-byte stores — two LDS latencies per round instead of eight
-        constexpr uint32_t NQI = (FB * 130u + FUSED_THREADS - 1u) / FUSED_THREADS;
+        constexpr uint32_t NQI = (FB * 130u + 7u + FUSED_THREADS - 1u) / FUSED_THREADS;
 #pragma unroll 1
         for (uint32_t m0 = 0; m0 < NQI; m0 += 4) {
-            if (m0 * FUSED_THREADS >= nq) break;  // block-uniform
+            if (m0 * FUSED_THREADS >= nq + k) break;  // block-uniform
             uint2 w[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
-                const bool ok = tid + (m0 + u) * FUSED_THREADS < nq;
-                w[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(ftile) + (ok ? la : 0u));
+                const uint32_t q = tid + (m0 + u) * FUSED_THREADS - k;  // (mod 2^32: a negative quad is >= nq)
+                w[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(ftile) + (q < nq ? la : 0u));
                 c += dc;
                 la += dla;
                 if (c >= qpr) {
@@ -693,7 +732,10 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
                 o[u] = make_uint4(look(w[u].x & 0xffffu), look(w[u].x >> 16), look(w[u].y & 0xffffu), look(w[u].y >> 16));
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t q = tid + (m0 + u) * FUSED_THREADS;
+                const uint32_t q = tid + (m0 + u) * FUSED_THREADS - k;
+#if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 4)  // ablation build: no RGBA stores
+                if (o[u].x == 0x12345678u && o[u].y == 0x9abcdef0u)
+#endif
                 if (q < nq) dst[q] = o[u];
             }
         }
