@@ -165,22 +165,6 @@ TH_API int th_plan_create(th_ctx *ctx, uint32_t sr, size_t win, size_t hop, size
 TH_API int th_plan_destroy(th_plan *plan);
 /* n_freq = n_fft/2+1; height = n_freq (linear) or n_mel (mel) = columns of the spec */
 TH_API int th_plan_dims(const th_plan *plan, size_t *n_freq, size_t *height);
-/* kernel selection: 0 = auto, 1 = force the generic workgroup kernel, 2 = force the wave kernel, 3 = wave kernel with
- * the matrix-core mel kernel instead of the fused mel epilogue (mel plans; same as 2 for linear ones), 4 = wave kernel
- * without the grid-aligned register reuse of hop = 480 / 441-style framings, 5 = that reuse also with the fused mel
- * epilogue (both for A/B measurements: it does not pay there), 6 = n_fft 1024 on the two-frames-per-wave plan instead of the
- * one-frame plan (A/B; other sizes: as 2; a wave count in the tuning form below is validated against that plan's launch
- * shapes: 8, 12 or 16), 7 = as 3 with the matrix-core kernel also where 3 runs the
- * banded-sum kernel over the amplitude rows (n_fft 512 under filters of at most 8 bins: the default mel counts of 8-12 kHz audio),
- * 8 = the fused mel epilogue in its pieces / gather form where banded sums are the default (A/B),
- * 9 = the wave kernel's packed-f32 pipeline (v_pk_fma_f32 butterflies on register pairs) where it is instantiated: n_fft 2048,
- * hop = n_fft / 4, linear dB, default waves (A/B: it measures the same as the scalar pipeline; elsewhere as 2),
- * 11 = the wave kernel with the "sweep" chunk schedule (4-frame chunks dealt out in order through a per-workgroup ticket
- * counter, the next chunk's first frame prefetched) on large batches of that same shape (A/B: a faster memory skeleton, the
- * same launch time; elsewhere as 2; 10 is reserved and behaves as 2);
- * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
- * frames per queue pull */
-TH_API int th_plan_set_kernel(th_plan *plan, int which);
 /* find_min_max over every resident spec (core/mod.rs:169-178) without leaving the device: reduces the n_chan
  * (min, max) pairs a th_calc_spec_batch_dev left in d_minmax to d_out = [min, -max] (2 floats, DEVICE), the form
  * in which ONE element-wise MIN all-reduce merges the ranks of a multi-GPU job.  n_chan = 0 gives [+inf, +inf]. */
@@ -193,14 +177,6 @@ TH_API int th_global_db_range_dev(th_ctx *ctx, const float *d_min_negmax, float 
  * d_min_negmax (may be NULL) additionally receives [min, -max]. */
 TH_API int th_minmax_reduce_range_dev(th_ctx *ctx, const float *d_minmax, size_t n_chan, float dB_range,
                                       float *d_min_negmax, float *d_range);
-/* Measurement hook: with enable != 0 every th_calc_spec_batch_dev records two HIP events on the context's stream
- * around its dominant kernel launch (the wave kernel, or the generic one when that is all there is);
- * recording does not synchronise.  th_plan_kernel_ms_history returns the durations of the most recent launches
- * (oldest first, at most 64 are kept; it waits for them), th_plan_last_kernel_ms the latest one.
- * th_plan_time_kernel also resets the history. */
-TH_API int th_plan_time_kernel(th_plan *plan, int enable);
-TH_API int th_plan_kernel_ms_history(th_plan *plan, float *out_ms, size_t capacity, size_t *n_out);
-TH_API int th_plan_last_kernel_ms(th_plan *plan, float *ms);
 /* name of the kernel th_calc_spec_batch_dev will launch for this plan (for profiles / tests) */
 TH_API const char *th_plan_kernel_name(const th_plan *plan);
 
@@ -476,14 +452,12 @@ TH_API int th_tm_set_lod_source(th_tm *tm, int per_request);
 /* shape of (and, with out != NULL, a dense copy of) one resident mip level; (0, 0) is the image itself */
 TH_API int th_tm_mip_level(th_tm *tm, size_t id, uint32_t ch, uint32_t level_x, uint32_t level_y, uint16_t *out,
                            size_t capacity_px, size_t *width, size_t *height);
-/* Replaces the pixels of one resident u16 image (same shape: H x W dense u16, row 0 = lowest frequency) and rebuilds its mip
- * pyramid, as update_spec_imgs does after a re-quantise (core/mod.rs:181-229).  For hosts that quantise elsewhere and for
- * the parity tests, which pin the pyramid to third-party known answers on given images (tests/golden/lod_pillow_cases.npz);
- * the next update_spec_imgs of that channel overwrites it.  Bumps the spectrogram revision. */
-TH_API int th_tm_put_img(th_tm *tm, size_t id, uint32_t ch, const uint16_t *img, size_t height, size_t width);
 /* device memory the manager holds besides audio, specs and images (accounting / leak checks): the Lanczos tap tables of
  * the pyramid passes (one per (axis length, level) some resident image needs; dropped with the last such image) and the
  * mip pyramids.  Any out pointer may be NULL. */
 TH_API int th_tm_lod_footprint(th_tm *tm, size_t *n_axis_tables, size_t *axis_table_bytes, size_t *mip_bytes);
+
+/* Test and measurement entry points (kernel selectors for A/B runs, per-launch kernel timing, replacing a resident image
+ * with given pixels) are NOT part of this interface: include/thesia_amd_testing.h declares them; a thesia host binds none. */
 
 #endif /* THESIA_AMD_H */

@@ -9,10 +9,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "thesia_amd.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"TH_API\s+[\w\s\*]+?\b(th_\w+)\s*\(", txt)))
+HEADERS = ("thesia_amd.h", "thesia_amd_testing.h")   # the product interface | test and measurement entry points
+TESTING_ONLY = {"th_plan_set_kernel", "th_plan_time_kernel", "th_plan_kernel_ms_history", "th_plan_last_kernel_ms", "th_tm_put_img"}
+
+
+def header_symbols(headers=HEADERS):
+    out = set()
+    for h in headers:
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out |= set(re.findall(r"TH_API\s+[\w\s\*]+?\b(th_\w+)\s*\(", txt))
+    return sorted(out)
 
 
 def test_header_declares_expected_surface():
@@ -21,6 +28,16 @@ def test_header_declares_expected_surface():
     for must in ("th_calc_spec_batch_dev", "th_spec_to_img_dev", "th_encode_spectrogram_tile_dev",
                  "th_encode_waveform_tile_dev", "th_tm_apply_track_list_changes", "th_plan_create"):
         assert must in syms
+
+
+def test_testing_entry_points_are_not_in_the_product_header():
+    """kernel selectors, kernel timing and th_tm_put_img have no reference counterpart — they live in
+    include/thesia_amd_testing.h, and the reference-side binding of INTEGRATION.md names none of them."""
+    product, testing = set(header_symbols(HEADERS[:1])), set(header_symbols(HEADERS[1:]))
+    assert testing == TESTING_ONLY and not (product & TESTING_ONLY)
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    binding = "\n".join(re.findall(r"```rust(.*?)```", integ, flags=re.S))
+    assert binding and not any(sym in binding for sym in TESTING_ONLY)
 
 
 def test_library_exports_every_header_symbol():

@@ -6,6 +6,7 @@
 #include <new>
 
 #include "../../include/thesia_amd.h"
+#include "../../include/thesia_amd_testing.h"  // (exported by the same library; a host binds none of it)
 
 namespace th {
 
