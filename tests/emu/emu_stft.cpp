@@ -9,6 +9,8 @@
 
 #include "../../thesia_amd/csrc/stft_wave.h"
 #include "../../thesia_amd/csrc/stft_wave_multi.h"
+#include <type_traits>
+
 #include "../../thesia_amd/csrc/stft_block.h"
 #include "../../thesia_amd/csrc/mel_fuse.h"
 
@@ -132,33 +134,48 @@ static void emu_frame_block(const float *wav, uint32_t frame, const StftGeom &g,
             const uint32_t n = t + (uint32_t)T * m;
             z[t][m] = {wav[e0 + 2 * n] * wtab[n].re, wav[e0 + 2 * n + 1] * wtab[n].im};
         }
-    for (uint32_t t = 0; t < (uint32_t)T; t++) B::pass_first(t, z[t], buf.data());
-    for (uint32_t t = 0; t < (uint32_t)T; t++) B::template read_in<B::FIRST_LAYOUT>(t, z[t], buf.data());
+    // an exchange: every thread stores, (barrier), every thread reads; planar plans (n_fft 65536) run it per part
+    auto exchange = [&](auto store, auto read) {
+        if constexpr (B::PLANAR) {
+            for (uint32_t t = 0; t < (uint32_t)T; t++) store(t, std::integral_constant<int, 0>{});
+            for (uint32_t t = 0; t < (uint32_t)T; t++) read(t, std::integral_constant<int, 0>{});
+            for (uint32_t t = 0; t < (uint32_t)T; t++) store(t, std::integral_constant<int, 1>{});
+            for (uint32_t t = 0; t < (uint32_t)T; t++) read(t, std::integral_constant<int, 1>{});
+        } else {
+            for (uint32_t t = 0; t < (uint32_t)T; t++) store(t, std::integral_constant<int, -1>{});
+            for (uint32_t t = 0; t < (uint32_t)T; t++) read(t, std::integral_constant<int, -1>{});
+        }
+    };
+    for (uint32_t t = 0; t < (uint32_t)T; t++) B::pass_first_compute(z[t]);
+    exchange([&](uint32_t t, auto part) { B::template pass_first_store<decltype(part)::value>(t, z[t], buf.data()); },
+             [&](uint32_t t, auto part) { B::template read_in<B::FIRST_LAYOUT, decltype(part)::value>(t, z[t], buf.data()); });
     if (B::R2_FIRST) {
         for (uint32_t t = 0; t < (uint32_t)T; t++) {
             cf32 w[B::NTW];
             B::template load_tw<B::NS_A>(t, w, tw);
             B::template pass_mid_compute<B::NS_A>(z[t], w);
         }
-        for (uint32_t t = 0; t < (uint32_t)T; t++) B::template pass_mid_store<B::NS_A>(t, z[t], buf.data());
-        for (uint32_t t = 0; t < (uint32_t)T; t++) B::template read_in<B::NS_A>(t, z[t], buf.data());
+        exchange([&](uint32_t t, auto part) { B::template pass_mid_store<B::NS_A, decltype(part)::value>(t, z[t], buf.data()); },
+                 [&](uint32_t t, auto part) { B::template read_in<B::NS_A, decltype(part)::value>(t, z[t], buf.data()); });
     }
     for (uint32_t t = 0; t < (uint32_t)T; t++) {
         cf32 w[B::NTW];
         B::template load_tw<B::NS_B>(t, w, tw);
         B::template pass_mid_compute<B::NS_B>(z[t], w);
     }
-    for (uint32_t t = 0; t < (uint32_t)T; t++) B::template pass_mid_store<B::NS_B>(t, z[t], buf.data());
-    for (uint32_t t = 0; t < (uint32_t)T; t++) B::template read_in<B::NS_B>(t, z[t], buf.data());
+    exchange([&](uint32_t t, auto part) { B::template pass_mid_store<B::NS_B, decltype(part)::value>(t, z[t], buf.data()); },
+             [&](uint32_t t, auto part) { B::template read_in<B::NS_B, decltype(part)::value>(t, z[t], buf.data()); });
     for (uint32_t t = 0; t < (uint32_t)T; t++) {
         cf32 w[B::NTW];
         B::template load_tw<B::NS_C>(t, w, tw);
         B::pass_last(z[t], w);
     }
-    for (uint32_t t = 0; t < (uint32_t)T; t++) B::write_z(t, z[t], buf.data());
+    static cf32 zm[T][8];
+    exchange([&](uint32_t t, auto part) { B::template write_z<decltype(part)::value>(t, z[t], buf.data()); },
+             [&](uint32_t t, auto part) { B::template split_read<decltype(part)::value>(t, buf.data(), zm[t]); });
     std::vector<int> hits(NC + 1, 0);
     for (uint32_t t = 0; t < (uint32_t)T; t++)
-        B::split(t, z[t], buf.data(), tw[t], [&](uint32_t k, float p) {
+        B::split_compute(t, z[t], zm[t], tw[t], [&](uint32_t k, float p) {
             row[k] = power_to_dB(p);
             hits[k]++;
         });
@@ -312,6 +329,7 @@ static int emu_stft_wave_impl(const float *wav, uint32_t n_samples, uint32_t win
             case 8192: emu_frame_block<12>(wav, f, g, wtab.data(), tw.data(), row); break;
             case 16384: emu_frame_block<13>(wav, f, g, wtab.data(), tw.data(), row); break;
             case 32768: emu_frame_block<14>(wav, f, g, wtab.data(), tw.data(), row); break;
+            case 65536: emu_frame_block<15>(wav, f, g, wtab.data(), tw.data(), row); break;
             default: return -1;
         }
     }

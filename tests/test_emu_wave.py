@@ -31,7 +31,9 @@ def emu():
                                              (2047, 2047, 2048, 9000),
                                              # the workgroup-per-frame plan (stft_block.h)
                                              (8192, 2048, 8192, 30000), (7680, 1920, 8192, 30000), (16384, 4096, 16384, 60000),
-                                             (15001, 5000, 16384, 70000), (32768, 8192, 32768, 100000), (19200, 4800, 32768, 80000)])
+                                             (15001, 5000, 16384, 70000), (32768, 8192, 32768, 100000), (19200, 4800, 32768, 80000),
+                                             # n_fft 65536: the same plan with planar exchanges (round 5)
+                                             (65536, 16384, 65536, 200000), (48000, 12000, 65536, 160000)])
 def test_emulated_wave_kernel_matches_oracle(emu, win, hop, n_fft, n):
     x = synth_track(n_fft + win, 48000, n)
     w = orc.calc_normalized_win(win, n_fft)

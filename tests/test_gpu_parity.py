@@ -85,10 +85,13 @@ def test_tiny_transforms(ctx, win, hop, n_fft, n):
 
 @pytest.mark.parametrize("sr,win,hop,n_fft,scale,n_mel", [(48000, 19200, 4800, 32768, 0, 0), (48000, 32768, 8192, 32768, 0, 0),
                                                           (192000, 19200, 9600, 32768, 0, 0), (96000, 38400, 9600, 65536, 0, 0),
+                                                          (48000, 65536, 16384, 65536, 0, 0), (48000, 48000, 12000, 65536, 1, 200),
+                                                          (48000, 65536, 16384, 131072, 0, 0),
                                                           (48000, 32768, 8192, 32768, 1, 128), (48000, 19200, 4800, 32768, 1, 0)])
 def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
-    """n_fft 32768 / 65536 (400 ms at 48 kHz, 100 ms at 192 kHz: winMillisec has no upper bound, Control.tsx:96-107): the
-    generic kernel with its frame buffers in global scratch.  Ragged batch incl. a channel shorter than the window, oracle
+    """n_fft 32768 / 65536 / 131072 (400 ms at 48 kHz, 100 ms at 192 kHz: winMillisec has no upper bound, Control.tsx:96-107):
+    the workgroup-per-frame kernel up to 65536 (round 5: planar LDS exchanges), beyond it the generic kernel with its frame
+    buffers in global scratch.  Ragged batch incl. a channel shorter than the window, oracle
     on every channel, min / max = extrema of the stored rows.  (scale 1: mel, n_mel 0 = the reference's default count:
     5571 mels at n_fft 32768 / 48 kHz.)"""
     lens = [n_fft * 3 + 17, n_fft + hop * 2 + 1, n_fft // 3 + 5, 5 * hop]
@@ -97,7 +100,7 @@ def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
     # n_fft 32768 is the largest frame that fits the CU's LDS: workgroup-per-frame kernel (1024 threads, stft_block.h), with the
     # matrix-core filterbank for mel plans of ANY mel count (round 4: the default counts — 5571 mels here — used to drop to
     # the generic kernel); beyond 32768 the generic kernel
-    want_kernel = ("stft_generic_kernel" if n_fft > 32768 else
+    want_kernel = ("stft_generic_kernel" if n_fft > 65536 else  # (65536: round 5, planar exchanges)
                    "stft_block_kernel+mel_mfma_kernel" if scale else "stft_block_kernel")
     assert plan.kernel_name == want_kernel
     fb = None

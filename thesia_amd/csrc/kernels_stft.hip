@@ -1465,8 +1465,153 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) __attribute__((amdgpu_wa
     }
 }
 
-#undef TH_VT
 #undef TH_BLOCK_SWAP
+
+// ------------------------------------------------------------------------------------------
+// n_fft 65536 (round 5; VERDICT r4 #7: the generic kernel through global scratch ran at 0.017 of the roofline): the
+// workgroup-per-frame plan with PLANAR exchanges (BlockFft<15>: Nc = 32768 = 8 x 16 x 16 x 16).  The 256 KB exchange image does
+// not fit the CU's LDS as complex slots, its real parts do (139 KB): every exchange runs twice — real parts out, barrier,
+// real parts in, barrier, imaginary parts out, barrier, imaginary parts in, barrier — 512 threads, VT = 4 virtual threads each
+// (64 complex points per thread in 128 VGPRs; a pass's constants are loaded when it starts: one set per pass, the last
+// pass's per virtual thread).  One workgroup per CU; the frame's samples and window pairs come from L2 / HBM once per frame
+// (hop = n_fft / 4: 256 KB of audio re-read + 256 KB of window per 64 KB of new samples — the L2 serves most of it).
+// ------------------------------------------------------------------------------------------
+template <int LOG2_NC, bool AMP, int VT>
+__global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) void stft_block_planar_kernel(
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_tiles,
+    const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax) {
+    using B = BlockFft<LOG2_NC>;
+    constexpr int T = B::T, NC = B::NC, TT = T / VT;
+    static_assert(B::PLANAR && B::R2_FIRST && TT % B::NS_B == 0 && TT % B::NS_A == 0, "planar plan, shared constants of the first two twiddled passes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // BUF_LEN floats + the (min, max) scratch
+    cf32 *const buf = reinterpret_cast<cf32 *>(smem_raw);
+    float *const red = reinterpret_cast<float *>(smem_raw) + B::BUF_LEN;
+    const uint32_t t = threadIdx.x;  // virtual thread ids: t + TT v
+    const FrameCursor cur = cursor_at(g, jobs, chunk_tab, n_tiles, blockIdx.x);
+    if (!cur.valid) return;
+    auto tw_lane = [&](uint32_t tv) {  // (opaque per use: the loop-invariant constant loads must not be hoisted out of the frame loop)
+        uint32_t x_ = tv;
+        asm volatile("" : "+v"(x_));
+        return x_;
+    };
+    // (the split twiddle W^t is loaded per frame, through the opaque thread id: resident, its sixteen products with the W^(T c)
+    // per virtual thread are loop-invariant — 64 registers hoisted out of the frame loop and spilled)
+    float lmin = __builtin_inff(), lmax = -__builtin_inff();
+    // one exchange: STORE and READ are called with the part as template argument
+#define TH_PLANAR_EXCHANGE(STORE0, READ0, STORE1, READ1) \
+    do {                                                 \
+        TH_VT { STORE0; TH_SCHED_BARRIER(); }            \
+        __syncthreads();                                 \
+        TH_VT { READ0; }                                 \
+        __syncthreads();                                 \
+        TH_VT { STORE1; TH_SCHED_BARRIER(); }            \
+        __syncthreads();                                 \
+        TH_VT { READ1; }                                 \
+        __syncthreads();                                 \
+    } while (0)
+    for (uint32_t f = cur.f; f < cur.f1; f++) {
+        // (an opaque copy of the virtual thread ids per frame: every LDS / row address below is "f(id) + immediate" and
+        // loop-invariant — hoisted out of the frame loop they are ~200 live registers, i.e. 640 bytes of scratch per lane)
+        uint32_t tv[VT];
+        TH_VT tv[v] = tw_lane(t + (uint32_t)TT * v);
+        cf32 z[VT][16];
+        {   // the frame's n_fft-sample span starts at e0 (interior frames only: the whole span is inside the channel)
+            const int64_t e0 = (int64_t)f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;
+            TH_VT {
+                // (one virtual thread's 32 loads at a time: left to itself the scheduler requests all 128 first and spills)
+                const uint32_t tl = tv[v];
+#pragma unroll
+                for (int m = 0; m < 16; m++) {
+                    const gptr<const float> p = cur.wav + (e0 + 2 * (int64_t)(tl + (uint32_t)T * m));
+                    const cf32 w = wtab_g[tl + (uint32_t)T * m];
+                    z[v][m] = {p[0] * w.re, p[1] * w.im};
+                }
+                TH_SCHED_BARRIER();
+            }
+        }
+        TH_VT {
+            B::pass_first_compute(z[v]);
+            TH_SCHED_BARRIER();
+        }
+        TH_PLANAR_EXCHANGE(B::template pass_first_store<0>(tv[v], z[v], buf),
+                           (B::template read_in<B::FIRST_LAYOUT, 0>(tv[v], z[v], buf)),
+                           B::template pass_first_store<1>(tv[v], z[v], buf),
+                           (B::template read_in<B::FIRST_LAYOUT, 1>(tv[v], z[v], buf)));
+        {
+            cf32 wA[B::NTW];
+            B::template load_tw<B::NS_A>(tv[0], wA, tw);
+            TH_VT {
+                B::template pass_mid_compute<B::NS_A>(z[v], wA);
+                TH_SCHED_BARRIER();  // (one virtual thread after the other: interleaved, their temporaries add up)
+            }
+        }
+        TH_PLANAR_EXCHANGE((B::template pass_mid_store<B::NS_A, 0>(tv[v], z[v], buf)),
+                           (B::template read_in<B::NS_A, 0>(tv[v], z[v], buf)),
+                           (B::template pass_mid_store<B::NS_A, 1>(tv[v], z[v], buf)),
+                           (B::template read_in<B::NS_A, 1>(tv[v], z[v], buf)));
+        {
+            cf32 wB[B::NTW];
+            B::template load_tw<B::NS_B>(tv[0], wB, tw);
+            TH_VT {
+                B::template pass_mid_compute<B::NS_B>(z[v], wB);
+                TH_SCHED_BARRIER();
+            }
+        }
+        TH_PLANAR_EXCHANGE((B::template pass_mid_store<B::NS_B, 0>(tv[v], z[v], buf)),
+                           (B::template read_in<B::NS_B, 0>(tv[v], z[v], buf)),
+                           (B::template pass_mid_store<B::NS_B, 1>(tv[v], z[v], buf)),
+                           (B::template read_in<B::NS_B, 1>(tv[v], z[v], buf)));
+        TH_VT {
+            cf32 wC[B::NTW];
+            B::template load_tw<B::NS_C>(tv[v], wC, tw);
+            B::pass_last(z[v], wC);
+            TH_SCHED_BARRIER();
+        }
+        cf32 zm[VT][8];
+        TH_PLANAR_EXCHANGE(B::template write_z<0>(tv[v], z[v], buf), B::template split_read<0>(tv[v], buf, zm[v]),
+                           B::template write_z<1>(tv[v], z[v], buf), B::template split_read<1>(tv[v], buf, zm[v]));
+        const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch;
+        auto emit = [&](uint32_t k, float p) {
+            if constexpr (AMP) {  // amplitude rows for the two-kernel mel path
+                row[k] = power_to_amp(p);
+            } else {
+                const float d = power_to_dB(p);
+                row[k] = d;
+                lmin = nmin(lmin, d);
+                lmax = nmax(lmax, d);
+            }
+        };
+        TH_VT {
+            B::split_compute(tv[v], z[v], zm[v], tw[tv[v]], emit);
+            TH_SCHED_BARRIER();
+        }
+        {   // complete the row's last 128-byte line (see wave_frame)
+            const uint32_t height = (uint32_t)(NC + 1), padn = cur.spec_pitch - height;
+            if (t - 1u < ((padn < 32u && cur.spec_pitch % 32u == 0) ? padn : 0u)) row[height - 1u + t] = 0.0f;
+        }
+    }
+#undef TH_PLANAR_EXCHANGE
+    if (minmax != nullptr) {  // one (min, max) pair per chunk, folded per channel by wave_post_kernel
+        lmin = wave_min(lmin);
+        lmax = wave_max(lmax);
+        if ((t & 63u) == 0) {
+            red[2 * (t >> 6)] = lmin;
+            red[2 * (t >> 6) + 1] = lmax;
+        }
+        __syncthreads();
+        if (t == 0) {
+            float a = red[0], b = red[1];
+            for (int w = 1; w < TT / 64; w++) {
+                a = nmin(a, red[2 * w]);
+                b = nmax(b, red[2 * w + 1]);
+            }
+            minmax[2 * (size_t)cur.t] = a;
+            minmax[2 * (size_t)cur.t + 1] = b;
+        }
+    }
+}
+
+#undef TH_VT
 
 #if !defined(TH_BLOCK_VT_13)
 #define TH_BLOCK_VT_13 1  // virtual threads per thread of the n_fft 16384 block kernel: 2 measured 1.35 ms against 1.01 (profiles/r04_ab_block_virtual_threads.txt)
@@ -1501,6 +1646,23 @@ static hipError_t launch_block(const StftGeom &g, const ChanJob *d_jobs, const u
     return launch_block_t<LOG2_NC, AMP, false, VT>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
 }
 
+
+#if !defined(TH_BLOCK_VT_15)
+#define TH_BLOCK_VT_15 4  // virtual threads per thread of the planar n_fft 65536 kernel (512 threads, 256 VGPRs)
+#endif
+template <int LOG2_NC, bool AMP>
+static hipError_t launch_block_planar(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
+                                      const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
+    using B = BlockFft<LOG2_NC>;
+    constexpr int VT = TH_BLOCK_VT_15;
+    auto kern = stft_block_planar_kernel<LOG2_NC, AMP, VT>;
+    constexpr size_t lds = sizeof(float) * B::BUF_LEN + sizeof(float) * 2 * (B::T / VT / 64);
+    static_assert(lds + 64 <= 160 * 1024, "one part of the exchange image fits the CU's LDS");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(B::T / VT), lds, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax);
+    return hipGetLastError();
+}
 
 // ------------------------------------------------------------------------------------------
 // launchers
@@ -1650,7 +1812,7 @@ bool stft_wave_supported(const StftGeom &g) {
     // n_fft 512 (multi-frame kernel) ... 4096 (one frame per wave), 8192 / 16384 / 32768 (block kernel); mel plans: fused
     // epilogue at n_fft 512 / 1024 / 2048 where the tables fit (at most 512 mels), else amplitude rows + a second kernel
     // (banded sums or the matrix cores: any mel count)
-    return g.log2_nc >= 8 && g.log2_nc <= 14;
+    return g.log2_nc >= 8 && g.log2_nc <= 15;  // (15: n_fft 65536, the planar block plan of round 5)
 }
 bool stft_is_block_plan(const StftGeom &g) { return g.log2_nc >= 12; }
 bool stft_wave_multi_applies(const StftGeom &g, int out_mode) {
@@ -1971,11 +2133,13 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
             if (g.log2_nc == 12) return launch_block<12, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
             if (g.log2_nc == 13) return launch_block<13, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
             if (g.log2_nc == 14) return launch_block<14, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
+            if (g.log2_nc == 15) return launch_block_planar<15, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
             return hipErrorInvalidValue;
         }
         if (g.log2_nc == 12) return launch_block<12, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
         if (g.log2_nc == 13) return launch_block<13, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
         if (g.log2_nc == 14) return launch_block<14, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+        if (g.log2_nc == 15) return launch_block_planar<15, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
         return hipErrorInvalidValue;
     }
     switch (g.log2_nc) {

@@ -66,6 +66,24 @@ TH_HD f32x4 lds_ld4(const float *p) {
 #endif
 }
 
+// 16-byte LDS write (ds_write_b128, 16-byte aligned address)
+TH_HD void lds_st4(float *p, const f32x4 &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v q;
+    q.x = v.a;
+    q.y = v.b;
+    q.z = v.c;
+    q.w = v.d;
+    *(__attribute__((address_space(3))) f32x4v *)(p) = q;
+#else
+    p[0] = v.a;
+    p[1] = v.b;
+    p[2] = v.c;
+    p[3] = v.d;
+#endif
+}
+
 // 16-byte LDS read as two packed pairs (sub-registers of the loaded quad: no moves), for the packed-f32 plan (stft_pk.h)
 struct v2x2 {
     v2f lo, hi;
