@@ -22,7 +22,10 @@
  * hop = n_fft / 4, linear dB, default waves (A/B: it measures the same as the scalar pipeline; elsewhere as 2),
  * 11 = the wave kernel with the "sweep" chunk schedule (4-frame chunks dealt out in order through a per-workgroup ticket
  * counter, the next chunk's first frame prefetched) on large batches of that same shape (A/B: a faster memory skeleton, the
- * same launch time; elsewhere as 2; 10 is reserved and behaves as 2);
+ * same launch time; elsewhere as 2; 10 is reserved and behaves as 2),
+ * 12 = mel plans at n_fft 4096: the banded sums as the FFT kernel's epilogue with the table read from global memory (L2) instead of
+ * the second kernel over amplitude rows, on the launch shapes it is instantiated for (hop 1024 and the 96 / 88.2 kHz defaults,
+ * at most 512 mels; A/B: measured slower, profiles/r05_ab_mel4096_fused.txt; elsewhere as 2);
  * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
  * frames per queue pull */
 TH_API int th_plan_set_kernel(th_plan *plan, int which);

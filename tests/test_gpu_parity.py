@@ -341,6 +341,7 @@ def test_calc_spec_mel_parity(ctx, sr, win, hop, n_fft, n_mel):
                                                     (8000, 320, 80, 512, 0), (16000, 512, 128, 512, 64),
                                                     (11025, 441, 110, 512, 0), (8000, 512, 128, 512, 512),
                                                     (96000, 3840, 960, 4096, 0), (88200, 3528, 882, 4096, 100), (88200, 3528, 882, 4096, 0),
+                                                    (96000, 4096, 1024, 4096, 0),
                                                     (16000, 400, 50, 512, 5), (12000, 512, 256, 512, 33),
                                                     (192000, 7680, 1920, 8192, 0), (48000, 16384, 4096, 16384, 200),
                                                     # more than 512 mels (round 4: the two-kernel path takes any mel count) — the
@@ -369,14 +370,19 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
                 for g in range(0, want_n_mel, 64)]
     band_rows = n_fft == 4096 and want_n_mel <= 512 and max(grp_taps) <= 128
     assert band_rows == ((sr, n_fft, n_mel) in ((96000, 4096, 0), (88200, 4096, 0)))
+    # (round 5: where that table exists and the launch shape is hop 1024 or the 96 / 88.2 kHz default, the same banded sums run in
+    # the FFT kernel's epilogue with the table read from global memory — no amplitude rows through HBM)
+    fused_4096 = band_rows and (hop == 1024 or (sr, hop) in ((96000, 960), (88200, 882)))
     second = "+mel_rows_kernel" if rows else "+mel_band_rows_kernel" if band_rows else "+mel_mfma_kernel"
     mfma = fft_kernel + second  # (any mel count since round 4; beyond 512 mels there is no fused form)
     # auto: the fused epilogue for n_fft 2048 and (when the piece table fits: <= 512 pieces) 1024, else the matrix-core path
     fused = "stft_wave_kernel(fused mel)"
     # (n_fft 1024 / 2048: the fused epilogue has two forms — banded sums, lane = mel, where the filters are narrow (the default mel
     # counts), pieces / gather otherwise; selector 8 keeps the second form everywhere)
-    for which, name in ((1, "stft_generic_kernel"), (3, mfma), (7, fft_kernel + "+mel_mfma_kernel"), (8, None), (0, None)):
+    for which, name in ((1, "stft_generic_kernel"), (3, mfma), (7, fft_kernel + "+mel_mfma_kernel"), (8, None), (12, fused), (0, None)):
         if which == 7 and not (rows or band_rows):
+            continue
+        if which == 12 and not fused_4096:  # (selector 12: the n_fft 4096 epilogue with the table from global memory, an A/B route)
             continue
         if which == 8 and n_fft not in (1024, 2048):
             continue
@@ -387,6 +393,8 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
             assert plan.kernel_name == fused if ((n_fft == 2048 and want_n_mel <= 512) or rows) else plan.kernel_name in (fused, mfma)
             if want_n_mel > 512:
                 assert plan.kernel_name == mfma
+            if n_fft == 4096 and which == 0:
+                assert plan.kernel_name == mfma  # (the fused form of round 5 measured slower: selector 12 only)
             if (n_fft, want_n_mel) in ((1024, 128), (1024, 385), (1024, 308)):
                 assert plan.kernel_name == fused  # incl. the default mel counts of 16 and 22.05 kHz audio
         else:

@@ -391,6 +391,12 @@ bool th_plan::use_wave() const {
 // 2048 at the default launch shape), else amplitude out of the FFT kernel and the filterbank on the matrix cores
 bool th_plan::use_mel_fused() const {
     if (g.n_mel == 0 || !use_wave() || kernel_choice == 3 || kernel_choice == 7) return false;
+    // n_fft 4096 (round 5: banded sums in the FFT kernel's epilogue, the table read from global memory / L2): instantiated for hop
+    // 1024 and for the even-offset grid-aligned shapes of the 96 / 88.2 kHz defaults — not when selector 4 switches that mode off
+    // MEASURED SLOWER than the two kernels (profiles/r05_ab_mel4096_fused.txt: 2.23 against 2.04 ms at the 96 kHz default — every
+    // wave re-reads the 30-36 KB table from L2 once per frame, 14 GB per launch through the CUs' vector-memory path), so it is
+    // an A/B route only: selector 12.
+    if (g.log2_nc == 11 && kernel_choice != 12) return false;
     // n_fft 512 under narrow filters: the banded sums of mel_rows_kernel as the epilogue of the four-frames-per-wave kernel
     if (g.log2_nc == 8) return d_mel_rows != nullptr && th::stft_wave_multi_mel_fits(g, wave_waves, mel_rows_groups * (uint32_t)(th::MEL_ROWS_W + 1) * 64u);
     return mel_bsum_fits() || (d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words));
@@ -688,10 +694,12 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     // the banded-sum kernel for short rows under narrow filters is the default (n_fft 512), 8 fused mel epilogue in its pieces / gather
     // form where the banded sums are the default, 9 wave kernel with the packed-f32 pipeline (stft_pk.h) on the launch shape it is
     // instantiated for (n_fft 2048, hop = n_fft / 4, linear dB, default waves; elsewhere as 2), 11 wave kernel with the sweep chunk
-    // schedule (4-frame chunks dealt out in order) on large batches of that same shape (A/B; elsewhere as 2; 10 is reserved: as 2);
+    // schedule (4-frame chunks dealt out in order) on large batches of that same shape (A/B; elsewhere as 2; 10 is reserved: as 2),
+    // 12 mel plans at n_fft 4096: the banded sums in the FFT kernel's epilogue with the table read from global memory, on the
+    // launch shapes it is instantiated for (hop 1024, the 96 / 88.2 kHz defaults; A/B: slower than the two kernels; elsewhere as 2);
     // bits 8-15 (tuning): waves per workgroup
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 11, "kernel selector must be 0 .. 11");
+    TH_REQUIRE(k >= 0 && k <= 12, "kernel selector must be 0 .. 12");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     // the multi-frame plans (n_fft 512; n_fft 1024 under selector 6) are instantiated for 8, 12 and 16 waves only
@@ -760,7 +768,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     // 48 kHz / 347 mels 0.522 vs 0.521 ms, 44.1 kHz / 370 mels 0.513 vs 0.541 — the window then comes from LDS instead of
     // registers and the mel kernel is not bound by its loads)
     // (n_fft 4096 — the 40 ms default at 88.2 / 96 kHz — also with amplitude output for the matrix-core mel kernel)
-    const int phase_mode = (wave && (!mel_mfma || g.log2_nc == 11) && (!mel_fused || p->kernel_choice == 5) && p->kernel_choice != 4 && p->d_wtab_phased != nullptr)
+    const int phase_mode = (wave && (!mel_mfma || g.log2_nc == 11) && (!mel_fused || p->kernel_choice == 5 || g.log2_nc == 11) && p->kernel_choice != 4 && p->d_wtab_phased != nullptr)
                                ? th::stft_wave_phased_mode(g, p->wave_waves) : 0;
     const bool phased = phase_mode != 0;
     g.phased = (uint32_t)phase_mode;

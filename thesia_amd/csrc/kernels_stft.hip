@@ -617,7 +617,10 @@ __device__ __forceinline__ void wave_frame(
             slab_f[NC + 1 + lane] = 0.0f;
             slab_f[NC + 65 + lane] = 0.0f;
             wave_lds_sync();
-            mel_banded<TH_MEL_BAND_PAIRED != 0>(lane, slab_f, meltab, wo.mel_groups, wo.band_off, wo.band_n, emit_mel);
+            if constexpr (LOG2_NC == 11)  // no LDS for the table beside eight slabs: weights from global memory (L2)
+                mel_banded_global(lane, slab_f, as_global(wo.mel_tab), wo.mel_groups, wo.band_off, wo.band_n, emit_mel);
+            else
+                mel_banded<TH_MEL_BAND_PAIRED != 0>(lane, slab_f, meltab, wo.mel_groups, wo.band_off, wo.band_n, emit_mel);
         } else {
             cf32 *const prf = mel_prf != nullptr ? mel_prf : slab + (NC + 2) / 2;
             const MelFuseTab mt = mel_fuse_view(meltab, wo.mel_slots, wo.mel_groups);
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     if constexpr (STW_IN_LDS && PKP) W::fill_stwp(tid, 64 * WAVES, tw, stw);
     for (uint32_t i = tid; i < WPAD; i += 64 * WAVES) wtab[i] = wtab_g[i];
     W::fill_tables(tid, 64 * WAVES, tw, T2_IN_LDS ? t2 : nullptr, t3);
-    if constexpr (OUT == 2)
+    if constexpr (OUT == 2 && LOG2_NC != 11)  // (n_fft 4096 reads the banded table from global memory: mel_banded_global)
         for (uint32_t i = tid; i < wo.mel_words; i += 64 * WAVES) meltab[i] = wo.mel_tab[i];
     __syncthreads();
 
@@ -1890,7 +1893,7 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
         }
     }
     if (out.sweep != 0 && !sweep) return hipErrorInvalidValue;  // (the host only asks for it where it exists)
-    const size_t lds = (pkv ? wave_lds_bytes<LOG2_NC, WAVES, true>() : wave_lds_bytes<LOG2_NC, WAVES, false>()) + (sweep ? 128 : 0) + (OUT == 2 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
+    const size_t lds = (pkv ? wave_lds_bytes<LOG2_NC, WAVES, true>() : wave_lds_bytes<LOG2_NC, WAVES, false>()) + (sweep ? 128 : 0) + (OUT == 2 && LOG2_NC != 11 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
                        (OUT == 2 && LOG2_NC == 9 && out.mel_slots != 0 ? (size_t)WAVES * MEL_PRF_1024 * sizeof(cf32) : 0) +  // (pieces / gather only)
                        (SHIFT == -1 ? 48 * sizeof(cf32) : 0) +  // phased: zero pairs in front of the window table
                        (SHIFT <= -48 ? 0 : SHIFT <= -16 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes (even offsets only: neither)
@@ -1922,7 +1925,8 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                                                                         d_tw, nullptr, d_queue_head, n_cu, out, s);
         }
-        if constexpr (LOG2_NC <= 10) {
+        // (n_fft 4096, round 5: the banded table from global memory, for hop 1024 and the 96 / 88.2 kHz defaults — stft_wave_mel_fits)
+        if constexpr (LOG2_NC <= 10 || (LOG2_NC == 11 && (SHIFT == 8 || SHIFT == -48 - 7 || SHIFT == -48 - 6))) {
             if (out.mode == 2)
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                                                                         d_tw, d_minmax, d_queue_head, n_cu, out, s);
@@ -2083,6 +2087,12 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool bande
         return (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) &&
                wave_lds_bytes<9, WaveLaunchCfg<9>::DEFAULT_WAVES>() + extra + (512 + 128) * sizeof(cf32) +
                        (banded ? 0 : (size_t)WaveLaunchCfg<9>::DEFAULT_WAVES * MEL_PRF_1024 * sizeof(cf32)) <= 160 * 1024;
+    // n_fft 4096: nothing to fit (the table stays in global memory); the launch shapes the epilogue is instantiated for
+    if (g.log2_nc == 11 && banded && words > 0 && (waves <= 0 || waves == WaveLaunchCfg<11>::DEFAULT_WAVES)) {
+        const int pm = stft_wave_phased_mode(g, waves);
+        if (pm == 0) return g.hop == 1024;
+        return pm == 3 && (g.hop / 128 == 7 || g.hop / 128 == 6);
+    }
     return false;
 }
 // (the same sum as launch_wave_multi_n; ADVICE r3: without this check a small growth of SLAB_LEN or MEL_ROWS_W would turn the

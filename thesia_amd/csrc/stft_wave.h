@@ -1482,4 +1482,45 @@ TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint
     }
 }
 
+// The same banded sums with the table in GLOBAL memory (round 5: n_fft 4096, whose eight slabs leave no LDS for a 30-36 KB
+// table): paired layout only.  Every wave of the launch reads the same table frame after frame — L2-resident, 1 KiB per
+// wave-instruction (16 bytes per lane, lane-contiguous); the amplitudes come from the wave's own slab as in mel_banded.
+// A group's weight quads are requested in batches of BATCH (all of a batch in flight before the first FMA); quads past the
+// group's end re-read its last quad and are multiplied by zero (no branch around a load).
+#if defined(__HIPCC__)  // (both passes of hipcc see it: wave_frame is parsed by the host pass too; not the CPU lane emulator)
+template <int BATCH = 8, class Emit>
+__device__ __forceinline__ void mel_banded_global(uint32_t lane, const float *amp, gptr<const uint32_t> tab, uint32_t n_groups,
+                                                  const uint32_t (&off)[8], const uint32_t (&n)[8], Emit emit) {
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    uint32_t lo[8];  // every group's first bin up front: one L2 round trip for all of them
+    TH_UNROLL for (uint32_t g = 0; g < 8; g++) lo[g] = tab[off[g < n_groups ? g : 0] + lane];
+    TH_UNROLL for (uint32_t g = 0; g < 8; g++) {
+        if (g < n_groups) {  // wave-uniform
+            const float *ap = amp + lo[g];
+            const gptr<const f32x4v> wp = reinterpret_cast<gptr<const f32x4v>>(tab + (off[g] + 64u)) + lane;  // quad q: wp[64 q]
+            const uint32_t nq = n[g] >> 2;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t q0 = 0; q0 < nq; q0 += BATCH) {
+                f32x4v w[BATCH];
+                TH_UNROLL for (int u = 0; u < BATCH; u++) w[u] = wp[64u * min(q0 + (uint32_t)u, nq - 1u)];
+                cf32 a[BATCH][2];
+                TH_UNROLL for (int u = 0; u < BATCH; u++) {
+                    const float *q = ap + 4u * min(q0 + (uint32_t)u, nq - 1u);
+                    a[u][0] = lds_ld(reinterpret_cast<const cf32 *>(q));
+                    a[u][1] = lds_ld(reinterpret_cast<const cf32 *>(q + 2));
+                }
+                TH_UNROLL for (int u = 0; u < BATCH; u++) {
+                    const bool ok = q0 + (uint32_t)u < nq;  // wave-uniform
+                    acc[0] = fma_rn(a[u][0].re, ok ? w[u].x : 0.0f, acc[0]);
+                    acc[1] = fma_rn(a[u][0].im, ok ? w[u].y : 0.0f, acc[1]);
+                    acc[2] = fma_rn(a[u][1].re, ok ? w[u].z : 0.0f, acc[2]);
+                    acc[3] = fma_rn(a[u][1].im, ok ? w[u].w : 0.0f, acc[3]);
+                }
+            }
+            emit(64u * g + lane, (acc[0] + acc[1]) + (acc[2] + acc[3]));
+        }
+    }
+}
+#endif
+
 }  // namespace th
