@@ -13,6 +13,19 @@ want() { [ "$part" = all ] || [ "$part" = "$1" ]; }
 [ "$part" = all ] || [ "$part" = 1 ] && rm -rf "$out"
 mkdir -p "$out"
 if want 1; then
+# which card, and whether the library that runs is the one that travelled with the push or a rebuild on this box
+{ rocm-smi --showserial 2>/dev/null | grep -E "Serial"; } > "$out/box.txt"
+python3 - > "$out/build_mode.txt" <<'PY'
+import os, time
+lib = "thesia_amd/libthesia_amd.so"
+before = os.path.getmtime(lib) if os.path.exists(lib) else None
+t0 = time.time()
+import __graft_entry__ as ge
+ge.build()
+after = os.path.getmtime(lib)
+print("build_mode: %s (__graft_entry__.build() took %.1f s; %s)" % (
+    "reused the prebuilt library that travelled with the push" if before == after else "REBUILT on this box", time.time() - t0, lib))
+PY
 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -4 > "$out/gputest.txt"
 echo "bench" >> "$out/progress.txt"; python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
 cp gpurun_out/bench_extras.json "$out/bench_extras.json" 2>/dev/null
@@ -22,6 +35,10 @@ scripts/pmc_stft.sh "$out/pmc_stft" > "$out/pmc_stft.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stftpk" --kernel 9 > "$out/pmc_stftpk.log" 2>&1      # round 4: the packed-f32 pipeline
 scripts/pmc_stft.sh "$out/pmc_stftsweep" --kernel 11 > "$out/pmc_stftsweep.log" 2>&1  # round 4: the sweep chunk schedule
 TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pmc_img.log" 2>&1
+# the N > 1 launcher (round 5): `--gpus 2` on this one-GPU box must fail loudly, and the launcher -> torchrun -> rank -> RCCL route
+# end to end at one rank (TH_BENCH_FORCE_LAUNCHER=1)
+python3 bench.py --gpus 2 --steps 2 > "$out/gpus2.out" 2> "$out/gpus2.err"; echo "exit code $? ; stdout bytes $(wc -c < $out/gpus2.out)" >> "$out/gpus2.err"
+TH_BENCH_FORCE_LAUNCHER=1 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-single-track --no-full-cfg5 > "$out/launcher.out" 2> "$out/launcher.err"; grep "^{" "$out/launcher.out" | tail -1 > "$out/bench_line_launcher.json"
 # the RCCL path on one GPU (world size 1): the line bench.py prints with the process group up
 TH_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-single-track --no-full-cfg5 > "$out/force_dist.out" 2> "$out/force_dist.err"; grep "^{" "$out/force_dist.out" | tail -1 > "$out/bench_line_force_dist.json"
 # package power / clocks next to the kernel loop and next to plain memory streams (scripts/power_probe.sh)
@@ -58,7 +75,7 @@ if want 3; then
   python3 scripts/bench_stft.py --reps 30 --hop 1024
   python3 scripts/bench_stft.py --reps 30 --kernel $((2+(8<<8)+(32<<16))) $((2+(12<<8)+(32<<16))) $((2+(16<<8)+(32<<16)))
 } > "$out/bench_stft.txt" 2>&1
-python3 scripts/bench_img.py > "$out/bench_img.txt" 2>&1
+python3 scripts/bench_img.py --sustain 300 > "$out/bench_img.txt" 2>&1
 python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
 { python3 scripts/bench_cfg4.py; KERNEL=3 python3 scripts/bench_cfg4.py; SR=48000 WIN=1920 HOP=480 python3 scripts/bench_cfg4.py; } > "$out/bench_cfg4.txt" 2>&1
 {
@@ -69,7 +86,7 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 8192
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 16384
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 32768
-  python3 scripts/bench_stft.py --reps 10 --gap-ms 1 --nfft 65536
+  python3 scripts/bench_stft.py --reps 10 --gap-ms 1 --nfft 65536 --kernel 0 1   # round 5: planar block plan | generic kernel
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --win 1920 --hop 240 --kernel 0 4
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --win 1920 --hop 120 --kernel 0 4
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 4096 --seconds 60
@@ -90,6 +107,9 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 44100 --tracks 32 --seconds 60 --mel 128 --kernel 0 8
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 16000 --nfft 1024 --win 640 --hop 160 --mel 0 --seconds 90 --kernel 0 8
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 22050 --nfft 1024 --win 882 --hop 220 --mel 0 --seconds 60 --kernel 0 8
+  # round 5: mel at n_fft 4096 as the FFT kernel's epilogue with the table from global memory (12) against the two kernels (0)
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 --mel 0 --kernel 0 12
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 88200 --nfft 4096 --win 3528 --hop 882 --seconds 30 --mel 0 --kernel 0 12
   # round 4: the Mel default of long windows (more than 512 mels) on the two-kernel path against the generic kernel
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 4096 --mel 0 --kernel 0 1
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 8192 --mel 0 --kernel 0 1

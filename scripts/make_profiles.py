@@ -96,8 +96,13 @@ if os.path.exists(p):
 for f in ("bench_stft.txt", "bench_img.txt", "bench_cfg3.txt", "bench_cfg4.txt", "phase_prof.txt", "ubench_lds_rate.txt",
           "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt", "ubench_stream_shapes.txt", "ubench_fused_img_shapes.txt",
           "ubench_stft_skeleton_sweep.txt", "wave_times.txt", "power.txt",
-          "bench_line_force_dist.json", "gputest.txt"):
+          "bench_line_force_dist.json", "bench_line_launcher.json", "gputest.txt", "box.txt", "build_mode.txt"):
     if os.path.exists(f"{src}/{f}"):
         txt = "\n".join(l for l in open(f"{src}/{f}").read().splitlines() if "amdgpu.ids" not in l) + "\n"
         open(f"{dst}/{tag}_{f}", "w").write(txt)
 print("\n".join(sorted(os.listdir(dst))))
+
+# 6. the N > 1 launcher refusing a one-GPU box (round 5): bench.py --gpus 2 -> stderr + exit code, no record on stdout
+if os.path.exists(f"{src}/gpus2.err"):
+    keep = [l for l in open(f"{src}/gpus2.err").read().splitlines() if "bench.py" in l or l.startswith("exit code")]
+    open(f"{dst}/{tag}_bench_gpus2_on_one_gpu.txt", "w").write("# python3 bench.py --gpus 2 --steps 2 on a one-GPU box: must refuse (stderr, exit code != 0, empty stdout)\n" + "\n".join(keep) + "\n")
