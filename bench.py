@@ -10,6 +10,11 @@
 and starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a CHILD process
 (never an exec), relays its stdout and exits with its code.  Under torchrun, WORLD_SIZE must equal --gpus.
 
+TH_BENCH_SHARE_GPU=1 (a REHEARSAL, not a measurement of scaling): the N ranks all use GPU 0 and torch.distributed runs over
+gloo (RCCL refuses two ranks on one device), so that the whole N > 1 control flow — launcher, sharding, the range exchange
+between the two kernels of the step, max-over-ranks timing, the tile gather — runs with real processes on a one-GPU box.
+The record says so (`config.ranks_share_one_gpu`), and its frames/s is what N interleaved jobs get from ONE card.
+
 Workload (per GPU, fixed as N grows -> weak scaling): BASELINE config "1024 synthetic 48 kHz mono
 tracks, n_fft=2048, sharded across 8 GPUs" = 128 tracks x 30 s per GPU (track index = rank*128+i),
 Hann win 2048 / hop 512, linear-frequency dB.  At N = 8 this is exactly that config; at N = 1 it
@@ -39,6 +44,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SHARE_GPU = os.environ.get("TH_BENCH_SHARE_GPU") == "1"   # N ranks on GPU 0 over gloo: a control-flow rehearsal (module docstring)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32)
 
@@ -110,6 +116,9 @@ def launcher_plan(gpus: int, argv, env, n_visible: int):
     """What `bench.py --gpus N` (N > 1, no WORLD_SIZE) starts: (command, environment) of ONE child process — torchrun with
     N ranks on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve), this script and its own
     arguments unchanged.  Fewer than N visible devices: SystemExit with a message, never a smaller job."""
+    share = env.get("TH_BENCH_SHARE_GPU") == "1"   # rehearsal: every rank on GPU 0, gloo (see the module docstring)
+    if share and n_visible >= 1:
+        n_visible = gpus
     if n_visible < gpus:
         raise SystemExit(f"bench.py: --gpus {gpus} needs {gpus} visible GPUs, this node shows {n_visible}; refusing to run a smaller "
                          "job under the same name (set HIP_VISIBLE_DEVICES / pick --gpus to match)")
@@ -273,7 +282,12 @@ class Workload:
         # [min, -max] of this rank -> (N > 1: the path's only exchange step, a 2-float MIN all-reduce) -> clamp
         if dist is not None:
             self.ctx.minmax_reduce_dev(self.minmax.data_ptr(), self.n_tracks, self.range2.data_ptr())
-            dist.all_reduce(self.range2, op=dist.ReduceOp.MIN)
+            if SHARE_GPU:   # gloo rehearsal on one card: through host memory (a synchronisation inside the step: not a timing to quote)
+                r2 = self.range2.cpu()
+                dist.all_reduce(r2, op=dist.ReduceOp.MIN)
+                self.range2.copy_(r2)
+            else:
+                dist.all_reduce(self.range2, op=dist.ReduceOp.MIN)
             self.ctx.global_db_range_dev(self.range2.data_ptr(), 100.0, self.range_db.data_ptr())
 
         if record:
@@ -531,6 +545,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if SHARE_GPU:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} wants device {local_rank}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
@@ -542,7 +558,10 @@ def main():
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if SHARE_GPU:
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist = dist_mod
 
     sr, (hop, win, n_fft) = 48000, ta.calc_framing_params(2048 / 48, 4, 1, 48000)
@@ -582,9 +601,17 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if SHARE_GPU else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # every rank must have quantised against the SAME global dB range (the path's one exchange): collect the ranks' [min_dB, max_dB]
+    range_agrees = None
+    if dist is not None:
+        mine_r = wl.range_db.detach().cpu() if SHARE_GPU else wl.range_db.detach().clone()
+        all_r = [torch.empty_like(mine_r) for _ in range(world)]
+        dist.all_gather(all_r, mine_r)
+        range_agrees = bool(all(torch.equal(all_r[0], r) for r in all_r))
+        global_range = [float(v) for v in all_r[0].cpu()]
     # HIP events on the launch stream, inside the timed region: per-kernel average launch durations
     stft_stage_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in wl.ev]))  # init + STFT kernel + boundary-frame kernel
     stft_series = [float(v) for v in wl.plan.kernel_ms_history()[-args.steps:]]
@@ -836,17 +863,19 @@ def main():
     if dist is not None:
         from thesia_amd import dist as tdist
         # (one untimed gather first: the first point-to-point transfer between two ranks sets up their RCCL connection)
-        got = tdist.gather_tensor_to_root(wl.rgba.view(-1)[: 1 << 20], dist, root=0)
+        # (rehearsal on one card: a 64 MiB slice per rank through host memory — gloo moves CPU tensors)
+        payload = wl.rgba.view(-1)[: 1 << 26].cpu() if SHARE_GPU else wl.rgba.view(-1)
+        got = tdist.gather_tensor_to_root(payload[: 1 << 20], dist, root=0)
         del got
         barrier()
         t0 = time.perf_counter()
-        got = tdist.gather_tensor_to_root(wl.rgba.view(-1), dist, root=0)
+        got = tdist.gather_tensor_to_root(payload, dist, root=0)
         barrier()
         g_dt = time.perf_counter() - t0
         if rank == 0:
             inbound = sum(int(t.numel()) for r, t in enumerate(got) if r != 0)
             gather = {"what": "level-0 RGBA tiles of every track, device-resident send/recv to rank 0 (batch_isend_irecv)",
-                      "ms": g_dt * 1e3, "bytes_per_rank": int(wl.rgba.numel()), "inbound_bytes_root": inbound,
+                      "ms": g_dt * 1e3, "bytes_per_rank": int(payload.numel()), "inbound_bytes_root": inbound,
                       "inbound_GBs": inbound / g_dt / 1e9 if inbound else None, "ranks": world}
         del got
 
@@ -940,7 +969,9 @@ def main():
             "config": {"workload": f"cfg5 shard: {args.tracks_per_gpu} tracks/GPU x {args.seconds:g} s 48 kHz mono, "
                                    f"n_fft={n_fft} hop={hop} Hann, linear dB + u16 image + level-0 RGBA tiles",
                        "tracks_per_gpu": args.tracks_per_gpu, "frames_per_gpu": wl.frames,
-                       "parallelism": f"track-sharded x{world}, 2-float dB-range all-reduce"},
+                       "parallelism": f"track-sharded x{world}, 2-float dB-range all-reduce"
+                                      + (" — REHEARSAL: all ranks share GPU 0, gloo (TH_BENCH_SHARE_GPU=1); not a scaling figure" if SHARE_GPU else ""),
+                       **({"ranks_share_one_gpu": True, "backend": "gloo"} if SHARE_GPU else {})},
             "stft_frames_per_s": total_frames / (stft_stage_ms * 1e-3),
             "raster_mpixels_per_s": wl.pixels * world / 1e6 / (img_ms * 1e-3),
             "stft_kernel": wl.plan.kernel_name,
@@ -1052,8 +1083,12 @@ def main():
                 extras_out[k] = v
         if gather is not None:
             out["tile_gather"] = {"ms": gather["ms"], "inbound_GBs": gather["inbound_GBs"], "ranks": gather["ranks"]}
+        if range_agrees is not None:
+            out["global_dB_range"] = {"min_max_dB": global_range, "identical_on_all_ranks": range_agrees, "ranks": world}
+            if not range_agrees:
+                raise SystemExit("bench.py: the ranks disagree on the global dB range — the range exchange is broken")
         if range_exchange_ms is not None:
-            out["range_allreduce"] = {"in_step_ms": range_exchange_ms, "ranks": world, "backend": "nccl (RCCL)",
+            out["range_allreduce"] = {"in_step_ms": range_exchange_ms, "ranks": world, "backend": "gloo via host memory (rehearsal)" if SHARE_GPU else "nccl (RCCL)",
                                       "what": "minmax fold kernel + 2-float all_reduce(MIN) + clamp kernel, HIP events inside the timed step"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cmap_bytes, sr, n, win, hop, n_fft)

@@ -39,6 +39,8 @@ TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pm
 # end to end at one rank (TH_BENCH_FORCE_LAUNCHER=1)
 python3 bench.py --gpus 2 --steps 2 > "$out/gpus2.out" 2> "$out/gpus2.err"; echo "exit code $? ; stdout bytes $(wc -c < $out/gpus2.out)" >> "$out/gpus2.err"
 TH_BENCH_FORCE_LAUNCHER=1 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-single-track --no-full-cfg5 > "$out/launcher.out" 2> "$out/launcher.err"; grep "^{" "$out/launcher.out" | tail -1 > "$out/bench_line_launcher.json"
+# N > 1 control flow with real processes on this one card (REHEARSAL over gloo, every rank on GPU 0 — not a scaling figure)
+for n in 2 4; do TH_BENCH_SHARE_GPU=1 timeout -k 10 400 python3 bench.py --gpus $n --steps 20 --warmup 5 --no-cpu-baseline > "$out/share$n.out" 2> "$out/share$n.err"; grep "^{" "$out/share$n.out" | tail -1 > "$out/bench_line_rehearsal_${n}_ranks_one_gpu.json"; done
 # the RCCL path on one GPU (world size 1): the line bench.py prints with the process group up
 TH_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-single-track --no-full-cfg5 > "$out/force_dist.out" 2> "$out/force_dist.err"; grep "^{" "$out/force_dist.out" | tail -1 > "$out/bench_line_force_dist.json"
 # package power / clocks next to the kernel loop and next to plain memory streams (scripts/power_probe.sh)

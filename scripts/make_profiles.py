@@ -96,7 +96,7 @@ if os.path.exists(p):
 for f in ("bench_stft.txt", "bench_img.txt", "bench_cfg3.txt", "bench_cfg4.txt", "phase_prof.txt", "ubench_lds_rate.txt",
           "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt", "ubench_stream_shapes.txt", "ubench_fused_img_shapes.txt",
           "ubench_stft_skeleton_sweep.txt", "wave_times.txt", "power.txt",
-          "bench_line_force_dist.json", "bench_line_launcher.json", "gputest.txt", "box.txt", "build_mode.txt"):
+          "bench_line_force_dist.json", "bench_line_launcher.json", "bench_line_rehearsal_2_ranks_one_gpu.json", "bench_line_rehearsal_4_ranks_one_gpu.json", "gputest.txt", "box.txt", "build_mode.txt"):
     if os.path.exists(f"{src}/{f}"):
         txt = "\n".join(l for l in open(f"{src}/{f}").read().splitlines() if "amdgpu.ids" not in l) + "\n"
         open(f"{dst}/{tag}_{f}", "w").write(txt)

@@ -39,6 +39,17 @@ def test_launcher_refuses_fewer_devices_than_ranks():
     assert "needs 8 visible GPUs" in str(e.value) and "shows 1" in str(e.value)
 
 
+def test_share_gpu_rehearsal_passes_the_device_check_only_when_asked():
+    """TH_BENCH_SHARE_GPU=1: N ranks on GPU 0 over gloo — the launcher lets N > visible through (a GPU must still be there)."""
+    b = _bench()
+    cmd, env = b.launcher_plan(4, ["--gpus", "4"], {"TH_BENCH_SHARE_GPU": "1"}, n_visible=1)
+    assert "--nproc-per-node=4" in cmd and env["TH_BENCH_SHARE_GPU"] == "1"
+    with pytest.raises(SystemExit):
+        b.launcher_plan(4, [], {"TH_BENCH_SHARE_GPU": "1"}, n_visible=0)
+    with pytest.raises(SystemExit):
+        b.launcher_plan(4, [], {}, n_visible=1)
+
+
 def test_visible_gpu_count_honours_visibility_masks():
     b = _bench()
     assert b.visible_gpu_count({"TH_BENCH_ASSUME_GPUS": "8"}) == 8
