@@ -495,6 +495,9 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
         rinv = quantise_rinv(span);
         all_zero = lo == hi && __builtin_isinf(hi) && hi < 0.0f;  // every value -inf: zero image (drawing.rs:16-18)
     }
+#if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 64)  // ablation build: launch + job fetch only
+    if (job.n_frames != 0x7fffffffu) return;
+#endif
     const gptr<const float> spec = as_global(job.spec);
     const uint32_t out_h = job.i_end - job.i_start, W = job.n_frames;
     const uint32_t local = blockIdx.x - job.first_block;
@@ -594,6 +597,9 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
         }
         lut_store();
     };
+#if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 8)  // ablation build: no read / quantise phase
+    if (min_dB == 12345.0f)
+#endif
     if (packed && regular) {
         read_packed(std::false_type{});
     } else if (packed) {
@@ -692,6 +698,9 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
     // wave-instructions per 2080-byte row, the third with two lanes)
     // (wt >= 32: at least eight quads per row, so that a lane's "quad before the piece" lies in the one row before it)
     const bool flat = tb0 != nullptr && wt % 4u == 0 && wt >= 32u && (reinterpret_cast<uintptr_t>(tb0) & 15u) == 0 && nrows > 0;
+#if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 16)  // ablation build: no RGBA phase
+    if (min_dB == 12345.0f)
+#endif
     if (flat) {
         const uint32_t qpr = wt >> 2, nq = nrows * qpr;
         const uint32_t r_top = oy + ht - 1u - (r0 + nrows - 1u);  // tile row of the band's LAST image row = the piece's first row
