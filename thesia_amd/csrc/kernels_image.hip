@@ -512,6 +512,11 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
     const uint32_t ty0 = r0 / 512u, sy = ty0 * 512u, coreh = min(out_h - sy, 512u);
     const uint32_t oy = sy > 4u ? sy - 4u : 0u, ht = min(out_h, sy + coreh + 4u) - oy;
     uint8_t *const tb0 = (nrows && job.n_ty) ? tiles[job.tile0 + tx * job.n_ty + ty0] : nullptr;  // scalar load, long before its use
+    // the band's first four rows are also tile row ty0 - 1's top gutter when the band is the tile row's first, its last four tile
+    // row ty0 + 1's bottom gutter when it is the last band of a full tile row: those tiles' pointers, requested here as well
+    const bool lo_nb = nrows != 0 && ty0 > 0u && r0 == sy, hi_nb = nrows != 0 && ty0 + 1u < job.n_ty && r0 + FB == sy + 512u;
+    uint8_t *const tb_lo = lo_nb ? tiles[job.tile0 + tx * job.n_ty + ty0 - 1u] : nullptr;
+    uint8_t *const tb_hi = hi_nb ? tiles[job.tile0 + tx * job.n_ty + ty0 + 1u] : nullptr;
 
     // ---- read + quantise.  lane -> bins 4 bq .. 4 bq + 3 of the four frames of group g = GPW (wv + WAVES i) + fg
     const uint32_t bq = lane % LPR, fg = lane / LPR;
@@ -664,12 +669,18 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
         }
     }
     __syncthreads();
+#if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 128)  // ablation build: stop behind the barrier
+    if (job.n_frames != 0x7fffffffu) return;
+#endif
     // ---- u16 image rows: the column's core frames [sx, sx + core) (+ the row padding in the last column), 8 px per lane
     const gptr<uint16_t> img = as_global(job.img);
     // rows at the library's padded pitch own their padding (see spec_to_img_kernel): complete the last 128-byte line
     const uint32_t t_lim = (job.img_pitch % IMG_TILE_T == 0 && job.img_pitch - W < IMG_TILE_T) ? job.img_pitch : W;
     const uint32_t c_lim = min(t_lim - sx, 512u);  // columns of this tile column to write (the last column: up to the pitch)
     const bool img_al = (reinterpret_cast<uintptr_t>(job.img) & 15u) == 0 && job.img_pitch % 8u == 0;
+#if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 32)  // ablation build: no image-row phase
+    if (min_dB == 12345.0f)
+#endif
 #pragma unroll
     for (uint32_t i = 0; i < (FB + WAVES - 1) / WAVES; i++) {
         const uint32_t r = wv + WAVES * i, c = 8u * lane;
@@ -750,51 +761,55 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
         }
     }
     // rows that are ALSO a neighbour's gutter (the first / last 4 rows of a tile row's core), and the own tile where the flat
-    // form does not apply (odd widths: the last tile column): row by row
-    const bool lo_nb = ty0 > 0u && r0 - sy < 4u, hi_nb = ty0 + 1u < job.n_ty && r0 + FB + 4u > sy + 512u;
-    if ((flat && !lo_nb && !hi_nb) || nrows == 0) return;
-#pragma unroll 1
-    for (uint32_t i = 0; i < (FB + WAVES - 1) / WAVES; i++) {
-        const uint32_t r = wv + WAVES * i, r_img = r0 + r;
-        if (r >= nrows) continue;  // wave-uniform
-#pragma unroll 1
-        for (int dty = -1; dty <= 1; dty++) {
-            if (dty == 0 && flat) continue;
-            const int tyi = (int)ty0 + dty;
-            if (tyi < 0 || (uint32_t)tyi >= job.n_ty) continue;
-            const uint32_t ty = (uint32_t)tyi, sy2 = ty * 512u, coreh2 = min(out_h - sy2, 512u);
-            const uint32_t oy2 = sy2 > 4u ? sy2 - 4u : 0u, ht2 = min(out_h, sy2 + coreh2 + 4u) - oy2;
-            if (r_img < oy2 || r_img >= oy2 + ht2) continue;
-            uint8_t *const tbase = tiles[job.tile0 + tx * job.n_ty + ty];  // scalar load
-            if (tbase == nullptr) continue;
-            const gptr<uint32_t> dst = as_global(reinterpret_cast<uint32_t *>(tbase)) + (size_t)(oy2 + ht2 - 1u - r_img) * wt;
-            const uint16_t *const srow = &ftile[r * FUSED_PITCH + ct];
-            // 16-byte stores on the destination's 16-byte grid (rows of odd widths start 4 / 8 / 12 bytes off it)
-            const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(tbase) / 4u + (size_t)(oy2 + ht2 - 1u - r_img) * wt) & 3u;
+    // form does not apply (odd widths: the last tile column): row by row.  The neighbour tiles' pointers were requested at the
+    // top of the block: inside the row loop each was a dependent scalar load — a memory round trip per (row, neighbour) probe
+    // in the one block in eight that sits at a tile boundary, 0.08 ms of the launch's 0.28 ms without memory traffic.
+    auto row_to_tile = [&](uint32_t r, uint8_t *tbase, uint32_t ty) __attribute__((always_inline)) {
+        if (tbase == nullptr) return;
+        const uint32_t r_img = r0 + r;
+        const uint32_t sy2 = ty * 512u, coreh2 = min(out_h - sy2, 512u);
+        const uint32_t oy2 = sy2 > 4u ? sy2 - 4u : 0u, ht2 = min(out_h, sy2 + coreh2 + 4u) - oy2;
+        if (r_img < oy2 || r_img >= oy2 + ht2) return;
+        const gptr<uint32_t> dst = as_global(reinterpret_cast<uint32_t *>(tbase)) + (size_t)(oy2 + ht2 - 1u - r_img) * wt;
+        const uint16_t *const srow = &ftile[r * FUSED_PITCH + ct];
+        // 16-byte stores on the destination's 16-byte grid (rows of odd widths start 4 / 8 / 12 bytes off it)
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(tbase) / 4u + (size_t)(oy2 + ht2 - 1u - r_img) * wt) & 3u;
 #pragma unroll
-            for (uint32_t k = 0; k < 3; k++) {  // wt <= 520: at most 131 quads (+ 1 for a shifted grid)
-                const int32_t c = (int32_t)(4u * (lane + 64u * k)) - (int32_t)mis;
-                if (c >= (int32_t)wt) continue;
-                if (c >= 0 && (uint32_t)c + 4u <= wt) {
-                    uint32_t p0, p1, p2, p3;
-                    if (mis == 0u) {  // (wave-uniform) the source quad is 8-byte aligned: one LDS read
-                        const uint2 q = *reinterpret_cast<const uint2 *>(srow + c);
-                        p0 = q.x & 0xffffu;
-                        p1 = q.x >> 16;
-                        p2 = q.y & 0xffffu;
-                        p3 = q.y >> 16;
-                    } else {
-                        p0 = srow[c];
-                        p1 = srow[c + 1];
-                        p2 = srow[c + 2];
-                        p3 = srow[c + 3];
-                    }
-                    *reinterpret_cast<gptr<uint4>>(dst + c) = make_uint4(look(p0), look(p1), look(p2), look(p3));
+        for (uint32_t k = 0; k < 3; k++) {  // wt <= 520: at most 131 quads (+ 1 for a shifted grid)
+            const int32_t c = (int32_t)(4u * (lane + 64u * k)) - (int32_t)mis;
+            if (c >= (int32_t)wt) continue;
+            if (c >= 0 && (uint32_t)c + 4u <= wt) {
+                uint32_t p0, p1, p2, p3;
+                if (mis == 0u) {  // (wave-uniform) the source quad is 8-byte aligned: one LDS read
+                    const uint2 q = *reinterpret_cast<const uint2 *>(srow + c);
+                    p0 = q.x & 0xffffu;
+                    p1 = q.x >> 16;
+                    p2 = q.y & 0xffffu;
+                    p3 = q.y >> 16;
                 } else {
-                    for (int32_t q = c < 0 ? 0 : c; q < c + 4 && q < (int32_t)wt; q++) dst[q] = look(srow[q]);
+                    p0 = srow[c];
+                    p1 = srow[c + 1];
+                    p2 = srow[c + 2];
+                    p3 = srow[c + 3];
                 }
+                *reinterpret_cast<gptr<uint4>>(dst + c) = make_uint4(look(p0), look(p1), look(p2), look(p3));
+            } else {
+                for (int32_t q = c < 0 ? 0 : c; q < c + 4 && q < (int32_t)wt; q++) dst[q] = look(srow[q]);
             }
         }
+    };
+    if (nrows == 0) return;
+    if (!flat) {  // the band's own tile, row by row
+#pragma unroll 1
+        for (uint32_t r = wv; r < nrows; r += WAVES) row_to_tile(r, tb0, ty0);
+    }
+    if (lo_nb) {  // image rows sy .. sy + 3 = the band's rows 0 .. 3 (the band is the tile row's first): tile (tx, ty0 - 1)'s top gutter
+#pragma unroll 1
+        for (uint32_t r = wv; r < min(4u, nrows); r += WAVES) row_to_tile(r, tb_lo, ty0 - 1u);
+    }
+    if (hi_nb) {  // image rows sy + 508 .. sy + 511 = the band's last four rows (the band is a full tile row's last): tile (tx, ty0 + 1)'s bottom gutter
+#pragma unroll 1
+        for (uint32_t r = FB - 4u + wv; r < min(FB, nrows); r += WAVES) row_to_tile(r, tb_hi, ty0 + 1u);
     }
 }
 
