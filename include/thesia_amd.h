@@ -154,12 +154,14 @@ TH_API int th_timer_start(th_ctx *ctx);
 TH_API int th_timer_stop_ms(th_ctx *ctx, float *ms);
 
 /* ---------------------------------------------------------------- SpectrogramAnalyzer plan */
-/* largest transform a plan takes (powers of two from 2 up to this): 2^20 samples = 5.5 s at 192 kHz */
+/* largest transform a plan takes: 2^20 samples = 5.5 s at 192 kHz */
 #define TH_MAX_N_FFT (1u << 20)
 /* Device-resident window / twiddles / mel filterbank for one (sr, win, hop, n_fft, scale, n_mel)
  * key; mirrors prepare()/retain() (spectrogram.rs:116-185).  n_mel = 0 with TH_FREQ_MEL selects
- * calc_mel_fb_default's count.  n_fft must be a power of two in [2, TH_MAX_N_FFT] and win <= n_fft (else
- * TH_ERR_UNSUPPORTED; mel plans whose dense filterbank would exceed 1 GiB are refused the same way). */
+ * calc_mel_fb_default's count.  n_fft = 2^a * odd with a >= 1, odd <= 63, in [2, TH_MAX_N_FFT] and win <= n_fft (else
+ * TH_ERR_UNSUPPORTED; mel plans whose dense filterbank would exceed 1 GiB are refused the same way): every
+ * next_pow2(win) * f_overlap of spectrogram.rs:66-72 with f_overlap = 1 .. 63 (and their even multiples) — powers of two
+ * run on the wave / block kernels, the others (f_overlap 3, 5, 6, ...: no UI control offers them) on the generic kernel. */
 TH_API int th_plan_create(th_ctx *ctx, uint32_t sr, size_t win, size_t hop, size_t n_fft, int freq_scale,
                           size_t n_mel, th_plan **out);
 TH_API int th_plan_destroy(th_plan *plan);
@@ -369,9 +371,9 @@ TH_API int th_tm_destroy(th_tm *tm);
 /* init(colormap_rgba) — lib.rs:51-98, render_tiles.rs:80-85; sets colormap_length = bytes/4 */
 TH_API int th_tm_set_colormap(th_tm *tm, const uint8_t *rgba, size_t bytes);
 /* TrackManager::set_setting — core/mod.rs:107-115 (recomputes every resident track).  Transactional: when the new
- * setting cannot be planned (this library needs n_fft = next_pow2(win) * f_overlap to be a power of two in
- * [2, TH_MAX_N_FFT], which covers every window length the UI accepts; the reference's realfft takes any length, so
- * f_overlap = 3, which no control offers, is valid there and TH_ERR_UNSUPPORTED here) or memory runs out, the call
+ * setting cannot be planned (this library takes n_fft = next_pow2(win) * f_overlap up to TH_MAX_N_FFT with an odd factor
+ * of at most 63, which covers every window length the UI accepts and f_overlap = 3, 5, 6, ... since round 5; the reference's
+ * realfft takes any length, so e.g. f_overlap = 67 is valid there and TH_ERR_UNSUPPORTED here) or memory runs out, the call
  * fails and the manager — settings, plans,
  * specs, images, revisions — is exactly as before.  th_tm_add_tracks gives the same guarantee. */
 TH_API int th_tm_set_setting(th_tm *tm, double win_ms, uint32_t t_overlap, uint32_t f_overlap, int freq_scale);

@@ -146,6 +146,32 @@ static void rfft_f64(const float *x, size_t n_fft, float *out_ri, double *re, do
         for (size_t i = 0; i < n_fft; i++) { re[i] = (double)x[i]; im[i] = 0.0; }
         fft_c2c_f64(re, im, n_fft);
         for (size_t k = 0; k < F; k++) { out_ri[2 * k] = (float)re[k]; out_ri[2 * k + 1] = (float)im[k]; }
+    } else if (n_fft % 2 == 0 && n_fft >= 64) {
+        /* n_fft = M * odd, M a power of two (f_overlap = 3, 5, 6, ...: spectrogram.rs:66-72).  The same mathematical DFT in double,
+         * as `odd` interleaved sub-sequences: X[k] = sum_r W_N^{r k} F_r[k mod M], F_r = FFT_M(x[r], x[r + odd], ...) — O(N log N +
+         * odd N) instead of the O(N^2) of the direct sum below (which stays for small sizes and is what
+         * tests/test_oracle_numpy.py checks this branch against). */
+        size_t odd = n_fft, M = 1;
+        while (odd % 2 == 0) { odd /= 2; M *= 2; }
+        double *fr = (double *)malloc(sizeof(double) * 2 * n_fft);  /* F_r: re at [r * M ..], im at [n_fft + r * M ..] */
+        for (size_t r = 0; r < odd; r++) {
+            for (size_t m = 0; m < M; m++) { re[m] = (double)x[r + odd * m]; im[m] = 0.0; }
+            fft_c2c_f64(re, im, M);
+            memcpy(fr + r * M, re, sizeof(double) * M);
+            memcpy(fr + n_fft + r * M, im, sizeof(double) * M);
+        }
+        for (size_t k = 0; k < F; k++) {
+            double sr = 0.0, si = 0.0;
+            const size_t km = k % M;
+            for (size_t r = 0; r < odd; r++) {
+                const double ang = -2.0 * M_PI * (double)((r * k) % n_fft) / (double)n_fft;
+                const double wr = cos(ang), wi = sin(ang), ar = fr[r * M + km], ai = fr[n_fft + r * M + km];
+                sr += ar * wr - ai * wi;
+                si += ar * wi + ai * wr;
+            }
+            out_ri[2 * k] = (float)sr; out_ri[2 * k + 1] = (float)si;
+        }
+        free(fr);
     } else { /* direct DFT, any length (small sizes only) */
         for (size_t k = 0; k < F; k++) {
             double sr = 0.0, si = 0.0;

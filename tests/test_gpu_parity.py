@@ -128,10 +128,42 @@ def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
     plan.close()
 
 
+@pytest.mark.parametrize("sr,win_ms,t_overlap,f_overlap,scale", [(48000, 40.0, 4, 3, 0), (48000, 40.0, 4, 5, 1), (16000, 8.0, 2, 6, 0),
+                                                                  (8000, 2.0, 4, 7, 1), (48000, 170.0, 4, 3, 0), (48000, 0.05, 1, 3, 0)])
+def test_f_overlap_that_is_not_a_power_of_two(ctx, sr, win_ms, t_overlap, f_overlap, scale):
+    """SpecSetting::calc_framing_params (spectrogram.rs:66-72): n_fft = next_pow2(win) * f_overlap for ANY integer f_overlap, and
+    the reference's realfft plans any length.  No UI control offers f_overlap 3, 5, 6, 7 — the API accepts them: the generic
+    kernel takes the odd factor of Nc as one more Stockham pass (round 5; it was TH_ERR_UNSUPPORTED).  n_fft 6144, 10240, 768,
+    112, 49152 (global scratch), 12 against the oracle's f64 DFT on a ragged batch incl. a channel shorter than the window."""
+    hop, win, n_fft = ta.calc_framing_params(win_ms, t_overlap, f_overlap, sr)
+    assert n_fft & (n_fft - 1) and n_fft == (1 << (win - 1).bit_length()) * f_overlap
+    plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, 0)
+    assert plan.kernel_name == "stft_generic_kernel"
+    fb = orc.calc_mel_fb_default(sr, n_fft) if scale else None
+    lens = [3 * n_fft + 17, n_fft + 2 * hop + 1, max(2, win // 3), 5 * hop + 3] if n_fft <= 12288 else [2 * n_fft + 5, n_fft // 2]
+    wavs = [synth_track(900 + i, sr, n) for i, n in enumerate(lens)]
+    specs, mm = plan.calc_spec_batch(wavs)
+    for i, x in enumerate(wavs):
+        want, amp = orc.calc_spec(x, win, hop, n_fft, mel_fb=fb, return_amp=True)
+        assert specs[i].shape == want.shape
+        assert_spec_close(specs[i], want, amp if fb is None else None)
+        assert mm[i, 0] == specs[i].min() and mm[i, 1] == specs[i].max()
+    plan.close()
+    if (sr, f_overlap, scale) == (48000, 3, 0) and win_ms == 40.0:
+        # the same setting through the TrackManager mirror (set_spec_setting, lib.rs:257-266): planned, not refused
+        tm = ta.TrackManager(ctx)
+        tm.set_setting(win_ms, t_overlap, f_overlap, ta.LINEAR)
+        tm.add_tracks([(1, sr, wavs[0][None])])
+        tm.apply_track_list_changes()
+        assert tm.spec(1, 0).shape == specs[0].shape and np.array_equal(tm.spec(1, 0), specs[0])
+        tm.close()
+
+
 def test_transform_size_limits(ctx):
-    """powers of two from 2 to TH_MAX_N_FFT (2^20) are planned; everything else is TH_ERR_UNSUPPORTED, as is a mel plan whose
-    dense filterbank would not fit 1 GiB"""
-    for bad in (3, 6, 6144, 1 << 21):
+    """n_fft = 2^a * odd (a >= 1, odd <= 63) from 2 to TH_MAX_N_FFT (2^20) is planned — powers of two on the fast kernels, the
+    rest (f_overlap = 3, 5, 6, ...: round 5) on the generic kernel; everything else is TH_ERR_UNSUPPORTED, as is a mel plan
+    whose dense filterbank would not fit 1 GiB"""
+    for bad in (3, 2 * 67, 4096 * 65, 1 << 21):
         with pytest.raises(ta.ThError) as e:
             ta.Plan(ctx, 48000, min(bad, 2048), 512, bad, ta.LINEAR)
         assert e.value.code == -2
@@ -1093,7 +1125,7 @@ def test_lod_mip_pyramid_long_track(ctx):
 
 
 def test_track_manager_failed_setting_changes_nothing(ctx, golden_dir):
-    """a setting this library cannot plan (f_overlap = 3 -> n_fft not a power of two; the reference's realfft
+    """a setting this library cannot plan (f_overlap = 67 -> an odd factor the generic kernel does not take; the reference's realfft
     would take it) must fail WITHOUT touching the manager: settings, specs, images, db state, tiles and revisions are
     as before, and later calls keep working with the old setting."""
     cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
@@ -1105,7 +1137,7 @@ def test_track_manager_failed_setting_changes_nothing(ctx, golden_dir):
     tm.apply_track_list_changes()
     before = (tm.spec(7, 0).copy(), tm.img(7, 0).copy(), tm.db_state(), tm.revisions(), tm.get_spectrogram_tile(7, 0, 0, 0, 0, 0),
               tm.get_waveform_tile(7, 0, 3, 0))
-    for bad in [(40.0, 4, 3, ta.LINEAR), (40.0, 4, 5, ta.MEL)]:  # n_fft 6144, 10240: not powers of two
+    for bad in [(40.0, 4, 67, ta.LINEAR), (40.0, 4, 1024, ta.MEL)]:  # n_fft 2048 * 67 (odd factor > 63), 2^21 (> TH_MAX_N_FFT)
         with pytest.raises(ta.ThError) as e:
             tm.set_setting(*bad)
         assert e.value.code == -2, e.value

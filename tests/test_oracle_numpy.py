@@ -47,6 +47,19 @@ def test_three_segment_framing_equals_simple_formula(win, hop, n_fft):
         assert np.abs(got - want).max() <= 2e-6 * scale, (n, win, hop)
 
 
+@pytest.mark.parametrize("win,hop,n_fft", [(4, 1, 12), (16, 4, 48), (30, 10, 96), (64, 16, 192), (128, 32, 640), (1920, 480, 6144),
+                                           (1920, 480, 10240), (100, 25, 128 * 7), (512, 128, 512 * 63)])
+def test_oracle_dft_of_lengths_that_are_not_powers_of_two(win, hop, n_fft):
+    """f_overlap = 3, 5, 6, 7, 63 (spectrogram.rs:66-72): the oracle's DFT of n_fft = 2^a * odd — direct O(N^2) sum below 64
+    points, interleaved sub-transforms above — is the f64 DFT (numpy.fft.rfft)."""
+    rng = np.random.default_rng(n_fft)
+    x = rng.standard_normal(2 * n_fft + 3 * hop + 1).astype(np.float32)
+    got = orc.perform_stft(x, win, hop, n_fft)
+    want = numpy_stft(x, win, hop, n_fft)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+
+
 def test_frame_count_formula_sweep():
     for win in range(2, 40):
         for hop in range(1, win + 1):

@@ -450,8 +450,13 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
     // the UI accepts with f_overlap a power of two — winMillisec has a lower bound only (tracks.ts:205, Control.tsx:96-107),
     // so e.g. 400 ms at 48 kHz is n_fft 32768 and 1 ms at 4 kHz is n_fft 4.  (The reference's realfft takes any length: a
     // non-power-of-two n_fft needs f_overlap = 3, 5, ..., which no control offers.)
-    if (!is_pow2(n_fft) || n_fft < 2 || n_fft > TH_MAX_N_FFT)
-        return fail(TH_ERR_UNSUPPORTED, "n_fft=%zu: only powers of two in [2, %u] are supported", n_fft, (unsigned)TH_MAX_N_FFT);
+    // Round 5: n_fft = 2^a * odd with a >= 1 and odd <= 63 — f_overlap = 3, 5, 6, 7, ... (spectrogram.rs:66-72: n_fft =
+    // next_pow2(win) * f_overlap; no UI control offers them, the reference's realfft plans any length) run on the generic
+    // kernel, which takes the odd factor as one more Stockham pass.
+    size_t odd_part = n_fft;
+    while (odd_part > 1 && odd_part % 2 == 0) odd_part /= 2;
+    if (n_fft < 2 || n_fft % 2 != 0 || n_fft > TH_MAX_N_FFT || odd_part > 63)
+        return fail(TH_ERR_UNSUPPORTED, "n_fft=%zu: supported are 2^a * odd with a >= 1 and odd <= 63, up to %u", n_fft, (unsigned)TH_MAX_N_FFT);
     TH_HIP(hipSetDevice(c->device));
 
     th_plan *p = new th_plan();
@@ -464,7 +469,8 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
     g.n_fft = (uint32_t)n_fft;
     g.pad_left = (uint32_t)((n_fft - win) / 2);
     g.nc = (uint32_t)(n_fft / 2);
-    g.log2_nc = ilog2(g.nc);
+    g.odd_m1 = (uint32_t)odd_part - 1u;
+    g.log2_nc = ilog2(g.nc / (uint32_t)odd_part);  // log2 of the power-of-two part of nc
     g.n_freq = (uint32_t)(n_fft / 2 + 1);
     g.n_mel = 0;
     g.height = g.n_freq;

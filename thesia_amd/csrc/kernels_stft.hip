@@ -112,8 +112,14 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
             Ns = 2;
             cf32 *t = in; in = out; out = t;
         }
-        for (; Ns < g.nc; Ns <<= 2) {
+        const uint32_t odd = g.odd_m1 + 1u, n2 = g.nc / odd;  // nc = n2 * odd, n2 = 2^log2_nc
+        for (; Ns < n2; Ns <<= 2) {
             gen_pass_r4(tid, GEN_THREADS, g, Ns, tw, in, out);
+            __syncthreads();
+            cf32 *t = in; in = out; out = t;
+        }
+        if (odd > 1u) {  // f_overlap = 3, 5, 6, ... (spectrogram.rs:66-72): the odd factor as one more pass
+            gen_pass_odd(tid, GEN_THREADS, g, n2, odd, tw, in, out);
             __syncthreads();
             cf32 *t = in; in = out; out = t;
         }
@@ -1815,7 +1821,7 @@ bool stft_wave_supported(const StftGeom &g) {
     // n_fft 512 (multi-frame kernel) ... 4096 (one frame per wave), 8192 / 16384 / 32768 (block kernel); mel plans: fused
     // epilogue at n_fft 512 / 1024 / 2048 where the tables fit (at most 512 mels), else amplitude rows + a second kernel
     // (banded sums or the matrix cores: any mel count)
-    return g.log2_nc >= 8 && g.log2_nc <= 15;  // (15: n_fft 65536, the planar block plan of round 5)
+    return g.odd_m1 == 0 && g.log2_nc >= 8 && g.log2_nc <= 15;  // (15: n_fft 65536, the planar block plan of round 5; powers of two only)
 }
 bool stft_is_block_plan(const StftGeom &g) { return g.log2_nc >= 12; }
 bool stft_wave_multi_applies(const StftGeom &g, int out_mode) {

@@ -65,6 +65,10 @@ struct StftGeom {
     uint32_t n_mel;      // 0 = linear
     uint32_t frames_per_tile;
     uint32_t phased;     // wave kernel: 1 = frames are loaded from the 128-sample grid below their start (hop % 128 == 96)
+    // n_fft = next_pow2(win) * f_overlap (spectrogram.rs:66-72) is a power of two times an ODD factor when f_overlap is not a
+    // power of two (3, 5, 6, ...): nc = 2^log2_nc * (odd_m1 + 1).  0 for every power-of-two plan (round 5: the generic
+    // kernel takes the odd factor as one more Stockham pass; the wave / block kernels are power-of-two only)
+    uint32_t odd_m1;
 };
 
 // One frame range of one channel of the batch (device pointers).  A launch processes frames
@@ -173,6 +177,29 @@ TH_HD void gen_pass_r2(uint32_t tid, uint32_t nthr, const StftGeom &g, uint32_t 
     }
 }
 
+// Pass with an ODD radix R (round 5: the odd part of Nc as ONE pass, R <= 63; Ns = the power-of-two part already done):
+//   out[(j - k) R + k + c Ns] = sum_r in[j + r Nc / R] W_{Ns R}^{r k} W_R^{r c},   j < Nc / R, k = j mod Ns, c < R
+// One output element per loop trip (consecutive threads = consecutive j: the reads in[j + r Nc / R] are contiguous per r);
+// the two twiddles of a term are one table entry, W_{n_fft}^{r (k s1 + c s2)} with s1 = n_fft / (Ns R), s2 = n_fft / R.
+TH_HD void gen_pass_odd(uint32_t tid, uint32_t nthr, const StftGeom &g, uint32_t Ns, uint32_t R, const cf32 *tw,
+                        const cf32 *in, cf32 *out) {
+    const uint32_t nb = g.nc / R, s1 = g.n_fft / (Ns * R), s2 = g.n_fft / R;
+    for (uint32_t e = tid; e < g.nc; e += nthr) {
+        const uint32_t c = e / nb, j = e - c * nb, k = j % Ns;
+        const uint32_t step = (uint32_t)(((uint64_t)k * s1 + (uint64_t)c * s2) % g.n_fft);
+        cf32 acc = in[j];  // r = 0
+        uint32_t idx = 0;
+        for (uint32_t r = 1; r < R; r++) {
+            idx += step;
+            if (idx >= g.n_fft) idx -= g.n_fft;
+            const cf32 t = cmul(in[j + r * nb], tw[idx]);
+            acc.re += t.re;
+            acc.im += t.im;
+        }
+        out[(j - k) * R + k + c * Ns] = acc;
+    }
+}
+
 // Split pass of the packed real FFT: from Z (Nc-point FFT of x[2n] + i*x[2n+1]) to the magnitudes
 // of X[k] and X[Nc-k]:  E = (Z[k] + conj Z[Nc-k])/2, O = -i (Z[k] - conj Z[Nc-k])/2,
 // T = W_{n_fft}^k O;  X[k] = E + T,  X[Nc-k] = conj(E - T).
@@ -200,7 +227,7 @@ TH_HD void gen_split(uint32_t tid, uint32_t nthr, const StftGeom &g, const cf32 
     const uint32_t half = g.nc >> 1;
     for (uint32_t k = tid; k <= half; k += nthr) {
         const cf32 zk = z[k];
-        const cf32 zm = z[(g.nc - k) & (g.nc - 1)];
+        const cf32 zm = z[k ? g.nc - k : 0u];  // (Nc is not a power of two when f_overlap is not)
         float mk, mm;
         split_pair(zk, zm, tw[k], mk, mm);
         mag[k] = mk;
