@@ -454,6 +454,22 @@ __device__ __forceinline__ uint32_t pack_u16_sat(uint32_t lo, uint32_t hi) {  //
     return __builtin_bit_cast(uint32_t, p);
 }
 
+// Non-temporal hints (round 5): the kernel's three streams are each touched once — `nt` loads of the spec rows and `nt` stores of
+// the image rows and RGBA pieces: 0.732 -> 0.697 ms on a card where the instruction diet above had changed nothing (stores alone
+// 0.719; profiles/r05_ab_fused_image_cards.txt).  TH_FUSED_NT: 0 off, 1 stores, 2 stores + loads (default).
+#if !defined(TH_FUSED_NT)
+#define TH_FUSED_NT 2
+#endif
+typedef uint32_t th_u32x4 __attribute__((ext_vector_type(4)));
+typedef float th_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_spec4(gptr<const float> p) {  // 16-byte spec load, 16-byte aligned
+#if TH_FUSED_NT >= 2
+    const th_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<gptr<const th_f32x4>>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+#else
+    return *reinterpret_cast<gptr<const float4>>(p);
+#endif
+}
 template <bool LUT_IN_LDS>
 __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img_raster_kernel(
     const FusedJob *__restrict__ jobs, const uint32_t *__restrict__ block_job, uint8_t *const *__restrict__ tiles, float min_dB,
@@ -552,10 +568,10 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
                     v[i][q] = make_float4(-1.0f * (float)lane, -2.0f * f, -3.0f, -4.0f * fg);
                     if (min_dB == 12345.0f)
 #endif
-                    v[i][q] = *reinterpret_cast<gptr<const float4>>(rowp + voff);
+                    v[i][q] = ld_spec4(rowp + voff);
                 } else {
                     const uint32_t fc = min(sx + f + 4u * fg, W - 1u);
-                    v[i][q] = *reinterpret_cast<gptr<const float4>>(spec + ((size_t)fc * job.spec_pitch + b16));
+                    v[i][q] = ld_spec4(spec + ((size_t)fc * job.spec_pitch + b16));
                 }
             }
         // the eight gutter frames x FB bins: one 4-byte load per thread (a gutter the tile column does not have is never read
@@ -691,7 +707,11 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
 #if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 2)  // ablation build: no u16 image stores
                 if (reinterpret_cast<const uint4 *>(src)->x == 0x12345678u)
 #endif
+#if TH_FUSED_NT >= 1
+                __builtin_nontemporal_store(*reinterpret_cast<const th_u32x4 *>(src), reinterpret_cast<gptr<th_u32x4>>(dst));
+#else
                 *reinterpret_cast<gptr<uint4>>(dst) = *reinterpret_cast<const uint4 *>(src);
+#endif
             } else {
                 for (uint32_t k = 0; k < 8u && c + k < c_lim; k++) dst[k] = src[k];
             }
@@ -756,7 +776,11 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
 #if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 4)  // ablation build: no RGBA stores
                 if (o[u].x == 0x12345678u && o[u].y == 0x9abcdef0u)
 #endif
+#if TH_FUSED_NT >= 1
+                if (q < nq) __builtin_nontemporal_store(__builtin_bit_cast(th_u32x4, o[u]), reinterpret_cast<gptr<th_u32x4>>(dst) + q);
+#else
                 if (q < nq) dst[q] = o[u];
+#endif
             }
         }
     }

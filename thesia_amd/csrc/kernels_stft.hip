@@ -195,6 +195,16 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
 // 4*n_freq B written.
 // ------------------------------------------------------------------------------------------
 #define TH_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// Row stores of the wave kernel: TH_STFT_NT bit 0 = non-temporal stores (the rows are written once and read by a later kernel,
+// 1.5 GB behind), bit 1 = non-temporal sample loads.  A/B builds (profiles/r05_ab_stft_nt.txt); default 0.
+#if !defined(TH_STFT_NT)
+#define TH_STFT_NT 0
+#endif
+#if TH_STFT_NT & 1
+#define TH_ROW_STORE(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
+#else
+#define TH_ROW_STORE(PTR, VAL) (*(PTR) = (VAL))
+#endif
 // n_fft 2048: the packed-f32 pipeline (stft_pk.h, WaveFft<10>::*_pk) is template parameter PKV of wave_frame /
 // stft_wave_kernel.  Round 4 built it as VERDICT r3 asked (v_pk_fma_f32 butterflies on pairs: 417 VALU instructions per frame
 // instead of 681, 301 of them packed) and measured it against the scalar pipeline on one box, alternating, inside bench.py's
@@ -516,10 +526,10 @@ __device__ __forceinline__ void wave_frame(
             if constexpr (MELF) {
                 slab_f[kb + (uint32_t)kc] = power_to_amp_scaled(p);
             } else if constexpr (AMP) {
-                *row_at(kb, kc) = power_to_amp(p);
+                TH_ROW_STORE(row_at(kb, kc), power_to_amp(p));
             } else {
                 const float d = power_to_dB(p);
-                *row_at(kb, kc) = d;
+                TH_ROW_STORE(row_at(kb, kc), d);
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }
@@ -563,10 +573,10 @@ __device__ __forceinline__ void wave_frame(
             if constexpr (MELF) {
                 slab_f[kb + (uint32_t)kc] = power_to_amp_scaled(p);  // the slab is free after the second exchange: amplitude row for mel_pieces
             } else if constexpr (AMP) {
-                *row_at(kb, kc) = power_to_amp(p);
+                TH_ROW_STORE(row_at(kb, kc), power_to_amp(p));
             } else {
                 const float d = power_to_dB(p);
-                *row_at(kb, kc) = d;
+                TH_ROW_STORE(row_at(kb, kc), d);
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }

@@ -1206,7 +1206,11 @@ template <int P, int M0, class WavPtr>
 TH_HD void wave_fetch(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0) {
     TH_UNROLL for (int m = M0; m < P; m++) {
         const WavPtr p = wav + (e0 + 2 * (int64_t)(lane + 64u * m));  // two adjacent dwords: one 8-byte load
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TH_STFT_NT) && (TH_STFT_NT & 2)
+        x[m] = {__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1)};
+#else
         x[m] = {p[0], p[1]};
+#endif
     }
 }
 
@@ -1233,7 +1237,11 @@ template <int P, int S, int OFF, class WavPtr>
 TH_HD void wave_fetch_rot(uint32_t lane, cf32 (&x)[P], WavPtr wav, int64_t e0_next) {
     TH_UNROLL for (int i = 0; i < S; i++) {
         const WavPtr p = wav + (e0_next + 2 * (int64_t)(lane + 64u * (P - S + i)));
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TH_STFT_NT) && (TH_STFT_NT & 2)
+        x[(OFF + i) % P] = {__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1)};
+#else
         x[(OFF + i) % P] = {p[0], p[1]};
+#endif
     }
 }
 template <int P, int OFF>
