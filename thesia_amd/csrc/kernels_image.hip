@@ -460,6 +460,19 @@ __device__ __forceinline__ uint32_t pack_u16_sat(uint32_t lo, uint32_t hi) {  //
 #if !defined(TH_FUSED_NT)
 #define TH_FUSED_NT 2
 #endif
+// Raw buffer operations for the three streams of the regular path (round 5): the address is "resource (SGPRs) + scalar offset +
+// 32-bit lane offset" — no 64-bit vector address arithmetic — and the cache bits are free to choose: loads `nt` (aux 2), stores
+// `nt sc1` (aux 18: write through and do not keep the line).  Card 692537016606: plain 0.735 ms, `nt` global operations 0.650-0.678,
+// buffer operations nt / nt 0.652, nt / nt sc1 0.640, nt sc1 / nt sc1 0.636, sc1 alone 0.696 (profiles/r05_ab_fused_image_cards.txt).
+#if !defined(TH_FUSED_BUF)
+#define TH_FUSED_BUF 1
+#endif
+#if !defined(TH_FUSED_LD_AUX)
+#define TH_FUSED_LD_AUX 2
+#endif
+#if !defined(TH_FUSED_ST_AUX)
+#define TH_FUSED_ST_AUX 18
+#endif
 typedef uint32_t th_u32x4 __attribute__((ext_vector_type(4)));
 typedef float th_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_spec4(gptr<const float> p) {  // 16-byte spec load, 16-byte aligned
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
     // Packed path (block-uniform): 16-byte loads, the reciprocal quantiser, four frames of a bin as one ds_write_b64.
     // REGULAR block: every core frame and every bin of the band exists — no clamps, no selects.  EDGE block (the last tile
     // column, the last band, an image shorter than the band): frames clamped into the image, results outside it zeroed.
-    const bool packed = fastq && al16 && job.spec_pitch <= (1u << 24) && nrows > 0;
+    const bool packed = fastq && al16 && job.spec_pitch <= (1u << 20) && nrows > 0;
     const bool regular = core == 512u && nrows == FB && job.i_start + r0 + FB <= job.height;
     auto read_packed = [&](auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
@@ -556,6 +569,12 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
         const uint32_t b16 = EDGE ? min(bin0, job.spec_pitch - 4u) : bin0;
         const uint32_t voff = (4u * fg) * job.spec_pitch + (b16 - (job.i_start + r0));  // elements; 28 * pitch * 4 B < 2^31
         const gptr<const float> b0 = spec + (size_t)sx * job.spec_pitch + (job.i_start + r0);
+#if TH_FUSED_BUF
+        // (the block's corner of the spec as a buffer resource: 64-bit base in SGPRs, 32-bit offsets — spec_pitch <= 2^20 in the
+        // packed path, so 544 rows x 4 MiB stay below 2^32)
+        const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(job.spec + ((size_t)sx * job.spec_pitch + (job.i_start + r0))), 0, -1, 0x00020000);
+        (void)b0;
+#endif
         float4 v[NIT][4];
 #pragma unroll
         for (uint32_t i = 0; i < NIT; i++)
@@ -568,7 +587,16 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
                     v[i][q] = make_float4(-1.0f * (float)lane, -2.0f * f, -3.0f, -4.0f * fg);
                     if (min_dB == 12345.0f)
 #endif
+#if TH_FUSED_BUF  // raw buffer load: scalar row offset + per-lane offset, `nt`
+                    {
+                        const th_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_spec, voff * 4u, f * (job.spec_pitch * 4u), TH_FUSED_LD_AUX);
+                        // (scalar copies first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 for every element)
+                        const uint32_t t0 = t.x, t1 = t.y, t2 = t.z, t3 = t.w;
+                        v[i][q] = make_float4(__builtin_bit_cast(float, t0), __builtin_bit_cast(float, t1), __builtin_bit_cast(float, t2), __builtin_bit_cast(float, t3));
+                    }
+#else
                     v[i][q] = ld_spec4(rowp + voff);
+#endif
                 } else {
                     const uint32_t fc = min(sx + f + 4u * fg, W - 1u);
                     v[i][q] = ld_spec4(spec + ((size_t)fc * job.spec_pitch + b16));
@@ -694,6 +722,11 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
     const uint32_t t_lim = (job.img_pitch % IMG_TILE_T == 0 && job.img_pitch - W < IMG_TILE_T) ? job.img_pitch : W;
     const uint32_t c_lim = min(t_lim - sx, 512u);  // columns of this tile column to write (the last column: up to the pitch)
     const bool img_al = (reinterpret_cast<uintptr_t>(job.img) & 15u) == 0 && job.img_pitch % 8u == 0;
+#if TH_FUSED_BUF
+    // (the band's corner of the image as a buffer resource; 32 rows x img_pitch x 2 bytes below 2^32)
+    const bool img_buf = job.img_pitch <= (1u << 24);
+    const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(job.img + ((size_t)r0 * job.img_pitch + sx), 0, -1, 0x00020000);
+#endif
 #if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 32)  // ablation build: no image-row phase
     if (min_dB == 12345.0f)
 #endif
@@ -707,7 +740,11 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
 #if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 2)  // ablation build: no u16 image stores
                 if (reinterpret_cast<const uint4 *>(src)->x == 0x12345678u)
 #endif
-#if TH_FUSED_NT >= 1
+#if TH_FUSED_BUF
+                if (img_buf) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const th_u32x4 *>(src), rs_img, (r * job.img_pitch + c) * 2u, 0, TH_FUSED_ST_AUX);
+                else
+                    __builtin_nontemporal_store(*reinterpret_cast<const th_u32x4 *>(src), reinterpret_cast<gptr<th_u32x4>>(dst));
+#elif TH_FUSED_NT >= 1
                 __builtin_nontemporal_store(*reinterpret_cast<const th_u32x4 *>(src), reinterpret_cast<gptr<th_u32x4>>(dst));
 #else
                 *reinterpret_cast<gptr<uint4>>(dst) = *reinterpret_cast<const uint4 *>(src);
@@ -736,6 +773,10 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
         const uint32_t qpr = wt >> 2, nq = nrows * qpr;
         const uint32_t r_top = oy + ht - 1u - (r0 + nrows - 1u);  // tile row of the band's LAST image row = the piece's first row
         const gptr<uint4> dst = reinterpret_cast<gptr<uint4>>(as_global(reinterpret_cast<uint32_t *>(tb0)) + (size_t)r_top * wt);
+#if TH_FUSED_BUF
+        const __amdgpu_buffer_rsrc_t rs_rgba = __builtin_amdgcn_make_buffer_rsrc(tb0 + (size_t)r_top * wt * 4u, 0, -1, 0x00020000);
+        (void)dst;
+#endif
         const uint32_t dj = FUSED_THREADS / qpr, dc = FUSED_THREADS % qpr;  // block-uniform
         // The piece starts wherever its first row starts: at a multiple of 16 bytes, k quads into a 128-byte line.  Quads are
         // dealt to the lanes in LINE-ALIGNED order — lane t of round m takes quad qa - k of the piece, qa = t + THREADS m —
@@ -776,7 +817,9 @@ __global__ __launch_bounds__(FUSED_THREADS, TH_FUSED_MIN_WAVES) void spec_to_img
 #if defined(TH_FUSED_ABL) && (TH_FUSED_ABL & 4)  // ablation build: no RGBA stores
                 if (o[u].x == 0x12345678u && o[u].y == 0x9abcdef0u)
 #endif
-#if TH_FUSED_NT >= 1
+#if TH_FUSED_BUF
+                if (q < nq) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(th_u32x4, o[u]), rs_rgba, q * 16u, 0, TH_FUSED_ST_AUX);
+#elif TH_FUSED_NT >= 1
                 if (q < nq) __builtin_nontemporal_store(__builtin_bit_cast(th_u32x4, o[u]), reinterpret_cast<gptr<th_u32x4>>(dst) + q);
 #else
                 if (q < nq) dst[q] = o[u];
