@@ -439,6 +439,38 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
         plan.close()
 
 
+@pytest.mark.parametrize("sr,win,hop,n_fft,n_mel", [(48000, 1920, 480, 2048, 0), (44100, 2048, 512, 2048, 128), (48000, 2048, 1024, 2048, 0),
+                                                    (48000, 2048, 256, 2048, 256), (32000, 1280, 320, 2048, 0), (48000, 2048, 512, 2048, 40)])
+def test_mel_frame_pair_epilogue(ctx, sr, win, hop, n_fft, n_mel):
+    """Round 5: the fused mel epilogue of the n_fft 2048 wave kernel takes the frames of a chunk in PAIRS — the first frame's
+    amplitudes wait in registers, the second frame's epilogue runs the banded sums for both rows in one pass over the table
+    (stft_wave_kernel<.., OUT = 3>, mel_banded_pair); a chunk that ends on a first frame is finished by the one-frame sums.
+    Selector 13 keeps the one-frame epilogue: both against the oracle, and bit-identical to each other (the sums are formed in
+    the same order) on a ragged batch — chunks of even and odd length, boundary frames (one-frame chunks), a two-frame track,
+    silence."""
+    want_n_mel = n_mel or orc.mel_default_n_mel(sr, n_fft)
+    fb = orc.calc_mel_fb(sr, n_fft, want_n_mel)
+    lens = (sr * 2 + 123, 9 * n_fft + 7 * hop + 11, n_fft + hop, n_fft, 61 * hop + n_fft, 62 * hop + n_fft)
+    wavs = [synth_track(40 + i, sr, n) for i, n in enumerate(lens)] + [np.zeros(5 * n_fft, np.float32)]
+    pair, single = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel), ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
+    single.set_kernel(13)
+    assert pair.kernel_name == single.kernel_name == "stft_wave_kernel(fused mel)"
+    a, mma = pair.calc_spec_batch(wavs)
+    b, mmb = single.calc_spec_batch(wavs)
+    for i, (w, sa, sb) in enumerate(zip(wavs, a, b)):
+        assert sa.shape == sb.shape and sa.shape[1] == want_n_mel
+        assert np.array_equal(sa, sb), f"track {i}: frame pairs differ from the one-frame epilogue"
+        assert mma[i, 0] == mmb[i, 0] == sa.min() and mma[i, 1] == mmb[i, 1] == sa.max()
+        if i == len(wavs) - 1:
+            assert np.all(np.isneginf(sa))
+            continue
+        assert_spec_close(sa, orc.calc_spec(w, win, hop, n_fft, mel_fb=fb))
+        one, _, _ = pair.calc_spec(w)  # a single-track launch cuts shorter chunks: other pairings, same rows
+        assert np.array_equal(one, sa)
+    pair.close()
+    single.close()
+
+
 def test_packed_f32_pipeline_matches_oracle_and_scalar_pipeline(ctx):
     """th_plan_set_kernel(plan, 9): the n_fft 2048 wave kernel on register pairs (v_pk_fma_f32 butterflies, stft_pk.h; built
     in round 4 as the lever VERDICT r3 named — it measures the same as the scalar pipeline, which stays the default).  Same

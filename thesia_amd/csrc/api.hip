@@ -650,6 +650,7 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
                     p->mel_bsum_words = (uint32_t)mb.words.size();
                     std::copy(mb.words.begin(), mb.words.begin() + 16, p->mel_bsum_hdr);
                     p->mel_bsum_groups = mb.n_groups;
+                    p->mel_bsum_reach = mb.reach;
                     rc = up((void **)&p->d_mel_bsum, mb.words.data(), mb.words.size() * sizeof(uint32_t));
                 }
             }
@@ -703,9 +704,10 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     // schedule (4-frame chunks dealt out in order) on large batches of that same shape (A/B; elsewhere as 2; 10 is reserved: as 2),
     // 12 mel plans at n_fft 4096: the banded sums in the FFT kernel's epilogue with the table read from global memory, on the
     // launch shapes it is instantiated for (hop 1024, the 96 / 88.2 kHz defaults; A/B: slower than the two kernels; elsewhere as 2);
+    // 13 fused mel epilogue one frame at a time where the frame-pair form is the default (n_fft 2048 banded sums; A/B; elsewhere as 2);
     // bits 8-15 (tuning): waves per workgroup
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 12, "kernel selector must be 0 .. 12");
+    TH_REQUIRE(k >= 0 && k <= 13, "kernel selector must be 0 .. 13");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     // the multi-frame plans (n_fft 512; n_fft 1024 under selector 6) are instantiated for 8, 12 and 16 waves only
@@ -1023,6 +1025,8 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
                 wo.band_n[gq] = p->mel_bsum_hdr[2 * gq + 1];
             }
             wo.n_mel = g.n_mel;
+            // frame pairs (round 5): two consecutive frames per pass over the table; selector 13 keeps the one-frame epilogue (A/B)
+            wo.mel_pair = (p->kernel_choice != 13 && th::stft_wave_mel_pair_applies(g, p->wave_waves, p->mel_bsum_reach)) ? 1u : 0u;
         } else if (mel_fused) {
             wo.mel_tab = p->d_mel_fuse;
             wo.mel_words = p->mel_fuse_words;

@@ -67,7 +67,13 @@ struct WaveOut {
     // banded sums (mel_slots == 0, build_mel_band): the table's header again, as kernel arguments (scalar registers instead
     // of two LDS reads + v_readfirstlane per group and frame): block offset and taps of group g
     uint32_t band_off[8] = {0, 0, 0, 0, 0, 0, 0, 0}, band_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // banded sums, n_fft 2048: 1 = the frame-pair epilogue (two consecutive frames of a chunk share one pass over the table:
+    // stft_wave_kernel<.., OUT = 3>; the host sets it where stft_wave_mel_pair_applies says so)
+    uint32_t mel_pair = 0;
 };
+// the frame-pair form of the banded mel epilogue exists for this launch (n_fft 2048, hop a multiple of 128 samples or no register
+// reuse at all, default waves) and the table's reads stay inside the two amplitude rows a slab holds (reach: MelBandHost::reach)
+bool stft_wave_mel_pair_applies(const StftGeom &g, int waves, uint32_t reach);
 // pieces the per-wave (r, f) buffer of the fused mel epilogue can hold for this n_fft (0: not supported), and whether
 // the launch shape leaves room in LDS for a table of `words`
 int stft_wave_phased_mode(const StftGeom &g, int waves);  // 0 no, 1 phased (hop 480), 2 dynamic (e.g. 441)

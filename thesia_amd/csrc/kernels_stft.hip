@@ -359,7 +359,13 @@ constexpr uint32_t MEL_PRF_1024 = 512;  // pieces of the per-wave (r, f) buffer 
 // frame is requested in full — all P slots from (nwav, ne0) — where a frame otherwise requests the slots its successor in
 // the chunk needs: after the window multiply every slot is dead in a chunk's last frame, so the next chunk starts without an
 // exposed fetch and without an extra register.
-template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH = -1, bool PKV = false, bool SWEEPF = false>
+// MELP (OUT == 3, the frame-pair mel epilogue): 1 = first frame of a pair — its amplitudes stay in registers (ampA, in the split
+// pass's emit order) and nothing is written; 2 = second frame — its own amplitudes go to the second row of the slab, the first
+// frame's from ampA to the first row, and one pass over the banded table (mel_banded_pair) forms both frames' mel rows.  A chunk
+// that ends on a first frame is finished by wave_mel_flush.
+constexpr int MEL_PAIR_RB = 1092;     // float offset of the second amplitude row in the slab (n_fft 2048: 2176 floats; even, >= Nc + 1 + 64)
+constexpr uint32_t MEL_PAIR_PAD = 59;  // zeros behind the second row: 2176 - (1092 + 1025)
+template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH = -1, bool PKV = false, bool SWEEPF = false, int MELP = 0>
 __device__ __forceinline__ void wave_frame(
     const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
     uint32_t f, uint32_t f1, gptr<const float> wav, uint32_t n_samples, gptr<float> spec, uint32_t spec_pitch, cf32 (&x)[WaveFft<LOG2_NC>::P],
@@ -367,9 +373,12 @@ __device__ __forceinline__ void wave_frame(
     const cf32 (&rwa)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::NT3],
     const cf32 (&rwb)[(RES & 4) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::NT3],
     const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], cf32 rw_mid, float &lmin, float &lmax,
-    const uint32_t *meltab, cf32 *mel_prf, const WaveOut &wo, bool nxt_full = false, gptr<const float> nwav = nullptr,
-    int64_t ne0 = 0) {
-    constexpr bool AMP = OUT == 1, MELF = OUT == 2;
+    const uint32_t *meltab, cf32 *mel_prf, const WaveOut &wo, float (&ampA)[OUT == 3 ? WaveFft<LOG2_NC>::N_EMIT : 1], bool nxt_full = false,
+    gptr<const float> nwav = nullptr, int64_t ne0 = 0) {
+    constexpr bool AMP = OUT == 1, MELF = OUT == 2 || OUT == 3;
+    static_assert((OUT == 3) == (MELP != 0), "frame pairs: OUT = 3 with MELP = 1 (first frame) or 2 (second)");
+    static_assert(OUT != 3 || (LOG2_NC == 10 && !PKV && 2 * (int)WaveFft<LOG2_NC>::SLAB_LEN >= MEL_PAIR_RB + WaveFft<LOG2_NC>::NC + 1 + (int)MEL_PAIR_PAD),
+                  "frame pairs: n_fft 2048, scalar pipeline, two amplitude rows per slab");
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
     // Per-frame opaque copy of the lane id.  Everything below addresses LDS and the output row as
@@ -569,9 +578,12 @@ __device__ __forceinline__ void wave_frame(
         auto row_at = [&](uint32_t kb, int kc) -> gptr<float> {
             return (gptr<float>)((gptr<char>)row + (uint64_t)(kb << 2) + (int64_t)(4 * kc));
         };
+        int amp_i = 0;  // (a constant at every call once the split pass is unrolled)
         auto emit = [&](uint32_t kb, int kc, float p) {
-            if constexpr (MELF) {
-                slab_f[kb + (uint32_t)kc] = power_to_amp_scaled(p);  // the slab is free after the second exchange: amplitude row for mel_pieces
+            if constexpr (MELP == 1) {
+                ampA[amp_i++ % (OUT == 3 ? W::N_EMIT : 1)] = power_to_amp_scaled(p);  // first frame of a pair: kept for the second one's epilogue
+            } else if constexpr (MELF) {
+                slab_f[(MELP == 2 ? (uint32_t)MEL_PAIR_RB : 0u) + kb + (uint32_t)kc] = power_to_amp_scaled(p);  // the slab is free after the second exchange: amplitude row for mel_pieces
             } else if constexpr (AMP) {
                 TH_ROW_STORE(row_at(kb, kc), power_to_amp(p));
             } else {
@@ -613,7 +625,48 @@ __device__ __forceinline__ void wave_frame(
         W::split_sw(sl, z, z256, stw, emit);
     }
     }  // (scalar pipeline)
-    if constexpr (MELF) {
+    if constexpr (MELP == 2) {
+        // frame pair: this frame's amplitudes are in the slab's second row; lay the first frame's (f - 1) out as the first row,
+        // zeros behind both rows, then one pass over the banded table for both (mel_banded_pair, stft_wave.h)
+        float *const slab_f = reinterpret_cast<float *>(slab);
+        {
+            int k = 0;
+            W::split_enumerate(lane, [&](uint32_t kb, int kc) { slab_f[kb + (uint32_t)kc] = ampA[k++ % W::N_EMIT]; });
+        }
+        slab_f[NC + 1 + lane] = 0.0f;  // [Nc + 1, Nc + 65) < MEL_PAIR_RB
+        if (lane < MEL_PAIR_PAD) slab_f[MEL_PAIR_RB + NC + 1 + lane] = 0.0f;
+        wave_lds_sync();
+        const gptr<float> row_a = row - spec_pitch;
+        float mn = __builtin_inff(), mx = -__builtin_inff();  // of the pair's rows (values fresh from an FMA: no canonicalising per group)
+        auto emit_a = [&](uint32_t m, float v) {
+            if (m < wo.n_mel) {
+                const float d = amp_to_dB_fast(v);
+                row_a[m] = d;
+                mn = nmin(mn, d);
+                mx = nmax(mx, d);
+            }
+        };
+        auto emit_b = [&](uint32_t m, float v) {
+            if (m < wo.n_mel) {
+                const float d = amp_to_dB_fast(v);
+                row[m] = d;
+                mn = nmin(mn, d);
+                mx = nmax(mx, d);
+            }
+        };
+#if defined(TH_MELF_ABL) && (TH_MELF_ABL & 1)
+        if (wo.n_mel == 0x7fffffffu)
+#endif
+        mel_banded_pair<MEL_PAIR_RB>(lane, slab_f, meltab, wo.mel_groups, wo.band_off, wo.band_n, emit_a, emit_b);
+        lmin = nmin(lmin, mn);
+        lmax = nmax(lmax, mx);
+        wave_lds_sync();  // the next frame's pass 1 rewrites the slab
+        const uint32_t pad = spec_pitch - wo.n_mel;  // complete both rows' last 128-byte line (see below)
+        if (lane - 1u < ((pad < 32u && spec_pitch % 32u == 0) ? pad : 0u)) {
+            row_a[wo.n_mel - 1u + lane] = 0.0f;
+            row[wo.n_mel - 1u + lane] = 0.0f;
+        }
+    } else if constexpr (MELF && MELP == 0) {
         // fused mel filterbank (stft_wave.h / mel_fuse.h): the frame's amplitudes sit in the wave's slab; pieces of 4 bins
         // -> (r, f) partial sums -> one mel per lane and group; the (r, f) buffer sits behind the amplitude row
         float *const slab_f = reinterpret_cast<float *>(slab);
@@ -627,6 +680,9 @@ __device__ __forceinline__ void wave_frame(
                 lmax = nmax(lmax, d);
             }
         };
+#if defined(TH_MELF_ABL) && (TH_MELF_ABL & 1)  // ablation build: no filterbank sums (rows unwritten) — what the epilogue costs
+        if (wo.n_mel == 0x7fffffffu)
+#endif
         if (wo.mel_slots == 0) {  // wave-uniform: banded sums, lane = mel (mel_banded, stft_wave.h; table: build_mel_band)
             // the filters of a group reach up to its widest one's width past their own end: zeros behind the row
             static_assert(2 * (int)W::SLAB_LEN >= NC + 1 + 128, "room for the zeros behind the amplitude row");
@@ -650,12 +706,46 @@ __device__ __forceinline__ void wave_frame(
     // Rows at the library's padded pitch (th_pitch_f32): bin Nc would be the only dword written in its 128-byte line, and
     // a partially written line costs HBM a read-modify-write (scripts/ubench/row_stores.hip: 3.9 -> 5.4 TB/s for this row
     // shape).  The padding is ours, so complete the line with zeros.
-    {
+    if constexpr (MELP == 0) {
         const uint32_t height = MELF ? wo.n_mel : (uint32_t)(NC + 1);
         const uint32_t pad = spec_pitch - height;
         if (lane - 1u < ((pad < 32u && spec_pitch % 32u == 0) ? pad : 0u)) row[height - 1u + lane] = 0.0f;
     }
     TH_SCHED_BARRIER();
+}
+
+// Frame pairs (OUT == 3): a chunk ended on the first frame of a pair — frame f's amplitudes are in ampA.  Lay them out as a row
+// and run the one-frame banded sums (what wave_frame<.., OUT = 2> does behind its split pass).
+template <int LOG2_NC>
+__device__ __forceinline__ void wave_mel_flush(cf32 *slab, uint32_t lane_wave, uint32_t f, gptr<float> spec, uint32_t spec_pitch,
+                                               const float (&ampA)[WaveFft<LOG2_NC>::N_EMIT], float &lmin, float &lmax, const uint32_t *meltab,
+                                               const WaveOut &wo) {
+    using W = WaveFft<LOG2_NC>;
+    constexpr int NC = W::NC;
+    uint32_t lane = lane_wave;
+    asm volatile("" : "+v"(lane));
+    lane &= 63u;
+    float *const slab_f = reinterpret_cast<float *>(slab);
+    const gptr<float> row = spec + (size_t)f * spec_pitch;
+    {
+        int k = 0;
+        W::split_enumerate(lane, [&](uint32_t kb, int kc) { slab_f[kb + (uint32_t)kc] = ampA[k++ % W::N_EMIT]; });
+    }
+    slab_f[NC + 1 + lane] = 0.0f;
+    slab_f[NC + 65 + lane] = 0.0f;
+    wave_lds_sync();
+    auto emit_mel = [&](uint32_t m, float v) {
+        if (m < wo.n_mel) {
+            const float d = amp_to_dB_fast(v);
+            row[m] = d;
+            lmin = nmin(lmin, d);
+            lmax = nmax(lmax, d);
+        }
+    };
+    mel_banded<true>(lane, slab_f, meltab, wo.mel_groups, wo.band_off, wo.band_n, emit_mel);
+    wave_lds_sync();
+    const uint32_t pad = spec_pitch - wo.n_mel;
+    if (lane - 1u < ((pad < 32u && spec_pitch % 32u == 0) ? pad : 0u)) row[wo.n_mel - 1u + lane] = 0.0f;
 }
 
 // SHIFT = hop/128 register slots reused between consecutive frames (0 = no reuse: hop not a
@@ -721,7 +811,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     uint32_t *meltab = reinterpret_cast<uint32_t *>(slabs + (size_t)WAVES * W::SLAB_LEN);  // OUT == 2 only
     // (the banded mel table's paired layout is read with ds_read_b128, the amplitude row in the slab with ds_read_b64: the
     // table and every slab start on 16 bytes — all lengths in front of them are even numbers of 8-byte entries)
-    static_assert(OUT != 2 || ((NC + WPAD + (STW_IN_LDS ? STW_LEN : 0) + (T2_IN_LDS ? W::T2_LEN : 0) + W::T3_LEN) % 2 == 0 && W::SLAB_LEN % 2 == 0),
+    static_assert((OUT != 2 && OUT != 3) || ((NC + WPAD + (STW_IN_LDS ? STW_LEN : 0) + (T2_IN_LDS ? W::T2_LEN : 0) + W::T3_LEN) % 2 == 0 && W::SLAB_LEN % 2 == 0),
                   "mel table and slabs 16-byte aligned");
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -826,7 +916,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     if constexpr (STW_IN_LDS && PKP) W::fill_stwp(tid, 64 * WAVES, tw, stw);
     for (uint32_t i = tid; i < WPAD; i += 64 * WAVES) wtab[i] = wtab_g[i];
     W::fill_tables(tid, 64 * WAVES, tw, T2_IN_LDS ? t2 : nullptr, t3);
-    if constexpr (OUT == 2 && LOG2_NC != 11)  // (n_fft 4096 reads the banded table from global memory: mel_banded_global)
+    if constexpr ((OUT == 2 || OUT == 3) && LOG2_NC != 11)  // (n_fft 4096 reads the banded table from global memory: mel_banded_global)
         for (uint32_t i = tid; i < wo.mel_words; i += 64 * WAVES) meltab[i] = wo.mel_tab[i];
     __syncthreads();
 
@@ -850,10 +940,12 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     // slots reused / rotation offset / window table of body ROT
 #define TH_BODY_SHIFT(ROT) (PHASED ? ((ROT) == 0 ? 3 : 4) : DYN ? DYN_K : SHIFT)
 #define TH_BODY_OFF(ROT) (PHASED ? ((ROT) == 0 ? 0 : 4 * (ROT) - 1) : (ROTATE ? (ROT) * SHIFT : 0))
-#define TH_FRAME(ROT)                                                                                                  \
-    wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : DYN_EVEN ? -3 : DYN ? -2 : -1, PKV>( \
+#define TH_FRAME_P(ROT, MELP)                                                                                          \
+    wave_frame<LOG2_NC, TH_BODY_SHIFT(ROT), OUT, ROTATE, TH_BODY_OFF(ROT), RESK, PHASED ? (ROT) : DYN_EVEN ? -3 : DYN ? -2 : -1, PKV, false, (MELP)>( \
         g, wtab + (PHASED ? WPAD - ((96 * (ROT)) & 127) / 2 : 0), stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
-        lmax, meltab, mel_prf, wo)
+        lmax, meltab, mel_prf, wo, amp_a)
+#define TH_FRAME(ROT) TH_FRAME_P(ROT, 0)
+    float amp_a[OUT == 3 ? W::N_EMIT : 1];  // frame pairs: the first frame's amplitudes (wave_frame, MELP)
     // per-lane constant tables kept in registers for the whole launch (see wave_frame)
     cf32 rw[(RESK & 1) ? P : 1], rw2[(RESK & 2) ? W::NT2 : 1];
     cf32 rwa[(RESK & 4) ? W::NQ : 1][W::NT3], rwb[(RESK & 4) ? W::NQ : 1][W::NT3], rws[(RESK & 8) ? W::NQ : 1][W::R3];
@@ -877,7 +969,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #define TH_FRAME_SW(ROT, FULL)                                                                                         \
     wave_frame<LOG2_NC, SHIFT, OUT, true, (ROT) * SHIFT, RESK, -1, PKV, FULL>(                                          \
         g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin, \
-        lmax, meltab, mel_prf, wo, true, nwav, ne0)
+        lmax, meltab, mel_prf, wo, amp_a, true, nwav, ne0)
 #define TH_SW_NEXT() (nxt = cursor_next(g, jobs, chunk_tab, n_tiles, sweep_draw(), cur))
         while (sch.cur.valid) {
             const FrameCursor cur = sch.cur;
@@ -918,7 +1010,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
                 for (;;) {
                     wave_frame<LOG2_NC, 0, OUT, false, 0, RESK, -1, PKV>(
                         g, wtab, stw, t2, t3, slab, lane_wave, f, cur.f1, cur.wav, cur.n_samples, cur.spec, cur.spec_pitch, x, rw, rw2, rwa, rwb, rws, rw_mid, lmin,
-                        lmax, meltab, mel_prf, wo);
+                        lmax, meltab, mel_prf, wo, amp_a);
                     if (++f >= cur.f1) break;
                 }
                 TH_SW_NEXT();
@@ -949,6 +1041,34 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         // s_setprio 0..NROT-1 from frame to frame made all waves advance at the same pace (5.4 / 5.7 / 6.0 us) — and the
         // launch 1.5 % slower: the sum of the rates is what counts, the dynamic chunk queue already absorbs the different
         // speeds, and the kernel is bound by its total work, not by its tail.  Measured in round 2, not kept.)
+        if constexpr (OUT == 3) {
+            // frame pairs: bodies alternate first / second frame (rotation index as below); a chunk that ends on a first frame
+            // is finished by wave_mel_flush
+            static_assert(OUT != 3 || (!PHASED && !DYN && (NROT == 1 || NROT == 2 || NROT == 4)), "frame pairs: plain or rotating frame loop");
+            bool pending;
+            for (;;) {
+                TH_SCHED_PULL(sch, f, lane);
+                TH_FRAME_P(0, OUT == 3 ? 1 : 0);
+                pending = true;
+                if (++f >= cur.f1) break;
+                TH_SCHED_PULL(sch, f, lane);
+                TH_FRAME_P(NROT > 1 ? 1 : 0, OUT == 3 ? 2 : 0);
+                pending = false;
+                if (++f >= cur.f1) break;
+                if constexpr (NROT > 2) {
+                    TH_SCHED_PULL(sch, f, lane);
+                    TH_FRAME_P(NROT > 2 ? 2 : 0, OUT == 3 ? 1 : 0);
+                    pending = true;
+                    if (++f >= cur.f1) break;
+                    TH_SCHED_PULL(sch, f, lane);
+                    TH_FRAME_P(NROT > 2 ? 3 : 0, OUT == 3 ? 2 : 0);
+                    pending = false;
+                    if (++f >= cur.f1) break;
+                }
+            }
+            if constexpr (OUT == 3)
+                if (pending) wave_mel_flush<LOG2_NC>(slab, lane_wave, f - 1, cur.spec, cur.spec_pitch, amp_a, lmin, lmax, meltab, wo);
+        } else
         for (;;) {
             TH_SCHED_PULL(sch, f, lane);
             TH_FRAME(0);
@@ -990,6 +1110,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
     }
 #undef TH_FETCH_FIRST
 #undef TH_FRAME
+#undef TH_FRAME_P
 #undef TH_BODY_SHIFT
 #undef TH_BODY_OFF
 }
@@ -1909,7 +2030,7 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
         }
     }
     if (out.sweep != 0 && !sweep) return hipErrorInvalidValue;  // (the host only asks for it where it exists)
-    const size_t lds = (pkv ? wave_lds_bytes<LOG2_NC, WAVES, true>() : wave_lds_bytes<LOG2_NC, WAVES, false>()) + (sweep ? 128 : 0) + (OUT == 2 && LOG2_NC != 11 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
+    const size_t lds = (pkv ? wave_lds_bytes<LOG2_NC, WAVES, true>() : wave_lds_bytes<LOG2_NC, WAVES, false>()) + (sweep ? 128 : 0) + ((OUT == 2 || OUT == 3) && LOG2_NC != 11 ? (size_t)((out.mel_words + 1u) & ~1u) * 4 : 0) +
                        (OUT == 2 && LOG2_NC == 9 && out.mel_slots != 0 ? (size_t)WAVES * MEL_PRF_1024 * sizeof(cf32) : 0) +  // (pieces / gather only)
                        (SHIFT == -1 ? 48 * sizeof(cf32) : 0) +  // phased: zero pairs in front of the window table
                        (SHIFT <= -48 ? 0 : SHIFT <= -16 ? (WaveFft<LOG2_NC>::NC + 128) * sizeof(cf32) : 0);  // dynamic: second table + two prefixes (even offsets only: neither)
@@ -1942,6 +2063,14 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
                                                                         d_tw, nullptr, d_queue_head, n_cu, out, s);
         }
         // (n_fft 4096, round 5: the banded table from global memory, for hop 1024 and the 96 / 88.2 kHz defaults — stft_wave_mel_fits)
+        // (round 5: frame pairs — two consecutive frames per pass over the banded table; n_fft 2048, plain or rotating frame loop)
+        if constexpr (LOG2_NC == 10 && SHIFT >= 0) {
+            if (out.mode == 2 && out.mel_pair != 0) {
+                if (out.mel_slots != 0) return hipErrorInvalidValue;  // (banded sums only)
+                return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 3>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
+                                                                        d_tw, d_minmax, d_queue_head, n_cu, out, s);
+            }
+        }
         if constexpr (LOG2_NC <= 10 || (LOG2_NC == 11 && (SHIFT == 8 || SHIFT == -48 - 7 || SHIFT == -48 - 6))) {
             if (out.mode == 2)
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
@@ -2110,6 +2239,12 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool bande
         return pm == 3 && (g.hop / 128 == 7 || g.hop / 128 == 6);
     }
     return false;
+}
+bool stft_wave_mel_pair_applies(const StftGeom &g, int waves, uint32_t reach) {
+    if (g.log2_nc != 10 || g.phased != 0) return false;
+    if (!(waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES)) return false;
+    // the launch shapes launch_wave_t3 instantiates for non-negative SHIFT: hop = n_fft / 4, / 2, / 8 (rotation) and "no reuse"
+    return reach <= g.n_freq + MEL_PAIR_PAD;  // reads stay inside the zeros behind each of the two amplitude rows
 }
 // (the same sum as launch_wave_multi_n; ADVICE r3: without this check a small growth of SLAB_LEN or MEL_ROWS_W would turn the
 // default path into hipErrorInvalidValue at launch instead of the two-kernel fallback)

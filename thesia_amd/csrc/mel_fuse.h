@@ -155,6 +155,7 @@ struct MelBandHost {
     std::vector<uint32_t> words;
     uint32_t n_groups = 0, max_taps = 0;
     uint32_t taps_unshifted = 0;  // sum over the groups of their widest filter (rounded to 4), before the bank spreading below
+    uint32_t reach = 0;  // one past the highest bin index any lane reads: max over the groups of (first bin + the group's taps)
     bool ok = false;
 };
 constexpr uint32_t MEL_BAND_MAX_GROUPS = 8, MEL_BAND_HDR = 2 * MEL_BAND_MAX_GROUPS, MEL_BAND_MAX_TAPS = 128;
@@ -310,6 +311,7 @@ inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_m
             }
             const uint32_t first = lo[m] - shift[lane];
             t[off + lane] = first;
+            out.reach = std::max(out.reach, first + n);
             for (uint32_t k = lo[m]; k < hi[m]; k++) {
                 const uint32_t tap = k - first;
                 const size_t at = paired ? off + 64 + ((size_t)(tap / 4) * 64 + lane) * 4 + tap % 4 : off + 64 * (size_t)(1 + tap) + lane;

@@ -983,6 +983,26 @@ struct WaveFft {
         load_stw_paired(lane, ws, stw);
         split_paired_w(lane, za, zb, ws, stw[NC / 2], emit);
     }
+    // The bins of split_paired_w's emit calls, in its order: fn(base, C) once per call (the last one, bin Nc / 2, on lane 0 only).
+    // The frame-pair mel epilogue keeps a frame's amplitudes in registers in emit order and lays them out as a row one frame later.
+    static constexpr int N_EMIT = 2 * NQ * R3 + 1;
+    template <class Fn>
+    static TH_HD void split_enumerate(uint32_t lane, Fn fn) {
+        const bool l0 = (lane & 63u) == 0;
+        const SplitBase sb = split_base(lane);
+        TH_UNROLL for (int q = 0; q < NQ; q++) {
+            TH_UNROLL for (int s = 0; s < R3; s++) {
+                if (q == 0 && s >= R3 / 2) {
+                    fn(sb.hi, (s - R3 / 2) * NS3);
+                    fn(sb.mhi, (R3 - 1 - s) * NS3);
+                } else {
+                    fn(sb.lo, 64 * q + s * NS3);
+                    fn(sb.mlo, CMAX - (64 * q + s * NS3));
+                }
+            }
+        }
+        if (l0) fn((uint32_t)NC / 2, 0);
+    }
 
     // -----------------------------------------------------------------------------------------
     // Packed-f32 pipeline of the n_fft 2048 plane plan (round 4; arithmetic: stft_pk.h).  Same LDS layouts, same lane ->
@@ -1486,6 +1506,96 @@ TH_HD void mel_banded(uint32_t lane, const float *amp, const uint32_t *tab, uint
             }
             emit(64u * g + lane, (acc[0] + acc[1]) + (acc[2] + acc[3]));
             }
+        }
+    }
+}
+
+// Two frames at once (round 5, the frame-pair epilogue of stft_wave_kernel<.., OUT = 3>): amp[] holds the first frame's amplitude
+// row, amp[RB ..] the second one's.  A group's first bins, its weight quads and the loop around them are read / run once for both
+// frames — at the 48 kHz default (347 mels, 72 taps) the sums are 72 of the single-frame epilogue's ~250 vector instructions per
+// frame, the rest is per group.  Paired table layout only; the sums of each frame are formed in mel_banded's order (bit-identical).
+// All LDS addresses are 32-bit (cast first, then index) and every read keeps program order (volatile).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(3))) float *lds_cfp;
+#define TH_TO_LDS_CFP(p) ((lds_cfp)(p))
+TH_HD f32x4 ldsp_ld4(lds_cfp p) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *(const volatile __attribute__((address_space(3))) u32x4 *)(p);
+    const uint32_t x = v.x, y = v.y, z = v.z, w = v.w;
+    return {__builtin_bit_cast(float, x), __builtin_bit_cast(float, y), __builtin_bit_cast(float, z), __builtin_bit_cast(float, w)};
+}
+TH_HD cf32 ldsp_ld2(lds_cfp p) {
+    const uint64_t v = *(const volatile __attribute__((address_space(3))) uint64_t *)(p);
+    return {__builtin_bit_cast(float, (uint32_t)v), __builtin_bit_cast(float, (uint32_t)(v >> 32))};
+}
+#else
+typedef const float *lds_cfp;
+#define TH_TO_LDS_CFP(p) (p)
+TH_HD f32x4 ldsp_ld4(lds_cfp p) { return {p[0], p[1], p[2], p[3]}; }
+TH_HD cf32 ldsp_ld2(lds_cfp p) { return {p[0], p[1]}; }
+#endif
+template <int RB, class EmitA, class EmitB>
+TH_HD void mel_banded_pair(uint32_t lane, const float *amp, const uint32_t *tab, uint32_t n_groups, const uint32_t (&off)[8],
+                           const uint32_t (&n)[8], EmitA emitA, EmitB emitB) {
+    uint32_t lo[8];  // every group's first bin up front: one LDS round trip for all of them
+    TH_UNROLL for (uint32_t g = 0; g < 8; g++) lo[g] = tab[off[g < n_groups ? g : 0] + lane];
+    const lds_cfp amp3 = TH_TO_LDS_CFP(amp), tab3 = TH_TO_LDS_CFP(reinterpret_cast<const float *>(tab)) + 4u * lane;
+    TH_UNROLL for (uint32_t g = 0; g < 8; g++) {
+        if (g < n_groups) {  // wave-uniform
+            lds_cfp ap = amp3 + lo[g];
+            lds_cfp wp = tab3 + (off[g] + 64u);
+            float sa[4], sb[4];
+            {
+                const f32x4 w = ldsp_ld4(wp);
+                const cf32 a01 = ldsp_ld2(ap), a23 = ldsp_ld2(ap + 2), b01 = ldsp_ld2(ap + RB), b23 = ldsp_ld2(ap + RB + 2);
+                sa[0] = a01.re * w.a;
+                sa[1] = a01.im * w.b;
+                sa[2] = a23.re * w.c;
+                sa[3] = a23.im * w.d;
+                sb[0] = b01.re * w.a;
+                sb[1] = b01.im * w.b;
+                sb[2] = b23.re * w.c;
+                sb[3] = b23.im * w.d;
+            }
+            ap += 4;
+            wp += 256;
+            uint32_t t = 4;
+            for (; t + 8 <= n[g]; t += 8, ap += 8, wp += 512) {
+                const f32x4 w0 = ldsp_ld4(wp), w1 = ldsp_ld4(wp + 256);
+                cf32 a[4], b[4];
+                TH_UNROLL for (uint32_t u = 0; u < 4; u++) a[u] = ldsp_ld2(ap + 2u * u);
+                TH_UNROLL for (uint32_t u = 0; u < 4; u++) b[u] = ldsp_ld2(ap + RB + 2u * u);
+                sa[0] = fma_rn(a[0].re, w0.a, sa[0]);
+                sa[1] = fma_rn(a[0].im, w0.b, sa[1]);
+                sa[2] = fma_rn(a[1].re, w0.c, sa[2]);
+                sa[3] = fma_rn(a[1].im, w0.d, sa[3]);
+                sb[0] = fma_rn(b[0].re, w0.a, sb[0]);
+                sb[1] = fma_rn(b[0].im, w0.b, sb[1]);
+                sb[2] = fma_rn(b[1].re, w0.c, sb[2]);
+                sb[3] = fma_rn(b[1].im, w0.d, sb[3]);
+                sa[0] = fma_rn(a[2].re, w1.a, sa[0]);
+                sa[1] = fma_rn(a[2].im, w1.b, sa[1]);
+                sa[2] = fma_rn(a[3].re, w1.c, sa[2]);
+                sa[3] = fma_rn(a[3].im, w1.d, sa[3]);
+                sb[0] = fma_rn(b[2].re, w1.a, sb[0]);
+                sb[1] = fma_rn(b[2].im, w1.b, sb[1]);
+                sb[2] = fma_rn(b[3].re, w1.c, sb[2]);
+                sb[3] = fma_rn(b[3].im, w1.d, sb[3]);
+            }
+            if (t < n[g]) {  // (n is a multiple of 4)
+                const f32x4 w = ldsp_ld4(wp);
+                const cf32 a01 = ldsp_ld2(ap), a23 = ldsp_ld2(ap + 2), b01 = ldsp_ld2(ap + RB), b23 = ldsp_ld2(ap + RB + 2);
+                sa[0] = fma_rn(a01.re, w.a, sa[0]);
+                sa[1] = fma_rn(a01.im, w.b, sa[1]);
+                sa[2] = fma_rn(a23.re, w.c, sa[2]);
+                sa[3] = fma_rn(a23.im, w.d, sa[3]);
+                sb[0] = fma_rn(b01.re, w.a, sb[0]);
+                sb[1] = fma_rn(b01.im, w.b, sb[1]);
+                sb[2] = fma_rn(b23.re, w.c, sb[2]);
+                sb[3] = fma_rn(b23.im, w.d, sb[3]);
+            }
+            emitA(64u * g + lane, (sa[0] + sa[1]) + (sa[2] + sa[3]));
+            emitB(64u * g + lane, (sb[0] + sb[1]) + (sb[2] + sb[3]));
         }
     }
 }
