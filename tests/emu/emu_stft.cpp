@@ -374,6 +374,46 @@ extern "C" __attribute__((visibility("default"))) int emu_mel_fuse(const float *
     return 0;
 }
 
+// Frame pairs (mel_banded_pair, round 5): two amplitude rows RB floats apart, one pass over the paired table; out_a / out_b[m] and
+// (every lane's result, also those past the last mel) the extremes over all lanes in mm[0..3] = min a, max a, min b, max b — the
+// kernel folds every lane into its min / max because lanes past the last mel repeat the last filter.  reach = MelBandHost::reach.
+extern "C" __attribute__((visibility("default"))) int emu_mel_band_pair(const float *amp_a, const float *amp_b, const float *fb, uint32_t n_freq,
+                                                                         uint32_t n_mel, float *out_a, float *out_b, float *mm, uint32_t *reach) {
+    constexpr int RB = 1092;
+    const MelBandHost h = build_mel_band(fb, n_freq, n_mel, 1u << 16, true, true);
+    if (!h.ok) return 1;
+    *reach = h.reach;
+    if (n_freq > RB - 64 || h.reach > n_freq + 59) return 2;
+    std::vector<float> a(2 * RB + 64, NAN);  // (NaN wherever the kernel guarantees nothing)
+    for (uint32_t k = 0; k < n_freq; k++) {
+        a[k] = amp_a[k];
+        a[RB + k] = amp_b[k];
+    }
+    for (uint32_t k = 0; k < 64; k++) a[n_freq + k] = 0.0f;   // the zeros wave_frame writes behind the rows
+    for (uint32_t k = 0; k < 59; k++) a[RB + n_freq + k] = 0.0f;
+    uint32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t g = 0; g < h.n_groups; g++) {
+        off[g] = h.words[2 * g];
+        nt[g] = h.words[2 * g + 1];
+    }
+    mm[0] = mm[2] = INFINITY;
+    mm[1] = mm[3] = -INFINITY;
+    for (uint32_t l = 0; l < 64; l++)
+        mel_banded_pair<RB>(
+            l, a.data(), h.words.data(), h.n_groups, off, nt,
+            [&](uint32_t m, float v) {
+                mm[0] = std::fmin(mm[0], v);
+                mm[1] = std::fmax(mm[1], v);
+                if (m < n_mel) out_a[m] = v;
+            },
+            [&](uint32_t m, float v) {
+                mm[2] = std::fmin(mm[2], v);
+                mm[3] = std::fmax(mm[3], v);
+                if (m < n_mel) out_b[m] = v;
+            });
+    return 0;
+}
+
 // The same product as banded sums, lane = mel (build_mel_band + mel_banded): out[m] = the filter outputs (linear).
 // layout: 0 = first bins as the filters start, 1 = spread over the LDS banks, 2 = the paired layout (even first bins, weights
 // in quads).  info[0..4] = table words, groups, widest group's taps, all groups' taps, LDS cycles of one frame's amplitude reads

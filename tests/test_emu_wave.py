@@ -184,6 +184,35 @@ def test_banded_mel_epilogue_matches_the_dense_product(emu, sr, n_fft, n_mel):
                             info.ctypes.data_as(u32p)) == 1
 
 
+@pytest.mark.parametrize("sr,n_fft,n_mel", [(48000, 2048, 0), (44100, 2048, 128), (44100, 2048, 0), (32000, 2048, 0), (48000, 2048, 100),
+                                            (48000, 2048, 321)])
+def test_banded_mel_frame_pairs_match_the_one_frame_sums(emu, sr, n_fft, n_mel):
+    """mel_banded_pair (round 5: two amplitude rows, one pass over the paired table) == mel_banded on each row, bit for bit, and the
+    extremes over ALL 64 lanes of every group equal the extremes over the real mels (lanes past the last mel repeat the last
+    filter, so the kernel masks only their stores)."""
+    M = n_mel or orc.mel_default_n_mel(sr, n_fft)
+    fb = np.ascontiguousarray(orc.calc_mel_fb(sr, n_fft, M), np.float32)
+    F = n_fft // 2 + 1
+    rng = np.random.default_rng(11)
+    f32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    emu.emu_mel_band.argtypes = [f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p]
+    emu.emu_mel_band_pair.argtypes = [f32p, f32p, f32p, C.c_uint32, C.c_uint32, f32p, f32p, f32p, u32p]
+    for trial in range(3):
+        amps = [(rng.uniform(0, 1, F) * 10.0 ** rng.uniform(-6, 0, F)).astype(np.float32) for _ in range(2)]
+        pair = [np.empty(M, np.float32) for _ in range(2)]
+        mm, reach = np.zeros(4, np.float32), np.zeros(1, np.uint32)
+        rc = emu.emu_mel_band_pair(amps[0].ctypes.data_as(f32p), amps[1].ctypes.data_as(f32p), fb.ctypes.data_as(f32p), F, M,
+                                   pair[0].ctypes.data_as(f32p), pair[1].ctypes.data_as(f32p), mm.ctypes.data_as(f32p), reach.ctypes.data_as(u32p))
+        assert rc == 0, (rc, reach)
+        assert F <= reach[0] + 64 and reach[0] <= F + 59
+        for i in range(2):
+            one, info = np.empty(M, np.float32), np.zeros(5, np.uint32)
+            assert emu.emu_mel_band(amps[i].ctypes.data_as(f32p), fb.ctypes.data_as(f32p), F, M, 1 << 16, 2, one.ctypes.data_as(f32p),
+                                    info.ctypes.data_as(u32p)) == 0
+            assert np.array_equal(one, pair[i])
+            assert mm[2 * i] == one.min() and mm[2 * i + 1] == one.max()
+
+
 def test_fused_mel_tables_refuse_what_is_not_a_triangle_filterbank(emu):
     """build_mel_fuse (mel_fuse.h) verifies the structure it relies on and reports "not fusable" (the plan then keeps the
     matrix-core path) for: a dense matrix, three filters at one bin, two non-neighbouring filters at one bin, segments

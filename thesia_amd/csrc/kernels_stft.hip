@@ -638,21 +638,19 @@ __device__ __forceinline__ void wave_frame(
         wave_lds_sync();
         const gptr<float> row_a = row - spec_pitch;
         float mn = __builtin_inff(), mx = -__builtin_inff();  // of the pair's rows (values fresh from an FMA: no canonicalising per group)
+        // (lanes past the last mel repeat the last filter — build_mel_band — so every lane's value may enter min / max; only the
+        // store is masked)
         auto emit_a = [&](uint32_t m, float v) {
-            if (m < wo.n_mel) {
-                const float d = amp_to_dB_fast(v);
-                row_a[m] = d;
-                mn = nmin(mn, d);
-                mx = nmax(mx, d);
-            }
+            const float d = amp_to_dB_fast(v);
+            mn = nmin(mn, d);
+            mx = nmax(mx, d);
+            if (m < wo.n_mel) row_a[m] = d;
         };
         auto emit_b = [&](uint32_t m, float v) {
-            if (m < wo.n_mel) {
-                const float d = amp_to_dB_fast(v);
-                row[m] = d;
-                mn = nmin(mn, d);
-                mx = nmax(mx, d);
-            }
+            const float d = amp_to_dB_fast(v);
+            mn = nmin(mn, d);
+            mx = nmax(mx, d);
+            if (m < wo.n_mel) row[m] = d;
         };
 #if defined(TH_MELF_ABL) && (TH_MELF_ABL & 1)
         if (wo.n_mel == 0x7fffffffu)
@@ -1044,7 +1042,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
         if constexpr (OUT == 3) {
             // frame pairs: bodies alternate first / second frame (rotation index as below); a chunk that ends on a first frame
             // is finished by wave_mel_flush
-            static_assert(OUT != 3 || (!PHASED && !DYN && (NROT == 1 || NROT == 2 || NROT == 4)), "frame pairs: plain or rotating frame loop");
+            static_assert(OUT != 3 || (NROT == 1 || NROT == 2 || NROT == 4), "frame pairs: an even number of frame bodies per cycle");
             bool pending;
             for (;;) {
                 TH_SCHED_PULL(sch, f, lane);
@@ -1064,6 +1062,12 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
                     TH_FRAME_P(NROT > 2 ? 3 : 0, OUT == 3 ? 2 : 0);
                     pending = false;
                     if (++f >= cur.f1) break;
+                }
+                if constexpr (PHASED) {  // (as below: one slot move restores rotation 0)
+                    const cf32 t = x[P - 1];
+#pragma unroll
+                    for (int m = P - 1; m > 0; m--) x[m] = x[m - 1];
+                    x[0] = t;
                 }
             }
             if constexpr (OUT == 3)
@@ -2064,7 +2068,7 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
         }
         // (n_fft 4096, round 5: the banded table from global memory, for hop 1024 and the 96 / 88.2 kHz defaults — stft_wave_mel_fits)
         // (round 5: frame pairs — two consecutive frames per pass over the banded table; n_fft 2048, plain or rotating frame loop)
-        if constexpr (LOG2_NC == 10 && SHIFT >= 0) {
+        if constexpr (LOG2_NC == 10) {
             if (out.mode == 2 && out.mel_pair != 0) {
                 if (out.mel_slots != 0) return hipErrorInvalidValue;  // (banded sums only)
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 3>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
@@ -2241,7 +2245,7 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool bande
     return false;
 }
 bool stft_wave_mel_pair_applies(const StftGeom &g, int waves, uint32_t reach) {
-    if (g.log2_nc != 10 || g.phased != 0) return false;
+    if (g.log2_nc != 10) return false;  // (any frame loop of n_fft 2048: plain, rotating, phased, dynamic)
     if (!(waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES)) return false;
     // the launch shapes launch_wave_t3 instantiates for non-negative SHIFT: hop = n_fft / 4, / 2, / 8 (rotation) and "no reuse"
     return reach <= g.n_freq + MEL_PAIR_PAD;  // reads stay inside the zeros behind each of the two amplitude rows

@@ -304,12 +304,11 @@ inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_m
         t[2 * g + 1] = n;
         t.resize(off + 64 * (size_t)(1 + n), 0);
         for (uint32_t lane = 0; lane < 64; lane++) {
-            const uint32_t m = 64 * g + lane;
-            if (m >= n_mel) {  // zero weights; the address of the half's first lane, so that it is served by the same broadcast
-                t[off + lane] = t[off + (lane & 32u)];
-                continue;
-            }
-            const uint32_t first = lo[m] - shift[lane];
+            // lanes past the last mel repeat the group's last filter (same addresses: served by the same broadcast; same sums: a
+            // kernel may fold every lane's result into its min / max and mask only the store — round 5, mel_banded_pair's caller)
+            const uint32_t src = 64 * g + lane < n_mel ? lane : n_mel - 1 - 64 * g;
+            const uint32_t m = 64 * g + src;
+            const uint32_t first = lo[m] - shift[src];
             t[off + lane] = first;
             out.reach = std::max(out.reach, first + n);
             for (uint32_t k = lo[m]; k < hi[m]; k++) {
