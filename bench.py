@@ -738,6 +738,7 @@ def main():
                  ("cfg1_batch", "cfg1 shape, batch: n_fft 1024 / hop 256, linear dB", wl.wav, 48000, (1024, 256, 1024, ta.LINEAR, 0), 0),
                  ("app_default_linear", "app default framing (40 ms, t_overlap 4): 48 kHz, 1920 / 480 / 2048, linear dB", wl.wav, 48000, (1920, 480, 2048, ta.LINEAR, 0), 0),
                  ("app_default_mel", "app default, mel scale (the app's own default: 347 mels)", wl.wav, 48000, (1920, 480, 2048, ta.MEL, 0), 0),
+                 ("app_default_mel_one_frame_epilogue", "app default, mel scale, the fused epilogue one frame at a time (selector 13: round 4's form; the default takes frame pairs)", wl.wav, 48000, (1920, 480, 2048, ta.MEL, 0), 13),
                  ("overlap2", "40 ms, t_overlap 2: 1920 / 960 / 2048, linear dB", wl.wav, 48000, (1920, 960, 2048, ta.LINEAR, 0), 0),
                  ("overlap8", "40 ms, t_overlap 8: 1920 / 240 / 2048, linear dB", wl.wav, 48000, (1920, 240, 2048, ta.LINEAR, 0), 0),
                  ("overlap16", "40 ms, t_overlap 16: 1920 / 120 / 2048, linear dB", wl.wav, 48000, (1920, 120, 2048, ta.LINEAR, 0), 0),
