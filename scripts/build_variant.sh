@@ -9,11 +9,11 @@ cd "$(dirname "$0")/../thesia_amd/csrc"
 srcs=${VARIANT_SOURCES:-kernels_stft.hip}
 obj=../../build/obj   # __graft_entry__.build()'s object cache
 objs=""
-for f in api.hip track_manager.hip kernels_stft.hip kernels_mel.hip kernels_image.hip kernels_waveform.hip host_math.cpp tile_cache.cpp; do
+for f in api.hip track_manager.hip kernels_stft.hip kernels_stft_long.hip kernels_mel.hip kernels_image.hip kernels_waveform.hip host_math.cpp tile_cache.cpp; do
   if [[ " $srcs " == *" $f "* ]]; then
     extra=""
     case $f in
-      kernels_stft.hip) extra="-fno-slp-vectorize";;
+      kernels_stft.hip|kernels_stft_long.hip) extra="-fno-slp-vectorize";;
       kernels_image.hip|kernels_waveform.hip) extra="-ffp-contract=off";;
     esac
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden $extra "$@" -c $f -o $obj/${f}_$tag.o

@@ -103,6 +103,7 @@ struct th_plan {
     // the same epilogue as banded sums, lane = mel (build_mel_band): the default where its table fits; selector 8 keeps the pieces
     uint32_t *d_mel_bsum = nullptr;
     uint32_t mel_bsum_words = 0, mel_bsum_groups = 0, mel_bsum_hdr[16] = {};  // (header: offset and taps per group)
+    th::cf32 *d_twc = nullptr;  // n_fft 32768: the combining pass's per-thread constants (kernels_stft_long.hip)
     uint32_t mel_bsum_reach = 0;  // one past the highest amplitude index the banded sums read (MelBandHost::reach)
     bool mel_bsum_fits() const;
     th::DeviceTable jobs, tile_start;            // main launch: jobs + first chunk of every job (generic kernel) or the

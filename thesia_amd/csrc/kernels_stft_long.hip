@@ -1,0 +1,365 @@
+// kernels_stft_long.hip — n_fft 32768 as SIXTEEN WAVE TRANSFORMS plus one combining pass (round 5).
+//
+// stft_block_kernel (kernels_stft.hip / stft_block.h) runs the long transforms as four radix-16 Stockham passes of one workgroup
+// with the whole frame in LDS between them: ten workgroup barriers per frame, 512 threads (two waves per SIMD), nothing to
+// overlap a barrier or a fetch with — 18 us per frame where its arithmetic is 4 (profiles/r04_block_phase_prof.txt: barriers
+// 34 %, fetch 23 %; 0.17 of the HBM roofline).  Here the same 16384-point complex transform is decimated in time ONCE,
+//
+//     Z[k2 + 1024 k1] = sum_{n1 < 16} W_16384^(n1 k2) W_16^(n1 k1)  S_n1[k2],     S_n1 = DFT_1024 of z[n1 + 16 n2],
+//
+// and the sixteen 1024-point transforms S_n1 are exactly what the n_fft 2048 wave kernel does per frame: wave n1 of the
+// workgroup runs WaveFft<10>'s three register passes with its two plane exchanges through a slab of its own — no workgroup
+// barrier, sixteen waves (four per SIMD) drifting past each other as in the wave kernel.  What needs the workgroup:
+//   (0) the frame reaches the slabs transposed: thread t loads the windowed points t + 1024 j (coalesced), all of which belong
+//       to sub-transform t mod 16, column t / 16 — precisely the sixteen inputs one lane of that wave's first pass owns;
+//   (2) the combining pass: thread t = k2 reads S_n1[t] from the sixteen slabs and runs BlockFft<14>'s last pass (the same
+//       twiddled radix-16 FMA butterfly, ten constants per thread);
+//   (3) the real-FFT split pass needs Z[Nc - k]: Z goes through LDS once more (over the slabs), as in the block kernel.
+// Five barriers per frame, each between phases that every wave reaches at about the same time.  Arithmetic, twiddles, window and
+// output are the block kernel's (same tables, same butterflies): the results agree with it to rounding.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "stft_block.h"
+#include "stft_core.h"
+#include "stft_wave.h"
+
+namespace th {
+
+namespace {
+
+__device__ __forceinline__ float nmin_l(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float nmax_l(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float wave_min_l(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = nmin_l(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_l(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = nmax_l(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// orders this wave's LDS writes before its later LDS reads for the compiler (the hardware runs one wave's DS operations in order)
+__device__ __forceinline__ void wave_lds_sync_l() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup barrier for LDS traffic only.  __syncthreads() is a release / acquire fence over ALL address spaces: s_waitcnt vmcnt(0)
+// in front of the s_barrier, i.e. every wave waits for its row stores of the previous frame (and for the next frame's samples) to
+// complete before it may even arrive — thousands of cycles per barrier (scripts/subwave_prof.py).  The phases below only hand LDS
+// data to each other; global memory is never shared between the threads of a launch.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+constexpr int SUB_LOG2 = 10;                       // the sub-transform: WaveFft<10>, 1024 complex points, one wave
+using SW = WaveFft<SUB_LOG2>;
+constexpr int SUB_STRIDE = SW::SLAB_LEN + 2;       // cf32 per slab: 16-byte aligned, and consecutive slabs four banks apart (phase 0's scatter)
+
+template <bool AMP>
+__global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab,
+                                                            uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw,
+                                                            const cf32 *__restrict__ twc, float *__restrict__ minmax) {
+    using B = BlockFft<14>;
+    constexpr int NC = B::NC, T = B::T, R = 16;
+    static_assert(T == 1024 && NC == R * SW::NC && B::NS_C == SW::NC, "sixteen 1024-point sub-transforms, combined by the block plan's last pass");
+    static_assert(SW::PLANES && SW::PAIRED && SW::NQ == 2 && SW::R3 == 4, "the n_fft 2048 plane plan");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf32 *const t2 = reinterpret_cast<cf32 *>(smem_raw);
+    cf32 *const t3 = t2 + SW::T2_LEN;
+    float *const red = reinterpret_cast<float *>(t3 + SW::T3_LEN);  // 2 x 16 floats
+    cf32 *const slabs = reinterpret_cast<cf32 *>(red + 32);          // 16 slabs; Z (Nc + 1 slots) lies over them in phase 3
+    static_assert((SW::T2_LEN + SW::T3_LEN) % 2 == 0 && SUB_STRIDE % 2 == 0, "slabs 16-byte aligned");
+    static_assert(R * SUB_STRIDE >= NC + 1, "Z fits over the slabs");
+
+    const uint32_t t = threadIdx.x, lane_w = t & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    // Persistent workgroups: chunk blockIdx.x, then every gridDim.x-th (the chunks of a launch are equally long but for the
+    // channels' tails).  A workgroup of 1024 threads with 145 KB of LDS starts only when its predecessor on the CU has gone, and its
+    // set-up (tables, first frame) is three dependent memory round trips: 34 of the 142 us an 8-frame chunk took (scripts/subwave_prof.py).
+    uint32_t ct = blockIdx.x;
+    if (ct >= n_tiles) return;
+
+    // sub-transform tables: W_2048^i = tw[16 i] (tw = W_{n_fft}^i, n_fft = 2 Nc = 32768)
+    constexpr uint32_t TS = (uint32_t)(NC / SW::NC);
+    for (uint32_t i = t; i < (uint32_t)SW::T2_LEN; i += 1024u) t2[i] = tw[TS * SW::t2_index(i / SW::NS2, i % SW::NS2)];
+    for (uint32_t i = t; i < (uint32_t)SW::T3_LEN; i += 1024u) {
+        const uint32_t r = i / SW::NS3 + 1, k = i % SW::NS3;
+        t3[i] = tw[TS * ((r * k) * (2u * SW::NC / (SW::NS3 * SW::R3)))];
+    }
+    const cf32 stw_t = tw[t];  // the split twiddle of bin t
+    __syncthreads();
+
+    cf32 *const slab = slabs + (size_t)wv * SUB_STRIDE;
+    // the frame stream of this workgroup: (chunk, frame) -> next frame of the chunk, else the first frame of the next chunk
+    struct Cur {
+        uint32_t ct, f, f1, spec_pitch;
+        gptr<const float> wav;
+        gptr<float> spec;
+        bool valid;
+    };
+    auto open_chunk = [&](uint32_t c) -> Cur {
+        Cur k{};
+        k.valid = c < n_tiles;
+        if (k.valid) {
+            const uint32_t chan = chunk_tab[2 * (size_t)c];
+            k.ct = c;
+            k.f = chunk_tab[2 * (size_t)c + 1];
+            k.f1 = min(k.f + g.frames_per_tile, jobs[chan].f_end);
+            k.spec_pitch = jobs[chan].spec_pitch;
+            k.wav = as_global(jobs[chan].wav);
+            k.spec = as_global(jobs[chan].spec);
+        }
+        return k;
+    };
+    auto next_of = [&](const Cur &c) -> Cur {
+        if (c.f + 1 < c.f1) {
+            Cur k = c;
+            k.f = c.f + 1;
+            return k;
+        }
+        return open_chunk(c.ct + gridDim.x);
+    };
+    float lmin = __builtin_inff(), lmax = -__builtin_inff();
+    // (addresses as "uniform base of piece j (SGPRs) + 8 tid": no per-thread 64-bit pointers to keep or spill)
+    // raw samples (points tid + 1024 j) and window pairs of the frame being staged: locals of ONE loop iteration (loop-carried they
+    // would stay live through the sub-transform: the first build spilled them to scratch right behind their loads)
+    auto fetch = [&](const Cur &c, uint32_t tid, cf32 (&x)[16]) {
+        const int64_t e0 = (int64_t)c.f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;  // interior frames: the whole span is inside the channel
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+#if !(defined(TH_SUBW_ABL) && (TH_SUBW_ABL & 2))  // ablation build: no sample loads
+            const gptr<const float> pj = c.wav + (e0 + 2048 * (int64_t)j);
+            x[j] = {pj[2u * tid], pj[2u * tid + 1u]};
+#else
+            x[j] = {0.25f, -0.125f};
+#endif
+        }
+    };
+    auto fetch_window = [&](uint32_t tid, cf32 (&xw)[16]) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+#if defined(TH_SUBW_ABL) && (TH_SUBW_ABL & 1)  // ablation build: no window loads
+            xw[j] = {0.5f, 0.25f};
+#else
+            xw[j] = (wtab_g + 1024 * j)[tid];
+#endif
+        }
+    };
+    // phase 0: window, then to sub-transform tid mod 16 as column tid / 16 (slot 64 j + column)
+    auto stage = [&](uint32_t tid, const cf32 (&x)[16], const cf32 (&xw)[16]) {
+        cf32 *const dst = slabs + (size_t)(tid & 15u) * SUB_STRIDE + (tid >> 4);
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds_st(&dst[64 * j], cf32{x[j].re * xw[j].re, x[j].im * xw[j].im});
+    };
+    Cur cur = open_chunk(ct);
+    {
+        cf32 x0[16], w0[16];
+        fetch(cur, t & 1023u, x0);
+        fetch_window(t & 1023u, w0);
+        stage(t & 1023u, x0, w0);
+    }
+    // The instruction arbiter serves the oldest wave of a SIMD first: of the four waves of a SIMD the first finishes a phase at half
+    // time and the last one runs alone at the end, at a lone wave's issue rate.  Between two barriers a wave therefore LOWERS its
+    // priority as it advances: whoever is behind goes first, and the four arrive together.  Measured: 1.476 ms with, 1.464 without
+    // (profiles/r05_ab_subwave.txt) — off; -DTH_SUBW_PRIO=1 builds it.
+#if !defined(TH_SUBW_NT)
+#define TH_SUBW_NT 1
+#endif
+#if TH_SUBW_NT
+#define TH_SUBW_STORE(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
+#else
+#define TH_SUBW_STORE(PTR, VAL) (*(PTR) = (VAL))
+#endif
+#if !defined(TH_SUBW_PRIO)
+#define TH_SUBW_PRIO 0
+#endif
+#if TH_SUBW_PRIO
+#define TH_PRIO(P) __builtin_amdgcn_s_setprio(P)
+#else
+#define TH_PRIO(P) do { } while (0)
+#endif
+#if defined(TH_SUBW_PROF)  // development instrumentation: shader-clock ticks per phase, summed over the workgroup's frames (thread 0's view)
+    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp = __builtin_amdgcn_s_memtime();
+#define TH_STAMP(I) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); prof[I] += now_ - stamp; stamp = now_; } while (0)
+#else
+#define TH_STAMP(I) do { } while (0)
+#endif
+    while (cur.valid) {
+        // per-frame opaque copies of the thread / lane ids: every LDS address below is "f(id) + immediate"; left loop-invariant
+        // they are hoisted out of the frame loop and spilled (see wave_frame)
+        uint32_t tt = t, lane = lane_w;
+        asm volatile("" : "+v"(tt), "+v"(lane));
+        tt &= 1023u;
+        lane &= 63u;
+        TH_STAMP(0);
+        lds_barrier();  // (1) every slab holds its sub-transform's input (staged behind the previous frame's barrier 5)
+        TH_STAMP(1);
+        // the combining pass's ten constants (twiddle index k2 = tt): requested now, they land during the sub-transform
+        // (from the plan's per-thread table [constant][thread]: ten coalesced loads — read straight from tw they are gathers with
+        // strides of 16 .. 128 bytes, up to 64 cache lines per wave-load, and were the kernel's largest vector-memory client)
+        cf32 wC[B::NTW];
+#pragma unroll
+        for (int e = 0; e < B::NTW; e++) wC[e] = (twc + 1024 * e)[tt];
+        // ---- phase 1: the 1024-point transform of this wave (stft_wave.h; no workgroup barrier inside)
+        cf32 z[16];
+        {
+            const uint32_t col = SW::lane_col(lane);
+#pragma unroll
+            for (int m = 0; m < 16; m++) z[m] = lds_ld(&slab[64 * m + col]);
+        }
+        wave_lds_sync_l();
+        cf32 za[SW::NQ][SW::R3], zb[SW::NQ][SW::R3];
+        {
+            cf32 w2[SW::NT2];
+            SW::load_t2(lane, w2, t2);
+#if defined(TH_SUBW_ABL) && (TH_SUBW_ABL & 4)  // ablation build: no sub-transform
+            if (g.hop == 0x7fffffffu)
+#endif
+            {
+            TH_PRIO(3);
+            SW::pass1(lane, z, slab);
+            wave_lds_sync_l();
+            TH_PRIO(2);
+            SW::read1(lane, z, slab);
+            wave_lds_sync_l();
+            SW::pass2_w(lane, z, w2, slab);
+            wave_lds_sync_l();
+            TH_PRIO(1);
+            cf32 wa[SW::NQ][SW::NT3], wb[SW::NQ][SW::NT3];
+            const typename SW::PairBase pbs = SW::pair_base(lane);
+            SW::load_t3_paired(pbs, wa, wb, t3);
+            SW::read2_paired(lane, pbs, za, zb, slab);
+            wave_lds_sync_l();
+            SW::pass3_paired_w(za, zb, wa, wb);
+            }
+        }
+        // S_wv[k2] to the wave's own slab in natural order: za[q][r] = S[A_q + 256 r], zb[q][r] = S[B_q + 256 r]
+#pragma unroll
+        for (int q = 0; q < SW::NQ; q++) {
+            const uint32_t a = SW::jj_a(lane, q), b = SW::jj_b(lane, q);
+#pragma unroll
+            for (int r = 0; r < SW::R3; r++) {
+                lds_st(&slab[a + (uint32_t)(r * SW::NS3)], za[q][r]);
+                lds_st(&slab[b + (uint32_t)(r * SW::NS3)], zb[q][r]);
+            }
+        }
+        TH_PRIO(0);
+        TH_STAMP(2);
+        lds_barrier();  // (2) all sixteen spectra are in the slabs
+        TH_STAMP(3);
+        // the next frame of the stream (the next chunk's first when this chunk ends): its samples travel during the combining pass
+        // and the Z exchange
+        // (unconditional register flow: behind the stream's last frame the same frame is staged once more — in bounds, never read)
+        const Cur nxt = next_of(cur);
+        cf32 x[16], xw[16];
+        fetch(nxt.valid ? nxt : cur, tt, x);
+        // ---- phase 2: the combining pass, thread = k2
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) z[n1] = lds_ld(&slabs[(size_t)n1 * SUB_STRIDE + tt]);
+#if defined(TH_SUBW_ABL) && (TH_SUBW_ABL & 8)  // ablation build: no combining butterfly
+        if (g.hop == 0x7fffffffu)
+#endif
+        B::pass_last(z, wC);  // z[c] = Z[tt + 1024 c]
+        TH_STAMP(4);
+        lds_barrier();  // (3) the slabs have been read: Z may go over them
+        fetch_window(tt, xw);  // (behind the combining pass: its ten constants are dead, 32 registers for the window pairs)
+        B::write_z(tt, z, slabs);
+        lds_barrier();  // (4)
+        cf32 zm[8];
+        B::split_read(tt, slabs, zm);
+        lds_barrier();  // (5) the slabs are free again
+        TH_STAMP(5);
+        // phase 0 of the NEXT frame goes in front of this frame's split pass: its latency (samples, window) is behind us, and the
+        // row stores below overlap the next sub-transform (lds_barrier does not wait for them)
+        stage(tt, x, xw);
+        const gptr<float> row = cur.spec + (size_t)cur.f * cur.spec_pitch;
+        // (non-temporal row stores, TH_SUBW_NT: the 64 KB a frame writes should not push the 96 KB of samples the next frame re-reads out of the L2)
+        auto emit = [&](uint32_t k, float p) {
+            if constexpr (AMP) {
+                TH_SUBW_STORE(&row[k], power_to_amp(p));
+            } else {
+                const float d = power_to_dB(p);
+                TH_SUBW_STORE(&row[k], d);
+                lmin = nmin_l(lmin, d);
+                lmax = nmax_l(lmax, d);
+            }
+        };
+#if defined(TH_SUBW_ABL) && (TH_SUBW_ABL & 16)  // ablation build: no split pass, no rows
+        if (g.hop == 0x7fffffffu)
+#endif
+        B::split_compute(tt, z, zm, stw_t, emit);
+        {   // complete the row's last 128-byte line (see wave_frame)
+            const uint32_t height = (uint32_t)(NC + 1), padn = cur.spec_pitch - height;
+            if (tt - 1u < ((padn < 32u && cur.spec_pitch % 32u == 0) ? padn : 0u)) row[height - 1u + tt] = 0.0f;
+        }
+        TH_STAMP(6);
+        if (!(nxt.valid && nxt.ct == cur.ct)) {  // the chunk ends: its (min, max) pair, folded per channel by wave_post_kernel
+#if defined(TH_SUBW_PROF)
+            if (minmax != nullptr && t == 0) {  // (instead: phase TH_SUBW_PROF's ticks (7: all phases) per chunk so far)
+                uint64_t tot = 0;
+                for (int i = 0; i < 8; i++) tot += prof[i];
+                minmax[2 * (size_t)cur.ct] = (float)tot;
+                minmax[2 * (size_t)cur.ct + 1] = (float)(TH_SUBW_PROF < 7 ? prof[TH_SUBW_PROF] : tot);
+                for (int i = 0; i < 8; i++) prof[i] = 0;
+            }
+#else
+            if (minmax != nullptr) {
+                const float a = wave_min_l(lmin), b = wave_max_l(lmax);
+                if (lane_w == 0) {
+                    red[2 * wv] = a;
+                    red[2 * wv + 1] = b;
+                }
+                lds_barrier();  // (red[] is rewritten at the next chunk's end, at least five barriers from here)
+                if (t == 0) {
+                    float mn = red[0], mx = red[1];
+                    for (int w = 1; w < 16; w++) {
+                        mn = nmin_l(mn, red[2 * w]);
+                        mx = nmax_l(mx, red[2 * w + 1]);
+                    }
+                    minmax[2 * (size_t)cur.ct] = mn;
+                    minmax[2 * (size_t)cur.ct + 1] = mx;
+                }
+                lmin = __builtin_inff();
+                lmax = -__builtin_inff();
+            }
+#endif
+        }
+        cur = nxt;
+    }
+}
+
+}  // namespace
+
+bool stft_subwave_applies(const StftGeom &g) { return g.log2_nc == 14 && g.odd_m1 == 0; }
+
+// the combining pass's constants per thread, [constant e][thread t] (BlockFft<14>::load_tw<1024>, from the host copy of tw)
+void stft_subwave_build_twc(const cf32 *h_tw, cf32 *out) {
+    using B = BlockFft<14>;
+    for (uint32_t t = 0; t < 1024; t++) {
+        cf32 w[B::NTW];
+        B::template load_tw<B::NS_C>(t, w, h_tw);
+        for (int e = 0; e < B::NTW; e++) out[(size_t)e * 1024 + t] = w[e];
+    }
+}
+
+hipError_t launch_stft_subwave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles, const cf32 *d_wtab,
+                               const cf32 *d_tw, const cf32 *d_twc, float *d_minmax, bool amp, uint32_t n_cu, hipStream_t s) {
+    if (!stft_subwave_applies(g) || n_cu == 0 || d_twc == nullptr) return hipErrorInvalidValue;
+    if (!n_tiles) return hipSuccess;
+    constexpr size_t lds = sizeof(cf32) * (SW::T2_LEN + SW::T3_LEN + (size_t)16 * SUB_STRIDE) + 32 * sizeof(float);
+    static_assert(lds + 64 <= 160 * 1024, "tables and sixteen slabs fit the CU's LDS");
+    auto kern = amp ? stft_subwave_kernel<true> : stft_subwave_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint32_t grid = n_tiles < n_cu ? n_tiles : n_cu;  // persistent: one workgroup per CU walks every n_cu-th chunk
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax);
+    return hipGetLastError();
+}
+
+}  // namespace th
