@@ -19,6 +19,8 @@
 // output are the block kernel's (same tables, same butterflies): the results agree with it to rounding.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "stft_block.h"
 #include "stft_core.h"
@@ -61,7 +63,7 @@ constexpr int SUB_LOG2 = 10;                       // the sub-transform: WaveFft
 using SW = WaveFft<SUB_LOG2>;
 constexpr int SUB_STRIDE = SW::SLAB_LEN + 2;       // cf32 per slab: 16-byte aligned, and consecutive slabs four banks apart (phase 0's scatter)
 
-template <bool AMP>
+template <bool AMP, bool REUSE>
 __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab,
                                                             uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw,
                                                             const cf32 *__restrict__ twc, float *__restrict__ minmax) {
@@ -129,10 +131,11 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
     // (addresses as "uniform base of piece j (SGPRs) + 8 tid": no per-thread 64-bit pointers to keep or spill)
     // raw samples (points tid + 1024 j) and window pairs of the frame being staged: locals of ONE loop iteration (loop-carried they
     // would stay live through the sub-transform: the first build spilled them to scratch right behind their loads)
-    auto fetch = [&](const Cur &c, uint32_t tid, cf32 (&x)[16]) {
+    auto fetch = [&](const Cur &c, uint32_t tid, cf32 (&x)[16], auto j0_tag) {
+        constexpr int J0 = decltype(j0_tag)::value;  // first piece to load (REUSE: 12 — the pieces below it moved down from the previous frame)
         const int64_t e0 = (int64_t)c.f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;  // interior frames: the whole span is inside the channel
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = J0; j < 16; j++) {
 #if !(defined(TH_SUBW_ABL) && (TH_SUBW_ABL & 2))  // ablation build: no sample loads
             const gptr<const float> pj = c.wav + (e0 + 2048 * (int64_t)j);
             x[j] = {pj[2u * tid], pj[2u * tid + 1u]};
@@ -158,16 +161,27 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
         for (int j = 0; j < 16; j++) lds_st(&dst[64 * j], cf32{x[j].re * xw[j].re, x[j].im * xw[j].im});
     };
     Cur cur = open_chunk(ct);
+    // REUSE (hop = n_fft / 4): the raw samples stay in registers from frame to frame — frame f + 1 is frame f moved down by four of
+    // the thread's sixteen pieces, so only the new hop is requested (a quarter of the sample traffic; the re-read three quarters
+    // came from the L2 / MALL at best: removing the sample loads altogether is worth 0.32 of 1.48 ms, profiles/r05_ab_subwave.txt)
+    cf32 xk[REUSE ? 16 : 1];
     {
         cf32 x0[16], w0[16];
-        fetch(cur, t & 1023u, x0);
+        fetch(cur, t & 1023u, x0, std::integral_constant<int, 0>{});
         fetch_window(t & 1023u, w0);
         stage(t & 1023u, x0, w0);
+        if constexpr (REUSE) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) xk[j % (REUSE ? 16 : 1)] = x0[j];
+        }
     }
     // The instruction arbiter serves the oldest wave of a SIMD first: of the four waves of a SIMD the first finishes a phase at half
     // time and the last one runs alone at the end, at a lone wave's issue rate.  Between two barriers a wave therefore LOWERS its
     // priority as it advances: whoever is behind goes first, and the four arrive together.  Measured: 1.476 ms with, 1.464 without
     // (profiles/r05_ab_subwave.txt) — off; -DTH_SUBW_PRIO=1 builds it.
+#if !defined(TH_SUBW_REUSE)
+#define TH_SUBW_REUSE 1
+#endif
 #if !defined(TH_SUBW_NT)
 #define TH_SUBW_NT 1
 #endif
@@ -258,7 +272,18 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
         // (unconditional register flow: behind the stream's last frame the same frame is staged once more — in bounds, never read)
         const Cur nxt = next_of(cur);
         cf32 x[16], xw[16];
-        fetch(nxt.valid ? nxt : cur, tt, x);
+        if constexpr (REUSE) {
+            // the next frame continues this chunk: four pieces down, the new hop requested; a new chunk: everything
+            if (nxt.valid && nxt.ct == cur.ct) {  // workgroup-uniform
+#pragma unroll
+                for (int j = 0; j < 12; j++) x[j] = xk[(j + 4) % (REUSE ? 16 : 1)];
+                fetch(nxt, tt, x, std::integral_constant<int, 12>{});
+            } else {
+                fetch(nxt.valid ? nxt : cur, tt, x, std::integral_constant<int, 0>{});
+            }
+        } else {
+            fetch(nxt.valid ? nxt : cur, tt, x, std::integral_constant<int, 0>{});
+        }
         // ---- phase 2: the combining pass, thread = k2
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) z[n1] = lds_ld(&slabs[(size_t)n1 * SUB_STRIDE + tt]);
@@ -278,6 +303,10 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
         // phase 0 of the NEXT frame goes in front of this frame's split pass: its latency (samples, window) is behind us, and the
         // row stores below overlap the next sub-transform (lds_barrier does not wait for them)
         stage(tt, x, xw);
+        if constexpr (REUSE) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) xk[j % (REUSE ? 16 : 1)] = x[j];
+        }
         const gptr<float> row = cur.spec + (size_t)cur.f * cur.spec_pitch;
         // (non-temporal row stores, TH_SUBW_NT: the 64 KB a frame writes should not push the 96 KB of samples the next frame re-reads out of the L2)
         auto emit = [&](uint32_t k, float p) {
@@ -354,7 +383,9 @@ hipError_t launch_stft_subwave(const StftGeom &g, const ChanJob *d_jobs, const u
     if (!n_tiles) return hipSuccess;
     constexpr size_t lds = sizeof(cf32) * (SW::T2_LEN + SW::T3_LEN + (size_t)16 * SUB_STRIDE) + 32 * sizeof(float);
     static_assert(lds + 64 <= 160 * 1024, "tables and sixteen slabs fit the CU's LDS");
-    auto kern = amp ? stft_subwave_kernel<true> : stft_subwave_kernel<false>;
+    const bool reuse = TH_SUBW_REUSE && g.hop * 4 == g.n_fft;
+    auto kern = amp ? (reuse ? stft_subwave_kernel<true, true> : stft_subwave_kernel<true, false>)
+                    : (reuse ? stft_subwave_kernel<false, true> : stft_subwave_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint32_t grid = n_tiles < n_cu ? n_tiles : n_cu;  // persistent: one workgroup per CU walks every n_cu-th chunk
