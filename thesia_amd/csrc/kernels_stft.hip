@@ -1429,6 +1429,16 @@ static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, co
 //                samples resident on top (REUSE: 256 VGPRs + 120 bytes of scratch) 1.98: not used.
 //   n_fft 16384: ONE exchange buffer per workgroup of four waves, so that two workgroups share a CU: 1.35 ms against 1.01 for
 //                one workgroup of eight waves with two buffers and resident constants: not used.
+// Row stores of the block kernels: non-temporal (round 5, as in stft_subwave_kernel: the rows a frame writes should not push the
+// samples and window pairs the next frame re-reads out of the L2).  -DTH_BLOCK_NT=0: A/B builds.
+#if !defined(TH_BLOCK_NT)
+#define TH_BLOCK_NT 1
+#endif
+#if TH_BLOCK_NT
+#define TH_BLOCK_STORE(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
+#else
+#define TH_BLOCK_STORE(PTR, VAL) (*(PTR) = (VAL))
+#endif
 constexpr bool block_double_buffered(int log2_nc, int vt) { return log2_nc == 13 && vt == 1; }
 template <int LOG2_NC, bool AMP, bool REUSE, int VT>
 __global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) __attribute__((amdgpu_waves_per_eu(VT == 2 ? 2 : 1))) void stft_block_kernel(
@@ -1563,10 +1573,10 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) __attribute__((amdgpu_wa
         const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch;
         auto emit = [&](uint32_t k, float p) {
             if constexpr (AMP) {  // amplitude rows for the matrix-core mel path
-                row[k] = power_to_amp(p);
+                TH_BLOCK_STORE(&row[k], power_to_amp(p));
             } else {
                 const float d = power_to_dB(p);
-                row[k] = d;
+                TH_BLOCK_STORE(&row[k], d);
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }
@@ -1717,10 +1727,10 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) void stft_block_planar_k
         const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch;
         auto emit = [&](uint32_t k, float p) {
             if constexpr (AMP) {  // amplitude rows for the two-kernel mel path
-                row[k] = power_to_amp(p);
+                TH_BLOCK_STORE(&row[k], power_to_amp(p));
             } else {
                 const float d = power_to_dB(p);
-                row[k] = d;
+                TH_BLOCK_STORE(&row[k], d);
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
             }
