@@ -141,6 +141,35 @@ def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
     plan.close()
 
 
+@pytest.mark.parametrize("sr,win,hop,n_fft,scale,n_mel", [(48000, 8192, 2048, 8192, 0, 0), (96000, 3840, 960, 8192, 0, 0), (48000, 16384, 4096, 16384, 0, 0),
+                                                          (48000, 12000, 3000, 16384, 0, 0), (48000, 8192, 2048, 8192, 1, 0), (48000, 16384, 4096, 16384, 1, 200),
+                                                          (48000, 32768, 8192, 32768, 0, 0)])
+def test_subwave_plan(ctx, sr, win, hop, n_fft, scale, n_mel):
+    """Round 5: stft_subwave_kernel — the long transforms as R = n_fft / 2048 wave transforms of 1024 points (the n_fft 2048 plane
+    plan, one wave each) plus one radix-R combining pass and the block plan's split pass; resident samples at hop = n_fft / 4.
+    Selector 15 runs it wherever it exists (n_fft 8192 / 16384 / 32768; the default at 32768), selector 14 the block kernel:
+    both against the oracle on a ragged batch (chunks of every length, a channel shorter than the window, silence), linear dB
+    and mel over amplitude rows; min / max = extrema of the stored rows."""
+    lens = [n_fft * 5 + 17, n_fft + hop * 9 + 1, n_fft // 3 + 5, 23 * hop + n_fft, n_fft]
+    wavs = [synth_track(700 + i, sr, n) for i, n in enumerate(lens)] + [np.zeros(3 * n_fft, np.float32)]
+    fb = None
+    if scale:
+        fb = orc.calc_mel_fb(sr, n_fft, n_mel) if n_mel else orc.calc_mel_fb_default(sr, n_fft)
+    want = [orc.calc_spec(x, win, hop, n_fft, mel_fb=fb, return_amp=True) for x in wavs[:-1]]
+    for which, fft in ((15, "stft_subwave_kernel"), (14, "stft_block_kernel")):
+        plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, n_mel)
+        plan.set_kernel(which)
+        assert plan.kernel_name.startswith(fft), plan.kernel_name
+        a, mm = plan.calc_spec_batch(wavs)
+        for i, (w, amp) in enumerate(want):
+            assert_spec_close(a[i], w, amp if fb is None else None)
+            assert mm[i, 0] == a[i].min() and mm[i, 1] == a[i].max()
+        assert np.all(np.isneginf(a[-1]))
+        one, _, _ = plan.calc_spec(wavs[0])  # a single-track launch cuts other chunks
+        assert np.array_equal(one, a[0])
+        plan.close()
+
+
 @pytest.mark.parametrize("sr,win_ms,t_overlap,f_overlap,scale", [(48000, 40.0, 4, 3, 0), (48000, 40.0, 4, 5, 1), (16000, 8.0, 2, 6, 0),
                                                                   (8000, 2.0, 4, 7, 1), (48000, 170.0, 4, 3, 0), (48000, 0.05, 1, 3, 0)])
 def test_f_overlap_that_is_not_a_power_of_two(ctx, sr, win_ms, t_overlap, f_overlap, scale):
@@ -236,7 +265,8 @@ def test_wave_and_generic_kernels(ctx, win, hop, n_fft):
     n = 40000 + win if n_fft <= 4096 else 8 * n_fft + 4321
     x = synth_track(n_fft + hop, 48000, n)
     want, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
-    fast = "stft_wave_kernel" if n_fft <= 4096 else "stft_block_kernel"
+    # (round 5: n_fft 16384 at hops other than n_fft / 4 defaults to stft_subwave_kernel — eight 1024-point wave transforms + a combining pass)
+    fast = "stft_wave_kernel" if n_fft <= 4096 else "stft_subwave_kernel" if (n_fft == 16384 and 4 * hop != n_fft) else "stft_block_kernel"
     for which, name in ((1, "stft_generic_kernel"), (2, fast)):
         plan = ta.Plan(ctx, 48000, win, hop, n_fft, ta.LINEAR)
         plan.set_kernel(which)

@@ -524,8 +524,8 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
     }
     if (rc == TH_OK) rc = up((void **)&p->d_tw, tw.data(), tw.size() * sizeof(cf32));
     if (rc == TH_OK && th::stft_subwave_applies(g)) {  // n_fft 32768: per-thread constants of stft_subwave_kernel's combining pass
-        std::vector<cf32> twc(th::STFT_SUBWAVE_TWC_LEN);
-        th::stft_subwave_build_twc(tw.data(), twc.data());
+        std::vector<cf32> twc(th::stft_subwave_twc_len(g));
+        th::stft_subwave_build_twc(g, tw.data(), twc.data());
         rc = up((void **)&p->d_twc, twc.data(), twc.size() * sizeof(cf32));
     }
     if (rc == TH_OK && freq_scale == TH_FREQ_MEL) {
@@ -711,10 +711,11 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     // 12 mel plans at n_fft 4096: the banded sums in the FFT kernel's epilogue with the table read from global memory, on the
     // launch shapes it is instantiated for (hop 1024, the 96 / 88.2 kHz defaults; A/B: slower than the two kernels; elsewhere as 2);
     // 13 fused mel epilogue one frame at a time where the frame-pair form is the default (n_fft 2048 banded sums; A/B; elsewhere as 2);
-    // 14 n_fft 32768 on the workgroup-per-frame Stockham kernel (stft_block_kernel) where stft_subwave_kernel is the default (A/B; elsewhere as 2);
+    // 14 the workgroup-per-frame Stockham kernel (stft_block_kernel) where stft_subwave_kernel is the default (A/B; elsewhere as 2);
+    // 15 stft_subwave_kernel wherever it exists (n_fft 8192 .. 32768) also where the block kernel is the default (A/B; elsewhere as 2);
     // bits 8-15 (tuning): waves per workgroup
     const int k = which & 0xff, wv = (which >> 8) & 0xff;
-    TH_REQUIRE(k >= 0 && k <= 14, "kernel selector must be 0 .. 14");
+    TH_REQUIRE(k >= 0 && k <= 15, "kernel selector must be 0 .. 15");
     TH_REQUIRE(wv == 0 || wv == 4 || wv == 6 || wv == 7 || wv == 8 || wv == 10 || wv == 12 || wv == 14 || wv == 16,
                "waves per workgroup must be 4, 6, 7, 8, 10, 12, 14 or 16");
     // the multi-frame plans (n_fft 512; n_fft 1024 under selector 6) are instantiated for 8, 12 and 16 waves only
@@ -734,7 +735,7 @@ TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (p->use_mel_fused()) return "stft_wave_kernel(fused mel)";
     if (p->use_mel_mfma() && p->d_mel_rows != nullptr && p->kernel_choice != 7) return "stft_wave_kernel+mel_rows_kernel";
     // (n_fft 32768, round 5: sixteen wave transforms + a combining pass, kernels_stft_long.hip; selector 14 keeps the block kernel)
-    const bool subwave = th::stft_subwave_applies(p->g) && p->kernel_choice != 14;
+    const bool subwave = th::stft_subwave_applies(p->g) && p->d_twc != nullptr && (p->kernel_choice == 15 || (p->kernel_choice != 14 && th::stft_subwave_default(p->g)));
     if (p->use_mel_mfma() && p->g.log2_nc >= 11 && p->d_mel_bsum != nullptr && p->kernel_choice != 7)
         return subwave ? "stft_subwave_kernel+mel_band_rows_kernel" : th::stft_is_block_plan(p->g) ? "stft_block_kernel+mel_band_rows_kernel" : "stft_wave_kernel+mel_band_rows_kernel";
     if (p->use_mel_mfma()) return subwave ? "stft_subwave_kernel+mel_mfma_kernel" : th::stft_is_block_plan(p->g) ? "stft_block_kernel+mel_mfma_kernel" : "stft_wave_kernel+mel_mfma_kernel";
@@ -1020,7 +1021,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         wo.multi = (th::stft_wave_multi_applies(g, wo.mode) && (g.log2_nc == 8 || p->kernel_choice == 6)) ? 1 : 0;
         wo.packed = p->kernel_choice == 9 ? 1 : 0;
         wo.sweep = sweep ? 1 : 0;
-        wo.legacy_block = p->kernel_choice == 14 ? 1 : 0;
+        wo.long_plan = p->kernel_choice == 14 ? 1 : p->kernel_choice == 15 ? 2 : 0;
         wo.subwave_twc = p->d_twc;
         if (mel_fused && g.log2_nc == 8) {  // (the per-mel table of the banded sums, kernels.h)
             wo.mel_tab = p->d_mel_rows;

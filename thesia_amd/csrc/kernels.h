@@ -71,14 +71,15 @@ struct WaveOut {
     // stft_wave_kernel<.., OUT = 3>; the host sets it where stft_wave_mel_pair_applies says so)
     uint32_t mel_pair = 0;
     const cf32 *subwave_twc = nullptr;  // DEVICE: stft_subwave_build_twc's table (n_fft 32768 plans)
-    int legacy_block = 0;  // 1: n_fft 32768 on stft_block_kernel (round 3/4's plan; selector 14, A/B) instead of stft_subwave_kernel
+    int long_plan = 0;  // n_fft 8192 .. 32768: 0 = the default of the size (stft_subwave_default), 1 = stft_block_kernel, 2 = stft_subwave_kernel
 };
-// ---- kernels_stft_long.hip: n_fft 32768 as sixteen wave transforms + one combining pass (interior frames, as the block kernel)
+// ---- kernels_stft_long.hip: n_fft 8192 / 16384 / 32768 as 4 / 8 / 16 wave transforms + one combining pass (interior frames, as the block kernel)
 bool stft_subwave_applies(const StftGeom &g);
+bool stft_subwave_default(const StftGeom &g);  // the sizes where it is the default (measured: profiles/r05_ab_subwave.txt)
 hipError_t launch_stft_subwave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles, const cf32 *d_wtab,
                                const cf32 *d_tw, const cf32 *d_twc, float *d_minmax, bool amp, uint32_t n_cu, hipStream_t s);
-constexpr size_t STFT_SUBWAVE_TWC_LEN = 10 * 1024;  // cf32 entries of the combining pass's per-thread constant table
-void stft_subwave_build_twc(const cf32 *h_tw, cf32 *out);  // host: out[STFT_SUBWAVE_TWC_LEN] from the plan's tw table
+size_t stft_subwave_twc_len(const StftGeom &g);  // cf32 entries of the combining pass's per-thread constant table
+void stft_subwave_build_twc(const StftGeom &g, const cf32 *h_tw, cf32 *out);  // host: out[stft_subwave_twc_len(g)] from the plan's tw table
 // the frame-pair form of the banded mel epilogue exists for this launch (n_fft 2048, hop a multiple of 128 samples or no register
 // reuse at all, default waves) and the table's reads stay inside the two amplitude rows a slab holds (reach: MelBandHost::reach)
 bool stft_wave_mel_pair_applies(const StftGeom &g, int waves, uint32_t reach);

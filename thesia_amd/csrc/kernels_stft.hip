@@ -2304,8 +2304,8 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
     }
     if (g.log2_nc >= 12) {  // one workgroup per frame (stft_block.h): dB output, linear scale
         if (out.mode > 1 || g.phased) return hipErrorInvalidValue;
-        // n_fft 32768 (round 5): sixteen wave transforms + one combining pass (kernels_stft_long.hip)
-        if (stft_subwave_applies(g) && !out.legacy_block && out.subwave_twc != nullptr)
+        // round 5: R wave transforms + one combining pass (kernels_stft_long.hip): the default at n_fft 32768, selector 15 elsewhere
+        if (stft_subwave_applies(g) && out.subwave_twc != nullptr && (out.long_plan == 2 || (out.long_plan == 0 && stft_subwave_default(g))))
             return launch_stft_subwave(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, out.subwave_twc, out.mode == 1 ? nullptr : d_minmax, out.mode == 1, n_cu, s);
         if (out.mode == 1) {  // amplitude rows, no (min, max)
             if (g.log2_nc == 12) return launch_block<12, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);

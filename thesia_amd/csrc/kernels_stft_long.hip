@@ -63,20 +63,32 @@ constexpr int SUB_LOG2 = 10;                       // the sub-transform: WaveFft
 using SW = WaveFft<SUB_LOG2>;
 constexpr int SUB_STRIDE = SW::SLAB_LEN + 2;       // cf32 per slab: 16-byte aligned, and consecutive slabs four banks apart (phase 0's scatter)
 
-template <bool AMP, bool REUSE>
-__global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab,
-                                                            uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw,
-                                                            const cf32 *__restrict__ twc, float *__restrict__ minmax) {
-    using B = BlockFft<14>;
-    constexpr int NC = B::NC, T = B::T, R = 16;
-    static_assert(T == 1024 && NC == R * SW::NC && B::NS_C == SW::NC, "sixteen 1024-point sub-transforms, combined by the block plan's last pass");
+// LOG2_R = 4 (n_fft 32768: sixteen sub-transforms, 1024 threads, one workgroup per CU), 3 (n_fft 16384: eight, 512 threads, two
+// workgroups per CU) or 2 (n_fft 8192: four, 256 threads, four per CU).  The combining pass is the radix-R twiddled FMA butterfly of
+// stft_wave.h / stft_block.h; with R < 16 a thread combines 16 / R bins k2 (tid, tid + 64 R, ...), so that it always ends up with the
+// sixteen values Z[tid + 64 R c] the block plan's split pass expects.
+template <int LOG2_R>
+struct SubwaveCfg {
+    static constexpr int R = 1 << LOG2_R, NT = 64 * R, KPT = 16 / R;   // sub-transforms = waves, threads, bins k2 per thread
+    static constexpr int NTWC = R == 16 ? 10 : KPT * (R == 8 ? 4 : 2);  // combining-pass constants per thread
+    static constexpr int WG_PER_CU = 16 / R;
+    static constexpr size_t LDS = sizeof(cf32) * (SW::T2_LEN + SW::T3_LEN + (size_t)R * SUB_STRIDE) + 2 * R * sizeof(float);
+};
+template <int LOG2_R, bool AMP, bool REUSE>
+__global__ __launch_bounds__(SubwaveCfg<LOG2_R>::NT, SubwaveCfg<LOG2_R>::WG_PER_CU) void stft_subwave_kernel(
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_tiles, const cf32 *__restrict__ wtab_g,
+    const cf32 *__restrict__ tw, const cf32 *__restrict__ twc, float *__restrict__ minmax) {
+    using C = SubwaveCfg<LOG2_R>;
+    using B = BlockFft<10 + LOG2_R>;
+    constexpr int NC = B::NC, T = B::T, R = C::R, NT = C::NT, KPT = C::KPT;
+    static_assert(T == NT && NC == R * SW::NC, "R 1024-point sub-transforms; the block plan's thread count");
     static_assert(SW::PLANES && SW::PAIRED && SW::NQ == 2 && SW::R3 == 4, "the n_fft 2048 plane plan");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf32 *const t2 = reinterpret_cast<cf32 *>(smem_raw);
     cf32 *const t3 = t2 + SW::T2_LEN;
-    float *const red = reinterpret_cast<float *>(t3 + SW::T3_LEN);  // 2 x 16 floats
-    cf32 *const slabs = reinterpret_cast<cf32 *>(red + 32);          // 16 slabs; Z (Nc + 1 slots) lies over them in phase 3
-    static_assert((SW::T2_LEN + SW::T3_LEN) % 2 == 0 && SUB_STRIDE % 2 == 0, "slabs 16-byte aligned");
+    float *const red = reinterpret_cast<float *>(t3 + SW::T3_LEN);  // 2 x R floats
+    cf32 *const slabs = reinterpret_cast<cf32 *>(red + 2 * R);       // R slabs; Z (Nc + 1 slots) lies over them in phase 3
+    static_assert((SW::T2_LEN + SW::T3_LEN) % 2 == 0 && SUB_STRIDE % 2 == 0 && (2 * R) % 4 == 0, "slabs 16-byte aligned");
     static_assert(R * SUB_STRIDE >= NC + 1, "Z fits over the slabs");
 
     const uint32_t t = threadIdx.x, lane_w = t & 63u;
@@ -87,10 +99,10 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
     uint32_t ct = blockIdx.x;
     if (ct >= n_tiles) return;
 
-    // sub-transform tables: W_2048^i = tw[16 i] (tw = W_{n_fft}^i, n_fft = 2 Nc = 32768)
+    // sub-transform tables: W_2048^i = tw[R i] (tw = W_{n_fft}^i, n_fft = 2 Nc = 2048 R)
     constexpr uint32_t TS = (uint32_t)(NC / SW::NC);
-    for (uint32_t i = t; i < (uint32_t)SW::T2_LEN; i += 1024u) t2[i] = tw[TS * SW::t2_index(i / SW::NS2, i % SW::NS2)];
-    for (uint32_t i = t; i < (uint32_t)SW::T3_LEN; i += 1024u) {
+    for (uint32_t i = t; i < (uint32_t)SW::T2_LEN; i += (uint32_t)NT) t2[i] = tw[TS * SW::t2_index(i / SW::NS2, i % SW::NS2)];
+    for (uint32_t i = t; i < (uint32_t)SW::T3_LEN; i += (uint32_t)NT) {
         const uint32_t r = i / SW::NS3 + 1, k = i % SW::NS3;
         t3[i] = tw[TS * ((r * k) * (2u * SW::NC / (SW::NS3 * SW::R3)))];
     }
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
 #pragma unroll
         for (int j = J0; j < 16; j++) {
 #if !(defined(TH_SUBW_ABL) && (TH_SUBW_ABL & 2))  // ablation build: no sample loads
-            const gptr<const float> pj = c.wav + (e0 + 2048 * (int64_t)j);
+            const gptr<const float> pj = c.wav + (e0 + 2 * NT * (int64_t)j);
             x[j] = {pj[2u * tid], pj[2u * tid + 1u]};
 #else
             x[j] = {0.25f, -0.125f};
@@ -150,13 +162,13 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
 #if defined(TH_SUBW_ABL) && (TH_SUBW_ABL & 1)  // ablation build: no window loads
             xw[j] = {0.5f, 0.25f};
 #else
-            xw[j] = (wtab_g + 1024 * j)[tid];
+            xw[j] = (wtab_g + NT * j)[tid];
 #endif
         }
     };
-    // phase 0: window, then to sub-transform tid mod 16 as column tid / 16 (slot 64 j + column)
+    // phase 0: window, then to sub-transform tid mod R as column tid / R (slot 64 j + column)
     auto stage = [&](uint32_t tid, const cf32 (&x)[16], const cf32 (&xw)[16]) {
-        cf32 *const dst = slabs + (size_t)(tid & 15u) * SUB_STRIDE + (tid >> 4);
+        cf32 *const dst = slabs + (size_t)(tid & (uint32_t)(R - 1)) * SUB_STRIDE + (tid >> LOG2_R);
 #pragma unroll
         for (int j = 0; j < 16; j++) lds_st(&dst[64 * j], cf32{x[j].re * xw[j].re, x[j].im * xw[j].im});
     };
@@ -167,9 +179,9 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
     cf32 xk[REUSE ? 16 : 1];
     {
         cf32 x0[16], w0[16];
-        fetch(cur, t & 1023u, x0, std::integral_constant<int, 0>{});
-        fetch_window(t & 1023u, w0);
-        stage(t & 1023u, x0, w0);
+        fetch(cur, t & (uint32_t)(NT - 1), x0, std::integral_constant<int, 0>{});
+        fetch_window(t & (uint32_t)(NT - 1), w0);
+        stage(t & (uint32_t)(NT - 1), x0, w0);
         if constexpr (REUSE) {
 #pragma unroll
             for (int j = 0; j < 16; j++) xk[j % (REUSE ? 16 : 1)] = x0[j];
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
         // they are hoisted out of the frame loop and spilled (see wave_frame)
         uint32_t tt = t, lane = lane_w;
         asm volatile("" : "+v"(tt), "+v"(lane));
-        tt &= 1023u;
+        tt &= (uint32_t)(NT - 1);
         lane &= 63u;
         TH_STAMP(0);
         lds_barrier();  // (1) every slab holds its sub-transform's input (staged behind the previous frame's barrier 5)
@@ -217,9 +229,9 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
         // the combining pass's ten constants (twiddle index k2 = tt): requested now, they land during the sub-transform
         // (from the plan's per-thread table [constant][thread]: ten coalesced loads — read straight from tw they are gathers with
         // strides of 16 .. 128 bytes, up to 64 cache lines per wave-load, and were the kernel's largest vector-memory client)
-        cf32 wC[B::NTW];
+        cf32 wC[C::NTWC];
 #pragma unroll
-        for (int e = 0; e < B::NTW; e++) wC[e] = (twc + 1024 * e)[tt];
+        for (int e = 0; e < C::NTWC; e++) wC[e] = (twc + NT * e)[tt];
         // ---- phase 1: the 1024-point transform of this wave (stft_wave.h; no workgroup barrier inside)
         cf32 z[16];
         {
@@ -285,12 +297,39 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
             fetch(nxt.valid ? nxt : cur, tt, x, std::integral_constant<int, 0>{});
         }
         // ---- phase 2: the combining pass, thread = k2
+        if constexpr (R == 16) {
 #pragma unroll
-        for (int n1 = 0; n1 < 16; n1++) z[n1] = lds_ld(&slabs[(size_t)n1 * SUB_STRIDE + tt]);
+            for (int n1 = 0; n1 < 16; n1++) z[n1] = lds_ld(&slabs[(size_t)n1 * SUB_STRIDE + tt]);
 #if defined(TH_SUBW_ABL) && (TH_SUBW_ABL & 8)  // ablation build: no combining butterfly
-        if (g.hop == 0x7fffffffu)
+            if (g.hop == 0x7fffffffu)
 #endif
-        B::pass_last(z, wC);  // z[c] = Z[tt + 1024 c]
+            B::pass_last(z, wC);  // z[c] = Z[tt + 1024 c]
+        } else {
+            // bin k2 = tt + NT u: Z[k2 + 1024 k1] = radix-R butterfly over n1 of S_n1[k2] with t = W_Nc^k2 = slot c = u + KPT k1
+            cf32 v[KPT][R];
+#pragma unroll
+            for (int u = 0; u < KPT; u++)
+#pragma unroll
+                for (int n1 = 0; n1 < R; n1++) v[u][n1] = lds_ld(&slabs[(size_t)n1 * SUB_STRIDE + tt + (uint32_t)(NT * u)]);
+#pragma unroll
+            for (int u = 0; u < KPT; u++) {
+                if constexpr (R == 8) {
+                    cf32 b[8];
+#pragma unroll
+                    for (int n1 = 0; n1 < 8; n1++) b[n1] = v[u][n1 % R];
+                    SW::bfly8_tw(b, wC[(4 * u) % C::NTWC], wC[(4 * u + 1) % C::NTWC], wC[(4 * u + 2) % C::NTWC], wC[(4 * u + 3) % C::NTWC]);  // natural order in and out
+#pragma unroll
+                    for (int k1 = 0; k1 < 8; k1++) z[(u + KPT * k1) % 16] = b[k1];
+                } else {
+                    cf32 a = v[u][0], b = v[u][1 % R], c = v[u][2 % R], d = v[u][3 % R];
+                    bfly4_tw(a, b, c, d, wC[(2 * u) % C::NTWC], wC[(2 * u + 1) % C::NTWC]);  // out: a = X0, c = X1, b = X2, d = X3
+                    z[(u + KPT * 0) % 16] = a;
+                    z[(u + KPT * 1) % 16] = c;
+                    z[(u + KPT * 2) % 16] = b;
+                    z[(u + KPT * 3) % 16] = d;
+                }
+            }
+        }
         TH_STAMP(4);
         lds_barrier();  // (3) the slabs have been read: Z may go over them
         fetch_window(tt, xw);  // (behind the combining pass: its ten constants are dead, 32 registers for the window pairs)
@@ -347,7 +386,7 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
                 lds_barrier();  // (red[] is rewritten at the next chunk's end, at least five barriers from here)
                 if (t == 0) {
                     float mn = red[0], mx = red[1];
-                    for (int w = 1; w < 16; w++) {
+                    for (int w = 1; w < R; w++) {
                         mn = nmin_l(mn, red[2 * w]);
                         mx = nmax_l(mx, red[2 * w + 1]);
                     }
@@ -365,32 +404,75 @@ __global__ __launch_bounds__(1024) void stft_subwave_kernel(StftGeom g, const Ch
 
 }  // namespace
 
-bool stft_subwave_applies(const StftGeom &g) { return g.log2_nc == 14 && g.odd_m1 == 0; }
+bool stft_subwave_applies(const StftGeom &g) { return g.log2_nc >= 12 && g.log2_nc <= 14 && g.odd_m1 == 0; }
+// Where it is the default (profiles/r05_ab_subwave_sizes.txt, ms for 128 ch x 30 s, subwave | block): n_fft 32768 1.26 | 1.85 (19200 / 4800: 2.40 |
+// 3.26); 16384 at hop = n_fft / 4 0.98 | 1.00 (kept on the block kernel: its resident constants and two exchange buffers), 12000 / 3000 1.57 | 1.72;
+// 8192 0.84 | 0.70, 3840 / 960 at 96 kHz 3.9 | 2.9 — four waves per workgroup are too few between two barriers, the block kernel stays.
+bool stft_subwave_default(const StftGeom &g) {
+    return stft_subwave_applies(g) && (g.log2_nc == 14 || (g.log2_nc == 13 && g.hop * 4 != g.n_fft));
+}
+size_t stft_subwave_twc_len(const StftGeom &g) {
+    return g.log2_nc == 14 ? (size_t)SubwaveCfg<4>::NTWC * SubwaveCfg<4>::NT : g.log2_nc == 13 ? (size_t)SubwaveCfg<3>::NTWC * SubwaveCfg<3>::NT
+                                                                                                 : (size_t)SubwaveCfg<2>::NTWC * SubwaveCfg<2>::NT;
+}
 
-// the combining pass's constants per thread, [constant e][thread t] (BlockFft<14>::load_tw<1024>, from the host copy of tw)
-void stft_subwave_build_twc(const cf32 *h_tw, cf32 *out) {
-    using B = BlockFft<14>;
-    for (uint32_t t = 0; t < 1024; t++) {
-        cf32 w[B::NTW];
-        B::template load_tw<B::NS_C>(t, w, h_tw);
-        for (int e = 0; e < B::NTW; e++) out[(size_t)e * 1024 + t] = w[e];
+// the combining pass's constants per thread, [constant e][thread t], from the host copy of tw (tw[i] = W_{n_fft}^i):
+// R = 16: BlockFft<14>::load_tw<1024>;  R = 8: bins k2 = t + 512 u, (w, w^2, w^4, w W8) with w = W_Nc^k2 = tw[2 k2];  R = 4: k2 = t + 256 u, (w, w^2)
+void stft_subwave_build_twc(const StftGeom &g, const cf32 *h_tw, cf32 *out) {
+    const uint32_t n_fft = g.n_fft;
+    if (g.log2_nc == 14) {
+        using B = BlockFft<14>;
+        for (uint32_t t = 0; t < 1024; t++) {
+            cf32 w[B::NTW];
+            B::template load_tw<B::NS_C>(t, w, h_tw);
+            for (int e = 0; e < B::NTW; e++) out[(size_t)e * 1024 + t] = w[e];
+        }
+    } else if (g.log2_nc == 13) {
+        for (uint32_t t = 0; t < 512; t++)
+            for (uint32_t u = 0; u < 2; u++) {
+                const uint32_t k2 = t + 512 * u;
+                out[(size_t)(4 * u + 0) * 512 + t] = h_tw[(2 * k2) % n_fft];
+                out[(size_t)(4 * u + 1) * 512 + t] = h_tw[(4 * k2) % n_fft];
+                out[(size_t)(4 * u + 2) * 512 + t] = h_tw[(8 * k2) % n_fft];
+                out[(size_t)(4 * u + 3) * 512 + t] = h_tw[(2 * k2 + n_fft / 8) % n_fft];
+            }
+    } else {
+        for (uint32_t t = 0; t < 256; t++)
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t k2 = t + 256 * u;
+                out[(size_t)(2 * u + 0) * 256 + t] = h_tw[(2 * k2) % n_fft];
+                out[(size_t)(2 * u + 1) * 256 + t] = h_tw[(4 * k2) % n_fft];
+            }
     }
 }
+
+namespace {
+template <int LOG2_R>
+hipError_t launch_subwave_r(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles, const cf32 *d_wtab,
+                            const cf32 *d_tw, const cf32 *d_twc, float *d_minmax, bool amp, uint32_t n_cu, hipStream_t s) {
+    using C = SubwaveCfg<LOG2_R>;
+    static_assert(C::LDS * C::WG_PER_CU + 64 <= 160 * 1024, "tables and slabs of the CU's workgroups fit its LDS");
+    const bool reuse = TH_SUBW_REUSE && g.hop * 4 == g.n_fft;
+    auto kern = amp ? (reuse ? stft_subwave_kernel<LOG2_R, true, true> : stft_subwave_kernel<LOG2_R, true, false>)
+                    : (reuse ? stft_subwave_kernel<LOG2_R, false, true> : stft_subwave_kernel<LOG2_R, false, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+    if (e != hipSuccess) return e;
+    const uint32_t slots = n_cu * (uint32_t)C::WG_PER_CU;
+    const uint32_t grid = n_tiles < slots ? n_tiles : slots;  // persistent: every workgroup walks every grid-th chunk
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax);
+    return hipGetLastError();
+}
+}  // namespace
 
 hipError_t launch_stft_subwave(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles, const cf32 *d_wtab,
                                const cf32 *d_tw, const cf32 *d_twc, float *d_minmax, bool amp, uint32_t n_cu, hipStream_t s) {
     if (!stft_subwave_applies(g) || n_cu == 0 || d_twc == nullptr) return hipErrorInvalidValue;
     if (!n_tiles) return hipSuccess;
-    constexpr size_t lds = sizeof(cf32) * (SW::T2_LEN + SW::T3_LEN + (size_t)16 * SUB_STRIDE) + 32 * sizeof(float);
-    static_assert(lds + 64 <= 160 * 1024, "tables and sixteen slabs fit the CU's LDS");
-    const bool reuse = TH_SUBW_REUSE && g.hop * 4 == g.n_fft;
-    auto kern = amp ? (reuse ? stft_subwave_kernel<true, true> : stft_subwave_kernel<true, false>)
-                    : (reuse ? stft_subwave_kernel<false, true> : stft_subwave_kernel<false, false>);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    const uint32_t grid = n_tiles < n_cu ? n_tiles : n_cu;  // persistent: one workgroup per CU walks every n_cu-th chunk
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax);
-    return hipGetLastError();
+    switch (g.log2_nc) {
+        case 14: return launch_subwave_r<4>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax, amp, n_cu, s);
+        case 13: return launch_subwave_r<3>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax, amp, n_cu, s);
+        default: return launch_subwave_r<2>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax, amp, n_cu, s);
+    }
 }
 
 }  // namespace th
