@@ -62,6 +62,8 @@ scripts/pmc_stft.sh "$out/pmc_stftmel" --sr 44100 --tracks 32 --seconds 60 --mel
 scripts/pmc_stft.sh "$out/pmc_stft4096dyn" --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 > "$out/pmc_stft4096dyn.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_melrows" --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 > "$out/pmc_melrows.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stftmel48" --sr 48000 --win 1920 --hop 480 --mel 0 > "$out/pmc_stftmel48.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_stftmel48_one_frame" --sr 48000 --win 1920 --hop 480 --mel 0 --kernel 13 > "$out/pmc_stftmel48_one_frame.log" 2>&1  # round 5: the one-frame epilogue (the default takes frame pairs)
+scripts/pmc_stft.sh "$out/pmc_subwave32768" --nfft 32768 > "$out/pmc_subwave32768.log" 2>&1   # round 5: stft_subwave_kernel
 fi
 if want 3; then
 {
@@ -87,7 +89,11 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 4096
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 8192
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 16384
-  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 32768
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 32768 --kernel 0 14   # round 5: stft_subwave_kernel | stft_block_kernel
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 32768 --win 19200 --hop 4800 --kernel 0 14
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 16384 --win 12000 --hop 3000 --kernel 0 14
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 16384 --kernel 0 15
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 8192 --kernel 0 15
   python3 scripts/bench_stft.py --reps 10 --gap-ms 1 --nfft 65536 --kernel 0 1   # round 5: planar block plan | generic kernel
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --win 1920 --hop 240 --kernel 0 4
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --win 1920 --hop 120 --kernel 0 4
@@ -105,6 +111,9 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 11025 --nfft 512 --win 441 --hop 110 --mel 0 --seconds 120 --kernel 0 3 7
   # the fused mel epilogue: banded sums (0) against pieces / gather (8)
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 48000 --win 1920 --hop 480 --mel 0 --kernel 0 8
+  # round 5: the epilogue in frame pairs (0) against one frame at a time (13) and pairs under the grid-aligned frame loop (5)
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 48000 --win 1920 --hop 480 --mel 0 --kernel 0 13 5
+  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 44100 --tracks 32 --seconds 60 --mel 128 --kernel 0 13
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 44100 --win 1764 --hop 441 --mel 0 --tracks 32 --seconds 60 --kernel 0 8
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 44100 --tracks 32 --seconds 60 --mel 128 --kernel 0 8
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 16000 --nfft 1024 --win 640 --hop 160 --mel 0 --seconds 90 --kernel 0 8

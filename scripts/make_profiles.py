@@ -60,7 +60,9 @@ for name, script in (("stft", "scripts/bench_stft.py"), ("stftpk", "scripts/benc
                      ("stftmel", "scripts/bench_stft.py --sr 44100 --tracks 32 --seconds 60 --mel 128"),
                      ("stft4096dyn", "scripts/bench_stft.py --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30"),
                      ("melrows", "scripts/bench_stft.py --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180"),
-                     ("stftmel48", "scripts/bench_stft.py --sr 48000 --win 1920 --hop 480 --mel 0")):
+                     ("stftmel48", "scripts/bench_stft.py --sr 48000 --win 1920 --hop 480 --mel 0"),
+                     ("stftmel48_one_frame", "scripts/bench_stft.py --sr 48000 --win 1920 --hop 480 --mel 0 --kernel 13"),
+                     ("subwave32768", "scripts/bench_stft.py --nfft 32768")):
     p = f"{src}/pmc_{name}/summary.txt"
     if os.path.exists(p):
         open(f"{dst}/{tag}_{name}_pmc_summary.txt", "w").write(hdr.format(script=script) + open(p).read())
