@@ -483,7 +483,10 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
 
 
 @pytest.mark.parametrize("sr,win,hop,n_fft,n_mel", [(48000, 1920, 480, 2048, 0), (44100, 2048, 512, 2048, 128), (48000, 2048, 1024, 2048, 0),
-                                                    (48000, 2048, 256, 2048, 256), (32000, 1280, 320, 2048, 0), (48000, 2048, 512, 2048, 40)])
+                                                    (48000, 2048, 256, 2048, 256), (32000, 1280, 320, 2048, 0), (48000, 2048, 512, 2048, 40),
+                                                    # n_fft 1024 (the 16 / 22.05 kHz defaults and rotating frame loops): two rows of 513 in a 1088-float slab
+                                                    (16000, 640, 160, 1024, 0), (22050, 884, 221, 1024, 0), (48000, 1024, 256, 1024, 128),
+                                                    (24000, 1024, 512, 1024, 0), (48000, 1024, 128, 1024, 200)])
 def test_mel_frame_pair_epilogue(ctx, sr, win, hop, n_fft, n_mel):
     """Round 5: the fused mel epilogue of the n_fft 2048 wave kernel takes the frames of a chunk in PAIRS — the first frame's
     amplitudes wait in registers, the second frame's epilogue runs the banded sums for both rows in one pass over the table

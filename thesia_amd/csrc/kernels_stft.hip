@@ -363,8 +363,18 @@ constexpr uint32_t MEL_PRF_1024 = 512;  // pieces of the per-wave (r, f) buffer 
 // pass's emit order) and nothing is written; 2 = second frame — its own amplitudes go to the second row of the slab, the first
 // frame's from ampA to the first row, and one pass over the banded table (mel_banded_pair) forms both frames' mel rows.  A chunk
 // that ends on a first frame is finished by wave_mel_flush.
-constexpr int MEL_PAIR_RB = 1092;     // float offset of the second amplitude row in the slab (n_fft 2048: 2176 floats; even, >= Nc + 1 + 64)
-constexpr uint32_t MEL_PAIR_PAD = 59;  // zeros behind the second row: 2176 - (1092 + 1025)
+// Slab layout of a frame pair: the second amplitude row RB floats behind the first (even; n_fft 2048: 1092 of the slab's 2176 floats,
+// n_fft 1024: 544 of 1088), zeros behind each row: PAD_A (up to 64, below the second row) and PAD_B (to the end of the slab); the
+// banded table may read min(PAD_A, PAD_B) floats past a row (the host checks the table's reach: stft_wave_mel_pair_applies)
+template <int LOG2_NC>
+struct MelPair {
+    static constexpr int NC = 1 << LOG2_NC, SLAB_F = 2 * WaveFft<LOG2_NC>::SLAB_LEN;
+    static constexpr int RB = LOG2_NC == 10 ? 1092 : SLAB_F / 2;
+    static constexpr int PAD_A = RB - (NC + 1) < 64 ? RB - (NC + 1) : 64, PAD_B = SLAB_F - (RB + NC + 1) < 64 ? SLAB_F - (RB + NC + 1) : 64;
+    static constexpr int PAD = PAD_A < PAD_B ? PAD_A : PAD_B;
+    static_assert(RB % 2 == 0 && PAD_A > 0 && PAD_B > 0, "two rows and their zeros fit the slab");
+};
+constexpr int MEL_PAIR_RB = MelPair<10>::RB;
 template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH = -1, bool PKV = false, bool SWEEPF = false, int MELP = 0>
 __device__ __forceinline__ void wave_frame(
     const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
@@ -377,8 +387,8 @@ __device__ __forceinline__ void wave_frame(
     gptr<const float> nwav = nullptr, int64_t ne0 = 0) {
     constexpr bool AMP = OUT == 1, MELF = OUT == 2 || OUT == 3;
     static_assert((OUT == 3) == (MELP != 0), "frame pairs: OUT = 3 with MELP = 1 (first frame) or 2 (second)");
-    static_assert(OUT != 3 || (LOG2_NC == 10 && !PKV && 2 * (int)WaveFft<LOG2_NC>::SLAB_LEN >= MEL_PAIR_RB + WaveFft<LOG2_NC>::NC + 1 + (int)MEL_PAIR_PAD),
-                  "frame pairs: n_fft 2048, scalar pipeline, two amplitude rows per slab");
+    static_assert(OUT != 3 || ((LOG2_NC == 10 || LOG2_NC == 9) && !PKV), "frame pairs: n_fft 1024 / 2048, scalar pipeline");
+    using MP = MelPair<(LOG2_NC == 9 || LOG2_NC == 10) ? LOG2_NC : 10>;
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
     // Per-frame opaque copy of the lane id.  Everything below addresses LDS and the output row as
@@ -583,7 +593,7 @@ __device__ __forceinline__ void wave_frame(
             if constexpr (MELP == 1) {
                 ampA[amp_i++ % (OUT == 3 ? W::N_EMIT : 1)] = power_to_amp_scaled(p);  // first frame of a pair: kept for the second one's epilogue
             } else if constexpr (MELF) {
-                slab_f[(MELP == 2 ? (uint32_t)MEL_PAIR_RB : 0u) + kb + (uint32_t)kc] = power_to_amp_scaled(p);  // the slab is free after the second exchange: amplitude row for mel_pieces
+                slab_f[(MELP == 2 ? (uint32_t)MP::RB : 0u) + kb + (uint32_t)kc] = power_to_amp_scaled(p);  // the slab is free after the second exchange: amplitude row for mel_pieces
             } else if constexpr (AMP) {
                 TH_ROW_STORE(row_at(kb, kc), power_to_amp(p));
             } else {
@@ -612,9 +622,12 @@ __device__ __forceinline__ void wave_frame(
         W::pass3_sw(sl, z, w3, z256);
         W::mirror_swap(sl, z);
         float *const slab_f = reinterpret_cast<float *>(slab);
+        int amp_i = 0;  // (a constant at every call once split_sw is unrolled)
         auto emit = [&](uint32_t kb, int kc, float p) {  // bin kb + kc: per-lane base + compile-time constant
-            if constexpr (MELF) {
-                slab_f[kb + (uint32_t)kc] = power_to_amp_scaled(p);
+            if constexpr (MELP == 1) {
+                ampA[amp_i++ % (OUT == 3 ? W::N_EMIT : 1)] = power_to_amp_scaled(p);  // first frame of a pair (see the mirror-local path)
+            } else if constexpr (MELF) {
+                slab_f[(MELP == 2 ? (uint32_t)MP::RB : 0u) + kb + (uint32_t)kc] = power_to_amp_scaled(p);
             } else {
                 const float d = AMP ? power_to_amp(p) : power_to_dB(p);
                 *(gptr<float>)((gptr<char>)row + (uint64_t)(kb << 2) + (int64_t)(4 * kc)) = d;
@@ -633,8 +646,8 @@ __device__ __forceinline__ void wave_frame(
             int k = 0;
             W::split_enumerate(lane, [&](uint32_t kb, int kc) { slab_f[kb + (uint32_t)kc] = ampA[k++ % W::N_EMIT]; });
         }
-        slab_f[NC + 1 + lane] = 0.0f;  // [Nc + 1, Nc + 65) < MEL_PAIR_RB
-        if (lane < MEL_PAIR_PAD) slab_f[MEL_PAIR_RB + NC + 1 + lane] = 0.0f;
+        if (MP::PAD_A >= 64 || lane < (uint32_t)MP::PAD_A) slab_f[NC + 1 + lane] = 0.0f;  // below the second row
+        if (MP::PAD_B >= 64 || lane < (uint32_t)MP::PAD_B) slab_f[MP::RB + NC + 1 + lane] = 0.0f;
         wave_lds_sync();
         const gptr<float> row_a = row - spec_pitch;
         float mn = __builtin_inff(), mx = -__builtin_inff();  // of the pair's rows (values fresh from an FMA: no canonicalising per group)
@@ -655,7 +668,7 @@ __device__ __forceinline__ void wave_frame(
 #if defined(TH_MELF_ABL) && (TH_MELF_ABL & 1)
         if (wo.n_mel == 0x7fffffffu)
 #endif
-        mel_banded_pair<MEL_PAIR_RB>(lane, slab_f, meltab, wo.mel_groups, wo.band_off, wo.band_n, emit_a, emit_b);
+        mel_banded_pair<MP::RB, LOG2_NC != 9>(lane, slab_f, meltab, wo.mel_groups, wo.band_off, wo.band_n, emit_a, emit_b);
         lmin = nmin(lmin, mn);
         lmax = nmax(lmax, mx);
         wave_lds_sync();  // the next frame's pass 1 rewrites the slab
@@ -766,11 +779,13 @@ __device__ __forceinline__ void wave_mel_flush(cf32 *slab, uint32_t lane_wave, u
 // The (job, first frame) chunk table, the per-chunk (min, max) slots and wave_post_kernel's fold are the ones of the default
 // schedule; queue_head counts blocks here.
 constexpr uint32_t SWEEP_BLK = 12, SWEEP_RING = 8;
+// (the kernel's body as an inlined device function: two __global__ entry points share it — stft_wave_kernel, and
+// stft_wave_kernel_occ6 with a register budget for six waves per SIMD, see below)
 template <int LOG2_NC, int WAVES, int SHIFT, int OUT, int RES, bool PKV = false, bool SWEEP = false>
-__global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
-    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
+__device__ __forceinline__ void stft_wave_body(
+    const StftGeom &g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
     uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
-    uint32_t *__restrict__ queue_head, WaveOut wo) {
+    uint32_t *__restrict__ queue_head, const WaveOut &wo) {
     using W = WaveFft<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC;
     // SHIFT = -1: "phased" mode for hop = 3 * 128 + 96 samples (the app's 40 ms / 4 at 48 kHz = 480) with n_fft - win
@@ -1117,6 +1132,24 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
 #undef TH_FRAME_P
 #undef TH_BODY_SHIFT
 #undef TH_BODY_OFF
+}
+
+template <int LOG2_NC, int WAVES, int SHIFT, int OUT, int RES, bool PKV = false, bool SWEEP = false>
+__global__ __launch_bounds__(64 * WAVES) void stft_wave_kernel(
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
+    uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
+    uint32_t *__restrict__ queue_head, WaveOut wo) {
+    stft_wave_body<LOG2_NC, WAVES, SHIFT, OUT, RES, PKV, SWEEP>(g, jobs, chunk_tab, n_chan, n_tiles, wtab_g, tw, minmax, queue_head, wo);
+}
+// The same with at least six waves per SIMD asked of the register allocator (HIP's second __launch_bounds__ argument: 80 VGPRs).
+// The n_fft 1024 kernel runs two workgroups of twelve waves per CU; its frame-pair mel variant keeps nine amplitudes across the
+// next frame's transform and would otherwise take 81 registers — one more than two workgroups leave a wave.
+template <int LOG2_NC, int WAVES, int SHIFT, int OUT, int RES>
+__global__ __launch_bounds__(64 * WAVES, 6) void stft_wave_kernel_occ6(
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_chan,
+    uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax,
+    uint32_t *__restrict__ queue_head, WaveOut wo) {
+    stft_wave_body<LOG2_NC, WAVES, SHIFT, OUT, RES, false, false>(g, jobs, chunk_tab, n_chan, n_tiles, wtab_g, tw, minmax, queue_head, wo);
 }
 
 
@@ -2034,6 +2067,8 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
     auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES), (TH_USE_PK != 0)>;
     if constexpr (PK_SHAPE && TH_USE_PK == 0)
         if (pkv) kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES), true>;
+    if constexpr (LOG2_NC == 9 && OUT == 3 && WAVES == 12 && TH_USE_PK == 0)  // two workgroups per CU: 80 VGPRs (see the entry point)
+        kern = stft_wave_kernel_occ6<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES)>;
     // the sweep chunk schedule (large batches; the host then cut 4-frame chunks): the same shape, scalar pipeline
     bool sweep = false;
     if constexpr (PK_SHAPE) {
@@ -2078,7 +2113,7 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
         }
         // (n_fft 4096, round 5: the banded table from global memory, for hop 1024 and the 96 / 88.2 kHz defaults — stft_wave_mel_fits)
         // (round 5: frame pairs — two consecutive frames per pass over the banded table; n_fft 2048, plain or rotating frame loop)
-        if constexpr (LOG2_NC == 10) {
+        if constexpr (LOG2_NC == 10 || LOG2_NC == 9) {
             if (out.mode == 2 && out.mel_pair != 0) {
                 if (out.mel_slots != 0) return hipErrorInvalidValue;  // (banded sums only)
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 3>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
@@ -2255,10 +2290,10 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool bande
     return false;
 }
 bool stft_wave_mel_pair_applies(const StftGeom &g, int waves, uint32_t reach) {
-    if (g.log2_nc != 10) return false;  // (any frame loop of n_fft 2048: plain, rotating, phased, dynamic)
-    if (!(waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES)) return false;
-    // the launch shapes launch_wave_t3 instantiates for non-negative SHIFT: hop = n_fft / 4, / 2, / 8 (rotation) and "no reuse"
-    return reach <= g.n_freq + MEL_PAIR_PAD;  // reads stay inside the zeros behind each of the two amplitude rows
+    // (any frame loop of n_fft 1024 / 2048: plain, rotating, phased, dynamic; the default launch shape)
+    if (g.log2_nc == 10) return (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES) && reach <= g.n_freq + (uint32_t)MelPair<10>::PAD;
+    if (g.log2_nc == 9) return (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) && reach <= g.n_freq + (uint32_t)MelPair<9>::PAD;
+    return false;  // reads must stay inside the zeros behind each of the two amplitude rows
 }
 // (the same sum as launch_wave_multi_n; ADVICE r3: without this check a small growth of SLAB_LEN or MEL_ROWS_W would turn the
 // default path into hipErrorInvalidValue at launch instead of the two-kernel fallback)

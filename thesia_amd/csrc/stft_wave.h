@@ -985,9 +985,19 @@ struct WaveFft {
     }
     // The bins of split_paired_w's emit calls, in its order: fn(base, C) once per call (the last one, bin Nc / 2, on lane 0 only).
     // The frame-pair mel epilogue keeps a frame's amplitudes in registers in emit order and lays them out as a row one frame later.
-    static constexpr int N_EMIT = 2 * NQ * R3 + 1;
+    // (n_fft 1024, split_sw: nine calls — S1_i and S2_i for i < 4, then bin Nc on lane 0)
+    static constexpr int N_EMIT = PAIRED ? 2 * NQ * R3 + 1 : 9;
     template <class Fn>
     static TH_HD void split_enumerate(uint32_t lane, Fn fn) {
+        if constexpr (!PAIRED) {
+            const Swap8Lane s = swap8_lane(lane);
+            TH_UNROLL for (int i = 0; i < 4; i++) {
+                fn(s.b1, 64 * i);
+                fn(s.b2, 64 * (3 - i));
+            }
+            if (s.l0) fn((uint32_t)NC, 0);
+            return;
+        }
         const bool l0 = (lane & 63u) == 0;
         const SplitBase sb = split_base(lane);
         TH_UNROLL for (int q = 0; q < NQ; q++) {
@@ -1534,14 +1544,19 @@ typedef const float *lds_cfp;
 TH_HD f32x4 ldsp_ld4(lds_cfp p) { return {p[0], p[1], p[2], p[3]}; }
 TH_HD cf32 ldsp_ld2(lds_cfp p) { return {p[0], p[1]}; }
 #endif
-template <int RB, class EmitA, class EmitB>
+// WIDE = false: four taps per loop trip instead of eight (24 registers fewer in flight: the n_fft 1024 kernel lives on 80 VGPRs)
+template <int RB, bool WIDE = true, class EmitA, class EmitB>
 TH_HD void mel_banded_pair(uint32_t lane, const float *amp, const uint32_t *tab, uint32_t n_groups, const uint32_t (&off)[8],
                            const uint32_t (&n)[8], EmitA emitA, EmitB emitB) {
-    uint32_t lo[8];  // every group's first bin up front: one LDS round trip for all of them
-    TH_UNROLL for (uint32_t g = 0; g < 8; g++) lo[g] = tab[off[g < n_groups ? g : 0] + lane];
+    // every group's first bin up front: one LDS round trip for all of them (WIDE); the narrow form keeps one group ahead instead
+    // (two registers, not eight)
+    uint32_t lo[8];
+    TH_UNROLL for (uint32_t g = 0; g < (WIDE ? 8u : 1u); g++) lo[g] = tab[off[g < n_groups ? g : 0] + lane];
     const lds_cfp amp3 = TH_TO_LDS_CFP(amp), tab3 = TH_TO_LDS_CFP(reinterpret_cast<const float *>(tab)) + 4u * lane;
     TH_UNROLL for (uint32_t g = 0; g < 8; g++) {
         if (g < n_groups) {  // wave-uniform
+            if constexpr (!WIDE)
+                if (g + 1 < 8) lo[(g + 1) % 8] = tab[off[g + 1 < n_groups ? g + 1 : 0] + lane];
             lds_cfp ap = amp3 + lo[g];
             lds_cfp wp = tab3 + (off[g] + 64u);
             float sa[4], sb[4];
@@ -1560,7 +1575,7 @@ TH_HD void mel_banded_pair(uint32_t lane, const float *amp, const uint32_t *tab,
             ap += 4;
             wp += 256;
             uint32_t t = 4;
-            for (; t + 8 <= n[g]; t += 8, ap += 8, wp += 512) {
+            for (; WIDE && t + 8 <= n[g]; t += 8, ap += 8, wp += 512) {
                 const f32x4 w0 = ldsp_ld4(wp), w1 = ldsp_ld4(wp + 256);
                 cf32 a[4], b[4];
                 TH_UNROLL for (uint32_t u = 0; u < 4; u++) a[u] = ldsp_ld2(ap + 2u * u);
@@ -1582,7 +1597,7 @@ TH_HD void mel_banded_pair(uint32_t lane, const float *amp, const uint32_t *tab,
                 sb[2] = fma_rn(b[3].re, w1.c, sb[2]);
                 sb[3] = fma_rn(b[3].im, w1.d, sb[3]);
             }
-            if (t < n[g]) {  // (n is a multiple of 4)
+            for (; t < n[g]; t += 4, ap += 4, wp += 256) {  // (n is a multiple of 4; WIDE: at most one trip)
                 const f32x4 w = ldsp_ld4(wp);
                 const cf32 a01 = ldsp_ld2(ap), a23 = ldsp_ld2(ap + 2), b01 = ldsp_ld2(ap + RB), b23 = ldsp_ld2(ap + RB + 2);
                 sa[0] = fma_rn(a01.re, w.a, sa[0]);
