@@ -63,6 +63,8 @@ constexpr int SUB_LOG2 = 10;                       // the sub-transform: WaveFft
 using SW = WaveFft<SUB_LOG2>;
 constexpr int SUB_STRIDE = SW::SLAB_LEN + 2;       // cf32 per slab: 16-byte aligned, and consecutive slabs four banks apart (phase 0's scatter)
 
+}  // namespace
+
 // LOG2_R = 4 (n_fft 32768: sixteen sub-transforms, 1024 threads, one workgroup per CU), 3 (n_fft 16384: eight, 512 threads, two
 // workgroups per CU) or 2 (n_fft 8192: four, 256 threads, four per CU).  The combining pass is the radix-R twiddled FMA butterfly of
 // stft_wave.h / stft_block.h; with R < 16 a thread combines 16 / R bins k2 (tid, tid + 64 R, ...), so that it always ends up with the
@@ -75,7 +77,9 @@ struct SubwaveCfg {
     static constexpr size_t LDS = sizeof(cf32) * (SW::T2_LEN + SW::T3_LEN + (size_t)R * SUB_STRIDE) + 2 * R * sizeof(float);
 };
 template <int LOG2_R, bool AMP, bool REUSE>
-__global__ __launch_bounds__(SubwaveCfg<LOG2_R>::NT, SubwaveCfg<LOG2_R>::WG_PER_CU) void stft_subwave_kernel(
+// (HIP's second __launch_bounds__ argument is the least number of waves per SIMD to leave room for: four — 16 waves per CU, 128 VGPRs —
+// at every R; without it the R = 8 kernel with resident samples took 149 registers and its second workgroup no longer fitted the CU)
+__global__ __launch_bounds__(SubwaveCfg<LOG2_R>::NT, 4) void stft_subwave_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_tiles, const cf32 *__restrict__ wtab_g,
     const cf32 *__restrict__ tw, const cf32 *__restrict__ twc, float *__restrict__ minmax) {
     using C = SubwaveCfg<LOG2_R>;
@@ -168,7 +172,11 @@ __global__ __launch_bounds__(SubwaveCfg<LOG2_R>::NT, SubwaveCfg<LOG2_R>::WG_PER_
     };
     // phase 0: window, then to sub-transform tid mod R as column tid / R (slot 64 j + column)
     auto stage = [&](uint32_t tid, const cf32 (&x)[16], const cf32 (&xw)[16]) {
-        cf32 *const dst = slabs + (size_t)(tid & (uint32_t)(R - 1)) * SUB_STRIDE + (tid >> LOG2_R);
+        // column c of sub-transform n1 goes where the lane that owns it (lane_col(l) = c: l = (c >> 2) + 16 (c & 3)) reads in lane
+        // order — reading by column was a 4-way bank conflict on all sixteen reads (SQ_LDS_BANK_CONFLICT 16 % of the LDS cycles);
+        // R = 16: rotated by n1 within the 64 slots, so that the sixteen slabs a wave scatters to start on different bank pairs
+        const uint32_t c = tid >> LOG2_R, n1 = tid & (uint32_t)(R - 1);
+        cf32 *const dst = slabs + (size_t)n1 * SUB_STRIDE + (((c >> 2) + 16u * (c & 3u) - (R == 16 ? n1 : 0u)) & 63u);
 #pragma unroll
         for (int j = 0; j < 16; j++) lds_st(&dst[64 * j], cf32{x[j].re * xw[j].re, x[j].im * xw[j].im});
     };
@@ -235,9 +243,10 @@ __global__ __launch_bounds__(SubwaveCfg<LOG2_R>::NT, SubwaveCfg<LOG2_R>::WG_PER_
         // ---- phase 1: the 1024-point transform of this wave (stft_wave.h; no workgroup barrier inside)
         cf32 z[16];
         {
-            const uint32_t col = SW::lane_col(lane);
+            static_assert(SW::PLANES, "lane_col(l) = 4 (l & 15) + (l >> 4): the staging layout above is its inverse");
+            const uint32_t at = (lane - (R == 16 ? wv : 0u)) & 63u;
 #pragma unroll
-            for (int m = 0; m < 16; m++) z[m] = lds_ld(&slab[64 * m + col]);
+            for (int m = 0; m < 16; m++) z[m] = lds_ld(&slab[64 * m + at]);
         }
         wave_lds_sync_l();
         cf32 za[SW::NQ][SW::R3], zb[SW::NQ][SW::R3];
@@ -401,8 +410,6 @@ __global__ __launch_bounds__(SubwaveCfg<LOG2_R>::NT, SubwaveCfg<LOG2_R>::WG_PER_
         cur = nxt;
     }
 }
-
-}  // namespace
 
 bool stft_subwave_applies(const StftGeom &g) { return g.log2_nc >= 12 && g.log2_nc <= 14 && g.odd_m1 == 0; }
 // Where it is the default (profiles/r05_ab_subwave_sizes.txt, ms for 128 ch x 30 s, subwave | block): n_fft 32768 1.26 | 1.85 (19200 / 4800: 2.40 |
