@@ -830,7 +830,31 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
 #endif
         const uint64_t n_waves = (uint64_t)c->n_cu * (uint64_t)waves;
         uint64_t chunk;
-        if (total <= n_waves * 32) {
+        if (th::stft_is_block_plan(g) && g.log2_nc <= 14) {
+            // Workgroup-per-frame plans (n_fft 8192 .. 32768): what runs side by side is one workgroup per CU (two at n_fft 8192),
+            // not twelve waves, and a chunk start costs a workgroup launch + its set-up (30-50 us: tables / constants, the first
+            // frame) or, in the persistent subwave kernel, a full reload of the resident samples.  About two chunks per slot, the
+            // length that fills the last round best (round 5, profiles/r05_ab_block_chunks.txt: n_fft 16384 15 -> 44 frames 0.96 ->
+            // 0.84-0.92 ms, 32768 8 -> 43 1.26 -> 1.21, 8192 30 -> 60-90 0.70 -> 0.64-0.69; n_fft 65536 measures 5 % slower with
+            // longer chunks and keeps the rule below)
+            const uint64_t slots = (uint64_t)c->n_cu * (g.log2_nc == 12 ? 2u : 1u);
+            const uint64_t want = std::min<uint64_t>(128, std::max<uint64_t>(1, total / (slots * 2)));  // (a single track: one frame per chunk, every CU busy)
+            uint64_t best = want, best_cost = ~0ull;
+            for (uint64_t cand = std::max<uint64_t>(1, want - want / 4); cand <= want + want / 4; cand++) {
+                uint64_t n = 0;
+                for (size_t i = 0; i < n_chan; i++) {
+                    uint64_t fa, fb;
+                    interior(chans[i], chans[i].n_frames, fa, fb);
+                    n += (fb - fa + cand - 1) / cand;
+                }
+                const uint64_t cost = (n + slots - 1) / slots * cand;
+                if (cost < best_cost || (cost == best_cost && cand > best)) {
+                    best_cost = cost;
+                    best = cand;
+                }
+            }
+            chunk = best;
+        } else if (total <= n_waves * 32) {
             // small batch (one track ...): one chunk per wave, all of them assigned statically — the kernel then never
             // touches the queue (3072 waves finding it empty is 25 us of serialised atomics on a 20 us job)
             chunk = std::max<uint64_t>(1, (total + n_waves - 1) / n_waves);
