@@ -100,9 +100,9 @@ def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
     # n_fft 32768 is the largest frame that fits the CU's LDS: workgroup-per-frame kernel (1024 threads, stft_block.h), with the
     # matrix-core filterbank for mel plans of ANY mel count (round 4: the default counts — 5571 mels here — used to drop to
     # the generic kernel); beyond 32768 the generic kernel
-    # (round 5: n_fft 32768 as sixteen 1024-point wave transforms + one combining pass, stft_subwave_kernel; selector 14 keeps
-    # the block kernel: both run below)
-    fft = "stft_subwave_kernel" if n_fft == 32768 else "stft_block_kernel"
+    # (round 5: n_fft 32768 as sixteen 1024-point wave transforms + one combining pass, stft_subwave_kernel — n_fft 65536 as two
+    # such half transforms behind a radix-2 step, stft_subwave2_kernel; selector 14 keeps the block kernels: both run below)
+    fft = "stft_subwave_kernel" if n_fft in (32768, 65536) else "stft_block_kernel"
     want_kernel = ("stft_generic_kernel" if n_fft > 65536 else  # (65536: round 5, planar exchanges)
                    fft + "+mel_mfma_kernel" if scale else fft)
     assert plan.kernel_name == want_kernel
@@ -128,7 +128,7 @@ def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
             assert_spec_close(b[i], want, amp if fb is None else None)
     if ref is not None:
         ref.close()
-    if n_fft == 32768:  # the block kernel on the same batch: same tables and butterflies, another order of passes
+    if n_fft in (32768, 65536):  # the block kernel on the same batch: same tables and butterflies, another order of passes
         old = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, n_mel)
         old.set_kernel(14)
         assert old.kernel_name == want_kernel.replace("stft_subwave_kernel", "stft_block_kernel")

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#include <vector>
 
 #include "kernels.h"
 #include "stft_block.h"
@@ -411,15 +412,273 @@ __global__ __launch_bounds__(SubwaveCfg<LOG2_R>::NT, 4) void stft_subwave_kernel
     }
 }
 
-bool stft_subwave_applies(const StftGeom &g) { return g.log2_nc >= 12 && g.log2_nc <= 14 && g.odd_m1 == 0; }
+// ------------------------------------------------------------------------------------------
+// n_fft 65536 (Nc = 32768 packed points) on the same machinery: one radix-2 decimation-in-FREQUENCY step in front,
+//     a[n] = z[n] + z[n + 16384],   b[n] = (z[n] - z[n + 16384]) W_32768^n,      Z[2 k] = DFT_16384(a)[k],  Z[2 k + 1] = DFT_16384(b)[k],
+// and the sixteen-wave pipeline above (staging -> sixteen 1024-point wave transforms -> radix-16 combining pass) run twice per frame,
+// once on a and once on b.  Both half-spectra end up as thread t's A[t + 1024 c] and B[t + 1024 c] — and the real-FFT split pass
+// never mixes them: bin m = 2 k pairs Z[2 k] = A[k] with Z[N - 2 k] = A[16384 - k], bin m = 2 k + 1 pairs B[k] with B[16383 - k].
+// So A goes through the n_fft 32768 plan's mirror exchange and split pass unchanged (its bins k are the even bins 2 k: W_65536^(2 k) =
+// W_32768^k), B through a plain reversal with the twiddles W_65536^(2 k + 1), and a thread's results are the adjacent bins (2 k, 2 k + 1)
+// and (N - 2 k - 1, N - 2 k): 8-byte stores.  Eleven barriers per frame where the planar block plan has 33; 1024 threads instead of 512.
+// ------------------------------------------------------------------------------------------
+template <bool AMP>
+__global__ __launch_bounds__(1024, 4) void stft_subwave2_kernel(StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab,
+                                                                uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw,
+                                                                const cf32 *__restrict__ twc, float *__restrict__ minmax) {
+    using B = BlockFft<14>;  // the half transforms: 16384 points
+    constexpr int NH = B::NC, R = 16, NT = 1024;
+    static_assert(B::T == NT && NH == R * SW::NC, "two 16384-point half transforms of sixteen wave transforms each");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf32 *const t2 = reinterpret_cast<cf32 *>(smem_raw);
+    cf32 *const t3 = t2 + SW::T2_LEN;
+    float *const red = reinterpret_cast<float *>(t3 + SW::T3_LEN);
+    cf32 *const slabs = reinterpret_cast<cf32 *>(red + 2 * R);
+
+    const uint32_t t = threadIdx.x, lane_w = t & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (blockIdx.x >= n_tiles) return;
+    // sub-transform tables: W_2048^i = tw[32 i] (tw = W_65536^i)
+    constexpr uint32_t TS = 32;
+    for (uint32_t i = t; i < (uint32_t)SW::T2_LEN; i += (uint32_t)NT) t2[i] = tw[TS * SW::t2_index(i / SW::NS2, i % SW::NS2)];
+    for (uint32_t i = t; i < (uint32_t)SW::T3_LEN; i += (uint32_t)NT) {
+        const uint32_t r = i / SW::NS3 + 1, k = i % SW::NS3;
+        t3[i] = tw[TS * ((r * k) * (2u * SW::NC / (SW::NS3 * SW::R3)))];
+    }
+    const cf32 stw_a = tw[2 * t], stw_b = tw[2 * t + 1];  // W_65536^(2 t), W_65536^(2 t + 1): split twiddles of the even / odd bins; stw_a also = W_32768^t
+    __syncthreads();
+    cf32 *const slab = slabs + (size_t)wv * SUB_STRIDE;
+    // exp(-i pi j / 16), j = 0 .. 15
+    constexpr float RC[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                              0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.0f, -0.19509032201612826785f,
+                              -0.38268343236508977173f, -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                              -0.92387953251128675613f, -0.98078528040323044913f};
+    constexpr float RS[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f, 0.70710678118654752440f,
+                              0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f, 1.0f, 0.98078528040323044913f,
+                              0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                              0.38268343236508977173f, 0.19509032201612826785f};
+    float lmin = __builtin_inff(), lmax = -__builtin_inff();
+    for (uint32_t ct = blockIdx.x; ct < n_tiles; ct += gridDim.x) {  // persistent: every gridDim.x-th chunk
+        const uint32_t chan = chunk_tab[2 * (size_t)ct], f0 = chunk_tab[2 * (size_t)ct + 1];
+        const uint32_t f1 = min(f0 + g.frames_per_tile, jobs[chan].f_end), spec_pitch = jobs[chan].spec_pitch;
+        const gptr<const float> wav = as_global(jobs[chan].wav);
+        const gptr<float> spec = as_global(jobs[chan].spec);
+        for (uint32_t f = f0; f < f1; f++) {
+            uint32_t tt = t, lane = lane_w;
+            asm volatile("" : "+v"(tt), "+v"(lane));
+            tt &= 1023u;
+            lane &= 63u;
+            const int64_t e0 = (int64_t)f * g.hop - (int64_t)(g.win / 2) - (int64_t)g.pad_left;  // interior frames only
+            // (opaque per-frame copies: the 32 rotated twiddles derived from them are loop-invariant, and hoisted out of the frame
+            // loop they are 64 registers that get spilled — recomputing them is two to four operations each)
+            cf32 sa = stw_a, sb = stw_b;
+            asm volatile("" : "+v"(sa.re), "+v"(sa.im), "+v"(sb.re), "+v"(sb.im));
+            cf32 ha[16];  // A[tt + 1024 c] (kept through the second half transform)
+            cf32 z[16];
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                // ---- staging: thread tt forms a / b at the points tt + 1024 j (-> sub-transform tt mod 16, column tt / 16)
+                {
+                    // (an opaque thread index per pass: otherwise the second pass's loads are recognised as the first's and all 64
+                    // loaded pairs are carried from one pass to the other — through scratch)
+                    uint32_t tp = tt;
+                    asm volatile("" : "+v"(tp));
+                    tp &= 1023u;
+                    const uint32_t c = tp >> 4, n1 = tp & 15u;
+                    cf32 *const dst = slabs + (size_t)n1 * SUB_STRIDE + (((c >> 2) + 16u * (c & 3u) - n1) & 63u);
+                    // four points at a time, the next batch's 16 loads in flight while this one is multiplied and stored (two sets of
+                    // 32 registers; all 64 loads of a stage at once would be 128)
+                    cf32 xl[2][4], xh[2][4], wl[2][4], wh[2][4];
+                    auto request = [&](int h, int s_) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int j = 4 * h + i;
+                            const gptr<const float> pl = wav + (e0 + 2 * NT * (int64_t)j), ph = pl + 2 * NH;
+                            xl[s_][i] = {pl[2u * tp], pl[2u * tp + 1u]};
+                            xh[s_][i] = {ph[2u * tp], ph[2u * tp + 1u]};
+                            wl[s_][i] = (wtab_g + NT * j)[tp];
+                            wh[s_][i] = (wtab_g + NH + NT * j)[tp];
+                        }
+                    };
+                    // (the second pass keeps the first half spectrum in 32 registers: one batch in flight there)
+                    if (pass == 0) request(0, 0);
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        if (pass == 0) {
+                            if (h + 1 < 4) request(h + 1, (h + 1) & 1);
+                        } else {
+                            request(h, 0);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int j = 4 * h + i, s_ = pass == 0 ? (h & 1) : 0;
+                            const cf32 lo = {xl[s_][i].re * wl[s_][i].re, xl[s_][i].im * wl[s_][i].im}, hi = {xh[s_][i].re * wh[s_][i].re, xh[s_][i].im * wh[s_][i].im};
+                            cf32 v;
+                            if (pass == 0) {
+                                v = {lo.re + hi.re, lo.im + hi.im};
+                            } else {  // (lo - hi) W_32768^(tt + 1024 j) = (lo - hi) stw_a exp(-i pi j / 16)
+                                const cf32 d = {lo.re - hi.re, lo.im - hi.im};
+                                const cf32 w = cmul_c(sa, RC[j], -RS[j]);
+                                v = cmul_c(d, w.re, w.im);
+                            }
+                            lds_st(&dst[64 * j], v);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);  // (batch by batch: scheduled together, the 64 loads of a stage need 128 registers)
+                    }
+                }
+                lds_barrier();
+                // ---- the wave's 1024-point transform
+                {
+                    const uint32_t at = (lane - wv) & 63u;
+#pragma unroll
+                    for (int m = 0; m < 16; m++) z[m] = lds_ld(&slab[64 * m + at]);
+                }
+                wave_lds_sync_l();
+                {
+                    cf32 za[SW::NQ][SW::R3], zb[SW::NQ][SW::R3];
+                    cf32 w2[SW::NT2];
+                    SW::load_t2(lane, w2, t2);
+                    SW::pass1(lane, z, slab);
+                    wave_lds_sync_l();
+                    SW::read1(lane, z, slab);
+                    wave_lds_sync_l();
+                    SW::pass2_w(lane, z, w2, slab);
+                    wave_lds_sync_l();
+                    cf32 wa[SW::NQ][SW::NT3], wb[SW::NQ][SW::NT3];
+                    const typename SW::PairBase pbs = SW::pair_base(lane);
+                    SW::load_t3_paired(pbs, wa, wb, t3);
+                    SW::read2_paired(lane, pbs, za, zb, slab);
+                    wave_lds_sync_l();
+                    SW::pass3_paired_w(za, zb, wa, wb);
+#pragma unroll
+                    for (int q = 0; q < SW::NQ; q++) {
+                        const uint32_t a = SW::jj_a(lane, q), b = SW::jj_b(lane, q);
+#pragma unroll
+                        for (int r = 0; r < SW::R3; r++) {
+                            lds_st(&slab[a + (uint32_t)(r * SW::NS3)], za[q][r]);
+                            lds_st(&slab[b + (uint32_t)(r * SW::NS3)], zb[q][r]);
+                        }
+                    }
+                }
+                // (the combining pass's constants: requested behind the sub-transform — its registers are free — they land during the barrier)
+                cf32 wC[B::NTW];
+#pragma unroll
+                for (int e = 0; e < B::NTW; e++) wC[e] = (twc + NT * e)[tt];
+                lds_barrier();
+                // ---- combining pass: z[c] = half-spectrum bin tt + 1024 c
+#pragma unroll
+                for (int n1 = 0; n1 < 16; n1++) z[n1] = lds_ld(&slabs[(size_t)n1 * SUB_STRIDE + tt]);
+                B::pass_last(z, wC);
+                if (pass == 0) {
+#pragma unroll
+                    for (int c = 0; c < 16; c++) ha[c] = z[c];
+                }
+                lds_barrier();  // the slabs have been read: the next staging / the mirror exchange may write them
+            }
+            // ---- even bins: A through the n_fft 32768 plan's mirror exchange and split pass; results kept (bins 2 k, N - 2 k)
+            const gptr<float> row = spec + (size_t)f * spec_pitch;
+            float ra[17];
+            {
+                B::write_z(tt, ha, slabs);
+                lds_barrier();
+                cf32 zm[8];
+                B::split_read(tt, slabs, zm);
+                lds_barrier();
+                // (BlockFft::split_compute's arithmetic, results into registers: bins k = tt + 1024 c -> ra[2 c], 16384 - k -> ra[2 c + 1])
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const cf32 w = cmul_c(sa, RC[c], -RS[c]);  // W_32768^(tt + 1024 c)
+                    const cf32 zk = ha[c];
+                    const float er = zk.re + zm[c].re, ei = zk.im - zm[c].im;
+                    const float dr = zk.re - zm[c].re, di = zk.im + zm[c].im;
+                    const float xr = th_fma(di, w.re, th_fma(dr, w.im, er)), xi = th_fma(di, w.im, th_fma(-dr, w.re, ei));
+                    const float yr = th_fma(2.0f, er, -xr), yi = th_fma(2.0f, ei, -xi);
+                    const float px = xr * xr + xi * xi, py = yr * yr + yi * yi;
+                    ra[2 * c] = AMP ? power_to_amp(px) : power_to_dB(px);
+                    ra[2 * c + 1] = AMP ? power_to_amp(py) : power_to_dB(py);
+                }
+                {   // bin 8192 = Z[8 T] of thread 0: its own mirror, W^(Nc/2) = -i (only thread 0's value is used)
+                    const cf32 zh = ha[8];
+                    const float xr = 2.0f * zh.re, xi = -2.0f * zh.im;
+                    const float p = xr * xr + xi * xi;
+                    ra[16] = AMP ? power_to_amp(p) : power_to_dB(p);
+                }
+            }
+            // ---- odd bins: B[k] pairs with B[16383 - k]
+#pragma unroll
+            for (int c = 0; c < 16; c++) lds_st(&slabs[tt + (uint32_t)(NT * c)], z[c]);
+            lds_barrier();
+            cf32 zm[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) zm[c] = lds_ld(&slabs[(uint32_t)(NH - 1) - tt - (uint32_t)(NT * c)]);
+            lds_barrier();  // the slabs are free for the next frame's staging
+            float fmn = __builtin_inff(), fmx = -__builtin_inff();
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const cf32 w = cmul_c(sb, RC[c], -RS[c]);  // W_65536^(2 (tt + 1024 c) + 1)
+                const cf32 zk = z[c];
+                const float er = zk.re + zm[c].re, ei = zk.im - zm[c].im;
+                const float dr = zk.re - zm[c].re, di = zk.im + zm[c].im;
+                const float xr = th_fma(di, w.re, th_fma(dr, w.im, er)), xi = th_fma(di, w.im, th_fma(-dr, w.re, ei));
+                const float yr = th_fma(2.0f, er, -xr), yi = th_fma(2.0f, ei, -xi);
+                const float px = xr * xr + xi * xi, py = yr * yr + yi * yi;
+                const float ox = AMP ? power_to_amp(px) : power_to_dB(px), oy = AMP ? power_to_amp(py) : power_to_dB(py);
+                const uint32_t k = tt + (uint32_t)(NT * c);
+                // (2 k, 2 k + 1) = (A's bin k, this x);  (N - 2 k - 1, N - 2 k) = (this y, A's bin 16384 - k)
+                row[2u * k] = ra[2 * c];
+                row[2u * k + 1u] = ox;
+                row[2u * (uint32_t)NH - 2u * k - 1u] = oy;
+                row[2u * (uint32_t)NH - 2u * k] = ra[2 * c + 1];
+                if constexpr (!AMP) {
+                    fmn = nmin_l(nmin_l(fmn, ox), nmin_l(oy, nmin_l(ra[2 * c], ra[2 * c + 1])));
+                    fmx = nmax_l(nmax_l(fmx, ox), nmax_l(oy, nmax_l(ra[2 * c], ra[2 * c + 1])));
+                }
+            }
+            if (tt == 0) {  // A's self-mirrored bin 8192 = bin 16384 of the frame
+                row[(uint32_t)NH] = ra[16];
+                if constexpr (!AMP) {
+                    fmn = nmin_l(fmn, ra[16]);
+                    fmx = nmax_l(fmx, ra[16]);
+                }
+            }
+            lmin = nmin_l(lmin, fmn);
+            lmax = nmax_l(lmax, fmx);
+            {   // complete the row's last 128-byte line (see wave_frame)
+                const uint32_t height = (uint32_t)(2 * NH + 1), padn = spec_pitch - height;
+                if (tt - 1u < ((padn < 32u && spec_pitch % 32u == 0) ? padn : 0u)) row[height - 1u + tt] = 0.0f;
+            }
+        }
+        if (minmax != nullptr) {  // the chunk's (min, max) pair
+            const float a = wave_min_l(lmin), b = wave_max_l(lmax);
+            if (lane_w == 0) {
+                red[2 * wv] = a;
+                red[2 * wv + 1] = b;
+            }
+            lds_barrier();
+            if (t == 0) {
+                float mn = red[0], mx = red[1];
+                for (int w = 1; w < R; w++) {
+                    mn = nmin_l(mn, red[2 * w]);
+                    mx = nmax_l(mx, red[2 * w + 1]);
+                }
+                minmax[2 * (size_t)ct] = mn;
+                minmax[2 * (size_t)ct + 1] = mx;
+            }
+            lmin = __builtin_inff();
+            lmax = -__builtin_inff();
+        }
+    }
+}
+
+bool stft_subwave_applies(const StftGeom &g) { return g.log2_nc >= 12 && g.log2_nc <= 15 && g.odd_m1 == 0; }  // (15: stft_subwave2_kernel)
 // Where it is the default (profiles/r05_ab_subwave_sizes.txt, ms for 128 ch x 30 s, subwave | block): n_fft 32768 1.26 | 1.85 (19200 / 4800: 2.40 |
 // 3.26); 16384 at hop = n_fft / 4 0.98 | 1.00 (kept on the block kernel: its resident constants and two exchange buffers), 12000 / 3000 1.57 | 1.72;
 // 8192 0.84 | 0.70, 3840 / 960 at 96 kHz 3.9 | 2.9 — four waves per workgroup are too few between two barriers, the block kernel stays.
 bool stft_subwave_default(const StftGeom &g) {
-    return stft_subwave_applies(g) && (g.log2_nc == 14 || (g.log2_nc == 13 && g.hop * 4 != g.n_fft));
+    return stft_subwave_applies(g) && (g.log2_nc >= 14 || (g.log2_nc == 13 && g.hop * 4 != g.n_fft));
 }
 size_t stft_subwave_twc_len(const StftGeom &g) {
-    return g.log2_nc == 14 ? (size_t)SubwaveCfg<4>::NTWC * SubwaveCfg<4>::NT : g.log2_nc == 13 ? (size_t)SubwaveCfg<3>::NTWC * SubwaveCfg<3>::NT
+    return g.log2_nc >= 14 ? (size_t)SubwaveCfg<4>::NTWC * SubwaveCfg<4>::NT : g.log2_nc == 13 ? (size_t)SubwaveCfg<3>::NTWC * SubwaveCfg<3>::NT
                                                                                                  : (size_t)SubwaveCfg<2>::NTWC * SubwaveCfg<2>::NT;
 }
 
@@ -427,8 +686,15 @@ size_t stft_subwave_twc_len(const StftGeom &g) {
 // R = 16: BlockFft<14>::load_tw<1024>;  R = 8: bins k2 = t + 512 u, (w, w^2, w^4, w W8) with w = W_Nc^k2 = tw[2 k2];  R = 4: k2 = t + 256 u, (w, w^2)
 void stft_subwave_build_twc(const StftGeom &g, const cf32 *h_tw, cf32 *out) {
     const uint32_t n_fft = g.n_fft;
-    if (g.log2_nc == 14) {
+    if (g.log2_nc >= 14) {
+        // (n_fft 65536: the half transforms are 16384-point ones — their twiddles are every second entry of the plan's table)
         using B = BlockFft<14>;
+        std::vector<cf32> half;
+        if (g.log2_nc == 15) {
+            half.resize(n_fft / 2);
+            for (uint32_t i = 0; i < n_fft / 2; i++) half[i] = h_tw[2 * i];
+            h_tw = half.data();
+        }
         for (uint32_t t = 0; t < 1024; t++) {
             cf32 w[B::NTW];
             B::template load_tw<B::NS_C>(t, w, h_tw);
@@ -475,6 +741,15 @@ hipError_t launch_stft_subwave(const StftGeom &g, const ChanJob *d_jobs, const u
                                const cf32 *d_tw, const cf32 *d_twc, float *d_minmax, bool amp, uint32_t n_cu, hipStream_t s) {
     if (!stft_subwave_applies(g) || n_cu == 0 || d_twc == nullptr) return hipErrorInvalidValue;
     if (!n_tiles) return hipSuccess;
+    if (g.log2_nc == 15) {
+        using C = SubwaveCfg<4>;
+        auto kern = amp ? stft_subwave2_kernel<true> : stft_subwave2_kernel<false>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+        if (e != hipSuccess) return e;
+        const uint32_t grid = n_tiles < n_cu ? n_tiles : n_cu;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax);
+        return hipGetLastError();
+    }
     switch (g.log2_nc) {
         case 14: return launch_subwave_r<4>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax, amp, n_cu, s);
         case 13: return launch_subwave_r<3>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax, amp, n_cu, s);
