@@ -422,6 +422,17 @@ __global__ __launch_bounds__(SubwaveCfg<LOG2_R>::NT, 4) void stft_subwave_kernel
 // W_32768^k), B through a plain reversal with the twiddles W_65536^(2 k + 1), and a thread's results are the adjacent bins (2 k, 2 k + 1)
 // and (N - 2 k - 1, N - 2 k): 8-byte stores.  Eleven barriers per frame where the planar block plan has 33; 1024 threads instead of 512.
 // ------------------------------------------------------------------------------------------
+// (non-temporal row stores: 2.50 -> 2.44 ms.  Measured and not adopted: the first pass leaving lo - hi of every point in a per-workgroup
+// 128 KB stash in global memory for the second pass to read back instead of loading samples and window pairs twice — 2.96 ms: the stash
+// stores and the L1 invalidate in front of the read-back cost more than the 384 KB of L2 reads they save)
+#if !defined(TH_SUBW2_NT)
+#define TH_SUBW2_NT 1
+#endif
+#if TH_SUBW2_NT
+#define TH_SUBW2_STORE(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
+#else
+#define TH_SUBW2_STORE(PTR, VAL) (*(PTR) = (VAL))
+#endif
 template <bool AMP>
 __global__ __launch_bounds__(1024, 4) void stft_subwave2_kernel(StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab,
                                                                 uint32_t n_tiles, const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw,
@@ -625,10 +636,10 @@ __global__ __launch_bounds__(1024, 4) void stft_subwave2_kernel(StftGeom g, cons
                 const float ox = AMP ? power_to_amp(px) : power_to_dB(px), oy = AMP ? power_to_amp(py) : power_to_dB(py);
                 const uint32_t k = tt + (uint32_t)(NT * c);
                 // (2 k, 2 k + 1) = (A's bin k, this x);  (N - 2 k - 1, N - 2 k) = (this y, A's bin 16384 - k)
-                row[2u * k] = ra[2 * c];
-                row[2u * k + 1u] = ox;
-                row[2u * (uint32_t)NH - 2u * k - 1u] = oy;
-                row[2u * (uint32_t)NH - 2u * k] = ra[2 * c + 1];
+                TH_SUBW2_STORE(&row[2u * k], ra[2 * c]);
+                TH_SUBW2_STORE(&row[2u * k + 1u], ox);
+                TH_SUBW2_STORE(&row[2u * (uint32_t)NH - 2u * k - 1u], oy);
+                TH_SUBW2_STORE(&row[2u * (uint32_t)NH - 2u * k], ra[2 * c + 1]);
                 if constexpr (!AMP) {
                     fmn = nmin_l(nmin_l(fmn, ox), nmin_l(oy, nmin_l(ra[2 * c], ra[2 * c + 1])));
                     fmx = nmax_l(nmax_l(fmx, ox), nmax_l(oy, nmax_l(ra[2 * c], ra[2 * c + 1])));
