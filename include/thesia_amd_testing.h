@@ -25,7 +25,11 @@
  * same launch time; elsewhere as 2; 10 is reserved and behaves as 2),
  * 12 = mel plans at n_fft 4096: the banded sums as the FFT kernel's epilogue with the table read from global memory (L2) instead of
  * the second kernel over amplitude rows, on the launch shapes it is instantiated for (hop 1024 and the 96 / 88.2 kHz defaults,
- * at most 512 mels; A/B: measured slower, profiles/r05_ab_mel4096_fused.txt; elsewhere as 2);
+ * at most 512 mels; A/B: measured slower, profiles/r05_ab_mel4096_fused.txt; elsewhere as 2),
+ * 13 = the fused mel epilogue one frame at a time where frame pairs are the default (n_fft 1024 / 2048 banded sums; A/B, bit-identical),
+ * 14 = the workgroup-per-frame Stockham kernels (stft_block_kernel / its planar form) where stft_subwave_kernel is the default
+ * (n_fft 32768, 65536, 16384 at hops other than n_fft / 4; A/B),
+ * 15 = stft_subwave_kernel (R 1024-point wave transforms + a combining pass) wherever it exists, n_fft 8192 .. 65536 (A/B);
  * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
  * frames per queue pull */
 TH_API int th_plan_set_kernel(th_plan *plan, int which);
