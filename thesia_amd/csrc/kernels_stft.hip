@@ -45,6 +45,24 @@ __global__ void minmax_init_kernel(float *minmax, uint32_t n_chan) {
 __device__ __forceinline__ float nmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ float nmax(float a, float b) { return fmaxf(a, b); }
 
+// three-input forms (one instruction; NaN-ignoring like v_min_f32 / v_max_f32: the inputs here are dB values, never signalling).
+// -DTH_MINMAX3=1 folds two bins per v_min3_f32 / v_max3_f32 in the linear wave kernels (16 vector instructions fewer per frame of
+// 699): measured inside bench.py's step on one card, alternating — 0.472 / 0.482 / 0.491 ms against 0.478 / 0.472 / 0.482 without
+// (profiles/r05_ab_minmax3.txt): nothing, like every other cut of this kernel's instruction count.  Off.
+#if !defined(TH_MINMAX3)
+#define TH_MINMAX3 0
+#endif
+__device__ __forceinline__ float min3_f32(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = nmin(v, __shfl_xor(v, o, 64));
@@ -589,6 +607,8 @@ __device__ __forceinline__ void wave_frame(
             return (gptr<float>)((gptr<char>)row + (uint64_t)(kb << 2) + (int64_t)(4 * kc));
         };
         int amp_i = 0;  // (a constant at every call once the split pass is unrolled)
+        int mm_i = 0;
+        float mm_pend = __builtin_nanf("");  // (ignored by min / max until the first bin replaces it)
         auto emit = [&](uint32_t kb, int kc, float p) {
             if constexpr (MELP == 1) {
                 ampA[amp_i++ % (OUT == 3 ? W::N_EMIT : 1)] = power_to_amp_scaled(p);  // first frame of a pair: kept for the second one's epilogue
@@ -599,12 +619,29 @@ __device__ __forceinline__ void wave_frame(
             } else {
                 const float d = power_to_dB(p);
                 TH_ROW_STORE(row_at(kb, kc), d);
+#if TH_MINMAX3
+                // two bins per v_min3_f32 / v_max3_f32 (round 5: the running min / max were 34 of the frame's 699 vector instructions);
+                // mm_i is a constant at every call once the split pass is unrolled
+                if ((mm_i++ & 1) == 0) {
+                    mm_pend = d;
+                } else {
+                    lmin = min3_f32(lmin, mm_pend, d);
+                    lmax = max3_f32(lmax, mm_pend, d);
+                }
+#else
                 lmin = nmin(lmin, d);
                 lmax = nmax(lmax, d);
+#endif
             }
         };
         if constexpr (RES & 8) W::split_paired_w(lane, za, zb, rws, rw_mid, emit);
         else W::split_paired_w(lane, za, zb, ws, stw[NC / 2], emit);
+#if TH_MINMAX3
+        if constexpr (!MELF && !AMP) {  // lane 0's seventeenth bin (elsewhere a value that has been folded already: idempotent)
+            lmin = nmin(lmin, mm_pend);
+            lmax = nmax(lmax, mm_pend);
+        }
+#endif
     } else {
         // n_fft = 1024: one last-pass butterfly per lane; the halves of the wave swap registers for the split pass (no third
         // exchange, stft_wave.h)
