@@ -200,7 +200,9 @@ def fuzz_stft(ctx, seed=1, max_cases=10 ** 9, max_seconds=60.0, big=False, cap_b
     n_cases = 0
     worst = 0.0
     while time.time() < t_end and n_cases < max_cases:
-        n_fft = int(rng.choice([512, 1024, 2048, 2048, 4096, 8192, 16384, 32768]))  # multi-frame, one-frame and block kernels
+        n_fft = int(rng.choice([512, 1024, 2048, 2048, 4096, 8192, 16384, 32768]))  # multi-frame, one-frame, block and subwave kernels
+        if big and rng.random() < 0.04:
+            n_fft = 65536  # (round 5: stft_subwave2_kernel; rare — the generic kernel it is checked against takes its time there)
         win = int(rng.integers(n_fft // 2 + 1, n_fft + 1))
         if rng.random() < 0.5:
             win = n_fft if rng.random() < 0.5 else win // 2 * 2
