@@ -1612,7 +1612,8 @@ def _batch_on_gpu(ctx, plan, n_tr, n, seed):
     return wav, spec, mm
 
 
-@pytest.mark.parametrize("cfg", ["cfg5_shard", "cfg3", "cfg4_mel", "queue_512", "queue_512_odd", "queue_1024", "queue_2048_odd", "block_8192", "block_16384"])
+@pytest.mark.parametrize("cfg", ["cfg5_shard", "cfg3", "cfg4_mel", "queue_512", "queue_512_odd", "queue_1024", "queue_2048_odd", "block_8192", "block_16384",
+                                 "subwave_32768", "subwave_65536", "subwave_16384", "mel_pairs_app_default", "mel_pairs_1024"])
 def test_baseline_sizes_properties(ctx, cfg):
     """BASELINE.json configs at FULL size (the oracle cannot run these in test time): the batched launch must equal
     single-track launches of sampled tracks bit for bit (no cross-talk, chunk seams, boundary frames), agree with
@@ -1637,9 +1638,23 @@ def test_baseline_sizes_properties(ctx, cfg):
         sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 96000, (3840, 960, 8192), 24, 30 * 96000 + 3, ta.LINEAR, 0
     elif cfg == "block_16384":
         sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (16384, 4096, 16384), 16, 60 * 48000, ta.LINEAR, 0
+    # round 5: the long transforms on wave transforms + a combining pass (persistent workgroups walking several chunks each, resident
+    # samples at hop = n_fft / 4), and the fused mel epilogue in frame pairs (chunks of odd and even length, the app's own default)
+    elif cfg == "subwave_32768":
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (32768, 8192, 32768), 24, 60 * 48000 + 5, ta.LINEAR, 0
+    elif cfg == "subwave_65536":
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (65536, 16384, 65536), 12, 90 * 48000, ta.LINEAR, 0
+    elif cfg == "subwave_16384":
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (12000, 3000, 16384), 20, 60 * 48000, ta.LINEAR, 0
+    elif cfg == "mel_pairs_app_default":
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (1920, 480, 2048), 64, 30 * 48000, ta.MEL, 0
+    elif cfg == "mel_pairs_1024":
+        sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 16000, (640, 160, 1024), 64, 60 * 16000, ta.MEL, 0
     else:
         sr, (win, hop, n_fft), n_tr, n, scale, n_mel = 48000, (1801, 601, 2048), 53, 80 * 48000 + 5, ta.LINEAR, 0
     plan = ta.Plan(ctx, sr, win, hop, n_fft, scale, n_mel)
+    if cfg.startswith("subwave"):
+        assert plan.kernel_name == "stft_subwave_kernel"
     wav, spec, mm = _batch_on_gpu(ctx, plan, n_tr, n, 123)
     T, H = plan.n_frames(n), plan.height
     if cfg.startswith("cfg"):
@@ -1661,7 +1676,7 @@ def test_baseline_sizes_properties(ctx, cfg):
         assert (mn, mx) == (float(mm[i, 0]), float(mm[i, 1]))
         # oracle on the head and on the tail of the track (interior frames of those cuts are interior frames of the track)
         cut = 40 * hop + win
-        fb = orc.calc_mel_fb(sr, n_fft, n_mel) if scale == ta.MEL else None
+        fb = (orc.calc_mel_fb(sr, n_fft, n_mel) if n_mel else orc.calc_mel_fb_default(sr, n_fft)) if scale == ta.MEL else None
         head = orc.calc_spec(x[:cut], win, hop, n_fft, mel_fb=fb)
         assert_spec_close(got[:30], head[:30])
         k0 = (n - cut) // hop * hop                          # a hop-aligned tail cut: frame k0/hop + j of the track
