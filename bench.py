@@ -105,6 +105,20 @@ def visible_gpu_count(env=None) -> int:
             return int(r.stdout.strip().splitlines()[-1])
         except Exception:
             return 0
+    # a container may see more GPUs in /sys than its device cgroup lets it open: a GPU counts only with a render node this
+    # process can open (over-counting surfaced only as a rank's late failure, the other ranks stuck in rendezvous)
+    try:
+        usable = 0
+        for d in os.listdir("/dev/dri"):
+            if d.startswith("renderD"):
+                try:   # open + close of a render node: what the cgroup decides, and no HIP context
+                    os.close(os.open(os.path.join("/dev/dri", d), os.O_RDWR))
+                    usable += 1
+                except OSError:
+                    pass
+        n = min(n, usable)
+    except Exception:
+        pass
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = env.get(var)
         if v is not None:
@@ -122,15 +136,15 @@ def launcher_plan(gpus: int, argv, env, n_visible: int):
     if n_visible < gpus:
         raise SystemExit(f"bench.py: --gpus {gpus} needs {gpus} visible GPUs, this node shows {n_visible}; refusing to run a smaller "
                          "job under the same name (set HIP_VISIBLE_DEVICES / pick --gpus to match)")
+    # rendezvous on 127.0.0.1.  A port the environment names (the driver's form) is used as given; otherwise torchrun's own
+    # c10d rendezvous takes a free port itself (endpoint port 0) — a port picked HERE by bind-and-close could be taken by
+    # another process before torchrun binds it
     port = env.get("MASTER_PORT")
-    if not port:
-        import socket
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = str(s.getsockname()[1])
-        s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if port:
+        rdzv = ["--master-addr", "127.0.0.1", "--master-port", str(port)]
+    else:
+        rdzv = ["--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}"] + rdzv + [os.path.abspath(__file__)] + list(argv)
     child_env = dict(env)
     child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
     child_env.setdefault("OMP_NUM_THREADS", "4")
@@ -744,7 +758,9 @@ def main():
                  ("overlap16", "40 ms, t_overlap 16: 1920 / 120 / 2048, linear dB", wl.wav, 48000, (1920, 120, 2048, ta.LINEAR, 0), 0),
                  ("sr44k_default", "44.1 kHz default: 1764 / 441 / 2048, linear dB", wav44, 44100, (1764, 441, 2048, ta.LINEAR, 0), 0),
                  ("sr96k_default", "96 kHz default shape: 3840 / 960 / 4096, linear dB", wl.wav, 96000, (3840, 960, 4096, ta.LINEAR, 0), 0),
-                 ("sr96k_default_mel", "96 kHz default, mel scale (404 mels: FFT kernel -> amplitude rows -> banded sums, lane = mel)", wl.wav, 96000, (3840, 960, 4096, ta.MEL, 0), 0),
+                 ("sr96k_default_mel", "96 kHz default, mel scale (404 mels; round 6: the moment form of the filterbank in the FFT kernel's epilogue, one kernel)", wl.wav, 96000, (3840, 960, 4096, ta.MEL, 0), 0),
+                 ("sr96k_default_mel_two_kernels", "96 kHz default, mel scale, round 5's route (selector 12: FFT kernel -> amplitude rows -> banded sums, lane = mel)", wl.wav, 96000, (3840, 960, 4096, ta.MEL, 0), 12),
+                 ("sr88k_default_mel", "88.2 kHz default, mel scale (432 mels, 3528 / 882 / 4096; moment-form epilogue)", wav44, 88200, (3528, 882, 4096, ta.MEL, 0), 0),
                  ("nfft512", "short transform: n_fft 512 / hop 128, linear dB (four frames per wave)", wl.wav, 48000, (512, 128, 512, ta.LINEAR, 0), 0),
                  ("sr8k_default", "8 kHz default shape: 320 / 80 / 512, linear dB", wl.wav, 8000, (320, 80, 512, ta.LINEAR, 0), 0),
                  ("sr8k_default_mel", "8 kHz default, mel scale (257 mels: banded sums, lane = mel, in the epilogue of the four-frames-per-wave kernel)", wl.wav, 8000, (320, 80, 512, ta.MEL, 0), 0),
@@ -754,7 +770,8 @@ def main():
                  ("nfft32768_block_kernel", "n_fft 32768 / hop 8192 on the workgroup-per-frame Stockham kernel (selector 14: rounds 3-4's plan)", wl.wav, 48000, (32768, 8192, 32768, ta.LINEAR, 0), 14),
                  ("nfft65536", "n_fft 65536 / hop 16384, linear dB (1.4 s window at 48 kHz; round 5: the workgroup-per-frame plan with planar LDS exchanges)", wl.wav, 48000, (65536, 16384, 65536, ta.LINEAR, 0), 0),
                  # the Mel default of long windows has more than 512 mels (src-common/src/lib.rs:91-103): two kernels since round 4
-                 ("nfft4096_mel_default", "48 kHz, n_fft 4096 / hop 1024, mel scale at the default count (695 mels)", wl.wav, 48000, (4096, 1024, 4096, ta.MEL, 0), 0),
+                 ("nfft4096_mel_default", "48 kHz, n_fft 4096 / hop 1024, mel scale at the default count (695 mels; round 6: moment-form epilogue, one kernel)", wl.wav, 48000, (4096, 1024, 4096, ta.MEL, 0), 0),
+                 ("nfft4096_mel_default_two_kernels", "48 kHz, n_fft 4096 / hop 1024, 695 mels, round 5's route (selector 12: FFT kernel -> amplitude rows -> mel_mfma_kernel)", wl.wav, 48000, (4096, 1024, 4096, ta.MEL, 0), 12),
                  ("nfft16384_mel_default", "48 kHz, n_fft 16384 / hop 4096, mel scale at the default count (2785 mels)", wl.wav, 48000, (16384, 4096, 16384, ta.MEL, 0), 0))
         for key, label, wav_, sr_, (w_, h_, nf_, scale, n_mel), sel in cases:
             try:

@@ -208,6 +208,16 @@ def calc_mel_fb(sr: int, n_fft: int, n_mel: int, fmin: float = 0.0, fmax=None, d
     return out
 
 
+def mel_fb_points(sr: int, n_fft: int, n_mel: int, fmin: float = 0.0, fmax=None):
+    """(lin, mf): the f32 bin frequencies and triangle points calc_mel_fb works from (lib.rs:61-67)"""
+    lin, mf = np.empty(n_fft // 2 + 1, np.float32), np.empty(n_mel + 2, np.float32)
+    L = lib()
+    L.orc_mel_fb_points_f32.restype = None
+    L.orc_mel_fb_points_f32.argtypes = [C.c_uint32, C.c_size_t, C.c_size_t, C.c_float, C.c_float, _f32p, _f32p]
+    L.orc_mel_fb_points_f32(sr, n_fft, n_mel, fmin, -1.0 if fmax is None else fmax, _p(lin, _f32p), _p(mf, _f32p))
+    return lin, mf
+
+
 def mel_default_n_mel(sr: int, n_fft: int) -> int:
     return lib().orc_mel_default_n_mel(sr, n_fft)
 

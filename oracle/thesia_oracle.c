@@ -396,6 +396,16 @@ static void linspace_f64(double a, double b, size_t n, double *out) {
     for (size_t i = 0; i < n; i++) out[i] = a + step * (double)i;
 }
 
+/* The two f32 frequency arrays calc_mel_fb works from (lib.rs:61-67): lin[n_fft/2+1] = the bins' frequencies,
+ * mf[n_mel+2] = the triangle points.  For tests of table builders that need the filters' geometry, not only their values. */
+ORC_API void orc_mel_fb_points_f32(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, float *lin, float *mf) {
+    float f_nyquist = (float)(((double)sr) / 2.0);
+    if (fmax < 0.0f) fmax = f_nyquist;
+    linspace_f32(0.0f, f_nyquist, n_fft / 2 + 1, lin);
+    linspace_f32(orc_mel_from_hz_f32(fmin), orc_mel_from_hz_f32(fmax), n_mel + 2, mf);
+    for (size_t i = 0; i < n_mel + 2; i++) mf[i] = orc_mel_to_hz_f32(mf[i]);
+}
+
 /* calc_mel_fb::<f32>  lib.rs:46-89.  out: (n_fft/2+1) x n_mel, C order.
  * fmax < 0 means None (nyquist). */
 ORC_API void orc_calc_mel_fb_f32(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax,

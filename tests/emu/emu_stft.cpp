@@ -455,3 +455,51 @@ extern "C" __attribute__((visibility("default"))) int emu_mel_band(const float *
     }
     return 0;
 }
+
+// Moment form of the mel filterbank (round 6: build_mel_moments + mel_mom_lane / mel_mom_w_lane / mel_mom_combine, lane = segment):
+// out[m] = the filter outputs (linear).  amp_slab: the amplitude row followed by whatever the slab holds behind it (the caller
+// passes NaN there: the masks must keep it out).  info[0..5] = table words, groups, all groups' taps, widest group's taps, reach,
+// groups in the W form; dev[0..1] = MelMomHost::max_dev, max_amp.  Returns 0, 1 when the filterbank has no moment form.
+extern "C" __attribute__((visibility("default"))) int emu_mel_moments(const float *amp_slab, uint32_t slab_len, const float *fb, const float *lin,
+                                                                       const float *mf, uint32_t n_freq, uint32_t n_mel, uint32_t spread, float *out,
+                                                                       uint32_t *info, double *dev) {
+    const MelMomHost h = build_mel_moments(fb, lin, mf, n_freq, n_mel, slab_len, spread != 0);
+    dev[0] = h.max_dev;
+    dev[1] = h.max_amp;
+    if (!h.ok) return 1;
+    info[0] = (uint32_t)h.words.size();
+    info[1] = h.n_groups;
+    info[2] = h.taps;
+    info[3] = h.max_taps;
+    info[4] = h.reach;
+    info[5] = h.w_groups;
+    dev[0] = h.max_dev;
+    dev[1] = h.max_amp;
+    if (h.words[0] != h.n_groups || h.reach > slab_len) return -1;
+    for (uint32_t m = 0; m < n_mel; m++) out[m] = NAN;
+    float carry = 0.0f;  // F of lane 0 of the group above (the kernel walks the groups downwards)
+    for (uint32_t g = h.n_groups; g-- != 0;) {
+        const uint32_t nw = h.words[MEL_MOM_HDR0 + 2 * g], n = nw & 0xffffu, off = h.words[MEL_MOM_HDR0 + 1 + 2 * g];
+        const bool wform = (nw & MEL_MOM_FORM_W) != 0;
+        if (off % 4 != 0 || (wform ? (n < 1 || n > 2) : n % MEL_MOM_UNROLL != 0)) return -2;
+        const uint64_t *masks = reinterpret_cast<const uint64_t *>(h.words.data() + off + 256);
+        MelMomLane s[64];
+        for (uint32_t l = 0; l < 64; l++) {
+            float prm[3], w1[2];
+            std::memcpy(prm, &h.words[off + 4 * l + 1], 12);
+            std::memcpy(w1, &h.words[off + 256 + 2 * l], 8);
+            s[l] = wform ? mel_mom_w_lane(amp_slab, h.words[off + 4 * l], n, prm[0], prm[1], w1[0], w1[1])
+                         : mel_mom_lane(l, amp_slab, h.words[off + 4 * l], prm[0], prm[1], masks, n);
+        }
+        for (uint32_t l = 0; l < 64; l++) {
+            float inv_d;
+            std::memcpy(&inv_d, &h.words[off + 4 * l + 3], 4);
+            const float v = mel_mom_combine(inv_d, s[l].R, l == 63 ? carry : s[l + 1].F);
+            const uint32_t m = 64 * g + l;
+            if (m < n_mel) out[m] = v;
+            else if (v != 0.0f) return -3;  // lanes past the last mel hold 1 / d = 0
+        }
+        carry = s[0].F;
+    }
+    return 0;
+}

@@ -22,14 +22,15 @@ def test_launcher_plan_builds_the_drivers_command():
     cmd, env = b.launcher_plan(4, ["--gpus", "4", "--steps", "20", "--warmup", "5"], {"PATH": "/x"}, n_visible=8)
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    # no port named: torchrun's c10d rendezvous picks a free one itself (no bind-and-close race), still on 127.0.0.1
+    assert "--rdzv-endpoint=127.0.0.1:0" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"
+    assert "--master-port" not in cmd
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]    # the same arguments, unchanged
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/x"
     assert "WORLD_SIZE" not in env                                              # torchrun sets it for the ranks
     cmd2, _ = b.launcher_plan(2, [], {"MASTER_PORT": "29777"}, n_visible=2)
-    assert cmd2[cmd2.index("--master-port") + 1] == "29777"
+    assert cmd2[cmd2.index("--master-port") + 1] == "29777" and cmd2[cmd2.index("--master-addr") + 1] == "127.0.0.1"
 
 
 def test_launcher_refuses_fewer_devices_than_ranks():

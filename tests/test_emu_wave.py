@@ -240,3 +240,84 @@ def test_fused_mel_tables_refuse_what_is_not_a_triangle_filterbank(emu):
     bad = good.copy(); bad[k, 10] = -bad[k, 10]
     assert rc(bad) == 1                                                         # negative weight
     assert rc(good, max_pieces=8) == 1                                          # does not fit the (r, f) buffer
+
+
+MOMENT_CASES = [(96000, 4096, 0), (88200, 4096, 0), (48000, 4096, 0), (48000, 4096, 128), (44100, 4096, 64), (48000, 2048, 0),
+                (16000, 1024, 0), (8000, 512, 0), (48000, 8192, 0), (48000, 4096, 1000), (22050, 4096, 512), (48000, 4096, 5),
+                (192000, 4096, 0), (8000, 4096, 0), (32000, 4096, 0)]
+
+
+def _mom_args(emu):
+    f32p, u32p, f64p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+    emu.emu_mel_moments.argtypes = [f32p, C.c_uint32, f32p, f32p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, u32p, f64p]
+    return f32p, u32p, f64p
+
+
+@pytest.mark.parametrize("sr,n_fft,n_mel", MOMENT_CASES)
+def test_moment_form_of_the_mel_filterbank(emu, sr, n_fft, n_mel):
+    """build_mel_moments + mel_mom_lane / mel_mom_w_lane / mel_mom_combine (round 6: lane = segment of the triangle points; wide
+    segments as moments — per bin two additions, no weight table — narrow ones as their one or two weight pairs) against amp @ fb
+    in f64.  In the moment groups the reference's f32 weights are replaced by the line through the f32 triangle points (the table
+    additionally carries the rounding of the f32 bin frequencies): `max_dev` is that difference in units of an unnormalised
+    weight and `max_amp` how far a filter's 1 / d enlarges the rounding of the two terms the line is evaluated from; a result may
+    differ from the table's product by (max_dev + a few ulp * max_amp) * (amplitude under the filter) / d plus f32 summation
+    error — asserted mel by mel, also for isolated spectral lines (one term per mel: nothing averages out).  NaN behind the
+    amplitude row must not reach any sum."""
+    M = n_mel or orc.mel_default_n_mel(sr, n_fft)
+    fb = np.ascontiguousarray(orc.calc_mel_fb(sr, n_fft, M), np.float32)
+    lin, mf = orc.mel_fb_points(sr, n_fft, M)
+    F = n_fft // 2 + 1
+    slab_len = 2 * (F - 1 + (F - 1) // 16)   # floats of WaveFft::SLAB_LEN complex slots
+    rng = np.random.default_rng(17)
+    f32p, u32p, f64p = _mom_args(emu)
+    fb64 = fb.astype(np.float64)
+    # 1 / d_m (lib.rs:84-86) from the points themselves, f64
+    l64, p64 = lin.astype(np.float64), mf.astype(np.float64)
+    inv_d, under = np.zeros(M), np.zeros((F, M))
+    for m in range(M):
+        up = (l64 > p64[m]) & (l64 <= p64[m + 1])
+        dn = (l64 > p64[m + 1]) & (l64 <= p64[m + 2])   # (a bin ON the upper point has weight 0 but sits in the segment's sums)
+        d = ((l64[up] - p64[m]) / (p64[m + 1] - p64[m])).sum() + ((p64[m + 2] - l64[dn]) / (p64[m + 2] - p64[m + 1])).sum()
+        inv_d[m] = 1.0 / d if d > 0 else 0.0
+        under[up | dn, m] = 1.0
+    infos = []
+    for spread in (0, 1):
+        info, dev = np.zeros(6, np.uint32), np.zeros(2, np.float64)
+        for trial in range(5):
+            amp = (rng.uniform(0, 1, F) * 10.0 ** rng.uniform(-6, 0, F)).astype(np.float32)
+            if trial >= 3:
+                amp[:] = 0.0
+                amp[rng.integers(1, F, 9 if trial == 3 else 200)] = 1.0   # isolated lines
+            slab = np.full(slab_len, np.nan, np.float32)
+            slab[:F] = amp
+            out = np.empty(M, np.float32)
+            rc = emu.emu_mel_moments(slab.ctypes.data_as(f32p), slab_len, fb.ctypes.data_as(f32p), lin.ctypes.data_as(f32p),
+                                     mf.ctypes.data_as(f32p), F, M, spread, out.ctypes.data_as(f32p), info.ctypes.data_as(u32p),
+                                     dev.ctypes.data_as(f64p))
+            assert rc == 0, rc
+            assert not np.isnan(out).any()
+            want = amp.astype(np.float64) @ fb64
+            mass = amp.astype(np.float64) @ under    # amplitude in the filter's two segments
+            bound = (1.5 * dev[0] + 4e-7 * (1.0 + dev[1])) * mass * inv_d + 4e-6 * want + 1e-30
+            assert np.all(np.abs(out - want) <= bound), (np.abs(out - want) / np.maximum(bound, 1e-300)).max()
+            # the north-star scale (1e-4 of the frame's largest value): an order inside even for lone lines at sample rates whose
+            # bin spacing is not an f32 number (44.1 kHz family: max_dev ~ 1e-5; 48 kHz family: ~ 1e-7, the f32 sums of wide filters then dominate)
+            assert np.abs(out - want).max() <= (1e-5 if dev[0] > 5e-7 else 2e-6) * want.max() + 1e-30, np.abs(out - want).max() / want.max()
+        assert dev[0] < 2e-5 and dev[1] <= 8.0, dev
+        assert info[1] == (M + 1 + 63) // 64 and info[4] <= slab_len
+        infos.append(info.copy())
+    assert infos[1][2] <= infos[0][2] + 4 * infos[0][1]   # spreading adds at most two taps (one unroll step) per group
+    assert infos[1][5] == infos[0][5]
+
+
+def test_moment_form_refuses_what_is_not_a_triangle_filterbank(emu):
+    sr, n_fft, M = 48000, 2048, 64
+    fb = np.ascontiguousarray(orc.calc_mel_fb(sr, n_fft, M), np.float32)
+    lin, mf = orc.mel_fb_points(sr, n_fft, M)
+    fb[np.nonzero(fb[:, 10])[0][0], 10] *= 1.5   # not the reference's weight any more
+    F = n_fft // 2 + 1
+    f32p, u32p, f64p = _mom_args(emu)
+    slab = np.zeros(4 * F, np.float32)
+    out, info, dev = np.empty(M, np.float32), np.zeros(6, np.uint32), np.zeros(2, np.float64)
+    assert emu.emu_mel_moments(slab.ctypes.data_as(f32p), slab.size, fb.ctypes.data_as(f32p), lin.ctypes.data_as(f32p), mf.ctypes.data_as(f32p),
+                               F, M, 1, out.ctypes.data_as(f32p), info.ctypes.data_as(u32p), dev.ctypes.data_as(f64p)) == 1

@@ -529,35 +529,42 @@ class TrackManager:
         h = vp()
         check(lib.th_tm_create(ctx.handle, C.byref(h)))
         self.handle, self.ctx = h, ctx
-        # pinned output buffers of get_spectrogram_tiles(pinned=True): ONE PER CALLING THREAD (tile getters run
-        # concurrently from IPC threads and ctypes drops the GIL during the C call — ADVICE r4: a buffer shared by all
-        # callers let one caller read another's pixels and freed memory a kernel was still writing).  A thread's buffer is
-        # grow-only and only that thread ever replaces it, between its own calls; close() frees them all.
-        self._pin_tls = threading.local()
-        self._pin_all = {}   # id -> c_void_p of every live pinned buffer (for close()), under _pin_lock
+        # pinned output buffers of get_spectrogram_tiles(pinned=True): a small POOL, one buffer checked out per call (tile
+        # getters run concurrently from IPC threads and ctypes drops the GIL during the C call — ADVICE r4: a buffer shared
+        # by two calls in flight let one caller read another's pixels; ADVICE r5: a buffer per THREAD leaked one pinned block
+        # per exited thread).  At most PIN_POOL_MAX idle buffers are kept; close() frees them all.
+        self._pin_free = []  # idle buffers: (capacity, c_void_p), under _pin_lock
+        self._pin_all = {}   # address -> c_void_p of every live pinned buffer, idle or checked out (for close())
         self._pin_lock = threading.Lock()
 
-    def _pinned_for_this_thread(self, nbytes: int):
-        tls = self._pin_tls
-        if getattr(tls, "cap", 0) < nbytes:
-            old = getattr(tls, "ptr", None)
-            if old is not None:   # this thread's previous buffer: no call of this thread is in flight now
-                with self._pin_lock:
-                    self._pin_all.pop(old.value, None)
-                tls.ptr, tls.cap = None, 0
-                check(lib.th_host_free(self.ctx.handle, old))
-            p = C.c_void_p()
-            check(lib.th_host_alloc(self.ctx.handle, nbytes, C.byref(p)))
-            with self._pin_lock:
-                self._pin_all[p.value] = p
-            tls.ptr, tls.cap = p, nbytes
-        return tls.ptr, tls.cap
+    PIN_POOL_MAX = 4
+
+    def _pin_checkout(self, nbytes: int):
+        """An idle pinned buffer of >= nbytes (the smallest that fits), else a new one.  The caller owns it until _pin_return."""
+        with self._pin_lock:
+            fit = [i for i, (cap, _) in enumerate(self._pin_free) if cap >= nbytes]
+            if fit:
+                return self._pin_free.pop(min(fit, key=lambda i: self._pin_free[i][0]))
+        p = C.c_void_p()
+        check(lib.th_host_alloc(self.ctx.handle, nbytes, C.byref(p)))
+        with self._pin_lock:
+            self._pin_all[p.value] = p
+        return nbytes, p
+
+    def _pin_return(self, cap: int, p) -> None:
+        drop = None
+        with self._pin_lock:
+            self._pin_free.append((cap, p))
+            if len(self._pin_free) > self.PIN_POOL_MAX:   # keep the large ones: they serve every request size
+                drop = self._pin_free.pop(min(range(len(self._pin_free)), key=lambda i: self._pin_free[i][0]))
+                self._pin_all.pop(drop[1].value, None)
+        if drop is not None:
+            check(lib.th_host_free(self.ctx.handle, drop[1]))
 
     def _free_pinned(self):
-        """close(): every thread's buffer (the caller guarantees no tile call is in flight, as for the handle itself)"""
+        """close(): every buffer (the caller guarantees no tile call is in flight, as for the handle itself)"""
         with self._pin_lock:
-            bufs, self._pin_all = list(self._pin_all.values()), {}
-        self._pin_tls = threading.local()
+            bufs, self._pin_all, self._pin_free = list(self._pin_all.values()), {}, []
         for p in bufs:
             check(lib.th_host_free(self.ctx.handle, p))
 
@@ -646,11 +653,14 @@ class TrackManager:
         if n == 0 or need.value == 0:
             return []
         if pinned:
-            # one grow-only pinned buffer per calling thread (a hipHostMalloc / hipHostFree pair per call costs
-            # milliseconds, most of what the direct write saves; ADVICE r4: never shared between threads); freed in close()
-            pin, cap = self._pinned_for_this_thread(need.value)
-            check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, pin, cap, offs, C.byref(need)))
-            out = bytes((C.c_uint8 * need.value).from_address(pin.value))
+            # a pooled pinned buffer for the duration of this call (a hipHostMalloc / hipHostFree pair per call
+            # costs milliseconds, most of what the direct write saves; ADVICE r4: never shared by two calls in flight)
+            cap, pin = self._pin_checkout(need.value)
+            try:
+                check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, pin, cap, offs, C.byref(need)))
+                out = bytes((C.c_uint8 * need.value).from_address(pin.value))
+            finally:
+                self._pin_return(cap, pin)
         else:
             b = np.empty(need.value, np.uint8)
             check(lib.th_tm_get_spectrogram_tiles(self.handle, arr, n, b.ctypes.data_as(C.c_void_p), b.size, offs, C.byref(need)))

@@ -391,12 +391,10 @@ bool th_plan::use_wave() const {
 // 2048 at the default launch shape), else amplitude out of the FFT kernel and the filterbank on the matrix cores
 bool th_plan::use_mel_fused() const {
     if (g.n_mel == 0 || !use_wave() || kernel_choice == 3 || kernel_choice == 7) return false;
-    // n_fft 4096 (round 5: banded sums in the FFT kernel's epilogue, the table read from global memory / L2): instantiated for hop
-    // 1024 and for the even-offset grid-aligned shapes of the 96 / 88.2 kHz defaults — not when selector 4 switches that mode off
-    // MEASURED SLOWER than the two kernels (profiles/r05_ab_mel4096_fused.txt: 2.23 against 2.04 ms at the 96 kHz default — every
-    // wave re-reads the 30-36 KB table from L2 once per frame, 14 GB per launch through the CUs' vector-memory path), so it is
-    // an A/B route only: selector 12.
-    if (g.log2_nc == 11 && kernel_choice != 12) return false;
+    // n_fft 4096 (round 6): the moment form of the filterbank as the FFT kernel's epilogue — no table in LDS (the eight slabs
+    // leave none), any mel count; instantiated for hop 1024 and for the even-offset grid-aligned shapes of the 96 / 88.2 kHz
+    // defaults (not when selector 4 switches that mode off).  Selector 12 keeps round 5's two kernels (A/B).
+    if (g.log2_nc == 11) return kernel_choice != 12 && d_mel_mom != nullptr && th::stft_wave_mel_fits(g, wave_waves, 1, true);
     // n_fft 512 under narrow filters: the banded sums of mel_rows_kernel as the epilogue of the four-frames-per-wave kernel
     if (g.log2_nc == 8) return d_mel_rows != nullptr && th::stft_wave_multi_mel_fits(g, wave_waves, mel_rows_groups * (uint32_t)(th::MEL_ROWS_W + 1) * 64u);
     return mel_bsum_fits() || (d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words));
@@ -419,6 +417,7 @@ static void plan_free(th_plan *p) {
     if (p->d_mel_rows) (void)hipFree(p->d_mel_rows);
     if (p->d_mel_fuse) (void)hipFree(p->d_mel_fuse);
     if (p->d_mel_bsum) (void)hipFree(p->d_mel_bsum);
+    if (p->d_mel_mom) (void)hipFree(p->d_mel_mom);
     p->amp_buf.release();
     p->chunk_mm.release();
     p->post_jobs.release();
@@ -667,6 +666,20 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
                 rc = up((void **)&p->d_mel_fuse, mf.words.data(), mf.words.size() * sizeof(uint32_t));
             }
         }
+        if (rc == TH_OK && g.log2_nc == 11 && th::stft_wave_supported(g)) {
+            // n_fft 4096: the moment form (lane = segment of the triangle points; mel_fuse.h) for the fused epilogue, any mel count
+            std::vector<float> lin, mfp;
+            mel_fb_points(sr, n_fft, n_mel, 0.f, -1.f, lin, mfp);
+            const th::MelMomHost mm = th::build_mel_moments(p->h_mel_fb.data(), lin.data(), mfp.data(), g.n_freq, (uint32_t)n_mel,
+                                                            2u * (g.nc + g.nc / 16u), TH_MEL_BAND_SPREAD != 0);
+            if (mm.ok) {
+                p->mel_mom_groups = mm.n_groups;
+                p->mel_mom_taps = mm.taps;
+                p->mel_mom_max_dev = mm.max_dev;
+                p->mel_mom_max_amp = mm.max_amp;
+                rc = up((void **)&p->d_mel_mom, mm.words.data(), mm.words.size() * sizeof(uint32_t));
+            }
+        }
         if (rc == TH_OK) rc = up((void **)&p->d_mel_fb, p->h_mel_fb.data(), p->h_mel_fb.size() * sizeof(float));
         if (rc == TH_OK) rc = up((void **)&p->d_mel_lo, lo.data(), lo.size() * sizeof(uint32_t));
         if (rc == TH_OK) rc = up((void **)&p->d_mel_hi, hi.data(), hi.size() * sizeof(uint32_t));
@@ -708,8 +721,8 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     // form where the banded sums are the default, 9 wave kernel with the packed-f32 pipeline (stft_pk.h) on the launch shape it is
     // instantiated for (n_fft 2048, hop = n_fft / 4, linear dB, default waves; elsewhere as 2), 11 wave kernel with the sweep chunk
     // schedule (4-frame chunks dealt out in order) on large batches of that same shape (A/B; elsewhere as 2; 10 is reserved: as 2),
-    // 12 mel plans at n_fft 4096: the banded sums in the FFT kernel's epilogue with the table read from global memory, on the
-    // launch shapes it is instantiated for (hop 1024, the 96 / 88.2 kHz defaults; A/B: slower than the two kernels; elsewhere as 2);
+    // 12 mel plans at n_fft 4096: the two kernels (FFT -> amplitude rows -> banded sums / matrix cores) where the moment-form
+    // epilogue is the default (hop 1024, the 96 / 88.2 kHz defaults: round 5's route, A/B; elsewhere as 2);
     // 13 fused mel epilogue one frame at a time where the frame-pair form is the default (n_fft 2048 banded sums; A/B; elsewhere as 2);
     // 14 the workgroup-per-frame Stockham kernel (stft_block_kernel) where stft_subwave_kernel is the default (A/B; elsewhere as 2);
     // 15 stft_subwave_kernel wherever it exists (n_fft 8192 .. 32768) also where the block kernel is the default (A/B; elsewhere as 2);
@@ -1047,7 +1060,13 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         wo.sweep = sweep ? 1 : 0;
         wo.long_plan = p->kernel_choice == 14 ? 1 : p->kernel_choice == 15 ? 2 : 0;
         wo.subwave_twc = p->d_twc;
-        if (mel_fused && g.log2_nc == 8) {  // (the per-mel table of the banded sums, kernels.h)
+        if (mel_fused && g.log2_nc == 11) {  // moment form: the table stays in global memory (scalar + 16-byte lane loads)
+            wo.mel_tab = p->d_mel_mom;
+            wo.mel_words = 0;
+            wo.mel_slots = 0;
+            wo.mel_groups = p->mel_mom_groups;
+            wo.n_mel = g.n_mel;
+        } else if (mel_fused && g.log2_nc == 8) {  // (the per-mel table of the banded sums, kernels.h)
             wo.mel_tab = p->d_mel_rows;
             wo.mel_groups = p->mel_rows_groups;
             wo.mel_words = p->mel_rows_groups * (uint32_t)(th::MEL_ROWS_W + 1) * 64u;

@@ -105,6 +105,10 @@ struct th_plan {
     uint32_t mel_bsum_words = 0, mel_bsum_groups = 0, mel_bsum_hdr[16] = {};  // (header: offset and taps per group)
     th::cf32 *d_twc = nullptr;  // n_fft 32768: the combining pass's per-thread constants (kernels_stft_long.hip)
     uint32_t mel_bsum_reach = 0;  // one past the highest amplitude index the banded sums read (MelBandHost::reach)
+    // n_fft 4096 mel plans (round 6): the moment form of the filterbank in the FFT kernel's epilogue (build_mel_moments, mel_fuse.h)
+    uint32_t *d_mel_mom = nullptr;
+    uint32_t mel_mom_groups = 0, mel_mom_taps = 0;
+    double mel_mom_max_dev = 0.0, mel_mom_max_amp = 0.0;
     bool mel_bsum_fits() const;
     th::DeviceTable jobs, tile_start;            // main launch: jobs + first chunk of every job (generic kernel) or the
                                                  // per-chunk (job, first frame) table (wave kernels)

@@ -69,15 +69,24 @@ static void linspace(float a, float b, size_t n, float *out) {  // ndarray Array
     for (size_t i = 0; i < n; i++) out[i] = a + step * float(i);
 }
 
-// calc_mel_fb::<f32> — src-common/src/lib.rs:46-89; returns (n_fft/2+1) x n_mel, C order
-std::vector<float> calc_mel_fb(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, bool do_norm) {
+// the two f32 frequency arrays of calc_mel_fb (src-common/src/lib.rs:61-67): the bins' frequencies and the n_mel + 2 triangle
+// points; fmax < 0 = Nyquist
+void mel_fb_points(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, std::vector<float> &lin, std::vector<float> &mf) {
     const float f_nyquist = float(double(sr) / 2.);
     if (fmax < 0.f) fmax = f_nyquist;
     const size_t n_freq = n_fft / 2 + 1;
-    std::vector<float> lin(n_freq), mf(n_mel + 2), w(n_freq), fb(n_freq * n_mel, 0.f);
+    lin.assign(n_freq, 0.f);
+    mf.assign(n_mel + 2, 0.f);
     linspace(0.f, f_nyquist, n_freq, lin.data());
     linspace(mel_from_hz(fmin), mel_from_hz(fmax), n_mel + 2, mf.data());
     for (auto &m : mf) m = mel_to_hz(m);
+}
+
+// calc_mel_fb::<f32> — src-common/src/lib.rs:46-89; returns (n_fft/2+1) x n_mel, C order
+std::vector<float> calc_mel_fb(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, bool do_norm) {
+    const size_t n_freq = n_fft / 2 + 1;
+    std::vector<float> lin, mf, w(n_freq), fb(n_freq * n_mel, 0.f);
+    mel_fb_points(sr, n_fft, n_mel, fmin, fmax, lin, mf);
     for (size_t m = 0; m < n_mel; m++) {
         std::fill(w.begin(), w.end(), 0.f);
         for (size_t i = 0; i < n_freq; i++) {

@@ -15,6 +15,7 @@ std::vector<float> normalized_hann(size_t win, size_t n_fft);
 float mel_from_hz(float hz);
 float mel_to_hz(float mel);
 std::vector<float> calc_mel_fb(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, bool do_norm);
+void mel_fb_points(uint32_t sr, size_t n_fft, size_t n_mel, float fmin, float fmax, std::vector<float> &lin, std::vector<float> &mf);
 size_t mel_default_n_mel(uint32_t sr, size_t n_fft);
 void hz_range_to_idx(int freq_scale, float hz0, float hz1, uint32_t sr, size_t n, size_t *i0, size_t *i1);
 void shard_assign(const uint64_t *weights, size_t n, uint32_t world, uint32_t *owner);

@@ -731,16 +731,18 @@ __device__ __forceinline__ void wave_frame(
 #if defined(TH_MELF_ABL) && (TH_MELF_ABL & 1)  // ablation build: no filterbank sums (rows unwritten) — what the epilogue costs
         if (wo.n_mel == 0x7fffffffu)
 #endif
-        if (wo.mel_slots == 0) {  // wave-uniform: banded sums, lane = mel (mel_banded, stft_wave.h; table: build_mel_band)
+        if constexpr (LOG2_NC == 11) {
+            // no LDS for a table beside eight slabs: the moment form (lane = segment, two additions per bin; per-lane words and the
+            // taps' lane masks from global memory — mel_moments_global, stft_wave.h; build_mel_moments, mel_fuse.h)
+            wave_lds_sync();
+            mel_moments_global(lane, slab_f, as_global(wo.mel_tab), wo.mel_groups, emit_mel);
+        } else if (wo.mel_slots == 0) {  // wave-uniform: banded sums, lane = mel (mel_banded, stft_wave.h; table: build_mel_band)
             // the filters of a group reach up to its widest one's width past their own end: zeros behind the row
             static_assert(2 * (int)W::SLAB_LEN >= NC + 1 + 128, "room for the zeros behind the amplitude row");
             slab_f[NC + 1 + lane] = 0.0f;
             slab_f[NC + 65 + lane] = 0.0f;
             wave_lds_sync();
-            if constexpr (LOG2_NC == 11)  // no LDS for the table beside eight slabs: weights from global memory (L2)
-                mel_banded_global(lane, slab_f, as_global(wo.mel_tab), wo.mel_groups, wo.band_off, wo.band_n, emit_mel);
-            else
-                mel_banded<TH_MEL_BAND_PAIRED != 0>(lane, slab_f, meltab, wo.mel_groups, wo.band_off, wo.band_n, emit_mel);
+            mel_banded<TH_MEL_BAND_PAIRED != 0>(lane, slab_f, meltab, wo.mel_groups, wo.band_off, wo.band_n, emit_mel);
         } else {
             cf32 *const prf = mel_prf != nullptr ? mel_prf : slab + (NC + 2) / 2;
             const MelFuseTab mt = mel_fuse_view(meltab, wo.mel_slots, wo.mel_groups);
@@ -966,7 +968,7 @@ __device__ __forceinline__ void stft_wave_body(
     if constexpr (STW_IN_LDS && PKP) W::fill_stwp(tid, 64 * WAVES, tw, stw);
     for (uint32_t i = tid; i < WPAD; i += 64 * WAVES) wtab[i] = wtab_g[i];
     W::fill_tables(tid, 64 * WAVES, tw, T2_IN_LDS ? t2 : nullptr, t3);
-    if constexpr ((OUT == 2 || OUT == 3) && LOG2_NC != 11)  // (n_fft 4096 reads the banded table from global memory: mel_banded_global)
+    if constexpr ((OUT == 2 || OUT == 3) && LOG2_NC != 11)  // (n_fft 4096 keeps no table in LDS: the moment form, mel_moments_global)
         for (uint32_t i = tid; i < wo.mel_words; i += 64 * WAVES) meltab[i] = wo.mel_tab[i];
     __syncthreads();
 
@@ -2148,7 +2150,7 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                                                                         d_tw, nullptr, d_queue_head, n_cu, out, s);
         }
-        // (n_fft 4096, round 5: the banded table from global memory, for hop 1024 and the 96 / 88.2 kHz defaults — stft_wave_mel_fits)
+        // (n_fft 4096, round 6: the moment form, for hop 1024 and the 96 / 88.2 kHz defaults — stft_wave_mel_fits)
         // (round 5: frame pairs — two consecutive frames per pass over the banded table; n_fft 2048, plain or rotating frame loop)
         if constexpr (LOG2_NC == 10 || LOG2_NC == 9) {
             if (out.mode == 2 && out.mel_pair != 0) {
@@ -2318,7 +2320,7 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool bande
         return (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) &&
                wave_lds_bytes<9, WaveLaunchCfg<9>::DEFAULT_WAVES>() + extra + (512 + 128) * sizeof(cf32) +
                        (banded ? 0 : (size_t)WaveLaunchCfg<9>::DEFAULT_WAVES * MEL_PRF_1024 * sizeof(cf32)) <= 160 * 1024;
-    // n_fft 4096: nothing to fit (the table stays in global memory); the launch shapes the epilogue is instantiated for
+    // n_fft 4096: nothing to fit (the moment form keeps no table in LDS); the launch shapes the epilogue is instantiated for
     if (g.log2_nc == 11 && banded && words > 0 && (waves <= 0 || waves == WaveLaunchCfg<11>::DEFAULT_WAVES)) {
         const int pm = stft_wave_phased_mode(g, waves);
         if (pm == 0) return g.hop == 1024;

@@ -21,9 +21,12 @@
 //   gmax[G + (G & 1)] max over the group's lanes of the two piece counts added (the gather loop's trip count)
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
+
+#include "stft_core.h"  // MEL_MOM_HDR0, MEL_MOM_BATCH
 
 namespace th {
 
@@ -324,6 +327,222 @@ inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_m
     }
     out.n_groups = G;
     out.ok = true;
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Moment form of the same product (round 6): NO weight table.  The filters are triangles over the points p_0 < p_1 < ... <
+// p_{n_mel + 1} (src-common/src/lib.rs:65-86: filter m rises over (p_m, p_{m+1}] and falls over (p_{m+1}, p_{m+2})), so on
+// SEGMENT j = {bins k : p_j < f_k <= p_{j+1}} both weights are linear in the bin index,
+//     rise_j[k] = u_k / d_j,   fall_{j-1}[k] = (1 - u_k) / d_{j-1},   u_k = (f_k - p_j) / (p_{j+1} - p_j) = alpha_j t + beta_j,
+// t = k - (the lane's first bin), d_m = the filter's weight sum (lib.rs:84-86).  With the segment's moments
+//     S0_j = sum_k amp_k,   S1_j = sum_k amp_k t:      R_j = alpha_j S1_j + beta_j S0_j,   F_j = S0_j - R_j,
+//     mel[m] = (R_m + F_{m+1}) / d_m.
+// Lane = segment (64 per group): per bin of a segment two additions (P += a; S1' += P, walking the taps downwards, S0 = P at the
+// end; S1' = S1 + S0 and the host folds that into beta) where the banded sums spend a multiply-add per bin of a FILTER (two
+// segments) plus the weight reads — and nothing to keep in LDS beside the amplitude row: the n_fft 4096 kernel's eight slabs
+// leave no byte for a table (round 5 read a 36 KB one from L2 per frame: slower than two kernels).  Per group a lane loads four
+// words (first bin, alpha, beta', 1 / d) from global memory (1 KiB per wave-load, L1 / L2 resident) and the wave one 64-bit
+// lane mask per tap through the scalar cache: lanes whose segment does not cover tap t add zero.
+//
+// Two forms per group (word [2 + 2 g] bit 16):
+//   M (moments, above) where the group's widest segment has three bins or more.  R and F are differences of terms of size
+//     (alpha n + |beta'|) S0, so a filter whose bins all hug the far ends of its two segments (tiny d) would see that rounding
+//     1 / d times enlarged: `max_amp` = max over the M groups of (alpha n + |beta'|) / d is checked (<= 4: the error stays at a
+//     few ulp of the segment's amplitude sum over d, i.e. of a neighbouring mel value).
+//   W (weights) where every segment of the group has at most two bins — the bottom of every default filterbank, where segments
+//     are narrower than a bin and 1 / d reaches 10^4: the lane's one or two (u, 1 - u) pairs as the reference forms them in f32,
+//     R = a0 u0 + a1 u1, F = a0 v0 + a1 v1: exact products, no masks, two or four operations per group.
+//
+// NOT bit-faithful to the table in the M groups: the reference's f32 weights carry the rounding of its f32 frequencies, the line
+// through (p_j, p_{j+1}) does not.  `max_dev` is the largest |alpha t + beta - u_k(table)| over every bin of the M groups (1e-7
+// .. 1e-5) and bounds the result's deviation from the table's product relative to the segment's amplitude sum over d.
+//
+// Words: [0] = G, [1] = sum of the groups' taps; group g: [16 + 2 g] = taps n_g | form << 16 (M: n_g a multiple of
+// MEL_MOM_UNROLL, zero masks on top; W: 1 or 2), [17 + 2 g] = word offset of its block (16-byte aligned); the header is padded to
+// whole batches of 8 groups with (0, 0).  M block: 64 x {first
+// bin, alpha, beta', 1 / d} in lane order, then n_g masks (2 words each, tap t at 2 t).  W block: 64 x {first bin, u0, v0, 1 / d},
+// then 64 x {u1, v1}.  Lane l of group g = segment 64 g + l; mel m = 64 g + l takes F from the next lane (the next group's lane 0
+// across the group border: the kernel walks the groups downwards and carries it).
+// ---------------------------------------------------------------------------------------------
+struct MelMomHost {
+    std::vector<uint32_t> words;
+    uint32_t n_groups = 0, taps = 0, max_taps = 0, reach = 0, w_groups = 0;
+    double max_dev = 0.0, max_amp = 0.0;  // see above
+    bool ok = false;
+};
+constexpr uint32_t MEL_MOM_UNROLL = 4, MEL_MOM_FORM_W = 1u << 16;
+
+// fb: [n_freq][n_mel] (calc_mel_fb, normalised); lin[n_freq], mf[n_mel + 2]: the f32 frequency arrays it was built from
+// (mel_fb_points); max_index: amplitude floats a lane may address (the wave's slab)
+inline MelMomHost build_mel_moments(const float *fb, const float *lin, const float *mf, uint32_t n_freq, uint32_t n_mel,
+                                    uint32_t max_index, bool spread = true) {
+    MelMomHost out;
+    if (n_mel == 0 || n_freq < 2) return out;
+    const uint32_t n_seg = n_mel + 1, G = (n_seg + 63) / 64;
+    // segments: runs of bins, ascending, each bin in at most one
+    std::vector<uint32_t> lo(n_seg, 0), len(n_seg, 0);
+    {
+        uint32_t k = 0;
+        while (k < n_freq && !(lin[k] > mf[0])) k++;
+        for (uint32_t j = 0; j < n_seg; j++) {
+            if (!(mf[j] < mf[j + 1])) return out;  // (coinciding points: the reference divides by zero there)
+            lo[j] = k;
+            while (k < n_freq && lin[k] <= mf[j + 1]) k++;
+            len[j] = k - lo[j];
+        }
+        // every remaining bin must be weightless (f > fmax)
+        for (; k < n_freq; k++)
+            for (uint32_t m = 0; m < n_mel; m++)
+                if (fb[(size_t)k * n_mel + m] != 0.f) return out;
+    }
+    auto u_f32 = [&](uint32_t j, uint32_t k) -> float {  // the reference's f32 rise weight of filter j at bin k of segment j
+        return lin[k] == mf[j + 1] ? 1.f : (lin[k] - mf[j]) / (mf[j + 1] - mf[j]);
+    };
+    auto v_f32 = [&](uint32_t j, uint32_t k) -> float {  // ... and the fall weight of filter j - 1 there
+        return lin[k] == mf[j + 1] ? 0.f : (mf[j + 1] - lin[k]) / (mf[j + 1] - mf[j]);
+    };
+    // d_m as the reference sums it (f32, ascending bins, lib.rs:84-86), cross-checked against the table value by value
+    std::vector<float> dsum(n_mel, 0.f);
+    for (uint32_t m = 0; m < n_mel; m++) {
+        float s = 0.f;
+        for (uint32_t k = lo[m]; k < lo[m] + len[m]; k++) s += u_f32(m, k);
+        for (uint32_t k = lo[m + 1]; k < lo[m + 1] + len[m + 1]; k++) s += v_f32(m + 1, k);
+        const float d = std::max(s, 1.1920929e-7f);
+        dsum[m] = d;
+        for (uint32_t k = lo[m]; k < lo[m] + len[m]; k++)
+            if (fb[(size_t)k * n_mel + m] != u_f32(m, k) / d) return out;
+        for (uint32_t k = lo[m + 1]; k < lo[m + 1] + len[m + 1]; k++)
+            if (fb[(size_t)k * n_mel + m] != v_f32(m + 1, k) / d) return out;
+    }
+    const double step = (double)lin[1] - (double)lin[0];
+    std::vector<uint32_t> &t = out.words;
+    const uint32_t hdr = MEL_MOM_HDR0 + 2 * ((G + MEL_MOM_BATCH - 1) / MEL_MOM_BATCH * MEL_MOM_BATCH);  // (whole batches; padding groups: taps 0, offset 0)
+    t.assign(hdr, 0);
+    t[0] = G;
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t s0 = 64 * g, s1 = std::min(n_seg, 64 * g + 64), ns = s1 - s0;
+        uint32_t n = 1;
+        for (uint32_t j = s0; j < s1; j++) n = std::max(n, len[j]);
+        const size_t off = t.size();
+        t[MEL_MOM_HDR0 + 1 + 2 * g] = (uint32_t)off;
+        if (n <= 2) {  // W form
+            t[MEL_MOM_HDR0 + 2 * g] = n | MEL_MOM_FORM_W;
+            out.taps += n;
+            out.max_taps = std::max(out.max_taps, n);
+            out.w_groups++;
+            t.resize(off + 256 + 128, 0);
+            for (uint32_t l = 0; l < 64; l++) {
+                const uint32_t j = s0 + l;
+                float w[4] = {0.f, 0.f, 0.f, 0.f};  // u0, v0, u1, v1
+                uint32_t first = 0;
+                if (j < n_seg && len[j] > 0) {
+                    first = lo[j];
+                    for (uint32_t i = 0; i < len[j]; i++) {
+                        if (j < n_mel) w[2 * i] = u_f32(j, lo[j] + i);  // (the last segment has no rising filter)
+                        if (j >= 1) w[2 * i + 1] = v_f32(j, lo[j] + i);  // (the first none that falls)
+                    }
+                    out.reach = std::max(out.reach, first + n);
+                }
+                if (first + n > max_index) return MelMomHost{};
+                const float inv = j < n_mel ? (float)(1.0 / (double)dsum[j]) : 0.f;
+                std::memcpy(&t[off + 4 * l], &first, 4);
+                std::memcpy(&t[off + 4 * l + 1], &w[0], 8);
+                std::memcpy(&t[off + 4 * l + 3], &inv, 4);
+                std::memcpy(&t[off + 256 + 2 * l], &w[2], 8);
+            }
+            continue;
+        }
+        // M form.  First bins moved down onto different LDS banks where the group's tap count leaves room (mel_band_spread: at
+        // most `cap` first bins of a half wave on one bank); the masks cut the window out, so a shift costs nothing but beta
+        uint32_t shift[64] = {};
+        if (spread && ns > 1) {
+            uint32_t width[64] = {}, first[64] = {};
+            for (uint32_t l = 0; l < ns; l++) {
+                width[l] = std::max(1u, len[s0 + l]);
+                first[l] = lo[s0 + l];
+            }
+            const uint32_t h0 = std::min(32u, ns), h1 = ns - h0;
+            // (cost of a tap: three vector operations + the LDS cycles of its amplitude read by the bank rule)
+            uint32_t best = n * (3u + mel_band_half_cycles(first, h0) + (h1 ? mel_band_half_cycles(first + 32, h1) : 0u)), best_n = n;
+            for (uint32_t nn = n; nn <= n + 2; nn++) {
+                uint32_t sh[64] = {};
+                bool found = true;
+                uint32_t cycles = 0;
+                for (uint32_t h = 0; h < 2 && found; h++) {
+                    const uint32_t hb = h ? 32u : 0u, hn = h ? h1 : h0;
+                    if (!hn) continue;
+                    uint32_t cap = 1;
+                    while (cap <= 4 && !mel_band_spread(first + hb, width + hb, hn, nn, cap, sh + hb, 1)) cap++;
+                    found = cap <= 4;
+                    cycles += cap;
+                }
+                if (found && nn * (3u + cycles) < best) {
+                    best = nn * (3u + cycles);
+                    best_n = nn;
+                    std::copy(sh, sh + 64, shift);
+                }
+            }
+            // a shift enlarges beta' and with it the rounding a small d multiplies (max_amp): not in a group that holds such a filter
+            double amp_shifted = 0.0;
+            for (uint32_t l = 0; l < ns; l++) {
+                const uint32_t j = s0 + l;
+                if (!len[j]) continue;
+                const double dp = (double)mf[j + 1] - (double)mf[j], alpha = step / dp;
+                const double beta = ((double)lin[0] + step * (double)(lo[j] - shift[l]) - (double)mf[j]) / dp - alpha;
+                const double mag = alpha * (double)(shift[l] + len[j]) + std::fabs(beta);
+                if (j < n_mel) amp_shifted = std::max(amp_shifted, mag / (double)dsum[j]);
+                if (j >= 1) amp_shifted = std::max(amp_shifted, (1.0 + mag) / (double)dsum[j - 1]);
+            }
+            if (amp_shifted > 4.0) {
+                std::fill(shift, shift + 64, 0u);
+                best_n = 1;
+                for (uint32_t j = s0; j < s1; j++) best_n = std::max(best_n, len[j]);
+            }
+            n = best_n;
+        }
+        const uint32_t n_pad = (n + MEL_MOM_UNROLL - 1) / MEL_MOM_UNROLL * MEL_MOM_UNROLL;
+        t[MEL_MOM_HDR0 + 2 * g] = n_pad;
+        out.taps += n_pad;
+        out.max_taps = std::max(out.max_taps, n_pad);
+        t.resize(off + 256 + 2 * (size_t)n_pad, 0);
+        for (uint32_t l = 0; l < 64; l++) {
+            const uint32_t j = s0 + l;
+            float prm[4] = {0.f, 0.f, 0.f, 0.f};
+            uint32_t first = 0;
+            if (j < n_seg && len[j] > 0) {
+                first = lo[j] - shift[l];
+                if (first + n_pad > max_index) return MelMomHost{};
+                const double dp = (double)mf[j + 1] - (double)mf[j];
+                const double alpha = step / dp;
+                const double beta = ((double)lin[0] + step * (double)first - (double)mf[j]) / dp;  // u at tap 0
+                prm[1] = (float)alpha;
+                prm[2] = (float)(beta - alpha);  // the kernel's S1' counts tap t (t + 1) times: S1' = S1 + S0
+                for (uint32_t k = lo[j]; k < lo[j] + len[j]; k++) {
+                    const uint32_t tap = k - first;
+                    const uint64_t bit = 1ull << l;
+                    t[off + 256 + 2 * tap] |= (uint32_t)bit;
+                    t[off + 256 + 2 * tap + 1] |= (uint32_t)(bit >> 32);
+                    // deviation of the line (as the kernel's f32 constants give it) from the table's weights
+                    const double u_line = (double)prm[1] * (double)(tap + 1) + (double)prm[2];
+                    if (j < n_mel) out.max_dev = std::max(out.max_dev, std::fabs(u_line - (double)u_f32(j, k)));
+                    if (j >= 1) out.max_dev = std::max(out.max_dev, std::fabs((1.0 - u_line) - (double)v_f32(j, k)));
+                }
+                const double mag = (double)prm[1] * (double)(shift[l] + len[j]) + std::fabs((double)prm[2]);
+                if (j < n_mel) out.max_amp = std::max(out.max_amp, mag / (double)dsum[j]);
+                if (j >= 1) out.max_amp = std::max(out.max_amp, (1.0 + mag) / (double)dsum[j - 1]);
+                out.reach = std::max(out.reach, first + n_pad);
+            }
+            if (j < n_mel) prm[3] = (float)(1.0 / (double)dsum[j]);
+            std::memcpy(&t[off + 4 * l], &first, 4);
+            std::memcpy(&t[off + 4 * l + 1], &prm[1], 12);
+        }
+    }
+    t[1] = out.taps;
+    out.n_groups = G;
+    // (a filterbank whose segments are not lines in the bin index, or whose wide groups hold a filter with next to no weight: not this form)
+    out.ok = out.max_dev < 1e-4 && out.max_amp <= 8.0;
+    if (!out.ok) t.clear();
     return out;
 }
 

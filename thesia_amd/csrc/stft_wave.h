@@ -1615,42 +1615,143 @@ TH_HD void mel_banded_pair(uint32_t lane, const float *amp, const uint32_t *tab,
     }
 }
 
-// The same banded sums with the table in GLOBAL memory (round 5: n_fft 4096, whose eight slabs leave no LDS for a 30-36 KB
-// table): paired layout only.  Every wave of the launch reads the same table frame after frame — L2-resident, 1 KiB per
-// wave-instruction (16 bytes per lane, lane-contiguous); the amplitudes come from the wave's own slab as in mel_banded.
-// A group's weight quads are requested in batches of BATCH (all of a batch in flight before the first FMA); quads past the
-// group's end re-read its last quad and are multiplied by zero (no branch around a load).
-#if defined(__HIPCC__)  // (both passes of hipcc see it: wave_frame is parsed by the host pass too; not the CPU lane emulator)
-template <int BATCH = 8, class Emit>
-__device__ __forceinline__ void mel_banded_global(uint32_t lane, const float *amp, gptr<const uint32_t> tab, uint32_t n_groups,
-                                                  const uint32_t (&off)[8], const uint32_t (&n)[8], Emit emit) {
-    typedef float f32x4v __attribute__((ext_vector_type(4)));
-    uint32_t lo[8];  // every group's first bin up front: one L2 round trip for all of them
-    TH_UNROLL for (uint32_t g = 0; g < 8; g++) lo[g] = tab[off[g < n_groups ? g : 0] + lane];
-    TH_UNROLL for (uint32_t g = 0; g < 8; g++) {
-        if (g < n_groups) {  // wave-uniform
-            const float *ap = amp + lo[g];
-            const gptr<const f32x4v> wp = reinterpret_cast<gptr<const f32x4v>>(tab + (off[g] + 64u)) + lane;  // quad q: wp[64 q]
-            const uint32_t nq = n[g] >> 2;
-            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (uint32_t q0 = 0; q0 < nq; q0 += BATCH) {
-                f32x4v w[BATCH];
-                TH_UNROLL for (int u = 0; u < BATCH; u++) w[u] = wp[64u * min(q0 + (uint32_t)u, nq - 1u)];
-                cf32 a[BATCH][2];
-                TH_UNROLL for (int u = 0; u < BATCH; u++) {
-                    const float *q = ap + 4u * min(q0 + (uint32_t)u, nq - 1u);
-                    a[u][0] = lds_ld(reinterpret_cast<const cf32 *>(q));
-                    a[u][1] = lds_ld(reinterpret_cast<const cf32 *>(q + 2));
+// ---------------------------------------------------------------------------------------------
+// Moment form of the mel filterbank (round 6; tables and the algebra: build_mel_moments, mel_fuse.h): lane = SEGMENT of the
+// triangle points, no weight table.  amp[] = the frame's amplitude row in the wave's slab.  A lane walks the taps of its group
+// downwards, P += a_t (a_t = 0 where the wave's mask for tap t does not name the lane), S1' += P: S0 = P at the end and
+// S1' = sum_t a_t (t + 1).  Then R = alpha S1' + beta' S0 (the rising filter's share of the segment), F = S0 - R (the falling
+// one's), and mel m = (R of segment m + F of segment m + 1) / d_m.
+// ---------------------------------------------------------------------------------------------
+struct MelMomLane {
+    float R, F;
+};
+// a where the wave-uniform mask names this lane, else +0 (a select, not a product: whatever sits behind the amplitude row —
+// stale exchange data, NaN — never enters a sum)
+TH_HD float mel_mom_sel(float a, uint64_t mask, uint32_t lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(mask));  // (the mask straight from its SGPR pair: a scalar load's result)
+    (void)lane;
+    return r;
+#else
+    return ((mask >> lane) & 1u) ? a : 0.0f;
+#endif
+}
+struct MelMomMasks4 {
+    uint64_t m0, m1, m2, m3;
+};
+// the masks of taps t .. t + 3 (device: `masks` points into the CONSTANT address space and t is wave-uniform — one s_load_dwordx8)
+template <class MaskPtr>
+TH_HD MelMomMasks4 mel_mom_masks4(MaskPtr masks, uint32_t t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint64_t u64x4v __attribute__((ext_vector_type(4)));
+    const u64x4v v = *(const __attribute__((address_space(4))) u64x4v *)(masks + t);
+    return {v.x, v.y, v.z, v.w};
+#else
+    return {masks[t], masks[t + 1], masks[t + 2], masks[t + 3]};
+#endif
+}
+// one lane, one group: first = the lane's first bin, masks[t] = lanes whose segment holds bin first + t, n = the group's taps
+// (a multiple of MEL_MOM_UNROLL = 4, >= 4).  Four taps per trip; the next trip's amplitudes and masks are requested before this
+// trip's additions (two waves per SIMD hide little).
+template <class MaskPtr>
+TH_HD MelMomLane mel_mom_lane(uint32_t lane, const float *amp, uint32_t first, float alpha, float beta, MaskPtr masks, uint32_t n) {
+    const float *ap = amp + first + n - 4;
+    float P = 0.0f, S1 = 0.0f;
+    float a0 = lds_ldf(ap), a1 = lds_ldf(ap + 1), a2 = lds_ldf(ap + 2), a3 = lds_ldf(ap + 3);
+    MelMomMasks4 m = mel_mom_masks4(masks, n - 4);
+    for (uint32_t t0 = n - 4;; t0 -= 4) {  // taps t0 + 3 .. t0
+        const float c0 = a0, c1 = a1, c2 = a2, c3 = a3;
+        const MelMomMasks4 cm = m;
+        const bool more = t0 != 0;  // wave-uniform
+        if (more) {
+            ap -= 4;
+            a0 = lds_ldf(ap);
+            a1 = lds_ldf(ap + 1);
+            a2 = lds_ldf(ap + 2);
+            a3 = lds_ldf(ap + 3);
+            m = mel_mom_masks4(masks, t0 - 4);
+        }
+        P += mel_mom_sel(c3, cm.m3, lane);
+        S1 += P;
+        P += mel_mom_sel(c2, cm.m2, lane);
+        S1 += P;
+        P += mel_mom_sel(c1, cm.m1, lane);
+        S1 += P;
+        P += mel_mom_sel(c0, cm.m0, lane);
+        S1 += P;
+        if (!more) break;
+    }
+    const float R = fma_rn(alpha, S1, beta * P);
+    return {R, P - R};
+}
+// W form (groups whose segments hold one or two bins): the (u, 1 - u) pairs themselves, exact products
+TH_HD MelMomLane mel_mom_w_lane(const float *amp, uint32_t first, uint32_t n, float u0, float v0, float u1, float v1) {
+    const float a0 = lds_ldf(amp + first);
+    MelMomLane s = {a0 * u0, a0 * v0};
+    if (n > 1) {  // wave-uniform
+        const float a1 = lds_ldf(amp + first + 1);
+        s.R = fma_rn(a1, u1, s.R);
+        s.F = fma_rn(a1, v1, s.F);
+    }
+    return s;
+}
+// the filter output from its two shares (a sum of non-negative terms up to rounding: never below zero)
+TH_HD float mel_mom_combine(float inv_d, float R, float F_next) {
+    const float v = inv_d * (R + F_next);
+    return v > 0.0f ? v : 0.0f;
+}
+
+#if defined(__HIPCC__)  // (both passes of hipcc; not the CPU lane emulator, which drives the lane functions itself)
+// The whole epilogue of one frame: groups from the top down (mel m needs F of segment m + 1: the next lane, or across the
+// group border lane 0 of the group above — carried in a scalar), in BATCHES of MEL_MOM_BATCH groups: a batch's header words are
+// one scalar load and its per-lane words are requested together, so a frame pays the global-memory latency once per batch and
+// not once per group (a group's own work is a few dozen instructions: requested one group ahead, every group waited for its words
+// — 0.63 us per group, scripts/ubench/mom_probe.hip).  The table's group header is padded to whole batches (taps 0: skipped).
+template <class Emit>
+__device__ __forceinline__ void mel_moments_global(uint32_t lane, const float *amp, gptr<const uint32_t> tab, uint32_t n_groups, Emit emit) {
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x16v __attribute__((ext_vector_type(16)));
+    // the header words and the masks through the CONSTANT address space: the table is not written while the kernel runs, and
+    // wave-uniform loads from there are scalar loads (the rows this kernel stores keep the compiler from proving that of a
+    // global pointer)
+    typedef const __attribute__((address_space(4))) uint64_t *cptr64;
+    typedef const __attribute__((address_space(4))) u32x16v *cptr16v;
+    constexpr uint32_t GB = MEL_MOM_BATCH;
+    float carry = 0.0f;
+    for (uint32_t gb = (n_groups + GB - 1u) / GB * GB; gb != 0; gb -= GB) {  // groups gb - 1 .. gb - GB
+        const uint32_t g0 = gb - GB;
+        const u32x16v hv = *(cptr16v)(uintptr_t)(tab + MEL_MOM_HDR0 + 2u * g0);
+        // (scalar copies: vector elements are not indexed dynamically, and __builtin_bit_cast on a vector-element lvalue reads element 0)
+        const uint32_t nw[GB] = {hv.s0, hv.s2, hv.s4, hv.s6, hv.s8, hv.sa, hv.sc, hv.se};
+        const uint32_t off[GB] = {hv.s1, hv.s3, hv.s5, hv.s7, hv.s9, hv.sb, hv.sd, hv.sf};
+        u32x4v prm[GB];
+        u32x2v w1[GB];
+        TH_UNROLL for (uint32_t j = 0; j < GB; j++) {
+            prm[j] = *reinterpret_cast<gptr<const u32x4v>>(tab + off[j] + 4u * lane);  // (padding groups: offset 0, the header itself)
+            w1[j] = u32x2v{0u, 0u};
+            if ((nw[j] & 0x1ffffu) == 0x10002u) w1[j] = *reinterpret_cast<gptr<const u32x2v>>(tab + off[j] + 256u + 2u * lane);  // W form, two bins
+        }
+        TH_UNROLL for (uint32_t jj = GB; jj-- != 0;) {
+            const uint32_t n = nw[jj] & 0xffffu;
+            if (n != 0) {  // wave-uniform (0: padding behind the last group)
+                const uint32_t first = prm[jj].x, w_y = prm[jj].y, w_z = prm[jj].z, w_w = prm[jj].w;
+                MelMomLane s;
+                if (nw[jj] & 0x10000u) {  // W form
+                    const uint32_t u1 = w1[jj].x, v1 = w1[jj].y;
+                    s = mel_mom_w_lane(amp, first, n, __builtin_bit_cast(float, w_y), __builtin_bit_cast(float, w_z), __builtin_bit_cast(float, u1),
+                                       __builtin_bit_cast(float, v1));
+                } else {
+                    const cptr64 masks = (cptr64)(uintptr_t)(tab + off[jj] + 256u);
+                    s = mel_mom_lane(lane, amp, first, __builtin_bit_cast(float, w_y), __builtin_bit_cast(float, w_z), masks, n);
                 }
-                TH_UNROLL for (int u = 0; u < BATCH; u++) {
-                    const bool ok = q0 + (uint32_t)u < nq;  // wave-uniform
-                    acc[0] = fma_rn(a[u][0].re, ok ? w[u].x : 0.0f, acc[0]);
-                    acc[1] = fma_rn(a[u][0].im, ok ? w[u].y : 0.0f, acc[1]);
-                    acc[2] = fma_rn(a[u][1].re, ok ? w[u].z : 0.0f, acc[2]);
-                    acc[3] = fma_rn(a[u][1].im, ok ? w[u].w : 0.0f, acc[3]);
-                }
+                // F of the next lane; lane 63 takes the group above's lane 0
+                const float fn_in = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(4u * ((lane + 1u) & 63u)), __builtin_bit_cast(int, s.F)));
+                const float fn = lane == 63u ? carry : fn_in;
+                carry = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s.F)));
+                emit(64u * (g0 + jj) + lane, mel_mom_combine(__builtin_bit_cast(float, w_w), s.R, fn));
             }
-            emit(64u * g + lane, (acc[0] + acc[1]) + (acc[2] + acc[3]));
         }
     }
 }
