@@ -681,7 +681,7 @@ def main():
     # instead of 681 VALU instructions per frame — the lever VERDICT r3 named), inside the same step, right after the
     # default: reported so that the driver's record shows why it is not the default.
     pk_ms = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and ta.ab_variants():   # (A/B builds only: the product library no longer carries selector 9)
         try:
             wl.plan.set_kernel(9)
             for _ in range(args.spin_up_steps // 2):
@@ -767,7 +767,7 @@ def main():
                  ("nfft8192", "long transform: n_fft 8192 / hop 2048, linear dB (one workgroup per frame)", wl.wav, 48000, (8192, 2048, 8192, ta.LINEAR, 0), 0),
                  ("nfft16384", "long transform: n_fft 16384 / hop 4096, linear dB (one workgroup per frame)", wl.wav, 48000, (16384, 4096, 16384, ta.LINEAR, 0), 0),
                  ("nfft32768", "very long transform: n_fft 32768 / hop 8192, linear dB (400 ms window at 48 kHz; round 5: sixteen 1024-point wave transforms + one combining pass, stft_subwave_kernel)", wl.wav, 48000, (32768, 8192, 32768, ta.LINEAR, 0), 0),
-                 ("nfft32768_block_kernel", "n_fft 32768 / hop 8192 on the workgroup-per-frame Stockham kernel (selector 14: rounds 3-4's plan)", wl.wav, 48000, (32768, 8192, 32768, ta.LINEAR, 0), 14),
+                 *((("nfft32768_block_kernel", "n_fft 32768 / hop 8192 on the workgroup-per-frame Stockham kernel (selector 14: rounds 3-4's plan; A/B builds only)", wl.wav, 48000, (32768, 8192, 32768, ta.LINEAR, 0), 14),) if ta.ab_variants() else ()),
                  ("nfft65536", "n_fft 65536 / hop 16384, linear dB (1.4 s window at 48 kHz; round 5: the workgroup-per-frame plan with planar LDS exchanges)", wl.wav, 48000, (65536, 16384, 65536, ta.LINEAR, 0), 0),
                  # the Mel default of long windows has more than 512 mels (src-common/src/lib.rs:91-103): two kernels since round 4
                  ("nfft4096_mel_default", "48 kHz, n_fft 4096 / hop 1024, mel scale at the default count (695 mels; round 6: moment-form epilogue, one kernel)", wl.wav, 48000, (4096, 1024, 4096, ta.MEL, 0), 0),

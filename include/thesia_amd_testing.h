@@ -18,21 +18,24 @@
  * shapes: 8, 12 or 16), 7 = as 3 with the matrix-core kernel also where 3 runs the
  * banded-sum kernel over the amplitude rows (n_fft 512 under filters of at most 8 bins: the default mel counts of 8-12 kHz audio),
  * 8 = the fused mel epilogue in its pieces / gather form where banded sums are the default (A/B),
- * 9 = the wave kernel's packed-f32 pipeline (v_pk_fma_f32 butterflies on register pairs) where it is instantiated: n_fft 2048,
- * hop = n_fft / 4, linear dB, default waves (A/B: it measures the same as the scalar pipeline; elsewhere as 2),
- * 11 = the wave kernel with the "sweep" chunk schedule (4-frame chunks dealt out in order through a per-workgroup ticket
- * counter, the next chunk's first frame prefetched) on large batches of that same shape (A/B: a faster memory skeleton, the
- * same launch time; elsewhere as 2; 10 is reserved and behaves as 2),
- * 12 = mel plans at n_fft 4096: the banded sums as the FFT kernel's epilogue with the table read from global memory (L2) instead of
- * the second kernel over amplitude rows, on the launch shapes it is instantiated for (hop 1024 and the 96 / 88.2 kHz defaults,
- * at most 512 mels; A/B: measured slower, profiles/r05_ab_mel4096_fused.txt; elsewhere as 2),
+ * 12 = mel plans at n_fft 4096: the two kernels (FFT kernel -> amplitude rows -> banded sums / matrix cores) where the moment-form
+ * epilogue is the default (hop 1024, the 96 / 88.2 kHz defaults; round 5's route, kept for A/B; elsewhere as 2),
  * 13 = the fused mel epilogue one frame at a time where frame pairs are the default (n_fft 1024 / 2048 banded sums; A/B, bit-identical),
- * 14 = the workgroup-per-frame Stockham kernels (stft_block_kernel / its planar form) where stft_subwave_kernel is the default
- * (n_fft 32768, 65536, 16384 at hops other than n_fft / 4; A/B),
- * 15 = stft_subwave_kernel (R 1024-point wave transforms + a combining pass) wherever it exists, n_fft 8192 .. 65536 (A/B);
- * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with 4..16 waves per workgroup and `chunk`
- * frames per queue pull */
+ * 14 = the workgroup-per-frame Stockham kernel where stft_subwave_kernel is the default (n_fft 16384 at hops other than n_fft / 4),
+ * 15 = stft_subwave_kernel (R 1024-point wave transforms + a combining pass) at n_fft 16384 also at hop n_fft / 4 (A/B);
+ * 10 is reserved and behaves as 2;
+ * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with `waves` waves per workgroup (7, 8 or 12 — each size's default
+ * shapes; the multi-frame plans 8, 12, 16) and `chunk` frames per queue pull.
+ * Only in libraries built with -DTH_AB_VARIANTS=1 (th_build_ab_variants() == 1; scripts/build_variant.sh), TH_ERR_UNSUPPORTED
+ * otherwise — measured, dropped, and no longer part of the product binary (HISTORY.md has the numbers):
+ * 9 = the wave kernel's packed-f32 pipeline (v_pk_fma_f32 butterflies on register pairs; n_fft 2048, hop = n_fft / 4, linear dB),
+ * 11 = the "sweep" chunk schedule (4-frame chunks dealt out in order through a per-workgroup ticket counter) on large batches of
+ * that shape, 14 at n_fft 32768 / 65536 (stft_block_kernel / its planar form), 15 at n_fft 8192, and 4, 6, 10, 14 or 16 waves per
+ * workgroup for the one-frame wave kernels */
 TH_API int th_plan_set_kernel(th_plan *plan, int which);
+
+/* 1 when the library carries the A/B variants above (-DTH_AB_VARIANTS=1), 0 for the product build */
+TH_API int th_build_ab_variants(void);
 
 /* ---------------------------------------------------------------- measurement: the dominant kernel's launch duration */
 /* Measurement hook: with enable != 0 every th_calc_spec_batch_dev records two HIP events on the context's stream

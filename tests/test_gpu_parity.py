@@ -132,7 +132,13 @@ def test_very_long_transforms(ctx, sr, win, hop, n_fft, scale, n_mel):
             assert_spec_close(b[i], want, amp if fb is None else None)
     if ref is not None:
         ref.close()
-    if n_fft in (32768, 65536):  # the block kernel on the same batch: same tables and butterflies, another order of passes
+    if n_fft in (32768, 65536) and not ta.ab_variants():  # (selector 14 at these sizes is an A/B variant: refused by the product build)
+        old = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, n_mel)
+        with pytest.raises(ta.ThError) as e:
+            old.set_kernel(14)
+        assert e.value.code == -2 and "TH_AB_VARIANTS" in str(e.value)
+        old.close()
+    if n_fft in (32768, 65536) and ta.ab_variants():  # the block kernel on the same batch: same tables and butterflies, another order of passes
         old = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, n_mel)
         old.set_kernel(14)
         assert old.kernel_name == want_kernel.replace("stft_subwave_kernel", "stft_block_kernel")
@@ -162,7 +168,14 @@ def test_subwave_plan(ctx, sr, win, hop, n_fft, scale, n_mel):
     want = [orc.calc_spec(x, win, hop, n_fft, mel_fb=fb, return_amp=True) for x in wavs[:-1]]
     for which, fft in ((15, "stft_subwave_kernel"), (14, "stft_block_kernel")):
         plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, n_mel)
-        plan.set_kernel(which)
+        if not ta.ab_variants() and ((which == 15 and n_fft == 8192) or (which == 14 and n_fft == 32768)):
+            with pytest.raises(ta.ThError) as e:   # (the losing plan of the size: A/B builds only)
+                plan.set_kernel(which)
+            assert e.value.code == -2 and "TH_AB_VARIANTS" in str(e.value)
+            plan.set_kernel(0)
+            fft = "stft_block_kernel" if n_fft == 8192 else "stft_subwave_kernel"   # the size's default plan instead
+        else:
+            plan.set_kernel(which)
         assert plan.kernel_name.startswith(fft), plan.kernel_name
         a, mm = plan.calc_spec_batch(wavs)
         for i, (w, amp) in enumerate(want):
@@ -565,6 +578,14 @@ def test_mel_frame_pair_epilogue(ctx, sr, win, hop, n_fft, n_mel):
     single.close()
 
 
+def _product_build_refuses(plan, which):
+    """VERDICT r5 #12: measured-and-dropped variants are not in the product binary; their selectors are refused by name."""
+    with pytest.raises(ta.ThError) as e:
+        plan.set_kernel(which)
+    assert e.value.code == -2 and "TH_AB_VARIANTS" in str(e.value)
+    plan.set_kernel(0)
+
+
 def test_packed_f32_pipeline_matches_oracle_and_scalar_pipeline(ctx):
     """th_plan_set_kernel(plan, 9): the n_fft 2048 wave kernel on register pairs (v_pk_fma_f32 butterflies, stft_pk.h; built
     in round 4 as the lever VERDICT r3 named — it measures the same as the scalar pipeline, which stays the default).  Same
@@ -572,6 +593,11 @@ def test_packed_f32_pipeline_matches_oracle_and_scalar_pipeline(ctx):
     bit, true min / max, silence exactly -inf."""
     sr, win, hop, n_fft = 48000, 2048, 512, 2048
     plan, ref = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR), ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    if not ta.ab_variants():
+        _product_build_refuses(plan, 9)
+        plan.close()
+        ref.close()
+        pytest.skip("selector 9 (packed-f32 pipeline) is compiled into A/B builds only (-DTH_AB_VARIANTS=1): measured, dropped, pruned from the product")
     plan.set_kernel(9)
     assert plan.kernel_name == "stft_wave_kernel"
     xs = [synth_track(70 + i, sr, n) for i, n in enumerate((48000 * 4, 30011, 2048, 5000))] + [np.zeros(9000, np.float32)]
@@ -602,6 +628,11 @@ def test_sweep_chunk_schedule_matches_the_default_schedule(ctx):
     sr, win, hop, n_fft = 48000, 2048, 512, 2048
     lens = [48000 * 25 + 17 * i for i in range(44)] + [1500, 2048, 4099, 48000 * 3 + 1]
     plan, ref = ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR), ta.Plan(ctx, sr, win, hop, n_fft, ta.LINEAR)
+    if not ta.ab_variants():
+        _product_build_refuses(plan, 11)
+        plan.close()
+        ref.close()
+        pytest.skip("selector 11 (sweep chunk schedule) is compiled into A/B builds only (-DTH_AB_VARIANTS=1): measured, dropped, pruned from the product")
     plan.set_kernel(11)
     dev = torch.device("cuda", ctx.device)
     wavs = [torch.from_numpy(synth_track(900 + i, sr, n)).to(dev) for i, n in enumerate(lens)]
@@ -1215,7 +1246,15 @@ def test_set_kernel_rejects_launch_shapes_that_do_not_exist(ctx):
         assert_spec_close(plan.calc_spec(x)[0], want)
     plan.close()
     plan = ta.Plan(ctx, 48000, 1024, 256, 1024, ta.LINEAR)
-    plan.set_kernel(2 | (10 << 8))  # the one-frame plan of n_fft 1024 has this shape ...
+    if ta.ab_variants():
+        plan.set_kernel(2 | (10 << 8))  # (A/B builds) the one-frame plan of n_fft 1024 has this shape ...
+    else:
+        with pytest.raises(ta.ThError) as e:   # the product build keeps each size's default shapes: 7, 8, 12
+            plan.set_kernel(2 | (10 << 8))
+        assert e.value.code == -2 and "TH_AB_VARIANTS" in str(e.value)
+        for wv in (8, 12):
+            plan.set_kernel(2 | (wv << 8))
+            assert_spec_close(plan.calc_spec(synth_track(81, 48000, 30000))[0], orc.calc_spec(synth_track(81, 48000, 30000), 1024, 256, 1024))
     with pytest.raises(ta.ThError):
         plan.set_kernel(6 | (10 << 8))  # ... its two-frames-per-wave plan (selector 6) does not
     plan.close()

@@ -146,6 +146,7 @@ _SIGS = {
     "th_plan_destroy": [vp],
     "th_plan_dims": [vp, c_szp, c_szp],
     "th_plan_set_kernel": [vp, C.c_int],
+    "th_build_ab_variants": [],
     "th_plan_kernel_name": [vp],
     "th_calc_spec_batch_dev": [vp, C.POINTER(ChanDesc), C.c_size_t, vp],
     "th_calc_spec_batch_ranged_dev": [vp, C.POINTER(ChanDesc), C.c_size_t, vp, C.c_float, vp],

@@ -104,6 +104,12 @@ def pyramid_offset(n_samples: int, level: int) -> int:
     return lib.th_waveform_pyramid_offset(n_samples, level)
 
 
+def ab_variants() -> bool:
+    """True when the loaded library was built with -DTH_AB_VARIANTS=1 (the measured-and-dropped kernel variants behind
+    th_plan_set_kernel: include/thesia_amd_testing.h); the product build answers False and refuses those selectors."""
+    return bool(lib.th_build_ab_variants())
+
+
 def shard_assign(weights, world: int):
     """th_shard_assign: owner rank of every (track, channel) unit, by frame-count weight."""
     w = np.ascontiguousarray(weights, dtype=np.uint64)

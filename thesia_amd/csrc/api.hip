@@ -736,12 +736,26 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
     if (multi && !(wv == 0 || wv == 8 || wv == 12 || wv == 16))
         return fail(TH_ERR_UNSUPPORTED, "the multi-frame wave kernel of n_fft %u runs with 8, 12 or 16 waves per workgroup, not %d",
                     p->g.n_fft, wv);
+    // Variants that were measured and dropped are not in the product library (kernels.h, TH_AB_VARIANTS): refuse them by name
+    // instead of a launch failure later
+    if (!TH_AB_VARIANTS) {
+        const char *what = nullptr;
+        if (k == 9) what = "selector 9 (packed-f32 pipeline)";
+        else if (k == 11) what = "selector 11 (sweep chunk schedule)";
+        else if (k == 14 && p->g.log2_nc >= 14) what = "selector 14 at n_fft 32768 / 65536 (workgroup-per-frame Stockham kernels)";
+        else if (k == 15 && p->g.log2_nc == 12) what = "selector 15 at n_fft 8192 (stft_subwave_kernel with four waves)";
+        else if (!multi && p->g.log2_nc >= 9 && p->g.log2_nc <= 11 && !(wv == 0 || wv == 7 || wv == 8 || wv == 12))
+            what = "a waves-per-workgroup shape other than 7, 8 or 12";
+        if (what) return fail(TH_ERR_UNSUPPORTED, "%s is an A/B variant: build with -DTH_AB_VARIANTS=1 (scripts/build_variant.sh)", what);
+    }
     p->kernel_choice = k;
     p->wave_waves = wv;
     p->wave_chunk = (which >> 16) & 0xff;  // tuning: frames per chunk of the wave kernel (0 = default)
     return TH_OK;
     TH_CATCH
 }
+
+TH_API int th_build_ab_variants(void) { return TH_AB_VARIANTS ? 1 : 0; }
 
 TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (!p) return "";
@@ -1219,6 +1233,13 @@ TH_API int th_plan_kernel_ms_history(th_plan *p, float *out_ms, size_t capacity,
         const size_t slot = (size_t)((p->timed_launches - n + i) % th_plan::TIMER_SLOTS);
         TH_HIP(hipEventSynchronize(p->ev_k1[slot]));
         TH_HIP(hipEventElapsedTime(&out_ms[i], p->ev_k0[slot], p->ev_k1[slot]));
+    }
+    // (selector 11, A/B builds: a pipelined caller never lets the stream go idle between launches, so the launch path's check for a
+    // dropped chunk never runs there — this call has just waited for the launches it reports, check here as well: ADVICE r5)
+    if (n > 0 && p->kernel_choice == 11) {
+        TH_HIP(hipStreamSynchronize(p->ctx->stream));
+        const int src = sweep_check(p);
+        if (src != TH_OK) return src;
     }
     return TH_OK;
     TH_CATCH

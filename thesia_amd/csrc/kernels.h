@@ -9,8 +9,17 @@
 #include "../../include/thesia_amd.h"
 #include "stft_core.h"
 
+// Measured-and-dropped kernel variants: the packed-f32 pipeline (selector 9), the sweep chunk schedule (11), the
+// workgroup-per-frame Stockham kernels of n_fft 32768 / 65536 (14), the subwave plan at n_fft 8192 (15) and launch shapes other
+// than each size's defaults (waves-per-workgroup tuning) are compiled only with -DTH_AB_VARIANTS=1 (scripts/build_variant.sh
+// <tag> -DTH_AB_VARIANTS=1 ...); the product library carries the kernels a default route can reach.  th_build_ab_variants()
+// reports which build this is; th_plan_set_kernel refuses the selectors that are not in it.
+#if !defined(TH_AB_VARIANTS)
+#define TH_AB_VARIANTS 0
+#endif
 // The banded mel table of the n_fft 1024 / 2048 wave kernels in its paired layout (mel_fuse.h build_mel_band, stft_wave.h
-// mel_banded<true>): host table and device code must agree, so the switch lives here (0: plain layout, for A/B builds).
+// mel_banded<true>): host table and device code must agree, so the switch lives here (0: plain layout, for A/B builds; the
+// frame-pair epilogue reads the paired layout only and is then off: stft_wave_mel_pair_applies).
 #if !defined(TH_MEL_BAND_PAIRED)
 #define TH_MEL_BAND_PAIRED 1
 #endif

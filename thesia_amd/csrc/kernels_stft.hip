@@ -2101,7 +2101,7 @@ static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
                                  float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, const WaveOut &out, hipStream_t s) {
     // the packed-f32 pipeline (selector 9): instantiated for the headline shape only (n_fft 2048, 12 waves, hop = n_fft / 4, dB rows)
-    constexpr bool PK_SHAPE = LOG2_NC == 10 && WAVES == 12 && SHIFT == 4 && OUT == 0;
+    constexpr bool PK_SHAPE = (TH_AB_VARIANTS != 0) && LOG2_NC == 10 && WAVES == 12 && SHIFT == 4 && OUT == 0;  // (A/B builds only, kernels.h)
     const bool pkv = (TH_USE_PK != 0) || (PK_SHAPE && out.packed != 0);
     auto kern = stft_wave_kernel<LOG2_NC, WAVES, SHIFT, OUT, WaveLaunchCfg<LOG2_NC>::resident(WAVES), (TH_USE_PK != 0)>;
     if constexpr (PK_SHAPE && TH_USE_PK == 0)
@@ -2255,15 +2255,17 @@ static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const
     case WV:                                                                                                     \
         return launch_wave_t3<LOG2_NC, WV>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, \
                                                    d_queue_head, n_cu, out, s);
-    switch (waves) {
-        TH_WAVE_CASE(4)
-        TH_WAVE_CASE(6)
+    switch (waves) {  // (the default shapes: 12, n_fft 4096: 8 / 7; the others are tuning shapes of A/B builds, kernels.h)
         TH_WAVE_CASE(7)
         TH_WAVE_CASE(8)
-        TH_WAVE_CASE(10)
         TH_WAVE_CASE(12)
+#if TH_AB_VARIANTS
+        TH_WAVE_CASE(4)
+        TH_WAVE_CASE(6)
+        TH_WAVE_CASE(10)
         TH_WAVE_CASE(14)
         TH_WAVE_CASE(16)
+#endif
         default: return hipErrorInvalidValue;
     }
 #undef TH_WAVE_CASE
@@ -2329,6 +2331,8 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool bande
     return false;
 }
 bool stft_wave_mel_pair_applies(const StftGeom &g, int waves, uint32_t reach) {
+    // (mel_banded_pair and wave_mel_flush read the table's PAIRED layout: a -DTH_MEL_BAND_PAIRED=0 build keeps the one-frame epilogue — ADVICE r5)
+    if (TH_MEL_BAND_PAIRED == 0) return false;
     // (any frame loop of n_fft 1024 / 2048: plain, rotating, phased, dynamic; the default launch shape)
     if (g.log2_nc == 10) return (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES) && reach <= g.n_freq + (uint32_t)MelPair<10>::PAD;
     if (g.log2_nc == 9) return (waves <= 0 || waves == WaveLaunchCfg<9>::DEFAULT_WAVES) && reach <= g.n_freq + (uint32_t)MelPair<9>::PAD;
@@ -2344,7 +2348,7 @@ bool stft_wave_multi_mel_fits(const StftGeom &g, int waves, uint32_t words) {
 }
 
 bool stft_wave_sweep_applies(const StftGeom &g, int waves, int out_mode) {
-    return g.log2_nc == 10 && g.phased == 0 && g.hop * 4 == g.n_fft && out_mode == 0 && (TH_USE_PK == 0) &&
+    return (TH_AB_VARIANTS != 0) && g.log2_nc == 10 && g.phased == 0 && g.hop * 4 == g.n_fft && out_mode == 0 && (TH_USE_PK == 0) &&
            (waves <= 0 || waves == WaveLaunchCfg<10>::DEFAULT_WAVES);
 }
 
@@ -2384,14 +2388,18 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
         if (out.mode == 1) {  // amplitude rows, no (min, max)
             if (g.log2_nc == 12) return launch_block<12, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
             if (g.log2_nc == 13) return launch_block<13, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
+#if TH_AB_VARIANTS  // (n_fft 32768 / 65536 run stft_subwave_kernel; their block kernels are selector 14 of A/B builds)
             if (g.log2_nc == 14) return launch_block<14, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
             if (g.log2_nc == 15) return launch_block_planar<15, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
+#endif
             return hipErrorInvalidValue;
         }
         if (g.log2_nc == 12) return launch_block<12, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
         if (g.log2_nc == 13) return launch_block<13, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+#if TH_AB_VARIANTS
         if (g.log2_nc == 14) return launch_block<14, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
         if (g.log2_nc == 15) return launch_block_planar<15, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+#endif
         return hipErrorInvalidValue;
     }
     switch (g.log2_nc) {

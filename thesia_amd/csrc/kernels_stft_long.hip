@@ -764,7 +764,11 @@ hipError_t launch_stft_subwave(const StftGeom &g, const ChanJob *d_jobs, const u
     switch (g.log2_nc) {
         case 14: return launch_subwave_r<4>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax, amp, n_cu, s);
         case 13: return launch_subwave_r<3>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax, amp, n_cu, s);
+#if TH_AB_VARIANTS  // (n_fft 8192 runs the block kernel: four waves between two barriers are too few; selector 15 of A/B builds, kernels.h)
         default: return launch_subwave_r<2>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_twc, d_minmax, amp, n_cu, s);
+#else
+        default: return hipErrorInvalidValue;
+#endif
     }
 }
 

@@ -722,8 +722,8 @@ TH_API int th_tm_set_setting(th_tm *tm, double win_ms, uint32_t t_overlap, uint3
     TH_HIP(hipSetDevice(tm->ctx->device));
     // Transactional: plans and specs of the NEW setting are made first, into fresh buffers; the manager's own state
     // changes only when all of it exists.  (The reference cannot fail here: realfft takes any even length.  This
-    // library's plans need n_fft = a power of two in [2, TH_MAX_N_FFT]; e.g. f_overlap = 3 is refused and leaves everything
-    // as it was.)
+    // library plans n_fft = 2^a * odd with a >= 1 and odd <= 63, up to TH_MAX_N_FFT (th_plan_create): f_overlap = 3, 5, 6, 7 run
+    // on the generic kernel; e.g. f_overlap = 67 or an n_fft above 2^20 is refused and leaves everything as it was.)
     const Setting st{win_ms, t_overlap, f_overlap, freq_scale};
     std::vector<std::pair<uint32_t, Channel *>> chans;
     for (auto &kv : tm->tracks)
