@@ -24,14 +24,14 @@
  * 14 = the workgroup-per-frame Stockham kernel where stft_subwave_kernel is the default (n_fft 16384 at hops other than n_fft / 4),
  * 15 = stft_subwave_kernel (R 1024-point wave transforms + a combining pass) at n_fft 16384 also at hop n_fft / 4 (A/B);
  * 10 is reserved and behaves as 2;
- * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with `waves` waves per workgroup (7, 8 or 12 — each size's default
- * shapes; the multi-frame plans 8, 12, 16) and `chunk` frames per queue pull.
+ * tuning: (chunk << 16) | (waves << 8) | 2 runs the wave kernel with `waves` waves per workgroup (each size's own shapes: n_fft
+ * 1024 / 2048: 12; n_fft 4096: 8 or 7; the multi-frame plans 8, 12, 16) and `chunk` frames per queue pull.
  * Only in libraries built with -DTH_AB_VARIANTS=1 (th_build_ab_variants() == 1; scripts/build_variant.sh), TH_ERR_UNSUPPORTED
  * otherwise — measured, dropped, and no longer part of the product binary (HISTORY.md has the numbers):
  * 9 = the wave kernel's packed-f32 pipeline (v_pk_fma_f32 butterflies on register pairs; n_fft 2048, hop = n_fft / 4, linear dB),
  * 11 = the "sweep" chunk schedule (4-frame chunks dealt out in order through a per-workgroup ticket counter) on large batches of
- * that shape, 14 at n_fft 32768 / 65536 (stft_block_kernel / its planar form), 15 at n_fft 8192, and 4, 6, 10, 14 or 16 waves per
- * workgroup for the one-frame wave kernels */
+ * that shape, 14 at n_fft 32768 / 65536 (stft_block_kernel / its planar form), 15 at n_fft 8192, and every other waves-per-workgroup
+ * shape of the one-frame wave kernels (4 .. 16) */
 TH_API int th_plan_set_kernel(th_plan *plan, int which);
 
 /* 1 when the library carries the A/B variants above (-DTH_AB_VARIANTS=1), 0 for the product build */

@@ -78,7 +78,7 @@ int main(int argc, char **argv) {
                 std::memcpy(prm, &h.words[off + 4 * l + 1], 12);
                 std::memcpy(w1, &h.words[off + 256 + 2 * l], 8);
                 s[l] = (nw & MEL_MOM_FORM_W) ? mel_mom_w_lane(amp.data(), h.words[off + 4 * l], n, prm[0], prm[1], w1[0], w1[1])
-                                             : mel_mom_lane(l, amp.data(), h.words[off + 4 * l], prm[0], prm[1], masks, n);
+                                             : mel_mom_lane_any(l, amp.data(), h.words[off + 4 * l], prm[0], prm[1], masks, n);
             }
             for (uint32_t l = 0; l < 64; l++) {
                 float inv_d;

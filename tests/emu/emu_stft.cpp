@@ -489,7 +489,7 @@ extern "C" __attribute__((visibility("default"))) int emu_mel_moments(const floa
             std::memcpy(prm, &h.words[off + 4 * l + 1], 12);
             std::memcpy(w1, &h.words[off + 256 + 2 * l], 8);
             s[l] = wform ? mel_mom_w_lane(amp_slab, h.words[off + 4 * l], n, prm[0], prm[1], w1[0], w1[1])
-                         : mel_mom_lane(l, amp_slab, h.words[off + 4 * l], prm[0], prm[1], masks, n);
+                         : mel_mom_lane_any(l, amp_slab, h.words[off + 4 * l], prm[0], prm[1], masks, n);
         }
         for (uint32_t l = 0; l < 64; l++) {
             float inv_d;

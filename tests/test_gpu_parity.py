@@ -188,7 +188,10 @@ def test_subwave_plan(ctx, sr, win, hop, n_fft, scale, n_mel):
 
 
 @pytest.mark.parametrize("sr,win_ms,t_overlap,f_overlap,scale", [(48000, 40.0, 4, 3, 0), (48000, 40.0, 4, 5, 1), (16000, 8.0, 2, 6, 0),
-                                                                  (8000, 2.0, 4, 7, 1), (48000, 170.0, 4, 3, 0), (48000, 0.05, 1, 3, 0)])
+                                                                  (8000, 2.0, 4, 7, 1), (48000, 170.0, 4, 3, 0), (48000, 0.05, 1, 3, 0),
+                                                                  # n_fft = 2 * odd: Nc is odd — no radix-2 / radix-4 pass at all,
+                                                                  # the odd pass alone with Ns = 1, then the split pass: n_fft 6 and 10
+                                                                  (4000, 0.5, 1, 3, 0), (4000, 0.5, 2, 5, 0), (4000, 0.5, 1, 7, 1)])
 def test_f_overlap_that_is_not_a_power_of_two(ctx, sr, win_ms, t_overlap, f_overlap, scale):
     """SpecSetting::calc_framing_params (spectrogram.rs:66-72): n_fft = next_pow2(win) * f_overlap for ANY integer f_overlap, and
     the reference's realfft plans any length.  No UI control offers f_overlap 3, 5, 6, 7 — the API accepts them: the generic
@@ -1249,10 +1252,11 @@ def test_set_kernel_rejects_launch_shapes_that_do_not_exist(ctx):
     if ta.ab_variants():
         plan.set_kernel(2 | (10 << 8))  # (A/B builds) the one-frame plan of n_fft 1024 has this shape ...
     else:
-        with pytest.raises(ta.ThError) as e:   # the product build keeps each size's default shapes: 7, 8, 12
-            plan.set_kernel(2 | (10 << 8))
-        assert e.value.code == -2 and "TH_AB_VARIANTS" in str(e.value)
-        for wv in (8, 12):
+        for wv in (10, 8):
+            with pytest.raises(ta.ThError) as e:   # the product build keeps each size's own shapes (n_fft 1024: 12 waves)
+                plan.set_kernel(2 | (wv << 8))
+            assert e.value.code == -2 and "TH_AB_VARIANTS" in str(e.value)
+        for wv in (12, 0):
             plan.set_kernel(2 | (wv << 8))
             assert_spec_close(plan.calc_spec(synth_track(81, 48000, 30000))[0], orc.calc_spec(synth_track(81, 48000, 30000), 1024, 256, 1024))
     with pytest.raises(ta.ThError):

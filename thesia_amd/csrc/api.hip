@@ -744,8 +744,8 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
         else if (k == 11) what = "selector 11 (sweep chunk schedule)";
         else if (k == 14 && p->g.log2_nc >= 14) what = "selector 14 at n_fft 32768 / 65536 (workgroup-per-frame Stockham kernels)";
         else if (k == 15 && p->g.log2_nc == 12) what = "selector 15 at n_fft 8192 (stft_subwave_kernel with four waves)";
-        else if (!multi && p->g.log2_nc >= 9 && p->g.log2_nc <= 11 && !(wv == 0 || wv == 7 || wv == 8 || wv == 12))
-            what = "a waves-per-workgroup shape other than 7, 8 or 12";
+        else if (!multi && p->g.log2_nc >= 9 && p->g.log2_nc <= 11 && wv != 0 && !(p->g.log2_nc == 11 ? (wv == 7 || wv == 8) : wv == 12))
+            what = "a waves-per-workgroup shape other than the size's own (n_fft 1024 / 2048: 12; n_fft 4096: 8 or 7)";
         if (what) return fail(TH_ERR_UNSUPPORTED, "%s is an A/B variant: build with -DTH_AB_VARIANTS=1 (scripts/build_variant.sh)", what);
     }
     p->kernel_choice = k;

@@ -2255,19 +2255,31 @@ static hipError_t launch_wave_t2(const StftGeom &g, const ChanJob *d_jobs, const
     case WV:                                                                                                     \
         return launch_wave_t3<LOG2_NC, WV>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, \
                                                    d_queue_head, n_cu, out, s);
-    switch (waves) {  // (the default shapes: 12, n_fft 4096: 8 / 7; the others are tuning shapes of A/B builds, kernels.h)
-        TH_WAVE_CASE(7)
-        TH_WAVE_CASE(8)
-        TH_WAVE_CASE(12)
 #if TH_AB_VARIANTS
+    switch (waves) {
         TH_WAVE_CASE(4)
         TH_WAVE_CASE(6)
+        TH_WAVE_CASE(7)
+        TH_WAVE_CASE(8)
         TH_WAVE_CASE(10)
+        TH_WAVE_CASE(12)
         TH_WAVE_CASE(14)
         TH_WAVE_CASE(16)
-#endif
         default: return hipErrorInvalidValue;
     }
+#else
+    // the product build: each size's own launch shapes only (n_fft 1024 / 2048: 12 waves; n_fft 4096: 8, and 7 for the grid-aligned
+    // mode with two window tables) — the other wave counts are tuning shapes of A/B builds (kernels.h)
+    switch (waves) {
+        case WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES:
+            return launch_wave_t3<LOG2_NC, WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
+        default:
+            if constexpr (WaveLaunchCfg<LOG2_NC>::GRID_WAVES != WaveLaunchCfg<LOG2_NC>::DEFAULT_WAVES)
+                if (waves == WaveLaunchCfg<LOG2_NC>::GRID_WAVES)
+                    return launch_wave_t3<LOG2_NC, WaveLaunchCfg<LOG2_NC>::GRID_WAVES>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, out, s);
+            return hipErrorInvalidValue;
+    }
+#endif
 #undef TH_WAVE_CASE
 }
 

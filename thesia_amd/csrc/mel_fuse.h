@@ -360,7 +360,7 @@ inline MelBandHost build_mel_band(const float *fb, uint32_t n_freq, uint32_t n_m
 //
 // Words: [0] = G, [1] = sum of the groups' taps; group g: [16 + 2 g] = taps n_g | form << 16 (M: n_g a multiple of
 // MEL_MOM_UNROLL, zero masks on top; W: 1 or 2), [17 + 2 g] = word offset of its block (16-byte aligned); the header is padded to
-// whole batches of 8 groups with (0, 0).  M block: 64 x {first
+// whole batches of MEL_MOM_BATCH groups with (0, 0).  M block: 64 x {first
 // bin, alpha, beta', 1 / d} in lane order, then n_g masks (2 words each, tap t at 2 t).  W block: 64 x {first bin, u0, v0, 1 / d},
 // then 64 x {u1, v1}.  Lane l of group g = segment 64 g + l; mel m = 64 g + l takes F from the next lane (the next group's lane 0
 // across the group border: the kernel walks the groups downwards and carries it).
@@ -505,7 +505,7 @@ inline MelMomHost build_mel_moments(const float *fb, const float *lin, const flo
         t[MEL_MOM_HDR0 + 2 * g] = n_pad;
         out.taps += n_pad;
         out.max_taps = std::max(out.max_taps, n_pad);
-        t.resize(off + 256 + 2 * (size_t)n_pad, 0);
+        t.resize(off + 256 + std::max<size_t>(2 * (size_t)n_pad, 128), 0);  // (the kernel's batch fetch reads 128 words behind every block's per-lane words)
         for (uint32_t l = 0; l < 64; l++) {
             const uint32_t j = s0 + l;
             float prm[4] = {0.f, 0.f, 0.f, 0.f};
@@ -538,6 +538,7 @@ inline MelMomHost build_mel_moments(const float *fb, const float *lin, const flo
             std::memcpy(&t[off + 4 * l + 1], &prm[1], 12);
         }
     }
+    t.resize(t.size() + 384, 0);  // (padding groups fetch "block" 0, the header: 256 + 128 words must exist behind word 0 in every table)
     t[1] = out.taps;
     out.n_groups = G;
     // (a filterbank whose segments are not lines in the bin index, or whose wide groups hold a filter with next to no weight: not this form)

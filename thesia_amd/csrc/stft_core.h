@@ -33,8 +33,8 @@
 namespace th {
 
 // moment-form mel tables (build_mel_moments, mel_fuse.h <-> mel_moments_global, stft_wave.h): the group headers start at word 16
-// (64-byte aligned) and are padded to whole batches of 8 groups — the kernel takes a batch's header as one s_load_dwordx16
-constexpr uint32_t MEL_MOM_HDR0 = 16, MEL_MOM_BATCH = 8;
+// (64-byte aligned) and are padded to whole batches of 4 groups — the kernel takes a batch's header as one s_load_dwordx8
+constexpr uint32_t MEL_MOM_HDR0 = 16, MEL_MOM_BATCH = 4;
 
 struct __attribute__((aligned(8))) cf32 {
     float re, im;

@@ -1629,10 +1629,8 @@ struct MelMomLane {
 // stale exchange data, NaN — never enters a sum)
 TH_HD float mel_mom_sel(float a, uint64_t mask, uint32_t lane) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    float r;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(mask));  // (the mask straight from its SGPR pair: a scalar load's result)
     (void)lane;
-    return r;
+    return __builtin_amdgcn_inverse_ballot_w64(mask) ? a : 0.0f;  // v_cndmask_b32 with the mask's SGPR pair (a scalar load's result) as its condition
 #else
     return ((mask >> lane) & 1u) ? a : 0.0f;
 #endif
@@ -1685,6 +1683,44 @@ TH_HD MelMomLane mel_mom_lane(uint32_t lane, const float *amp, uint32_t first, f
     const float R = fma_rn(alpha, S1, beta * P);
     return {R, P - R};
 }
+// The same sums for a group of exactly 4 K taps as straight-line code (the kernel dispatches on the group's trip count): all
+// amplitude reads up front, no loop registers to rotate, tap offsets as immediates.  Same additions in the same order as
+// mel_mom_lane: bit-identical.
+template <int K, class MaskPtr>
+TH_HD MelMomLane mel_mom_lane_k(uint32_t lane, const float *amp, uint32_t first, float alpha, float beta, MaskPtr masks) {
+    const float *ap = amp + first;
+    float a[4 * K];
+    TH_UNROLL for (int i = 4 * K - 1; i >= 0; i--) a[i] = lds_ldf(ap + i);
+    float P = 0.0f, S1 = 0.0f;
+    TH_UNROLL for (int c = K - 1; c >= 0; c--) {
+        const MelMomMasks4 m = mel_mom_masks4(masks, 4u * (uint32_t)c);
+        P += mel_mom_sel(a[4 * c + 3], m.m3, lane);
+        S1 += P;
+        P += mel_mom_sel(a[4 * c + 2], m.m2, lane);
+        S1 += P;
+        P += mel_mom_sel(a[4 * c + 1], m.m1, lane);
+        S1 += P;
+        P += mel_mom_sel(a[4 * c], m.m0, lane);
+        S1 += P;
+    }
+    const float R = fma_rn(alpha, S1, beta * P);
+    return {R, P - R};
+}
+// dispatch on the trip count (wave-uniform): straight-line code up to 32 taps, the loop beyond
+template <class MaskPtr>
+TH_HD MelMomLane mel_mom_lane_any(uint32_t lane, const float *amp, uint32_t first, float alpha, float beta, MaskPtr masks, uint32_t n) {
+    switch (n >> 2) {
+        case 1: return mel_mom_lane_k<1>(lane, amp, first, alpha, beta, masks);
+        case 2: return mel_mom_lane_k<2>(lane, amp, first, alpha, beta, masks);
+        case 3: return mel_mom_lane_k<3>(lane, amp, first, alpha, beta, masks);
+        case 4: return mel_mom_lane_k<4>(lane, amp, first, alpha, beta, masks);
+        case 5: return mel_mom_lane_k<5>(lane, amp, first, alpha, beta, masks);
+        case 6: return mel_mom_lane_k<6>(lane, amp, first, alpha, beta, masks);
+        case 7: return mel_mom_lane_k<7>(lane, amp, first, alpha, beta, masks);
+        case 8: return mel_mom_lane_k<8>(lane, amp, first, alpha, beta, masks);
+        default: return mel_mom_lane(lane, amp, first, alpha, beta, masks, n);
+    }
+}
 // W form (groups whose segments hold one or two bins): the (u, 1 - u) pairs themselves, exact products
 TH_HD MelMomLane mel_mom_w_lane(const float *amp, uint32_t first, uint32_t n, float u0, float v0, float u1, float v1) {
     const float a0 = lds_ldf(amp + first);
@@ -1705,46 +1741,62 @@ TH_HD float mel_mom_combine(float inv_d, float R, float F_next) {
 #if defined(__HIPCC__)  // (both passes of hipcc; not the CPU lane emulator, which drives the lane functions itself)
 // The whole epilogue of one frame: groups from the top down (mel m needs F of segment m + 1: the next lane, or across the
 // group border lane 0 of the group above — carried in a scalar), in BATCHES of MEL_MOM_BATCH groups: a batch's header words are
-// one scalar load and its per-lane words are requested together, so a frame pays the global-memory latency once per batch and
-// not once per group (a group's own work is a few dozen instructions: requested one group ahead, every group waited for its words
-// — 0.63 us per group, scripts/ubench/mom_probe.hip).  The table's group header is padded to whole batches (taps 0: skipped).
+// one scalar load and its per-lane words are requested together — and a batch AHEAD of their use, i.e. before the rows of the
+// batch in front of it are stored: vmcnt counts loads and stores in one order, so per-lane words requested behind a row store
+// would wait for that store's round trip (two batches of 8 groups, each fetched when its turn came: 695 mels 0.88 ms against
+// 0.78 for the group-ahead fetch this replaces; one group's own work is only a few dozen instructions — scripts/ubench/mom_probe.hip).
+// The table's group header is padded to whole batches (taps 0: skipped).
 template <class Emit>
 __device__ __forceinline__ void mel_moments_global(uint32_t lane, const float *amp, gptr<const uint32_t> tab, uint32_t n_groups, Emit emit) {
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
-    typedef uint32_t u32x16v __attribute__((ext_vector_type(16)));
+    typedef uint32_t u32x8v __attribute__((ext_vector_type(8)));
     // the header words and the masks through the CONSTANT address space: the table is not written while the kernel runs, and
     // wave-uniform loads from there are scalar loads (the rows this kernel stores keep the compiler from proving that of a
     // global pointer)
     typedef const __attribute__((address_space(4))) uint64_t *cptr64;
-    typedef const __attribute__((address_space(4))) u32x16v *cptr16v;
+    typedef const __attribute__((address_space(4))) u32x8v *cptr8v;
     constexpr uint32_t GB = MEL_MOM_BATCH;
-    float carry = 0.0f;
-    for (uint32_t gb = (n_groups + GB - 1u) / GB * GB; gb != 0; gb -= GB) {  // groups gb - 1 .. gb - GB
-        const uint32_t g0 = gb - GB;
-        const u32x16v hv = *(cptr16v)(uintptr_t)(tab + MEL_MOM_HDR0 + 2u * g0);
-        // (scalar copies: vector elements are not indexed dynamically, and __builtin_bit_cast on a vector-element lvalue reads element 0)
-        const uint32_t nw[GB] = {hv.s0, hv.s2, hv.s4, hv.s6, hv.s8, hv.sa, hv.sc, hv.se};
-        const uint32_t off[GB] = {hv.s1, hv.s3, hv.s5, hv.s7, hv.s9, hv.sb, hv.sd, hv.sf};
+    static_assert(GB == 4, "a batch's header is one s_load_dwordx8");
+    struct Batch {
+        uint32_t nw[GB], off[GB];
         u32x4v prm[GB];
         u32x2v w1[GB];
+    };
+    const uint32_t lane16 = lane << 4, lane8 = lane << 3;
+    auto fetch = [&](Batch &bt, uint32_t g0) {
+        const u32x8v hv = *(cptr8v)(uintptr_t)(tab + MEL_MOM_HDR0 + 2u * g0);
+        // (scalar copies: vector elements are not indexed dynamically, and __builtin_bit_cast on a vector-element lvalue reads element 0)
+        const uint32_t nw[GB] = {hv.s0, hv.s2, hv.s4, hv.s6}, off[GB] = {hv.s1, hv.s3, hv.s5, hv.s7};
         TH_UNROLL for (uint32_t j = 0; j < GB; j++) {
-            prm[j] = *reinterpret_cast<gptr<const u32x4v>>(tab + off[j] + 4u * lane);  // (padding groups: offset 0, the header itself)
-            w1[j] = u32x2v{0u, 0u};
-            if ((nw[j] & 0x1ffffu) == 0x10002u) w1[j] = *reinterpret_cast<gptr<const u32x2v>>(tab + off[j] + 256u + 2u * lane);  // W form, two bins
+            bt.nw[j] = nw[j];
+            bt.off[j] = off[j];
+            // address = block (scalar: table + offset) + zext(lane's byte offset): global_load's saddr + voffset form, no 64-bit vector adds
+            const gptr<const char> blk = reinterpret_cast<gptr<const char>>(tab) + ((uint64_t)off[j] << 2);
+            bt.prm[j] = *reinterpret_cast<gptr<const u32x4v>>(blk + (uint64_t)lane16);  // (padding groups: offset 0, the header itself)
+            bt.w1[j] = *reinterpret_cast<gptr<const u32x2v>>(blk + 1024 + (uint64_t)lane8);  // (W form: the second pair; M form: two mask words, unused)
         }
+    };
+    float carry = 0.0f;
+    const uint32_t top = (n_groups + GB - 1u) / GB * GB;
+    Batch nxt;
+    fetch(nxt, top - GB);
+    for (uint32_t gb = top; gb != 0; gb -= GB) {  // groups gb - 1 .. gb - GB
+        const uint32_t g0 = gb - GB;
+        const Batch cur = nxt;
+        if (g0 != 0) fetch(nxt, g0 - GB);  // wave-uniform
         TH_UNROLL for (uint32_t jj = GB; jj-- != 0;) {
-            const uint32_t n = nw[jj] & 0xffffu;
+            const uint32_t n = cur.nw[jj] & 0xffffu;
             if (n != 0) {  // wave-uniform (0: padding behind the last group)
-                const uint32_t first = prm[jj].x, w_y = prm[jj].y, w_z = prm[jj].z, w_w = prm[jj].w;
+                const uint32_t first = cur.prm[jj].x, w_y = cur.prm[jj].y, w_z = cur.prm[jj].z, w_w = cur.prm[jj].w;
                 MelMomLane s;
-                if (nw[jj] & 0x10000u) {  // W form
-                    const uint32_t u1 = w1[jj].x, v1 = w1[jj].y;
+                if (cur.nw[jj] & 0x10000u) {  // W form
+                    const uint32_t u1 = cur.w1[jj].x, v1 = cur.w1[jj].y;
                     s = mel_mom_w_lane(amp, first, n, __builtin_bit_cast(float, w_y), __builtin_bit_cast(float, w_z), __builtin_bit_cast(float, u1),
                                        __builtin_bit_cast(float, v1));
                 } else {
-                    const cptr64 masks = (cptr64)(uintptr_t)(tab + off[jj] + 256u);
-                    s = mel_mom_lane(lane, amp, first, __builtin_bit_cast(float, w_y), __builtin_bit_cast(float, w_z), masks, n);
+                    const cptr64 masks = (cptr64)(uintptr_t)(tab + cur.off[jj] + 256u);
+                    s = mel_mom_lane_any(lane, amp, first, __builtin_bit_cast(float, w_y), __builtin_bit_cast(float, w_z), masks, n);
                 }
                 // F of the next lane; lane 63 takes the group above's lane 0
                 const float fn_in = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(4u * ((lane + 1u) & 63u)), __builtin_bit_cast(int, s.F)));
