@@ -14,9 +14,13 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
+#include <chrono>
+#include <list>
 #include <map>
 #include <memory>
 #include <set>
+#include <thread>
+#include <atomic>
 #include <shared_mutex>
 #include <tuple>
 #include <vector>
@@ -67,7 +71,15 @@ constexpr size_t TILE_BYTES_MAX = 520 * 520 * 4;  // 512 core + 2 x 4 gutter (re
 constexpr size_t MAX_READER_SLOTS = 16;
 
 // Lanczos tap table of one image axis at one LOD level, resident on the device (shared by every channel of that size)
+// a device allocation shared by the tap tables that were made together (freed when the last of them goes)
+struct DevBlock {
+    void *p = nullptr;
+    ~DevBlock() {
+        if (p) (void)hipFree(p);
+    }
+};
 struct AxisTable {
+    std::shared_ptr<DevBlock> owner;  // d_blob points into it
     void *d_blob = nullptr;
     uint32_t n_out = 0, max_taps = 0;
     uint32_t span[3] = {0, 0, 0};  // LodAxis::span
@@ -77,6 +89,9 @@ struct AxisTable {
 struct Track {
     uint32_t sr = 0;
     std::vector<Channel> ch;
+    // ONE device allocation for the samples and waveform pyramids of all channels (round 6: two hipMalloc per channel were 0.7 ms
+    // of a 32-track add); Channel::d_wav / d_pyr are views into it and live exactly as long as the track
+    void *d_pool = nullptr;
 };
 
 using PlanKey = std::tuple<uint32_t, size_t, size_t, size_t, int>;  // sr, win, hop, n_fft, scale
@@ -113,6 +128,17 @@ struct th_tm {
     std::map<std::pair<uint32_t, uint32_t>, AxisTable> axis_tabs;  // (source length, level) -> taps
     th::DeviceTable mip_jobs;                                       // job table of the batched mip-pyramid passes
     th::DeviceTable mip_scratch;                                    // transposed images of one chunk of the batch
+    std::list<std::vector<unsigned char>> axis_staging;             // host copies of tap tables whose upload may still be in flight (cleared by writer_done)
+    hipStream_t copy_stream = nullptr;                              // th_tm_add_tracks: uploads of group g + 1 beside the kernels of group g
+    hipEvent_t copy_ev = nullptr;
+    // update_spec_imgs records img_ev behind the quantiser and mips_ev behind the last pass of the mip pyramids.  The two
+    // interactive mutators (apply_track_list_changes, set_dB_range) return when the IMAGES are made and leave the pyramids — an
+    // acceleration structure of this library for LOD > 0 tiles, 2.7 of the 4 ms of a 32-track update; the reference has none —
+    // building on the context stream: a tile reader that crops a mip level makes its own stream wait for mips_ev (on the
+    // device, not on the host), level-0 tiles do not wait at all, and everything else that touches images or levels runs on
+    // the context stream, i.e. behind the build anyway.
+    hipEvent_t img_ev = nullptr, mips_ev = nullptr;
+    bool img_ev_recorded = false;
     uint64_t stat_tiles_served = 0;
     // th_tm_get_spectrogram_tiles: pinned staging for callers whose buffer the GPU cannot write directly (one batch at a time)
     std::mutex batch_mu;
@@ -141,13 +167,18 @@ void free_mips(Channel &c) {
     c.mips.clear();
 }
 
-void free_channel(Channel &c) {
-    if (c.d_wav) (void)hipFree(c.d_wav);
-    if (c.d_pyr) (void)hipFree(c.d_pyr);
+void free_channel(Channel &c) {  // (d_wav / d_pyr belong to the track's pool: free_track)
     if (c.d_spec) (void)hipFree(c.d_spec);
     if (c.d_img) (void)hipFree(c.d_img);
     free_mips(c);
     c = Channel();
+}
+
+void free_track(Track &t) {
+    for (Channel &ch : t.ch) free_channel(ch);
+    t.ch.clear();
+    if (t.d_pool) (void)hipFree(t.d_pool);
+    t.d_pool = nullptr;
 }
 
 struct Setting {
@@ -215,8 +246,34 @@ void free_new_specs(std::vector<NewSpec> &v) {
 // TrackManager::update_specs — core/mod.rs:137-164: one batched launch per plan, INTO FRESH BUFFERS.  Nothing the
 // manager owns is touched: the caller attaches the results (commit_specs) once every launch has succeeded, so a
 // failure (unsupported n_fft, out of memory) leaves settings, specs and has_spec exactly as they were.
+// pending != NULL: the per-channel (min, max) pairs stay on the device (entries appended to *pending) and NOTHING here waits for
+// the launches — the caller synchronises once and calls finish_specs (th_tm_add_tracks launches group after group this way,
+// beside the next group's upload)
+struct PendingMinMax {
+    float *d_mm = nullptr;
+    size_t first = 0, count = 0;
+};
+int finish_specs(th_tm *tm, std::vector<PendingMinMax> &pending, std::vector<NewSpec> *out, bool read) {
+    int rc = TH_OK;
+    for (PendingMinMax &pm : pending) {
+        if (read && rc == TH_OK) {
+            std::vector<float> mm(2 * pm.count);
+            const hipError_t e = hipMemcpy(mm.data(), pm.d_mm, mm.size() * sizeof(float), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = th::fail(TH_ERR_HIP, "%s", hipGetErrorString(e));
+            else
+                for (size_t i = 0; i < pm.count; i++) {
+                    (*out)[pm.first + i].mn = mm[2 * i];
+                    (*out)[pm.first + i].mx = mm[2 * i + 1];
+                }
+        }
+        (void)hipFree(pm.d_mm);
+    }
+    pending.clear();
+    (void)tm;
+    return rc;
+}
 int compute_specs(th_tm *tm, const Setting &st, const std::vector<std::pair<uint32_t, Channel *>> &chans,
-                  std::map<PlanKey, th_plan *> &created, std::vector<NewSpec> *out) {
+                  std::map<PlanKey, th_plan *> &created, std::vector<NewSpec> *out, std::vector<PendingMinMax> *pending = nullptr) {
     th_ctx *c = tm->ctx;
     std::map<th_plan *, std::vector<Channel *>> groups;
     for (auto &sc : chans) {
@@ -242,6 +299,12 @@ int compute_specs(th_tm *tm, const Setting &st, const std::vector<std::pair<uint
         }
         float *d_mm = nullptr;
         TH_HIP(hipMalloc((void **)&d_mm, 2 * chs.size() * sizeof(float)));
+        if (pending != nullptr) {
+            pending->push_back(PendingMinMax{d_mm, first, chs.size()});  // (recorded before the launch: the caller frees it on any outcome)
+            const int prc = th_calc_spec_batch_dev(p, descs.data(), descs.size(), d_mm);
+            if (prc != TH_OK) return prc;
+            continue;
+        }
         int rc = th_calc_spec_batch_dev(p, descs.data(), descs.size(), d_mm);
         std::vector<float> mm(2 * chs.size());
         hipError_t e = hipSuccess;
@@ -282,38 +345,100 @@ void commit_specs(std::vector<NewSpec> &v) {
 constexpr uint32_t MIP_MAX_LX = 12, MIP_MAX_LY = 3, MIP_MIN_DIM = 16;
 constexpr uint32_t PYR_FIRST = 2;  // first materialised level of the resident waveform pyramids (levels 0, 1: from the samples)
 
+// The host half of a tap table: Lanczos3 taps of the whole axis as the crop box (origin 0, extent n_in:
+// resize_spectrogram_tile with the full image as the crop), packed as LodAxis reads it, + the span of R = 8, 4, 2 outputs
+struct AxisHostTable {
+    std::vector<unsigned char> blob;
+    uint32_t n_out = 0, max_taps = 0, span[3] = {0, 0, 0};
+};
+void build_axis_host(uint32_t n_in, uint32_t level, AxisHostTable &h) {
+    const size_t n_out = (n_in + ((size_t)1 << level) - 1) >> level;
+    LodAxisHost ax;
+    build_lod_axis(0.0, (double)n_in, n_out, 0, (long)n_in, ax);
+    h.blob.resize(ax.blob_bytes(n_out));
+    ax.pack(h.blob.data(), n_out);
+    h.n_out = (uint32_t)n_out;
+    h.max_taps = ax.max_taps;
+    for (int k = 0; k < 3; k++) {  // source rows under the tap windows of R = 8, 4, 2 consecutive outputs
+        const size_t r = (size_t)8 >> k;
+        int64_t span = 0;
+        for (size_t o0 = 0; o0 < n_out; o0 += r) {
+            int64_t hi = 0;
+            for (size_t o = o0; o < std::min(n_out, o0 + r); o++) hi = std::max<int64_t>(hi, (int64_t)ax.start[o] + ax.count[o]);
+            span = std::max(span, hi - (int64_t)ax.start[o0]);
+        }
+        h.span[k] = (uint32_t)span;
+    }
+}
+
+// Make every tap table in `keys` that is not resident yet: the host halves side by side on a few threads (a table is ~6 taps per
+// SOURCE element whatever the level — 17 k sinc evaluations for a 30 s track's x axis — and a batch of tracks needs a dozen
+// levels per distinct length: 2.1 of the 3.7 ms an apply_track_list_changes took for 32 equal tracks, and proportionally more
+// for tracks of different lengths), then the uploads, stream-ordered in front of the passes that read them.  The blobs stay
+// alive in tm->axis_staging until the writer's final synchronisation (writer_done): nothing waits per table.
+int make_axis_tables(th_tm *tm, const std::set<std::pair<uint32_t, uint32_t>> &keys) {
+    std::vector<std::pair<uint32_t, uint32_t>> todo;
+    for (auto &k : keys)
+        if (!tm->axis_tabs.count(k)) todo.push_back(k);
+    if (todo.empty()) return TH_OK;
+    std::vector<AxisHostTable> host(todo.size());
+    {
+        const size_t n_thr = std::min<size_t>(todo.size(), std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+        std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};
+        auto work = [&]() {
+            try {
+                for (size_t i = next.fetch_add(1); i < todo.size(); i = next.fetch_add(1)) build_axis_host(todo[i].first, todo[i].second, host[i]);
+            } catch (...) {
+                failed = true;
+            }
+        };
+        std::vector<std::thread> thr;
+        try {
+            for (size_t i = 1; i < n_thr; i++) thr.emplace_back(work);
+        } catch (...) {  // (no more threads: the ones that started and this one do all of it)
+        }
+        work();
+        for (auto &t : thr) t.join();
+        if (failed) return th::fail(TH_ERR_OOM, "host allocation failed while building LOD tap tables");
+    }
+    // ONE allocation and ONE upload for the tables of this call (fifteen small pageable copies were 0.3 ms of host time)
+    std::vector<size_t> at(todo.size());
+    size_t total = 0;
+    for (size_t i = 0; i < todo.size(); i++) {
+        at[i] = total;
+        total += (host[i].blob.size() + 255) / 256 * 256;
+    }
+    tm->axis_staging.emplace_back(total);
+    std::vector<unsigned char> &stage = tm->axis_staging.back();
+    for (size_t i = 0; i < todo.size(); i++) std::memcpy(stage.data() + at[i], host[i].blob.data(), host[i].blob.size());
+    std::shared_ptr<DevBlock> blk = std::make_shared<DevBlock>();
+    TH_HIP(hipMalloc(&blk->p, total));
+    const hipError_t e = hipMemcpyAsync(blk->p, stage.data(), total, hipMemcpyHostToDevice, tm->ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(tm->ctx->stream);
+        TH_HIP(e);
+    }
+    for (size_t i = 0; i < todo.size(); i++) {
+        AxisTable t;
+        t.owner = blk;
+        t.d_blob = static_cast<unsigned char *>(blk->p) + at[i];
+        t.n_out = host[i].n_out;
+        t.max_taps = host[i].max_taps;
+        t.bytes = host[i].blob.size();
+        for (int k = 0; k < 3; k++) t.span[k] = host[i].span[k];
+        tm->axis_tabs.emplace(todo[i], t);
+    }
+    return TH_OK;
+}
+
 int axis_table(th_tm *tm, uint32_t n_in, uint32_t level, AxisTable **out) {
     const auto key = std::make_pair(n_in, level);
     auto it = tm->axis_tabs.find(key);
     if (it == tm->axis_tabs.end()) {
-        const size_t n_out = (n_in + ((size_t)1 << level) - 1) >> level;
-        LodAxisHost ax;
-        // the whole axis as the crop box: origin 0, extent n_in (resize_spectrogram_tile with the full image as the crop)
-        build_lod_axis(0.0, (double)n_in, n_out, 0, (long)n_in, ax);
-        std::vector<unsigned char> blob(ax.blob_bytes(n_out));
-        ax.pack(blob.data(), n_out);
-        AxisTable t;
-        TH_HIP(hipMalloc(&t.d_blob, blob.size()));
-        hipError_t e = hipMemcpyAsync(t.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, tm->ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(tm->ctx->stream);  // blob is a local
-        if (e != hipSuccess) {
-            (void)hipFree(t.d_blob);
-            TH_HIP(e);
-        }
-        t.n_out = (uint32_t)n_out;
-        t.max_taps = ax.max_taps;
-        t.bytes = blob.size();
-        for (int k = 0; k < 3; k++) {  // source rows under the tap windows of R = 8, 4, 2 consecutive outputs
-            const size_t r = (size_t)8 >> k;
-            int64_t span = 0;
-            for (size_t o0 = 0; o0 < n_out; o0 += r) {
-                int64_t hi = 0;
-                for (size_t o = o0; o < std::min(n_out, o0 + r); o++) hi = std::max<int64_t>(hi, (int64_t)ax.start[o] + ax.count[o]);
-                span = std::max(span, hi - (int64_t)ax.start[o0]);
-            }
-            t.span[k] = (uint32_t)span;
-        }
-        it = tm->axis_tabs.emplace(key, t).first;
+        const int rc = make_axis_tables(tm, {key});
+        if (rc != TH_OK) return rc;
+        it = tm->axis_tabs.find(key);
     }
     *out = &it->second;
     return TH_OK;
@@ -348,8 +473,7 @@ void prune_axis_tabs(th_tm *tm) {
         if (live.count(it->first)) {
             ++it;
         } else {
-            (void)hipFree(it->second.d_blob);
-            it = tm->axis_tabs.erase(it);
+            it = tm->axis_tabs.erase(it);  // (its block goes with the last table made beside it)
         }
     }
 }
@@ -482,20 +606,36 @@ int build_mips(th_tm *tm, const std::vector<Channel *> &chans) {
         }
     }
     if (launches.empty()) return TH_OK;
+    const bool prof = getenv("TH_TM_PROF") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tb0 = now();
+    double t_axis = 0.0;
     int rc = tm->mip_jobs.upload(s, jobs.data(), jobs.size() * sizeof(LodPassJob));
     if (rc != TH_OK) return rc;
     const LodPassJob *dj = static_cast<const LodPassJob *>(tm->mip_jobs.dptr);
+    {   // every tap table the passes below read, made together (in parallel on the host) before the first launch
+        std::set<std::pair<uint32_t, uint32_t>> keys;
+        for (const Launch &l : launches)
+            if (l.kind == VPASS) keys.insert({l.n_in, l.level});
+        const double ta_ = now();
+        rc = make_axis_tables(tm, keys);
+        t_axis += now() - ta_;
+        if (rc != TH_OK) return rc;
+    }
     for (const Launch &l : launches) {
         if (l.kind == TRANSPOSE) {
             // a x b: the SOURCE has b rows of a elements (dst[x][y] = src[y][x], x < a, y < b)
             TH_HIP(launch_transpose_u16_batch(dj + l.first, l.count, l.a, l.b, s));
         } else {
             AxisTable *t = nullptr;
+            const double ta_ = now();
             rc = axis_table(tm, l.n_in, l.level, &t);
+            t_axis += now() - ta_;
             if (rc != TH_OK) return rc;
             TH_HIP(launch_lod_vpass_batch(dj + l.first, l.count, axis_view(*t), l.a, s));
         }
     }
+    if (prof) fprintf(stderr, "build_mips prof: %zu launches %.2f ms of which axis tables %.2f\n", launches.size(), now() - tb0, t_axis);
     return TH_OK;
 }
 
@@ -549,6 +689,9 @@ int update_spec_imgs(th_tm *tm, bool force_update_all, std::vector<size_t> *upda
                 }
     std::vector<th_img_desc> descs;
     std::vector<Channel *> made;
+    const bool prof = getenv("TH_TM_PROF") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tq0 = now();
     for (size_t id : ids) {
         auto it = tm->tracks.find(id);
         if (it == tm->tracks.end()) continue;  // filter over specs: ids without a spec are skipped
@@ -570,9 +713,22 @@ int update_spec_imgs(th_tm *tm, bool force_update_all, std::vector<size_t> *upda
             made.push_back(&ch);
         }
     }
+    const double tq1 = now();
     int rc = th_spec_to_img_batch_dev(tm->ctx, descs.data(), descs.size(), tm->min_dB, tm->max_dB, tm->colormap_length);
+    if (rc == TH_OK) {
+        TH_HIP(hipEventRecord(tm->img_ev, tm->ctx->stream));
+        tm->img_ev_recorded = true;
+    }
+    const double tq2 = now();
     // the LOD mip pyramid of every image that was just re-made (render_tiles.rs:290-313,354-393)
     if (rc == TH_OK) rc = build_mips(tm, made);
+    if (rc == TH_OK) TH_HIP(hipEventRecord(tm->mips_ev, tm->ctx->stream));
+    if (prof) {
+        const double tq3 = now();
+        (void)hipStreamSynchronize(tm->ctx->stream);
+        fprintf(stderr, "update_spec_imgs prof: image allocations %.2f ms, quantise launch %.2f, build_mips (host side) %.2f, drain %.2f\n", tq1 - tq0, tq2 - tq1,
+                tq3 - tq2, now() - tq3);
+    }
     if (rc != TH_OK) {
         // Not failure-atomic otherwise: the images above are already re-quantised, so a pyramid that was only
         // partly rebuilt would serve pixels of the old dB range under the new revision.  Without levels every LOD request
@@ -641,8 +797,20 @@ void put_u64(uint8_t *p, uint64_t v) { std::memcpy(p, &v, 8); }
 // a mutator's last act before it releases the write lock: readers use their own streams
 int writer_done(th_tm *tm, int rc) {
     hipError_t e = hipStreamSynchronize(tm->ctx->stream);
+    tm->axis_staging.clear();  // (every upload from these host copies has completed)
+    tm->img_ev_recorded = false;
     if (rc == TH_OK && e != hipSuccess) TH_HIP(e);
     return rc;
+}
+
+// the same for the mutators that only re-make images (see th_tm::img_ev): wait for the quantiser, not for the mip pyramids behind
+// it.  The tap tables' host copies (axis_staging) stay until a later mutator has drained the stream.
+int writer_done_images(th_tm *tm, int rc) {
+    if (rc != TH_OK || !tm->img_ev_recorded || tm->lod_source != 0) return writer_done(tm, rc);
+    const hipError_t e = hipEventSynchronize(tm->img_ev);
+    tm->img_ev_recorded = false;
+    if (e != hipSuccess) TH_HIP(e);
+    return TH_OK;
 }
 
 }  // namespace
@@ -650,9 +818,22 @@ int writer_done(th_tm *tm, int rc) {
 TH_API int th_tm_create(th_ctx *c, th_tm **out) {
     TH_TRY
     TH_REQUIRE(c && out, "NULL argument");
-    th_tm *tm = new th_tm();
+    std::unique_ptr<th_tm> tm(new th_tm());
     tm->ctx = c;
-    *out = tm;
+    // the manager's own device objects up front (a stream takes milliseconds to create: not inside the first add_tracks)
+    TH_HIP(hipSetDevice(c->device));
+    hipError_t e = hipStreamCreateWithFlags(&tm->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&tm->copy_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&tm->img_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&tm->mips_ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (tm->mips_ev) (void)hipEventDestroy(tm->mips_ev);
+        if (tm->img_ev) (void)hipEventDestroy(tm->img_ev);
+        if (tm->copy_ev) (void)hipEventDestroy(tm->copy_ev);
+        if (tm->copy_stream) (void)hipStreamDestroy(tm->copy_stream);
+        TH_HIP(e);
+    }
+    *out = tm.release();
     return TH_OK;
     TH_CATCH
 }
@@ -668,13 +849,20 @@ TH_API int th_tm_destroy(th_tm *tm) {
         (void)hipHostFree(sp->h_tile);
     }
     for (auto &kv : tm->tracks)
-        for (Channel &ch : kv.second.ch) free_channel(ch);
+        free_track(kv.second);
     for (auto &kv : tm->plans) th_plan_destroy(kv.second);
-    for (auto &kv : tm->axis_tabs) (void)hipFree(kv.second.d_blob);
+    tm->axis_tabs.clear();
     if (tm->batch_stage) (void)hipHostFree(tm->batch_stage);
     tm->mip_jobs.release();
     tm->mip_scratch.release();
     if (tm->d_colormap) (void)hipFree(tm->d_colormap);
+    if (tm->copy_ev) (void)hipEventDestroy(tm->copy_ev);
+    if (tm->img_ev) (void)hipEventDestroy(tm->img_ev);
+    if (tm->mips_ev) (void)hipEventDestroy(tm->mips_ev);
+    if (tm->copy_stream) {
+        (void)hipStreamSynchronize(tm->copy_stream);
+        (void)hipStreamDestroy(tm->copy_stream);
+    }
     delete tm;
     return TH_OK;
     TH_CATCH
@@ -761,7 +949,7 @@ TH_API int th_tm_set_dB_range(th_tm *tm, float dB_range) {
     std::vector<size_t> upd;
     int rc = update_spec_imgs(tm, true, &upd);
     tm->invalidate_spectrogram();  // lib.rs:265
-    return writer_done(tm, rc);
+    return writer_done_images(tm, rc);
     TH_CATCH
 }
 
@@ -783,57 +971,101 @@ TH_API int th_tm_add_tracks(th_tm *tm, size_t n_tracks, const size_t *ids, const
     TH_HIP(hipSetDevice(c->device));
     // Transactional: the new tracks are staged (audio upload, waveform pyramid, spec) beside the resident ones and
     // swapped in when everything has succeeded.  A failure frees the staging area and changes nothing.
+    // Pipelined (round 6; the reference overlaps decode and calc_spec across rayon tasks, core/track.rs:211-239 -> core/mod.rs:
+    // 153-163): the tracks go up in GROUPS on a copy stream of the manager's own; the waveform pyramids and the STFT of group g run
+    // on the context stream (behind an event of the copy stream) while the host feeds group g + 1 to the copy engine — a pageable
+    // source keeps the calling thread inside hipMemcpyAsync for the length of the transfer, so the kernels of the group before
+    // cost nothing; nothing waits for the device until the end (one synchronisation, then the per-channel (min, max) read-back).
+    // Inputs stay borrowed until the call returns.
     std::map<size_t, Track> staged;
     std::map<PlanKey, th_plan *> created;
     std::vector<NewSpec> fresh;
+    std::vector<PendingMinMax> pending;
+    TH_REQUIRE(tm->copy_stream != nullptr && tm->copy_ev != nullptr, "manager without its copy stream");  // (th_tm_create)
     auto abort_staging = [&]() {
+        (void)hipStreamSynchronize(tm->copy_stream);
         (void)hipStreamSynchronize(c->stream);
+        (void)finish_specs(tm, pending, &fresh, false);
         free_new_specs(fresh);
-        for (auto &kv : staged)
-            for (Channel &ch : kv.second.ch) free_channel(ch);
+        for (auto &kv : staged) free_track(kv.second);
         for (auto &kv : created) th_plan_destroy(kv.second);
     };
     int rc = TH_OK;
     hipError_t e = hipSuccess;
-    size_t flat = 0;
     std::vector<size_t> added;
-    std::vector<th_pyramid_desc> pdescs;
-    for (size_t t = 0; t < n_tracks && e == hipSuccess; t++) {
-        Track &tr = staged[ids[t]];  // the same id twice in one call: the later one wins, as sequential adds would
-        for (Channel &ch : tr.ch) free_channel(ch);
-        tr.sr = srs[t];
-        tr.ch.assign(n_channels[t], Channel());
-        for (uint32_t k = 0; k < n_channels[t] && e == hipSuccess; k++, flat++) {
-            Channel &ch = tr.ch[k];
-            ch.n = n_samples[t];
-            e = hipMalloc((void **)&ch.d_wav, ch.n * sizeof(float));
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(ch.d_wav, channels_flat[flat], ch.n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    const bool prof = getenv("TH_TM_PROF") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = now();
+    // the same id twice in one call: the later one wins, as sequential adds would — only its data is uploaded
+    std::map<size_t, size_t> last_of;
+    std::vector<size_t> flat0(n_tracks, 0);
+    {
+        size_t flat = 0;
+        for (size_t t = 0; t < n_tracks; t++) {
+            last_of[ids[t]] = t;
+            flat0[t] = flat;
+            flat += n_channels[t];
+            added.push_back(ids[t]);
+        }
+    }
+    // groups of about 96 MB of samples (at least one track each): a group's launches cost ~0.2 ms of host time (descriptor tables,
+    // spec allocations: six groups of 32 MB were SLOWER than no pipeline, 6.0 against 5.1 ms for 32 tracks), the last group's
+    // kernels are the only ones nothing hides
+    constexpr size_t GROUP_BYTES = (size_t)96 << 20;
+    const Setting st = setting_of(tm);
+    size_t t = 0;
+    double t_launch = 0.0;
+    while (t < n_tracks && e == hipSuccess && rc == TH_OK) {
+        std::vector<std::pair<uint32_t, Channel *>> chans;
+        std::vector<th_pyramid_desc> pdescs;
+        size_t bytes = 0;
+        for (; t < n_tracks && (bytes == 0 || bytes < GROUP_BYTES) && e == hipSuccess; t++) {
+            if (last_of[ids[t]] != t) continue;
+            Track &tr = staged[ids[t]];
+            tr.sr = srs[t];
+            tr.ch.assign(n_channels[t], Channel());
             // resident waveform pyramid: levels up to the one whose single bin spans the channel (render_tiles.rs:232-259)
-            uint32_t lv = 1;
-            while (lv < PYR_MAX_LEVELS && ((uint64_t)1 << (lv - 1)) < ch.n) lv++;
-            ch.pyr_levels = lv;
             // (levels PYR_FIRST .. lv - 1: level 0 would be (x, x, x) per sample — half of the pyramid's bytes — and level 1 a
             // quarter; tiles of both are served from the resident samples instead, th_pyramid_desc.first_level)
-            if (e == hipSuccess)
-                e = hipMalloc((void **)&ch.d_pyr,
-                              std::max<size_t>(1, th_waveform_pyramid_offset(ch.n, std::max(lv, PYR_FIRST)) - th_waveform_pyramid_offset(ch.n, PYR_FIRST)) * sizeof(float));
+            const size_t n = n_samples[t];
+            uint32_t lv = 1;
+            while (lv < PYR_MAX_LEVELS && ((uint64_t)1 << (lv - 1)) < n) lv++;
+            const size_t wav_f = (n + 63) / 64 * 64;  // (256-byte pieces: every view starts on a 256-byte boundary)
+            const size_t pyr_f = (std::max<size_t>(1, th_waveform_pyramid_offset(n, std::max(lv, PYR_FIRST)) - th_waveform_pyramid_offset(n, PYR_FIRST)) + 63) / 64 * 64;
+            e = hipMalloc(&tr.d_pool, (wav_f + pyr_f) * n_channels[t] * sizeof(float));
+            for (uint32_t k = 0; k < n_channels[t] && e == hipSuccess; k++) {
+                Channel &ch = tr.ch[k];
+                ch.n = n;
+                ch.pyr_levels = lv;
+                ch.d_wav = static_cast<float *>(tr.d_pool) + (size_t)k * (wav_f + pyr_f);
+                ch.d_pyr = ch.d_wav + wav_f;
+                e = hipMemcpyAsync(ch.d_wav, channels_flat[flat0[t] + k], ch.n * sizeof(float), hipMemcpyHostToDevice, tm->copy_stream);
+                bytes += ch.n * sizeof(float);
+                // (std::map nodes and this vector do not move any more: the pointer stays valid while later groups are staged)
+                chans.push_back({tr.sr, &ch});
+                pdescs.push_back(th_pyramid_desc{ch.d_wav, ch.d_pyr, ch.n, ch.pyr_levels, PYR_FIRST});
+            }
         }
-        added.push_back(ids[t]);
+        if (e != hipSuccess) break;
+        if (chans.empty()) continue;
+        const double tl0 = now();
+        e = hipEventRecord(tm->copy_ev, tm->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, tm->copy_ev, 0);
+        if (e != hipSuccess) break;
+        rc = th_waveform_pyramid_dev(c, pdescs.data(), pdescs.size());
+        if (rc == TH_OK) rc = compute_specs(tm, st, chans, created, &fresh, &pending);
+        t_launch += now() - tl0;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // inputs are borrowed for this call only
-    if (e != hipSuccess) {
+    const double tp1 = now();
+    if (e == hipSuccess && rc == TH_OK) e = hipStreamSynchronize(tm->copy_stream);  // inputs are borrowed for this call only
+    if (e == hipSuccess && rc == TH_OK) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess || rc != TH_OK) {
         abort_staging();
+        if (rc != TH_OK) return rc;
         TH_HIP(e);
     }
-    std::vector<std::pair<uint32_t, Channel *>> chans;
-    for (auto &kv : staged)
-        for (Channel &ch : kv.second.ch) {
-            chans.push_back({kv.second.sr, &ch});
-            pdescs.push_back(th_pyramid_desc{ch.d_wav, ch.d_pyr, ch.n, ch.pyr_levels, PYR_FIRST});
-        }
-    rc = th_waveform_pyramid_dev(c, pdescs.data(), pdescs.size());
-    if (rc == TH_OK) rc = compute_specs(tm, setting_of(tm), chans, created, &fresh);
+    rc = finish_specs(tm, pending, &fresh, true);
+    if (prof) fprintf(stderr, "th_tm_add_tracks prof: staging + launches %.2f ms (of which pyramid / STFT launches %.2f), drain %.2f\n", tp1 - tp0, t_launch, now() - tp1);
     if (rc != TH_OK) {
         abort_staging();
         return rc;
@@ -842,8 +1074,9 @@ TH_API int th_tm_add_tracks(th_tm *tm, size_t n_tracks, const size_t *ids, const
     for (auto &kv : created) tm->plans[kv.first] = kv.second;
     for (auto &kv : staged) {
         Track &dst = tm->tracks[kv.first];  // re-adding an id replaces it (reload_tracks, core/mod.rs:73-82)
-        for (Channel &ch : dst.ch) free_channel(ch);
+        free_track(dst);
         dst = std::move(kv.second);
+        kv.second.d_pool = nullptr;
     }
     std::set<size_t> uniq(added.begin(), added.end());
     tm->no_spec_img_ids.insert(tm->no_spec_img_ids.end(), uniq.begin(), uniq.end());  // core/mod.rs:70
@@ -865,7 +1098,7 @@ TH_API int th_tm_remove_track(th_tm *tm, size_t id) {
     auto it = tm->tracks.find(id);
     if (it == tm->tracks.end()) return fail(TH_ERR_NOT_FOUND, "Track %zu does not exist", id);
     TH_HIP(hipStreamSynchronize(tm->ctx->stream));
-    for (Channel &ch : it->second.ch) free_channel(ch);
+    free_track(it->second);
     tm->tracks.erase(it);
     prune_axis_tabs(tm);
     retain_plans(tm);      // core/mod.rs:96-99
@@ -881,7 +1114,7 @@ TH_API int th_tm_apply_track_list_changes(th_tm *tm, size_t *updated_ids, size_t
     std::unique_lock<std::shared_mutex> wl(tm->rw);
     TH_HIP(hipSetDevice(tm->ctx->device));
     std::vector<size_t> upd;
-    int rc = writer_done(tm, update_spec_imgs(tm, false, &upd));
+    int rc = writer_done_images(tm, update_spec_imgs(tm, false, &upd));
     if (rc != TH_OK) return rc;
     if (n_updated) *n_updated = upd.size();
     if (updated_ids)
@@ -1078,6 +1311,12 @@ TH_API int th_tm_get_spectrogram_tile(th_tm *tm, size_t id, uint32_t ch, uint32_
     int rc = acquire_slot(tm, &lease.slot);
     if (rc != TH_OK) return rc;
     ReaderSlot &sl = *lease.slot;
+    // (a mip level may still be building behind the mutator that re-made the images: th_tm::mips_ev)
+    // (asked of the host first: a wait packet for an event that completed long ago still costs a request ~20 us)
+    if ((level_x != 0 || level_y != 0) && tm->mips_ev != nullptr && hipEventQuery(tm->mips_ev) != hipSuccess) {
+        (void)hipGetLastError();  // (hipErrorNotReady is the answer, not a failure)
+        TH_HIP(hipStreamWaitEvent(sl.stream, tm->mips_ev, 0));
+    }
     // The raster kernel writes the pixels straight into the slot's pinned, device-visible host buffer (16 bytes per lane,
     // 1 KB per wave-instruction over PCIe): no device staging tile, no copy-engine transfer queued behind other readers'.
     TH_HIP(launch_raster_tile(src, src_w, src_h, src_pitch, (uint32_t)g.origin_x, (uint32_t)g.origin_y, (uint32_t)g.width,
