@@ -505,7 +505,11 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
 
 @pytest.mark.parametrize("sr,win,hop,n_fft,n_mel", [(96000, 3840, 960, 4096, 0), (88200, 3528, 882, 4096, 0), (48000, 4096, 1024, 4096, 0),
                                                     (44100, 4096, 1024, 4096, 0), (48000, 4096, 1024, 4096, 128), (96000, 3840, 960, 4096, 64),
-                                                    (48000, 4096, 1024, 4096, 5), (22050, 4096, 1024, 4096, 1000), (88200, 3528, 882, 4096, 2049)])
+                                                    (48000, 4096, 1024, 4096, 5), (22050, 4096, 1024, 4096, 1000), (88200, 3528, 882, 4096, 2049),
+                                                    # the other frame loops of the size: t_overlap 8 at 96 kHz (grid-aligned, three slots of
+                                                    # reuse), hop 2048 / 512 (16 / 4 slots), a hop off the 128-sample grid (no reuse)
+                                                    (96000, 3840, 480, 4096, 0), (48000, 4096, 2048, 4096, 0), (48000, 4096, 512, 4096, 200),
+                                                    (48000, 4000, 1000, 4096, 0)])
 def test_mel_moment_epilogue_n_fft_4096(ctx, sr, win, hop, n_fft, n_mel):
     """Round 6: the n_fft 4096 wave kernel forms the mel rows in its own epilogue, in the MOMENT form (lane = segment of the triangle
     points; wide segments as (S0, S1) moments, narrow ones as their weight pairs; mel_fuse.h / stft_wave.h) — the default for the

@@ -16,6 +16,16 @@
 #include "stft_wave_multi.h"
 #include "stft_block.h"
 
+// Translation units (compile time: this file took 2 min 10 s of a 2 min 10 s build): compiled FOUR times — as itself
+// (TH_STFT_PART undefined: every kernel but the one-frame wave kernels, every host-side helper, the dispatcher) and through
+// kernels_stft_w1024.hip / _w2048.hip / _w4096.hip, which define TH_STFT_PART = 9 / 10 / 11 and compile the wave kernel's
+// instantiations of that size and its launcher, nothing else.
+#if defined(TH_STFT_PART)
+#define TH_PART_MAIN 0
+#else
+#define TH_PART_MAIN 1
+#endif
+
 namespace th {
 
 // ------------------------------------------------------------------------------------------
@@ -33,6 +43,7 @@ __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
     else atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 
+#if TH_PART_MAIN
 __global__ void minmax_init_kernel(float *minmax, uint32_t n_chan) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (minmax != nullptr && i < n_chan) {
@@ -41,6 +52,7 @@ __global__ void minmax_init_kernel(float *minmax, uint32_t n_chan) {
     }
 }
 
+#endif
 // f32::min / f32::max semantics of the reference's scalar reductions (NaN-ignoring).
 __device__ __forceinline__ float nmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ float nmax(float a, float b) { return fmaxf(a, b); }
@@ -96,6 +108,7 @@ __device__ __forceinline__ uint32_t find_chan(const uint32_t *__restrict__ tile_
 // n_fft/2-point regions of a global scratch area per workgroup (L2-resident: 256 KB at 32768) and a
 // persistent grid walks the tiles; __syncthreads orders the workgroup's global writes and reads.
 // ------------------------------------------------------------------------------------------
+#if TH_PART_MAIN
 constexpr int GEN_THREADS = 256;
 
 template <bool SCRATCH>
@@ -190,6 +203,7 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
   }
 }
 
+#endif  // TH_PART_MAIN (generic kernel)
 // ------------------------------------------------------------------------------------------
 // Wave kernel (the fast path): one 64-lane wave per frame, n_fft in {1024, 2048, 4096}, linear
 // frequency scale.  See stft_wave.h for the FFT structure.
@@ -393,6 +407,7 @@ struct MelPair {
     static_assert(RB % 2 == 0 && PAD_A > 0 && PAD_B > 0, "two rows and their zeros fit the slab");
 };
 constexpr int MEL_PAIR_RB = MelPair<10>::RB;
+#if !TH_PART_MAIN  // the one-frame wave kernel: the per-size translation units
 template <int LOG2_NC, int SHIFT, int OUT, bool ROTATE, int OFF, int RES, int PH = -1, bool PKV = false, bool SWEEPF = false, int MELP = 0>
 __device__ __forceinline__ void wave_frame(
     const StftGeom &g, const cf32 *wtab, const cf32 *stw, const cf32 *t2, const cf32 *t3, cf32 *slab, uint32_t lane_wave,
@@ -1192,6 +1207,8 @@ __global__ __launch_bounds__(64 * WAVES, 6) void stft_wave_kernel_occ6(
 }
 
 
+#endif  // !TH_PART_MAIN
+#if TH_PART_MAIN  // multi-frame and workgroup-per-frame kernels, launchers, host-side helpers
 // ------------------------------------------------------------------------------------------
 // Multi-frame wave kernel (stft_wave_multi.h): n_fft = 1024 -> two frames per wave, n_fft = 512 -> four; every lane
 // holds 16 complex points, the instruction stream is that of the 2048-point plan.  Same launch shape, chunk queue, job
@@ -2055,6 +2072,7 @@ uint32_t stft_wave_multi_tail_guard(const StftGeom &g) {
     return staged && g.hop % 4u != 0 ? 2u : 0u;
 }
 
+#endif  // TH_PART_MAIN
 // Waves per workgroup (one persistent workgroup per CU).  Bounded by LDS (tables + one slab per
 // wave <= 160 KB) and by the VGPR file (64*WAVES threads => 512/(WAVES/4) VGPRs per lane).
 #if !defined(TH_RES12)
@@ -2096,6 +2114,7 @@ static size_t wave_lds_bytes() {
     return sizeof(cf32) * ((size_t)W::NC + (stw_in_lds ? stw_len : 0) + (t2_in_lds ? W::T2_LEN : 0) + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN);
 }
 
+#if !TH_PART_MAIN
 template <int LOG2_NC, int WAVES, int SHIFT, int OUT>
 static hipError_t launch_wave_t5(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                  uint32_t n_chan, uint32_t n_tiles, const cf32 *d_wtab, const cf32 *d_tw,
@@ -2159,7 +2178,9 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
                                                                         d_tw, d_minmax, d_queue_head, n_cu, out, s);
             }
         }
-        if constexpr (LOG2_NC <= 10 || (LOG2_NC == 11 && (SHIFT == 8 || SHIFT == -48 - 7 || SHIFT == -48 - 6))) {
+        // (n_fft 4096: every plain frame loop — hop a multiple of 128 samples with 8, 16 or 4 slots of reuse, or none — and the
+        // even-offset grid-aligned shapes of the 96 / 88.2 kHz defaults at t_overlap 4 and 8)
+        if constexpr (LOG2_NC <= 10 || (LOG2_NC == 11 && (SHIFT == 8 || SHIFT == 16 || SHIFT == 4 || SHIFT == 0 || SHIFT == -48 - 7 || SHIFT == -48 - 6 || SHIFT == -48 - 3))) {
             if (out.mode == 2)
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                                                                         d_tw, d_minmax, d_queue_head, n_cu, out, s);
@@ -2292,6 +2313,25 @@ static hipError_t launch_wave_t(const StftGeom &g, const ChanJob *d_jobs, const 
                                    waves, out, s);
 }
 
+// this size's launcher (the dispatcher in the main translation unit calls it)
+#define TH_PART_NAME2(N) launch_stft_wave_part_##N
+#define TH_PART_NAME(N) TH_PART_NAME2(N)
+hipError_t TH_PART_NAME(TH_STFT_PART)(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan, uint32_t n_tiles,
+                                      const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves,
+                                      const WaveOut &out, hipStream_t s) {
+    return launch_wave_t<TH_STFT_PART>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
+}
+#endif  // !TH_PART_MAIN
+#if TH_PART_MAIN
+hipError_t launch_stft_wave_part_9(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan, uint32_t n_tiles,
+                                   const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves,
+                                   const WaveOut &out, hipStream_t s);
+hipError_t launch_stft_wave_part_10(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan, uint32_t n_tiles,
+                                    const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves,
+                                    const WaveOut &out, hipStream_t s);
+hipError_t launch_stft_wave_part_11(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan, uint32_t n_tiles,
+                                    const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, uint32_t *d_queue_head, uint32_t n_cu, int waves,
+                                    const WaveOut &out, hipStream_t s);
 // grid-aligned register reuse for hops that are not multiples of 128 samples (stft_wave_kernel): 0 = not applicable, 1 =
 // phased (n_fft 2048, hop = 3 * 128 + 96, n_fft - win >= 96), 2 = dynamic (n_fft 2048: any other hop in (256, 512), n_fft
 // 1024: hop in (128, 256); n_fft - win >= 127); default launch shapes, dB output
@@ -2337,8 +2377,8 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool bande
     // n_fft 4096: nothing to fit (the moment form keeps no table in LDS); the launch shapes the epilogue is instantiated for
     if (g.log2_nc == 11 && banded && words > 0 && (waves <= 0 || waves == WaveLaunchCfg<11>::DEFAULT_WAVES)) {
         const int pm = stft_wave_phased_mode(g, waves);
-        if (pm == 0) return g.hop == 1024;
-        return pm == 3 && (g.hop / 128 == 7 || g.hop / 128 == 6);
+        if (pm == 0) return true;  // (plain frame loops: every hop — reuse of 8 / 16 / 4 slots or none)
+        return pm == 3 && (g.hop / 128 == 7 || g.hop / 128 == 6 || g.hop / 128 == 3);
     }
     return false;
 }
@@ -2415,11 +2455,12 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
         return hipErrorInvalidValue;
     }
     switch (g.log2_nc) {
-        case 9: return launch_wave_t<9>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
-        case 10: return launch_wave_t<10>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
-        case 11: return launch_wave_t<11>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
+        case 9: return launch_stft_wave_part_9(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
+        case 10: return launch_stft_wave_part_10(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
+        case 11: return launch_stft_wave_part_11(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
         default: return hipErrorInvalidValue;
     }
 }
 
+#endif  // TH_PART_MAIN
 }  // namespace th
