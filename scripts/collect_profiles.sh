@@ -26,14 +26,13 @@ after = os.path.getmtime(lib)
 print("build_mode: %s (__graft_entry__.build() took %.1f s; %s)" % (
     "reused the prebuilt library that travelled with the push" if before == after else "REBUILT on this box", time.time() - t0, lib))
 PY
-python3 -m pytest tests -x -q -m gpu 2>&1 | tail -4 > "$out/gputest.txt"
+python3 -m pytest tests -x -q -m gpu -s 2>&1 | grep -E "passed|failed|error|moment-form" | tail -30 > "$out/gputest.txt"
 echo "bench" >> "$out/progress.txt"; python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
 cp gpurun_out/bench_extras.json "$out/bench_extras.json" 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single-track --no-skeleton > "$out/bench_under_rocprof.json" 2> "$out/trace.err"
 find "$out/trace" -type f ! -name "*kernel_stats.csv" -delete
 scripts/pmc_stft.sh "$out/pmc_stft" > "$out/pmc_stft.log" 2>&1
-scripts/pmc_stft.sh "$out/pmc_stftpk" --kernel 9 > "$out/pmc_stftpk.log" 2>&1      # round 4: the packed-f32 pipeline
-scripts/pmc_stft.sh "$out/pmc_stftsweep" --kernel 11 > "$out/pmc_stftsweep.log" 2>&1  # round 4: the sweep chunk schedule
+# (round 6: the packed-f32 pipeline and the sweep schedule — selectors 9 / 11 — are A/B builds only; their counters are in profiles/r05_stftpk_* / r05_stftsweep_*)
 TH_PMC_SCRIPT=scripts/bench_img.py scripts/pmc_stft.sh "$out/pmc_img" > "$out/pmc_img.log" 2>&1
 # the N > 1 launcher (round 5): `--gpus 2` on this one-GPU box must fail loudly, and the launcher -> torchrun -> rank -> RCCL route
 # end to end at one rank (TH_BENCH_FORCE_LAUNCHER=1)
@@ -45,9 +44,8 @@ for n in 2 4; do TH_BENCH_SHARE_GPU=1 timeout -k 10 400 python3 bench.py --gpus 
 TH_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-single-track --no-full-cfg5 > "$out/force_dist.out" 2> "$out/force_dist.err"; grep "^{" "$out/force_dist.out" | tail -1 > "$out/bench_line_force_dist.json"
 # package power / clocks next to the kernel loop and next to plain memory streams (scripts/power_probe.sh)
 {
-  for k in stft stftpk copy store; do
+  for k in stft copy store; do
     if [ $k = stft ]; then bash scripts/power_probe.sh "$out/pw_$k" python3 scripts/bench_stft.py --reps 20000
-    elif [ $k = stftpk ]; then bash scripts/power_probe.sh "$out/pw_$k" python3 scripts/bench_stft.py --reps 20000 --kernel 9
     else bash scripts/power_probe.sh "$out/pw_$k" python3 scripts/power_loops.py $k 12; fi
     echo "== $k loop: $(tail -1 $out/pw_$k.cmd)"; grep -E "Power|sclk" "$out/pw_$k" | tail -4
   done
@@ -60,7 +58,12 @@ scripts/pmc_stft.sh "$out/pmc_stft512_multi" --nfft 512 > "$out/pmc_stft512_mult
 scripts/pmc_stft.sh "$out/pmc_stft4096" --nfft 4096 --seconds 60 > "$out/pmc_stft4096.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stftmel" --sr 44100 --tracks 32 --seconds 60 --mel 128 > "$out/pmc_stftmel.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stft4096dyn" --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 > "$out/pmc_stft4096dyn.log" 2>&1
-scripts/pmc_stft.sh "$out/pmc_melrows" --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 > "$out/pmc_melrows.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_stft512mel" --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180 > "$out/pmc_stft512mel.log" 2>&1   # (the 8 kHz Mel default: stft_wave_multi_kernel with the fused epilogue; rounds 3-5 filed it as "melrows")
+# round 6: mel at n_fft 4096 — the moment-form epilogue (default) and round 5's two kernels (selector 12): mel_band_rows_kernel (96 kHz default, 404 mels) and mel_mfma_kernel (48 kHz, 695 mels)
+scripts/pmc_stft.sh "$out/pmc_stft4096mel96" --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 --mel 0 > "$out/pmc_stft4096mel96.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_melbandrows96" --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 --mel 0 --kernel 12 > "$out/pmc_melbandrows96.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_stft4096mel48" --sr 48000 --nfft 4096 --mel 0 > "$out/pmc_stft4096mel48.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_melmfma48" --sr 48000 --nfft 4096 --mel 0 --kernel 12 > "$out/pmc_melmfma48.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stftmel48" --sr 48000 --win 1920 --hop 480 --mel 0 > "$out/pmc_stftmel48.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stftmel48_one_frame" --sr 48000 --win 1920 --hop 480 --mel 0 --kernel 13 > "$out/pmc_stftmel48_one_frame.log" 2>&1  # round 5: the one-frame epilogue (the default takes frame pairs)
 scripts/pmc_stft.sh "$out/pmc_subwave32768" --nfft 32768 > "$out/pmc_subwave32768.log" 2>&1   # round 5: stft_subwave_kernel
@@ -68,7 +71,6 @@ fi
 if want 3; then
 {
   python3 scripts/bench_stft.py --reps 30 --kernel 0 1
-  python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --kernel 0 9 11 0 9 11   # round 4: default | packed-f32 | sweep schedule
   python3 scripts/bench_stft.py --reps 30 --nfft 1024
   python3 scripts/bench_stft.py --reps 30 --nfft 4096
   python3 scripts/bench_stft.py --reps 30 --win 1920 --hop 480 --kernel 0 4   # phased mode vs plain wave kernel
@@ -77,7 +79,6 @@ if want 3; then
   python3 scripts/bench_stft.py --reps 30 --win 1764 --hop 441 --gap-ms 1
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1
   python3 scripts/bench_stft.py --reps 30 --hop 1024
-  python3 scripts/bench_stft.py --reps 30 --kernel $((2+(8<<8)+(32<<16))) $((2+(12<<8)+(32<<16))) $((2+(16<<8)+(32<<16)))
 } > "$out/bench_stft.txt" 2>&1
 python3 scripts/bench_img.py --sustain 300 > "$out/bench_img.txt" 2>&1
 python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
@@ -89,11 +90,11 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 4096
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 8192
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --nfft 16384
-  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 32768 --kernel 0 14   # round 5: stft_subwave_kernel | stft_block_kernel
-  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 32768 --win 19200 --hop 4800 --kernel 0 14
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 32768
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 32768 --win 19200 --hop 4800
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 16384 --win 12000 --hop 3000 --kernel 0 14
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 16384 --kernel 0 15
-  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 8192 --kernel 0 15
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --nfft 8192
   python3 scripts/bench_stft.py --reps 10 --gap-ms 1 --nfft 65536 --kernel 0 1   # round 5: planar block plan | generic kernel
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --win 1920 --hop 240 --kernel 0 4
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --win 1920 --hop 120 --kernel 0 4
@@ -118,9 +119,12 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 44100 --tracks 32 --seconds 60 --mel 128 --kernel 0 8
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 16000 --nfft 1024 --win 640 --hop 160 --mel 0 --seconds 90 --kernel 0 8
   python3 scripts/bench_stft.py --reps 30 --gap-ms 1 --sr 22050 --nfft 1024 --win 882 --hop 220 --mel 0 --seconds 60 --kernel 0 8
-  # round 5: mel at n_fft 4096 as the FFT kernel's epilogue with the table from global memory (12) against the two kernels (0)
+  # round 6: mel at n_fft 4096 as the FFT kernel's epilogue in the moment form (0, default) against round 5's two kernels (12)
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 --mel 0 --kernel 0 12
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 88200 --nfft 4096 --win 3528 --hop 882 --seconds 30 --mel 0 --kernel 0 12
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 96000 --nfft 4096 --win 3840 --hop 480 --seconds 30 --mel 0 --kernel 0 12
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 4096 --mel 0 --kernel 0 12
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 4096 --hop 2048 --mel 0 --kernel 0 12
   # round 4: the Mel default of long windows (more than 512 mels) on the two-kernel path against the generic kernel
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 4096 --mel 0 --kernel 0 1
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 8192 --mel 0 --kernel 0 1
@@ -130,6 +134,7 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
 if [ -f scripts/variants/libthesia_amd_wt.so ]; then
   THESIA_AMD_LIB=scripts/variants/libthesia_amd_wt.so python3 scripts/wave_times.py > "$out/wave_times.txt" 2>&1
 fi
+[ -x scripts/ubench/mom_probe ] && { for a in "96000 4096 0" "88200 4096 0" "48000 4096 0"; do timeout 60 scripts/ubench/mom_probe $a 64; done; } > "$out/ubench_mom_probe.txt" 2>&1
 for u in lds_rate valu_rate valu_bank copy_rate row_stores stream_shapes fused_img_shapes; do
   [ -x scripts/ubench/$u ] && timeout 120 scripts/ubench/$u > "$out/ubench_$u.txt" 2>&1
 done

@@ -59,7 +59,11 @@ for name, script in (("stft", "scripts/bench_stft.py"), ("stftpk", "scripts/benc
                      ("stft4096", "scripts/bench_stft.py --nfft 4096 --seconds 60"),
                      ("stftmel", "scripts/bench_stft.py --sr 44100 --tracks 32 --seconds 60 --mel 128"),
                      ("stft4096dyn", "scripts/bench_stft.py --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30"),
-                     ("melrows", "scripts/bench_stft.py --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180"),
+                     ("stft512mel", "scripts/bench_stft.py --sr 8000 --nfft 512 --win 320 --hop 80 --mel 0 --seconds 180"),
+                     ("stft4096mel96", "scripts/bench_stft.py --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 --mel 0"),
+                     ("melbandrows96", "scripts/bench_stft.py --sr 96000 --nfft 4096 --win 3840 --hop 960 --seconds 30 --mel 0 --kernel 12"),
+                     ("stft4096mel48", "scripts/bench_stft.py --sr 48000 --nfft 4096 --mel 0"),
+                     ("melmfma48", "scripts/bench_stft.py --sr 48000 --nfft 4096 --mel 0 --kernel 12"),
                      ("stftmel48", "scripts/bench_stft.py --sr 48000 --win 1920 --hop 480 --mel 0"),
                      ("stftmel48_one_frame", "scripts/bench_stft.py --sr 48000 --win 1920 --hop 480 --mel 0 --kernel 13"),
                      ("subwave32768", "scripts/bench_stft.py --nfft 32768")):
@@ -97,7 +101,7 @@ if os.path.exists(p):
 # 5. plain-text measurement logs
 for f in ("bench_stft.txt", "bench_img.txt", "bench_cfg3.txt", "bench_cfg4.txt", "phase_prof.txt", "ubench_lds_rate.txt",
           "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt", "ubench_stream_shapes.txt", "ubench_fused_img_shapes.txt",
-          "ubench_stft_skeleton_sweep.txt", "wave_times.txt", "power.txt",
+          "ubench_stft_skeleton_sweep.txt", "ubench_mom_probe.txt", "wave_times.txt", "power.txt",
           "bench_line_force_dist.json", "bench_line_launcher.json", "bench_line_rehearsal_2_ranks_one_gpu.json", "bench_line_rehearsal_4_ranks_one_gpu.json", "gputest.txt", "box.txt", "build_mode.txt"):
     if os.path.exists(f"{src}/{f}"):
         txt = "\n".join(l for l in open(f"{src}/{f}").read().splitlines() if "amdgpu.ids" not in l) + "\n"
