@@ -772,7 +772,10 @@ def main():
                  # the Mel default of long windows has more than 512 mels (src-common/src/lib.rs:91-103): two kernels since round 4
                  ("nfft4096_mel_default", "48 kHz, n_fft 4096 / hop 1024, mel scale at the default count (695 mels; round 6: moment-form epilogue, one kernel)", wl.wav, 48000, (4096, 1024, 4096, ta.MEL, 0), 0),
                  ("nfft4096_mel_default_two_kernels", "48 kHz, n_fft 4096 / hop 1024, 695 mels, round 5's route (selector 12: FFT kernel -> amplitude rows -> mel_mfma_kernel)", wl.wav, 48000, (4096, 1024, 4096, ta.MEL, 0), 12),
-                 ("nfft16384_mel_default", "48 kHz, n_fft 16384 / hop 4096, mel scale at the default count (2785 mels)", wl.wav, 48000, (16384, 4096, 16384, ta.MEL, 0), 0))
+                 ("nfft8192_mel_default", "48 kHz, n_fft 8192 / hop 2048, mel scale at the default count (1392 mels; round 6: moment-form epilogue in the workgroup-per-frame kernel)", wl.wav, 48000, (8192, 2048, 8192, ta.MEL, 0), 0),
+                 ("nfft8192_mel_default_two_kernels", "48 kHz, n_fft 8192 / hop 2048, 1392 mels, round 5's route (selector 12: block kernel -> amplitude rows -> mel_mfma_kernel)", wl.wav, 48000, (8192, 2048, 8192, ta.MEL, 0), 12),
+                 ("nfft16384_mel_default", "48 kHz, n_fft 16384 / hop 4096, mel scale at the default count (2785 mels; round 6: moment-form epilogue, one kernel)", wl.wav, 48000, (16384, 4096, 16384, ta.MEL, 0), 0),
+                 ("nfft16384_mel_default_two_kernels", "48 kHz, n_fft 16384 / hop 4096, 2785 mels, round 5's route (selector 12)", wl.wav, 48000, (16384, 4096, 16384, ta.MEL, 0), 12))
         for key, label, wav_, sr_, (w_, h_, nf_, scale, n_mel), sel in cases:
             try:
                 pl = ta.Plan(ctx, sr_, w_, h_, nf_, scale, n_mel)

@@ -37,6 +37,12 @@ TH_API int th_plan_set_kernel(th_plan *plan, int which);
 /* 1 when the library carries the A/B variants above (-DTH_AB_VARIANTS=1), 0 for the product build */
 TH_API int th_build_ab_variants(void);
 
+/* Mel plans at n_fft 4096 / 8192 / 16384: the moment-form table of the fused epilogue, if the plan has one (n_groups = 0: it does not —
+ * not that size, or the filterbank's lines leave the reference's f32 weights by more than the builder allows, and the plan keeps
+ * the two kernels).  taps = segment taps per frame, max_dev = the largest difference between a line and the table's weight over
+ * all bins (units of an unnormalised weight), max_amp = how far a filter's 1 / d enlarges the moments' rounding.  Any may be NULL. */
+TH_API int th_plan_mel_moments_info(const th_plan *plan, uint32_t *n_groups, uint32_t *taps, double *max_dev, double *max_amp);
+
 /* ---------------------------------------------------------------- measurement: the dominant kernel's launch duration */
 /* Measurement hook: with enable != 0 every th_calc_spec_batch_dev records two HIP events on the context's stream
  * around its dominant kernel launch (the wave kernel, or the generic one when that is all there is);

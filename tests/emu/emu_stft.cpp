@@ -491,6 +491,22 @@ extern "C" __attribute__((visibility("default"))) int emu_mel_moments(const floa
             s[l] = wform ? mel_mom_w_lane(amp_slab, h.words[off + 4 * l], n, prm[0], prm[1], w1[0], w1[1])
                          : mel_mom_lane_any(l, amp_slab, h.words[off + 4 * l], prm[0], prm[1], masks, n);
         }
+        if (!wform) {  // the window words say what the masks say: the lockstep walk of the workgroup-per-frame kernels, bit for bit
+            const uint32_t *win = h.words.data() + off + 256 + mel_mom_mask_words(n);
+            uint32_t n_run = n;  // (the widest M group of the batch of MEL_MOM_BATCH groups this one is walked with)
+            for (uint32_t gg = g / MEL_MOM_BATCH * MEL_MOM_BATCH; gg < std::min(h.n_groups, (g / MEL_MOM_BATCH + 1) * MEL_MOM_BATCH); gg++) {
+                const uint32_t nw2 = h.words[MEL_MOM_HDR0 + 2 * gg];
+                if (!(nw2 & MEL_MOM_FORM_W)) n_run = std::max(n_run, nw2 & 0xffffu);
+            }
+            for (uint32_t l = 0; l < 64; l++) {
+                float prm[2];
+                std::memcpy(prm, &h.words[off + 4 * l + 1], 8);
+                const uint32_t first = h.words[off + 4 * l];
+                // (the wave kernel's slab ends closer behind the row than a workgroup's exchange buffer)
+                const MelMomLane w = mel_mom_lane_win(amp_slab, first, prm[0], prm[1], win[l], first + n_run <= slab_len ? n_run : n);
+                if (std::memcmp(&w, &s[l], sizeof w) != 0) return -4;
+            }
+        }
         for (uint32_t l = 0; l < 64; l++) {
             float inv_d;
             std::memcpy(&inv_d, &h.words[off + 4 * l + 3], 4);
@@ -500,6 +516,59 @@ extern "C" __attribute__((visibility("default"))) int emu_mel_moments(const floa
             else if (v != 0.0f) return -3;  // lanes past the last mel hold 1 / d = 0
         }
         carry = s[0].F;
+    }
+    // The workgroup-per-frame kernels' lane table (made without spreading: a lane's window starts at its first bin): walked as
+    // mel_moments_range_lockstep walks it — batches of MEL_MOM_BATCH groups counted from 0, every M group of a batch over the taps
+    // of the widest — the same numbers bit for bit.
+    if (spread == 0) {
+        const std::vector<uint32_t> lt = build_mel_mom_lanes(h);
+        if (lt.size() != MEL_LANE_BLK0 + (size_t)MEL_LANE_STRIDE * (h.n_groups + MEL_MOM_BATCH)) return -6;
+        for (uint32_t i = 0; i < MEL_LANE_BLK0; i++)
+            if (lt[i] != h.words[i]) return -6;
+        float carry2 = 0.0f;
+        for (uint32_t g = h.n_groups; g-- != 0;) {
+            const uint32_t *blk = &lt[MEL_LANE_BLK0 + (size_t)MEL_LANE_STRIDE * g];
+            const uint32_t nw = blk[256 + 2], n = nw & 0xffffu;
+            uint32_t n_run = 0;
+            for (uint32_t gg = g / MEL_MOM_BATCH * MEL_MOM_BATCH; gg < std::min(h.n_groups, (g / MEL_MOM_BATCH + 1) * MEL_MOM_BATCH); gg++) {
+                const uint32_t nw2 = lt[MEL_LANE_BLK0 + (size_t)MEL_LANE_STRIDE * gg + 256 + 2];
+                if (!(nw2 & MEL_MOM_FORM_W)) n_run = std::max(n_run, nw2 & 0xffffu);
+            }
+            MelMomLane s[64];
+            for (uint32_t l = 0; l < 64; l++) {
+                if (blk[256 + 4 * l + 2] != nw) return -7;
+                float p[4], q[2];
+                std::memcpy(p, &blk[4 * l], 16);
+                std::memcpy(q, &blk[256 + 4 * l], 8);
+                const uint32_t first = blk[4 * l], win = blk[256 + 4 * l];
+                if (nw & MEL_MOM_FORM_W) {
+                    s[l] = mel_mom_w_lane(amp_slab, first, n, p[1], p[2], q[0], q[1]);
+                } else {
+                    if ((win & 0xffffu) != 0) return -7;
+                    s[l] = mel_mom_lane_win(amp_slab, first, p[1], p[2], win, first + n_run <= slab_len ? n_run : n);
+                }
+            }
+            for (uint32_t l = 0; l < 64; l++) {
+                float inv_d;
+                std::memcpy(&inv_d, &blk[4 * l + 3], 4);
+                const float v = mel_mom_combine(inv_d, s[l].R, l == 63 ? carry2 : s[l + 1].F);
+                const uint32_t m = 64 * g + l;
+                if (m < n_mel && std::memcmp(&v, &out[m], 4) != 0) return -8;
+            }
+            carry2 = s[0].F;
+        }
+        // the waves' ranges: ascending, from 0 to the last group
+        if (lt[3] == 1) {
+            auto byte = [&](uint32_t b) { return (lt[b / 4] >> (8 * (b % 4))) & 255u; };
+            for (uint32_t pass = 0; pass < 2; pass++) {
+                const uint32_t b0 = pass ? MEL_MOM_SPLIT4_BYTE : MEL_MOM_SPLIT8_BYTE, nw = pass ? 4 : 8;
+                if (byte(b0) != 0 || byte(b0 + nw) != h.n_groups) return -9;
+                for (uint32_t w = 0; w < nw; w++)
+                    if (byte(b0 + w) > byte(b0 + w + 1)) return -9;
+            }
+        } else if (h.n_groups <= 255) {
+            return -9;
+        }
     }
     return 0;
 }

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 HEADERS = ("thesia_amd.h", "thesia_amd_testing.h")   # the product interface | test and measurement entry points
-TESTING_ONLY = {"th_plan_set_kernel", "th_build_ab_variants", "th_plan_time_kernel", "th_plan_kernel_ms_history", "th_plan_last_kernel_ms", "th_tm_put_img"}
+TESTING_ONLY = {"th_plan_set_kernel", "th_build_ab_variants", "th_plan_mel_moments_info", "th_plan_time_kernel", "th_plan_kernel_ms_history", "th_plan_last_kernel_ms", "th_tm_put_img"}
 
 
 def header_symbols(headers=HEADERS):

@@ -244,7 +244,7 @@ def test_fused_mel_tables_refuse_what_is_not_a_triangle_filterbank(emu):
 
 MOMENT_CASES = [(96000, 4096, 0), (88200, 4096, 0), (48000, 4096, 0), (48000, 4096, 128), (44100, 4096, 64), (48000, 2048, 0),
                 (16000, 1024, 0), (8000, 512, 0), (48000, 8192, 0), (48000, 4096, 1000), (22050, 4096, 512), (48000, 4096, 5),
-                (192000, 4096, 0), (8000, 4096, 0), (32000, 4096, 0)]
+                (192000, 4096, 0), (8000, 4096, 0), (32000, 4096, 0), (48000, 16384, 0), (48000, 16384, 40), (96000, 8192, 200)]
 
 
 def _mom_args(emu):
@@ -262,7 +262,8 @@ def test_moment_form_of_the_mel_filterbank(emu, sr, n_fft, n_mel):
     weight and `max_amp` how far a filter's 1 / d enlarges the rounding of the two terms the line is evaluated from; a result may
     differ from the table's product by (max_dev + a few ulp * max_amp) * (amplitude under the filter) / d plus f32 summation
     error — asserted mel by mel, also for isolated spectral lines (one term per mel: nothing averages out).  NaN behind the
-    amplitude row must not reach any sum."""
+    amplitude row must not reach any sum.  The emulator also walks the workgroup-per-frame kernels' lane table
+    (build_mel_mom_lanes; windows instead of masks, batches in lockstep) and wants the same bits."""
     M = n_mel or orc.mel_default_n_mel(sr, n_fft)
     fb = np.ascontiguousarray(orc.calc_mel_fb(sr, n_fft, M), np.float32)
     lin, mf = orc.mel_fb_points(sr, n_fft, M)

@@ -468,6 +468,8 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     # (round 6: at hop 1024 and the 96 / 88.2 kHz defaults the n_fft 4096 kernel takes the filterbank in its epilogue in the MOMENT
     # form — no table in LDS, any mel count, no amplitude rows through HBM; selector 12 keeps round 5's two kernels)
     fused_4096 = n_fft == 4096 and (hop == 1024 or (sr, hop) in ((96000, 960), (88200, 882)))
+    # (and the same epilogue in the workgroup-per-frame kernel of n_fft 8192 / 16384, where that kernel is the plan that runs)
+    fused_block = n_fft == 8192 or (n_fft == 16384 and hop * 4 == n_fft)
     second = "+mel_rows_kernel" if rows else "+mel_band_rows_kernel" if band_rows else "+mel_mfma_kernel"
     mfma = fft_kernel + second  # (any mel count since round 4; beyond 512 mels there is no fused form)
     # auto: the fused epilogue for n_fft 2048 and (when the piece table fits: <= 512 pieces) 1024, else the matrix-core path
@@ -477,26 +479,37 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     for which, name in ((1, "stft_generic_kernel"), (3, mfma), (7, fft_kernel + "+mel_mfma_kernel"), (8, None), (12, mfma), (0, None)):
         if which == 7 and not (rows or band_rows):
             continue
-        if which == 12 and not fused_4096:  # (selector 12: the two kernels where the moment-form epilogue is the default, an A/B route)
+        if which == 12 and not (fused_4096 or fused_block):  # (selector 12: the two kernels where the moment-form epilogue is the default, an A/B route)
             continue
         if which == 8 and n_fft not in (1024, 2048):
             continue
         plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
+        # (a bank whose lines leave the reference's f32 weights by more than 1.2e-5 — the finer 44.1 kHz-family banks — has no
+        # moment table and keeps the two kernels: th_plan_mel_moments_info, mel_fuse.h)
+        has_table = plan.mel_moments_info()["groups"] > 0
+        assert has_table == ((fused_4096 or fused_block or n_fft in (4096, 8192, 16384)) and (sr, n_fft, n_mel) not in ((44100, 16384, 0),)), plan.mel_moments_info()
+        if which == 12 and not has_table:
+            plan.close()
+            continue
         if which:
             plan.set_kernel(which)
-        if name is None:
+        if name is None and (fused_block or fused_4096) and not has_table:
+            assert plan.kernel_name == mfma
+        elif name is None and fused_block:
+            assert plan.kernel_name == (mfma if which == 8 else "stft_block_kernel(fused mel)")
+        elif name is None:
             assert plan.kernel_name == fused if ((n_fft == 2048 and want_n_mel <= 512) or rows) else plan.kernel_name in (fused, mfma)
             if want_n_mel > 512 and not fused_4096:
                 assert plan.kernel_name == mfma
             if n_fft == 4096 and which == 0:
-                assert plan.kernel_name == (fused if fused_4096 else mfma)
+                assert plan.kernel_name == (fused if fused_4096 and has_table else mfma)
             if (n_fft, want_n_mel) in ((1024, 128), (1024, 385), (1024, 308)):
                 assert plan.kernel_name == fused  # incl. the default mel counts of 16 and 22.05 kHz audio
         else:
             assert plan.kernel_name == name
         assert plan.height == want_n_mel
         specs, mm = plan.calc_spec_batch(wavs)
-        moments = fused_4096 and plan.kernel_name == fused
+        moments = (fused_4096 and plan.kernel_name == fused) or plan.kernel_name == "stft_block_kernel(fused mel)"
         for i, (s, w) in enumerate(zip(specs, want)):
             assert_spec_close(s, w, floor=MOMENT_FLOOR if moments else F32_FLOOR)
             assert mm[i, 0] == s.min() and mm[i, 1] == s.max()
@@ -509,7 +522,11 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
                                                     # the other frame loops of the size: t_overlap 8 at 96 kHz (grid-aligned, three slots of
                                                     # reuse), hop 2048 / 512 (16 / 4 slots), a hop off the 128-sample grid (no reuse)
                                                     (96000, 3840, 480, 4096, 0), (48000, 4096, 2048, 4096, 0), (48000, 4096, 512, 4096, 200),
-                                                    (48000, 4000, 1000, 4096, 0)])
+                                                    (48000, 4000, 1000, 4096, 0),
+                                                    # the workgroup-per-frame kernels (n_fft 8192 / 16384): every wave takes a share of the groups
+                                                    (48000, 8192, 2048, 8192, 0), (96000, 7680, 1920, 8192, 0), (48000, 8192, 1000, 8192, 128),
+                                                    (48000, 16384, 4096, 16384, 0), (44100, 16384, 4096, 16384, 200), (48000, 8192, 2048, 8192, 3),
+                                                    (44100, 8192, 2048, 8192, 0)])
 def test_mel_moment_epilogue_n_fft_4096(ctx, sr, win, hop, n_fft, n_mel):
     """Round 6: the n_fft 4096 wave kernel forms the mel rows in its own epilogue, in the MOMENT form (lane = segment of the triangle
     points; wide segments as (S0, S1) moments, narrow ones as their weight pairs; mel_fuse.h / stft_wave.h) — the default for the
@@ -521,7 +538,7 @@ def test_mel_moment_epilogue_n_fft_4096(ctx, sr, win, hop, n_fft, n_mel):
     want_n_mel = n_mel or orc.mel_default_n_mel(sr, n_fft)
     fb = orc.calc_mel_fb(sr, n_fft, want_n_mel)
     rng = np.random.default_rng(3)
-    lens = (sr // 2 + 123, 9 * n_fft + 7 * hop + 11, n_fft + hop, n_fft, 31 * hop + n_fft, 3000)
+    lens = (max(sr // 2, 3 * n_fft) + 123, 9 * n_fft + 7 * hop + 11, n_fft + hop, n_fft, 31 * hop + n_fft, 3000)
     wavs = [synth_track(60 + i, sr, n) for i, n in enumerate(lens)]
     t = np.arange(6 * n_fft) / sr
     # lone lines ON bin centres (window leakage puts 3 bins under them) and far off them
@@ -530,7 +547,20 @@ def test_mel_moment_epilogue_n_fft_4096(ctx, sr, win, hop, n_fft, n_mel):
     wavs.append(np.zeros(5 * n_fft, np.float32))
     fused, two = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel), ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
     two.set_kernel(12)
-    assert fused.kernel_name == "stft_wave_kernel(fused mel)" and two.kernel_name.startswith("stft_wave_kernel+mel_")
+    kind = "stft_wave_kernel" if n_fft == 4096 else "stft_block_kernel"
+    info = fused.mel_moments_info()
+    if (sr, n_fft, n_mel) in ((22050, 4096, 1000), (88200, 4096, 2049), (44100, 8192, 0)):
+        # the finer banks of the 44.1 kHz family: their lines leave the reference's f32 weights by 1.7 - 2.5e-5 (the rounding of its f32
+        # bin frequencies against narrow segments) — more than the builder allows: no table, the plan keeps the two kernels
+        assert info["groups"] == 0 and fused.kernel_name == two.kernel_name and fused.kernel_name.startswith(kind + "+mel_")
+        a, _ = fused.calc_spec_batch(wavs[:3])
+        for w, sa in zip(wavs[:3], a):
+            assert_spec_close(sa, orc.calc_spec(w, win, hop, n_fft, mel_fb=fb))
+        fused.close()
+        two.close()
+        return
+    assert info["groups"] == (want_n_mel + 1 + 63) // 64 and 0 < info["max_dev"] <= 1.2e-5 and info["max_amp"] <= 8.0, info
+    assert fused.kernel_name == kind + "(fused mel)" and two.kernel_name.startswith(kind + "+mel_")
     a, mma = fused.calc_spec_batch(wavs)
     b, mmb = two.calc_spec_batch(wavs)
     worst = 0.0
@@ -545,7 +575,8 @@ def test_mel_moment_epilogue_n_fft_4096(ctx, sr, win, hop, n_fft, n_mel):
         assert_spec_close(sa, sb, floor=MOMENT_FLOOR)           # the table's weights on the GPU's own spectrum
         one, _, _ = fused.calc_spec(w)                         # a single-track launch cuts other chunks: same rows
         assert np.array_equal(one, sa)
-    print(f"moment-form mel epilogue {sr} Hz {win}/{hop}/{n_fft}, {want_n_mel} mels: max error {worst:.2e} of the frame maximum")
+    print(f"moment-form mel epilogue {sr} Hz {win}/{hop}/{n_fft}, {want_n_mel} mels: max error {worst:.2e} of the frame maximum (table: {info['taps']} taps in {info['groups']} groups, "
+          f"max_dev {info['max_dev']:.2e}, max_amp {info['max_amp']:.2f})")
     fused.close()
     two.close()
 

@@ -147,6 +147,7 @@ _SIGS = {
     "th_plan_dims": [vp, c_szp, c_szp],
     "th_plan_set_kernel": [vp, C.c_int],
     "th_build_ab_variants": [],
+    "th_plan_mel_moments_info": [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "th_plan_kernel_name": [vp],
     "th_calc_spec_batch_dev": [vp, C.POINTER(ChanDesc), C.c_size_t, vp],
     "th_calc_spec_batch_ranged_dev": [vp, C.POINTER(ChanDesc), C.c_size_t, vp, C.c_float, vp],

@@ -416,6 +416,12 @@ class Plan:
         check(lib.th_plan_last_kernel_ms(self.handle, C.byref(ms)))
         return ms.value
 
+    def mel_moments_info(self) -> dict:
+        """the moment-form table of the fused mel epilogue (n_fft 4096 / 8192 / 16384), if the plan has one (groups == 0: it does not)"""
+        g, t, d, a = C.c_uint32(), C.c_uint32(), C.c_double(), C.c_double()
+        check(lib.th_plan_mel_moments_info(self.handle, C.byref(g), C.byref(t), C.byref(d), C.byref(a)))
+        return {"groups": g.value, "taps": t.value, "max_dev": d.value, "max_amp": a.value}
+
     def set_kernel(self, which: int):
         check(lib.th_plan_set_kernel(self.handle, which))
 

@@ -395,6 +395,10 @@ bool th_plan::use_mel_fused() const {
     // leave none), any mel count; instantiated for hop 1024 and for the even-offset grid-aligned shapes of the 96 / 88.2 kHz
     // defaults (not when selector 4 switches that mode off).  Selector 12 keeps round 5's two kernels (A/B).
     if (g.log2_nc == 11) return kernel_choice != 12 && d_mel_mom != nullptr && th::stft_wave_mel_fits(g, wave_waves, 1, true);
+    // n_fft 8192 / 16384 (round 6): the same moment form as the epilogue of the workgroup-per-frame kernel, where that kernel is the
+    // plan that runs (not the subwave plan: 16384 at hops other than n_fft / 4, or selector 15); selector 12 keeps the two kernels
+    if (g.log2_nc == 12 || g.log2_nc == 13)
+        return kernel_choice != 12 && d_mel_mom != nullptr && th::stft_block_mel_fused_applies(g, kernel_choice == 14 ? 1 : kernel_choice == 15 ? 2 : 0);
     // n_fft 512 under narrow filters: the banded sums of mel_rows_kernel as the epilogue of the four-frames-per-wave kernel
     if (g.log2_nc == 8) return d_mel_rows != nullptr && th::stft_wave_multi_mel_fits(g, wave_waves, mel_rows_groups * (uint32_t)(th::MEL_ROWS_W + 1) * 64u);
     return mel_bsum_fits() || (d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words));
@@ -666,18 +670,25 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
                 rc = up((void **)&p->d_mel_fuse, mf.words.data(), mf.words.size() * sizeof(uint32_t));
             }
         }
-        if (rc == TH_OK && g.log2_nc == 11 && th::stft_wave_supported(g)) {
-            // n_fft 4096: the moment form (lane = segment of the triangle points; mel_fuse.h) for the fused epilogue, any mel count
+        if (rc == TH_OK && (g.log2_nc == 11 || g.log2_nc == 12 || g.log2_nc == 13) && th::stft_wave_supported(g)) {
+            // n_fft 4096 (the wave kernel) and 8192 / 16384 (the workgroup-per-frame kernel): the moment form (lane = segment of the
+            // triangle points; mel_fuse.h) for the fused epilogue, any mel count
             std::vector<float> lin, mfp;
             mel_fb_points(sr, n_fft, n_mel, 0.f, -1.f, lin, mfp);
             const th::MelMomHost mm = th::build_mel_moments(p->h_mel_fb.data(), lin.data(), mfp.data(), g.n_freq, (uint32_t)n_mel,
-                                                            2u * (g.nc + g.nc / 16u), TH_MEL_BAND_SPREAD != 0);
-            if (mm.ok) {
+                                                            g.log2_nc == 11 ? 2u * (g.nc + g.nc / 16u) : th::stft_block_mel_max_index(g), g.log2_nc == 11 && TH_MEL_BAND_SPREAD != 0);
+            // (the workgroup-per-frame kernels walk a batch of groups in lockstep: a lane reads up to the table's widest group's
+            // taps behind its first bin — inside the exchange buffer)
+            const bool reach_ok = g.log2_nc == 11 || (uint64_t)g.n_freq + mm.max_taps <= th::stft_block_mel_max_index(g);
+            // (the workgroup-per-frame kernels: the same numbers at fixed addresses, build_mel_mom_lanes)
+            const std::vector<uint32_t> lanes = g.log2_nc == 11 ? std::vector<uint32_t>() : th::build_mel_mom_lanes(mm);
+            const std::vector<uint32_t> &tab = g.log2_nc == 11 ? mm.words : lanes;
+            if (mm.ok && reach_ok && !tab.empty()) {
                 p->mel_mom_groups = mm.n_groups;
                 p->mel_mom_taps = mm.taps;
                 p->mel_mom_max_dev = mm.max_dev;
                 p->mel_mom_max_amp = mm.max_amp;
-                rc = up((void **)&p->d_mel_mom, mm.words.data(), mm.words.size() * sizeof(uint32_t));
+                rc = up((void **)&p->d_mel_mom, tab.data(), tab.size() * sizeof(uint32_t));
             }
         }
         if (rc == TH_OK) rc = up((void **)&p->d_mel_fb, p->h_mel_fb.data(), p->h_mel_fb.size() * sizeof(float));
@@ -757,9 +768,21 @@ TH_API int th_plan_set_kernel(th_plan *p, int which) {
 
 TH_API int th_build_ab_variants(void) { return TH_AB_VARIANTS ? 1 : 0; }
 
+TH_API int th_plan_mel_moments_info(const th_plan *p, uint32_t *n_groups, uint32_t *taps, double *max_dev, double *max_amp) {
+    TH_TRY
+    TH_REQUIRE(p, "plan is NULL");
+    const bool have = p->d_mel_mom != nullptr;
+    if (n_groups) *n_groups = have ? p->mel_mom_groups : 0u;
+    if (taps) *taps = have ? p->mel_mom_taps : 0u;
+    if (max_dev) *max_dev = have ? p->mel_mom_max_dev : 0.0;
+    if (max_amp) *max_amp = have ? p->mel_mom_max_amp : 0.0;
+    return TH_OK;
+    TH_CATCH
+}
+
 TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (!p) return "";
-    if (p->use_mel_fused()) return "stft_wave_kernel(fused mel)";
+    if (p->use_mel_fused()) return th::stft_is_block_plan(p->g) ? "stft_block_kernel(fused mel)" : "stft_wave_kernel(fused mel)";
     if (p->use_mel_mfma() && p->d_mel_rows != nullptr && p->kernel_choice != 7) return "stft_wave_kernel+mel_rows_kernel";
     // (n_fft 32768, round 5: sixteen wave transforms + a combining pass, kernels_stft_long.hip; selector 14 keeps the block kernel)
     const bool subwave = th::stft_subwave_applies(p->g) && p->d_twc != nullptr && (p->kernel_choice == 15 || (p->kernel_choice != 14 && th::stft_subwave_default(p->g)));
@@ -1074,7 +1097,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         wo.sweep = sweep ? 1 : 0;
         wo.long_plan = p->kernel_choice == 14 ? 1 : p->kernel_choice == 15 ? 2 : 0;
         wo.subwave_twc = p->d_twc;
-        if (mel_fused && g.log2_nc == 11) {  // moment form: the table stays in global memory (scalar + 16-byte lane loads)
+        if (mel_fused && g.log2_nc >= 11) {  // moment form: the table stays in global memory (scalar + 16-byte lane loads)
             wo.mel_tab = p->d_mel_mom;
             wo.mel_words = 0;
             wo.mel_slots = 0;

@@ -49,6 +49,9 @@ bool stft_wave_supported(const StftGeom &g);
 // n_fft 8192 / 16384: launch_stft_wave runs the workgroup-per-frame kernel (stft_block.h): interior frames only, the
 // boundary frames always go to the generic kernel
 bool stft_is_block_plan(const StftGeom &g);
+// n_fft 8192 / 16384 mel plans: the filterbank (moment form) in the block kernel's epilogue where that kernel is the plan that runs
+bool stft_block_mel_fused_applies(const StftGeom &g, int long_plan);
+uint32_t stft_block_mel_max_index(const StftGeom &g);
 // the multi-frame kernel (two / four frames per wave) takes this launch: n_fft 512 or 1024, dB output, no grid-aligned mode
 bool stft_wave_multi_applies(const StftGeom &g, int out_mode);
 uint32_t stft_wave_multi_tail_guard(const StftGeom &g);  // samples an interior span must stay clear of the channel's end

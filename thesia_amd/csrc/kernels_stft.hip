@@ -1529,11 +1529,19 @@ static hipError_t launch_wave_multi(const StftGeom &g, const ChanJob *d_jobs, co
 #define TH_BLOCK_STORE(PTR, VAL) (*(PTR) = (VAL))
 #endif
 constexpr bool block_double_buffered(int log2_nc, int vt) { return log2_nc == 13 && vt == 1; }
-template <int LOG2_NC, bool AMP, bool REUSE, int VT>
+// OUT: 0 dB rows, 1 amplitude rows (first half of the two-kernel mel paths), 2 mel rows (round 6): the amplitudes go to the exchange
+// buffer that is free behind the split pass, and the filterbank is applied in its moment form (mel_moments_range_lockstep,
+// stft_wave.h; table: build_mel_moments) — every wave of the workgroup takes a share of the groups (mel_mom_splits: shares of
+// equal cost), from the top down, and walks the one group above its share along with it instead of waiting for the wave that
+// owns it: one more barrier per frame.
+template <int LOG2_NC, int OUT, bool REUSE, int VT>
 __global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) __attribute__((amdgpu_waves_per_eu(VT == 2 ? 2 : 1))) void stft_block_kernel(
     StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ chunk_tab, uint32_t n_tiles,
-    const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax) {
+    const cf32 *__restrict__ wtab_g, const cf32 *__restrict__ tw, float *__restrict__ minmax, const uint32_t *__restrict__ mel_tab,
+    uint32_t mel_groups, uint32_t n_mel) {
     using B = BlockFft<LOG2_NC>;
+    constexpr bool AMP = OUT == 1, MELF = OUT == 2;
+    static_assert(!MELF || VT == 1, "mel rows: one virtual thread per thread");
     constexpr int T = B::T, NC = B::NC, TT = T / VT;
     static_assert(VT == 1 || VT == 2, "one or two virtual threads");
     static_assert(VT == 1 || (TT % B::NS_B == 0 && (!B::R2_FIRST || TT % B::NS_A == 0)), "shared pass constants");
@@ -1599,6 +1607,27 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) __attribute__((amdgpu_wa
             }
         }
     };
+    // MELF: this wave's share of the filterbank's groups, the same for every frame (ranges of equal cost from the table, mel_mom_splits)
+    uint32_t g_lo = 0, g_hi = 0;
+    if constexpr (MELF) {
+        constexpr uint32_t n_wv = (uint32_t)(TT / 64);
+        static_assert(n_wv == 4 || n_wv == 8, "the table carries the ranges of 4 and of 8 waves");
+        const uint32_t wv = __builtin_amdgcn_readfirstlane(t >> 6);
+        typedef const __attribute__((address_space(4))) uint32_t *cptr32;
+        const cptr32 tb = (cptr32)(uintptr_t)mel_tab;
+        if (tb[3] != 0) {
+            const uint32_t b0 = (n_wv == 8 ? MEL_MOM_SPLIT8_BYTE : MEL_MOM_SPLIT4_BYTE) + wv, b1 = b0 + 1u;
+            g_lo = (tb[b0 >> 2] >> (8u * (b0 & 3u))) & 255u;
+            g_hi = (tb[b1 >> 2] >> (8u * (b1 & 3u))) & 255u;
+        } else {  // (more than 255 groups: equal counts)
+            const uint32_t per = (mel_groups + n_wv - 1u) / n_wv;
+            g_lo = min(wv * per, mel_groups);
+            g_hi = min(g_lo + per, mel_groups);
+        }
+    }
+#if defined(TH_BLK_MEL_PROF)  // development build (scripts/build_variant.sh prof -DTH_BLK_MEL_PROF): shader clocks of the mel epilogue's parts, printed by two workgroups
+    uint64_t prof_acc[5] = {0, 0, 0, 0, 0}, prof_q[4] = {0, 0, 0, 0}, prof_last = __builtin_readcyclecounter();
+#endif
     if constexpr (REUSE) fetch(cur.f);
     for (uint32_t f = cur.f; f < cur.f1; f++) {
         if constexpr (!REUSE) fetch(f);
@@ -1660,8 +1689,11 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) __attribute__((amdgpu_wa
         TH_VT B::write_z(t + (uint32_t)TT * v, z[v], wr);
         __syncthreads();
         const gptr<float> row = cur.spec + (size_t)f * cur.spec_pitch;
+        float *const amp_f = reinterpret_cast<float *>(DBUF ? nx : wr);  // MELF: the buffer the split pass writes its amplitudes to (wr behind TH_BLOCK_SWAP)
         auto emit = [&](uint32_t k, float p) {
-            if constexpr (AMP) {  // amplitude rows for the matrix-core mel path
+            if constexpr (MELF) {
+                amp_f[k] = power_to_amp_scaled(p);
+            } else if constexpr (AMP) {  // amplitude rows for the matrix-core mel path
                 TH_BLOCK_STORE(&row[k], power_to_amp(p));
             } else {
                 const float d = power_to_dB(p);
@@ -1683,11 +1715,57 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) __attribute__((amdgpu_wa
             }
             TH_BLOCK_SWAP();
         }
+        if constexpr (MELF) {
+#if defined(TH_BLK_MEL_PROF)
+            const uint64_t pA = __builtin_readcyclecounter();
+#endif
+            __syncthreads();  // the amplitude row is complete
+#if defined(TH_BLK_MEL_PROF)
+            const uint64_t pB = __builtin_readcyclecounter();
+#endif
+            if (g_lo < g_hi) {  // wave-uniform
+                mel_moments_range_lockstep(t & 63u, amp_f, as_global(mel_tab), g_lo, g_hi, min(g_hi + 1u, mel_groups), [&](uint32_t m, float v) {
+                    if (m < n_mel) {
+                        const float d = amp_to_dB_fast(v);
+                        TH_BLOCK_STORE(&row[m], d);
+                        lmin = nmin(lmin, d);
+                        lmax = nmax(lmax, d);
+                    }
+                }
+#if defined(TH_BLK_MEL_PROF)
+                , prof_q
+#endif
+                );
+            }
+#if defined(TH_BLK_MEL_PROF)
+            const uint64_t pC = __builtin_readcyclecounter();
+#endif
+            TH_BLOCK_SWAP();  // (the amplitude row's buffer is the next frame's first exchange buffer: two buffers — the other one; one — a barrier)
+#if defined(TH_BLK_MEL_PROF)
+            {
+                const uint64_t pD = __builtin_readcyclecounter();
+                prof_acc[0] += pB - pA;
+                prof_acc[1] += pC - pB;
+                prof_acc[2] += pD - pC;
+                prof_acc[3] += pD - prof_last;
+                prof_last = pD;
+                prof_acc[4] += 1;
+            }
+#endif
+        }
         {   // complete the row's last 128-byte line (see wave_frame)
-            const uint32_t height = (uint32_t)(NC + 1), padn = cur.spec_pitch - height;
+            const uint32_t height = MELF ? n_mel : (uint32_t)(NC + 1), padn = cur.spec_pitch - height;
             if (t - 1u < ((padn < 32u && cur.spec_pitch % 32u == 0) ? padn : 0u)) row[height - 1u + t] = 0.0f;
         }
     }
+#if defined(TH_BLK_MEL_PROF)
+    if constexpr (MELF)
+        if ((t & 63u) == 0 && (blockIdx.x == 3 || blockIdx.x == 1000))
+            printf("blk %u wave %u share [%u, %u): frames %llu  barrier %llu  epilogue %llu  swap %llu  frame %llu cycles; per frame: batches %llu load-wait %llu walk %llu emit %llu\n", blockIdx.x, t >> 6, g_lo, g_hi,
+                   (unsigned long long)prof_acc[4], (unsigned long long)(prof_acc[0] / prof_acc[4]), (unsigned long long)(prof_acc[1] / prof_acc[4]),
+                   (unsigned long long)(prof_acc[2] / prof_acc[4]), (unsigned long long)(prof_acc[3] / prof_acc[4]), (unsigned long long)(prof_q[3] / prof_acc[4]),
+                   (unsigned long long)(prof_q[0] / prof_acc[4]), (unsigned long long)(prof_q[1] / prof_acc[4]), (unsigned long long)(prof_q[2] / prof_acc[4]));
+#endif
     if (minmax != nullptr) {  // one (min, max) pair per chunk, folded per channel by wave_post_kernel
         lmin = wave_min(lmin);
         lmax = wave_max(lmax);
@@ -1865,28 +1943,30 @@ __global__ __launch_bounds__(BlockFft<LOG2_NC>::T / VT) void stft_block_planar_k
 #if !defined(TH_BLOCK_VT2_REUSE)
 #define TH_BLOCK_VT2_REUSE 0  // resident samples under VT = 2: 1.98 ms against 1.94 without at n_fft 32768 (256 VGPRs + 120 bytes of scratch)
 #endif
-template <int LOG2_NC, bool AMP, bool REUSE, int VT>
+template <int LOG2_NC, int OUT, bool REUSE, int VT>
 static hipError_t launch_block_t(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
-                               const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
+                               const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s, const WaveOut *mel = nullptr) {
     using B = BlockFft<LOG2_NC>;
-    auto kern = stft_block_kernel<LOG2_NC, AMP, REUSE, VT>;
+    auto kern = stft_block_kernel<LOG2_NC, OUT, REUSE, VT>;
     constexpr size_t lds = sizeof(cf32) * (block_double_buffered(LOG2_NC, VT) ? 2 : 1) * B::BUF_LEN + sizeof(float) * 2 * (B::T / VT / 64);
     static_assert(lds + 64 <= 160 * 1024, "the exchange buffers fit the CU's LDS");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(B::T / VT), lds, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax);
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(B::T / VT), lds, s, g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax,
+                       mel ? mel->mel_tab : nullptr, mel ? mel->mel_groups : 0u, mel ? mel->n_mel : 0u);
     return hipGetLastError();
 }
 
-template <int LOG2_NC, bool AMP>
+template <int LOG2_NC, int OUT>
 static hipError_t launch_block(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_chunk_tab, uint32_t n_tiles,
-                               const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s) {
+                               const cf32 *d_wtab, const cf32 *d_tw, float *d_minmax, hipStream_t s, const WaveOut *mel = nullptr) {
     constexpr int VT = LOG2_NC == 13 ? TH_BLOCK_VT_13 : LOG2_NC == 14 ? TH_BLOCK_VT_14 : 1;
+    static_assert(OUT != 2 || VT == 1, "mel rows: sizes whose block kernel runs one virtual thread per thread");
     // (every frame of a chunk then sits exactly four slots behind its predecessor; at n_fft 32768 only with two virtual threads:
     // 1024 threads have 128 VGPRs each)
     if constexpr (LOG2_NC <= 13 || VT == 2)
-        if (g.hop * 4 == g.n_fft && (VT == 1 || TH_BLOCK_VT2_REUSE)) return launch_block_t<LOG2_NC, AMP, true, VT>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
-    return launch_block_t<LOG2_NC, AMP, false, VT>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s);
+        if (g.hop * 4 == g.n_fft && (VT == 1 || TH_BLOCK_VT2_REUSE)) return launch_block_t<LOG2_NC, OUT, true, VT>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s, mel);
+    return launch_block_t<LOG2_NC, OUT, false, VT>(g, d_jobs, d_chunk_tab, n_tiles, d_wtab, d_tw, d_minmax, s, mel);
 }
 
 
@@ -2058,6 +2138,14 @@ bool stft_wave_supported(const StftGeom &g) {
     return g.odd_m1 == 0 && g.log2_nc >= 8 && g.log2_nc <= 15;  // (15: n_fft 65536, the planar block plan of round 5; powers of two only)
 }
 bool stft_is_block_plan(const StftGeom &g) { return g.log2_nc >= 12; }
+// mel rows in the block kernel's own epilogue (moment form): n_fft 8192 / 16384 where stft_block_kernel is what runs
+// (long_plan: 0 the size's default plan, 1 block kernel, 2 subwave plan — WaveOut::long_plan)
+bool stft_block_mel_fused_applies(const StftGeom &g, int long_plan) {
+    if (g.odd_m1 != 0 || g.phased != 0 || (g.log2_nc != 12 && g.log2_nc != 13)) return false;
+    return long_plan == 1 || (long_plan == 0 && !stft_subwave_default(g));
+}
+// amplitude floats a lane of that epilogue may address (the exchange buffer), and the most groups it takes
+uint32_t stft_block_mel_max_index(const StftGeom &g) { return 2u * (g.nc + g.nc / 16u + 2u) - 64u; }
 bool stft_wave_multi_applies(const StftGeom &g, int out_mode) {
     return g.phased == 0 && ((out_mode == 0 && (g.log2_nc == 8 || g.log2_nc == 9)) || ((out_mode == 1 || out_mode == 2) && g.log2_nc == 8));
 }
@@ -2432,24 +2520,30 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
         if (g.log2_nc == 8) return launch_wave_multi<8, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
         return launch_wave_multi<9, 0>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s);
     }
-    if (g.log2_nc >= 12) {  // one workgroup per frame (stft_block.h): dB output, linear scale
-        if (out.mode > 1 || g.phased) return hipErrorInvalidValue;
+    if (g.log2_nc >= 12) {  // one workgroup per frame (stft_block.h)
+        if (g.phased) return hipErrorInvalidValue;
+        if (out.mode == 2) {  // mel rows in the block kernel's epilogue, moment form (round 6): n_fft 8192 / 16384
+            if (out.mel_tab == nullptr || out.mel_groups == 0 || !stft_block_mel_fused_applies(g, out.long_plan)) return hipErrorInvalidValue;
+            if (g.log2_nc == 12) return launch_block<12, 2>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s, &out);
+            return launch_block<13, 2>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s, &out);
+        }
+        if (out.mode > 1) return hipErrorInvalidValue;
         // round 5: R wave transforms + one combining pass (kernels_stft_long.hip): the default at n_fft 32768, selector 15 elsewhere
         if (stft_subwave_applies(g) && out.subwave_twc != nullptr && (out.long_plan == 2 || (out.long_plan == 0 && stft_subwave_default(g))))
             return launch_stft_subwave(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, out.subwave_twc, out.mode == 1 ? nullptr : d_minmax, out.mode == 1, n_cu, s);
         if (out.mode == 1) {  // amplitude rows, no (min, max)
-            if (g.log2_nc == 12) return launch_block<12, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
-            if (g.log2_nc == 13) return launch_block<13, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
+            if (g.log2_nc == 12) return launch_block<12, 1>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
+            if (g.log2_nc == 13) return launch_block<13, 1>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
 #if TH_AB_VARIANTS  // (n_fft 32768 / 65536 run stft_subwave_kernel; their block kernels are selector 14 of A/B builds)
-            if (g.log2_nc == 14) return launch_block<14, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
+            if (g.log2_nc == 14) return launch_block<14, 1>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
             if (g.log2_nc == 15) return launch_block_planar<15, true>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, nullptr, s);
 #endif
             return hipErrorInvalidValue;
         }
-        if (g.log2_nc == 12) return launch_block<12, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
-        if (g.log2_nc == 13) return launch_block<13, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+        if (g.log2_nc == 12) return launch_block<12, 0>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+        if (g.log2_nc == 13) return launch_block<13, 0>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
 #if TH_AB_VARIANTS
-        if (g.log2_nc == 14) return launch_block<14, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
+        if (g.log2_nc == 14) return launch_block<14, 0>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
         if (g.log2_nc == 15) return launch_block_planar<15, false>(g, d_jobs, d_tile_start, n_tiles, d_wtab, d_tw, d_minmax, s);
 #endif
         return hipErrorInvalidValue;

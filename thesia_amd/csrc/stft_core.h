@@ -35,6 +35,12 @@ namespace th {
 // moment-form mel tables (build_mel_moments, mel_fuse.h <-> mel_moments_global, stft_wave.h): the group headers start at word 16
 // (64-byte aligned) and are padded to whole batches of 4 groups — the kernel takes a batch's header as one s_load_dwordx8
 constexpr uint32_t MEL_MOM_HDR0 = 16, MEL_MOM_BATCH = 4;
+// words of an M block's masks (n taps, 2 words each; at least 128: the batch fetch reads that far behind a block's per-lane words)
+TH_HD uint32_t mel_mom_mask_words(uint32_t n) { return 2u * n > 128u ? 2u * n : 128u; }
+// The workgroup-per-frame kernels' LANE TABLE (build_mel_mom_lanes <-> mel_moments_range_lockstep): the same words [0] .. [8],
+// no group header — group g's block sits at word MEL_LANE_BLK0 + MEL_LANE_STRIDE g, two planes of 64 x 4 words
+constexpr uint32_t MEL_LANE_BLK0 = 16, MEL_LANE_STRIDE = 512;
+constexpr uint32_t MEL_MOM_SPLIT8_BYTE = 16, MEL_MOM_SPLIT4_BYTE = 28;  // (mel_mom_splits, mel_fuse.h)
 
 struct __attribute__((aligned(8))) cf32 {
     float re, im;

@@ -49,6 +49,24 @@ TH_HD float lds_ldf(const float *p) {
 #endif
 }
 
+#if defined(__HIPCC__)
+// the same by 32-bit LDS byte address (a loop that moves a generic pointer pays a 64-bit addition and a null check per read)
+__device__ __forceinline__ uint32_t lds_addr(const float *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)(p);
+#else
+    return 0;
+#endif
+}
+__device__ __forceinline__ float lds_ldf_at(uint32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(float, *(const volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t)(a));
+#else
+    return 0.0f;
+#endif
+}
+#endif
+
 // 16-byte LDS read (ds_read_b128, 16-byte aligned address), as four scalars (no vector-typed arithmetic downstream)
 struct f32x4 {
     float a, b, c, d;
@@ -1721,6 +1739,21 @@ TH_HD MelMomLane mel_mom_lane_any(uint32_t lane, const float *amp, uint32_t firs
         default: return mel_mom_lane(lane, amp, first, alpha, beta, masks, n);
     }
 }
+// The select by the lane's own WINDOW instead of a wave-uniform mask (win = first tap | taps << 16, the table's window words):
+// three vector operations instead of one, but no scalar load in the walk — what the workgroup-per-frame kernels want, whose
+// waves all sit in the epilogue at once and hide nothing.
+TH_HD float mel_mom_win_sel(float a, uint32_t t, uint32_t win) { return (t - (win & 0xffffu)) < (win >> 16) ? a : 0.0f; }
+// one lane, one group, walked from tap n_run - 1 (n_run >= the group's taps, a multiple of 4: the taps of the widest group of
+// the batch walked in lockstep).  Taps above the group's own add +0 to P = +0: bit-identical to mel_mom_lane.
+TH_HD MelMomLane mel_mom_lane_win(const float *amp, uint32_t first, float alpha, float beta, uint32_t win, uint32_t n_run) {
+    float P = 0.0f, S1 = 0.0f;
+    for (uint32_t t = n_run; t-- != 0;) {
+        P += mel_mom_win_sel(lds_ldf(amp + first + t), t, win);
+        S1 += P;
+    }
+    const float R = fma_rn(alpha, S1, beta * P);
+    return {R, P - R};
+}
 // W form (groups whose segments hold one or two bins): the (u, 1 - u) pairs themselves, exact products
 TH_HD MelMomLane mel_mom_w_lane(const float *amp, uint32_t first, uint32_t n, float u0, float v0, float u1, float v1) {
     const float a0 = lds_ldf(amp + first);
@@ -1739,15 +1772,17 @@ TH_HD float mel_mom_combine(float inv_d, float R, float F_next) {
 }
 
 #if defined(__HIPCC__)  // (both passes of hipcc; not the CPU lane emulator, which drives the lane functions itself)
-// The whole epilogue of one frame: groups from the top down (mel m needs F of segment m + 1: the next lane, or across the
-// group border lane 0 of the group above — carried in a scalar), in BATCHES of MEL_MOM_BATCH groups: a batch's header words are
-// one scalar load and its per-lane words are requested together — and a batch AHEAD of their use, i.e. before the rows of the
-// batch in front of it are stored: vmcnt counts loads and stores in one order, so per-lane words requested behind a row store
-// would wait for that store's round trip (two batches of 8 groups, each fetched when its turn came: 695 mels 0.88 ms against
-// 0.78 for the group-ahead fetch this replaces; one group's own work is only a few dozen instructions — scripts/ubench/mom_probe.hip).
-// The table's group header is padded to whole batches (taps 0: skipped).
+// The whole epilogue of one frame — or, in the workgroup-per-frame kernels, one wave's share of it: the groups [g_lo, g_hi) from
+// the top down (mel m needs F of segment m + 1: the next lane, or across the group border lane 0 of the group above — carried in
+// a scalar; `carry` on entry = F of lane 0 of group g_hi, 0 above the last group), in BATCHES of MEL_MOM_BATCH groups: a batch's
+// header words are one scalar load and its per-lane words are requested together — and a batch AHEAD of their use, i.e. before
+// the rows of the batch in front of it are stored: vmcnt counts loads and stores in one order, so per-lane words requested behind
+// a row store would wait for that store's round trip (two batches of 8 groups, each fetched when its turn came: 695 mels 0.88 ms
+// against 0.78 for the group-ahead fetch this replaces; one group's own work is only a few dozen instructions —
+// scripts/ubench/mom_probe.hip).  The table's group header carries MEL_MOM_BATCH zero entries behind the last group (taps 0:
+// skipped; offset 0: the fetch reads the header itself).
 template <class Emit>
-__device__ __forceinline__ void mel_moments_global(uint32_t lane, const float *amp, gptr<const uint32_t> tab, uint32_t n_groups, Emit emit) {
+__device__ __forceinline__ void mel_moments_range(uint32_t lane, const float *amp, gptr<const uint32_t> tab, uint32_t g_lo, uint32_t g_hi, float carry, Emit emit) {
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x8v __attribute__((ext_vector_type(8)));
@@ -1758,6 +1793,7 @@ __device__ __forceinline__ void mel_moments_global(uint32_t lane, const float *a
     typedef const __attribute__((address_space(4))) u32x8v *cptr8v;
     constexpr uint32_t GB = MEL_MOM_BATCH;
     static_assert(GB == 4, "a batch's header is one s_load_dwordx8");
+    if (g_hi <= g_lo) return;
     struct Batch {
         uint32_t nw[GB], off[GB];
         u32x4v prm[GB];
@@ -1769,7 +1805,7 @@ __device__ __forceinline__ void mel_moments_global(uint32_t lane, const float *a
         // (scalar copies: vector elements are not indexed dynamically, and __builtin_bit_cast on a vector-element lvalue reads element 0)
         const uint32_t nw[GB] = {hv.s0, hv.s2, hv.s4, hv.s6}, off[GB] = {hv.s1, hv.s3, hv.s5, hv.s7};
         TH_UNROLL for (uint32_t j = 0; j < GB; j++) {
-            bt.nw[j] = nw[j];
+            bt.nw[j] = g0 + j < g_hi ? nw[j] : 0u;  // (groups of the wave above, or the padding behind the last group: skipped)
             bt.off[j] = off[j];
             // address = block (scalar: table + offset) + zext(lane's byte offset): global_load's saddr + voffset form, no 64-bit vector adds
             const gptr<const char> blk = reinterpret_cast<gptr<const char>>(tab) + ((uint64_t)off[j] << 2);
@@ -1777,17 +1813,21 @@ __device__ __forceinline__ void mel_moments_global(uint32_t lane, const float *a
             bt.w1[j] = *reinterpret_cast<gptr<const u32x2v>>(blk + 1024 + (uint64_t)lane8);  // (W form: the second pair; M form: two mask words, unused)
         }
     };
-    float carry = 0.0f;
-    const uint32_t top = (n_groups + GB - 1u) / GB * GB;
+    // batches [b, b + GB) with b = g_lo + GB i: the top one first
+    uint32_t b = g_lo + (g_hi - g_lo - 1u) / GB * GB;
     Batch nxt;
-    fetch(nxt, top - GB);
-    for (uint32_t gb = top; gb != 0; gb -= GB) {  // groups gb - 1 .. gb - GB
-        const uint32_t g0 = gb - GB;
+    fetch(nxt, b);
+    for (;;) {
+        const uint32_t g0 = b;
         const Batch cur = nxt;
-        if (g0 != 0) fetch(nxt, g0 - GB);  // wave-uniform
+        const bool more = b != g_lo;  // wave-uniform
+        if (more) {
+            b -= GB;
+            fetch(nxt, b);
+        }
         TH_UNROLL for (uint32_t jj = GB; jj-- != 0;) {
             const uint32_t n = cur.nw[jj] & 0xffffu;
-            if (n != 0) {  // wave-uniform (0: padding behind the last group)
+            if (n != 0) {  // wave-uniform (0: not this wave's, or padding)
                 const uint32_t first = cur.prm[jj].x, w_y = cur.prm[jj].y, w_z = cur.prm[jj].z, w_w = cur.prm[jj].w;
                 MelMomLane s;
                 if (cur.nw[jj] & 0x10000u) {  // W form
@@ -1805,8 +1845,163 @@ __device__ __forceinline__ void mel_moments_global(uint32_t lane, const float *a
                 emit(64u * (g0 + jj) + lane, mel_mom_combine(__builtin_bit_cast(float, w_w), s.R, fn));
             }
         }
+        if (!more) break;
     }
 }
+template <class Emit>
+__device__ __forceinline__ void mel_moments_global(uint32_t lane, const float *amp, gptr<const uint32_t> tab, uint32_t n_groups, Emit emit) {
+    mel_moments_range(lane, amp, tab, 0u, n_groups, 0.0f, emit);
+}
+
+// One wave's share of a frame in the workgroup-per-frame kernels: the groups [g_lo, g_hi), and the group g_hi above them walked
+// along without being emitted (g_top = g_hi + 1, or g_hi at the top of the filterbank) for the F its lane 0 owes to mel
+// 64 g_hi - 1.  All waves of the workgroup are in this epilogue together, so a wave's own latency is the frame's: the M groups of
+// a batch are walked in LOCKSTEP (one loop over the taps of the widest, four independent P / S1' chains, sixteen amplitude reads
+// in flight) and select by the per-lane window words (mel_mom_win_sel: no scalar load, i.e. no lgkmcnt(0) drain, inside the
+// walk).  mel_moments_range's group-after-group walk cost this kernel ~2400 cycles per group (n_fft 16384, 2785 mels: 1.22 ms
+// against 0.74 for linear rows).  Batches as there: the next one's header and per-lane words are requested before this one's
+// rows are stored.  Reads above a narrower group's own taps stay inside the exchange buffer (build_mel_moments checks first +
+// the table's widest group against max_index when asked to) and are never selected.
+#if defined(TH_BLK_MEL_PROF)
+#define TH_PROF_Q_PARAM , uint64_t *th_prof_q
+#else
+#define TH_PROF_Q_PARAM
+#endif
+// a batch's per-lane words: the two planes of the lane table (stft_core.h).  No load depends on another: the blocks sit at
+// fixed addresses.  (Requested in front of the barrier before the epilogue, the first batch's words stay live across it and
+// the kernels leave their register budget: 274 VGPRs at n_fft 8192, scratch at 16384.)
+struct MelLaneBatch {
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v p0[MEL_MOM_BATCH], p1[MEL_MOM_BATCH];
+};
+__device__ __forceinline__ void mel_lane_fetch(MelLaneBatch &bt, gptr<const uint32_t> tab, uint32_t lane, uint32_t g0) {
+    typedef MelLaneBatch::u32x4v u32x4v;
+    TH_UNROLL for (uint32_t j = 0; j < MEL_MOM_BATCH; j++) {
+        const gptr<const char> blk = reinterpret_cast<gptr<const char>>(tab) + 4u * (MEL_LANE_BLK0 + MEL_LANE_STRIDE * (g0 + j));
+        bt.p0[j] = *reinterpret_cast<gptr<const u32x4v>>(blk + (uint64_t)(lane << 4));
+        bt.p1[j] = *reinterpret_cast<gptr<const u32x4v>>(blk + 1024 + (uint64_t)(lane << 4));
+    }
+}
+// the first (topmost) batch of the share [g_lo, g_top)
+__device__ __forceinline__ uint32_t mel_lane_first_batch(uint32_t g_lo, uint32_t g_top) { return g_lo + (g_top - g_lo - 1u) / MEL_MOM_BATCH * MEL_MOM_BATCH; }
+template <class Emit>
+__device__ __forceinline__ void mel_moments_range_lockstep(uint32_t lane, const float *amp, gptr<const uint32_t> tab, uint32_t g_lo, uint32_t g_hi, uint32_t g_top, Emit emit TH_PROF_Q_PARAM) {
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+    constexpr uint32_t GB = MEL_MOM_BATCH;
+    constexpr uint32_t TAPS = 4;  // per group and trip of the walk (the groups' taps are multiples of MEL_MOM_UNROLL = 4)
+    if (g_hi <= g_lo) return;
+    typedef MelLaneBatch Batch;
+    auto fetch = [&](Batch &bt, uint32_t g0) { mel_lane_fetch(bt, tab, lane, g0); };
+    uint32_t b = mel_lane_first_batch(g_lo, g_top);
+    float carry = 0.0f;
+    const uint32_t amp_b = lds_addr(amp);
+    Batch nxt;
+    fetch(nxt, b);
+    for (;;) {
+        const uint32_t g0 = b;
+        const Batch got = nxt;
+        const bool more = b != g_lo;  // wave-uniform
+        if (more) {  // (requested before the batch in hand is looked at: both of a share's first two batches are one round trip)
+            b -= GB;
+            fetch(nxt, b);
+        }
+#if defined(TH_BLK_MEL_PROF)
+        const uint64_t q0 = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t q1 = __builtin_readcyclecounter();
+#endif
+        struct {
+            uint32_t nw[GB], win[GB];
+            u32x4v prm[GB];
+            u32x2v w1[GB];
+        } cur;
+        TH_UNROLL for (uint32_t j = 0; j < GB; j++) {
+            const uint32_t w_nw = got.p1[j].z, w_win = got.p1[j].x, w_v1 = got.p1[j].y;  // (scalar copies, see mel_moments_range)
+            cur.nw[j] = g0 + j < g_top ? (uint32_t)__builtin_amdgcn_readfirstlane((int)w_nw) : 0u;  // (the same word in every lane; groups above g_top and the padding: skipped)
+            cur.win[j] = w_win;
+            cur.w1[j] = u32x2v{w_win, w_v1};
+            cur.prm[j] = got.p0[j];
+        }
+        uint32_t n_run = 0;  // taps of the batch's widest M group
+        TH_UNROLL for (uint32_t j = 0; j < GB; j++)
+            if (!(cur.nw[j] & 0x10000u)) n_run = max(n_run, cur.nw[j] & 0xffffu);
+        float P[GB], S1[GB];
+        TH_UNROLL for (uint32_t j = 0; j < GB; j++) P[j] = S1[j] = 0.0f;
+        uint32_t ao[GB];  // LDS byte address of the group's first bin (32-bit: no flat-pointer arithmetic in the walk)
+        TH_UNROLL for (uint32_t j = 0; j < GB; j++) {
+            const uint32_t first = cur.prm[j].x;
+            ao[j] = amp_b + 4u * first;
+        }
+        if (n_run != 0) {  // wave-uniform
+            uint32_t wn[GB];  // the lane's taps: its window is [0, wn) (the lane table is built without shifted first bins)
+            TH_UNROLL for (uint32_t j = 0; j < GB; j++) wn[j] = cur.win[j] >> 16;
+            // taps t0 + TAPS - 1 .. t0 of every group per trip (not software-pipelined: the registers of a second set of
+            // amplitudes cost the n_fft 8192 kernel its second workgroup per CU).  Per tap and group: one compare with the
+            // wave-uniform tap number, one select, two additions — the epilogue is bound by the vector unit (the workgroup's
+            // waves all walk at once, two to a SIMD).
+            for (uint32_t t0 = n_run - TAPS;; t0 -= TAPS) {
+                float c[GB][TAPS];
+                TH_UNROLL for (uint32_t j = 0; j < GB; j++)
+                    TH_UNROLL for (uint32_t i = 0; i < TAPS; i++) c[j][i] = lds_ldf_at(ao[j] + 4u * (t0 + i));
+                TH_UNROLL for (uint32_t i = TAPS; i-- != 0;) {
+                    TH_UNROLL for (uint32_t j = 0; j < GB; j++) {
+                        P[j] += (t0 + i) < wn[j] ? c[j][i] : 0.0f;
+                        S1[j] += P[j];
+                    }
+                }
+                if (t0 == 0) break;  // wave-uniform
+            }
+        }
+#if defined(TH_BLK_MEL_PROF)
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t q2 = __builtin_readcyclecounter();
+#endif
+        // The batch's four groups side by side, without a branch (group after group, every step waited for the one before:
+        // ~400 cycles per group): the W groups' amplitudes, then the four exchanges of F, then the rows.
+        float a0[GB], a1[GB];
+        TH_UNROLL for (uint32_t j = 0; j < GB; j++) {
+            a0[j] = lds_ldf_at(ao[j]);
+            a1[j] = lds_ldf_at(ao[j] + 4u);
+        }
+        MelMomLane sj[GB];
+        float fn_in[GB];
+        TH_UNROLL for (uint32_t j = 0; j < GB; j++) {
+            const uint32_t w_y = cur.prm[j].y, w_z = cur.prm[j].z, u1 = cur.w1[j].x, v1 = cur.w1[j].y;
+            const float py = __builtin_bit_cast(float, w_y), pz = __builtin_bit_cast(float, w_z);
+            const bool wform = (cur.nw[j] & 0x10000u) != 0, two = (cur.nw[j] & 0xffffu) > 1u;  // wave-uniform
+            // W form: mel_mom_w_lane's operations
+            float Rw = a0[j] * py, Fw = a0[j] * pz;
+            const float Rw2 = fma_rn(a1[j], __builtin_bit_cast(float, u1), Rw), Fw2 = fma_rn(a1[j], __builtin_bit_cast(float, v1), Fw);
+            Rw = two ? Rw2 : Rw;
+            Fw = two ? Fw2 : Fw;
+            const float Rm = fma_rn(py, S1[j], pz * P[j]), Fm = P[j] - Rm;
+            sj[j].R = wform ? Rw : Rm;
+            sj[j].F = wform ? Fw : Fm;
+            fn_in[j] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(4u * ((lane + 1u) & 63u)), __builtin_bit_cast(int, sj[j].F)));
+        }
+        TH_UNROLL for (uint32_t jj = GB; jj-- != 0;) {
+            const bool part = (cur.nw[jj] & 0xffffu) != 0;  // wave-uniform (not: above g_top, or padding — the top of the top batch only)
+            const uint32_t w_w = cur.prm[jj].w;
+            const float fn = lane == 63u ? carry : fn_in[jj];
+            const float f0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sj[jj].F)));
+            carry = part ? f0 : carry;
+            const uint32_t m = (part && g0 + jj < g_hi) ? 64u * (g0 + jj) + lane : 0xffffffffu;  // (emit drops mel numbers past the last)
+            emit(m, mel_mom_combine(__builtin_bit_cast(float, w_w), sj[jj].R, fn));
+        }
+#if defined(TH_BLK_MEL_PROF)
+        {
+            const uint64_t q3 = __builtin_readcyclecounter();
+            th_prof_q[0] += q1 - q0;
+            th_prof_q[1] += q2 - q1;
+            th_prof_q[2] += q3 - q2;
+            th_prof_q[3] += 1;
+        }
+#endif
+        if (!more) break;
+    }
+}
+
 #endif
 
 }  // namespace th
