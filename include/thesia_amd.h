@@ -158,10 +158,11 @@ TH_API int th_timer_stop_ms(th_ctx *ctx, float *ms);
 #define TH_MAX_N_FFT (1u << 20)
 /* Device-resident window / twiddles / mel filterbank for one (sr, win, hop, n_fft, scale, n_mel)
  * key; mirrors prepare()/retain() (spectrogram.rs:116-185).  n_mel = 0 with TH_FREQ_MEL selects
- * calc_mel_fb_default's count.  n_fft = 2^a * odd with a >= 1, odd <= 63, in [2, TH_MAX_N_FFT] and win <= n_fft (else
- * TH_ERR_UNSUPPORTED; mel plans whose dense filterbank would exceed 1 GiB are refused the same way): every
- * next_pow2(win) * f_overlap of spectrogram.rs:66-72 with f_overlap = 1 .. 63 (and their even multiples) — powers of two
- * run on the wave / block kernels, the others (f_overlap 3, 5, 6, ...: no UI control offers them) on the generic kernel. */
+ * calc_mel_fb_default's count.  n_fft: every EVEN value in [2, TH_MAX_N_FFT], win <= n_fft (else TH_ERR_UNSUPPORTED; mel
+ * plans whose dense filterbank would exceed 1 GiB are refused the same way): every next_pow2(win) * f_overlap of
+ * spectrogram.rs:66-72 up to the limit — powers of two run on the wave / block kernels, 2^a * odd with odd <= 63
+ * (f_overlap 3, 5, 6, ...) on the generic kernel with the odd factor as one more pass, larger odd factors (f_overlap 67,
+ * 71, 130, ...; round 6) as a chirp-z convolution in double precision.  No UI control offers the last two kinds. */
 TH_API int th_plan_create(th_ctx *ctx, uint32_t sr, size_t win, size_t hop, size_t n_fft, int freq_scale,
                           size_t n_mel, th_plan **out);
 TH_API int th_plan_destroy(th_plan *plan);
@@ -371,9 +372,8 @@ TH_API int th_tm_destroy(th_tm *tm);
 /* init(colormap_rgba) — lib.rs:51-98, render_tiles.rs:80-85; sets colormap_length = bytes/4 */
 TH_API int th_tm_set_colormap(th_tm *tm, const uint8_t *rgba, size_t bytes);
 /* TrackManager::set_setting — core/mod.rs:107-115 (recomputes every resident track).  Transactional: when the new
- * setting cannot be planned (this library takes n_fft = next_pow2(win) * f_overlap up to TH_MAX_N_FFT with an odd factor
- * of at most 63, which covers every window length the UI accepts and f_overlap = 3, 5, 6, ... since round 5; the reference's
- * realfft takes any length, so e.g. f_overlap = 67 is valid there and TH_ERR_UNSUPPORTED here) or memory runs out, the call
+ * setting cannot be planned (this library takes every n_fft = next_pow2(win) * f_overlap up to TH_MAX_N_FFT = 2^20 — any
+ * f_overlap since round 6; beyond the limit, or with a mel filterbank above 1 GiB, TH_ERR_UNSUPPORTED) or memory runs out, the call
  * fails and the manager — settings, plans,
  * specs, images, revisions — is exactly as before.  th_tm_add_tracks gives the same guarantee. */
 TH_API int th_tm_set_setting(th_tm *tm, double win_ms, uint32_t t_overlap, uint32_t f_overlap, int freq_scale);

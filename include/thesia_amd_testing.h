@@ -18,7 +18,7 @@
  * shapes: 8, 12 or 16), 7 = as 3 with the matrix-core kernel also where 3 runs the
  * banded-sum kernel over the amplitude rows (n_fft 512 under filters of at most 8 bins: the default mel counts of 8-12 kHz audio),
  * 8 = the fused mel epilogue in its pieces / gather form where banded sums are the default (A/B),
- * 12 = mel plans at n_fft 4096: the two kernels (FFT kernel -> amplitude rows -> banded sums / matrix cores) where the moment-form
+ * 12 = mel plans at n_fft 4096 / 8192 / 16384: the two kernels (FFT kernel -> amplitude rows -> banded sums / matrix cores) where the moment-form
  * epilogue is the default (hop 1024, the 96 / 88.2 kHz defaults; round 5's route, kept for A/B; elsewhere as 2),
  * 13 = the fused mel epilogue one frame at a time where frame pairs are the default (n_fft 1024 / 2048 banded sums; A/B, bit-identical),
  * 14 = the workgroup-per-frame Stockham kernel where stft_subwave_kernel is the default (n_fft 16384 at hops other than n_fft / 4),

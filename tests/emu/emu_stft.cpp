@@ -13,6 +13,7 @@
 
 #include "../../thesia_amd/csrc/stft_block.h"
 #include "../../thesia_amd/csrc/mel_fuse.h"
+#include "../../thesia_amd/csrc/host_math.h"  // bluestein_tables (host_math.cpp is compiled into the emulator)
 
 using namespace th;
 
@@ -572,3 +573,42 @@ extern "C" __attribute__((visibility("default"))) int emu_mel_moments(const floa
     }
     return 0;
 }
+
+// The chirp-z plan (an odd factor of n_fft above 63; stft_bluestein_kernel): the kernel's phases (stft_core.h) run by one
+// "thread" over the tables the plan uploads (bluestein_tables, host_math.cpp).  Every frame incl. the reflected boundary
+// frames; out[f][k] = amplitude (not dB).  Returns M.
+extern "C" __attribute__((visibility("default"))) int emu_stft_bluestein(const float *wav, uint32_t n_samples, uint32_t win, uint32_t hop,
+                                                                          uint32_t n_fft, const float *window, uint32_t n_frames, float *out) {
+    if (n_fft < 2 || n_fft % 2) return -1;
+    StftGeom g{};
+    g.hop = hop;
+    g.win = win;
+    g.n_fft = n_fft;
+    g.pad_left = (n_fft - win) / 2;
+    g.nc = n_fft / 2;
+    g.n_freq = n_fft / 2 + 1;
+    g.height = g.n_freq;
+    uint32_t M = 1;
+    while (M < 2 * g.nc - 1) M <<= 1;
+    const BluesteinTables bt = bluestein_tables(n_fft, M);
+    if (bt.chirp.size() != 2 * (size_t)g.nc || bt.bhat.size() != 2 * (size_t)M || bt.tws.size() != 2 * (size_t)(g.nc / 2 + 1)) return -2;
+    const cf64 *chirp = reinterpret_cast<const cf64 *>(bt.chirp.data()), *bhat = reinterpret_cast<const cf64 *>(bt.bhat.data());
+    const cf64 *twm = reinterpret_cast<const cf64 *>(bt.twm.data()), *tws = reinterpret_cast<const cf64 *>(bt.tws.data());
+    std::vector<cf64> a(M), b(M);
+    for (uint32_t f = 0; f < n_frames; f++) {
+        const int64_t s0 = (int64_t)f * hop - (int64_t)(win / 2);
+        bluestein_load(0, 1, g, M, wav, n_samples, s0, window, chirp, a.data());
+        cf64 *in = a.data(), *o = b.data();
+        for (int pass = 0; pass < 2; pass++) {
+            for (uint32_t Ns = 1; Ns < M; Ns <<= 1) {
+                bluestein_pass(0, 1, M, Ns, twm, in, o);
+                std::swap(in, o);
+            }
+            if (pass == 0) bluestein_product(0, 1, M, bhat, in);
+        }
+        bluestein_unchirp(0, 1, g, M, chirp, in, o);
+        bluestein_split(0, 1, g, tws, o, out + (size_t)f * g.n_freq);
+    }
+    return (int)M;
+}
+

@@ -322,3 +322,27 @@ def test_moment_form_refuses_what_is_not_a_triangle_filterbank(emu):
     out, info, dev = np.empty(M, np.float32), np.zeros(6, np.uint32), np.zeros(2, np.float64)
     assert emu.emu_mel_moments(slab.ctypes.data_as(f32p), slab.size, fb.ctypes.data_as(f32p), lin.ctypes.data_as(f32p), mf.ctypes.data_as(f32p),
                                F, M, 1, out.ctypes.data_as(f32p), info.ctypes.data_as(u32p), dev.ctypes.data_as(f64p)) == 1
+
+
+@pytest.mark.parametrize("sr,win_ms,t_overlap,f_overlap", [(4000, 0.5, 1, 67), (8000, 2.0, 4, 65), (16000, 8.0, 2, 71), (8000, 2.0, 2, 130),
+                                                           (4000, 0.5, 1, 3), (48000, 5.0, 4, 1)])
+def test_chirp_z_plan_on_the_cpu(emu, sr, win_ms, t_overlap, f_overlap):
+    """stft_bluestein_kernel's phases (stft_core.h: bluestein_load / _pass / _product / _unchirp / _split) over the tables the plan
+    uploads (host_math.cpp: bluestein_tables) — the path n_fft takes when its odd factor is above 63 (f_overlap 65, 67, 71, 130;
+    spectrogram.rs:66-72) — against the oracle's f64 DFT, boundary frames (reflect padding) and a channel shorter than the window
+    included.  The algorithm does not care what n_fft is: a small odd factor and a power of two go through it here as well.
+    Double precision throughout: the amplitudes are the oracle's to f32 rounding."""
+    hop, win, n_fft = orc.calc_framing_params(win_ms, t_overlap, f_overlap, sr)
+    emu.emu_stft_bluestein.argtypes = emu.emu_stft_wave.argtypes
+    f32p = C.POINTER(C.c_float)
+    w = orc.calc_normalized_win(win, n_fft)
+    for n in (3 * n_fft + 17, max(2, win // 3)):
+        x = synth_track(300 + n_fft, sr, n)
+        T = orc.stft_n_frames(n, win, hop)
+        out = np.empty((T, n_fft // 2 + 1), np.float32)
+        M = emu.emu_stft_bluestein(x.ctypes.data_as(f32p), n, win, hop, n_fft, w.ctypes.data_as(f32p), T, out.ctypes.data_as(f32p))
+        assert M >= n_fft - 1 and M & (M - 1) == 0 and M < 2 * n_fft
+        _, amp = orc.calc_spec(x, win, hop, n_fft, return_amp=True)
+        assert amp.shape == out.shape
+        assert np.abs(out - amp).max() <= 2e-7 * amp.max() + 1e-30, np.abs(out - amp).max() / amp.max()
+

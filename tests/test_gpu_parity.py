@@ -191,16 +191,26 @@ def test_subwave_plan(ctx, sr, win, hop, n_fft, scale, n_mel):
                                                                   (8000, 2.0, 4, 7, 1), (48000, 170.0, 4, 3, 0), (48000, 0.05, 1, 3, 0),
                                                                   # n_fft = 2 * odd: Nc is odd — no radix-2 / radix-4 pass at all,
                                                                   # the odd pass alone with Ns = 1, then the split pass: n_fft 6 and 10
-                                                                  (4000, 0.5, 1, 3, 0), (4000, 0.5, 2, 5, 0), (4000, 0.5, 1, 7, 1)])
+                                                                  (4000, 0.5, 1, 3, 0), (4000, 0.5, 2, 5, 0), (4000, 0.5, 1, 7, 1),
+                                                                  # an odd factor above 63 (round 6): the chirp-z kernel.  n_fft 134 (Nc = 67, a prime),
+                                                                  # 1040 = 16 * 65, 9088 = 128 * 71 with the mel default, 2080 = 16 * 130,
+                                                                  # 137216 = 2048 * 67 (the 40 ms default at f_overlap 67: M = 2^18), 130 * 2 = 260 under mel
+                                                                  (4000, 0.5, 1, 67, 0), (8000, 2.0, 4, 65, 0), (16000, 8.0, 2, 71, 1), (8000, 2.0, 2, 130, 0),
+                                                                  (48000, 40.0, 4, 67, 0), (4000, 0.5, 1, 130, 1)])
 def test_f_overlap_that_is_not_a_power_of_two(ctx, sr, win_ms, t_overlap, f_overlap, scale):
     """SpecSetting::calc_framing_params (spectrogram.rs:66-72): n_fft = next_pow2(win) * f_overlap for ANY integer f_overlap, and
     the reference's realfft plans any length.  No UI control offers f_overlap 3, 5, 6, 7 — the API accepts them: the generic
-    kernel takes the odd factor of Nc as one more Stockham pass (round 5; it was TH_ERR_UNSUPPORTED).  n_fft 6144, 10240, 768,
-    112, 49152 (global scratch), 12 against the oracle's f64 DFT on a ragged batch incl. a channel shorter than the window."""
+    kernel takes the odd factor of Nc as one more Stockham pass (round 5; it was TH_ERR_UNSUPPORTED), and an odd factor above 63
+    runs as a chirp-z convolution in double precision (round 6, stft_bluestein_kernel: f_overlap 65, 67, 71, 130).  n_fft 6144,
+    10240, 768, 112, 49152 (global scratch), 12, ... against the oracle's f64 DFT on a ragged batch incl. a channel shorter than
+    the window."""
     hop, win, n_fft = ta.calc_framing_params(win_ms, t_overlap, f_overlap, sr)
     assert n_fft & (n_fft - 1) and n_fft == (1 << (win - 1).bit_length()) * f_overlap
     plan = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL if scale else ta.LINEAR, 0)
-    assert plan.kernel_name == "stft_generic_kernel"
+    odd = n_fft
+    while odd % 2 == 0:
+        odd //= 2
+    assert plan.kernel_name == ("stft_bluestein_kernel" if odd > 63 else "stft_generic_kernel")
     fb = orc.calc_mel_fb_default(sr, n_fft) if scale else None
     lens = [3 * n_fft + 17, n_fft + 2 * hop + 1, max(2, win // 3), 5 * hop + 3] if n_fft <= 12288 else [2 * n_fft + 5, n_fft // 2]
     wavs = [synth_track(900 + i, sr, n) for i, n in enumerate(lens)]
@@ -222,10 +232,13 @@ def test_f_overlap_that_is_not_a_power_of_two(ctx, sr, win_ms, t_overlap, f_over
 
 
 def test_transform_size_limits(ctx):
-    """n_fft = 2^a * odd (a >= 1, odd <= 63) from 2 to TH_MAX_N_FFT (2^20) is planned — powers of two on the fast kernels, the
-    rest (f_overlap = 3, 5, 6, ...: round 5) on the generic kernel; everything else is TH_ERR_UNSUPPORTED, as is a mel plan
-    whose dense filterbank would not fit 1 GiB"""
-    for bad in (3, 2 * 67, 4096 * 65, 1 << 21):
+    """every even n_fft from 2 to TH_MAX_N_FFT (2^20) is planned — powers of two on the fast kernels, 2^a * odd with odd <= 63
+    (f_overlap = 3, 5, 6, ...: round 5) on the generic kernel, larger odd factors on the chirp-z kernel (round 6); an odd n_fft
+    (no next_pow2(win) * f_overlap is one) and anything above the limit is TH_ERR_UNSUPPORTED, as is a mel plan whose dense
+    filterbank would not fit 1 GiB"""
+    for ok in (2 * 67, 4096 * 65):
+        ta.Plan(ctx, 48000, min(ok, 2048), 512, ok, ta.LINEAR).close()
+    for bad in (3, 6145, (1 << 20) + 2, 1 << 21):
         with pytest.raises(ta.ThError) as e:
             ta.Plan(ctx, 48000, min(bad, 2048), 512, bad, ta.LINEAR)
         assert e.value.code == -2
@@ -780,8 +793,16 @@ def test_calc_spec_golden_f64_fixtures(ctx, golden_dir):
 
 def test_plan_rejects_unsupported(ctx):
     with pytest.raises(ta.ThError) as e:
-        ta.Plan(ctx, 48000, 1500, 500, 3000)
+        ta.Plan(ctx, 48000, 1500, 500, 3001)   # an odd n_fft (no next_pow2(win) * f_overlap is one)
     assert e.value.code == -2
+    # n_fft 3000 = 8 * 375 was refused until round 6 (odd factor above 63): the chirp-z kernel takes it, whatever produced it
+    plan = ta.Plan(ctx, 48000, 1500, 500, 3000)
+    assert plan.kernel_name == "stft_bluestein_kernel"
+    x = synth_track(5, 48000, 20011)
+    spec, _, _ = plan.calc_spec(x)
+    want, amp = orc.calc_spec(x, 1500, 500, 3000, return_amp=True)
+    assert_spec_close(spec, want, amp)
+    plan.close()
     with pytest.raises(ta.ThError):
         ta.Plan(ctx, 48000, 4096, 512, 2048)  # win > n_fft
 
@@ -1329,7 +1350,7 @@ def test_lod_mip_pyramid_long_track(ctx):
 
 
 def test_track_manager_failed_setting_changes_nothing(ctx, golden_dir):
-    """a setting this library cannot plan (f_overlap = 67 -> an odd factor the generic kernel does not take; the reference's realfft
+    """a setting this library cannot plan (f_overlap = 1024 -> n_fft 2^21, above TH_MAX_N_FFT; the reference's realfft
     would take it) must fail WITHOUT touching the manager: settings, specs, images, db state, tiles and revisions are
     as before, and later calls keep working with the old setting."""
     cmap = open(f"{golden_dir}/colormap_inferno_rgba258.bin", "rb").read()
@@ -1341,7 +1362,7 @@ def test_track_manager_failed_setting_changes_nothing(ctx, golden_dir):
     tm.apply_track_list_changes()
     before = (tm.spec(7, 0).copy(), tm.img(7, 0).copy(), tm.db_state(), tm.revisions(), tm.get_spectrogram_tile(7, 0, 0, 0, 0, 0),
               tm.get_waveform_tile(7, 0, 3, 0))
-    for bad in [(40.0, 4, 67, ta.LINEAR), (40.0, 4, 1024, ta.MEL)]:  # n_fft 2048 * 67 (odd factor > 63), 2^21 (> TH_MAX_N_FFT)
+    for bad in [(40.0, 4, 1024, ta.LINEAR), (40.0, 4, 1024, ta.MEL)]:  # n_fft 2^21 (> TH_MAX_N_FFT)
         with pytest.raises(ta.ThError) as e:
             tm.set_setting(*bad)
         assert e.value.code == -2, e.value

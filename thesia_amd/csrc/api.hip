@@ -428,6 +428,10 @@ static void plan_free(th_plan *p) {
     p->mel_jobs.release();
     p->mel_tile_start.release();
     if (p->d_window) (void)hipFree(p->d_window);
+    if (p->d_bs_chirp) (void)hipFree(p->d_bs_chirp);
+    if (p->d_bs_bhat) (void)hipFree(p->d_bs_bhat);
+    if (p->d_bs_twm) (void)hipFree(p->d_bs_twm);
+    if (p->d_bs_tws) (void)hipFree(p->d_bs_tws);
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_twc) (void)hipFree(p->d_twc);
     if (p->d_mel_fb) (void)hipFree(p->d_mel_fb);
@@ -459,8 +463,10 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
     // kernel, which takes the odd factor as one more Stockham pass.
     size_t odd_part = n_fft;
     while (odd_part > 1 && odd_part % 2 == 0) odd_part /= 2;
-    if (n_fft < 2 || n_fft % 2 != 0 || n_fft > TH_MAX_N_FFT || odd_part > 63)
-        return fail(TH_ERR_UNSUPPORTED, "n_fft=%zu: supported are 2^a * odd with a >= 1 and odd <= 63, up to %u", n_fft, (unsigned)TH_MAX_N_FFT);
+    // Round 6: an odd factor above 63 (f_overlap = 67, 71, 130, ...) runs as a chirp-z convolution (stft_bluestein_kernel): every
+    // even n_fft up to TH_MAX_N_FFT is planned.  (n_fft = next_pow2(win) * f_overlap is even for every win > 1.)
+    if (n_fft < 2 || n_fft % 2 != 0 || n_fft > TH_MAX_N_FFT)
+        return fail(TH_ERR_UNSUPPORTED, "n_fft=%zu: supported is every even n_fft from 2 to %u", n_fft, (unsigned)TH_MAX_N_FFT);
     TH_HIP(hipSetDevice(c->device));
 
     th_plan *p = new th_plan();
@@ -526,6 +532,13 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
         rc = up((void **)&p->d_queue_head, zero, sizeof zero);
     }
     if (rc == TH_OK) rc = up((void **)&p->d_tw, tw.data(), tw.size() * sizeof(cf32));
+    if (rc == TH_OK && odd_part > th::STFT_MAX_DIRECT_ODD) {  // Bluestein plan: chirp, FFT_M(b), twiddles of the M-point passes and of the split pass (doubles)
+        const BluesteinTables bt = bluestein_tables(n_fft, th::stft_bluestein_m(g));
+        rc = up((void **)&p->d_bs_chirp, bt.chirp.data(), bt.chirp.size() * sizeof(double));
+        if (rc == TH_OK) rc = up((void **)&p->d_bs_bhat, bt.bhat.data(), bt.bhat.size() * sizeof(double));
+        if (rc == TH_OK) rc = up((void **)&p->d_bs_twm, bt.twm.data(), bt.twm.size() * sizeof(double));
+        if (rc == TH_OK) rc = up((void **)&p->d_bs_tws, bt.tws.data(), bt.tws.size() * sizeof(double));
+    }
     if (rc == TH_OK && th::stft_subwave_applies(g)) {  // n_fft 32768: per-thread constants of stft_subwave_kernel's combining pass
         std::vector<cf32> twc(th::stft_subwave_twc_len(g));
         th::stft_subwave_build_twc(g, tw.data(), twc.data());
@@ -791,7 +804,7 @@ TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (p->use_mel_mfma()) return subwave ? "stft_subwave_kernel+mel_mfma_kernel" : th::stft_is_block_plan(p->g) ? "stft_block_kernel+mel_mfma_kernel" : "stft_wave_kernel+mel_mfma_kernel";
     if (p->use_wave() && subwave) return "stft_subwave_kernel";
     if (p->use_wave() && th::stft_is_block_plan(p->g)) return "stft_block_kernel";
-    return p->use_wave() ? "stft_wave_kernel" : "stft_generic_kernel";
+    return p->use_wave() ? "stft_wave_kernel" : p->bluestein() ? "stft_bluestein_kernel" : "stft_generic_kernel";
 }
 
 TH_API size_t th_pitch_f32(size_t n) { return (n + 31) / 32 * 32; }
@@ -1070,7 +1083,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     if (rc != TH_OK) return rc;
     {   // n_fft >= 32768: the generic kernel's frame buffers live in global scratch (all frames of a plan without a fast
         // kernel, or the boundary frames of the n_fft 32768 block plan)
-        const size_t need = !wave ? th::stft_generic_scratch_bytes(g, (uint32_t)tiles, c->n_cu)
+        const size_t need = !wave ? (p->bluestein() ? th::stft_bluestein_scratch_bytes(g, (uint32_t)tiles, c->n_cu) : th::stft_generic_scratch_bytes(g, (uint32_t)tiles, c->n_cu))
                                   : (edge.empty() ? 0 : th::stft_generic_scratch_bytes(ge, (uint32_t)edge_tiles, c->n_cu));
         if (need) {
             if (need > p->gen_scratch.cap) TH_HIP(hipStreamSynchronize(c->stream));  // (a launch may still use the old buffer)
@@ -1177,6 +1190,11 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
                                        (uint32_t)edge.size(), (uint32_t)edge_tiles, p->d_window, p->d_tw, p->d_mel_fb,
                                        p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream, p->gen_scratch.dptr, c->n_cu));
     } else {
+        if (p->bluestein())
+            TH_HIP(launch_stft_bluestein(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr, (uint32_t)jobs.size(),
+                                         (uint32_t)tiles, p->d_window, p->d_bs_chirp, p->d_bs_bhat, p->d_bs_twm, p->d_bs_tws, p->d_mel_fb,
+                                         p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream, p->gen_scratch.dptr, c->n_cu));
+        else
         TH_HIP(launch_stft_generic(g, (const ChanJob *)p->jobs.dptr, (const uint32_t *)p->tile_start.dptr,
                                    (uint32_t)jobs.size(), (uint32_t)tiles, p->d_window, p->d_tw, p->d_mel_fb,
                                    p->d_mel_lo, p->d_mel_hi, d_minmax, c->stream, p->gen_scratch.dptr, c->n_cu));

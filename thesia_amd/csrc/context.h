@@ -75,6 +75,9 @@ struct th_plan {
     th::StftGeom g{};
     float *d_window = nullptr;
     th::cf32 *d_tw = nullptr;
+    // Bluestein plans (an odd factor of n_fft above 63; stft_bluestein_kernel): complex-double tables, NULL otherwise
+    double *d_bs_chirp = nullptr, *d_bs_bhat = nullptr, *d_bs_twm = nullptr, *d_bs_tws = nullptr;
+    bool bluestein() const { return d_bs_chirp != nullptr; }
     uint32_t *d_queue_head = nullptr;  // wave kernel: chunk queue head (rewound by wave_post_kernel after every launch)
     bool queue_dirty = false;          // a wave launch went out whose rewind did not: the next launch zeroes the head first
     th::cf32 *d_wtab = nullptr;  // wave kernel: 0.5 * zero-padded window as (even, odd) pairs

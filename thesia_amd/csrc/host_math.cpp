@@ -275,4 +275,55 @@ void LodAxisHost::pack(unsigned char *p, size_t n_out) const {
     std::memcpy(p + n_out * 16, w.data(), w.size() * 8);
 }
 
+
+BluesteinTables bluestein_tables(size_t n_fft, size_t M) {
+    BluesteinTables t;
+    const size_t nc = n_fft / 2, h = M / 2;
+    t.chirp.resize(2 * nc);
+    for (size_t n = 0; n < nc; n++) {
+        const uint64_t r = (uint64_t)n * n % (2 * (uint64_t)nc);  // e^{-i pi n^2 / nc} has period 2 nc in n^2
+        const double a = -M_PI * (double)r / (double)nc;
+        t.chirp[2 * n] = std::cos(a);
+        t.chirp[2 * n + 1] = std::sin(a);
+    }
+    t.twm.resize(2 * std::max<size_t>(h, 1));
+    for (size_t k = 0; k < std::max<size_t>(h, 1); k++) {
+        const double a = -2.0 * M_PI * (double)k / (double)M;
+        t.twm[2 * k] = std::cos(a);
+        t.twm[2 * k + 1] = std::sin(a);
+    }
+    t.tws.resize(2 * (nc / 2 + 1));
+    for (size_t k = 0; k <= nc / 2; k++) {
+        const double a = -2.0 * M_PI * (double)k / (double)n_fft;
+        t.tws[2 * k] = std::cos(a);
+        t.tws[2 * k + 1] = std::sin(a);
+    }
+    // bhat = FFT_M(b): radix-2 Stockham, the kernel's own pass structure
+    std::vector<double> x(2 * M, 0.0), y(2 * M, 0.0);
+    for (size_t n = 0; n < nc; n++) {
+        x[2 * n] = t.chirp[2 * n];
+        x[2 * n + 1] = -t.chirp[2 * n + 1];
+        if (n) {
+            x[2 * (M - n)] = t.chirp[2 * n];
+            x[2 * (M - n) + 1] = -t.chirp[2 * n + 1];
+        }
+    }
+    for (size_t Ns = 1; Ns < M; Ns <<= 1) {
+        const size_t step = h / Ns;
+        for (size_t j = 0; j < h; j++) {
+            const size_t k = j & (Ns - 1), j0 = (j - k) * 2 + k;
+            const double wr = t.twm[2 * k * step], wi = t.twm[2 * k * step + 1];
+            const double ar = x[2 * j], ai = x[2 * j + 1], br0 = x[2 * (j + h)], bi0 = x[2 * (j + h) + 1];
+            const double br = br0 * wr - bi0 * wi, bi = br0 * wi + bi0 * wr;
+            y[2 * j0] = ar + br;
+            y[2 * j0 + 1] = ai + bi;
+            y[2 * (j0 + Ns)] = ar - br;
+            y[2 * (j0 + Ns) + 1] = ai - bi;
+        }
+        x.swap(y);
+    }
+    t.bhat = std::move(x);
+    return t;
+}
+
 }  // namespace th

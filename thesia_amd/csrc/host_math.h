@@ -21,6 +21,14 @@ void hz_range_to_idx(int freq_scale, float hz0, float hz1, uint32_t sr, size_t n
 void shard_assign(const uint64_t *weights, size_t n, uint32_t world, uint32_t *owner);
 void global_db_range(const float *mins, const float *maxs, size_t n, float dB_range, float *mn, float *mx);
 
+// Tables of a Bluestein plan (stft_bluestein_kernel, kernels_stft.hip): interleaved (re, im) doubles.  nc = n_fft / 2 points,
+// M = 2^m >= 2 nc - 1.  chirp[n] = e^{-i pi n^2 / nc} (n^2 reduced mod 2 nc before the angle is formed), bhat = FFT_M of
+// b[n] = b[M - n] = conj chirp[n], twm[k] = e^{-2 pi i k / M} (k < M / 2), tws[k] = e^{-2 pi i k / n_fft} (k <= nc / 2).
+struct BluesteinTables {
+    std::vector<double> chirp, bhat, twm, tws;
+};
+BluesteinTables bluestein_tables(size_t n_fft, size_t M);
+
 struct TileGeom {
     size_t width, height, origin_x, origin_y, lod_w, lod_h;
 };

@@ -40,6 +40,15 @@ size_t stft_generic_lds_bytes(const StftGeom &g);
 // n_fft >= 32768: the generic kernel keeps its two frame buffers in global scratch (d_scratch, at least
 // stft_generic_scratch_bytes) instead of LDS and runs as a persistent grid; 0 bytes = the LDS variant, no scratch needed
 size_t stft_generic_scratch_bytes(const StftGeom &g, uint32_t n_tiles, uint32_t n_cu);
+// Bluestein plans (an odd factor of n_fft above 63; stft_bluestein_kernel): convolution length, scratch bytes of a launch, launch.
+// d_chirp[nc], d_bhat[M], d_twm[M / 2], d_tws[nc / 2 + 1]: complex doubles (bluestein_tables, host_math.h)
+constexpr uint32_t STFT_MAX_DIRECT_ODD = 63;  // the largest odd factor the generic kernel takes as one direct pass
+uint32_t stft_bluestein_m(const StftGeom &g);
+size_t stft_bluestein_scratch_bytes(const StftGeom &g, uint32_t n_tiles, uint32_t n_cu);
+hipError_t launch_stft_bluestein(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan, uint32_t n_tiles,
+                                 const float *d_window, const void *d_chirp, const void *d_bhat, const void *d_twm, const void *d_tws,
+                                 const float *d_mel_fb, const uint32_t *d_mel_lo, const uint32_t *d_mel_hi, float *d_minmax, hipStream_t s,
+                                 void *d_scratch, uint32_t n_cu);
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,
                                uint32_t n_chan, uint32_t n_tiles, const float *d_window, const cf32 *d_tw,
                                const float *d_mel_fb, const uint32_t *d_mel_lo, const uint32_t *d_mel_hi,

@@ -203,6 +203,95 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Bluestein kernel (round 6): n_fft = 2^a * odd with an odd factor above 63 — f_overlap = 67, 71, 130, ...
+// (spectrogram.rs:66-72: n_fft = next_pow2(win) * f_overlap for ANY integer f_overlap; the reference's realfft plans any
+// length; no UI control offers such values).  The packed Nc-point transform of a frame (Nc = n_fft / 2, any integer) as a
+// circular convolution of length M = 2^m >= 2 Nc - 1 with the chirp c[n] = e^{-i pi n^2 / Nc}:
+//   Z[k] = c[k] * IFFT_M( FFT_M(z c) . FFT_M(b) )[k],   b[n] = b[M - n] = conj c[n]  (n < Nc), 0 elsewhere,
+// in DOUBLE precision throughout (chirp products reach M |z|: in f32 the result would carry ~1e-5 of the frame maximum, above the
+// 1e-3 dB bar of the parity tests; the card's f64 rate makes that free for a path no UI reaches): radix-2 Stockham passes over
+// two M-point cf64 buffers per workgroup in global scratch, FFT_M(b) from the host, the inverse transform as conj FFT conj.
+// The samples are windowed in f32 as the reference does (stft.rs:137-146); split pass and magnitudes in f64, rounded once.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEN_THREADS) void stft_bluestein_kernel(
+    StftGeom g, const ChanJob *__restrict__ jobs, const uint32_t *__restrict__ tile_start, uint32_t n_chan, uint32_t n_tiles,
+    const float *__restrict__ window, const cf64 *__restrict__ chirp, const cf64 *__restrict__ bhat, const cf64 *__restrict__ twm,
+    const cf64 *__restrict__ tws, const float *__restrict__ mel_fb, const uint32_t *__restrict__ mel_lo,
+    const uint32_t *__restrict__ mel_hi, float *__restrict__ minmax, cf64 *__restrict__ scratch, uint32_t M) {
+    cf64 *const bufA = scratch + (size_t)blockIdx.x * 2u * M, *const bufB = bufA + M;
+    __shared__ float red[2 * (GEN_THREADS / 64)];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t chan = find_chan(tile_start, n_chan, tile);
+        const ChanJob job = jobs[chan];
+        const uint32_t f0 = job.f_begin + (tile - tile_start[chan]) * g.frames_per_tile;
+        const uint32_t f1 = min(f0 + g.frames_per_tile, job.f_end);
+        float lmin = __builtin_inff(), lmax = -__builtin_inff();
+        for (uint32_t f = f0; f < f1; f++) {
+            const int64_t s0 = (int64_t)f * g.hop - (int64_t)(g.win / 2);
+            bluestein_load(tid, GEN_THREADS, g, M, as_global(job.wav), job.n_samples, s0, as_global(window), chirp, bufA);
+            __syncthreads();
+            cf64 *in = bufA, *out = bufB;
+            for (int pass = 0; pass < 2; pass++) {  // FFT_M, then (behind the product with FFT_M(b)) the inverse as conj FFT conj
+                for (uint32_t Ns = 1; Ns < M; Ns <<= 1) {
+                    bluestein_pass(tid, GEN_THREADS, M, Ns, twm, in, out);
+                    __syncthreads();
+                    cf64 *t = in; in = out; out = t;
+                }
+                if (pass == 0) {
+                    bluestein_product(tid, GEN_THREADS, M, bhat, in);
+                    __syncthreads();
+                }
+            }
+            bluestein_unchirp(tid, GEN_THREADS, g, M, chirp, in, out);  // Z in `out`
+            __syncthreads();
+            float *const mag = reinterpret_cast<float *>(in);  // (nc + 1 floats fit the nc cf64 of the transform's buffer)
+            bluestein_split(tid, GEN_THREADS, g, tws, out, mag);
+            __syncthreads();
+            const gptr<float> row = as_global(job.spec) + (size_t)f * job.spec_pitch;
+            if (g.n_mel == 0) {
+                for (uint32_t k = tid; k < g.n_freq; k += GEN_THREADS) {
+                    const float d = amp_to_dB(mag[k]);
+                    row[k] = d;
+                    lmin = nmin(lmin, d);
+                    lmax = nmax(lmax, d);
+                }
+            } else {  // linspec.dot(mel_fb) restricted to each filter's non-zero band, ascending f (as the generic kernel)
+                for (uint32_t m = tid; m < g.n_mel; m += GEN_THREADS) {
+                    float acc = 0.0f;
+                    const uint32_t lo = mel_lo[m], hi = mel_hi[m];
+                    for (uint32_t k = lo; k < hi; k++) acc += mag[k] * mel_fb[(size_t)k * g.n_mel + m];
+                    const float d = amp_to_dB(acc);
+                    row[m] = d;
+                    lmin = nmin(lmin, d);
+                    lmax = nmax(lmax, d);
+                }
+            }
+            __syncthreads();
+        }
+        if (minmax != nullptr) {
+            lmin = wave_min(lmin);
+            lmax = wave_max(lmax);
+            if ((tid & 63) == 0) {
+                red[2 * (tid >> 6)] = lmin;
+                red[2 * (tid >> 6) + 1] = lmax;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float a = red[0], b = red[1];
+                for (int w = 1; w < GEN_THREADS / 64; w++) {
+                    a = nmin(a, red[2 * w]);
+                    b = nmax(b, red[2 * w + 1]);
+                }
+                atomic_min_f32(&minmax[2 * job.mm_index], a);
+                atomic_max_f32(&minmax[2 * job.mm_index + 1], b);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 #endif  // TH_PART_MAIN (generic kernel)
 // ------------------------------------------------------------------------------------------
 // Wave kernel (the fast path): one 64-lane wave per frame, n_fft in {1024, 2048, 4096}, linear
@@ -2102,6 +2191,31 @@ uint32_t stft_generic_scratch_grid(const StftGeom &g, uint32_t n_tiles, uint32_t
 }
 size_t stft_generic_scratch_bytes(const StftGeom &g, uint32_t n_tiles, uint32_t n_cu) {
     return (size_t)stft_generic_scratch_grid(g, n_tiles, n_cu) * stft_generic_lds_bytes(g);
+}
+
+// Bluestein plans: M = 2^m >= 2 Nc - 1; two M-point cf64 buffers per workgroup, at most 1 GiB of scratch per plan
+uint32_t stft_bluestein_m(const StftGeom &g) {
+    uint32_t M = 1;
+    while (M < 2u * g.nc - 1u) M <<= 1;
+    return M;
+}
+static uint32_t stft_bluestein_grid(const StftGeom &g, uint32_t n_tiles, uint32_t n_cu) {
+    const size_t per_wg = 2 * (size_t)stft_bluestein_m(g) * sizeof(cf64);
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>({(size_t)n_tiles, (size_t)n_cu * 4, ((size_t)1 << 30) / per_wg}));
+}
+size_t stft_bluestein_scratch_bytes(const StftGeom &g, uint32_t n_tiles, uint32_t n_cu) {
+    return n_tiles ? (size_t)stft_bluestein_grid(g, n_tiles, n_cu) * 2 * (size_t)stft_bluestein_m(g) * sizeof(cf64) : 0;
+}
+hipError_t launch_stft_bluestein(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start, uint32_t n_chan, uint32_t n_tiles,
+                                 const float *d_window, const void *d_chirp, const void *d_bhat, const void *d_twm, const void *d_tws,
+                                 const float *d_mel_fb, const uint32_t *d_mel_lo, const uint32_t *d_mel_hi, float *d_minmax, hipStream_t s,
+                                 void *d_scratch, uint32_t n_cu) {
+    if (!n_tiles) return hipSuccess;
+    if (d_scratch == nullptr || d_chirp == nullptr || d_bhat == nullptr || d_twm == nullptr || d_tws == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stft_bluestein_kernel, dim3(stft_bluestein_grid(g, n_tiles, n_cu)), dim3(GEN_THREADS), 0, s, g, d_jobs, d_tile_start, n_chan,
+                       n_tiles, d_window, static_cast<const cf64 *>(d_chirp), static_cast<const cf64 *>(d_bhat), static_cast<const cf64 *>(d_twm),
+                       static_cast<const cf64 *>(d_tws), d_mel_fb, d_mel_lo, d_mel_hi, d_minmax, static_cast<cf64 *>(d_scratch), stft_bluestein_m(g));
+    return hipGetLastError();
 }
 
 hipError_t launch_stft_generic(const StftGeom &g, const ChanJob *d_jobs, const uint32_t *d_tile_start,

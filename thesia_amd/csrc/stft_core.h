@@ -245,4 +245,61 @@ TH_HD void gen_split(uint32_t tid, uint32_t nthr, const StftGeom &g, const cf32 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Phases of the Bluestein kernel (stft_bluestein_kernel, kernels_stft.hip; the CPU emulator runs them with one "thread"):
+// the packed Nc-point transform of a frame as a circular convolution of length M = 2^m >= 2 Nc - 1 with the chirp
+// c[n] = e^{-i pi n^2 / Nc}, in double precision.  Tables: bluestein_tables (host_math.h).
+// ---------------------------------------------------------------------------------------------
+struct cf64 {
+    double re, im;
+};
+TH_HD cf64 cmul64(cf64 a, cf64 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// a[n] = z[n] c[n] (z: the windowed samples as pairs, the product x * w in f32 as the reference forms it, stft.rs:137-146), 0 from Nc on
+template <class WavPtr, class WinPtr>
+TH_HD void bluestein_load(uint32_t tid, uint32_t nthr, const StftGeom &g, uint32_t M, WavPtr wav, uint32_t n_samples, int64_t s0, WinPtr window,
+                          const cf64 *chirp, cf64 *buf) {
+    for (uint32_t n = tid; n < M; n += nthr) {
+        cf64 a = {0.0, 0.0};
+        if (n < g.nc) {
+            const cf64 z = {(double)frame_value(wav, n_samples, s0, 2 * n, window, g), (double)frame_value(wav, n_samples, s0, 2 * n + 1, window, g)};
+            a = cmul64(z, chirp[n]);
+        }
+        buf[n] = a;
+    }
+}
+// one radix-2 Stockham pass of the M-point transform (sub-transform size Ns; twm[k] = W_M^k, k < M / 2)
+TH_HD void bluestein_pass(uint32_t tid, uint32_t nthr, uint32_t M, uint32_t Ns, const cf64 *twm, const cf64 *in, cf64 *out) {
+    const uint32_t h = M >> 1, tw_step = h / Ns;  // W_{2 Ns}^k = W_M^(k M / (2 Ns))
+    for (uint32_t j = tid; j < h; j += nthr) {
+        const uint32_t k = j & (Ns - 1);
+        const cf64 v0 = in[j], v1 = cmul64(in[j + h], twm[k * tw_step]);
+        const uint32_t j0 = (j - k) * 2 + k;
+        out[j0] = {v0.re + v1.re, v0.im + v1.im};
+        out[j0 + Ns] = {v0.re - v1.re, v0.im - v1.im};
+    }
+}
+// y <- conj(y FFT_M(b)): the inverse transform that follows is conj FFT conj
+TH_HD void bluestein_product(uint32_t tid, uint32_t nthr, uint32_t M, const cf64 *bhat, cf64 *y) {
+    for (uint32_t k = tid; k < M; k += nthr) {
+        const cf64 c = cmul64(y[k], bhat[k]);
+        y[k] = {c.re, -c.im};
+    }
+}
+// Z[k] = c[k] conj(Y[k]) / M, k < Nc
+TH_HD void bluestein_unchirp(uint32_t tid, uint32_t nthr, const StftGeom &g, uint32_t M, const cf64 *chirp, const cf64 *y, cf64 *z) {
+    const double inv_m = 1.0 / (double)M;
+    for (uint32_t k = tid; k < g.nc; k += nthr) z[k] = cmul64(cf64{y[k].re * inv_m, -y[k].im * inv_m}, chirp[k]);
+}
+// split pass of the packed real transform (split_pair) in f64, the magnitudes rounded once; tws[k] = W_{n_fft}^k, k <= Nc / 2
+TH_HD void bluestein_split(uint32_t tid, uint32_t nthr, const StftGeom &g, const cf64 *tws, const cf64 *z, float *mag) {
+    for (uint32_t k = tid; k <= g.nc / 2; k += nthr) {
+        const cf64 zk = z[k], zm = z[k ? g.nc - k : 0u];
+        const cf64 e = {0.5 * (zk.re + zm.re), 0.5 * (zk.im - zm.im)}, d = {0.5 * (zk.re - zm.re), 0.5 * (zk.im + zm.im)};
+        const cf64 t = cmul64(cf64{d.im, -d.re}, tws[k]);
+        const double kr = e.re + t.re, ki = e.im + t.im, mr = e.re - t.re, mi = e.im - t.im;
+        mag[k] = (float)__builtin_sqrt(kr * kr + ki * ki);
+        mag[g.nc - k] = (float)__builtin_sqrt(mr * mr + mi * mi);  // (k = 0 writes mag[nc], the Nyquist bin)
+    }
+}
+
 }  // namespace th
