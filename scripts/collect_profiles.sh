@@ -67,6 +67,10 @@ scripts/pmc_stft.sh "$out/pmc_melmfma48" --sr 48000 --nfft 4096 --mel 0 --kernel
 scripts/pmc_stft.sh "$out/pmc_stftmel48" --sr 48000 --win 1920 --hop 480 --mel 0 > "$out/pmc_stftmel48.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_stftmel48_one_frame" --sr 48000 --win 1920 --hop 480 --mel 0 --kernel 13 > "$out/pmc_stftmel48_one_frame.log" 2>&1  # round 5: the one-frame epilogue (the default takes frame pairs)
 scripts/pmc_stft.sh "$out/pmc_subwave32768" --nfft 32768 > "$out/pmc_subwave32768.log" 2>&1   # round 5: stft_subwave_kernel
+# round 6: the moment-form mel epilogue inside the workgroup-per-frame kernel (n_fft 16384 / 8192 Mel defaults) and the linear kernel beside it
+scripts/pmc_stft.sh "$out/pmc_blockmel16384" --nfft 16384 --mel 0 > "$out/pmc_blockmel16384.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_blockmel8192" --nfft 8192 --mel 0 > "$out/pmc_blockmel8192.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_block16384" --nfft 16384 > "$out/pmc_block16384.log" 2>&1
 fi
 if want 3; then
 {
@@ -125,6 +129,11 @@ python3 scripts/bench_cfg3.py > "$out/bench_cfg3.txt" 2>&1
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 96000 --nfft 4096 --win 3840 --hop 480 --seconds 30 --mel 0 --kernel 0 12
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 4096 --mel 0 --kernel 0 12
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 4096 --hop 2048 --mel 0 --kernel 0 12
+  # round 6: mel inside the workgroup-per-frame kernel (0, default) against the two kernels (12), 64 ch x 30 s
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --tracks 64 --nfft 16384 --mel 0 --kernel 0 12
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --tracks 64 --nfft 8192 --mel 0 --kernel 0 12
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --tracks 64 --nfft 16384
+  python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --tracks 64 --nfft 8192
   # round 4: the Mel default of long windows (more than 512 mels) on the two-kernel path against the generic kernel
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 4096 --mel 0 --kernel 0 1
   python3 scripts/bench_stft.py --reps 20 --gap-ms 1 --sr 48000 --nfft 8192 --mel 0 --kernel 0 1
@@ -135,6 +144,8 @@ if [ -f scripts/variants/libthesia_amd_wt.so ]; then
   THESIA_AMD_LIB=scripts/variants/libthesia_amd_wt.so python3 scripts/wave_times.py > "$out/wave_times.txt" 2>&1
 fi
 [ -x scripts/ubench/mom_probe ] && { for a in "96000 4096 0" "88200 4096 0" "48000 4096 0"; do timeout 60 scripts/ubench/mom_probe $a 64; done; } > "$out/ubench_mom_probe.txt" 2>&1
+timeout -k 10 200 python3 scripts/bluestein_probe.py 2>/dev/null | grep -v amdgpu.ids > "$out/bluestein_probe.txt"
+timeout -k 10 200 python3 scripts/fuzz_mel_moments.py 6 90 2>/dev/null | grep -v "^refused\|amdgpu.ids" > "$out/fuzz_mel_moments.txt"
 for u in lds_rate valu_rate valu_bank copy_rate row_stores stream_shapes fused_img_shapes; do
   [ -x scripts/ubench/$u ] && timeout 120 scripts/ubench/$u > "$out/ubench_$u.txt" 2>&1
 done

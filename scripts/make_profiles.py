@@ -66,7 +66,9 @@ for name, script in (("stft", "scripts/bench_stft.py"), ("stftpk", "scripts/benc
                      ("melmfma48", "scripts/bench_stft.py --sr 48000 --nfft 4096 --mel 0 --kernel 12"),
                      ("stftmel48", "scripts/bench_stft.py --sr 48000 --win 1920 --hop 480 --mel 0"),
                      ("stftmel48_one_frame", "scripts/bench_stft.py --sr 48000 --win 1920 --hop 480 --mel 0 --kernel 13"),
-                     ("subwave32768", "scripts/bench_stft.py --nfft 32768")):
+                     ("subwave32768", "scripts/bench_stft.py --nfft 32768"),
+                     ("blockmel16384", "scripts/bench_stft.py --nfft 16384 --mel 0"), ("blockmel8192", "scripts/bench_stft.py --nfft 8192 --mel 0"),
+                     ("block16384", "scripts/bench_stft.py --nfft 16384")):
     p = f"{src}/pmc_{name}/summary.txt"
     if os.path.exists(p):
         open(f"{dst}/{tag}_{name}_pmc_summary.txt", "w").write(hdr.format(script=script) + open(p).read())
@@ -101,7 +103,7 @@ if os.path.exists(p):
 # 5. plain-text measurement logs
 for f in ("bench_stft.txt", "bench_img.txt", "bench_cfg3.txt", "bench_cfg4.txt", "phase_prof.txt", "ubench_lds_rate.txt",
           "ubench_valu_rate.txt", "ubench_valu_bank.txt", "ubench_copy_rate.txt", "ubench_stream_shapes.txt", "ubench_fused_img_shapes.txt",
-          "ubench_stft_skeleton_sweep.txt", "ubench_mom_probe.txt", "wave_times.txt", "power.txt",
+          "ubench_stft_skeleton_sweep.txt", "ubench_mom_probe.txt", "bluestein_probe.txt", "fuzz_mel_moments.txt", "wave_times.txt", "power.txt",
           "bench_line_force_dist.json", "bench_line_launcher.json", "bench_line_rehearsal_2_ranks_one_gpu.json", "bench_line_rehearsal_4_ranks_one_gpu.json", "gputest.txt", "box.txt", "build_mode.txt"):
     if os.path.exists(f"{src}/{f}"):
         txt = "\n".join(l for l in open(f"{src}/{f}").read().splitlines() if "amdgpu.ids" not in l) + "\n"
