@@ -775,7 +775,12 @@ def main():
                  ("nfft8192_mel_default", "48 kHz, n_fft 8192 / hop 2048, mel scale at the default count (1392 mels; round 6: moment-form epilogue in the workgroup-per-frame kernel)", wl.wav, 48000, (8192, 2048, 8192, ta.MEL, 0), 0),
                  ("nfft8192_mel_default_two_kernels", "48 kHz, n_fft 8192 / hop 2048, 1392 mels, round 5's route (selector 12: block kernel -> amplitude rows -> mel_mfma_kernel)", wl.wav, 48000, (8192, 2048, 8192, ta.MEL, 0), 12),
                  ("nfft16384_mel_default", "48 kHz, n_fft 16384 / hop 4096, mel scale at the default count (2785 mels; round 6: moment-form epilogue, one kernel)", wl.wav, 48000, (16384, 4096, 16384, ta.MEL, 0), 0),
-                 ("nfft16384_mel_default_two_kernels", "48 kHz, n_fft 16384 / hop 4096, 2785 mels, round 5's route (selector 12)", wl.wav, 48000, (16384, 4096, 16384, ta.MEL, 0), 12))
+                 ("nfft16384_mel_default_two_kernels", "48 kHz, n_fft 16384 / hop 4096, 2785 mels, round 5's route (selector 12)", wl.wav, 48000, (16384, 4096, 16384, ta.MEL, 0), 12),
+                 # the UI's own way to n_fft 16384: a 340 ms window is 16320 samples, hop 4080 — not n_fft / 4.  Linear rows run the subwave plan there; a mel plan
+                 # takes the workgroup-per-frame kernel for its epilogue (round 6), the two-kernel route stays on the subwave plan
+                 ("win340ms_mel_default", "48 kHz, 340 ms window: 16320 / 4080 / 16384, Mel default (2785 mels): block kernel with the moment-form epilogue", wl.wav, 48000, (16320, 4080, 16384, ta.MEL, 0), 0),
+                 ("win340ms_mel_default_two_kernels", "48 kHz, 340 ms window, 2785 mels, round 5's route (selector 12: stft_subwave_kernel -> amplitude rows -> mel_mfma_kernel)", wl.wav, 48000, (16320, 4080, 16384, ta.MEL, 0), 12),
+                 ("win340ms", "48 kHz, 340 ms window: 16320 / 4080 / 16384, linear dB (stft_subwave_kernel)", wl.wav, 48000, (16320, 4080, 16384, ta.LINEAR, 0), 0))
         for key, label, wav_, sr_, (w_, h_, nf_, scale, n_mel), sel in cases:
             try:
                 pl = ta.Plan(ctx, sr_, w_, h_, nf_, scale, n_mel)

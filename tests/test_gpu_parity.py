@@ -539,7 +539,9 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
                                                     # the workgroup-per-frame kernels (n_fft 8192 / 16384): every wave takes a share of the groups
                                                     (48000, 8192, 2048, 8192, 0), (96000, 7680, 1920, 8192, 0), (48000, 8192, 1000, 8192, 128),
                                                     (48000, 16384, 4096, 16384, 0), (44100, 16384, 4096, 16384, 200), (48000, 8192, 2048, 8192, 3),
-                                                    (44100, 8192, 2048, 8192, 0)])
+                                                    (44100, 8192, 2048, 8192, 0),
+                                                    # n_fft 16384 at hops other than n_fft / 4 (the UI's 340 ms window): mel plans take the block kernel there too
+                                                    (48000, 16320, 4080, 16384, 0), (48000, 12000, 3000, 16384, 300), (48000, 8160, 2040, 8192, 0)])
 def test_mel_moment_epilogue_n_fft_4096(ctx, sr, win, hop, n_fft, n_mel):
     """Round 6: the n_fft 4096 wave kernel forms the mel rows in its own epilogue, in the MOMENT form (lane = segment of the triangle
     points; wide segments as (S0, S1) moments, narrow ones as their weight pairs; mel_fuse.h / stft_wave.h) — the default for the
@@ -573,7 +575,9 @@ def test_mel_moment_epilogue_n_fft_4096(ctx, sr, win, hop, n_fft, n_mel):
         two.close()
         return
     assert info["groups"] == (want_n_mel + 1 + 63) // 64 and 0 < info["max_dev"] <= 1.2e-5 and info["max_amp"] <= 8.0, info
-    assert fused.kernel_name == kind + "(fused mel)" and two.kernel_name.startswith(kind + "+mel_")
+    # (n_fft 16384 at hops other than n_fft / 4: linear rows and the two-kernel route run the subwave plan, a mel plan with a table the block kernel)
+    kind_two = "stft_subwave_kernel" if n_fft == 16384 and 4 * hop != n_fft else kind
+    assert fused.kernel_name == kind + "(fused mel)" and two.kernel_name.startswith(kind_two + "+mel_"), (fused.kernel_name, two.kernel_name)
     a, mma = fused.calc_spec_batch(wavs)
     b, mmb = two.calc_spec_batch(wavs)
     worst = 0.0

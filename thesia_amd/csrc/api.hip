@@ -389,6 +389,16 @@ bool th_plan::use_wave() const {
 }
 // mel plans on the wave kernel: the filterbank fused into the FFT kernel's epilogue where its table fits (n_fft 1024 /
 // 2048 at the default launch shape), else amplitude out of the FFT kernel and the filterbank on the matrix cores
+int th_plan::long_plan() const {
+    if (kernel_choice == 14) return 1;
+    if (kernel_choice == 15) return 2;
+    // Mel plans at n_fft 16384 that have a moment table: the workgroup-per-frame kernel with the filterbank in its epilogue at EVERY
+    // hop.  For linear rows the subwave plan is the faster one at hops other than n_fft / 4 (0.63 against 0.67 ms at 16320 / 4080,
+    // the UI's 340 ms window), but it has no epilogue and would need the second kernel: 0.99 against 0.82 ms there, 1.23 against 1.04
+    // at 12000 / 3000, 1.79 against 1.50 at 16320 / 2040 (64 ch x 30 s).  Selector 12 (the two kernels) keeps the size's default.
+    if (g.n_mel != 0 && g.log2_nc == 13 && d_mel_mom != nullptr && kernel_choice != 12) return 1;
+    return 0;
+}
 bool th_plan::use_mel_fused() const {
     if (g.n_mel == 0 || !use_wave() || kernel_choice == 3 || kernel_choice == 7) return false;
     // n_fft 4096 (round 6): the moment form of the filterbank as the FFT kernel's epilogue — no table in LDS (the eight slabs
@@ -396,9 +406,9 @@ bool th_plan::use_mel_fused() const {
     // defaults (not when selector 4 switches that mode off).  Selector 12 keeps round 5's two kernels (A/B).
     if (g.log2_nc == 11) return kernel_choice != 12 && d_mel_mom != nullptr && th::stft_wave_mel_fits(g, wave_waves, 1, true);
     // n_fft 8192 / 16384 (round 6): the same moment form as the epilogue of the workgroup-per-frame kernel, where that kernel is the
-    // plan that runs (not the subwave plan: 16384 at hops other than n_fft / 4, or selector 15); selector 12 keeps the two kernels
+    // plan that runs (long_plan(): at 16384 a mel plan with a table takes the block kernel at every hop; not under selector 15); selector 12 keeps the two kernels
     if (g.log2_nc == 12 || g.log2_nc == 13)
-        return kernel_choice != 12 && d_mel_mom != nullptr && th::stft_block_mel_fused_applies(g, kernel_choice == 14 ? 1 : kernel_choice == 15 ? 2 : 0);
+        return kernel_choice != 12 && d_mel_mom != nullptr && th::stft_block_mel_fused_applies(g, long_plan());
     // n_fft 512 under narrow filters: the banded sums of mel_rows_kernel as the epilogue of the four-frames-per-wave kernel
     if (g.log2_nc == 8) return d_mel_rows != nullptr && th::stft_wave_multi_mel_fits(g, wave_waves, mel_rows_groups * (uint32_t)(th::MEL_ROWS_W + 1) * 64u);
     return mel_bsum_fits() || (d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words));
@@ -798,7 +808,7 @@ TH_API const char *th_plan_kernel_name(const th_plan *p) {
     if (p->use_mel_fused()) return th::stft_is_block_plan(p->g) ? "stft_block_kernel(fused mel)" : "stft_wave_kernel(fused mel)";
     if (p->use_mel_mfma() && p->d_mel_rows != nullptr && p->kernel_choice != 7) return "stft_wave_kernel+mel_rows_kernel";
     // (n_fft 32768, round 5: sixteen wave transforms + a combining pass, kernels_stft_long.hip; selector 14 keeps the block kernel)
-    const bool subwave = th::stft_subwave_applies(p->g) && p->d_twc != nullptr && (p->kernel_choice == 15 || (p->kernel_choice != 14 && th::stft_subwave_default(p->g)));
+    const bool subwave = th::stft_subwave_applies(p->g) && p->d_twc != nullptr && (p->long_plan() == 2 || (p->long_plan() == 0 && th::stft_subwave_default(p->g)));
     if (p->use_mel_mfma() && p->g.log2_nc >= 11 && p->d_mel_bsum != nullptr && p->kernel_choice != 7)
         return subwave ? "stft_subwave_kernel+mel_band_rows_kernel" : th::stft_is_block_plan(p->g) ? "stft_block_kernel+mel_band_rows_kernel" : "stft_wave_kernel+mel_band_rows_kernel";
     if (p->use_mel_mfma()) return subwave ? "stft_subwave_kernel+mel_mfma_kernel" : th::stft_is_block_plan(p->g) ? "stft_block_kernel+mel_mfma_kernel" : "stft_wave_kernel+mel_mfma_kernel";
@@ -1108,7 +1118,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         wo.multi = (th::stft_wave_multi_applies(g, wo.mode) && (g.log2_nc == 8 || p->kernel_choice == 6)) ? 1 : 0;
         wo.packed = p->kernel_choice == 9 ? 1 : 0;
         wo.sweep = sweep ? 1 : 0;
-        wo.long_plan = p->kernel_choice == 14 ? 1 : p->kernel_choice == 15 ? 2 : 0;
+        wo.long_plan = p->long_plan();
         wo.subwave_twc = p->d_twc;
         if (mel_fused && g.log2_nc >= 11) {  // moment form: the table stays in global memory (scalar + 16-byte lane loads)
             wo.mel_tab = p->d_mel_mom;
