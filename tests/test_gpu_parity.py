@@ -541,7 +541,9 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
                                                     (48000, 16384, 4096, 16384, 0), (44100, 16384, 4096, 16384, 200), (48000, 8192, 2048, 8192, 3),
                                                     (44100, 8192, 2048, 8192, 0),
                                                     # n_fft 16384 at hops other than n_fft / 4 (the UI's 340 ms window): mel plans take the block kernel there too
-                                                    (48000, 16320, 4080, 16384, 0), (48000, 12000, 3000, 16384, 300), (48000, 8160, 2040, 8192, 0)])
+                                                    (48000, 16320, 4080, 16384, 0), (48000, 12000, 3000, 16384, 300), (48000, 8160, 2040, 8192, 0),
+                                                    # n_fft 4096 at hops whose grid-aligned frame loop has no epilogue: the plain loop + epilogue instead of two kernels
+                                                    (48000, 1920, 240, 4096, 0), (88200, 3528, 441, 4096, 0), (96000, 3840, 120, 4096, 0), (16000, 640, 160, 4096, 0)])
 def test_mel_moment_epilogue_n_fft_4096(ctx, sr, win, hop, n_fft, n_mel):
     """Round 6: the n_fft 4096 wave kernel forms the mel rows in its own epilogue, in the MOMENT form (lane = segment of the triangle
     points; wide segments as (S0, S1) moments, narrow ones as their weight pairs; mel_fuse.h / stft_wave.h) — the default for the

@@ -861,7 +861,7 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
     // registers and the mel kernel is not bound by its loads)
     // (n_fft 4096 — the 40 ms default at 88.2 / 96 kHz — also with amplitude output for the matrix-core mel kernel)
     const int phase_mode = (wave && (!mel_mfma || g.log2_nc == 11) && (!mel_fused || p->kernel_choice == 5 || g.log2_nc == 11) && p->kernel_choice != 4 && p->d_wtab_phased != nullptr)
-                               ? th::stft_wave_phased_mode(g, p->wave_waves) : 0;
+                               ? (mel_fused ? th::stft_wave_mel_phase_mode(g, p->wave_waves) : th::stft_wave_phased_mode(g, p->wave_waves)) : 0;
     const bool phased = phase_mode != 0;
     g.phased = (uint32_t)phase_mode;
     const int waves = p->wave_waves > 0 ? p->wave_waves : stft_wave_default_waves(g);

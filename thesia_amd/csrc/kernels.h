@@ -107,6 +107,7 @@ bool stft_wave_mel_pair_applies(const StftGeom &g, int waves, uint32_t reach);
 // pieces the per-wave (r, f) buffer of the fused mel epilogue can hold for this n_fft (0: not supported), and whether
 // the launch shape leaves room in LDS for a table of `words`
 int stft_wave_phased_mode(const StftGeom &g, int waves);  // 0 no, 1 phased (hop 480), 2 dynamic (e.g. 441)
+int stft_wave_mel_phase_mode(const StftGeom &g, int waves);  // the same for a launch with the fused mel epilogue (n_fft 4096: only the modes it is instantiated for)
 uint32_t stft_wave_mel_max_pieces(const StftGeom &g);
 // the sweep chunk schedule exists for this launch (shape, output mode, wave count; the caller adds: batch large enough)
 bool stft_wave_sweep_applies(const StftGeom &g, int waves, int out_mode);

@@ -2577,12 +2577,19 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool bande
                wave_lds_bytes<9, WaveLaunchCfg<9>::DEFAULT_WAVES>() + extra + (512 + 128) * sizeof(cf32) +
                        (banded ? 0 : (size_t)WaveLaunchCfg<9>::DEFAULT_WAVES * MEL_PRF_1024 * sizeof(cf32)) <= 160 * 1024;
     // n_fft 4096: nothing to fit (the moment form keeps no table in LDS); the launch shapes the epilogue is instantiated for
-    if (g.log2_nc == 11 && banded && words > 0 && (waves <= 0 || waves == WaveLaunchCfg<11>::DEFAULT_WAVES)) {
-        const int pm = stft_wave_phased_mode(g, waves);
-        if (pm == 0) return true;  // (plain frame loops: every hop — reuse of 8 / 16 / 4 slots or none)
-        return pm == 3 && (g.hop / 128 == 7 || g.hop / 128 == 6 || g.hop / 128 == 3);
-    }
+    // (every hop: the plain frame loop takes any — reuse of 8 / 16 / 4 slots or none; of the grid-aligned loops the epilogue is instantiated for
+    // those stft_wave_mel_grid_ok names, a mel plan elsewhere runs the plain loop: stft_wave_mel_phase_mode)
+    if (g.log2_nc == 11 && banded && words > 0 && (waves <= 0 || waves == WaveLaunchCfg<11>::DEFAULT_WAVES)) return true;
     return false;
+}
+// n_fft 4096 with the mel epilogue: the frame loop's mode.  The grid-aligned loop (stft_wave_phased_mode) where the epilogue is
+// instantiated for it — the even-offset shapes of the 96 / 88.2 kHz defaults at t_overlap 4, 2 and 8 — else the plain loop: a
+// mel plan at hop 240 / 120 / 441 ... gives up the grid's register reuse (7 % of the linear kernel) and keeps one kernel
+// instead of two (round 6: 48 kHz 1920 / 240 / 4096, 695 mels).
+int stft_wave_mel_phase_mode(const StftGeom &g, int waves) {
+    const int pm = stft_wave_phased_mode(g, waves);
+    if (g.log2_nc != 11) return pm;
+    return (pm == 3 && (g.hop / 128 == 7 || g.hop / 128 == 6 || g.hop / 128 == 3)) ? 3 : 0;
 }
 bool stft_wave_mel_pair_applies(const StftGeom &g, int waves, uint32_t reach) {
     // (mel_banded_pair and wave_mel_flush read the table's PAIRED layout: a -DTH_MEL_BAND_PAIRED=0 build keeps the one-frame epilogue — ADVICE r5)
