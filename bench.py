@@ -780,7 +780,14 @@ def main():
                  # takes the workgroup-per-frame kernel for its epilogue (round 6), the two-kernel route stays on the subwave plan
                  ("win340ms_mel_default", "48 kHz, 340 ms window: 16320 / 4080 / 16384, Mel default (2785 mels): block kernel with the moment-form epilogue", wl.wav, 48000, (16320, 4080, 16384, ta.MEL, 0), 0),
                  ("win340ms_mel_default_two_kernels", "48 kHz, 340 ms window, 2785 mels, round 5's route (selector 12: stft_subwave_kernel -> amplitude rows -> mel_mfma_kernel)", wl.wav, 48000, (16320, 4080, 16384, ta.MEL, 0), 12),
-                 ("win340ms", "48 kHz, 340 ms window: 16320 / 4080 / 16384, linear dB (stft_subwave_kernel)", wl.wav, 48000, (16320, 4080, 16384, ta.LINEAR, 0), 0))
+                 ("win340ms", "48 kHz, 340 ms window: 16320 / 4080 / 16384, linear dB (stft_subwave_kernel)", wl.wav, 48000, (16320, 4080, 16384, ta.LINEAR, 0), 0),
+                 # two more Mel settings the UI's controls produce that ran two kernels until the round's last day (scripts/ui_shapes.py lists all 836):
+                 # the 40 ms default at t_overlap 8 / f_overlap 2 (a hop whose grid-aligned frame loop has no mel epilogue: the plain loop + epilogue now), and
+                 # 16 kHz audio under an 85 ms window (771 mels at n_fft 2048: more than an LDS table holds — the moment form with its table in global memory)
+                 ("tov8_fov2_mel", "48 kHz, 40 ms window, t_overlap 8, f_overlap 2: 1920 / 240 / 4096, Mel default (695 mels), one kernel", wl.wav, 48000, (1920, 240, 4096, ta.MEL, 0), 0),
+                 ("tov8_fov2_mel_two_kernels", "the same, selector 12 (grid-aligned frame loop -> amplitude rows -> mel_mfma_kernel)", wl.wav, 48000, (1920, 240, 4096, ta.MEL, 0), 12),
+                 ("sr16k_win85ms_mel", "16 kHz, 85 ms window: 1360 / 340 / 2048, Mel default (771 mels), one kernel", wl.wav, 16000, (1360, 340, 2048, ta.MEL, 0), 0),
+                 ("sr16k_win85ms_mel_two_kernels", "the same, selector 12 (FFT kernel -> amplitude rows -> mel_mfma_kernel)", wl.wav, 16000, (1360, 340, 2048, ta.MEL, 0), 12))
         for key, label, wav_, sr_, (w_, h_, nf_, scale, n_mel), sel in cases:
             try:
                 pl = ta.Plan(ctx, sr_, w_, h_, nf_, scale, n_mel)

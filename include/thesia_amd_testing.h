@@ -18,7 +18,7 @@
  * shapes: 8, 12 or 16), 7 = as 3 with the matrix-core kernel also where 3 runs the
  * banded-sum kernel over the amplitude rows (n_fft 512 under filters of at most 8 bins: the default mel counts of 8-12 kHz audio),
  * 8 = the fused mel epilogue in its pieces / gather form where banded sums are the default (A/B),
- * 12 = mel plans at n_fft 4096 / 8192 / 16384: the two kernels (FFT kernel -> amplitude rows -> banded sums / matrix cores) where the moment-form
+ * 12 = mel plans whose default is the moment-form epilogue (n_fft 4096 / 8192 / 16384; n_fft 512 .. 2048 where no LDS table form exists): the two kernels (FFT kernel -> amplitude rows -> banded sums / matrix cores) where the moment-form
  * epilogue is the default (hop 1024, the 96 / 88.2 kHz defaults; round 5's route, kept for A/B; elsewhere as 2),
  * 13 = the fused mel epilogue one frame at a time where frame pairs are the default (n_fft 1024 / 2048 banded sums; A/B, bit-identical),
  * 14 = the workgroup-per-frame Stockham kernel where stft_subwave_kernel is the default (n_fft 16384 at hops other than n_fft / 4),
@@ -37,8 +37,8 @@ TH_API int th_plan_set_kernel(th_plan *plan, int which);
 /* 1 when the library carries the A/B variants above (-DTH_AB_VARIANTS=1), 0 for the product build */
 TH_API int th_build_ab_variants(void);
 
-/* Mel plans at n_fft 4096 / 8192 / 16384: the moment-form table of the fused epilogue, if the plan has one (n_groups = 0: it does not —
- * not that size, or the filterbank's lines leave the reference's f32 weights by more than the builder allows, and the plan keeps
+/* Mel plans: the moment-form table of the fused epilogue, if the plan has one (n_fft 4096 / 8192 / 16384, and n_fft 512 .. 2048 where no LDS table form exists; n_groups = 0: it does not —
+ * not such a plan, or the filterbank's lines leave the reference's f32 weights by more than the builder allows, and the plan keeps
  * the two kernels).  taps = segment taps per frame, max_dev = the largest difference between a line and the table's weight over
  * all bins (units of an unnormalised weight), max_amp = how far a filter's 1 / d enlarges the moments' rounding.  Any may be NULL. */
 TH_API int th_plan_mel_moments_info(const th_plan *plan, uint32_t *n_groups, uint32_t *taps, double *max_dev, double *max_amp);

@@ -480,9 +480,12 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     assert band_rows == ((sr, n_fft, n_mel) in ((96000, 4096, 0), (88200, 4096, 0)))
     # (round 6: at hop 1024 and the 96 / 88.2 kHz defaults the n_fft 4096 kernel takes the filterbank in its epilogue in the MOMENT
     # form — no table in LDS, any mel count, no amplitude rows through HBM; selector 12 keeps round 5's two kernels)
-    fused_4096 = n_fft == 4096 and (hop == 1024 or (sr, hop) in ((96000, 960), (88200, 882)))
-    # (and the same epilogue in the workgroup-per-frame kernel of n_fft 8192 / 16384, where that kernel is the plan that runs)
-    fused_block = n_fft == 8192 or (n_fft == 16384 and hop * 4 == n_fft)
+    # (every hop since the round's last days: hops whose grid-aligned frame loop has no epilogue run the plain loop)
+    fused_4096 = n_fft == 4096
+    # (and the same epilogue in the workgroup-per-frame kernel of n_fft 8192 / 16384 — at 16384 a mel plan with a table takes that kernel at every hop)
+    fused_block = n_fft in (8192, 16384)
+    # (and at n_fft 512 / 1024 / 2048 where no LDS table form exists: more than 512 mels, or at 512 filters wider than the banded table's 8 bins)
+    small_moment = (n_fft in (1024, 2048) and want_n_mel > 512) or (n_fft == 512 and not rows)
     second = "+mel_rows_kernel" if rows else "+mel_band_rows_kernel" if band_rows else "+mel_mfma_kernel"
     mfma = fft_kernel + second  # (any mel count since round 4; beyond 512 mels there is no fused form)
     # auto: the fused epilogue for n_fft 2048 and (when the piece table fits: <= 512 pieces) 1024, else the matrix-core path
@@ -492,7 +495,7 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
     for which, name in ((1, "stft_generic_kernel"), (3, mfma), (7, fft_kernel + "+mel_mfma_kernel"), (8, None), (12, mfma), (0, None)):
         if which == 7 and not (rows or band_rows):
             continue
-        if which == 12 and not (fused_4096 or fused_block):  # (selector 12: the two kernels where the moment-form epilogue is the default, an A/B route)
+        if which == 12 and not (fused_4096 or fused_block or small_moment):  # (selector 12: the two kernels where the moment-form epilogue is the default, an A/B route)
             continue
         if which == 8 and n_fft not in (1024, 2048):
             continue
@@ -500,7 +503,10 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
         # (a bank whose lines leave the reference's f32 weights by more than 1.2e-5 — the finer 44.1 kHz-family banks — has no
         # moment table and keeps the two kernels: th_plan_mel_moments_info, mel_fuse.h)
         has_table = plan.mel_moments_info()["groups"] > 0
-        assert has_table == ((fused_4096 or fused_block or n_fft in (4096, 8192, 16384)) and (sr, n_fft, n_mel) not in ((44100, 16384, 0),)), plan.mel_moments_info()
+        if n_fft >= 4096 or n_fft in (1024, 2048):
+            assert has_table == ((n_fft >= 4096 or small_moment) and (sr, n_fft, n_mel) not in ((44100, 16384, 0),)), plan.mel_moments_info()
+        else:  # (n_fft 512: the builder refuses small banks that mix filters narrower than a bin with three-bin segments in one group)
+            assert not has_table or small_moment, plan.mel_moments_info()
         if which == 12 and not has_table:
             plan.close()
             continue
@@ -510,6 +516,8 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
             assert plan.kernel_name == mfma
         elif name is None and fused_block:
             assert plan.kernel_name == (mfma if which == 8 else "stft_block_kernel(fused mel)")
+        elif name is None and small_moment:
+            assert plan.kernel_name == (fused if has_table and which == 0 else mfma), (plan.kernel_name, has_table)
         elif name is None:
             assert plan.kernel_name == fused if ((n_fft == 2048 and want_n_mel <= 512) or rows) else plan.kernel_name in (fused, mfma)
             if want_n_mel > 512 and not fused_4096:
@@ -522,7 +530,7 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
             assert plan.kernel_name == name
         assert plan.height == want_n_mel
         specs, mm = plan.calc_spec_batch(wavs)
-        moments = (fused_4096 and plan.kernel_name == fused) or plan.kernel_name == "stft_block_kernel(fused mel)"
+        moments = ((fused_4096 or small_moment) and plan.kernel_name == fused) or plan.kernel_name == "stft_block_kernel(fused mel)"
         for i, (s, w) in enumerate(zip(specs, want)):
             assert_spec_close(s, w, floor=MOMENT_FLOOR if moments else F32_FLOOR)
             assert mm[i, 0] == s.min() and mm[i, 1] == s.max()
@@ -543,7 +551,12 @@ def test_mel_on_matrix_cores(ctx, sr, win, hop, n_fft, n_mel):
                                                     # n_fft 16384 at hops other than n_fft / 4 (the UI's 340 ms window): mel plans take the block kernel there too
                                                     (48000, 16320, 4080, 16384, 0), (48000, 12000, 3000, 16384, 300), (48000, 8160, 2040, 8192, 0),
                                                     # n_fft 4096 at hops whose grid-aligned frame loop has no epilogue: the plain loop + epilogue instead of two kernels
-                                                    (48000, 1920, 240, 4096, 0), (88200, 3528, 441, 4096, 0), (96000, 3840, 120, 4096, 0), (16000, 640, 160, 4096, 0)])
+                                                    (48000, 1920, 240, 4096, 0), (88200, 3528, 441, 4096, 0), (96000, 3840, 120, 4096, 0), (16000, 640, 160, 4096, 0),
+                                                    # n_fft 2048 / 1024 under more mels than an LDS table holds (512): low sample rates under long windows, f_overlap 2 / 4
+                                                    (16000, 1360, 340, 2048, 0), (24000, 2040, 510, 2048, 0), (16000, 640, 160, 2048, 0), (8000, 680, 170, 1024, 0),
+                                                    (24000, 960, 240, 2048, 0), (48000, 2048, 512, 2048, 900), (8000, 320, 80, 1024, 0),
+                                                    # n_fft 512 (four frames per wave) under filters wider than the banded table's 8 bins: 10 / 20 ms windows at 16 .. 48 kHz
+                                                    (48000, 480, 120, 512, 0), (16000, 320, 80, 512, 0), (24000, 240, 30, 512, 0), (44100, 442, 221, 512, 0)])
 def test_mel_moment_epilogue_n_fft_4096(ctx, sr, win, hop, n_fft, n_mel):
     """Round 6: the n_fft 4096 wave kernel forms the mel rows in its own epilogue, in the MOMENT form (lane = segment of the triangle
     points; wide segments as (S0, S1) moments, narrow ones as their weight pairs; mel_fuse.h / stft_wave.h) — the default for the
@@ -564,11 +577,13 @@ def test_mel_moment_epilogue_n_fft_4096(ctx, sr, win, hop, n_fft, n_mel):
     wavs.append(np.zeros(5 * n_fft, np.float32))
     fused, two = ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel), ta.Plan(ctx, sr, win, hop, n_fft, ta.MEL, n_mel)
     two.set_kernel(12)
-    kind = "stft_wave_kernel" if n_fft == 4096 else "stft_block_kernel"
+    kind = "stft_wave_kernel" if n_fft <= 4096 else "stft_block_kernel"
     info = fused.mel_moments_info()
-    if (sr, n_fft, n_mel) in ((22050, 4096, 1000), (88200, 4096, 2049), (44100, 8192, 0)):
+    if (sr, n_fft, n_mel) in ((22050, 4096, 1000), (88200, 4096, 2049), (44100, 8192, 0), (48000, 512, 0), (44100, 512, 0)):
         # the finer banks of the 44.1 kHz family: their lines leave the reference's f32 weights by 1.7 - 2.5e-5 (the rounding of its f32
-        # bin frequencies against narrow segments) — more than the builder allows: no table, the plan keeps the two kernels
+        # bin frequencies against narrow segments) — more than the builder allows: no table, the plan keeps the two kernels.
+        # n_fft 512 at 44.1 / 48 kHz (86 / 91 mels in two groups): the first group mixes filters narrower than a bin with segments of
+        # three bins, i.e. a moment group that would enlarge its rounding by 1 / d = 200 .. 2000 (max_amp) — refused as well
         assert info["groups"] == 0 and fused.kernel_name == two.kernel_name and fused.kernel_name.startswith(kind + "+mel_")
         a, _ = fused.calc_spec_batch(wavs[:3])
         for w, sa in zip(wavs[:3], a):

@@ -410,8 +410,17 @@ bool th_plan::use_mel_fused() const {
     if (g.log2_nc == 12 || g.log2_nc == 13)
         return kernel_choice != 12 && d_mel_mom != nullptr && th::stft_block_mel_fused_applies(g, long_plan());
     // n_fft 512 under narrow filters: the banded sums of mel_rows_kernel as the epilogue of the four-frames-per-wave kernel
-    if (g.log2_nc == 8) return d_mel_rows != nullptr && th::stft_wave_multi_mel_fits(g, wave_waves, mel_rows_groups * (uint32_t)(th::MEL_ROWS_W + 1) * 64u);
-    return mel_bsum_fits() || (d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words));
+    if (g.log2_nc == 8) return (d_mel_rows != nullptr && th::stft_wave_multi_mel_fits(g, wave_waves, mel_rows_groups * (uint32_t)(th::MEL_ROWS_W + 1) * 64u)) || use_mel_moment_small();
+    return mel_bsum_fits() || (d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words)) || use_mel_moment_small();
+}
+// n_fft 1024 / 2048 under more mels than an LDS table form holds (512: low sample rates under long windows, or f_overlap 2 / 4): the moment form
+// with its table in global memory, as at n_fft 4096 (one-frame epilogue; any frame loop of the size).  Selectors 12 / 2 keep the two kernels.
+bool th_plan::use_mel_moment_small() const {
+    if (g.n_mel == 0 || g.log2_nc < 8 || g.log2_nc > 10 || d_mel_mom == nullptr || kernel_choice == 12 || kernel_choice == 8 || kernel_choice == 3 || kernel_choice == 7) return false;
+    // n_fft 512 (four frames per wave): where the banded rows table does not exist — filters wider than its 8 bins: 10 / 20 ms windows at 16 .. 48 kHz
+    if (g.log2_nc == 8) return d_mel_rows == nullptr && th::stft_wave_multi_applies(g, 2) && th::stft_wave_multi_mel_fits(g, wave_waves, 0);
+    if (mel_bsum_fits() || (d_mel_fuse != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_fuse_words))) return false;
+    return th::stft_wave_mel_fits(g, wave_waves, 0, true);
 }
 bool th_plan::mel_bsum_fits() const {
     return kernel_choice != 8 && d_mel_bsum != nullptr && th::stft_wave_mel_fits(g, wave_waves, mel_bsum_words, true);
@@ -693,19 +702,21 @@ TH_API int th_plan_create(th_ctx *c, uint32_t sr, size_t win, size_t hop, size_t
                 rc = up((void **)&p->d_mel_fuse, mf.words.data(), mf.words.size() * sizeof(uint32_t));
             }
         }
-        if (rc == TH_OK && (g.log2_nc == 11 || g.log2_nc == 12 || g.log2_nc == 13) && th::stft_wave_supported(g)) {
+        // (n_fft 1024 / 2048: only where no LDS table form exists — more than 512 mels)
+        const bool small_mom = ((g.log2_nc == 9 || g.log2_nc == 10) && p->d_mel_bsum == nullptr && p->d_mel_fuse == nullptr) || (g.log2_nc == 8 && p->d_mel_rows == nullptr);
+        if (rc == TH_OK && (g.log2_nc == 11 || g.log2_nc == 12 || g.log2_nc == 13 || small_mom) && th::stft_wave_supported(g)) {
             // n_fft 4096 (the wave kernel) and 8192 / 16384 (the workgroup-per-frame kernel): the moment form (lane = segment of the
             // triangle points; mel_fuse.h) for the fused epilogue, any mel count
             std::vector<float> lin, mfp;
             mel_fb_points(sr, n_fft, n_mel, 0.f, -1.f, lin, mfp);
             const th::MelMomHost mm = th::build_mel_moments(p->h_mel_fb.data(), lin.data(), mfp.data(), g.n_freq, (uint32_t)n_mel,
-                                                            g.log2_nc == 11 ? 2u * (g.nc + g.nc / 16u) : th::stft_block_mel_max_index(g), g.log2_nc == 11 && TH_MEL_BAND_SPREAD != 0);
+                                                            g.log2_nc == 8 ? th::stft_wave_multi_amp_pitch() : g.log2_nc <= 11 ? 2u * (g.nc + g.nc / 16u) : th::stft_block_mel_max_index(g), g.log2_nc <= 11 && TH_MEL_BAND_SPREAD != 0);
             // (the workgroup-per-frame kernels walk a batch of groups in lockstep: a lane reads up to the table's widest group's
             // taps behind its first bin — inside the exchange buffer)
-            const bool reach_ok = g.log2_nc == 11 || (uint64_t)g.n_freq + mm.max_taps <= th::stft_block_mel_max_index(g);
+            const bool reach_ok = g.log2_nc <= 11 || (uint64_t)g.n_freq + mm.max_taps <= th::stft_block_mel_max_index(g);
             // (the workgroup-per-frame kernels: the same numbers at fixed addresses, build_mel_mom_lanes)
-            const std::vector<uint32_t> lanes = g.log2_nc == 11 ? std::vector<uint32_t>() : th::build_mel_mom_lanes(mm);
-            const std::vector<uint32_t> &tab = g.log2_nc == 11 ? mm.words : lanes;
+            const std::vector<uint32_t> lanes = g.log2_nc <= 11 ? std::vector<uint32_t>() : th::build_mel_mom_lanes(mm);
+            const std::vector<uint32_t> &tab = g.log2_nc <= 11 ? mm.words : lanes;
             if (mm.ok && reach_ok && !tab.empty()) {
                 p->mel_mom_groups = mm.n_groups;
                 p->mel_mom_taps = mm.taps;
@@ -1120,7 +1131,8 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         wo.sweep = sweep ? 1 : 0;
         wo.long_plan = p->long_plan();
         wo.subwave_twc = p->d_twc;
-        if (mel_fused && g.log2_nc >= 11) {  // moment form: the table stays in global memory (scalar + 16-byte lane loads)
+        if (mel_fused && (g.log2_nc >= 11 || p->use_mel_moment_small())) {  // moment form: the table stays in global memory (scalar + 16-byte lane loads)
+            wo.mel_moment = g.log2_nc >= 11 ? 0u : 1u;
             wo.mel_tab = p->d_mel_mom;
             wo.mel_words = 0;
             wo.mel_slots = 0;

@@ -100,6 +100,7 @@ struct th_plan {
     th::DeviceTable post_jobs;                           // per-channel tile ranges for wave_post_kernel
     bool use_mel_mfma() const;   // mel plan: amplitude rows + mel_mfma_kernel
     bool use_mel_fused() const;  // mel plan: filterbank fused into the wave kernel's epilogue (mel_fuse.h)
+    bool use_mel_moment_small() const;  // n_fft 1024 / 2048 mel plan whose table forms do not fit LDS: the moment-form epilogue (round 6)
     int long_plan() const;       // n_fft 8192 .. 65536: 0 = the size's default plan, 1 = stft_block_kernel, 2 = stft_subwave_kernel (WaveOut::long_plan)
     // fused mel epilogue: device copy of the mel_fuse.h word table
     uint32_t *d_mel_fuse = nullptr;

@@ -91,6 +91,9 @@ struct WaveOut {
     // banded sums, n_fft 2048: 1 = the frame-pair epilogue (two consecutive frames of a chunk share one pass over the table:
     // stft_wave_kernel<.., OUT = 3>; the host sets it where stft_wave_mel_pair_applies says so)
     uint32_t mel_pair = 0;
+    // n_fft 1024 / 2048: 1 = the moment form of the filterbank (mel_tab = build_mel_moments' table, read from global memory; mel_words = 0):
+    // mel counts above what an LDS table holds.  (n_fft 4096 .. 16384 mel plans are always this form.)
+    uint32_t mel_moment = 0;
     const cf32 *subwave_twc = nullptr;  // DEVICE: stft_subwave_build_twc's table (n_fft 32768 plans)
     int long_plan = 0;  // n_fft 8192 .. 32768: 0 = the default of the size (stft_subwave_default), 1 = stft_block_kernel, 2 = stft_subwave_kernel
 };
@@ -115,6 +118,7 @@ bool stft_wave_sweep_applies(const StftGeom &g, int waves, int out_mode);
 bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool banded = false);
 // n_fft 512 (four frames per wave): does the mel_rows table fit the launch's LDS beside the slabs at this wave count?
 bool stft_wave_multi_mel_fits(const StftGeom &g, int waves, uint32_t words);
+uint32_t stft_wave_multi_amp_pitch();  // floats per amplitude row of that kernel's mel epilogue (a lane of the moment form reads inside its frame's row)
 // waves: waves per workgroup (4, 8, 12 or 16; <= 0 selects the default for this n_fft)
 // d_tile_start: HERE the per-chunk table, 2 words per chunk: (job, first frame) — not the jobs' first chunks as in
 // launch_stft_generic; chunks 0 .. W - 1 are statically assigned (W = waves of the grid), the queue serves the rest

@@ -840,6 +840,9 @@ __device__ __forceinline__ void wave_frame(
             // taps' lane masks from global memory — mel_moments_global, stft_wave.h; build_mel_moments, mel_fuse.h)
             wave_lds_sync();
             mel_moments_global(lane, slab_f, as_global(wo.mel_tab), wo.mel_groups, emit_mel);
+        } else if (wo.mel_moment != 0) {  // wave-uniform: n_fft 1024 / 2048 under more mels than an LDS table holds (512) — the same moment form, table in global memory
+            wave_lds_sync();
+            mel_moments_global(lane, slab_f, as_global(wo.mel_tab), wo.mel_groups, emit_mel);
         } else if (wo.mel_slots == 0) {  // wave-uniform: banded sums, lane = mel (mel_banded, stft_wave.h; table: build_mel_band)
             // the filters of a group reach up to its widest one's width past their own end: zeros behind the row
             static_assert(2 * (int)W::SLAB_LEN >= NC + 1 + 128, "room for the zeros behind the amplitude row");
@@ -1481,6 +1484,22 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
                 constexpr int MW = MEL_ROWS_W;
                 const uint32_t height = wo.n_mel, pad = cur.spec_pitch - height;
                 const uint32_t npad = (pad < 32u && cur.spec_pitch % 32u == 0) ? pad : 0u;
+                if (wo.mel_moment != 0) {  // wave-uniform: filters wider than the banded table's 8 bins — the moment form, frame after frame (table in global memory)
+#pragma unroll 1
+                    for (int fr = 0; fr < G; fr++) {
+                        const uint32_t dgf = (uint32_t)fr < last ? (uint32_t)fr : last;  // (groups past the chunk's end repeat its last frame)
+                        const gptr<float> orow = cur.spec + (size_t)f * cur.spec_pitch + (size_t)dgf * cur.spec_pitch;
+                        mel_moments_global(lane, ampf + fr * MELR_AP, as_global(wo.mel_tab), wo.mel_groups, [&](uint32_t m, float v) {
+                            if (m < height) {
+                                const float d = amp_to_dB_fast(v);
+                                orow[m] = d;
+                                lmin = nmin(lmin, d);
+                                lmax = nmax(lmax, d);
+                            }
+                        });
+                        if (lane < npad) orow[height + lane] = 0.0f;  // complete the row's last 128-byte line (see wave_frame)
+                    }
+                } else
 #pragma unroll
                 for (int gq = 0; gq < MEL_ROWS_MAX_GROUPS; gq++) {
                     if ((uint32_t)gq < wo.mel_groups) {  // wave-uniform
@@ -1539,8 +1558,9 @@ static hipError_t launch_wave_multi_n(const StftGeom &g, const ChanJob *d_jobs, 
     using W = WaveFftM<LOG2_NC>;
     auto kern = stft_wave_multi_kernel<LOG2_NC, WAVES, OUT, NLD>;
     static_assert(NLD * 1024 <= (int)(sizeof(cf32) * W::SLAB_LEN), "the staged samples fit the wave's slab");
-    if (OUT == 2 && (out.mel_tab == nullptr || out.mel_groups == 0 || out.mel_groups > (uint32_t)MEL_ROWS_MAX_GROUPS ||
-                     out.mel_words != out.mel_groups * (MEL_ROWS_W + 1) * 64u))
+    if (OUT == 2 && out.mel_moment != 0 ? (out.mel_tab == nullptr || out.mel_groups == 0 || out.mel_words != 0)
+                                        : (OUT == 2 && (out.mel_tab == nullptr || out.mel_groups == 0 || out.mel_groups > (uint32_t)MEL_ROWS_MAX_GROUPS ||
+                                                        out.mel_words != out.mel_groups * (MEL_ROWS_W + 1) * 64u)))
         return hipErrorInvalidValue;
     const size_t lds = sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN) +
                        (OUT == 2 ? (size_t)out.mel_words * 4 : 0);
@@ -2601,6 +2621,7 @@ bool stft_wave_mel_pair_applies(const StftGeom &g, int waves, uint32_t reach) {
 }
 // (the same sum as launch_wave_multi_n; ADVICE r3: without this check a small growth of SLAB_LEN or MEL_ROWS_W would turn the
 // default path into hipErrorInvalidValue at launch instead of the two-kernel fallback)
+uint32_t stft_wave_multi_amp_pitch() { return (uint32_t)MELR_AP; }
 bool stft_wave_multi_mel_fits(const StftGeom &g, int waves, uint32_t words) {
     if (g.log2_nc != 8) return false;
     using W = WaveFftM<8>;
