@@ -507,7 +507,7 @@ __device__ __forceinline__ void wave_frame(
     const cf32 (&rws)[(RES & 8) ? WaveFft<LOG2_NC>::NQ : 1][WaveFft<LOG2_NC>::R3], cf32 rw_mid, float &lmin, float &lmax,
     const uint32_t *meltab, cf32 *mel_prf, const WaveOut &wo, float (&ampA)[OUT == 3 ? WaveFft<LOG2_NC>::N_EMIT : 1], bool nxt_full = false,
     gptr<const float> nwav = nullptr, int64_t ne0 = 0) {
-    constexpr bool AMP = OUT == 1, MELF = OUT == 2 || OUT == 3;
+    constexpr bool AMP = OUT == 1, MELF = OUT == 2 || OUT == 3 || OUT == 4;  // (4: the moment form of the one-frame epilogue where no LDS table form exists, n_fft 1024 / 2048)
     static_assert((OUT == 3) == (MELP != 0), "frame pairs: OUT = 3 with MELP = 1 (first frame) or 2 (second)");
     static_assert(OUT != 3 || ((LOG2_NC == 10 || LOG2_NC == 9) && !PKV), "frame pairs: n_fft 1024 / 2048, scalar pipeline");
     using MP = MelPair<(LOG2_NC == 9 || LOG2_NC == 10) ? LOG2_NC : 10>;
@@ -835,12 +835,9 @@ __device__ __forceinline__ void wave_frame(
 #if defined(TH_MELF_ABL) && (TH_MELF_ABL & 1)  // ablation build: no filterbank sums (rows unwritten) — what the epilogue costs
         if (wo.n_mel == 0x7fffffffu)
 #endif
-        if constexpr (LOG2_NC == 11) {
-            // no LDS for a table beside eight slabs: the moment form (lane = segment, two additions per bin; per-lane words and the
+        if constexpr (LOG2_NC == 11 || OUT == 4) {
+            // no LDS for a table beside eight slabs (n_fft 1024 / 2048, OUT = 4: more mels than an LDS table holds): the moment form (lane = segment, two additions per bin; per-lane words and the
             // taps' lane masks from global memory — mel_moments_global, stft_wave.h; build_mel_moments, mel_fuse.h)
-            wave_lds_sync();
-            mel_moments_global(lane, slab_f, as_global(wo.mel_tab), wo.mel_groups, emit_mel);
-        } else if (wo.mel_moment != 0) {  // wave-uniform: n_fft 1024 / 2048 under more mels than an LDS table holds (512) — the same moment form, table in global memory
             wave_lds_sync();
             mel_moments_global(lane, slab_f, as_global(wo.mel_tab), wo.mel_groups, emit_mel);
         } else if (wo.mel_slots == 0) {  // wave-uniform: banded sums, lane = mel (mel_banded, stft_wave.h; table: build_mel_band)
@@ -1327,7 +1324,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
     uint32_t *__restrict__ queue_head, WaveOut wo) {
     using W = WaveFftM<LOG2_NC>;
     constexpr int P = W::P, NC = W::NC, G = W::G, L = W::L;
-    constexpr bool AMP = OUT == 1, MELR = OUT == 2;
+    constexpr bool AMP = OUT == 1, MELR = OUT == 2 || OUT == 4, MELM = OUT == 4;  // (4: mel rows in the moment form, table in global memory — filters wider than the banded table's 8 bins)
     static_assert(!MELR || (LOG2_NC == 8 && 4 * MELR_AP * (int)sizeof(float) <= (int)(sizeof(cf32) * W::SLAB_LEN) &&
                             NC + MEL_ROWS_W <= MELR_AP), "mel rows: four amplitude rows in the wave's slab");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1484,7 +1481,7 @@ __global__ __launch_bounds__(64 * WAVES) void stft_wave_multi_kernel(
                 constexpr int MW = MEL_ROWS_W;
                 const uint32_t height = wo.n_mel, pad = cur.spec_pitch - height;
                 const uint32_t npad = (pad < 32u && cur.spec_pitch % 32u == 0) ? pad : 0u;
-                if (wo.mel_moment != 0) {  // wave-uniform: filters wider than the banded table's 8 bins — the moment form, frame after frame (table in global memory)
+                if constexpr (MELM) {  // filters wider than the banded table's 8 bins — the moment form, frame after frame (table in global memory)
 #pragma unroll 1
                     for (int fr = 0; fr < G; fr++) {
                         const uint32_t dgf = (uint32_t)fr < last ? (uint32_t)fr : last;  // (groups past the chunk's end repeat its last frame)
@@ -1558,9 +1555,9 @@ static hipError_t launch_wave_multi_n(const StftGeom &g, const ChanJob *d_jobs, 
     using W = WaveFftM<LOG2_NC>;
     auto kern = stft_wave_multi_kernel<LOG2_NC, WAVES, OUT, NLD>;
     static_assert(NLD * 1024 <= (int)(sizeof(cf32) * W::SLAB_LEN), "the staged samples fit the wave's slab");
-    if (OUT == 2 && out.mel_moment != 0 ? (out.mel_tab == nullptr || out.mel_groups == 0 || out.mel_words != 0)
-                                        : (OUT == 2 && (out.mel_tab == nullptr || out.mel_groups == 0 || out.mel_groups > (uint32_t)MEL_ROWS_MAX_GROUPS ||
-                                                        out.mel_words != out.mel_groups * (MEL_ROWS_W + 1) * 64u)))
+    if (OUT == 4 ? (out.mel_tab == nullptr || out.mel_groups == 0 || out.mel_words != 0 || out.mel_moment == 0)
+                 : (OUT == 2 && (out.mel_tab == nullptr || out.mel_groups == 0 || out.mel_groups > (uint32_t)MEL_ROWS_MAX_GROUPS ||
+                                 out.mel_words != out.mel_groups * (MEL_ROWS_W + 1) * 64u)))
         return hipErrorInvalidValue;
     const size_t lds = sizeof(cf32) * ((size_t)2 * W::NC + W::T2_LEN + W::T3_LEN + (size_t)WAVES * W::SLAB_LEN) +
                        (OUT == 2 ? (size_t)out.mel_words * 4 : 0);
@@ -2393,6 +2390,12 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
         }
         // (n_fft 4096, round 6: the moment form, for hop 1024 and the 96 / 88.2 kHz defaults — stft_wave_mel_fits)
         // (round 5: frame pairs — two consecutive frames per pass over the banded table; n_fft 2048, plain or rotating frame loop)
+        if constexpr ((LOG2_NC == 10 || LOG2_NC == 9) && SHIFT == 0) {  // (its own instantiation: inlined into OUT = 2 it cost the one-frame epilogue 9 %)
+            if (out.mode == 2 && out.mel_moment != 0)
+                return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 4>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
+                                                                        d_tw, d_minmax, d_queue_head, n_cu, out, s);
+        }
+        if (out.mode == 2 && out.mel_moment != 0 && LOG2_NC <= 10) return hipErrorInvalidValue;  // (wave_shift keeps such launches at SHIFT 0)
         if constexpr (LOG2_NC == 10 || LOG2_NC == 9) {
             if (out.mode == 2 && out.mel_pair != 0) {
                 if (out.mel_slots != 0) return hipErrorInvalidValue;  // (banded sums only)
@@ -2475,7 +2478,8 @@ static hipError_t launch_wave_t3(const StftGeom &g, const ChanJob *d_jobs, const
         }
         return hipErrorInvalidValue;
     }
-    const int sh = wave_shift<LOG2_NC>(g);
+    // (the moment-form epilogue of n_fft 1024 / 2048 is instantiated for the full-reload frame loop only)
+    const int sh = (LOG2_NC <= 10 && out.mode == 2 && out.mel_moment != 0) ? 0 : wave_shift<LOG2_NC>(g);
     // instantiate the common overlaps only: 75 % (hop = n_fft/4), 50 % and 87.5 %
 #define TH_SHIFT_CASE(SH)                                                                                             \
     if constexpr ((SH) > 0 && (SH) < P)                                                                               \
@@ -2655,6 +2659,9 @@ hipError_t launch_stft_wave(const StftGeom &g, const ChanJob *d_jobs, const uint
         if (!stft_wave_multi_applies(g, out.mode)) return hipErrorInvalidValue;
         if (out.mode == 1)  // amplitude rows (mel on the matrix cores): n_fft 512 only, 1024 has the one-frame kernel for that
             return g.log2_nc == 8 ? launch_wave_multi<8, 1>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, nullptr, d_queue_head, n_cu, waves, out, s)
+                                  : hipErrorInvalidValue;
+        if (out.mode == 2 && out.mel_moment != 0)  // mel rows in the moment form (filters wider than the banded table's 8 bins): its own instantiation
+            return g.log2_nc == 8 ? launch_wave_multi<8, 4>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s)
                                   : hipErrorInvalidValue;
         if (out.mode == 2)  // mel rows by banded sums in the epilogue (n_fft 512 under narrow filters)
             return g.log2_nc == 8 ? launch_wave_multi<8, 2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab, d_tw, d_minmax, d_queue_head, n_cu, waves, out, s)
