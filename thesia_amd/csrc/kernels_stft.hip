@@ -2405,7 +2405,7 @@ static hipError_t launch_wave_t4(const StftGeom &g, const ChanJob *d_jobs, const
         }
         // (n_fft 4096: every plain frame loop — hop a multiple of 128 samples with 8, 16 or 4 slots of reuse, or none — and the
         // even-offset grid-aligned shapes of the 96 / 88.2 kHz defaults at t_overlap 4 and 8)
-        if constexpr (LOG2_NC <= 10 || (LOG2_NC == 11 && (SHIFT == 8 || SHIFT == 16 || SHIFT == 4 || SHIFT == 0 || SHIFT == -48 - 7 || SHIFT == -48 - 6 || SHIFT == -48 - 3))) {
+        if constexpr (LOG2_NC <= 10 || (LOG2_NC == 11 && (SHIFT == 8 || SHIFT == 16 || SHIFT == 4 || SHIFT == 0 || SHIFT == -48 - 7 || SHIFT == -48 - 6 || SHIFT == -48 - 3 || SHIFT == -48 - 1 || SHIFT == -48 - 0 || SHIFT == -48 - 13))) {
             if (out.mode == 2)
                 return launch_wave_t5<LOG2_NC, WAVES, SHIFT, 2>(g, d_jobs, d_tile_start, n_chan, n_tiles, d_wtab,
                                                                         d_tw, d_minmax, d_queue_head, n_cu, out, s);
@@ -2613,7 +2613,7 @@ bool stft_wave_mel_fits(const StftGeom &g, int waves, uint32_t words, bool bande
 int stft_wave_mel_phase_mode(const StftGeom &g, int waves) {
     const int pm = stft_wave_phased_mode(g, waves);
     if (g.log2_nc != 11) return pm;
-    return (pm == 3 && (g.hop / 128 == 7 || g.hop / 128 == 6 || g.hop / 128 == 3)) ? 3 : 0;
+    return pm == 3 ? 3 : 0;  // (every even-offset shape stft_wave_phased_mode names: hop / 128 = 7, 6, 3, 1, 0, 13)
 }
 bool stft_wave_mel_pair_applies(const StftGeom &g, int waves, uint32_t reach) {
     // (mel_banded_pair and wave_mel_flush read the table's PAIRED layout: a -DTH_MEL_BAND_PAIRED=0 build keeps the one-frame epilogue — ADVICE r5)
