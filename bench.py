@@ -379,14 +379,22 @@ def tm_end_to_end_and_latency(torch, ta, ctx, wl, sr, cmap_bytes, n_tracks=32):
     lib = _ffi.lib
     host = wl.wav[:n_tracks].cpu().numpy()
     n = host.shape[1]
-    tm = ta.TrackManager(ctx)
-    tm.set_setting(2048 / 48, 4, 1, ta.LINEAR)
-    tm.set_colormap(cmap_bytes)
-    t0 = time.perf_counter()
-    tm.add_tracks([(i, sr, host[i][None]) for i in range(n_tracks)])
-    t1 = time.perf_counter()
-    tm.apply_track_list_changes()
-    t2 = time.perf_counter()
+    # The sequence twice, the SECOND one reported: a process's first add / apply also pays what no later one does (code objects of the
+    # pyramid / quantise / mip kernels on first use, the runtime's pageable staging buffers, first-touch page faults of `host` — 20 ms
+    # typically, 117 ms seen once); the first call's time is in the record as first_call_*.
+    first_call = None
+    for rep in range(2):
+        tm = ta.TrackManager(ctx)
+        tm.set_setting(2048 / 48, 4, 1, ta.LINEAR)
+        tm.set_colormap(cmap_bytes)
+        t0 = time.perf_counter()
+        tm.add_tracks([(i, sr, host[i][None]) for i in range(n_tracks)])
+        t1 = time.perf_counter()
+        tm.apply_track_list_changes()
+        t2 = time.perf_counter()
+        if rep == 0:
+            first_call = {"first_call_upload_pyramid_stft_ms": (t1 - t0) * 1e3, "first_call_range_quantise_mips_ms": (t2 - t1) * 1e3}
+            tm.close()
     # the same tracks handed over in PINNED host memory (th_host_alloc): the upload then runs at PCIe speed
     pinned_in = None
     try:
@@ -453,7 +461,8 @@ def tm_end_to_end_and_latency(torch, ta, ctx, wl, sr, cmap_bytes, n_tracks=32):
     frames = n_tracks * ta.stft_n_frames(n, 2048, 512)
     e2e = {"workload": f"{n_tracks} tracks x {n / sr:.0f} s 48 kHz mono from pageable host memory, n_fft=2048 hop=512: th_tm_add_tracks "
                        "-> th_tm_apply_track_list_changes -> every level-0 tile to host memory",
-           "frames": frames, "upload_pyramid_stft_ms": (t1 - t0) * 1e3, "range_quantise_mips_ms": (t2 - t1) * 1e3,
+           "frames": frames, "upload_pyramid_stft_ms": (t1 - t0) * 1e3, "range_quantise_mips_ms": (t2 - t1) * 1e3, **(first_call or {}),
+           "timed": "the second add_tracks / apply_track_list_changes of the process (a fresh TrackManager each time); first_call_* = the first",
            "all_level0_tiles_ms": (t4 - t3) * 1e3, "tile_bytes": nbytes, "all_level0_tiles_one_batch": batch,
            "set_dB_range_ms": min(t5 - t4b, t6 - t5) * 1e3,
            "frames_per_s_compute_only": frames / (t2 - t0), "frames_per_s_with_tile_fetch": frames / ((t2 - t0) + (t4 - t3)),
