@@ -71,6 +71,11 @@ scripts/pmc_stft.sh "$out/pmc_subwave32768" --nfft 32768 > "$out/pmc_subwave3276
 scripts/pmc_stft.sh "$out/pmc_blockmel16384" --nfft 16384 --mel 0 > "$out/pmc_blockmel16384.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_blockmel8192" --nfft 8192 --mel 0 > "$out/pmc_blockmel8192.log" 2>&1
 scripts/pmc_stft.sh "$out/pmc_block16384" --nfft 16384 > "$out/pmc_block16384.log" 2>&1
+# round 6, last day: the moment-form epilogue where no LDS table form exists (16 kHz under 85 ms: n_fft 2048, 771 mels; 16 kHz under 20 ms: n_fft 512, four frames per wave)
+# and n_fft 4096 with the epilogue under hop 120 (48 kHz, 40 ms, t_overlap 16, f_overlap 2: the even-offset grid-aligned loop)
+scripts/pmc_stft.sh "$out/pmc_melsmall2048" --sr 16000 --nfft 2048 --win 1360 --hop 340 --seconds 90 --mel 0 > "$out/pmc_melsmall2048.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_melsmall512" --sr 16000 --nfft 512 --win 320 --hop 80 --seconds 90 --mel 0 > "$out/pmc_melsmall512.log" 2>&1
+scripts/pmc_stft.sh "$out/pmc_mel4096hop120" --sr 48000 --nfft 4096 --win 1920 --hop 120 --mel 0 > "$out/pmc_mel4096hop120.log" 2>&1
 fi
 if want 3; then
 {

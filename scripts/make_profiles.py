@@ -68,7 +68,10 @@ for name, script in (("stft", "scripts/bench_stft.py"), ("stftpk", "scripts/benc
                      ("stftmel48_one_frame", "scripts/bench_stft.py --sr 48000 --win 1920 --hop 480 --mel 0 --kernel 13"),
                      ("subwave32768", "scripts/bench_stft.py --nfft 32768"),
                      ("blockmel16384", "scripts/bench_stft.py --nfft 16384 --mel 0"), ("blockmel8192", "scripts/bench_stft.py --nfft 8192 --mel 0"),
-                     ("block16384", "scripts/bench_stft.py --nfft 16384")):
+                     ("block16384", "scripts/bench_stft.py --nfft 16384"),
+                     ("melsmall2048", "scripts/bench_stft.py --sr 16000 --nfft 2048 --win 1360 --hop 340 --seconds 90 --mel 0"),
+                     ("melsmall512", "scripts/bench_stft.py --sr 16000 --nfft 512 --win 320 --hop 80 --seconds 90 --mel 0"),
+                     ("mel4096hop120", "scripts/bench_stft.py --sr 48000 --nfft 4096 --win 1920 --hop 120 --mel 0")):
     p = f"{src}/pmc_{name}/summary.txt"
     if os.path.exists(p):
         open(f"{dst}/{tag}_{name}_pmc_summary.txt", "w").write(hdr.format(script=script) + open(p).read())
