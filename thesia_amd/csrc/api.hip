@@ -995,6 +995,14 @@ static int calc_spec_batch_impl(th_plan *p, const th_chan_desc *chans, size_t n_
         if (phase_mode == 1) g.frames_per_tile = std::max<uint32_t>(4, (g.frames_per_tile + 3) / 4 * 4);  // chunks start on the grid
     } else {
         g.frames_per_tile = 8;
+        // (short transforms — n_fft 256 and below, the generic kernel's only full plans: a tile of 8 frames is one round of its frames-side-by-side
+        // loop, and the workgroup's set-up and (min, max) fold then cost as much as the frames; up to 64 frames a tile where the batch still fills the chip)
+        if (g.nc <= 256 && g.odd_m1 == 0) {
+            uint64_t all = 0;
+            for (size_t i = 0; i < n_chan; i++) all += chans[i].n_frames;
+            const uint64_t want = all / ((uint64_t)c->n_cu * 16u);
+            g.frames_per_tile = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, want / 8 * 8));
+        }
     }
     ge.frames_per_tile = 1;
     // main jobs: the wave kernel takes the interior frames [fa, fb) of every channel (all windowed

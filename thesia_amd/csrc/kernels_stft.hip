@@ -110,6 +110,16 @@ __device__ __forceinline__ uint32_t find_chan(const uint32_t *__restrict__ tile_
 // ------------------------------------------------------------------------------------------
 #if TH_PART_MAIN
 constexpr int GEN_THREADS = 256;
+// frames the LDS variant of the generic kernel runs side by side: 256 threads / the butterflies of a radix-4 pass (at least 16 threads a
+// frame, at most a tile's 8 frames); 1 from n_fft 2048 on and wherever the buffers would not fit (the scratch variant)
+__host__ __device__ inline uint32_t stft_generic_frames_par(const StftGeom &g) {
+    const uint32_t per = g.nc / 4u < 16u ? 16u : g.nc / 4u;
+    uint32_t fp = (uint32_t)GEN_THREADS / per;
+    if (fp > 8u) fp = 8u;
+    if (fp < 1u) fp = 1u;
+    while (fp & (fp - 1u)) fp &= fp - 1u;  // (a power of two: nc / 4 need not be one when f_overlap is not)
+    return fp;
+}
 
 template <bool SCRATCH>
 __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
@@ -118,11 +128,17 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
     const uint32_t *__restrict__ mel_lo, const uint32_t *__restrict__ mel_hi, float *__restrict__ minmax,
     cf32 *__restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf32 *bufA = SCRATCH ? scratch + (size_t)blockIdx.x * 2u * g.nc : reinterpret_cast<cf32 *>(smem_raw);
-    cf32 *bufB = bufA + g.nc;
     __shared__ float red[2 * (GEN_THREADS / 64)];
 
     const uint32_t tid = threadIdx.x;
+    // Short transforms (round 6): a radix-4 pass of an Nc-point frame has Nc / 4 butterflies — 32 at n_fft 256, three quarters of the
+    // workgroup idle through eight barriers per frame (408 M frames/s where the n_fft 512 wave kernel makes 1770).  The LDS variant
+    // therefore runs FP = 256 / max(Nc / 4, 16) frames side by side, each on its own group of TPF threads and its own pair of
+    // buffers, the barriers shared (stft_generic_frames_par; 8 frames at n_fft 256, a tile's worth).  Same arithmetic per element.
+    const uint32_t FP = SCRATCH ? 1u : stft_generic_frames_par(g), TPF = GEN_THREADS / FP;
+    const uint32_t sub = tid / TPF, ts = tid - sub * TPF;
+    cf32 *bufA = SCRATCH ? scratch + (size_t)blockIdx.x * 2u * g.nc : reinterpret_cast<cf32 *>(smem_raw) + (size_t)sub * 2u * g.nc;
+    cf32 *bufB = bufA + g.nc;
   for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // (LDS variant: the grid is n_tiles, one trip)
     const uint32_t chan = find_chan(tile_start, n_chan, tile);
     const ChanJob job = jobs[chan];
@@ -131,36 +147,39 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
 
     float lmin = __builtin_inff(), lmax = -__builtin_inff();
 
-    for (uint32_t f = f0; f < f1; f++) {
+    for (uint32_t fb = f0; fb < f1; fb += FP) {
+        const uint32_t f = fb + sub;
+        const bool act = f < f1;  // (a group without a frame in this round only keeps the barriers company)
         const int64_t s0 = (int64_t)f * g.hop - (int64_t)(g.win / 2);
-        gen_load(tid, GEN_THREADS, g, as_global(job.wav), job.n_samples, s0, as_global(window), bufA);
+        if (act) gen_load(ts, TPF, g, as_global(job.wav), job.n_samples, s0, as_global(window), bufA);
         __syncthreads();
         cf32 *in = bufA, *out = bufB;
         uint32_t Ns = 1;
         if (g.log2_nc & 1) {
-            gen_pass_r2(tid, GEN_THREADS, g, Ns, tw, in, out);
+            if (act) gen_pass_r2(ts, TPF, g, Ns, tw, in, out);
             __syncthreads();
             Ns = 2;
             cf32 *t = in; in = out; out = t;
         }
         const uint32_t odd = g.odd_m1 + 1u, n2 = g.nc / odd;  // nc = n2 * odd, n2 = 2^log2_nc
         for (; Ns < n2; Ns <<= 2) {
-            gen_pass_r4(tid, GEN_THREADS, g, Ns, tw, in, out);
+            if (act) gen_pass_r4(ts, TPF, g, Ns, tw, in, out);
             __syncthreads();
             cf32 *t = in; in = out; out = t;
         }
         if (odd > 1u) {  // f_overlap = 3, 5, 6, ... (spectrogram.rs:66-72): the odd factor as one more pass
-            gen_pass_odd(tid, GEN_THREADS, g, n2, odd, tw, in, out);
+            if (act) gen_pass_odd(ts, TPF, g, n2, odd, tw, in, out);
             __syncthreads();
             cf32 *t = in; in = out; out = t;
         }
         // `in` holds Z in natural order; magnitudes go to the other buffer (nc+1 floats fit in nc cf32)
         float *mag = reinterpret_cast<float *>(out);
-        gen_split(tid, GEN_THREADS, g, tw, in, mag);
+        if (act) gen_split(ts, TPF, g, tw, in, mag);
         __syncthreads();
         const gptr<float> row = as_global(job.spec) + (size_t)f * job.spec_pitch;
-        if (g.n_mel == 0) {
-            for (uint32_t k = tid; k < g.n_freq; k += GEN_THREADS) {
+        if (!act) {
+        } else if (g.n_mel == 0) {
+            for (uint32_t k = ts; k < g.n_freq; k += TPF) {
                 const float d = amp_to_dB(mag[k]);
                 row[k] = d;
                 lmin = nmin(lmin, d);
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(GEN_THREADS) void stft_generic_kernel(
             }
         } else {
             // linspec.dot(mel_fb) restricted to each filter's non-zero band, ascending f
-            for (uint32_t m = tid; m < g.n_mel; m += GEN_THREADS) {
+            for (uint32_t m = ts; m < g.n_mel; m += TPF) {
                 float acc = 0.0f;
                 const uint32_t lo = mel_lo[m], hi = mel_hi[m];
                 for (uint32_t k = lo; k < hi; k++) acc += mag[k] * mel_fb[(size_t)k * g.n_mel + m];
@@ -2197,7 +2216,7 @@ hipError_t launch_wave_post(const WavePostJob *d_pj, uint32_t n_pj, const float 
     return hipGetLastError();
 }
 
-size_t stft_generic_lds_bytes(const StftGeom &g) { return 2 * (size_t)g.nc * sizeof(cf32); }
+size_t stft_generic_lds_bytes(const StftGeom &g) { return 2 * (size_t)g.nc * sizeof(cf32) * stft_generic_frames_par(g); }
 // n_fft > 16384: the frame buffers do not fit LDS; workgroups and bytes of global scratch the launch needs (0: LDS variant)
 uint32_t stft_generic_scratch_grid(const StftGeom &g, uint32_t n_tiles, uint32_t n_cu) {
     if (stft_generic_lds_bytes(g) <= 128 * 1024) return 0;
